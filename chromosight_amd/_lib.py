@@ -1,0 +1,280 @@
+"""ctypes binding of libchromosight_hip.so (the C ABI in include/chromosight_hip.h).
+
+The library is the only compute backend of this package: if it cannot be loaded, or no
+MI355X/HIP device is usable, every device entry point raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import pathlib
+import threading
+
+import numpy as np
+
+CS_F32, CS_F64 = 0, 1
+LAYOUT_DENSE, LAYOUT_BAND = 0, 1
+MASK_NONE, MASK_BINS, MASK_EXPLICIT = 0, 1, 2
+
+_LIB_PATH = pathlib.Path(__file__).with_name("libchromosight_hip.so")
+
+
+class CsMatrix(C.Structure):
+    _fields_ = [
+        ("d_ptr", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("layout", C.c_int32),
+        ("ld", C.c_int64),
+        ("band_lo", C.c_int32),
+        ("band_w", C.c_int32),
+    ]
+
+
+class CsKernel(C.Structure):
+    _fields_ = [
+        ("km", C.c_int32),
+        ("kn", C.c_int32),
+        ("h_kernel", C.POINTER(C.c_double)),
+        ("h_kernel_conv", C.POINTER(C.c_double)),
+        ("h_kernel_sq", C.POINTER(C.c_double)),
+    ]
+
+
+class CsNormxcorr2Params(C.Structure):
+    _fields_ = [
+        ("ms", C.c_int32),
+        ("ns", C.c_int32),
+        ("full", C.c_int32),
+        ("sym_upper", C.c_int32),
+        ("max_dist", C.c_int32),
+        ("mask_mode", C.c_int32),
+        ("d_miss_row", C.c_void_p),
+        ("d_miss_col", C.c_void_p),
+        ("d_mask", C.c_void_p),
+        ("min_present", C.c_int32),
+        ("compute_dtype", C.c_int32),
+        ("xcorr_threshold", C.c_double),
+        ("denom_eps", C.c_double),
+    ]
+
+
+class CsCsr(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("nnz", C.c_int64),
+        ("d_indptr", C.c_void_p),
+        ("d_indices", C.c_void_p),
+        ("d_data", C.c_void_p),
+        ("dtype", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/chromosight_hip.h declares
+_PROTOTYPES = {
+    "cs_version": (C.c_char_p, []),
+    "cs_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "cs_ctx_destroy": (None, [C.c_void_p]),
+    "cs_last_error": (C.c_char_p, [C.c_void_p]),
+    "cs_device_cu_count": (C.c_int, [C.c_void_p]),
+    "cs_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "cs_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cs_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cs_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cs_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "cs_stream_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cs_stream_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cs_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cs_event_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cs_event_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cs_event_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "cs_normxcorr2": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
+                                C.POINTER(CsNormxcorr2Params), C.POINTER(CsMatrix), C.POINTER(CsMatrix)]),
+    "cs_xcorr2": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.c_int32, C.c_int32,
+                            C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                            C.POINTER(CsMatrix)]),
+    "cs_rescore_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
+                                 C.POINTER(CsNormxcorr2Params), C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p]),
+    "cs_compact_ge": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.c_int32, C.c_int32,
+                                C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_void_p]),
+    "cs_distance_law_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p]),
+    "cs_detrend_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_void_p, C.c_int32,
+                                 C.c_double, C.c_void_p]),
+    "cs_csr_to_band": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_void_p, C.c_int32,
+                                 C.c_double, C.POINTER(CsMatrix)]),
+}
+
+ABI_SYMBOLS = tuple(sorted(_PROTOTYPES))
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class HipLibraryError(RuntimeError):
+    """libchromosight_hip.so is missing, or a HIP call failed."""
+
+
+def load_library():
+    """dlopen the in-tree shared library and declare the prototypes (no GPU needed)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not _LIB_PATH.exists():
+            raise HipLibraryError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C chromosight_amd/csrc`. There is no CPU fallback."
+            )
+        lib = C.CDLL(str(_LIB_PATH))
+        for name, (restype, argtypes) in _PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return lib
+
+
+def np_dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return CS_F32
+    if dtype == np.float64:
+        return CS_F64
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+class DeviceBuffer:
+    """A typed HBM allocation owned by a Device (freed on garbage collection)."""
+
+    def __init__(self, device, shape, dtype):
+        self.device = device
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        ptr = C.c_void_p()
+        device._check(device.lib.cs_malloc(device.ctx, max(self.nbytes, 1), C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) and self.device.ctx:
+                self.device.lib.cs_free(self.device.ctx, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+    def upload(self, array, stream=None):
+        array = np.ascontiguousarray(array, dtype=self.dtype)
+        if array.nbytes != self.nbytes:
+            raise ValueError("size mismatch in upload")
+        self.device._check(self.device.lib.cs_memcpy_h2d(
+            self.device.ctx, self.ptr, array.ctypes.data, array.nbytes, stream))
+        # pageable host memory: the runtime has consumed `array` when the call returns
+        return self
+
+    def download(self, stream=None):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.device._check(self.device.lib.cs_memcpy_d2h(
+            self.device.ctx, out.ctypes.data, self.ptr, self.nbytes, stream))
+        return out
+
+    def zero(self, stream=None):
+        self.device._check(self.device.lib.cs_memset(self.device.ctx, self.ptr, 0, self.nbytes, stream))
+        return self
+
+
+class Device:
+    """One context on one GPU (one per process in multi-GPU runs)."""
+
+    def __init__(self, index=0):
+        self.lib = load_library()
+        self.index = int(index)
+        ctx = C.c_void_p()
+        rc = self.lib.cs_ctx_create(self.index, C.byref(ctx))
+        if rc != 0:
+            self.ctx = None
+            raise HipLibraryError(
+                f"cs_ctx_create(device={index}) failed with status {rc}: no usable HIP device. "
+                "This package has no CPU fallback."
+            )
+        self.ctx = ctx.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.cs_ctx_destroy(self.ctx)
+        except Exception:
+            pass
+        self.ctx = None
+
+    # -- helpers --------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = self.lib.cs_last_error(self.ctx).decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        if rc == -3:
+            raise NotImplementedError(msg)
+        raise HipLibraryError(f"status {rc}: {msg}")
+
+    @property
+    def cu_count(self):
+        return self.lib.cs_device_cu_count(self.ctx)
+
+    def empty(self, shape, dtype):
+        return DeviceBuffer(self, shape, dtype)
+
+    def zeros(self, shape, dtype, stream=None):
+        return DeviceBuffer(self, shape, dtype).zero(stream)
+
+    def to_device(self, array, dtype=None, stream=None):
+        array = np.ascontiguousarray(array, dtype=dtype)
+        return DeviceBuffer(self, array.shape, array.dtype).upload(array, stream)
+
+    def sync(self, stream=None):
+        self._check(self.lib.cs_stream_sync(self.ctx, stream))
+
+    def new_stream(self):
+        s = C.c_void_p()
+        self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))
+        return s.value
+
+    def new_event(self):
+        e = C.c_void_p()
+        self._check(self.lib.cs_event_create(self.ctx, C.byref(e)))
+        return e.value
+
+    def record(self, event, stream=None):
+        self._check(self.lib.cs_event_record(self.ctx, event, stream))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        self._check(self.lib.cs_event_elapsed_ms(self.ctx, start, stop, C.byref(ms)))
+        return float(ms.value)
+
+
+_devices = {}
+
+
+def get_device(index=None):
+    """Process-wide Device for `index` (default: $CHROMOSIGHT_HIP_DEVICE, $LOCAL_RANK or 0)."""
+    if index is None:
+        index = int(os.environ.get("CHROMOSIGHT_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    dev = _devices.get(index)
+    if dev is None:
+        dev = Device(index)
+        _devices[index] = dev
+    return dev
+
+
+def dense_matrix(buf, ld=None):
+    rows, cols = buf.shape
+    return CsMatrix(buf.ptr, np_dtype_code(buf.dtype), LAYOUT_DENSE, cols if ld is None else ld, 0, 0)
+
+
+def band_matrix(buf, band_lo, band_w):
+    rows, ld = buf.shape
+    return CsMatrix(buf.ptr, np_dtype_code(buf.dtype), LAYOUT_BAND, ld, int(band_lo), int(band_w))

@@ -1,0 +1,588 @@
+// cs_api.cpp -- the C ABI (include/chromosight_hip.h): argument validation, template
+// statistics, weight upload and kernel dispatch.  No torch types, no retained pointers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/chromosight_hip.h"
+#include "cs_device.h"
+#include "cs_launch.h"
+#include "cs_launch_aux.h"
+
+struct cs_ctx {
+    int device = 0;
+    int n_cu = 0;
+    std::string err;
+    // device buffer for the template weights of the call in flight (3 * kk elements)
+    void* d_w = nullptr;
+    size_t d_w_bytes = 0;
+    // host copy of what d_w currently holds, to skip re-uploads of an unchanged template
+    std::vector<unsigned char> w_cached;
+};
+
+namespace {
+
+int fail(cs_ctx* ctx, int code, const char* fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define CS_HIP(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+cs::MatView view_of(const cs_matrix* m)
+{
+    cs::MatView v;
+    v.ptr = m ? m->d_ptr : nullptr;
+    v.ld = m ? m->ld : 0;
+    v.layout = m ? m->layout : 0;
+    v.band_lo = m ? m->band_lo : 0;
+    v.band_w = m ? m->band_w : 0;
+    return v;
+}
+
+struct HostStats {
+    double n, kmean, kstd, kvar, ksum, k2sum;
+};
+
+// statistics of the exact template, float64, in the reference's order of operations
+// (detection.py:1002-1003: kernel.mean(), kernel.std(); :1023-1026: sums and means)
+HostStats template_stats(const double* k, int kk)
+{
+    HostStats s;
+    s.n = (double)kk;
+    double sum = 0, sum2 = 0;
+    for (int t = 0; t < kk; ++t) {
+        sum += k[t];
+        sum2 += k[t] * k[t];
+    }
+    s.ksum = sum;
+    s.k2sum = sum2;
+    s.kmean = sum / kk;
+    s.kvar = sum2 / kk - s.kmean * s.kmean;
+    double dev = 0;
+    for (int t = 0; t < kk; ++t) dev += (k[t] - s.kmean) * (k[t] - s.kmean);
+    s.kstd = std::sqrt(dev / kk);
+    return s;
+}
+
+template <typename TC>
+int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w64)
+{
+    std::vector<TC> w(w64.size());
+    for (size_t t = 0; t < w64.size(); ++t) w[t] = (TC)w64[t];
+    const size_t bytes = w.size() * sizeof(TC);
+    if (bytes > ctx->d_w_bytes) {
+        if (ctx->d_w) CS_HIP(ctx, hipFree(ctx->d_w));
+        ctx->d_w = nullptr;
+        ctx->d_w_bytes = 0;
+        CS_HIP(ctx, hipMalloc(&ctx->d_w, bytes));
+        ctx->d_w_bytes = bytes;
+        ctx->w_cached.clear();
+    }
+    if (ctx->w_cached.size() == bytes && std::memcmp(ctx->w_cached.data(), w.data(), bytes) == 0)
+        return CS_OK;
+    // pageable source: the runtime stages it before returning, so `w` may die here
+    CS_HIP(ctx, hipMemcpyAsync(ctx->d_w, w.data(), bytes, hipMemcpyHostToDevice, stream));
+    ctx->w_cached.assign((unsigned char*)w.data(), (unsigned char*)w.data() + bytes);
+    return CS_OK;
+}
+
+struct Dispatch {
+    int kfast;  // compile-time size served by a fast kernel, 0 = generic
+};
+
+bool fast_available(int km, int kn, int* K)
+{
+    (void)km;
+    (void)kn;
+    (void)K;
+#ifdef CS_HAVE_FAST
+    if (km != kn) return false;
+    switch (km) {
+        case 7: case 9: case 11: case 13: case 15: case 17:
+            *K = km;
+            return true;
+        default:
+            return false;
+    }
+#else
+    return false;
+#endif
+}
+
+template <typename TC>
+void fill_grid(cs::CorrArgs<TC>& A, int tw, int th)
+{
+    A.tile_w = tw;
+    A.tile_h = th;
+    A.tiles_y = (A.ms + th - 1) / th;
+    if (A.out.layout == CS_LAYOUT_BAND) {
+        A.out_lo = A.out.band_lo;
+        A.out_hi = A.out.band_lo + A.out.band_w - 1;
+        const long long span = (long long)(A.out_hi - A.out_lo) + th + tw - 1;
+        A.tiles_x = (int)(span / tw) + 2;
+        const int max_x = (A.ns + tw - 1) / tw;
+        if (A.tiles_x > max_x) A.tiles_x = max_x;
+    } else {
+        A.out_lo = -(1 << 30);
+        A.out_hi = (1 << 30);
+        A.tiles_x = (A.ns + tw - 1) / tw;
+    }
+}
+
+template <typename TC>
+int launch_corr(cs_ctx* ctx, cs::CorrArgs<TC>& A, hipStream_t stream, bool allow_fast);
+
+template <>
+int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, bool allow_fast)
+{
+    int K = 0, tw, th, rc;
+    if (allow_fast && fast_available(A.km, A.kn, &K)) {
+#ifdef CS_HAVE_FAST
+#define CS_CASE(KK)                          \
+    case KK:                                 \
+        cs::corr_fast_tile_k##KK(&tw, &th);  \
+        fill_grid(A, tw, th);                \
+        rc = cs::launch_corr_fast_f32_k##KK(A, stream); \
+        break;
+        switch (K) {
+            CS_CASE(7) CS_CASE(9) CS_CASE(11) CS_CASE(13) CS_CASE(15) CS_CASE(17)
+            default: rc = -1;
+        }
+#undef CS_CASE
+#else
+        rc = -1;
+#endif
+    } else {
+        cs::corr_generic_tile(A.km, A.kn, &tw, &th);
+        fill_grid(A, tw, th);
+        rc = cs::launch_corr_generic_f32(A, stream);
+    }
+    if (rc == -3) return fail(ctx, CS_ERR_UNSUPPORTED, "template %dx%d needs more than 160 KiB of LDS", A.km, A.kn);
+    if (rc != 0) return fail(ctx, CS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+template <>
+int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream, bool allow_fast)
+{
+    int K = 0, tw, th, rc;
+    if (allow_fast && fast_available(A.km, A.kn, &K)) {
+#ifdef CS_HAVE_FAST
+#define CS_CASE(KK)                          \
+    case KK:                                 \
+        cs::corr_fast_tile_k##KK(&tw, &th);  \
+        fill_grid(A, tw, th);                \
+        rc = cs::launch_corr_fast_f64_k##KK(A, stream); \
+        break;
+        switch (K) {
+            CS_CASE(7) CS_CASE(9) CS_CASE(11) CS_CASE(13) CS_CASE(15) CS_CASE(17)
+            default: rc = -1;
+        }
+#undef CS_CASE
+#else
+        rc = -1;
+#endif
+    } else {
+        cs::corr_generic_tile(A.km, A.kn, &tw, &th);
+        fill_grid(A, tw, th);
+        rc = cs::launch_corr_generic_f64(A, stream);
+    }
+    if (rc == -3) return fail(ctx, CS_ERR_UNSUPPORTED, "template %dx%d needs more than 160 KiB of LDS", A.km, A.kn);
+    if (rc != 0) return fail(ctx, CS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int check_matrix(cs_ctx* ctx, const cs_matrix* m, const char* what, int ns)
+{
+    if (!m || !m->d_ptr) return fail(ctx, CS_ERR_INVALID, "%s: null matrix", what);
+    if (m->dtype != CS_F32 && m->dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "%s: bad dtype", what);
+    if (m->layout == CS_LAYOUT_DENSE) {
+        if (m->ld < ns) return fail(ctx, CS_ERR_INVALID, "%s: ld < number of columns", what);
+    } else if (m->layout == CS_LAYOUT_BAND) {
+        if (m->band_w <= 0 || m->ld < m->band_w) return fail(ctx, CS_ERR_INVALID, "%s: bad band geometry", what);
+    } else {
+        return fail(ctx, CS_ERR_INVALID, "%s: bad layout", what);
+    }
+    return CS_OK;
+}
+
+// Build the device argument block shared by cs_normxcorr2 and cs_rescore_f64.
+template <typename TC>
+int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const cs_kernel* kernel,
+               const cs_normxcorr2_params* p, cs::CorrArgs<TC>* out)
+{
+    if (!signal || !kernel || !p) return fail(ctx, CS_ERR_INVALID, "null argument");
+    const int km = kernel->km, kn = kernel->kn, kk = km * kn;
+    if (km <= 0 || kn <= 0 || !kernel->h_kernel) return fail(ctx, CS_ERR_INVALID, "bad template");
+    if (!(km & 1) || !(kn & 1))
+        return fail(ctx, CS_ERR_INVALID, "template dimensions must be odd (reference preprocessing.py:774-775)");
+    if (p->ms <= 0 || p->ns <= 0) return fail(ctx, CS_ERR_INVALID, "empty signal");
+    int rc = check_matrix(ctx, signal, "signal", p->ns);
+    if (rc) return rc;
+    if (p->mask_mode != CS_MASK_NONE) {
+        // detection.py:880-881
+        if (std::min(km, kn) >= std::max(p->ms, p->ns))
+            return fail(ctx, CS_ERR_INVALID, "cannot have kernel bigger than signal");
+        if (p->mask_mode == CS_MASK_BINS && (!p->d_miss_row || !p->d_miss_col))
+            return fail(ctx, CS_ERR_INVALID, "missing-bin vectors are null");
+        if (p->mask_mode == CS_MASK_EXPLICIT && !p->d_mask)
+            return fail(ctx, CS_ERR_INVALID, "explicit mask is null");
+    }
+    const HostStats st = template_stats(kernel->h_kernel, kk);
+    if (!(st.kstd > 0)) return fail(ctx, CS_ERR_INVALID, "Cannot have flat kernel.");  // detection.py:887-888
+    const double* kconv = kernel->h_kernel_conv ? kernel->h_kernel_conv : kernel->h_kernel;
+    std::vector<double> w(3 * (size_t)kk);
+    for (int t = 0; t < kk; ++t) {
+        const double kc = kconv[t];
+        const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
+        w[t] = kc - st.kmean;
+        w[kk + t] = kc - st.kmean;
+        // chosen so that kb + 2*kmean*ka + kmean^2*nm == sum over missing pixels of k2
+        w[2 * kk + t] = k2 - 2.0 * st.kmean * kc + st.kmean * st.kmean;
+    }
+    rc = upload_weights<TC>(ctx, stream, w);
+    if (rc) return rc;
+
+    cs::CorrArgs<TC> A;
+    std::memset(&A, 0, sizeof(A));
+    A.sig = view_of(signal);
+    A.sig_is_f64 = signal->dtype == CS_F64;
+    A.ms = p->ms;
+    A.ns = p->ns;
+    A.km = km;
+    A.kn = kn;
+    A.full = p->full ? 1 : 0;
+    A.sym_upper = p->sym_upper ? 1 : 0;
+    A.max_dist = p->max_dist;
+    A.mask_mode = p->mask_mode;
+    A.miss_row = p->d_miss_row;
+    A.miss_col = p->d_miss_col;
+    A.mask = A.sig;
+    A.mask.ptr = (void*)p->d_mask;
+    A.w = reinterpret_cast<const TC*>(ctx->d_w);
+    A.ks.n = (TC)st.n;
+    A.ks.inv_n = (TC)(1.0 / st.n);
+    A.ks.kmean = (TC)st.kmean;
+    A.ks.kstd = (TC)st.kstd;
+    A.ks.kvar = (TC)st.kvar;
+    A.ks.ksum = (TC)st.ksum;
+    A.ks.k2sum = (TC)st.k2sum;
+    A.ks.thr = (TC)p->xcorr_threshold;
+    A.ks.eps = (TC)p->denom_eps;
+    A.ks.cut = (TC)p->min_present;
+    A.xcorr_only = 0;
+    *out = A;
+    return CS_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+const char* cs_version(void) { return "chromosight_hip 0.1 (gfx950)"; }
+
+int cs_ctx_create(int device, cs_ctx** out)
+{
+    if (!out) return CS_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return CS_ERR_HIP;
+    if (device < 0 || device >= count) return CS_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return CS_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CS_ERR_HIP;
+    cs_ctx* ctx = new cs_ctx();
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return CS_OK;
+}
+
+void cs_ctx_destroy(cs_ctx* ctx)
+{
+    if (!ctx) return;
+    if (ctx->d_w) (void)hipFree(ctx->d_w);
+    delete ctx;
+}
+
+const char* cs_last_error(const cs_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int cs_device_cu_count(const cs_ctx* ctx) { return ctx ? ctx->n_cu : 0; }
+
+int cs_malloc(cs_ctx* ctx, size_t bytes, void** d_ptr)
+{
+    if (!ctx || !d_ptr) return CS_ERR_INVALID;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    CS_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return CS_OK;
+}
+
+int cs_free(cs_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    if (d_ptr) CS_HIP(ctx, hipFree(d_ptr));
+    return CS_OK;
+}
+
+int cs_memcpy_h2d(cs_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    if (bytes) CS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return CS_OK;
+}
+
+int cs_memcpy_d2h(cs_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    if (bytes) {
+        CS_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    }
+    return CS_OK;
+}
+
+int cs_memset(cs_ctx* ctx, void* d_dst, int value, size_t bytes, void* stream)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    if (bytes) CS_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+    return CS_OK;
+}
+
+int cs_stream_sync(cs_ctx* ctx, void* stream)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return CS_OK;
+}
+
+int cs_stream_create(cs_ctx* ctx, void** stream)
+{
+    if (!ctx || !stream) return CS_ERR_INVALID;
+    hipStream_t s;
+    CS_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return CS_OK;
+}
+
+int cs_stream_destroy(cs_ctx* ctx, void* stream)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    if (stream) CS_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    return CS_OK;
+}
+
+int cs_event_create(cs_ctx* ctx, void** event)
+{
+    if (!ctx || !event) return CS_ERR_INVALID;
+    hipEvent_t e;
+    CS_HIP(ctx, hipEventCreate(&e));
+    *event = (void*)e;
+    return CS_OK;
+}
+
+int cs_event_destroy(cs_ctx* ctx, void* event)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    if (event) CS_HIP(ctx, hipEventDestroy((hipEvent_t)event));
+    return CS_OK;
+}
+
+int cs_event_record(cs_ctx* ctx, void* event, void* stream)
+{
+    if (!ctx || !event) return CS_ERR_INVALID;
+    CS_HIP(ctx, hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return CS_OK;
+}
+
+int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms)
+{
+    if (!ctx || !start || !stop || !ms) return CS_ERR_INVALID;
+    CS_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+    CS_HIP(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return CS_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                  const cs_normxcorr2_params* p, const cs_matrix* out_corr, const cs_matrix* out_nobs)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p) return fail(ctx, CS_ERR_INVALID, "null params");
+    int rc = check_matrix(ctx, out_corr, "out_corr", p->ns);
+    if (rc) return rc;
+    const bool want_nobs = out_nobs && out_nobs->d_ptr;
+    if (want_nobs) {
+        rc = check_matrix(ctx, out_nobs, "out_nobs", p->ns);
+        if (rc) return rc;
+        if (out_nobs->dtype != CS_F32) return fail(ctx, CS_ERR_INVALID, "out_nobs must be float32");
+    }
+    const bool allow_fast = getenv("CHROMOSIGHT_HIP_FORCE_GENERIC") == nullptr;
+    if (p->compute_dtype == CS_F64) {
+        cs::CorrArgs<double> A;
+        rc = build_args<double>(ctx, stream, signal, kernel, p, &A);
+        if (rc) return rc;
+        A.out = view_of(out_corr);
+        A.out_is_f64 = out_corr->dtype == CS_F64;
+        A.nobs = want_nobs ? view_of(out_nobs) : cs::MatView{nullptr, 0, 0, 0, 0};
+        return launch_corr<double>(ctx, A, stream, allow_fast);
+    } else if (p->compute_dtype == CS_F32) {
+        cs::CorrArgs<float> A;
+        rc = build_args<float>(ctx, stream, signal, kernel, p, &A);
+        if (rc) return rc;
+        A.out = view_of(out_corr);
+        A.out_is_f64 = out_corr->dtype == CS_F64;
+        A.nobs = want_nobs ? view_of(out_nobs) : cs::MatView{nullptr, 0, 0, 0, 0};
+        return launch_corr<float>(ctx, A, stream, allow_fast);
+    }
+    return fail(ctx, CS_ERR_INVALID, "bad compute dtype");
+}
+
+int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, int32_t ns,
+              const double* h_weights, int32_t km, int32_t kn, double threshold, int32_t compute_dtype,
+              const cs_matrix* out)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h_weights || km <= 0 || kn <= 0) return fail(ctx, CS_ERR_INVALID, "bad weights");
+    if (ms < km || ns < kn) return fail(ctx, CS_ERR_INVALID, "signal smaller than kernel");
+    int rc = check_matrix(ctx, signal, "signal", ns);
+    if (rc) return rc;
+    rc = check_matrix(ctx, out, "out", ns);
+    if (rc) return rc;
+    const int kk = km * kn;
+    std::vector<double> w(3 * (size_t)kk, 0.0);
+    for (int t = 0; t < kk; ++t) w[t] = h_weights[t];
+#define CS_XC(TC)                                                         \
+    {                                                                     \
+        rc = upload_weights<TC>(ctx, stream, w);                          \
+        if (rc) return rc;                                                \
+        cs::CorrArgs<TC> A;                                               \
+        std::memset(&A, 0, sizeof(A));                                    \
+        A.sig = view_of(signal);                                          \
+        A.sig_is_f64 = signal->dtype == CS_F64;                           \
+        A.out = view_of(out);                                             \
+        A.out_is_f64 = out->dtype == CS_F64;                              \
+        A.ms = ms; A.ns = ns; A.km = km; A.kn = kn;                       \
+        A.max_dist = -1;                                                  \
+        A.w = reinterpret_cast<const TC*>(ctx->d_w);                      \
+        A.ks.n = (TC)kk; A.ks.thr = (TC)threshold;                        \
+        A.xcorr_only = 1;                                                 \
+        return launch_corr<TC>(ctx, A, stream, false);                    \
+    }
+    if (compute_dtype == CS_F64) CS_XC(double)
+    if (compute_dtype == CS_F32) CS_XC(float)
+#undef CS_XC
+    return fail(ctx, CS_ERR_INVALID, "bad compute dtype");
+}
+
+int cs_rescore_f64(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                   const cs_normxcorr2_params* p, const int32_t* d_rows, const int32_t* d_cols,
+                   int64_t n_px, double* d_out_corr, double* d_out_nobs)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_px < 0 || (n_px > 0 && (!d_rows || !d_cols || !d_out_corr)))
+        return fail(ctx, CS_ERR_INVALID, "bad pixel list");
+    cs::CorrArgs<double> A;
+    int rc = build_args<double>(ctx, stream, signal, kernel, p, &A);
+    if (rc) return rc;
+    rc = cs::launch_rescore_f64(A, d_rows, d_cols, n_px, d_out_corr, d_out_nobs, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "rescore launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_compact_ge(cs_ctx* ctx, void* stream_, const cs_matrix* corr, int32_t ms, int32_t ns,
+                  double threshold, int32_t lo_diag, int32_t hi_diag, int32_t* d_rows, int32_t* d_cols,
+                  double* d_vals, int64_t cap, int64_t* d_count)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    int rc = check_matrix(ctx, corr, "corr", ns);
+    if (rc) return rc;
+    if (!d_rows || !d_cols || !d_vals || !d_count || cap < 0) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
+    rc = cs::launch_compact_ge(view_of(corr), corr->dtype == CS_F64, ms, ns, threshold, lo_diag, hi_diag, d_rows,
+                               d_cols, d_vals, cap, (long long*)d_count, ctx->n_cu, (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+static int csr_view(cs_ctx* ctx, const cs_csr* m, cs::CsrView* v)
+{
+    if (!m) return fail(ctx, CS_ERR_INVALID, "null csr");
+    if (m->n_rows < 0 || m->n_cols < 0 || m->nnz < 0) return fail(ctx, CS_ERR_INVALID, "bad csr shape");
+    if (m->dtype != CS_F32 && m->dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "bad csr dtype");
+    if (!m->d_indptr || (m->nnz > 0 && (!m->d_indices || !m->d_data))) return fail(ctx, CS_ERR_INVALID, "null csr arrays");
+    v->n_rows = m->n_rows;
+    v->n_cols = m->n_cols;
+    v->nnz = m->nnz;
+    v->indptr = (const long long*)m->d_indptr;
+    v->indices = m->d_indices;
+    v->data = m->d_data;
+    v->is_f64 = m->dtype == CS_F64;
+    return CS_OK;
+}
+
+int cs_distance_law_csr(cs_ctx* ctx, void* stream_, const cs_csr* mat, const uint8_t* d_detectable,
+                        int32_t n_diags, double* d_sum, int64_t* d_cnt)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    cs::CsrView v;
+    int rc = csr_view(ctx, mat, &v);
+    if (rc) return rc;
+    if (n_diags < 0 || (n_diags > 0 && (!d_sum || !d_cnt))) return fail(ctx, CS_ERR_INVALID, "bad law buffers");
+    rc = cs::launch_distance_law(v, d_detectable, n_diags, d_sum, (long long*)d_cnt, ctx->n_cu, (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "distance law launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_detrend_csr(cs_ctx* ctx, void* stream_, const cs_csr* mat, const double* d_law, int32_t n_law,
+                   double max_val, void* d_out)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    cs::CsrView v;
+    int rc = csr_view(ctx, mat, &v);
+    if (rc) return rc;
+    if (!d_law || n_law < 0 || (v.nnz > 0 && !d_out)) return fail(ctx, CS_ERR_INVALID, "bad detrend buffers");
+    rc = cs::launch_detrend_csr(v, d_law, n_law, max_val, d_out, ctx->n_cu, (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "detrend launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_csr_to_band(cs_ctx* ctx, void* stream_, const cs_csr* mat, const double* d_law, int32_t n_law,
+                   double max_val, const cs_matrix* band)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    cs::CsrView v;
+    int rc = csr_view(ctx, mat, &v);
+    if (rc) return rc;
+    if (!band || !band->d_ptr) return fail(ctx, CS_ERR_INVALID, "null output matrix");
+    if (band->dtype != CS_F32 && band->dtype != CS_F64 && band->dtype != CS_U8)
+        return fail(ctx, CS_ERR_INVALID, "bad output dtype");
+    if (band->layout == CS_LAYOUT_DENSE ? band->ld < v.n_cols : (band->band_w <= 0 || band->ld < band->band_w))
+        return fail(ctx, CS_ERR_INVALID, "bad output geometry");
+    rc = cs::launch_csr_to_band(v, d_law, n_law, max_val, view_of(band), band->dtype, ctx->n_cu,
+                                (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "csr_to_band launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+}  // extern "C"

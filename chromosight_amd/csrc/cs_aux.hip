@@ -1,0 +1,320 @@
+// cs_aux.hip -- HBM-bound helper kernels either side of the correlation:
+//   * per-diagonal distance-law reduction over CSR      (reference preprocessing.py:129-197)
+//   * detrend of CSR values                             (reference preprocessing.py:256-310)
+//   * CSR -> diagonal-band tiler with fused detrend     (+ diag_trim, preprocessing.py:93-126)
+//   * threshold compaction of a coefficient map         (first step of pick_foci, detection.py:417-421)
+//   * float64 re-scoring of a list of pixels            (detection.py:917-1131 evaluated per pixel)
+#include "cs_device.h"
+#include "cs_launch_aux.h"
+
+namespace cs {
+
+// ------------------------------------------------------------------------------------------
+// distance law: sum / count of the strictly positive pixels of each diagonal whose two bins are
+// detectable.  One wave per CSR row, lanes stride over the row's stored entries (coalesced);
+// per-block partial sums live in LDS (ds_add_f64), flushed with one global atomic per diagonal.
+// ------------------------------------------------------------------------------------------
+template <typename TV, bool USE_LDS>
+__global__ __launch_bounds__(256) void distance_law_kernel(CsrView M, const uint8_t* __restrict__ det,
+                                                           int n_diags, double* __restrict__ g_sum,
+                                                           unsigned long long* __restrict__ g_cnt,
+                                                           int rows_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* l_sum = reinterpret_cast<double*>(smem_raw);
+    unsigned int* l_cnt = reinterpret_cast<unsigned int*>(smem_raw + sizeof(double) * (size_t)n_diags);
+    const int tid = threadIdx.x;
+    if (USE_LDS) {
+        for (int d = tid; d < n_diags; d += 256) {
+            l_sum[d] = 0.0;
+            l_cnt[d] = 0u;
+        }
+        __syncthreads();
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(r_begin + rows_per_block, M.n_rows);
+    const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
+    for (int row = r_begin + wv; row < r_end; row += 4) {
+        if (det && !det[row]) continue;
+        const long long b = M.indptr[row], e = M.indptr[row + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int col = M.indices[k];
+            const int d = col - row;
+            if (d < 0 || d >= n_diags) continue;
+            if (det && !det[col]) continue;
+            const double v = (double)data[k];
+            if (!(v > 0.0)) continue;  // also drops NaN (preprocessing.py:188)
+            if (USE_LDS) {
+                atomicAdd(&l_sum[d], v);
+                atomicAdd(&l_cnt[d], 1u);
+            } else {
+                atomicAdd(&g_sum[d], v);
+                atomicAdd(&g_cnt[d], 1ull);
+            }
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int d = tid; d < n_diags; d += 256) {
+            if (l_cnt[d]) {
+                atomicAdd(&g_sum[d], l_sum[d]);
+                atomicAdd(&g_cnt[d], (unsigned long long)l_cnt[d]);
+            }
+        }
+    }
+}
+
+int launch_distance_law(const CsrView& M, const uint8_t* det, int n_diags, double* d_sum,
+                        long long* d_cnt, int n_cu, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(double) * (size_t)n_diags, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(d_cnt, 0, sizeof(long long) * (size_t)n_diags, stream);
+    if (e != hipSuccess) return (int)e;
+    if (M.n_rows == 0 || M.nnz == 0 || n_diags == 0) return 0;
+    const size_t smem = (sizeof(double) + sizeof(unsigned int)) * (size_t)n_diags;
+    const bool use_lds = smem <= 64 * 1024;
+    int blocks = min((M.n_rows + 3) / 4, n_cu * 8);
+    if (blocks < 1) blocks = 1;
+    const int rows_per_block = (M.n_rows + blocks - 1) / blocks;
+    blocks = (M.n_rows + rows_per_block - 1) / rows_per_block;
+    auto cnt = reinterpret_cast<unsigned long long*>(d_cnt);
+#define CS_DL(TV, L)                                                                             \
+    hipLaunchKernelGGL((distance_law_kernel<TV, L>), dim3(blocks), dim3(256), (L) ? smem : 0,     \
+                       stream, M, det, n_diags, d_sum, cnt, rows_per_block)
+    if (M.is_f64) {
+        if (use_lds) {
+            if (smem > 48 * 1024)
+                (void)hipFuncSetAttribute((const void*)distance_law_kernel<double, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            CS_DL(double, true);
+        } else {
+            CS_DL(double, false);
+        }
+    } else {
+        if (use_lds) {
+            if (smem > 48 * 1024)
+                (void)hipFuncSetAttribute((const void*)distance_law_kernel<float, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            CS_DL(float, true);
+        } else {
+            CS_DL(float, false);
+        }
+    }
+#undef CS_DL
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// detrend value: v / law[|d|], then >= max_val -> 1 (NaN stays NaN; the band writer turns it
+// into 0 as contacts_map.py:539-540 does after trimming)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double detrend_value(double v, int d, const double* __restrict__ law,
+                                                int n_law, double max_val)
+{
+    const int ad = d < 0 ? -d : d;
+    const double y = (ad < n_law) ? law[ad] : 0.0;
+    double out = v / y;
+    if (max_val > 0.0 && out >= max_val) out = 1.0;
+    return out;
+}
+
+template <typename TV>
+__global__ __launch_bounds__(256) void detrend_csr_kernel(CsrView M, const double* __restrict__ law,
+                                                          int n_law, double max_val, TV* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
+    for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
+        const long long b = M.indptr[row], e = M.indptr[row + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int d = M.indices[k] - row;
+            out[k] = (TV)detrend_value((double)data[k], d, law, n_law, max_val);
+        }
+    }
+}
+
+int launch_detrend_csr(const CsrView& M, const double* law, int n_law, double max_val, void* out,
+                       int n_cu, hipStream_t stream)
+{
+    if (M.n_rows == 0 || M.nnz == 0) return 0;
+    int blocks = min((M.n_rows + 3) / 4, n_cu * 16);
+    if (M.is_f64)
+        hipLaunchKernelGGL(detrend_csr_kernel<double>, dim3(blocks), dim3(256), 0, stream, M, law, n_law,
+                           max_val, (double*)out);
+    else
+        hipLaunchKernelGGL(detrend_csr_kernel<float>, dim3(blocks), dim3(256), 0, stream, M, law, n_law,
+                           max_val, (float*)out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// CSR -> band (or dense) scatter: one wave per row; a row's stored entries are contiguous in the
+// band, so both the CSR reads and the band writes are coalesced runs.  TB = uint8_t writes a
+// 0/1 mask (explicit missing masks).
+// ------------------------------------------------------------------------------------------
+template <typename TV, typename TB>
+__global__ __launch_bounds__(256) void csr_to_band_kernel(CsrView M, const double* __restrict__ law,
+                                                          int n_law, double max_val, MatView band)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
+    TB* __restrict__ dst = reinterpret_cast<TB*>(band.ptr);
+    for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
+        const long long b = M.indptr[row], e = M.indptr[row + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int col = M.indices[k];
+            const long long off = mat_offset(band, row, col);
+            if (off < 0) continue;
+            double v = (double)data[k];
+            if (law) v = detrend_value(v, col - row, law, n_law, max_val);
+            if (v != v) v = 0.0;
+            if constexpr (sizeof(TB) == 1) dst[off] = (v != 0.0) ? 1 : 0;
+            else dst[off] = (TB)v;
+        }
+    }
+}
+
+int launch_csr_to_band(const CsrView& M, const double* law, int n_law, double max_val,
+                       const MatView& band, int band_dtype, int n_cu, hipStream_t stream)
+{
+    const size_t esz = band_dtype == 1 ? 8 : (band_dtype == 2 ? 1 : 4);
+    hipError_t e = hipMemsetAsync(band.ptr, 0, esz * (size_t)band.ld * (size_t)M.n_rows, stream);
+    if (e != hipSuccess) return (int)e;
+    if (M.n_rows == 0 || M.nnz == 0) return 0;
+    int blocks = min((M.n_rows + 3) / 4, n_cu * 16);
+#define CS_C2B(TV, TB) \
+    hipLaunchKernelGGL((csr_to_band_kernel<TV, TB>), dim3(blocks), dim3(256), 0, stream, M, law, n_law, max_val, band)
+    if (M.is_f64) {
+        if (band_dtype == 1) CS_C2B(double, double);
+        else if (band_dtype == 2) CS_C2B(double, uint8_t);
+        else CS_C2B(double, float);
+    } else {
+        if (band_dtype == 1) CS_C2B(float, double);
+        else if (band_dtype == 2) CS_C2B(float, uint8_t);
+        else CS_C2B(float, float);
+    }
+#undef CS_C2B
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// thresholded compaction: append (row, col, value) of every stored pixel >= threshold
+// ------------------------------------------------------------------------------------------
+template <typename TV>
+__global__ __launch_bounds__(256) void compact_ge_kernel(MatView corr, int ms, int ns, double threshold,
+                                                         int lo_diag, int hi_diag, int* __restrict__ rows,
+                                                         int* __restrict__ cols, double* __restrict__ vals,
+                                                         long long cap, unsigned long long* __restrict__ count)
+{
+    const int width = (corr.layout == 1) ? corr.band_w : ns;
+    const long long total = (long long)ms * width;
+    const TV* __restrict__ src = reinterpret_cast<const TV*>(corr.ptr);
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // every lane runs the same number of iterations so that the wave-level ballot is well defined
+    const long long n_iter = (total + stride - 1) / stride;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long it = 0; it < n_iter; ++it, idx += stride) {
+        bool hit = false;
+        int i = 0, j = 0;
+        double v = 0.0;
+        if (idx < total) {
+            i = (int)(idx / width);
+            const int x = (int)(idx - (long long)i * width);
+            j = (corr.layout == 1) ? (i + corr.band_lo + x) : x;
+            if (j >= 0 && j < ns) {
+                const int d = j - i;
+                v = (double)src[(long long)i * corr.ld + x];
+                hit = (d >= lo_diag) && (d <= hi_diag) && (v >= threshold);
+            }
+        }
+        const unsigned long long ballot = __ballot(hit);
+        if (ballot) {
+            const int n_hit = __popcll(ballot);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned long long)n_hit);
+            base = __shfl(base, 0);
+            if (hit) {
+                const unsigned long long pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+                if ((long long)pos < cap) {
+                    rows[pos] = i;
+                    cols[pos] = j;
+                    vals[pos] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, double threshold,
+                      int lo_diag, int hi_diag, int* rows, int* cols, double* vals, long long cap,
+                      long long* count, int n_cu, hipStream_t stream)
+{
+    const int width = (corr.layout == 1) ? corr.band_w : ns;
+    const long long total = (long long)ms * width;
+    if (total == 0) return 0;
+    long long want = (total + 255) / 256;
+    int blocks = (int)(want < (long long)n_cu * 8 ? want : (long long)n_cu * 8);
+    auto cnt = reinterpret_cast<unsigned long long*>(count);
+    if (corr_is_f64)
+        hipLaunchKernelGGL(compact_ge_kernel<double>, dim3(blocks), dim3(256), 0, stream, corr, ms, ns,
+                           threshold, lo_diag, hi_diag, rows, cols, vals, cap, cnt);
+    else
+        hipLaunchKernelGGL(compact_ge_kernel<float>, dim3(blocks), dim3(256), 0, stream, corr, ms, ns,
+                           threshold, lo_diag, hi_diag, rows, cols, vals, cap, cnt);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// float64 evaluation of the coefficient at a list of pixels (one lane per pixel; the window is
+// read straight from HBM/L2 -- candidate lists are tiny compared with the map)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double> A, const int* __restrict__ rows,
+                                                          const int* __restrict__ cols, long long n_px,
+                                                          double* __restrict__ out_corr,
+                                                          double* __restrict__ out_nobs)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_px) return;
+    const int oi = rows[t], oj = cols[t];
+    double r = 0.0, nobs = A.ks.n;
+    const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
+    if (inside && !pixel_forced_zero(A, oi, oj)) {
+        const int km = A.km, kn = A.kn, kk = km * kn;
+        const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+        const bool masked = A.mask_mode != 0;
+        double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
+        for (int ki = 0; ki < km; ++ki) {
+            const int p = oi - kh + ki;
+            for (int kj = 0; kj < kn; ++kj) {
+                const int q = oj - kw + kj;
+                const double v = load_signal(A, p, q);
+                cs_ = fma(v, A.w[ki * kn + kj], cs_);
+                s1 += v;
+                s2 = fma(v, v, s2);
+                if (masked && missing_pred(A, p, q)) {
+                    nm += 1.0;
+                    ka += A.w[kk + ki * kn + kj];
+                    kb += A.w[2 * kk + ki * kn + kj];
+                }
+            }
+        }
+        r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
+    }
+    out_corr[t] = r;
+    if (out_nobs) out_nobs[t] = nobs;
+}
+
+int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* cols, long long n_px,
+                       double* out_corr, double* out_nobs, hipStream_t stream)
+{
+    if (n_px == 0) return 0;
+    const int blocks = (int)((n_px + 255) / 256);
+    hipLaunchKernelGGL(rescore_f64_kernel, dim3(blocks), dim3(256), 0, stream, A, rows, cols, n_px, out_corr,
+                       out_nobs);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cs

@@ -1,0 +1,257 @@
+// cs_device.h -- device-side parameter blocks and helpers shared by all kernels.
+//
+// gfx950 / CDNA4 only (wave64, 160 KiB LDS per CU).  No portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cs {
+
+constexpr int kWave = 64;
+
+// One matrix operand as the kernels see it (mirrors cs_matrix of the C ABI).
+struct MatView {
+    void* ptr;
+    long long ld;
+    int layout;   // 0 dense row-major, 1 diagonal band
+    int band_lo;  // first stored diagonal offset (band)
+    int band_w;   // number of stored diagonals (band)
+};
+
+// element offset of (p, q), or -1 if the pixel is not stored
+__device__ __forceinline__ long long mat_offset(const MatView& m, int p, int q)
+{
+    if (m.layout == 0) return (long long)p * m.ld + q;
+    int d = q - p - m.band_lo;
+    if (d < 0 || d >= m.band_w) return -1;
+    return (long long)p * m.ld + d;
+}
+
+template <typename T>
+struct KernelStats {
+    T n;        // km * kn
+    T inv_n;
+    T kmean;    // mean of the exact template
+    T kstd;     // population std of the exact template (numpy .std())
+    T kvar;     // k2mean - kmean^2
+    T ksum;
+    T k2sum;
+    T thr;      // 1e-4
+    T eps;      // 1e-10
+    T cut;      // int((1 - missing_tol) * n) as a float
+};
+
+// Arguments of the tile kernels.  Weights live in a small device buffer:
+//   w[0 .. kk)      conv weights minus kmean            (sum S * (K' - kmean))
+//   w[kk .. 2kk)    mask weights minus kmean            (sum M * (K' - kmean))
+//   w[2kk .. 3kk)   mask weights for the square term    (sum M * Wb), see cs_api.cpp
+template <typename TC>
+struct CorrArgs {
+    MatView sig;
+    MatView out;
+    MatView nobs;            // ptr == nullptr -> not written; float elements
+    int sig_is_f64;
+    int out_is_f64;
+    int ms, ns;
+    int km, kn;
+    int full, sym_upper, max_dist;
+    int mask_mode;           // 0 none, 1 bins, 2 explicit
+    const uint8_t* miss_row;
+    const uint8_t* miss_col;
+    MatView mask;            // explicit mask (uint8), same geometry as sig
+    const TC* __restrict__ w;
+    KernelStats<TC> ks;
+    int xcorr_only;          // 1: out = thresholded sum S*w[0..kk) (plain xcorr2)
+    // tile grid
+    int tiles_x;             // tiles per row-block
+    int tiles_y;
+    int tile_w, tile_h;
+    int out_lo, out_hi;      // only pixels with out_lo <= j - i <= out_hi are produced
+};
+
+// ---------------------------------------------------------------------------------------
+// The framed missing predicate (reference preprocessing.py:535-633 make_missing_mask and
+// :404-498 frame_missing_mask), evaluated analytically for matrix coordinates (p, q) that
+// may lie in the virtual frame (p in [-(km-1), ms+km-1), q likewise).
+// ---------------------------------------------------------------------------------------
+template <typename TC>
+__device__ __forceinline__ bool missing_pred(const CorrArgs<TC>& A, int p, int q)
+{
+    if (A.mask_mode == 0) return false;
+    const bool in_r = (p >= 0) & (p < A.ms);
+    const bool in_c = (q >= 0) & (q < A.ns);
+    const int d = q - p;
+    const bool have_md = A.max_dist >= 0;
+    bool m = false;
+    if (in_r & in_c) {
+        if (A.mask_mode == 1) {
+            m = (A.miss_row[p] | A.miss_col[q]) != 0;
+            if (A.sym_upper) {
+                const int md = have_md ? A.max_dist : min(A.ms, A.ns);
+                m = m & (d >= 0) & (d <= md);
+            }
+        } else {
+            long long off = mat_offset(A.mask, p, q);
+            m = (off >= 0) ? (((const uint8_t*)A.mask.ptr)[off] != 0) : false;
+            if (A.full && A.sym_upper && have_md) {
+                // frame_missing_mask trims the mask to diagonals 0 .. max_dist + max(k)
+                const int lim = A.max_dist + max(A.km, A.kn);
+                m = m & (d >= 0) & (d <= lim);
+            }
+        }
+        if (!A.full) return m;
+    } else {
+        if (!A.full) return false;  // no frame in 'valid' mode
+        if (A.sym_upper && have_md) {
+            if (q >= A.ns) {
+                m = p >= A.ms - A.max_dist - 2;          // right margin, last max_dist+km+1 framed rows
+            } else if (p < 0) {
+                m = (q < 0) ? true : (q < A.max_dist + A.kn);  // top-left corner / top margin
+            } else {
+                m = false;                                // left and bottom margins are not flagged
+            }
+        } else {
+            m = true;                                     // all four margins
+        }
+    }
+    if (A.sym_upper) {
+        const int off = d + (A.kn - A.km);                // diagonal offset in framed coordinates
+        const int big_k = max(A.km, A.kn);
+        m = m | ((off <= -1) & (off >= -big_k));
+    }
+    return m;
+}
+
+// load one signal pixel as TC (0 outside the matrix / outside the stored band)
+template <typename TC>
+__device__ __forceinline__ TC load_signal(const CorrArgs<TC>& A, int p, int q)
+{
+    if ((p < 0) | (p >= A.ms) | (q < 0) | (q >= A.ns)) return TC(0);
+    long long off = mat_offset(A.sig, p, q);
+    if (off < 0) return TC(0);
+    if (A.sig_is_f64) return (TC)(((const double*)A.sig.ptr)[off]);
+    return (TC)(((const float*)A.sig.ptr)[off]);
+}
+
+__device__ __forceinline__ float cs_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double cs_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float cs_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double cs_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float cs_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double cs_fma(double a, double b, double c) { return fma(a, b, c); }
+
+// ---------------------------------------------------------------------------------------
+// Per-pixel epilogue: window sums -> Pearson coefficient, following SURVEY.md 8(a2)
+// (reference detection.py:1000-1107).  Inputs:
+//   cs  = sum S * (K' - kmean)      s1 = sum S        s2 = sum S^2
+//   nm  = number of missing pixels in the window (0 when no mask)
+//   ka  = sum_missing (K' - kmean)  kb = sum_missing Wb   (see CorrArgs::w)
+// `mask_branch` selects the reference's missing-mask code path (different but equivalent
+// ordering of the denominator); n_obs receives the number of present pixels.
+// ---------------------------------------------------------------------------------------
+template <typename TC>
+__device__ __forceinline__ TC pearson_from_sums(TC cs, TC s1, TC s2, TC nm, TC ka, TC kb,
+                                                const KernelStats<TC>& K, bool mask_branch,
+                                                TC* n_obs)
+{
+    const TC m1 = s1 * K.inv_n;
+    const TC m2 = s2 * K.inv_n;
+    const TC c = cs_fma(K.kmean, s1, cs) * K.inv_n;
+    const bool z1 = cs_abs(m1) < K.thr;
+    const bool z2 = cs_abs(m2) < K.thr;
+    const bool zc = cs_abs(c) < K.thr;
+    const TC m1z = z1 ? TC(0) : m1;
+    const TC m2z = z2 ? TC(0) : m2;
+    const TC cz = zc ? TC(0) : c;
+    TC num, den;
+    *n_obs = K.n;
+    if (!mask_branch || nm < TC(0.5)) {
+        num = (z1 | zc) ? (cz - m1z * K.kmean) : cs * K.inv_n;
+        const TC var = m2z - m1z * m1z;
+        den = mask_branch ? cs_sqrt(var * K.kvar) : cs_sqrt(var) * K.kstd;
+    } else {
+        const TC np = K.n - nm;
+        *n_obs = np;
+        const TC inv_np = TC(1) / np;
+        const TC km_ = cs_fma(K.kmean, nm, ka);                                   // sum_missing K'
+        const TC k2m = kb + TC(2) * K.kmean * ka + K.kmean * K.kmean * nm;        // sum_missing K'^2
+        const bool zk = cs_abs(km_) < K.thr;
+        const bool zk2 = cs_abs(k2m) < K.thr;
+        TC kmw, kvw;
+        if (!zk && !zk2) {
+            const TC a = ka * inv_np;
+            kmw = K.kmean - a;
+            kvw = (K.n * K.kvar - kb) * inv_np - a * a;
+        } else {
+            kmw = (K.ksum - (zk ? TC(0) : km_)) * inv_np;
+            const TC k2mw = (K.k2sum - (zk2 ? TC(0) : k2m)) * inv_np;
+            kvw = k2mw - kmw * kmw;
+        }
+        const TC m1w = m1z * K.n * inv_np;
+        const TC m2w = m2z * K.n * inv_np;
+        den = cs_sqrt((m2w - m1w * m1w) * kvw);
+        if (np < K.cut) den = TC(0);
+        if (!z1 && !zc && !zk)
+            num = cs_fma(s1 * ka, inv_np, cs) * inv_np;
+        else
+            num = (cz - m1z * kmw) * K.n * inv_np;
+    }
+    TC r = (cs_abs(den) < K.eps) ? TC(0) : num / den;
+    if (!(cs_abs(r) <= TC(3.0e38))) r = TC(0);   // NaN / inf -> 0 (detection.py:1101)
+    r = r < TC(-1) ? TC(-1) : r;
+    r = r > TC(1) ? TC(1) : r;
+    return r;
+}
+
+// does output pixel (i, j) exist, and is its value forced to 0?
+//   valid-mode margins (detection.py:720-722, 797-801) and sym_upper triu (:1098-1099)
+template <typename TC>
+__device__ __forceinline__ bool pixel_forced_zero(const CorrArgs<TC>& A, int i, int j)
+{
+    const int kh = (A.km - 1) / 2, kw = (A.kn - 1) / 2;
+    bool z = false;
+    // window rows [i-kh, i-kh+km-1] must lie inside the signal (also right for even sizes)
+    if (!A.full) z = (i < kh) | (i > A.ms - A.km + kh) | (j < kw) | (j > A.ns - A.kn + kw);
+    // triu is applied in framed coordinates when full (frame = (km-1, kn-1))
+    if (A.sym_upper) z = z | ((j - i) + (A.full ? (A.kn - A.km) : 0) < 0);
+    return z;
+}
+
+template <typename TC>
+__device__ __forceinline__ void store_pixel(const CorrArgs<TC>& A, int i, int j, TC r, TC nobs)
+{
+    long long off = mat_offset(A.out, i, j);
+    if (off >= 0) {
+        if (A.out_is_f64) ((double*)A.out.ptr)[off] = (double)r;
+        else ((float*)A.out.ptr)[off] = (float)r;
+    }
+    if (A.nobs.ptr) {
+        long long o2 = mat_offset(A.nobs, i, j);
+        if (o2 >= 0) ((float*)A.nobs.ptr)[o2] = (float)nobs;
+    }
+}
+
+// tile origin of a block.  Dense: plain 2-D tiling.  Band: for row-block by, the x tiles start
+// at the tile column containing (i0 + out_lo), clamped to >= 0.
+template <typename TC>
+__device__ __forceinline__ bool tile_origin(const CorrArgs<TC>& A, int bx, int by, int* i0, int* j0)
+{
+    *i0 = by * A.tile_h;
+    int jbase = 0;
+    if (A.out.layout == 1) {
+        int jmin = *i0 + A.out_lo;
+        if (jmin < 0) jmin = 0;
+        jbase = (jmin / A.tile_w) * A.tile_w;
+    }
+    *j0 = jbase + bx * A.tile_w;
+    if (*i0 >= A.ms || *j0 >= A.ns) return false;
+    if (A.out.layout == 1) {
+        // tile intersects the diagonal range [out_lo, out_hi]?
+        const int dmax = (*j0 + A.tile_w - 1) - *i0;
+        const int dmin = *j0 - (*i0 + A.tile_h - 1);
+        if (dmax < A.out_lo || dmin > A.out_hi) return false;
+    }
+    return true;
+}
+
+}  // namespace cs

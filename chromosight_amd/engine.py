@@ -1,0 +1,215 @@
+"""Device-side plumbing between the reference-shaped Python API (chromosight_amd.utils) and
+the C ABI: buffer staging, band geometry, and the calls themselves.  Everything here runs on
+the GPU through libchromosight_hip.so; nothing falls back to the host.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
+                   CsCsr, CsKernel, CsMatrix, CsNormxcorr2Params, band_matrix, dense_matrix)
+
+XCORR_THRESHOLD = 1e-4   # reference detection.py:595 (default `threshold` of xcorr2)
+DENOM_EPS = 1e-10        # reference detection.py:1010, 1088
+CS_U8 = 2
+
+_precision = os.environ.get("CHROMOSIGHT_HIP_PRECISION", "f32")
+
+
+def set_precision(mode):
+    """'f32' (default): float32 arithmetic on the bulk map, float64 re-scoring of the pixels
+    that decide detection.  'f64': float64 arithmetic everywhere."""
+    global _precision
+    if mode not in ("f32", "f64"):
+        raise ValueError("precision must be 'f32' or 'f64'")
+    _precision = mode
+
+
+def get_precision():
+    return _precision
+
+
+def compute_code(precision=None):
+    return CS_F64 if (precision or _precision) == "f64" else CS_F32
+
+
+class KernelSpec:
+    """Host-side description of one pattern template (keeps the float64 arrays alive while the
+    C struct points at them).  With tsvd, the correlated kernels are the truncated-SVD
+    reconstructions (reference detection.py:618-619, 1037-1043, preprocessing.py:810-847)."""
+
+    def __init__(self, kernel, tsvd=None):
+        kernel = np.ascontiguousarray(np.asarray(kernel, dtype=np.float64))
+        if kernel.ndim != 2:
+            raise ValueError("kernel must be 2-dimensional")
+        self.kernel = kernel
+        self.km, self.kn = kernel.shape
+        self.conv = None
+        self.sq = None
+        if tsvd is not None:
+            from .utils.preprocessing import factorise_kernel
+            u, v = factorise_kernel(kernel.copy(), prop_info=tsvd)
+            self.conv = np.ascontiguousarray(u @ v)
+            u2, v2 = factorise_kernel(kernel ** 2, prop_info=tsvd)
+            self.sq = np.ascontiguousarray(u2 @ v2)
+        dp = C.POINTER(C.c_double)
+        self.struct = CsKernel(
+            self.km, self.kn,
+            self.kernel.ctypes.data_as(dp),
+            self.conv.ctypes.data_as(dp) if self.conv is not None else None,
+            self.sq.ctypes.data_as(dp) if self.sq is not None else None,
+        )
+
+
+def min_present(kernel_shape, missing_tol):
+    """int((1 - missing_tol) * km * kn), reference detection.py:1069-1072."""
+    return int((1 - missing_tol) * kernel_shape[0] * kernel_shape[1])
+
+
+def run_normxcorr2(dev, sig, shape, kspec, out, *, full, sym_upper, max_dist, mask_mode=MASK_NONE,
+                   miss_row=None, miss_col=None, mask=None, missing_tol=0.75, nobs=None,
+                   precision=None, stream=None):
+    """sig / out / nobs are CsMatrix; miss_row / miss_col / mask are DeviceBuffers (uint8)."""
+    params = CsNormxcorr2Params(
+        int(shape[0]), int(shape[1]), int(bool(full)), int(bool(sym_upper)),
+        -1 if max_dist is None else int(max_dist), int(mask_mode),
+        miss_row.ptr if miss_row is not None else None,
+        miss_col.ptr if miss_col is not None else None,
+        mask.ptr if mask is not None else None,
+        min_present((kspec.km, kspec.kn), missing_tol), compute_code(precision),
+        XCORR_THRESHOLD, DENOM_EPS,
+    )
+    dev._check(dev.lib.cs_normxcorr2(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params),
+                                     C.byref(out), C.byref(nobs) if nobs is not None else None))
+    return params
+
+
+def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist, mask_mode=MASK_NONE,
+                miss_row=None, miss_col=None, mask=None, missing_tol=0.75, stream=None):
+    """float64 coefficients (and present-pixel counts) at the given pixels."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    n = rows.size
+    if n == 0:
+        return np.zeros(0), np.zeros(0)
+    params = CsNormxcorr2Params(
+        int(shape[0]), int(shape[1]), int(bool(full)), int(bool(sym_upper)),
+        -1 if max_dist is None else int(max_dist), int(mask_mode),
+        miss_row.ptr if miss_row is not None else None,
+        miss_col.ptr if miss_col is not None else None,
+        mask.ptr if mask is not None else None,
+        min_present((kspec.km, kspec.kn), missing_tol), CS_F64, XCORR_THRESHOLD, DENOM_EPS,
+    )
+    d_rows, d_cols = dev.to_device(rows), dev.to_device(cols)
+    d_r, d_n = dev.empty(n, np.float64), dev.empty(n, np.float64)
+    dev._check(dev.lib.cs_rescore_f64(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params),
+                                      d_rows.ptr, d_cols.ptr, n, d_r.ptr, d_n.ptr))
+    return d_r.download(stream), d_n.download(stream)
+
+
+def run_compact(dev, corr, shape, threshold, lo_diag, hi_diag, stream=None, guess=1 << 16):
+    """(rows, cols, vals) of the stored pixels of `corr` with value >= threshold inside the
+    diagonal range; sorted row-major."""
+    cap = int(guess)
+    while True:
+        d_rows, d_cols = dev.empty(cap, np.int32), dev.empty(cap, np.int32)
+        d_vals = dev.empty(cap, np.float64)
+        d_count = dev.zeros(1, np.int64, stream)
+        dev._check(dev.lib.cs_compact_ge(dev.ctx, stream, C.byref(corr), int(shape[0]), int(shape[1]),
+                                         float(threshold), int(lo_diag), int(hi_diag), d_rows.ptr, d_cols.ptr,
+                                         d_vals.ptr, cap, d_count.ptr))
+        count = int(d_count.download(stream)[0])
+        if count <= cap:
+            break
+        cap = count
+    rows = d_rows.download(stream)[:count]
+    cols = d_cols.download(stream)[:count]
+    vals = d_vals.download(stream)[:count]
+    order = np.lexsort((cols, rows))
+    return rows[order], cols[order], vals[order]
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR staging
+# ------------------------------------------------------------------------------------------------
+class DeviceCsr:
+    def __init__(self, dev, mat, dtype=None, stream=None):
+        mat = sp.csr_matrix(mat)
+        if not mat.has_canonical_format:
+            mat = mat.copy()
+            mat.sum_duplicates()
+        if dtype is None:
+            dtype = np.float32 if mat.dtype == np.float32 else np.float64
+        self.shape = mat.shape
+        self.nnz = int(mat.nnz)
+        self.indptr = dev.to_device(mat.indptr, np.int64, stream)
+        self.indices = dev.to_device(mat.indices, np.int32, stream)
+        self.data = dev.to_device(mat.data, dtype, stream)
+        self.struct = CsCsr(self.shape[0], self.shape[1], self.nnz, self.indptr.ptr, self.indices.ptr,
+                            self.data.ptr, _lib.np_dtype_code(dtype))
+
+
+def diag_range(mat):
+    """(lo, hi) of col - row over the stored entries of a sparse matrix, or None if empty."""
+    coo = mat.tocoo()
+    if coo.nnz == 0:
+        return None
+    d = coo.col.astype(np.int64) - coo.row.astype(np.int64)
+    return int(d.min()), int(d.max())
+
+
+def csr_to_matrix(dev, dcsr, *, layout, dtype, band_lo=0, band_w=0, law=None, max_val=0.0, stream=None):
+    """Scatter a device CSR into a zero-filled dense or band buffer (optionally detrending).
+    Returns (DeviceBuffer, CsMatrix)."""
+    n_rows, n_cols = dcsr.shape
+    if layout == LAYOUT_BAND:
+        ld = (int(band_w) + 63) // 64 * 64
+        buf = dev.empty((n_rows, ld), dtype)
+        code = CS_U8 if np.dtype(dtype) == np.uint8 else _lib.np_dtype_code(dtype)
+        mat = CsMatrix(buf.ptr, code, LAYOUT_BAND, ld, int(band_lo), int(band_w))
+    else:
+        ld = (n_cols + 15) // 16 * 16
+        buf = dev.empty((n_rows, ld), dtype)
+        code = CS_U8 if np.dtype(dtype) == np.uint8 else _lib.np_dtype_code(dtype)
+        mat = CsMatrix(buf.ptr, code, LAYOUT_DENSE, ld, 0, 0)
+    d_law = None
+    n_law = 0
+    if law is not None:
+        law = np.ascontiguousarray(law, dtype=np.float64)
+        d_law = dev.to_device(law, np.float64, stream)
+        n_law = law.size
+    dev._check(dev.lib.cs_csr_to_band(dev.ctx, stream, C.byref(dcsr.struct), d_law.ptr if d_law else None,
+                                      n_law, float(max_val or 0.0), C.byref(mat)))
+    return buf, mat
+
+
+def distance_law_sums(dev, dcsr, detectable_mask, n_diags, stream=None):
+    """Per-diagonal (sum, count) of the positive pixels between detectable bins."""
+    d_det = dev.to_device(np.asarray(detectable_mask, dtype=np.uint8), np.uint8, stream) \
+        if detectable_mask is not None else None
+    d_sum, d_cnt = dev.empty(max(n_diags, 1), np.float64), dev.empty(max(n_diags, 1), np.int64)
+    dev._check(dev.lib.cs_distance_law_csr(dev.ctx, stream, C.byref(dcsr.struct),
+                                           d_det.ptr if d_det else None, int(n_diags), d_sum.ptr, d_cnt.ptr))
+    return d_sum.download(stream)[:n_diags], d_cnt.download(stream)[:n_diags]
+
+
+def detrend_values(dev, dcsr, law, max_val, stream=None):
+    """Detrended stored values of the CSR (same order as dcsr.data)."""
+    law = np.ascontiguousarray(law, dtype=np.float64)
+    d_law = dev.to_device(law, np.float64, stream)
+    out = dev.empty(max(dcsr.nnz, 1), dcsr.data.dtype)
+    dev._check(dev.lib.cs_detrend_csr(dev.ctx, stream, C.byref(dcsr.struct), d_law.ptr, law.size,
+                                      float(max_val or 0.0), out.ptr))
+    return out.download(stream)[:dcsr.nnz]
+
+
+def band_to_coo(band, band_lo, band_w, n_cols):
+    """Non-zero entries of a host band array as (rows, cols, vals)."""
+    view = band[:, :band_w]
+    rows, offs = np.nonzero(view)
+    cols = rows + band_lo + offs
+    ok = (cols >= 0) & (cols < n_cols)
+    return rows[ok], cols[ok], view[rows[ok], offs[ok]]

@@ -1,0 +1,589 @@
+"""Detection half of the hot path with the reference's call surface
+(chromosight/utils/detection.py).  `xcorr2`, `normxcorr2` and the correlation inside
+`pattern_detector` run on the MI355X (libchromosight_hip.so); foci picking, window
+validation and neighbour removal are the host-side callers that turn the coefficient map
+into pattern coordinates with the reference's exact rules.
+
+Numerics: the bulk coefficient map is computed in float32 (or float64 with
+chromosight_amd.set_precision("f64")); every pixel that decides a detection -- all pixels at
+or above the Pearson threshold, and all reported scores -- is re-evaluated in float64 on the
+device (cs_rescore_f64), so candidate coordinates do not depend on float32 rounding.
+"""
+import ctypes as C
+import pathlib
+import warnings
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+from scipy.sparse import csgraph
+
+from . import preprocessing as preproc
+from . import stats as cus
+from .. import engine
+from .._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
+                    CsMatrix, get_device, np_dtype_code)
+
+# margin below the Pearson threshold within which float32 scores are re-evaluated in float64
+RESCORE_MARGIN = 2e-3
+
+
+# ============================================================================================
+# signal staging
+# ============================================================================================
+class _Staged:
+    """A signal resident in HBM in dense or band layout, plus the geometry of the output map."""
+
+    def __init__(self, dev, signal, kernel_shape, sym_upper, full, extra_range=None,
+                 out_diag_range=None):
+        km, kn = kernel_shape
+        self.dev = dev
+        self.shape = ms, ns = signal.shape
+        self.sparse = sp.issparse(signal)
+        self.keep = []  # device buffers that must outlive the calls
+        reach = (km - 1) // 2 + (kn - 1) // 2
+        if self.sparse:
+            rng = engine.diag_range(signal)
+            if extra_range is not None:
+                rng = extra_range if rng is None else (min(rng[0], extra_range[0]), max(rng[1], extra_range[1]))
+            if rng is None:
+                rng = (0, 0)
+            lo, hi = rng
+            out_lo, out_hi = max(lo - reach, -(ms - 1)), min(hi + reach, ns - 1)
+            if sym_upper:
+                out_lo = max(out_lo, (km - kn) if full else 0)
+            if out_diag_range is not None:
+                out_lo, out_hi = max(out_lo, out_diag_range[0]), min(out_hi, out_diag_range[1])
+            out_hi = max(out_hi, out_lo)
+            in_w, out_w = hi - lo + 1, out_hi - out_lo + 1
+            use_band = 2 * max(in_w, out_w) < ns
+            in_dtype = np.float32 if signal.dtype == np.float32 else np.float64
+            self.dcsr = engine.DeviceCsr(dev, signal, in_dtype)
+            if use_band:
+                self.layout = LAYOUT_BAND
+                self.in_lo, self.in_w = lo, in_w
+                self.out_lo, self.out_w = out_lo, out_w
+                buf, self.sig = engine.csr_to_matrix(dev, self.dcsr, layout=LAYOUT_BAND, dtype=in_dtype,
+                                                     band_lo=lo, band_w=in_w)
+            else:
+                self.layout = LAYOUT_DENSE
+                buf, self.sig = engine.csr_to_matrix(dev, self.dcsr, layout=LAYOUT_DENSE, dtype=in_dtype)
+            self.keep.append(buf)
+            self.sig_buf = buf
+        else:
+            arr = np.asarray(signal)
+            if arr.dtype != np.float32:
+                arr = arr.astype(np.float64, copy=False)
+            self.layout = LAYOUT_DENSE
+            ld = (ns + 15) // 16 * 16
+            padded = np.zeros((ms, ld), dtype=arr.dtype)
+            padded[:, :ns] = arr
+            buf = dev.to_device(padded)
+            self.sig_buf = buf
+            self.keep.append(buf)
+            self.sig = CsMatrix(buf.ptr, np_dtype_code(arr.dtype), LAYOUT_DENSE, ld, 0, 0)
+
+    def stage_mask(self, mask):
+        """Explicit missing mask (scipy sparse bool) -> uint8 buffer with the signal's geometry."""
+        dmask = engine.DeviceCsr(self.dev, sp.csr_matrix(mask, dtype=np.float32), np.float32)
+        if self.layout == LAYOUT_BAND:
+            buf, _ = engine.csr_to_matrix(self.dev, dmask, layout=LAYOUT_BAND, dtype=np.uint8,
+                                          band_lo=self.in_lo, band_w=self.in_w)
+        else:
+            buf, _ = engine.csr_to_matrix(self.dev, dmask, layout=LAYOUT_DENSE, dtype=np.uint8)
+        self.keep.append(buf)
+        return buf
+
+    def alloc_out(self, dtype):
+        ms, ns = self.shape
+        if self.layout == LAYOUT_BAND:
+            ld = (self.out_w + 63) // 64 * 64
+            buf = self.dev.zeros((ms, ld), dtype)
+            mat = CsMatrix(buf.ptr, np_dtype_code(dtype), LAYOUT_BAND, ld, self.out_lo, self.out_w)
+        else:
+            ld = (ns + 15) // 16 * 16
+            buf = self.dev.empty((ms, ld), dtype)
+            mat = CsMatrix(buf.ptr, np_dtype_code(dtype), LAYOUT_DENSE, ld, 0, 0)
+        return buf, mat
+
+    def to_host_coo(self, buf):
+        """(rows, cols, vals) of the non-zero entries of an output buffer."""
+        host = buf.download()
+        ms, ns = self.shape
+        if self.layout == LAYOUT_BAND:
+            return engine.band_to_coo(host, self.out_lo, self.out_w, ns)
+        view = host[:, :ns]
+        rows, cols = np.nonzero(view)
+        return rows, cols, view[rows, cols]
+
+    def to_host_dense(self, buf):
+        host = buf.download()
+        return np.ascontiguousarray(host[:, :self.shape[1]])
+
+
+def _out_dtype():
+    return np.float64 if engine.get_precision() == "f64" else np.float32
+
+
+# ============================================================================================
+# xcorr2 / normxcorr2
+# ============================================================================================
+def xcorr2(signal, kernel, threshold=1e-4, tsvd=None):
+    """Cross-correlate (no flip) a dense or sparse 2-D signal with a dense kernel; the result
+    is aligned on the window centre, zero on the (k-1)//2 margins, and values with
+    |v| < threshold are zeroed (reference detection.py:595-624, 627-723, 726-804).
+    Same container type as the input.  With `tsvd`, the kernel is replaced by its truncated-SVD
+    reconstruction (reference preprocessing.py:810-847)."""
+    if sp.issparse(kernel):
+        raise ValueError("cannot handle kernel in sparse format")
+    kernel = np.asarray(kernel, dtype=np.float64)
+    if tsvd is not None:
+        u, v = preproc.factorise_kernel(kernel, prop_info=tsvd)
+        kernel = u @ v
+    km, kn = kernel.shape
+    sm, sn = signal.shape
+    if sm < km or sn < kn:
+        raise ValueError("cannot have kernel bigger than signal")
+    dev = get_device()
+    st = _Staged(dev, signal, (km, kn), sym_upper=False, full=False)
+    out_buf, out_mat = st.alloc_out(_out_dtype())
+    w = np.ascontiguousarray(kernel, dtype=np.float64)
+    dev._check(dev.lib.cs_xcorr2(dev.ctx, None, C.byref(st.sig), sm, sn,
+                                 w.ctypes.data_as(C.POINTER(C.c_double)), km, kn, float(threshold),
+                                 engine.compute_code(), C.byref(out_mat)))
+    # even kernel sizes give an output one row/column short, like the reference's re-padding
+    osm = sm - km + 1 + 2 * ((km - 1) // 2)
+    osn = sn - kn + 1 + 2 * ((kn - 1) // 2)
+    if st.sparse:
+        rows, cols, vals = st.to_host_coo(out_buf)
+        ok = (rows < osm) & (cols < osn)
+        return sp.csr_matrix((vals[ok].astype(np.float64), (rows[ok], cols[ok])), shape=(osm, osn))
+    return st.to_host_dense(out_buf)[:osm, :osn].astype(np.float64)
+
+
+def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missing_mask=None,
+               missing_tol=0.75, tsvd=None, pval=False):
+    """Pearson correlation of every kernel-sized window of `signal` with `kernel`
+    (reference detection.py:807-914 -> :917-1131 sparse, :1134-1273 dense).
+
+    Returns (corr, log10_pvals or None), containers of the same type and shape as `signal`.
+    See SURVEY.md section 8(a2) for the per-pixel definition that the device kernel evaluates
+    (zeroing thresholds, missing-pixel handling, the `missing_tol` cut, clipping).
+
+    Differences with the reference, all in places where the reference raises by accident:
+    a dense signal with a missing mask, and dense full=True with pval=True, are evaluated with
+    the sparse formulas instead of crashing (reference detection.py:1246, :1263)."""
+    if sp.issparse(kernel):
+        raise ValueError("cannot handle kernel in sparse format")
+    kernel = np.asarray(kernel, dtype=np.float64)
+    if missing_mask is not None:
+        if not sp.issparse(missing_mask):
+            raise ValueError("Missing mask must be a sparse matrix.")
+        if not signal.shape == missing_mask.shape:
+            raise ValueError("Signal and missing mask do not have the same shape")
+        if missing_mask.dtype != bool:
+            raise ValueError(f"Missing mask dtype is {missing_mask.dtype}. Should be bool.")
+        if min(kernel.shape) >= max(signal.shape):
+            raise ValueError("cannot have kernel bigger than signal")
+        preproc.check_missing_mask(signal, missing_mask)
+    if not (kernel.std() > 0):
+        raise ValueError("Cannot have flat kernel.")
+    km, kn = kernel.shape
+    ms, ns = signal.shape
+    if not (km % 2 and kn % 2):
+        raise ValueError("kernel dimensions must be odd")
+    if not full and (ms < km or ns < kn):
+        raise ValueError("cannot have kernel bigger than signal")
+    dev = get_device()
+    kspec = engine.KernelSpec(kernel, tsvd)
+    mask_range = engine.diag_range(missing_mask) if missing_mask is not None else None
+    st = _Staged(dev, signal, (km, kn), sym_upper, full, extra_range=mask_range)
+    mask_buf = None
+    mask_mode = MASK_NONE
+    if missing_mask is not None:
+        if full:
+            _check_framed_signal(signal, missing_mask, (km, kn), sym_upper, max_dist)
+        mask_buf = st.stage_mask(missing_mask)
+        mask_mode = MASK_EXPLICIT
+    out_dtype = _out_dtype()
+    out_buf, out_mat = st.alloc_out(out_dtype)
+    want_nobs = pval and full and missing_mask is not None
+    nobs_buf = nobs_mat = None
+    if want_nobs:
+        nobs_buf, nobs_mat = st.alloc_out(np.float32)
+    engine.run_normxcorr2(dev, st.sig, (ms, ns), kspec, out_mat, full=full, sym_upper=sym_upper,
+                          max_dist=max_dist, mask_mode=mask_mode, mask=mask_buf,
+                          missing_tol=missing_tol, nobs=nobs_mat)
+    n = km * kn
+    if st.sparse:
+        rows, cols, vals = st.to_host_coo(out_buf)
+        vals = vals.astype(np.float64)
+        corr = sp.csr_matrix((vals, (rows, cols)), shape=(ms, ns))
+        pvals = None
+        if pval:
+            if want_nobs:
+                nobs_host = nobs_buf.download()
+                if st.layout == LAYOUT_BAND:
+                    n_obs = nobs_host[rows, cols - rows - st.out_lo].astype(np.float64)
+                else:
+                    n_obs = nobs_host[rows, cols].astype(np.float64)
+                n_obs[n_obs == 0] = n
+                logp = cus.corr_to_pval(vals, n_obs)
+            else:
+                logp = cus.corr_to_pval(vals, n)
+            pvals = sp.csr_matrix((logp, (rows, cols)), shape=(ms, ns))
+        return corr, pvals
+    corr = st.to_host_dense(out_buf).astype(np.float64)
+    pvals = None
+    if pval:
+        if want_nobs:
+            n_obs = st.to_host_dense(nobs_buf).astype(np.float64)
+            pvals = cus.corr_to_pval(corr, n_obs)
+        else:
+            pvals = cus.corr_to_pval(corr.ravel(), n).reshape(corr.shape)
+    return corr, pvals
+
+
+def _check_framed_signal(signal, mask, kernel_shape, sym_upper, max_dist):
+    """Second safety check of the reference (detection.py:1022): in full mode the framed mask
+    also flags the first max(mk, nk) sub-diagonals of upper-symmetric maps, which must then
+    hold no signal."""
+    if not sym_upper:
+        return
+    big_k = max(kernel_shape)
+    mk, nk = kernel_shape
+    coo = sp.coo_matrix(signal) if sp.issparse(signal) else sp.coo_matrix(np.asarray(signal))
+    off = coo.col.astype(np.int64) - coo.row.astype(np.int64) + (nk - mk)
+    bad = (off <= -1) & (off >= -big_k) & (np.abs(coo.data) > 0)
+    n_bad = int(np.count_nonzero(bad))
+    if n_bad:
+        raise ValueError("There are", n_bad, "non-zero elements reported as missing.")
+
+
+# ============================================================================================
+# foci picking (host)
+# ============================================================================================
+def label_foci(matrix):
+    """Label the 4-connected components of the non-zero pixels of a sparse 0/1 matrix
+    (reference detection.py:459-554).  Returns (num_foci, coo matrix of labels starting at 1);
+    labels are numbered by the row-major position of each focus' first pixel."""
+    mat = sp.coo_matrix(sp.csr_matrix(matrix))
+    n_rows, n_cols = mat.shape
+    rows, cols = mat.row.astype(np.int64), mat.col.astype(np.int64)
+    n_px = rows.size
+    key = rows * n_cols + cols                       # sorted: csr -> coo is row-major
+    if n_px and np.any(np.diff(key) <= 0):
+        raise ValueError("matrix_sp is not properly double sorted")
+    # right neighbour: next pixel in row-major order on the same row, next column
+    right = np.flatnonzero((np.diff(rows) == 0) & (np.diff(cols) == 1))
+    # lower neighbour: pixel with key + n_cols
+    pos = np.searchsorted(key, key + n_cols)
+    pos_ok = pos < n_px
+    has_low = np.zeros(n_px, dtype=bool)
+    has_low[pos_ok] = key[pos[pos_ok]] == key[pos_ok] + n_cols
+    low_src = np.flatnonzero(has_low)
+    src = np.concatenate([right, low_src])
+    dst = np.concatenate([right + 1, pos[low_src]])
+    adj = sp.coo_matrix((np.ones(src.size, dtype=np.int8), (src, dst)), shape=(n_px, n_px))
+    num_foci, labels = csgraph.connected_components(adj, directed=False)
+    foci_mat = sp.coo_matrix((labels + 1, (mat.row, mat.col)), shape=(n_rows, n_cols))
+    return num_foci, foci_mat
+
+
+def filter_foci(foci_mat, min_size=2):
+    """Erase foci with fewer than min_size pixels (reference detection.py:557-592).  Like the
+    reference, operates on (and modifies) the data array of the input matrix."""
+    data = foci_mat.data
+    ids, sizes = np.unique(data, return_counts=True)
+    small = ids[sizes < min_size]
+    data[np.isin(data, small)] = 0
+    filtered = foci_mat.copy()
+    filtered.data = data
+    filtered.eliminate_zeros()
+    return int(np.count_nonzero(sizes >= min_size)), filtered
+
+
+def pick_foci(mat_conv, pearson, min_size=2):
+    """Threshold the coefficient map at `pearson` (>= passes), label 4-connected foci, drop foci
+    of fewer than min_size pixels and return, per focus, the first pixel (row-major) holding its
+    maximum coefficient (reference detection.py:387-456).  Returns (coords, labelled matrix) or
+    (None, None)."""
+    cand = sp.coo_matrix(mat_conv).copy()
+    cand.data = np.where(cand.data < pearson, 0.0, cand.data)
+    cand.data[cand.data != 0] = 1
+    cand.eliminate_zeros()
+    if cand.nnz == 0:
+        return None, None
+    _, labelled = label_foci(cand)
+    num_foci, labelled = filter_foci(labelled, min_size=min_size)
+    if num_foci == 0:
+        return None, None
+    conv = sp.csr_matrix(mat_conv)
+    scores = np.asarray(conv[labelled.row, labelled.col]).ravel()
+    coords = _argmax_per_label(labelled.row, labelled.col, labelled.data, scores)
+    return coords, labelled
+
+
+def _argmax_per_label(rows, cols, labels, scores):
+    """First row-major pixel with the maximal score of each label, labels in increasing order."""
+    order = np.lexsort((-scores, labels))      # stable: ties keep the row-major order
+    lab_sorted = labels[order]
+    first = np.concatenate([[True], lab_sorted[1:] != lab_sorted[:-1]])
+    best = order[first]
+    out = np.zeros((best.size, 2), dtype=int)
+    out[:, 0] = rows[best]
+    out[:, 1] = cols[best]
+    return out
+
+
+# ============================================================================================
+# window validation / neighbours / pileup (host)
+# ============================================================================================
+def _validate(coords, matrix, scores, missing_rows, missing_cols, kernel_shape, drop, zero_tol,
+              missing_tol):
+    """Shared body of validate_patterns: `scores[i]` is the coefficient at coords[i]."""
+    matrix = sp.csr_matrix(matrix)
+    win_h, win_w = kernel_shape
+    half_h, half_w = win_h // 2 + 1, win_w // 2 + 1
+    n = coords.shape[0]
+    out_scores = np.full(n, np.nan)
+    windows = np.full((n, win_h, win_w), np.nan)
+    miss_r = np.zeros(matrix.shape[0], dtype=bool)
+    miss_c = np.zeros(matrix.shape[1], dtype=bool)
+    miss_r[missing_rows] = True
+    miss_c[missing_cols] = True
+    failed = np.zeros(n, dtype=bool)
+    for i in range(n):
+        p1, p2 = int(coords[i, 0]), int(coords[i, 1])
+        high, low = p1 - half_h + 1, p1 + half_h
+        left, right = p2 - half_w + 1, p2 + half_w
+        # strict upper bounds, as in the reference (detection.py:99-104)
+        if not (high >= 0 and low < matrix.shape[0] and left >= 0 and right < matrix.shape[1]):
+            failed[i] = True
+            continue
+        win = matrix[high:low, left:right].toarray().astype(np.float64)
+        win[miss_r[high:low], :] = np.nan
+        win[:, miss_c[left:right]] = np.nan
+        tot = win.size
+        n_zero = np.count_nonzero(win == 0)
+        n_miss = np.count_nonzero(~np.isfinite(win))
+        with np.errstate(all="ignore"):
+            prop_undetected = n_miss / tot
+            prop_zero = n_zero / (tot - n_miss)
+        if (prop_undetected < missing_tol) and (prop_zero < zero_tol):
+            out_scores[i] = scores[i]
+            windows[i] = win
+        else:
+            failed[i] = True
+    table = pd.DataFrame({"bin1": coords[:, 0], "bin2": coords[:, 1], "score": out_scores})
+    if drop:
+        return table.loc[~failed, :], windows[~failed]
+    return table, windows
+
+
+def validate_patterns(coords, matrix, conv_mat, detectable_bins, kernel_matrix, drop=True,
+                      zero_tol=0.3, missing_tol=0.75):
+    """Drop (or flag with NaN) the patterns whose window leaves the matrix or holds too many
+    missing / zero pixels, and return the window of each pattern
+    (reference detection.py:18-155)."""
+    matrix = sp.csr_matrix(matrix)
+    coords = np.asarray(coords)
+    conv = sp.csr_matrix(conv_mat)
+    rr = np.clip(coords[:, 0].astype(int), 0, conv.shape[0] - 1)
+    cc = np.clip(coords[:, 1].astype(int), 0, conv.shape[1] - 1)
+    scores = np.asarray(conv[rr, cc]).ravel() if coords.shape[0] else np.zeros(0)
+    missing_rows = preproc.valid_to_missing(detectable_bins[0], matrix.shape[0])
+    missing_cols = preproc.valid_to_missing(detectable_bins[1], matrix.shape[1])
+    return _validate(coords, matrix, scores, missing_rows, missing_cols, np.shape(kernel_matrix),
+                     drop, zero_tol, missing_tol)
+
+
+def pileup_patterns(pattern_windows):
+    """Pixel-wise mean of a stack of windows, ignoring NaN (reference detection.py:158-174)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return np.nanmean(pattern_windows, axis=0)
+
+
+def remove_neighbours(patterns, win_size=8):
+    """Greedy suppression by decreasing score: a kept pattern blacklists every other pattern
+    closer than win_size bins on both axes (reference detection.py:348-384).  Returns a boolean
+    keep-mask aligned on the input rows."""
+    ordered = patterns.copy().sort_values("score", ascending=False)
+    idx = ordered.index.values
+    b1 = ordered.bin1.to_numpy()
+    b2 = ordered.bin2.to_numpy()
+    dropped = np.zeros(len(idx), dtype=bool)   # in sorted order
+    for k in range(len(idx)):
+        if dropped[k]:
+            continue
+        close = (np.abs(b1 - b1[k]) < win_size) & (np.abs(b2 - b2[k]) < win_size)
+        close[k] = False
+        dropped |= close
+    keep = np.ones(patterns.shape[0], dtype=bool)
+    keep[idx[dropped]] = False
+    return keep
+
+
+# ============================================================================================
+# pattern_detector
+# ============================================================================================
+def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dump=None, full=False,
+                     tsvd=None):
+    """Detect patterns in one contact map (or, with `coords`, quantify the given positions)
+    (reference detection.py:177-345).
+
+    contact_map needs the attributes `matrix` (scipy sparse), `detectable_bins` (pair of index
+    arrays -- boolean masks are accepted when full=False, as in the reference), `max_dist`,
+    `inter` (and `name` when dumping).  Returns (DataFrame[bin1, bin2, score, pvalue],
+    windows (n, km, kn)) or (None, None)."""
+    kernel_matrix = np.asarray(kernel_matrix, dtype=np.float64)
+    km, kn = kernel_matrix.shape
+    kh, kw = (km - 1) // 2, (kn - 1) // 2
+    run_mode = "detect" if coords is None else "quantify"
+    matrix = contact_map.matrix
+    ms, ns = matrix.shape
+    if min(ms, ns) <= max(km, kn):
+        return None, None
+    inter = bool(contact_map.inter)
+    max_dist = contact_map.max_dist
+    missing_tol = kernel_config["max_perc_undetected"] / 100
+    zero_tol = kernel_config["max_perc_zero"] / 100
+    pearson = kernel_config["pearson"]
+    sym_upper = not inter
+
+    dev = get_device()
+    kspec = engine.KernelSpec(kernel_matrix, tsvd)
+    csr = sp.csr_matrix(matrix)
+    if dump:
+        return _pattern_detector_dump(contact_map, kernel_config, kernel_matrix, coords, dump, full, tsvd)
+
+    out_range = None
+    if not inter and max_dist is not None:
+        out_range = (0, max_dist)       # diag_trim(mat_conv, max_dist), detection.py:269-270
+    st = _Staged(dev, csr, (km, kn), sym_upper, full, out_diag_range=out_range)
+    mask_kw = dict(mask_mode=MASK_NONE)
+    if full:
+        miss_r = dev.to_device(preproc.missing_flags(contact_map.detectable_bins[0], ms))
+        miss_c = dev.to_device(preproc.missing_flags(contact_map.detectable_bins[1], ns))
+        mask_kw = dict(mask_mode=MASK_BINS, miss_row=miss_r, miss_col=miss_c)
+    common = dict(full=full, sym_upper=sym_upper, max_dist=max_dist, missing_tol=missing_tol, **mask_kw)
+    lo_diag, hi_diag = (-(ms - 1), ns - 1) if out_range is None else out_range
+    if not inter and max_dist is None:
+        lo_diag = 0
+
+    if run_mode == "detect":
+        out_buf, out_mat = st.alloc_out(_out_dtype())
+        engine.run_normxcorr2(dev, st.sig, (ms, ns), kspec, out_mat, **common)
+        exact = engine.get_precision() == "f64"
+        thr = pearson if exact else pearson - RESCORE_MARGIN
+        rows, cols, vals = engine.run_compact(dev, out_mat, (ms, ns), thr, lo_diag, hi_diag)
+        if not exact and rows.size:
+            vals, _ = engine.run_rescore(dev, st.sig, (ms, ns), kspec, rows, cols, **common)
+        keep = (vals >= pearson) & (vals != 0)
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+        if rows.size == 0:
+            return None, None
+        cand = sp.coo_matrix((vals, (rows, cols)), shape=(ms, ns))
+        coords, _ = pick_foci(cand, pearson)
+        if coords is None:
+            return None, None
+    else:
+        coords_in = coords
+        coords = np.array(coords_in, dtype=int, copy=True)
+
+    # 1-D patterns live on the diagonal (detection.py:311-315)
+    if not inter and kernel_config["max_dist"] == 0:
+        coords[:, 0] = coords[:, 1]
+
+    # coefficient (trimmed map) and p-value (untrimmed map) at the final coordinates
+    rr, cc = coords[:, 0].astype(np.int64), coords[:, 1].astype(np.int64)
+    inside = (rr >= 0) & (rr < ms) & (cc >= 0) & (cc < ns)
+    r64, nobs = engine.run_rescore(dev, st.sig, (ms, ns), kspec, np.where(inside, rr, 0),
+                                   np.where(inside, cc, 0), **common)
+    r64 = np.where(inside, r64, 0.0)
+    in_band = inside.copy()
+    if not inter:
+        d = cc - rr
+        in_band &= (d >= 0) & ((d <= max_dist) if max_dist is not None else True)
+    conv_at = np.where(in_band, r64, 0.0)
+    n_obs = nobs if full else np.full(r64.shape, float(km * kn))
+    with np.errstate(all="ignore"):
+        logp = np.where(r64 != 0, cus.corr_to_pval(r64, np.where(n_obs == 0, km * kn, n_obs)), 0.0)
+
+    # window validation on the (zero padded when full) contact map, detection.py:287-329
+    mat = csr
+    missing_rows = preproc.valid_to_missing(contact_map.detectable_bins[0], ms)
+    missing_cols = preproc.valid_to_missing(contact_map.detectable_bins[1], ns)
+    vcoords = coords.copy()
+    if full:
+        mat = preproc.zero_pad_sparse(mat, kh, kw, fmt="csr")
+        in_r = np.ones(ms + 2 * kw, dtype=bool)  # zero_pad_sparse(mat, kh, kw): kh columns, kw rows
+        in_c = np.ones(ns + 2 * kh, dtype=bool)
+        det_r = np.asarray(contact_map.detectable_bins[0]) + kh
+        det_c = np.asarray(contact_map.detectable_bins[1]) + kw
+        in_r[det_r[det_r < in_r.size]] = False
+        in_c[det_c[det_c < in_c.size]] = False
+        missing_rows, missing_cols = np.flatnonzero(in_r), np.flatnonzero(in_c)
+        vcoords[:, 0] += kh
+        vcoords[:, 1] += kw
+        # the reference shifts the caller's array in place when coords are given (:297-298)
+        if run_mode == "quantify":
+            try:
+                coords_in[:, 0] += kh
+                coords_in[:, 1] += kw
+                if not inter and kernel_config["max_dist"] == 0:
+                    coords_in[:, 0] = coords_in[:, 1]
+            except (TypeError, ValueError, IndexError):
+                pass
+    if not inter:
+        big_k = max(km, kn)
+        mat = sp.csr_matrix(mat, dtype=np.float64)
+        stripes = sp.diags([np.full(mat.shape[0], np.nan)] * big_k, -np.arange(1, big_k + 1),
+                           shape=mat.shape, format="csr")
+        mat = mat + stripes
+    table, windows = _validate(vcoords, mat, conv_at, missing_rows, missing_cols, (km, kn),
+                               drop=(run_mode == "detect"), zero_tol=zero_tol, missing_tol=missing_tol)
+    kept = table.index.to_numpy()
+    if full:
+        table.bin1 -= kh
+        table.bin2 -= kw
+    table["pvalue"] = 10 ** logp[kept] if len(kept) else None
+    return table, windows
+
+
+def _pattern_detector_dump(contact_map, kernel_config, kernel_matrix, coords, dump, full, tsvd):
+    """pattern_detector with the reference's intermediate dumps (03_normxcorr2, 04_diag_trim,
+    05_foci; reference detection.py:227-231, 265, 272, 285): materialises the whole coefficient
+    map on the host, so it is the slow, inspectable variant."""
+    class _NoDump:
+        pass
+    shadow = _NoDump()
+    for attr in ("matrix", "detectable_bins", "max_dist", "inter"):
+        setattr(shadow, attr, getattr(contact_map, attr))
+    km, kn = kernel_matrix.shape
+
+    def save(base, mat):
+        sp.save_npz(pathlib.Path(dump) / f"{contact_map.name}_{base}", mat)
+
+    mask = None
+    if full:
+        mask = preproc.make_missing_mask(
+            contact_map.matrix.shape, valid_rows=contact_map.detectable_bins[0],
+            valid_cols=contact_map.detectable_bins[1], max_dist=contact_map.max_dist,
+            sym_upper=not contact_map.inter)
+    conv, _ = normxcorr2(sp.csr_matrix(contact_map.matrix), kernel_matrix, max_dist=contact_map.max_dist,
+                         sym_upper=not contact_map.inter, full=full, missing_mask=mask, tsvd=tsvd,
+                         pval=False, missing_tol=kernel_config["max_perc_undetected"] / 100)
+    save("03_normxcorr2", conv)
+    conv.data[np.isnan(conv.data)] = 0
+    if not contact_map.inter:
+        conv = preproc.diag_trim(conv.tocsr(), contact_map.max_dist)
+        save("04_diag_trim", conv)
+    if coords is None:
+        conv = conv.tocoo()
+        conv.eliminate_zeros()
+        _, foci = pick_foci(conv, kernel_config["pearson"])
+        if foci is not None:
+            save("05_foci", foci)
+    return pattern_detector(shadow, kernel_config, kernel_matrix, coords=coords, dump=None, full=full, tsvd=tsvd)

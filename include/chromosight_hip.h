@@ -1,0 +1,190 @@
+/*
+ * chromosight_hip.h -- C ABI of the MI355X (gfx950) implementation of chromosight's
+ * sliding-window Pearson-correlation hot path.
+ *
+ * The reference (koszullab/chromosight, pure Python) has no FFI for this path; the
+ * entry points below are what a binding for the bodies of the following reference
+ * functions would call (all paths relative to /root/reference/chromosight/utils/):
+ *
+ *   cs_xcorr2_*            detection.py:595  xcorr2  (-> :627 _xcorr2_sparse, :726 _xcorr2_dense)
+ *   cs_normxcorr2_*        detection.py:807  normxcorr2 (-> :917 _normxcorr2_sparse, :1134 _normxcorr2_dense)
+ *                          incl. the missing-pixel predicate of preprocessing.py:535 make_missing_mask
+ *                          and :404 frame_missing_mask, evaluated analytically on the device
+ *   cs_distance_law_csr    preprocessing.py:129 distance_law (per-diagonal sum / count reduction)
+ *   cs_csr_to_band         preprocessing.py:256 detrend (divide by the law, >= max_val -> 1) fused with
+ *                          preprocessing.py:93 diag_trim and the CSR -> dense diagonal-band tiler
+ *   cs_detrend_csr         preprocessing.py:256 detrend on the stored values of a CSR/COO matrix
+ *   cs_compact_*           the thresholding step of detection.py:387 pick_foci (score >= pearson)
+ *   cs_rescore_f64         detection.py:917 evaluated in float64 at a list of pixels
+ *                          (quantify mode, detection.py:277, and exact re-scoring of candidates)
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative
+ *     cs_status; cs_last_error(ctx) gives a message for the last failure on that context.
+ *   - pointers named d_* are DEVICE pointers (HBM); h_* are HOST pointers.  The caller owns
+ *     all buffers; the library retains no pointer after a call returns.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream unless documented otherwise; one in-flight call per
+ *     context (re-entrant across contexts).
+ *   - matrices: "dense" = row-major, leading dimension `ld` in elements;
+ *     "band" = diagonal-offset layout: element (i, j) of an n x n matrix is stored at
+ *     d_band[i * ld + (j - i - lo)] for lo <= j - i < lo + width.
+ *   - dtype codes: CS_F32 = 0, CS_F64 = 1.
+ */
+#ifndef CHROMOSIGHT_HIP_H
+#define CHROMOSIGHT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_ctx cs_ctx;
+
+typedef enum {
+    CS_OK = 0,
+    CS_ERR_INVALID = -1,   /* bad argument (the Python shim raises ValueError) */
+    CS_ERR_HIP = -2,       /* HIP runtime error */
+    CS_ERR_UNSUPPORTED = -3,
+    CS_ERR_OVERFLOW = -4   /* an output buffer was too small; see the call's doc */
+} cs_status;
+
+enum { CS_F32 = 0, CS_F64 = 1, CS_U8 = 2 /* masks only */ };
+enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1 };
+enum { CS_MASK_NONE = 0, CS_MASK_BINS = 1, CS_MASK_EXPLICIT = 2 };
+
+/* ---- context ----------------------------------------------------------------------- */
+int cs_ctx_create(int device, cs_ctx** out);
+void cs_ctx_destroy(cs_ctx* ctx);
+const char* cs_last_error(const cs_ctx* ctx);
+/* library / device facts: returns the device's compute-unit count, 0 if ctx is NULL */
+int cs_device_cu_count(const cs_ctx* ctx);
+const char* cs_version(void);
+
+/* ---- device memory helpers (so a ctypes caller needs nothing but this library) ------ */
+int cs_malloc(cs_ctx* ctx, size_t bytes, void** d_ptr);
+int cs_free(cs_ctx* ctx, void* d_ptr);
+int cs_memcpy_h2d(cs_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream);
+int cs_memcpy_d2h(cs_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream);
+int cs_memset(cs_ctx* ctx, void* d_dst, int value, size_t bytes, void* stream);
+int cs_stream_sync(cs_ctx* ctx, void* stream);
+/* streams and events (hipStream_t / hipEvent_t as void*), for callers without a HIP binding */
+int cs_stream_create(cs_ctx* ctx, void** stream);
+int cs_stream_destroy(cs_ctx* ctx, void* stream);
+int cs_event_create(cs_ctx* ctx, void** event);
+int cs_event_destroy(cs_ctx* ctx, void* event);
+int cs_event_record(cs_ctx* ctx, void* event, void* stream);
+/* synchronises on `stop`, then returns the elapsed milliseconds between the two events */
+int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms);
+
+/* ---- description of one matrix operand --------------------------------------------- */
+typedef struct {
+    void* d_ptr;       /* device pointer                                             */
+    int32_t dtype;     /* CS_F32 / CS_F64                                            */
+    int32_t layout;    /* CS_LAYOUT_DENSE / CS_LAYOUT_BAND                           */
+    int64_t ld;        /* leading dimension in elements                              */
+    int32_t band_lo;   /* band layout: first stored diagonal offset (j - i)          */
+    int32_t band_w;    /* band layout: number of stored diagonals                    */
+} cs_matrix;
+
+/* ---- pattern kernel (template) operand --------------------------------------------- */
+/* All arrays are HOST pointers to km*kn float64 values, row-major.
+ *   h_kernel      the template K; its statistics (sum, mean, std) are the ones used in the
+ *                 normalisation (detection.py:1002-1003, 1023-1026)
+ *   h_kernel_conv the kernel actually correlated with the signal and with the missing mask;
+ *                 NULL = h_kernel.  With --tsvd this is the truncated-SVD reconstruction
+ *                 U.V (detection.py:618-619, preprocessing.py:810-847)
+ *   h_kernel_sq   the kernel correlated with the mask for the sum-of-squares term; NULL =
+ *                 h_kernel squared.  With --tsvd: the reconstruction of K**2 (detection.py:1043)
+ */
+typedef struct {
+    int32_t km, kn;
+    const double* h_kernel;
+    const double* h_kernel_conv;
+    const double* h_kernel_sq;
+} cs_kernel;
+
+/* ---- normalised cross-correlation --------------------------------------------------- */
+typedef struct {
+    int32_t ms, ns;          /* signal shape                                            */
+    int32_t full;            /* 1 = 'full' mode: virtual zero frame of (km-1, kn-1)      */
+    int32_t sym_upper;       /* 1 = keep j >= i only (detection.py:1098-1099)            */
+    int32_t max_dist;        /* -1 = None                                               */
+    int32_t mask_mode;       /* CS_MASK_*                                               */
+    const uint8_t* d_miss_row; /* CS_MASK_BINS: ms bytes, 1 = bin not detectable         */
+    const uint8_t* d_miss_col; /* CS_MASK_BINS: ns bytes                                 */
+    const uint8_t* d_mask;   /* CS_MASK_EXPLICIT: missing mask, same layout/ld as signal */
+    int32_t min_present;     /* int((1 - missing_tol) * km * kn), detection.py:1069-1072 */
+    int32_t compute_dtype;   /* CS_F32 or CS_F64 arithmetic                             */
+    double xcorr_threshold;  /* 1e-4: xcorr2's zeroing threshold (detection.py:595,716)  */
+    double denom_eps;        /* 1e-10 (detection.py:1088)                                */
+} cs_normxcorr2_params;
+
+/* Coefficient map.  `signal`, `out_corr` (and `out_nobs` when d_ptr != NULL) share the
+ * logical shape ms x ns; layouts may differ (e.g. band in, band out with another range).
+ * out_nobs (CS_F32 only) receives the number of present pixels of each window.
+ * Pixels outside the stored band of `out_corr` are not written. */
+int cs_normxcorr2(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
+                  const cs_normxcorr2_params* params, const cs_matrix* out_corr,
+                  const cs_matrix* out_nobs);
+
+/* Plain cross-correlation: centre-aligned, zero on the (k-1)/2 margins, |v| < threshold -> 0
+ * (detection.py:716-722, 797-803).  `h_weights` = km*kn float64 host values. */
+int cs_xcorr2(cs_ctx* ctx, void* stream, const cs_matrix* signal, int32_t ms, int32_t ns,
+              const double* h_weights, int32_t km, int32_t kn, double threshold,
+              int32_t compute_dtype, const cs_matrix* out);
+
+/* Float64 evaluation of the coefficient at `n_px` pixels (d_rows/d_cols int32 device arrays).
+ * d_out_corr / d_out_nobs: n_px float64 each (d_out_nobs may be NULL). */
+int cs_rescore_f64(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
+                   const cs_normxcorr2_params* params, const int32_t* d_rows,
+                   const int32_t* d_cols, int64_t n_px, double* d_out_corr, double* d_out_nobs);
+
+/* ---- thresholded compaction of a coefficient map ------------------------------------ */
+/* Appends (row, col, value) of every stored pixel of `corr` (float32 or float64) with
+ * value >= threshold, and lo_diag <= col - row <= hi_diag, to the output arrays (capacity
+ * `cap`).  *d_count (device int64, caller-zeroed) receives the total number of matches; if it
+ * exceeds cap only the first cap are stored and the caller must retry with a larger buffer. */
+int cs_compact_ge(cs_ctx* ctx, void* stream, const cs_matrix* corr, int32_t ms, int32_t ns,
+                  double threshold, int32_t lo_diag, int32_t hi_diag, int32_t* d_rows,
+                  int32_t* d_cols, double* d_vals, int64_t cap, int64_t* d_count);
+
+/* ---- CSR side: distance law, detrend, band tiler ------------------------------------- */
+typedef struct {
+    int32_t n_rows, n_cols;
+    int64_t nnz;
+    const int64_t* d_indptr;  /* n_rows + 1 */
+    const int32_t* d_indices; /* nnz        */
+    const void* d_data;       /* nnz values of `dtype` */
+    int32_t dtype;
+} cs_csr;
+
+/* Per-diagonal sums and counts of the strictly positive stored values whose row and column
+ * bins are both detectable, for diagonals 0 <= d < n_diags (upper triangle, col >= row).
+ * d_sum / d_cnt: n_diags float64 / int64, overwritten.  The host finishes with
+ * law[d] = sum/cnt (NaN when cnt == 0), preprocessing.py:173-188.
+ * d_detectable: n_rows bytes (1 = detectable) or NULL (all). */
+int cs_distance_law_csr(cs_ctx* ctx, void* stream, const cs_csr* mat, const uint8_t* d_detectable,
+                        int32_t n_diags, double* d_sum, int64_t* d_cnt);
+
+/* In-place-capable detrend of the stored values: out[k] = data[k] / law[|row-col|] then
+ * (max_val > 0) values >= max_val -> 1 (preprocessing.py:298-309).  d_law: n_law float64
+ * (NaN already replaced by 0 by the caller); diagonals >= n_law use law = 0.  d_out has the
+ * CSR's dtype and nnz entries. */
+int cs_detrend_csr(cs_ctx* ctx, void* stream, const cs_csr* mat, const double* d_law,
+                   int32_t n_law, double max_val, void* d_out);
+
+/* CSR -> diagonal band (or dense, by `band->layout`).  Zero-fills the n_rows x ld output then
+ * scatters the stored pixels that fall inside it (band: band_lo <= col - row < band_lo + band_w).
+ * With d_law != NULL the detrend above is fused into the scatter; NaN results are stored as 0
+ * (contacts_map.py:539-540).  Output dtype CS_F32 / CS_F64, or CS_U8 to write a 0/1 mask of the
+ * non-zero stored values.  Duplicated entries are not supported (canonical CSR). */
+int cs_csr_to_band(cs_ctx* ctx, void* stream, const cs_csr* mat, const double* d_law,
+                   int32_t n_law, double max_val, const cs_matrix* band);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHROMOSIGHT_HIP_H */

@@ -1,0 +1,258 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors generated from
+the reference and against the numpy oracle on seeded inputs.  Tolerances: float32 compute
+1e-5 absolute on the coefficient (BASELINE.json north_star), float64 compute 1e-10."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import chromosight_amd
+from chromosight_amd.utils import detection as cud
+from chromosight_amd.utils import preprocessing as cup
+from oracle import pearson_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-5, "f64": 1e-10}
+
+
+@pytest.fixture(params=["f32", "f64"])
+def precision(request):
+    old = chromosight_amd.get_precision()
+    chromosight_amd.set_precision(request.param)
+    yield request.param
+    chromosight_amd.set_precision(old)
+
+
+def coo(g, prefix):
+    shape = tuple(g[f"{prefix}_shape"])
+    return sp.coo_matrix((g[f"{prefix}_val"], (g[f"{prefix}_row"], g[f"{prefix}_col"])), shape=shape)
+
+
+def well_conditioned(signal, kernel_shape, full):
+    """Mask of output pixels whose window variance is not degenerate (the reference itself is
+    only reproducible to ~1e-7 on constant windows, see tests/test_oracle_golden.py)."""
+    s = np.asarray(signal, dtype=np.float64)
+    km, kn = kernel_shape
+    if full:
+        f = np.zeros((s.shape[0] + 2 * (km - 1), s.shape[1] + 2 * (kn - 1)))
+        f[km - 1:km - 1 + s.shape[0], kn - 1:kn - 1 + s.shape[1]] = s
+    else:
+        f = s
+    ones = np.ones((km, kn)) / (km * kn)
+    m1 = orc.window_sums(f, ones)
+    m2 = orc.window_sums(f ** 2, ones)
+    ok = (m2 - m1 ** 2) > 1e-6 * np.maximum(m2, 1e-30)
+    out = np.ones(f.shape, dtype=bool)
+    kh, kw = (km - 1) // 2, (kn - 1) // 2
+    out[kh:kh + ok.shape[0], kw:kw + ok.shape[1]] = ok
+    if full:
+        out = out[km - 1:km - 1 + s.shape[0], kn - 1:kn - 1 + s.shape[1]]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+def test_xcorr2_golden(golden, precision):
+    g = golden("xcorr2")
+    tol = 2e-6 if precision == "f32" else 1e-12
+    for c in range(3):
+        sig = g[f"sig{c}"]
+        d = cud.xcorr2(sig, g["gauss_kernel"], threshold=1e-4)
+        s = cud.xcorr2(sp.csr_matrix(sig), g["gauss_kernel"], threshold=1e-4)
+        assert isinstance(d, np.ndarray) and sp.issparse(s)
+        # values right at the 1e-4 zeroing threshold may flip in float32
+        ref = g[f"dense{c}"]
+        near = np.abs(np.abs(orc.xcorr2_oracle(sig, g["gauss_kernel"], threshold=0)) - 1e-4) < 1e-6
+        assert np.abs(d - ref)[~near].max() < tol
+        assert np.abs(s.toarray() - g[f"sparse{c}"])[~near].max() < tol
+        k1 = np.ones((11, 11)) / 121
+        cst = cud.xcorr2(sp.csr_matrix(sig), k1)
+        near = np.abs(np.abs(orc.xcorr2_oracle(sig, k1, threshold=0)) - 1e-4) < 1e-6
+        assert np.abs(cst.toarray() - g[f"const{c}"])[~near].max() < tol
+    r = cud.xcorr2(g["rand"], g["rect_kernel_5x9"])
+    assert np.abs(r - g["rand_rect_5x9"]).max() < (2e-5 if precision == "f32" else 1e-11)
+    t = cud.xcorr2(sp.csr_matrix(g["rand"]), chromosight_amd.kernels.loops["kernels"][0], tsvd=0.999)
+    assert np.abs(t.toarray() - g["rand_loops_tsvd999"]).max() < (2e-4 if precision == "f32" else 1e-10)
+
+
+def test_normxcorr2_dense_golden(golden, templates, precision):
+    g = golden("normxcorr2_dense")
+    tol = TOL[precision]
+    for name in "ab":
+        sig = g[f"sig_{name}"]
+        for kname in ("loops", "small", "hairpin"):
+            k = templates[kname]
+            for full in (False, True):
+                tag = f"{name}_{kname}_{'full' if full else 'valid'}"
+                ok = well_conditioned(sig, k.shape, full)
+                cd, pd_ = cud.normxcorr2(sig, k, full=full, pval=not full)
+                cs_, ps = cud.normxcorr2(sp.csr_matrix(sig), k, full=full, pval=True)
+                assert isinstance(cd, np.ndarray) and sp.issparse(cs_)
+                assert np.abs(cd - g[f"dense_{tag}_corr"])[ok].max() < tol, tag
+                assert np.abs(cs_.toarray() - g[f"sparse_{tag}_corr"])[ok].max() < tol, tag
+                assert np.abs(cd).max() <= 1.0
+                ref_p = g[f"sparse_{tag}_pval"]
+                err = np.abs(ps.toarray() - ref_p)[ok]
+                # log10 p amplifies coefficient errors by up to ~ n / ln(10)
+                assert err.max() < (5e-3 if precision == "f32" else 1e-7), tag
+        sq = sig[:80, :80]
+        ok = well_conditioned(np.triu(sq), (17, 17), True)
+        c, p = cud.normxcorr2(sp.csr_matrix(np.triu(sq)), templates["loops"], sym_upper=True, full=True, pval=True)
+        assert np.abs(c.toarray() - g[f"sparse_{name}_loops_symfull_corr"])[ok].max() < tol
+        assert np.all(np.tril(c.toarray(), -1) == 0)
+        ok = well_conditioned(np.triu(sq), (17, 17), False)
+        c, _ = cud.normxcorr2(np.triu(sq), templates["loops"], sym_upper=True, full=False)
+        assert np.abs(c - g[f"dense_{name}_loops_symvalid_corr"])[ok].max() < tol
+    c, _ = cud.normxcorr2(sp.csr_matrix(g["sig_a"]), templates["loops"], full=True, tsvd=0.999)
+    assert np.abs(c.toarray() - g["sparse_a_loops_full_tsvd999_corr"]).max() < tol
+
+
+def test_normxcorr2_mask_golden(golden, templates, precision):
+    g = golden("normxcorr2_mask")
+    tol = TOL[precision]
+    for i in range(int(g["n_intra"])):
+        sig, k, valid = g[f"intra{i}_sig"], g[f"intra{i}_kernel"], g[f"intra{i}_valid"]
+        md, mtol = int(g[f"intra{i}_max_dist"]), float(g[f"intra{i}_tol"])
+        n = sig.shape[0]
+        mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+        c, p = cud.normxcorr2(sp.csr_matrix(sig), k, max_dist=md, sym_upper=True, full=True,
+                              missing_mask=mask, missing_tol=mtol, pval=True)
+        err = np.abs(c.toarray() - g[f"intra{i}_corr"])
+        assert err.max() < tol, (i, err.max())
+        perr = np.abs(p.toarray() - g[f"intra{i}_pval"])
+        assert perr.max() < (5e-3 if precision == "f32" else 1e-7), (i, perr.max())
+    n = g["nomd_sig"].shape[0]
+    mask = cup.make_missing_mask((n, n), g["nomd_valid"], g["nomd_valid"], max_dist=None, sym_upper=True)
+    c, _ = cud.normxcorr2(sp.csr_matrix(g["nomd_sig"]), templates["small"], max_dist=None, sym_upper=True,
+                          full=True, missing_mask=mask, missing_tol=0.75)
+    assert np.abs(c.toarray() - g["nomd_corr"]).max() < tol
+    shape = g["inter_sig"].shape
+    mask = cup.make_missing_mask(shape, g["inter_valid_rows"], g["inter_valid_cols"], max_dist=None, sym_upper=False)
+    for kn in ("loops", "b11"):
+        c, p = cud.normxcorr2(sp.csr_matrix(g["inter_sig"]), g[f"inter_{kn}_kernel"], max_dist=None,
+                              sym_upper=False, full=True, missing_mask=mask, missing_tol=0.75, pval=True)
+        assert np.abs(c.toarray() - g[f"inter_{kn}_corr"]).max() < tol, kn
+    c, _ = cud.normxcorr2(sp.csr_matrix(g["valid_sig"]), templates["small"], max_dist=20, sym_upper=True,
+                          full=False, missing_mask=sp.csr_matrix(g["valid_mask"]), missing_tol=0.75)
+    assert np.abs(c.toarray() - g["valid_corr"]).max() < tol
+
+
+def test_distance_law_detrend_golden(golden):
+    g = golden("example_blocks")
+    for ci in range(3):
+        block = coo(g, f"chr{ci}_balanced")
+        det = g[f"chr{ci}_det"]
+        for pname in ("loops", "borders", "hairpins"):
+            keep = int(g[f"chr{ci}_{pname}_keep"])
+            law = cup.distance_law(block.tocsr(), detectable_bins=det, max_dist=keep, smooth=False)
+            ref = g[f"chr{ci}_{pname}_law"]
+            assert np.array_equal(np.isnan(law), np.isnan(ref))
+            assert np.nanmax(np.abs(law - ref) / np.maximum(np.abs(ref), 1e-300)) < 1e-12
+            m = cup.detrend(block, max_dist=keep, smooth=False, detectable_bins=det, max_val=10)
+            m = cup.diag_trim(m.tocsr(), keep)
+            m.data[np.isnan(m.data)] = 0
+            m.eliminate_zeros()
+            ref_m = coo(g, f"chr{ci}_{pname}_prepared").toarray()
+            assert np.abs(m.toarray() - ref_m).max() < 1e-11
+
+
+def test_reference_distance_law_example():
+    """Known answer of the reference's own test (tests/test_preprocessing.py:202-213)."""
+    m = np.ones((3, 3)) + np.array([1, 2, 3])
+    assert np.all(cup.distance_law(sp.csr_matrix(m), smooth=False) == np.array([3.0, 3.5, 4.0]))
+    assert np.all(cup.distance_law(sp.csr_matrix(m), smooth=True) == np.array([3.5, 3.5, 3.5]))
+
+
+def test_example_blocks_maps_and_tables(golden, templates, precision):
+    g = golden("example_blocks")
+    tol = TOL[precision]
+    pats = {
+        "loops": (dict(pearson=0.3, max_perc_undetected=50.0, max_perc_zero=10.0, max_dist=2000000), [templates["loops"]]),
+        "borders": (dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0), templates["borders"]),
+        "hairpins": (dict(pearson=0.1, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0), [templates["hairpin"]]),
+    }
+
+    class Map:
+        pass
+
+    for ci in range(3):
+        det = g[f"chr{ci}_det"]
+        for pname, (cfg, kernels) in pats.items():
+            m = coo(g, f"chr{ci}_{pname}_prepared").tocsr()
+            max_dist = int(g[f"chr{ci}_{pname}_max_dist"])
+            for ki, kern in enumerate(kernels):
+                tag = f"chr{ci}_{pname}{ki}"
+                mask = cup.make_missing_mask(m.shape, det, det, max_dist=max_dist, sym_upper=True)
+                c, p = cud.normxcorr2(m, kern, max_dist=max_dist, sym_upper=True, full=True,
+                                      missing_mask=mask, pval=True,
+                                      missing_tol=cfg["max_perc_undetected"] / 100)
+                ref = coo(g, f"{tag}_corr").toarray()
+                assert np.abs(c.toarray() - ref).max() < tol, tag
+                cmap = Map()
+                cmap.matrix, cmap.detectable_bins = m.copy(), (det.copy(), det.copy())
+                cmap.max_dist, cmap.inter = max_dist, False
+                tab, wins = cud.pattern_detector(cmap, cfg, kern, full=True)
+                ref_tab = g[f"{tag}_table"]
+                if ref_tab.shape[0] == 0:
+                    assert tab is None or len(tab) == 0
+                    continue
+                got = tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+                # bit-exact coordinates, in the reference's order
+                assert np.array_equal(got[:, :2], ref_tab[:, :2]), tag
+                assert np.abs(got[:, 2] - ref_tab[:, 2]).max() < 1e-9, tag
+                assert np.allclose(got[:, 3], ref_tab[:, 3], rtol=1e-6, atol=1e-300), tag
+                assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12), tag
+
+
+def test_quantify_and_inter(golden, templates):
+    g = golden("example_blocks")
+
+    class Map:
+        pass
+
+    cfg = dict(pearson=0.3, max_perc_undetected=50.0, max_perc_zero=10.0, max_dist=2000000)
+    cmap = Map()
+    cmap.matrix = coo(g, "quant_prepared").tocsr()
+    det = g["quant_det"]
+    cmap.detectable_bins, cmap.max_dist, cmap.inter = (det.copy(), det.copy()), int(g["quant_max_dist"]), False
+    coords = g["quant_coords"].copy()
+    tab, wins = cud.pattern_detector(cmap, cfg, templates["loops"], coords=coords, full=True)
+    got = tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+    ref = g["quant_table"]
+    assert np.array_equal(got[:, :2], ref[:, :2])
+    assert np.allclose(got[:, 2], ref[:, 2], equal_nan=True, rtol=0, atol=1e-9)
+    assert np.allclose(got[:, 3], ref[:, 3], equal_nan=True, rtol=1e-6, atol=1e-300)
+    assert np.allclose(wins, g["quant_windows"], equal_nan=True, rtol=0, atol=1e-12)
+    # the reference shifts the caller's coords in place (detection.py:297-298)
+    assert np.array_equal(coords, g["quant_coords"] + 8)
+    cmap = Map()
+    cmap.matrix = coo(g, "inter_prepared").tocsr()
+    cmap.detectable_bins = (g["inter_det_rows"].copy(), g["inter_det_cols"].copy())
+    cmap.max_dist, cmap.inter = None, True
+    tab, wins = cud.pattern_detector(cmap, cfg, templates["loops"], coords=g["inter_coords"].copy(), full=True)
+    got = tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+    ref = g["inter_table"]
+    assert np.array_equal(got[:, :2], ref[:, :2])
+    assert np.allclose(got[:, 2], ref[:, 2], equal_nan=True, rtol=0, atol=1e-9)
+    assert np.allclose(got[:, 3], ref[:, 3], equal_nan=True, rtol=1e-6, atol=1e-300)
+    assert np.allclose(wins, g["inter_windows"], equal_nan=True, rtol=0, atol=1e-12)
+
+
+def test_errors():
+    k = chromosight_amd.kernels.loops["kernels"][0]
+    sig = sp.csr_matrix(np.random.default_rng(0).random((40, 40)))
+    with pytest.raises(ValueError):
+        cud.normxcorr2(sig, np.ones((5, 5)))                       # flat kernel
+    with pytest.raises(ValueError):
+        cud.normxcorr2(sig, sp.csr_matrix(k))                      # sparse kernel
+    with pytest.raises(ValueError):
+        cud.normxcorr2(sig, k, missing_mask=np.zeros((40, 40), bool))   # dense mask
+    with pytest.raises(ValueError):
+        cud.normxcorr2(sig, k, missing_mask=sp.csr_matrix((30, 30), dtype=bool))
+    with pytest.raises(ValueError):
+        cud.normxcorr2(sig, k, missing_mask=sp.csr_matrix((40, 40), dtype=int))
+    bad = sp.csr_matrix(np.ones((40, 40), dtype=bool))
+    with pytest.raises(ValueError):
+        cud.normxcorr2(sig, k, missing_mask=bad)                   # signal under the mask
+    small = sp.csr_matrix(np.random.default_rng(0).random((10, 10)))
+    with pytest.raises(ValueError):
+        cud.normxcorr2(small, k, missing_mask=sp.csr_matrix((10, 10), dtype=bool))

@@ -10,6 +10,7 @@ reference's own Python call surface:
 All arithmetic of the path runs in hand-written HIP kernels (chromosight_amd/csrc) reached
 through the C ABI of include/chromosight_hip.h; there is no CPU fallback.
 """
+from . import kernels  # noqa: F401
 from .engine import get_precision, set_precision  # noqa: F401
 
 __version__ = "0.1.0"

@@ -255,9 +255,15 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
         const double kc = kconv[t];
         const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
         w[t] = kc - st.kmean;
-        w[kk + t] = kc - st.kmean;
-        // chosen so that kb + 2*kmean*ka + kmean^2*nm == sum over missing pixels of k2
-        w[2 * kk + t] = k2 - 2.0 * st.kmean * kc + st.kmean * st.kmean;
+        if (sizeof(TC) == 8) {
+            // float64 kernels use the reference's literal (un-centred) mask sums
+            w[kk + t] = kc;
+            w[2 * kk + t] = k2;
+        } else {
+            w[kk + t] = kc - st.kmean;
+            // chosen so that kb + 2*kmean*ka + kmean^2*nm == sum over missing pixels of k2
+            w[2 * kk + t] = k2 - 2.0 * st.kmean * kc + st.kmean * st.kmean;
+        }
     }
     rc = upload_weights<TC>(ctx, stream, w);
     if (rc) return rc;

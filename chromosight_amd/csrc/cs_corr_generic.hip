@@ -52,14 +52,19 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(const CorrArgs<TC> A)
 
     const int kk = km * kn;
     for (int ki = 0; ki < km; ++ki) {
+        // two-level summation (per template row, then across rows) keeps the float32 rounding
+        // of the box sums at ~sqrt(kn) + sqrt(km) ulps instead of sqrt(km * kn)
+        TC rc[GEN_RG], r1[GEN_RG], r2[GEN_RG];
+#pragma unroll
+        for (int i = 0; i < GEN_RG; ++i) rc[i] = r1[i] = r2[i] = TC(0);
         for (int kj = 0; kj < kn; ++kj) {
             const TC wc = A.w[ki * kn + kj];
 #pragma unroll
             for (int i = 0; i < GEN_RG; ++i) {
                 const TC v = sS[(tr0 + i + ki) * LWP + lane + kj];
-                cs_[i] = cs_fma(v, wc, cs_[i]);
-                s1[i] += v;
-                s2[i] = cs_fma(v, v, s2[i]);
+                rc[i] = cs_fma(v, wc, rc[i]);
+                r1[i] += v;
+                r2[i] = cs_fma(v, v, r2[i]);
             }
             if (masked) {
                 const TC wa = A.w[kk + ki * kn + kj];
@@ -72,6 +77,12 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(const CorrArgs<TC> A)
                     kb[i] = cs_fma(m, wb, kb[i]);
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < GEN_RG; ++i) {
+            cs_[i] += rc[i];
+            s1[i] += r1[i];
+            s2[i] += r2[i];
         }
     }
 

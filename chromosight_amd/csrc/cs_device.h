@@ -43,8 +43,8 @@ struct KernelStats {
 
 // Arguments of the tile kernels.  Weights live in a small device buffer:
 //   w[0 .. kk)      conv weights minus kmean            (sum S * (K' - kmean))
-//   w[kk .. 2kk)    mask weights minus kmean            (sum M * (K' - kmean))
-//   w[2kk .. 3kk)   mask weights for the square term    (sum M * Wb), see cs_api.cpp
+//   w[kk .. 2kk)    mask weights Wa   (float64: K'; float32: K' - kmean)
+//   w[2kk .. 3kk)   mask weights Wb   (float64: K'^2; float32: the centred form), see cs_api.cpp
 template <typename TC>
 struct CorrArgs {
     MatView sig;
@@ -145,7 +145,8 @@ __device__ __forceinline__ double cs_fma(double a, double b, double c) { return 
 // (reference detection.py:1000-1107).  Inputs:
 //   cs  = sum S * (K' - kmean)      s1 = sum S        s2 = sum S^2
 //   nm  = number of missing pixels in the window (0 when no mask)
-//   ka  = sum_missing (K' - kmean)  kb = sum_missing Wb   (see CorrArgs::w)
+//   ka, kb = mask-weighted template sums; their definition depends on the precision, see the
+//            masked branch below and build_args() in cs_api.cpp
 // `mask_branch` selects the reference's missing-mask code path (different but equivalent
 // ordering of the denominator); n_obs receives the number of present pixels.
 // ---------------------------------------------------------------------------------------
@@ -173,26 +174,48 @@ __device__ __forceinline__ TC pearson_from_sums(TC cs, TC s1, TC s2, TC nm, TC k
         const TC np = K.n - nm;
         *n_obs = np;
         const TC inv_np = TC(1) / np;
-        const TC km_ = cs_fma(K.kmean, nm, ka);                                   // sum_missing K'
-        const TC k2m = kb + TC(2) * K.kmean * ka + K.kmean * K.kmean * nm;        // sum_missing K'^2
-        const bool zk = cs_abs(km_) < K.thr;
-        const bool zk2 = cs_abs(k2m) < K.thr;
-        TC kmw, kvw;
-        if (!zk && !zk2) {
-            const TC a = ka * inv_np;
-            kmw = K.kmean - a;
-            kvw = (K.n * K.kvar - kb) * inv_np - a * a;
-        } else {
-            kmw = (K.ksum - (zk ? TC(0) : km_)) * inv_np;
-            const TC k2mw = (K.k2sum - (zk2 ? TC(0) : k2m)) * inv_np;
+        TC kmw, kvw, dk;  // dk = kmean - kmw, kept separately to avoid re-rounding
+        bool zk;
+        if constexpr (sizeof(TC) == 8) {
+            // float64: the reference's own order of operations, so that windows whose present
+            // template pixels are all equal (piecewise-constant templates such as borders) give
+            // an exactly zero variance, as they do in the reference.  ka = sum_missing K',
+            // kb = sum_missing K'^2 (un-centred mask weights).
+            zk = cs_abs(ka) < K.thr;
+            const bool zk2 = cs_abs(kb) < K.thr;
+            // true divisions: (np * v) / np == v exactly, (np * v) * (1 / np) need not be
+            kmw = (K.ksum - (zk ? TC(0) : ka)) / np;
+            const TC k2mw = (K.k2sum - (zk2 ? TC(0) : kb)) / np;
             kvw = k2mw - kmw * kmw;
+            dk = K.kmean - kmw;
+        } else {
+            // float32: centred mask sums (ka = sum_missing (K' - kmean), kb chosen so that
+            // kb + 2 kmean ka + kmean^2 nm = sum_missing K'^2) avoid the cancellation of the
+            // literal form; a variance below 1e-5 of the template's is rounding noise of an
+            // exactly degenerate window and is snapped to the reference's exact zero.
+            const TC km_ = cs_fma(K.kmean, nm, ka);
+            const TC k2m = kb + TC(2) * K.kmean * ka + K.kmean * K.kmean * nm;
+            zk = cs_abs(km_) < K.thr;
+            const bool zk2 = cs_abs(k2m) < K.thr;
+            if (!zk && !zk2) {
+                const TC a = ka * inv_np;
+                kmw = K.kmean - a;
+                dk = a;
+                kvw = (K.n * K.kvar - kb) * inv_np - a * a;
+                if (kvw < TC(1e-5) * K.kvar) kvw = TC(0);
+            } else {
+                kmw = (K.ksum - (zk ? TC(0) : km_)) * inv_np;
+                const TC k2mw = (K.k2sum - (zk2 ? TC(0) : k2m)) * inv_np;
+                kvw = k2mw - kmw * kmw;
+                dk = K.kmean - kmw;
+            }
         }
         const TC m1w = m1z * K.n * inv_np;
         const TC m2w = m2z * K.n * inv_np;
         den = cs_sqrt((m2w - m1w * m1w) * kvw);
         if (np < K.cut) den = TC(0);
         if (!z1 && !zc && !zk)
-            num = cs_fma(s1 * ka, inv_np, cs) * inv_np;
+            num = cs_fma(s1, dk, cs) * inv_np;
         else
             num = (cz - m1z * kmw) * K.n * inv_np;
     }

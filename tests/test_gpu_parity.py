@@ -68,10 +68,11 @@ def test_xcorr2_golden(golden, precision):
         cst = cud.xcorr2(sp.csr_matrix(sig), k1)
         near = np.abs(np.abs(orc.xcorr2_oracle(sig, k1, threshold=0)) - 1e-4) < 1e-6
         assert np.abs(cst.toarray() - g[f"const{c}"])[~near].max() < tol
+    rtol = 2e-6 if precision == "f32" else 1e-13
     r = cud.xcorr2(g["rand"], g["rect_kernel_5x9"])
-    assert np.abs(r - g["rand_rect_5x9"]).max() < (2e-5 if precision == "f32" else 1e-11)
+    assert np.abs(r - g["rand_rect_5x9"]).max() < rtol * np.abs(g["rand_rect_5x9"]).max()
     t = cud.xcorr2(sp.csr_matrix(g["rand"]), chromosight_amd.kernels.loops["kernels"][0], tsvd=0.999)
-    assert np.abs(t.toarray() - g["rand_loops_tsvd999"]).max() < (2e-4 if precision == "f32" else 1e-10)
+    assert np.abs(t.toarray() - g["rand_loops_tsvd999"]).max() < rtol * np.abs(g["rand_loops_tsvd999"]).max()
 
 
 def test_normxcorr2_dense_golden(golden, templates, precision):

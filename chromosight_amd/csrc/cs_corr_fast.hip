@@ -1,14 +1,13 @@
-// cs_corr_fast.hip -- explicit instantiations of the LDS-tiled Pearson kernel for one
-// compile-time template size.  Compiled once per size with -DCS_K=<odd K> so the sizes
-// build in parallel (each fully unrolled kernel takes tens of seconds to compile).
-#include "cs_corr_tile.h"
+// cs_corr_fast.hip -- explicit instantiations of the streaming Pearson kernel
+// (cs_corr_stream.h) for one compile-time template size.  Compiled once per size with
+// -DCS_K=<odd K> so that the sizes build in parallel.
+#include <cstdlib>
+
+#include "cs_corr_stream.h"
 #include "cs_launch.h"
 
 #ifndef CS_K
 #error "compile with -DCS_K=<odd kernel size>"
-#endif
-#ifndef CS_RH
-#define CS_RH 8
 #endif
 
 namespace cs {
@@ -16,20 +15,17 @@ namespace cs {
 template <typename TC>
 static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
 {
-    using G = TileGeom<CS_K, CS_RH>;
-    constexpr size_t smem = corr_tile_smem_bytes<CS_K, CS_RH, TC>();
-    dim3 grid(A.tiles_x, A.tiles_y), block(G::NTHREADS);
-    if (A.mask_mode != 0) {
-        auto kern = corr_tile_kernel<TC, CS_K, CS_RH, true>;
-        if (smem > 48 * 1024)
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, A);
-    } else {
-        auto kern = corr_tile_kernel<TC, CS_K, CS_RH, false>;
-        if (smem > 48 * 1024)
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, A);
+    using G = StreamGeom<CS_K>;
+    constexpr size_t smem = corr_stream_smem_bytes<CS_K, TC>();
+    const int n_waves = A.tiles_x * A.tiles_y;
+    const int blocks = (n_waves + G::NWAVES - 1) / G::NWAVES;
+    auto kern = corr_stream_kernel<TC, CS_K>;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
     }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem, stream, A, A.tile_h, A.tiles_x,
+                       A.tiles_y);
     return (int)hipGetLastError();
 }
 
@@ -38,10 +34,24 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
 
 int CS_CAT(launch_corr_fast_f32_k, CS_K)(const CorrArgs<float>& A, hipStream_t s) { return launch_fast<float>(A, s); }
 int CS_CAT(launch_corr_fast_f64_k, CS_K)(const CorrArgs<double>& A, hipStream_t s) { return launch_fast<double>(A, s); }
-void CS_CAT(corr_fast_tile_k, CS_K)(int* tw, int* th)
+
+// strip geometry: 128 columns per wave; the strip height trades the K-1 warm-up rows of every
+// strip against having enough waves to fill 256 CUs x 4 SIMDs a few times over
+void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int n_cu, int* tw, int* th)
 {
-    *tw = TileGeom<CS_K, CS_RH>::TW;
-    *th = TileGeom<CS_K, CS_RH>::TH;
+    *tw = StreamGeom<CS_K>::TW;
+    int h = 256;
+    const long long want = (long long)n_cu * 4 * 3;  // ~3 waves per SIMD
+    while (h > 32) {
+        const long long waves = (long long)((ns + *tw - 1) / *tw) * ((ms + h - 1) / h);
+        if (waves >= want) break;
+        h >>= 1;
+    }
+    if (const char* e = getenv("CHROMOSIGHT_HIP_STRIP_H")) {
+        const int v = atoi(e);
+        if (v >= 1) h = v;
+    }
+    *th = h;
 }
 
 }  // namespace cs

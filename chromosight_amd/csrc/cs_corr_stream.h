@@ -1,0 +1,274 @@
+// cs_corr_stream.h -- the hot kernel: streaming sliding-window Pearson correlation for a
+// K x K template (K odd, compile-time), no missing mask.
+//
+// Replaces the reference's three sparse/dense cross-correlations of the unmasked branch
+// (detection.py:1000-1018, 1213-1220: signal*1, signal^2*1, signal*K) by one pass.
+//
+// Design (gfx950, wave64):
+//   * One WAVE owns a strip of 128 output columns (2 adjacent columns per lane) and walks down
+//     STRIP_H output rows.  No block-level barrier: each wave has a private LDS ring of the last
+//     RING staged rows.  Lane l reads its K+1 consecutive values of a row with aligned
+//     ds_read_b64 (conflict free).
+//   * K rotating accumulators per column: after staged row t, acc[s] holds the partial sum of
+//     output row t - s over template rows 0..s.  Row t+1 turns slot s into slot s+1
+//     (acc[s+1] = acc[s] + row * W[s+1], written in place by the first FMA, no moves), slot K-1
+//     completes an output row.  Every staged value is therefore loaded once and used K times
+//     per column from registers.
+//   * Template weights are wave-uniform: one s_load of a template row (K scalars) feeds K packed
+//     FMAs.  The float32 math is v_pk_fma_f32 on the lane's (column, column+1) accumulator pair
+//     with an SGPR weight: measured on MI355X (tools/ubench/fma_rate.hip) v_pk_fma_f32 with a
+//     scalar operand sustains 137 TFLOP/s, v_fma_f32 with a scalar operand only 73, v_fma_f32 on
+//     three VGPRs 117.  The row is therefore held twice in registers, as even-aligned pairs
+//     (v[2m], v[2m+1]) and odd-aligned pairs (v[2m+1], v[2m+2]), so that no operand needs a move.
+//     289 weights never fit the 102 SGPRs; they are re-streamed from the scalar cache once per
+//     staged row.
+//   * Box sums (sum S, sum S^2 over the window) are separable: horizontal K-sums of the new row
+//     are added to, and those of the row leaving the window subtracted from, float64 running
+//     sums (exact sliding; the float32 horizontal partials are recomputed bit-identically).
+//
+// Work per output pixel at K = 17: 289 FMA + ~40 VALU (box sums, epilogue) => FP32-FMA bound
+// (SURVEY.md 8(d)); HBM traffic ~ (1 + 16/128)(1 + 16/STRIP_H) * 4 B in + 4 B out per pixel.
+#pragma once
+#include "cs_device.h"
+
+namespace cs {
+
+template <int K>
+struct StreamGeom {
+    static constexpr int RW = 2;                    // output columns per lane
+    static constexpr int TW = kWave * RW;           // 128 output columns per wave
+    static constexpr int LW = TW + K - 1;           // staged columns per row
+    static constexpr int LWP = ((LW + 3) / 4) * 4;  // row pitch in elements (16-byte multiple)
+    static constexpr int RING = K + 3;              // rows t-K .. t+1 live, +1 slack
+    static constexpr int NWAVES = 4;                // independent waves per workgroup
+};
+
+// weights are read through the constant address space so that the (wave-uniform) loads are
+// selected as scalar s_load even though the kernel also stores to global memory
+template <typename TC>
+using ConstPtr = const __attribute__((address_space(4))) TC*;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Staged row of one lane: K+1 consecutive values v[0..K] starting at its first output column.
+template <typename TC, int K>
+struct RowRegs {
+    TC v[K + 1];
+    __device__ __forceinline__ void load(const TC* __restrict__ p)
+    {
+#pragma unroll
+        for (int t = 0; t < K + 1; ++t) v[t] = p[t];
+    }
+    // acc_out[c] = acc_in[c] + sum_kj v[kj + c] * w[kj]
+    __device__ __forceinline__ void slot(ConstPtr<TC> w, const TC (&in)[2], TC (&out)[2]) const
+    {
+        TC a0 = cs_fma(v[0], w[0], in[0]);
+        TC a1 = cs_fma(v[1], w[0], in[1]);
+#pragma unroll
+        for (int kj = 1; kj < K; ++kj) {
+            a0 = cs_fma(v[kj], w[kj], a0);
+            a1 = cs_fma(v[kj + 1], w[kj], a1);
+        }
+        out[0] = a0;
+        out[1] = a1;
+    }
+    __device__ __forceinline__ TC at(int t) const { return v[t]; }
+};
+
+// float32: the row is kept as even pairs (v[2m], v[2m+1]) and odd pairs (v[2m+1], v[2m+2]) so
+// that every packed FMA reads an aligned VGPR pair
+template <int K>
+struct RowRegs<float, K> {
+    static constexpr int NE = (K + 2) / 2;   // even pairs cover v[0 .. K]
+    static constexpr int NO = K / 2;         // odd pairs cover v[1 .. K-1]
+    f32x2 e[NE];
+    f32x2 o[NO];
+    __device__ __forceinline__ void load(const float* __restrict__ p)
+    {
+#pragma unroll
+        for (int m = 0; m < NE; ++m) e[m] = *reinterpret_cast<const f32x2*>(p + 2 * m);
+#pragma unroll
+        for (int m = 0; m < NO; ++m) {
+            o[m].x = p[2 * m + 1];
+            o[m].y = p[2 * m + 2];
+        }
+    }
+    __device__ __forceinline__ void slot(ConstPtr<float> w, const float (&in)[2], float (&out)[2]) const
+    {
+        // two independent dependency chains (even / odd template columns), summed at the end
+        f32x2 a = {in[0], in[1]};
+        f32x2 b = {0.0f, 0.0f};
+#pragma unroll
+        for (int kj = 0; kj < K; ++kj) {
+            const float wk = w[kj];
+            const f32x2 wv = {wk, wk};
+            if (kj & 1) b = __builtin_elementwise_fma(o[kj >> 1], wv, b);
+            else a = __builtin_elementwise_fma(e[kj >> 1], wv, a);
+        }
+        a += b;
+        out[0] = a.x;
+        out[1] = a.y;
+    }
+    __device__ __forceinline__ float at(int t) const { return (t & 1) ? e[t >> 1].y : e[t >> 1].x; }
+};
+
+// horizontal K-sums of one staged row for this lane's two columns
+template <typename TC, int K>
+__device__ __forceinline__ void row_box(const RowRegs<TC, K>& r, TC (&h1)[2], TC (&h2)[2])
+{
+    h1[0] = r.at(0);
+    h2[0] = r.at(0) * r.at(0);
+#pragma unroll
+    for (int t = 1; t < K; ++t) {
+        h1[0] += r.at(t);
+        h2[0] = cs_fma(r.at(t), r.at(t), h2[0]);
+    }
+    h1[1] = (h1[0] - r.at(0)) + r.at(K);
+    h2[1] = cs_fma(r.at(K), r.at(K), cs_fma(-r.at(0), r.at(0), h2[0]));
+}
+
+template <typename TC, int K>
+__global__ __launch_bounds__(256) void corr_stream_kernel(const CorrArgs<TC> A, int strip_h,
+                                                          int strips_x, int strips_y)
+{
+    using G = StreamGeom<K>;
+    constexpr int KH = (K - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    TC* ring = reinterpret_cast<TC*>(smem_raw) + (size_t)wv * G::RING * G::LWP;
+
+    // strip of this wave (uniform per wave); x fastest so that neighbouring waves share halos
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * G::NWAVES + wv);
+    if (wid >= strips_x * strips_y) return;
+    const int sy = wid / strips_x;
+    const int sx = wid - sy * strips_x;
+    const int i0 = sy * strip_h;                          // first output row
+    int j0 = sx * G::TW;                                  // first output column
+    if (A.out.layout == 1) {
+        int jmin = i0 + A.out_lo;
+        if (jmin < 0) jmin = 0;
+        j0 += (jmin / G::TW) * G::TW;
+        const int dmax = (j0 + G::TW - 1) - i0;
+        const int dmin = j0 - (i0 + strip_h - 1);
+        if (j0 >= A.ns || dmax < A.out_lo || dmin > A.out_hi) return;
+    }
+    const int rows_out = min(strip_h, A.ms - i0);
+    const int n_staged = rows_out + K - 1;
+
+    // ---- staging of one input row into the ring (lanes 0..LWP/4-1 move 4 elements each) -----
+    // element (p, q) lives at p * ld + (q - shift(p)); dense: shift = 0, band: shift = p + band_lo
+    const int q_lane = j0 - KH + lane * 4;
+    const bool band_in = A.sig.layout == 1;
+    const long long ld_in = A.sig.ld;
+    const int bw_in = band_in ? A.sig.band_w : 0x7fffffff;
+    const int lo_in = A.sig.band_lo;
+    const bool f64_in = A.sig_is_f64 != 0;
+    bool col_ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) col_ok[e] = (lane * 4 + e < G::LW) & (q_lane + e >= 0) & (q_lane + e < A.ns);
+    auto fetch = [&](int t, TC (&x)[4]) {
+        const int p = i0 - KH + t;
+        const bool row_ok = (p >= 0) & (p < A.ms);
+        const int shift = band_in ? p + lo_in : 0;
+        const long long base = (long long)p * ld_in - shift;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int dd = q_lane + e - shift;
+            const bool ok = row_ok & col_ok[e] & (dd >= 0) & (dd < bw_in);
+            x[e] = TC(0);
+            if (ok) {
+                if (f64_in) x[e] = (TC)((const double*)A.sig.ptr)[base + q_lane + e];
+                else x[e] = (TC)((const float*)A.sig.ptr)[base + q_lane + e];
+            }
+        }
+    };
+    auto commit = [&](int t, const TC (&x)[4]) {
+        if (lane * 4 < G::LWP) {
+            TC* dst = ring + (t % G::RING) * G::LWP + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = x[e];
+        }
+    };
+
+    TC acc[K][2];
+#pragma unroll
+    for (int s = 0; s < K; ++s) acc[s][0] = acc[s][1] = TC(0);
+    double b1[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
+
+    {
+        TC x[4];
+        fetch(0, x);
+        commit(0, x);
+    }
+    ConstPtr<TC> w = (ConstPtr<TC>)(uintptr_t)A.w;
+
+    for (int t = 0; t < n_staged; ++t) {
+        // issue the global loads of the next row now, commit them to LDS after this row's math
+        TC nx[4];
+        const bool have_next = (t + 1) < n_staged;
+        if (have_next) fetch(t + 1, nx);
+
+        RowRegs<TC, K> v;
+        v.load(ring + (t % G::RING) * G::LWP + lane * 2);
+        {
+            TC h1[2], h2[2];
+            row_box<TC, K>(v, h1, h2);
+            b1[0] += (double)h1[0];
+            b1[1] += (double)h1[1];
+            b2[0] += (double)h2[0];
+            b2[1] += (double)h2[1];
+        }
+        if (t >= K) {
+            RowRegs<TC, K> vo;
+            vo.load(ring + ((t - K) % G::RING) * G::LWP + lane * 2);
+            TC h1[2], h2[2];
+            row_box<TC, K>(vo, h1, h2);
+            b1[0] -= (double)h1[0];
+            b1[1] -= (double)h1[1];
+            b2[0] -= (double)h2[0];
+            b2[1] -= (double)h2[1];
+        }
+
+        // rotating accumulators, highest slot first so that acc[s] can be overwritten in place
+#pragma unroll
+        for (int s = K - 1; s >= 1; --s) {
+            if (s <= t) v.slot(w + s * K, acc[s - 1], acc[s]);
+            if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const TC zero[2] = {TC(0), TC(0)};
+            v.slot(w, zero, acc[0]);
+        }
+
+        if (t >= K - 1) {
+            const int oi = i0 + t - (K - 1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int oj = j0 + lane * 2 + c;
+                const int d = oj - oi;
+                if (oj < A.ns && d >= A.out_lo && d <= A.out_hi) {
+                    TC r, nobs;
+                    if (pixel_forced_zero(A, oi, oj)) {
+                        r = TC(0);
+                        nobs = A.ks.n;
+                    } else {
+                        r = pearson_from_sums<TC>(acc[K - 1][c], (TC)b1[c], (TC)b2[c], TC(0), TC(0), TC(0),
+                                                  A.ks, false, &nobs);
+                    }
+                    store_pixel(A, oi, oj, r, nobs);
+                }
+            }
+        }
+        if (have_next) commit(t + 1, nx);
+    }
+}
+
+template <int K, typename TC>
+constexpr size_t corr_stream_smem_bytes()
+{
+    using G = StreamGeom<K>;
+    return sizeof(TC) * G::NWAVES * G::RING * G::LWP;
+}
+
+}  // namespace cs

@@ -89,12 +89,14 @@ int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w
     std::vector<TC> w(w64.size());
     for (size_t t = 0; t < w64.size(); ++t) w[t] = (TC)w64[t];
     const size_t bytes = w.size() * sizeof(TC);
-    if (bytes > ctx->d_w_bytes) {
+    // + 64 bytes of slack: the fast kernels' scalar row loads over-read (cs_corr_stream.h WRow)
+    if (bytes + 64 > ctx->d_w_bytes) {
         if (ctx->d_w) CS_HIP(ctx, hipFree(ctx->d_w));
         ctx->d_w = nullptr;
         ctx->d_w_bytes = 0;
-        CS_HIP(ctx, hipMalloc(&ctx->d_w, bytes));
-        ctx->d_w_bytes = bytes;
+        CS_HIP(ctx, hipMalloc(&ctx->d_w, bytes + 64));
+        CS_HIP(ctx, hipMemset(ctx->d_w, 0, bytes + 64));
+        ctx->d_w_bytes = bytes + 64;
         ctx->w_cached.clear();
     }
     if (ctx->w_cached.size() == bytes && std::memcmp(ctx->w_cached.data(), w.data(), bytes) == 0)

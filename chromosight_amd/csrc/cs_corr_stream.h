@@ -50,6 +50,67 @@ using ConstPtr = const __attribute__((address_space(4))) TC*;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x8 __attribute__((ext_vector_type(8)));
+
+// One template row of weights in scalar registers, loaded by hand-placed s_load so that the
+// load of the NEXT row is in flight while the current row's FMAs issue.  hipcc cannot express
+// this by itself: it either hoists all 289 loop-invariant loads out of the row loop (and spills
+// them) or waits for each load right where it is issued.  The loads over-read up to 15 dwords
+// past a row; the weight buffer is allocated with that slack (cs_api.cpp upload_weights).
+template <typename TC, int K>
+struct WRow;
+
+template <int K>
+struct WRow<float, K> {
+    f32x16 a;
+    float b;
+    template <int BYTE_OFF>
+    __device__ __forceinline__ void issue(unsigned long long base)
+    {
+        if constexpr (K > 16)
+            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dword %1, %2, %4"
+                         : "=&s"(a), "=&s"(b) : "s"(base), "n"(BYTE_OFF), "n"(BYTE_OFF + 64));
+        else
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "n"(BYTE_OFF));
+    }
+    __device__ __forceinline__ void wait()
+    {
+        if constexpr (K > 16) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a));
+    }
+    __device__ __forceinline__ float get(int kj) const { return kj < 16 ? a[kj < 16 ? kj : 0] : b; }
+};
+
+template <int K>
+struct WRow<double, K> {
+    f64x8 a, b;
+    double c;
+    template <int BYTE_OFF>
+    __device__ __forceinline__ void issue(unsigned long long base)
+    {
+        if constexpr (K > 16)
+            asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                         : "=&s"(a), "=&s"(b), "=&s"(c)
+                         : "s"(base), "n"(BYTE_OFF), "n"(BYTE_OFF + 64), "n"(BYTE_OFF + 128));
+        else if constexpr (K > 8)
+            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+                         : "=&s"(a), "=&s"(b) : "s"(base), "n"(BYTE_OFF), "n"(BYTE_OFF + 64));
+        else
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "n"(BYTE_OFF));
+    }
+    __device__ __forceinline__ void wait()
+    {
+        if constexpr (K > 16) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c));
+        else if constexpr (K > 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a));
+    }
+    __device__ __forceinline__ double get(int kj) const
+    {
+        return kj < 8 ? a[kj < 8 ? kj : 0] : (kj < 16 ? b[(kj >= 8 && kj < 16) ? kj - 8 : 0] : c);
+    }
+};
+
 // Staged row of one lane: K+1 consecutive values v[0..K] starting at its first output column.
 template <typename TC, int K>
 struct RowRegs {
@@ -59,15 +120,15 @@ struct RowRegs {
 #pragma unroll
         for (int t = 0; t < K + 1; ++t) v[t] = p[t];
     }
-    // acc_out[c] = acc_in[c] + sum_kj v[kj + c] * w[kj]
-    __device__ __forceinline__ void slot(ConstPtr<TC> w, const TC (&in)[2], TC (&out)[2]) const
+    // acc_out[c] = acc_in[c] + sum_kj v[kj + c] * wk[kj]
+    __device__ __forceinline__ void slot(const WRow<TC, K>& wk, const TC (&in)[2], TC (&out)[2]) const
     {
-        TC a0 = cs_fma(v[0], w[0], in[0]);
-        TC a1 = cs_fma(v[1], w[0], in[1]);
+        TC a0 = cs_fma(v[0], wk.get(0), in[0]);
+        TC a1 = cs_fma(v[1], wk.get(0), in[1]);
 #pragma unroll
         for (int kj = 1; kj < K; ++kj) {
-            a0 = cs_fma(v[kj], w[kj], a0);
-            a1 = cs_fma(v[kj + 1], w[kj], a1);
+            a0 = cs_fma(v[kj], wk.get(kj), a0);
+            a1 = cs_fma(v[kj + 1], wk.get(kj), a1);
         }
         out[0] = a0;
         out[1] = a1;
@@ -93,15 +154,15 @@ struct RowRegs<float, K> {
             o[m].y = p[2 * m + 2];
         }
     }
-    __device__ __forceinline__ void slot(ConstPtr<float> w, const float (&in)[2], float (&out)[2]) const
+    // two independent dependency chains (even / odd template columns), summed at the end
+    __device__ __forceinline__ void slot(const WRow<float, K>& wk, const float (&in)[2], float (&out)[2]) const
     {
-        // two independent dependency chains (even / odd template columns), summed at the end
         f32x2 a = {in[0], in[1]};
         f32x2 b = {0.0f, 0.0f};
 #pragma unroll
         for (int kj = 0; kj < K; ++kj) {
-            const float wk = w[kj];
-            const f32x2 wv = {wk, wk};
+            const float wq = wk.get(kj);
+            const f32x2 wv = {wq, wq};
             if (kj & 1) b = __builtin_elementwise_fma(o[kj >> 1], wv, b);
             else a = __builtin_elementwise_fma(e[kj >> 1], wv, a);
         }
@@ -125,6 +186,36 @@ __device__ __forceinline__ void row_box(const RowRegs<TC, K>& r, TC (&h1)[2], TC
     }
     h1[1] = (h1[0] - r.at(0)) + r.at(K);
     h2[1] = cs_fma(r.at(K), r.at(K), cs_fma(-r.at(0), r.at(0), h2[0]));
+}
+
+// Slot S .. 0 of one staged row.  Compile-time recursion so that every s_load has an immediate
+// offset and the two weight buffers alternate statically.
+template <int S, typename TC, int K>
+__device__ __forceinline__ void slots_rec(const RowRegs<TC, K>& v, unsigned long long w_base,
+                                          TC (&acc)[K][2], WRow<TC, K>& cur, WRow<TC, K>& nxt)
+{
+    cur.wait();
+    if constexpr (S > 0) nxt.template issue<(S - 1) * K * (int)sizeof(TC)>(w_base);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S > 0) {
+        v.slot(cur, acc[S - 1], acc[S]);
+    } else {
+        const TC zero[2] = {TC(0), TC(0)};
+        v.slot(cur, zero, acc[0]);
+    }
+    // pin this slot's FMAs between the two hand-placed scalar loads: without a (volatile) use
+    // of their result the optimiser sinks them below all 17 loads and spills the weights
+    asm volatile("" : "+v"(acc[S][0]), "+v"(acc[S][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S > 0) slots_rec<S - 1, TC, K>(v, w_base, acc, nxt, cur);
+}
+
+template <int STOP, typename TC, int K>
+__device__ __forceinline__ void slots(const RowRegs<TC, K>& v, unsigned long long w_base, TC (&acc)[K][2])
+{
+    WRow<TC, K> wa, wb;
+    wa.template issue<STOP * K * (int)sizeof(TC)>(w_base);
+    slots_rec<STOP, TC, K>(v, w_base, acc, wa, wb);
 }
 
 template <typename TC, int K>
@@ -201,7 +292,7 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const CorrArgs<TC> A, 
         fetch(0, x);
         commit(0, x);
     }
-    ConstPtr<TC> w = (ConstPtr<TC>)(uintptr_t)A.w;
+    const unsigned long long w_base = (unsigned long long)(uintptr_t)A.w;
 
     for (int t = 0; t < n_staged; ++t) {
         // issue the global loads of the next row now, commit them to LDS after this row's math
@@ -230,16 +321,9 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const CorrArgs<TC> A, 
             b2[1] -= (double)h2[1];
         }
 
-        // rotating accumulators, highest slot first so that acc[s] can be overwritten in place
-#pragma unroll
-        for (int s = K - 1; s >= 1; --s) {
-            if (s <= t) v.slot(w + s * K, acc[s - 1], acc[s]);
-            if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-            const TC zero[2] = {TC(0), TC(0)};
-            v.slot(w, zero, acc[0]);
-        }
+        // rotating accumulators, highest slot first so that acc[s] can be overwritten in place;
+        // the weights of slot s-1 are in flight while slot s computes (two scalar buffers)
+        slots<K - 1>(v, w_base, acc);
 
         if (t >= K - 1) {
             const int oi = i0 + t - (K - 1);

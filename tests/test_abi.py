@@ -1,0 +1,45 @@
+"""The C-ABI shared library builds in-tree, loads, and exports every symbol that
+include/chromosight_hip.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import pathlib
+import re
+
+import pytest
+
+from chromosight_amd import _lib
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def header_functions():
+    text = (ROOT / "include" / "chromosight_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == list(_lib.ABI_SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    lib = _lib.load_library()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.cs_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Creating a device context without a GPU must fail loudly, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.Device(0)
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by the field lists of include/chromosight_hip.h on LP64
+    assert ctypes.sizeof(_lib.CsMatrix) == 32
+    assert ctypes.sizeof(_lib.CsKernel) == 32
+    assert ctypes.sizeof(_lib.CsNormxcorr2Params) == 72
+    assert ctypes.sizeof(_lib.CsCsr) == 48

@@ -1,0 +1,153 @@
+"""Pins the oracle (oracle/pearson_oracle.py and oracle/oracle.c) to the reference: every vector
+in tests/golden/*.npz was produced by importing /root/reference (tests/golden/make_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import c_oracle
+from oracle import pearson_oracle as orc
+
+TIGHT = 1e-12
+
+
+def coo(g, prefix):
+    shape = tuple(g[f"{prefix}_shape"])
+    return sp.coo_matrix((g[f"{prefix}_val"], (g[f"{prefix}_row"], g[f"{prefix}_col"])), shape=shape)
+
+
+def flags(valid, n):
+    f = np.ones(n, dtype=bool)
+    f[valid] = False
+    return f
+
+
+def test_xcorr2(golden):
+    g = golden("xcorr2")
+    for c in range(3):
+        o = orc.xcorr2_oracle(g[f"sig{c}"], g["gauss_kernel"])
+        assert np.abs(o - g[f"dense{c}"]).max() < TIGHT
+        assert np.abs(o - g[f"sparse{c}"]).max() < TIGHT
+        # the reference's own test oracle: scipy.signal.correlate2d "valid"
+        # (reference tests/test_detection.py:251-270)
+        sc = np.zeros_like(o)
+        sc[3:-3, 3:-3] = g[f"scipy_valid{c}"]
+        sc[sc < 1e-4] = 0
+        assert np.allclose(o, sc)
+        assert np.abs(orc.xcorr2_oracle(g[f"sig{c}"], np.ones((11, 11)) / 121) - g[f"const{c}"]).max() < TIGHT
+    assert np.abs(orc.xcorr2_oracle(g["rand"], g["rect_kernel_5x9"]) - g["rand_rect_5x9"]).max() < 1e-11
+    k_tsvd = g["loops_tsvd999_u"] @ g["loops_tsvd999_v"]
+    assert np.abs(orc.xcorr2_oracle(g["rand"], k_tsvd) - g["rand_loops_tsvd999"]).max() < 1e-10
+
+
+def test_normxcorr2_dense(golden, templates):
+    g = golden("normxcorr2_dense")
+    for name, tol in (("a", TIGHT), ("b", 1e-6)):   # sig_b holds a constant patch: 0/0 windows
+        s = g[f"sig_{name}"]
+        for kname in ("loops", "small", "hairpin"):
+            k = templates[kname]
+            for full in (False, True):
+                tag = f"{name}_{kname}_{'full' if full else 'valid'}"
+                r, nobs = orc.normxcorr2_oracle(s, k, full=full)
+                assert np.abs(r - g[f"dense_{tag}_corr"]).max() < tol, tag
+                assert np.abs(r - g[f"sparse_{tag}_corr"]).max() < tol, tag
+                rc, _ = c_oracle.normxcorr2(s, k, full=full)
+                assert np.abs(rc - g[f"dense_{tag}_corr"]).max() < tol, tag
+                lp = np.where(r != 0, orc.corr_to_pval_oracle(r, nobs), 0.0)
+                assert np.nanmax(np.abs(lp - g[f"sparse_{tag}_pval"])) < max(tol * 1e3, 1e-9), tag
+        sq = np.triu(s[:80, :80])
+        r, _ = orc.normxcorr2_oracle(sq, templates["loops"], sym_upper=True, full=True)
+        assert np.abs(r - g[f"sparse_{name}_loops_symfull_corr"]).max() < tol
+        r, _ = orc.normxcorr2_oracle(sq, templates["loops"], sym_upper=True, full=False)
+        assert np.abs(r - g[f"dense_{name}_loops_symvalid_corr"]).max() < tol
+
+
+def test_missing_predicate(golden):
+    g = golden("masks")
+    for i in range(int(g["n_sym"])):
+        n = int(g[f"sym{i}_n"])
+        ks = tuple(int(x) for x in g[f"sym{i}_kshape"])
+        md = int(g[f"sym{i}_max_dist"])
+        md = None if md < 0 else md
+        miss = flags(g[f"sym{i}_valid"], n)
+        H, W = n + 2 * (ks[0] - 1), n + 2 * (ks[1] - 1)
+        ref = np.unpackbits(g[f"sym{i}_framed"])[:H * W].reshape(H, W).astype(bool)
+        assert np.array_equal(orc.framed_missing_predicate((n, n), ks, miss, miss, True, md), ref), i
+    for i in range(int(g["n_inter"])):
+        shape = tuple(int(x) for x in g[f"inter{i}_shape"])
+        ks = tuple(int(x) for x in g[f"inter{i}_kshape"])
+        mr, mc = flags(g[f"inter{i}_valid_rows"], shape[0]), flags(g[f"inter{i}_valid_cols"], shape[1])
+        H, W = shape[0] + 2 * (ks[0] - 1), shape[1] + 2 * (ks[1] - 1)
+        ref = np.unpackbits(g[f"inter{i}_framed"])[:H * W].reshape(H, W).astype(bool)
+        assert np.array_equal(orc.framed_missing_predicate(shape, ks, mr, mc, False, None), ref), i
+
+
+def test_normxcorr2_masked(golden, templates):
+    g = golden("normxcorr2_mask")
+    for i in range(int(g["n_intra"])):
+        sig, k, valid = g[f"intra{i}_sig"], g[f"intra{i}_kernel"], g[f"intra{i}_valid"]
+        md, tol = int(g[f"intra{i}_max_dist"]), float(g[f"intra{i}_tol"])
+        miss = flags(valid, sig.shape[0])
+        M = orc.framed_missing_predicate(sig.shape, k.shape, miss, miss, True, md)
+        r, nobs = orc.normxcorr2_oracle(sig, k, max_dist=md, sym_upper=True, full=True, missing=M, missing_tol=tol)
+        assert np.abs(r - g[f"intra{i}_corr"]).max() < TIGHT, i
+        lp = np.where(r != 0, orc.corr_to_pval_oracle(r, nobs), 0.0)
+        assert np.nanmax(np.abs(lp - g[f"intra{i}_pval"])) < 1e-9, i
+        rc, _ = c_oracle.normxcorr2(sig, k, max_dist=md, sym_upper=True, full=True, miss_row=miss,
+                                    miss_col=miss, missing_tol=tol)
+        assert np.abs(rc - g[f"intra{i}_corr"]).max() < TIGHT, i
+    miss = flags(g["nomd_valid"], g["nomd_sig"].shape[0])
+    M = orc.framed_missing_predicate(g["nomd_sig"].shape, (7, 7), miss, miss, True, None)
+    r, _ = orc.normxcorr2_oracle(g["nomd_sig"], templates["small"], sym_upper=True, full=True, missing=M)
+    assert np.abs(r - g["nomd_corr"]).max() < TIGHT
+    shape = g["inter_sig"].shape
+    mr, mc = flags(g["inter_valid_rows"], shape[0]), flags(g["inter_valid_cols"], shape[1])
+    for kn in ("loops", "b11"):
+        k = g[f"inter_{kn}_kernel"]
+        M = orc.framed_missing_predicate(shape, k.shape, mr, mc, False, None)
+        r, _ = orc.normxcorr2_oracle(g["inter_sig"], k, full=True, missing=M)
+        assert np.abs(r - g[f"inter_{kn}_corr"]).max() < TIGHT, kn
+        rc, _ = c_oracle.normxcorr2(g["inter_sig"], k, full=True, miss_row=mr, miss_col=mc)
+        assert np.abs(rc - g[f"inter_{kn}_corr"]).max() < TIGHT, kn
+    r, _ = orc.normxcorr2_oracle(g["valid_sig"], templates["small"], max_dist=20, sym_upper=True, full=False,
+                                 missing=g["valid_mask"])
+    assert np.abs(r - g["valid_corr"]).max() < TIGHT
+
+
+@pytest.mark.parametrize("ci", [0, 2])
+def test_example_cool_blocks(golden, templates, ci):
+    """Real data: balanced block -> distance law -> detrended block -> coefficient map."""
+    g = golden("example_blocks")
+    det = g[f"chr{ci}_det"]
+    n = int(g[f"chr{ci}_n"])
+    block = coo(g, f"chr{ci}_balanced")
+    dense = block.toarray()
+    stored = np.zeros((n, n), dtype=bool)
+    stored[block.row, block.col] = True
+    for pname, kern, tol in (("loops", templates["loops"], 0.5), ("borders", templates["borders"][1], 0.75)):
+        keep = int(g[f"chr{ci}_{pname}_keep"])
+        md = int(g[f"chr{ci}_{pname}_max_dist"])
+        det_ref = orc.distance_law_oracle(np.where(stored, dense, 0.0), det, keep)
+        ref_law = g[f"chr{ci}_{pname}_law"]
+        assert np.array_equal(np.isnan(det_ref), np.isnan(ref_law))
+        assert np.nanmax(np.abs(det_ref - ref_law)) < 1e-12
+        out, _ = orc.detrend_oracle(dense, stored, det, keep, max_val=10)
+        ii, jj = np.indices((n, n))
+        out[(jj - ii < 0) | (jj - ii > keep)] = 0
+        out[np.isnan(out)] = 0
+        prepared = coo(g, f"chr{ci}_{pname}_prepared").toarray()
+        assert np.abs(out - prepared).max() < 1e-11
+        miss = flags(det, n)
+        ki = 0 if pname == "loops" else 1
+        rc, _ = c_oracle.normxcorr2(prepared, kern, max_dist=md, sym_upper=True, full=True, miss_row=miss,
+                                    miss_col=miss, missing_tol=tol)
+        assert np.abs(rc - coo(g, f"chr{ci}_{pname}{ki}_corr").toarray()).max() < 1e-11
+
+
+def test_corr_to_pval(golden):
+    g = golden("stats")
+    lp = orc.corr_to_pval_oracle(g["r"], g["n"].astype(float))
+    ref = g["logp_vec"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(lp), fin)
+    assert np.abs(lp[fin] - ref[fin]).max() < 1e-9

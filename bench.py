@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4p"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", type=int, default=4096, help="c2 only: side of the dense map (default 4096)")
     return ap.parse_args()
 
 
@@ -56,7 +57,7 @@ def loops_kernel():
 class Workload:
     """Device-resident inputs/outputs of one rank plus the launch closure."""
 
-    def __init__(self, name, dev, rank, precision):
+    def __init__(self, name, dev, rank, precision, size=4096):
         from chromosight_amd import engine
         from chromosight_amd._lib import (CsMatrix, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_NONE,
                                           np_dtype_code)
@@ -67,7 +68,7 @@ class Workload:
         out_dtype = np.float64 if precision == "f64" else np.float32
         self.precision = precision
         if name == "c2":
-            n = 4096
+            n = size
             rng = np.random.default_rng(0 + rank)
             self.host_sig = rng.gamma(4.0, 0.25, size=(n, n)).astype(np.float32)
             self.shape = (n, n)
@@ -78,7 +79,7 @@ class Workload:
             self.kwargs = dict(full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE)
             self.pixels = n * n
             self.bytes_per_pixel = 4 + np.dtype(out_dtype).itemsize
-            self.desc = ("C2: dense 4096x4096 float32 gamma(4,0.25) seed 0, 17x17 loops template, "
+            self.desc = (f"C2: dense {n}x{n} float32 gamma(4,0.25) seed 0, 17x17 loops template, "
                          "normxcorr2(full=False, no mask)")
         else:
             n, max_dist = (50000, 233) if name == "c3" else (200000, 1000)
@@ -136,7 +137,7 @@ def cpu_baseline(workload):
     dt = time.perf_counter() - t0
     return {
         "value": round(sample.size / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
-        "sample": f"first {rows} rows of the same 4096-wide map ({sample.size / 1e6:.2f} Mpixel), float64 C "
+        "sample": f"first {rows} rows of the same map ({sample.size / 1e6:.2f} Mpixel), float64 C "
                   f"restatement oracle/oracle.c with OpenMP, {dt:.1f} s",
     }
 
@@ -167,7 +168,7 @@ def main():
     from chromosight_amd._lib import get_device
     chromosight_amd.set_precision(args.precision)
     dev = get_device(local_rank)
-    wl = Workload(args.workload, dev, rank, args.precision)
+    wl = Workload(args.workload, dev, rank, args.precision, args.size)
 
     def full_sync():
         if torch is not None:

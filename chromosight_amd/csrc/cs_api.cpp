@@ -157,7 +157,7 @@ template <>
 int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
-    if (allow_fast && A.mask_mode == 0 && !A.xcorr_only && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && A.mask_mode == 0 && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
@@ -187,7 +187,7 @@ template <>
 int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
-    if (allow_fast && A.mask_mode == 0 && !A.xcorr_only && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && A.mask_mode == 0 && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \

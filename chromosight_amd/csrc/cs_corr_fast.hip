@@ -17,6 +17,29 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
 {
     using G = StreamGeom<CS_K>;
     constexpr size_t smem = corr_stream_smem_bytes<CS_K, TC>();
+    StreamArgs<TC> S;
+    S.sig = A.sig.ptr;
+    S.out = A.out.ptr;
+    S.w = (unsigned long long)(uintptr_t)A.w;
+    S.ld_in = A.sig.ld;
+    S.ld_out = A.out.ld;
+    S.sig_is_f64 = A.sig_is_f64;
+    S.out_is_f64 = A.out_is_f64;
+    S.band_in = A.sig.layout == 1;
+    S.lo_in = A.sig.band_lo;
+    S.bw_in = A.sig.band_w;
+    S.band_out = A.out.layout == 1;
+    S.out_lo = A.out_lo;
+    S.out_hi = A.out_hi;
+    S.lo_out = A.out.band_lo;
+    S.ms = A.ms;
+    S.ns = A.ns;
+    S.full = A.full;
+    S.sym_upper = A.sym_upper;
+    S.strip_h = A.tile_h;
+    S.strips_x = A.tiles_x;
+    S.strips_y = A.tiles_y;
+    S.ks = A.ks;
     const int n_waves = A.tiles_x * A.tiles_y;
     const int blocks = (n_waves + G::NWAVES - 1) / G::NWAVES;
     auto kern = corr_stream_kernel<TC, CS_K>;
@@ -24,8 +47,7 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem, stream, A, A.tile_h, A.tiles_x,
-                       A.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem, stream, S);
     return (int)hipGetLastError();
 }
 
@@ -41,7 +63,7 @@ void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int n_cu, int* tw, int* th)
 {
     *tw = StreamGeom<CS_K>::TW;
     int h = 256;
-    const long long want = (long long)n_cu * 4 * 3;  // ~3 waves per SIMD
+    const long long want = (long long)n_cu * 4 * 2;  // at least ~2 waves per SIMD
     while (h > 32) {
         const long long waves = (long long)((ns + *tw - 1) / *tw) * ((ms + h - 1) / h);
         if (waves >= want) break;

@@ -39,7 +39,7 @@ struct StreamGeom {
     static constexpr int TW = kWave * RW;           // 128 output columns per wave
     static constexpr int LW = TW + K - 1;           // staged columns per row
     static constexpr int LWP = ((LW + 3) / 4) * 4;  // row pitch in elements (16-byte multiple)
-    static constexpr int RING = K + 3;              // rows t-K .. t+1 live, +1 slack
+    static constexpr int RING = K + 2;              // rows t-K .. t+1 are live
     static constexpr int NWAVES = 4;                // independent waves per workgroup
 };
 
@@ -64,12 +64,12 @@ struct WRow;
 template <int K>
 struct WRow<float, K> {
     f32x16 a;
-    float b;
+    f32x2 b;   // weight 16 (+ one over-read dword)
     template <int BYTE_OFF>
     __device__ __forceinline__ void issue(unsigned long long base)
     {
         if constexpr (K > 16)
-            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dword %1, %2, %4"
+            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
                          : "=&s"(a), "=&s"(b) : "s"(base), "n"(BYTE_OFF), "n"(BYTE_OFF + 64));
         else
             asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "n"(BYTE_OFF));
@@ -79,8 +79,38 @@ struct WRow<float, K> {
         if constexpr (K > 16) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a));
     }
-    __device__ __forceinline__ float get(int kj) const { return kj < 16 ? a[kj < 16 ? kj : 0] : b; }
+    // aligned scalar pair holding weight kj (in its low half for even kj, high half for odd kj)
+    template <int KJ>
+    __device__ __forceinline__ f32x2 pair() const
+    {
+        if constexpr (KJ >= 16) return b;
+        else return __builtin_shufflevector(a, a, (KJ & ~1), (KJ & ~1) + 1);
+    }
 };
+
+// acc (+)= x * w broadcast, w = low (even KJ) or high (odd KJ) half of a scalar register pair.
+// Written as asm so that the half is selected with op_sel instead of an s_mov + s_nop per weight.
+template <int KJ>
+__device__ __forceinline__ f32x2 pk_fma_w(f32x2 x, f32x2 wpair, f32x2 acc)
+{
+    f32x2 out;
+    if constexpr ((KJ & 1) == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(out) : "v"(x), "s"(wpair), "v"(acc));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(out) : "v"(x), "s"(wpair), "v"(acc));
+    return out;
+}
+
+template <int KJ>
+__device__ __forceinline__ f32x2 pk_mul_w(f32x2 x, f32x2 wpair)
+{
+    f32x2 out;
+    if constexpr ((KJ & 1) == 0)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(out) : "v"(x), "s"(wpair));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(out) : "v"(x), "s"(wpair));
+    return out;
+}
 
 template <int K>
 struct WRow<double, K> {
@@ -155,17 +185,21 @@ struct RowRegs<float, K> {
         }
     }
     // two independent dependency chains (even / odd template columns), summed at the end
+    template <int KJ>
+    __device__ __forceinline__ void chain(const WRow<float, K>& wk, f32x2& a, f32x2& b) const
+    {
+        if constexpr (KJ < K) {
+            if constexpr (KJ == 1) b = pk_mul_w<KJ>(o[0], wk.template pair<KJ>());
+            else if constexpr (KJ & 1) b = pk_fma_w<KJ>(o[KJ >> 1], wk.template pair<KJ>(), b);
+            else a = pk_fma_w<KJ>(e[KJ >> 1], wk.template pair<KJ>(), a);
+            chain<KJ + 1>(wk, a, b);
+        }
+    }
     __device__ __forceinline__ void slot(const WRow<float, K>& wk, const float (&in)[2], float (&out)[2]) const
     {
         f32x2 a = {in[0], in[1]};
-        f32x2 b = {0.0f, 0.0f};
-#pragma unroll
-        for (int kj = 0; kj < K; ++kj) {
-            const float wq = wk.get(kj);
-            const f32x2 wv = {wq, wq};
-            if (kj & 1) b = __builtin_elementwise_fma(o[kj >> 1], wv, b);
-            else a = __builtin_elementwise_fma(e[kj >> 1], wv, a);
-        }
+        f32x2 b;
+        chain<0>(wk, a, b);
         a += b;
         out[0] = a.x;
         out[1] = a.y;
@@ -218,9 +252,25 @@ __device__ __forceinline__ void slots(const RowRegs<TC, K>& v, unsigned long lon
     slots_rec<STOP, TC, K>(v, w_base, acc, wa, wb);
 }
 
+// Lean view of the launch arguments (only what the row loop needs stays in registers).
+template <typename TC>
+struct StreamArgs {
+    const void* sig;        // input map
+    void* out;              // coefficient map
+    unsigned long long w;   // device address of the centred template weights (K*K)
+    long long ld_in, ld_out;
+    int sig_is_f64, out_is_f64;
+    int band_in, lo_in, bw_in;     // input layout: band flag, first stored diagonal, stored diagonals
+    int band_out, out_lo, out_hi;  // output layout / produced diagonal range
+    int lo_out;                    // first stored diagonal of the output band
+    int ms, ns;
+    int full, sym_upper;
+    int strip_h, strips_x, strips_y;
+    KernelStats<TC> ks;
+};
+
 template <typename TC, int K>
-__global__ __launch_bounds__(256) void corr_stream_kernel(const CorrArgs<TC> A, int strip_h,
-                                                          int strips_x, int strips_y)
+__global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
     constexpr int KH = (K - 1) / 2;
@@ -231,60 +281,83 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const CorrArgs<TC> A, 
 
     // strip of this wave (uniform per wave); x fastest so that neighbouring waves share halos
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * G::NWAVES + wv);
-    if (wid >= strips_x * strips_y) return;
-    const int sy = wid / strips_x;
-    const int sx = wid - sy * strips_x;
-    const int i0 = sy * strip_h;                          // first output row
+    if (wid >= A.strips_x * A.strips_y) return;
+    const int sy = wid / A.strips_x;
+    const int sx = wid - sy * A.strips_x;
+    const int i0 = sy * A.strip_h;                        // first output row
     int j0 = sx * G::TW;                                  // first output column
-    if (A.out.layout == 1) {
+    if (A.band_out) {
         int jmin = i0 + A.out_lo;
         if (jmin < 0) jmin = 0;
         j0 += (jmin / G::TW) * G::TW;
         const int dmax = (j0 + G::TW - 1) - i0;
-        const int dmin = j0 - (i0 + strip_h - 1);
+        const int dmin = j0 - (i0 + A.strip_h - 1);
         if (j0 >= A.ns || dmax < A.out_lo || dmin > A.out_hi) return;
     }
-    const int rows_out = min(strip_h, A.ms - i0);
+    const int rows_out = min(A.strip_h, A.ms - i0);
     const int n_staged = rows_out + K - 1;
 
-    // ---- staging of one input row into the ring (lanes 0..LWP/4-1 move 4 elements each) -----
-    // element (p, q) lives at p * ld + (q - shift(p)); dense: shift = 0, band: shift = p + band_lo
+    // zero the ring: rows "older" than the strip are read (and subtracted) as zeros, which
+    // makes the row loop branch free
+    for (int idx = lane; idx < G::RING * G::LWP; idx += kWave) ring[idx] = TC(0);
+
+    // ---- per-lane staging state: lanes 0..LWP/4-1 move 4 consecutive elements of each row ----
+    // element (p, q) lives at p * ld + q - shift(p); dense: shift = 0, band: shift = p + lo
     const int q_lane = j0 - KH + lane * 4;
-    const bool band_in = A.sig.layout == 1;
-    const long long ld_in = A.sig.ld;
-    const int bw_in = band_in ? A.sig.band_w : 0x7fffffff;
-    const int lo_in = A.sig.band_lo;
-    const bool f64_in = A.sig_is_f64 != 0;
+    const int p_first = i0 - KH;
+    const int shift0 = A.band_in ? p_first + A.lo_in : 0;
+    long long in_idx = (long long)p_first * A.ld_in + (q_lane - shift0);   // element index of e = 0
+    const long long in_step = A.band_in ? A.ld_in - 1 : A.ld_in;          // per-row increment
+    int dd = q_lane - shift0;                                              // stored-diagonal index
+    const int dd_step = A.band_in ? -1 : 0;
+    const unsigned bw = A.band_in ? (unsigned)A.bw_in : 0x7fffffffu;
     bool col_ok[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) col_ok[e] = (lane * 4 + e < G::LW) & (q_lane + e >= 0) & (q_lane + e < A.ns);
+    const bool stage_lane = lane * 4 < G::LWP;
+
     auto fetch = [&](int t, TC (&x)[4]) {
-        const int p = i0 - KH + t;
-        const bool row_ok = (p >= 0) & (p < A.ms);
-        const int shift = band_in ? p + lo_in : 0;
-        const long long base = (long long)p * ld_in - shift;
+        const int p = p_first + t;
+        const bool row_ok = (p >= 0) & (p < A.ms) & (t < n_staged);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int dd = q_lane + e - shift;
-            const bool ok = row_ok & col_ok[e] & (dd >= 0) & (dd < bw_in);
-            x[e] = TC(0);
-            if (ok) {
-                if (f64_in) x[e] = (TC)((const double*)A.sig.ptr)[base + q_lane + e];
-                else x[e] = (TC)((const float*)A.sig.ptr)[base + q_lane + e];
-            }
+            const bool ok = row_ok & col_ok[e] & (A.band_in ? ((unsigned)(dd + e) < bw) : true);
+            const long long idx = ok ? in_idx + e : 0;        // always a valid address
+            TC val;
+            if (A.sig_is_f64) val = (TC)((const double*)A.sig)[idx];
+            else val = (TC)((const float*)A.sig)[idx];
+            x[e] = ok ? val : TC(0);
         }
+        in_idx += in_step;
+        dd += dd_step;
     };
-    auto commit = [&](int t, const TC (&x)[4]) {
-        if (lane * 4 < G::LWP) {
-            TC* dst = ring + (t % G::RING) * G::LWP + lane * 4;
+    auto commit = [&](int slot, const TC (&x)[4]) {
+        if (stage_lane) {
+            TC* dst = ring + slot * G::LWP + lane * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[e] = x[e];
         }
     };
 
+    // ---- per-lane output state -------------------------------------------------------------
+    const int oj0 = j0 + lane * 2;
+    const int lo_o = A.band_out ? A.lo_out : 0;
+    long long out_idx = (long long)i0 * A.ld_out + (oj0 - (A.band_out ? i0 + lo_o : 0));
+    const long long out_step = A.band_out ? A.ld_out - 1 : A.ld_out;
+    int d_out = oj0 - i0;                                  // diagonal of column 0 at the first output row
+    bool ocol_ok[2], ocol_margin[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        ocol_ok[c] = (oj0 + c) < A.ns;
+        ocol_margin[c] = !A.full && ((oj0 + c < KH) | (oj0 + c > A.ns - K + KH));
+    }
+
     TC acc[K][2];
 #pragma unroll
     for (int s = 0; s < K; ++s) acc[s][0] = acc[s][1] = TC(0);
+    // running box sums (sum S, sum S^2 over the K staged rows of the window), updated by
+    // (row entering) - (row leaving).  The difference of the two float32 horizontal partials is
+    // accumulated in float64, so the rounding does not grow with the strip height.
     double b1[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
 
     {
@@ -292,59 +365,64 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const CorrArgs<TC> A, 
         fetch(0, x);
         commit(0, x);
     }
-    const unsigned long long w_base = (unsigned long long)(uintptr_t)A.w;
+    int slot_new = 0;                // ring slot of row t
+    int slot_old = G::RING - K;      // ring slot of row t - K  ((t - K) mod RING)
 
     for (int t = 0; t < n_staged; ++t) {
         // issue the global loads of the next row now, commit them to LDS after this row's math
         TC nx[4];
-        const bool have_next = (t + 1) < n_staged;
-        if (have_next) fetch(t + 1, nx);
+        fetch(t + 1, nx);
+        int slot_next = slot_new + 1;
+        if (slot_next == G::RING) slot_next = 0;
 
         RowRegs<TC, K> v;
-        v.load(ring + (t % G::RING) * G::LWP + lane * 2);
+        v.load(ring + slot_new * G::LWP + lane * 2);
         {
-            TC h1[2], h2[2];
+            TC h1[2], h2[2], g1[2], g2[2];
             row_box<TC, K>(v, h1, h2);
-            b1[0] += (double)h1[0];
-            b1[1] += (double)h1[1];
-            b2[0] += (double)h2[0];
-            b2[1] += (double)h2[1];
-        }
-        if (t >= K) {
             RowRegs<TC, K> vo;
-            vo.load(ring + ((t - K) % G::RING) * G::LWP + lane * 2);
-            TC h1[2], h2[2];
-            row_box<TC, K>(vo, h1, h2);
-            b1[0] -= (double)h1[0];
-            b1[1] -= (double)h1[1];
-            b2[0] -= (double)h2[0];
-            b2[1] -= (double)h2[1];
+            vo.load(ring + slot_old * G::LWP + lane * 2);
+            row_box<TC, K>(vo, g1, g2);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                b1[c] += (double)(h1[c] - g1[c]);
+                b2[c] += (double)(h2[c] - g2[c]);
+            }
         }
 
         // rotating accumulators, highest slot first so that acc[s] can be overwritten in place;
         // the weights of slot s-1 are in flight while slot s computes (two scalar buffers)
-        slots<K - 1>(v, w_base, acc);
+        slots<K - 1>(v, A.w, acc);
 
         if (t >= K - 1) {
             const int oi = i0 + t - (K - 1);
+            const bool row_margin = !A.full && ((oi < KH) | (oi > A.ms - K + KH));
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int oj = j0 + lane * 2 + c;
-                const int d = oj - oi;
-                if (oj < A.ns && d >= A.out_lo && d <= A.out_hi) {
-                    TC r, nobs;
-                    if (pixel_forced_zero(A, oi, oj)) {
-                        r = TC(0);
-                        nobs = A.ks.n;
-                    } else {
-                        r = pearson_from_sums<TC>(acc[K - 1][c], (TC)b1[c], (TC)b2[c], TC(0), TC(0), TC(0),
-                                                  A.ks, false, &nobs);
-                    }
-                    store_pixel(A, oi, oj, r, nobs);
+                const int d = d_out + c;
+                const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi);
+                const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
+                TC r;
+                if constexpr (sizeof(TC) == 4) {
+                    r = pearson_nomask_f32(acc[K - 1][c], (float)b1[c], (float)b2[c], A.ks);
+                } else {
+                    TC nobs;
+                    r = pearson_from_sums<TC>(acc[K - 1][c], (TC)b1[c], (TC)b2[c], TC(0), TC(0), TC(0), A.ks,
+                                              false, &nobs);
+                }
+                r = zero ? TC(0) : r;
+                if (in_range) {
+                    if (A.out_is_f64) ((double*)A.out)[out_idx + c] = (double)r;
+                    else ((float*)A.out)[out_idx + c] = (float)r;
                 }
             }
+            out_idx += out_step;
+            d_out -= 1;
         }
-        if (have_next) commit(t + 1, nx);
+        commit(slot_next, nx);
+        slot_new = slot_next;
+        slot_old += 1;
+        if (slot_old == G::RING) slot_old = 0;
     }
 }
 

@@ -226,6 +226,27 @@ __device__ __forceinline__ TC pearson_from_sums(TC cs, TC s1, TC s2, TC nm, TC k
     return r;
 }
 
+// Unmasked branch only (reference detection.py:1000-1018, 1213-1220), used by the streaming
+// float32 kernel: same thresholds, hardware 1-ulp sqrt / reciprocal instead of the IEEE sequences.
+__device__ __forceinline__ float pearson_nomask_f32(float cs, float s1, float s2, const KernelStats<float>& K)
+{
+    const float m1 = s1 * K.inv_n;
+    const float m2 = s2 * K.inv_n;
+    const float c = fmaf(K.kmean, s1, cs) * K.inv_n;
+    const bool z1 = fabsf(m1) < K.thr;
+    const bool z2 = fabsf(m2) < K.thr;
+    const bool zc = fabsf(c) < K.thr;
+    const float m1z = z1 ? 0.0f : m1;
+    const float m2z = z2 ? 0.0f : m2;
+    const float num = (z1 | zc) ? ((zc ? 0.0f : c) - m1z * K.kmean) : cs * K.inv_n;
+    const float var = fmaf(-m1z, m1z, m2z);
+    const float den = __builtin_amdgcn_sqrtf(var) * K.kstd;      // NaN for var < 0
+    float r = num * __builtin_amdgcn_rcpf(den);
+    r = (fabsf(den) < K.eps) ? 0.0f : r;
+    r = (fabsf(r) <= 3.0e38f) ? r : 0.0f;                           // NaN / inf -> 0
+    return fminf(fmaxf(r, -1.0f), 1.0f);
+}
+
 // does output pixel (i, j) exist, and is its value forced to 0?
 //   valid-mode margins (detection.py:720-722, 797-801) and sym_upper triu (:1098-1099)
 template <typename TC>

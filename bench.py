@@ -124,21 +124,27 @@ class Workload:
                                    precision=self.precision, **self.kwargs)
 
 
-def cpu_baseline(workload):
-    """The C restatement of the oracle ("port") timed on a bounded sample of the same map."""
+def cpu_baseline(workload, budget_s=12.0):
+    """The C restatement of the oracle ("port", oracle/oracle.c with OpenMP on all host cores)
+    timed on the same map: whole passes over the first rows until ~budget_s of wall time."""
     from oracle import c_oracle
     if workload.host_sig is None:
         return None
-    rows = 1024 + 16
+    rows = min(workload.host_sig.shape[0], 2048 + 16)
     sample = workload.host_sig[:rows].astype(np.float64)
     threads = c_oracle.max_threads()
-    t0 = time.perf_counter()
-    c_oracle.normxcorr2(sample, loops_kernel(), n_threads=threads)
-    dt = time.perf_counter() - t0
+    c_oracle.normxcorr2(sample[:64], loops_kernel(), n_threads=threads)  # load + warm the library
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.normxcorr2(sample, loops_kernel(), n_threads=threads)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or passes >= 200:
+            break
     return {
-        "value": round(sample.size / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
-        "sample": f"first {rows} rows of the same map ({sample.size / 1e6:.2f} Mpixel), float64 C "
-                  f"restatement oracle/oracle.c with OpenMP, {dt:.1f} s",
+        "value": round(passes * sample.size / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+        "sample": f"{passes} passes over the first {rows} rows of the same map ({sample.size / 1e6:.2f} Mpixel "
+                  f"each), float64 C restatement oracle/oracle.c, OpenMP x{threads}, {dt:.1f} s",
     }
 
 

@@ -1,0 +1,114 @@
+"""Multi-GPU driver of the hot path: one process per GPU, sub-matrices sharded across ranks,
+candidate records gathered at the end.
+
+Mirrors the only parallelism of the reference -- `multiprocessing.Pool(threads).imap` over
+independent sub-matrices, one task = one sub-matrix x one kernel
+(reference chromosight/cli/chromosight.py:406-410, 748-752) -- with `torch.distributed`
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  Sub-matrices are
+independent (own distance law, mask and foci), so the data path has no collective; the only
+exchange is the final gather of the per-block pattern tables (a few MB at most).
+
+    tables = detect_blocks(blocks, kernel_config, kernel_matrix, detector=...)
+
+`blocks` is a list of objects with the attributes pattern_detector reads (`matrix`,
+`detectable_bins`, `max_dist`, `inter`); every rank passes the same list (or builds the same
+list lazily through `loader`), processes its own share and receives the gathered result.
+"""
+import numpy as np
+
+RECORD_FIELDS = ("block", "bin1", "bin2", "score", "pvalue")
+
+
+def block_cost(shape, max_dist, inter):
+    """Pixels the correlation scans for one sub-matrix (SURVEY.md 8(d) unit of work)."""
+    rows, cols = shape
+    if inter or max_dist is None:
+        return int(rows) * int(cols)
+    return int(rows) * int(min(max_dist + 1, cols))
+
+
+def assign_blocks(costs, world_size):
+    """Longest-processing-time-first assignment of blocks to ranks.  Returns a list with, for
+    every rank, the (sorted) indices of its blocks; deterministic, identical on every rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0] * world_size
+    owned = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owned[r].append(i)
+        load[r] += costs[i]
+    return [sorted(o) for o in owned]
+
+
+def _world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist, dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return None, 0, 1
+
+
+def gather_records(records, device=None):
+    """All-gather variable-length float64 record arrays (n_i x n_fields) from every rank.
+    Count exchange followed by one padded all_gather (fixed-size records)."""
+    dist, rank, world = _world()
+    records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, len(RECORD_FIELDS))
+    if dist is None or world == 1:
+        return records
+    import torch
+    dev = device if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    count = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    padded = torch.zeros((width, len(RECORD_FIELDS)), dtype=torch.float64, device=dev)
+    if records.shape[0]:
+        padded[:records.shape[0]] = torch.from_numpy(records).to(dev)
+    parts = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    out = [p[:c].cpu().numpy() for p, c in zip(parts, counts)]
+    merged = np.concatenate(out, axis=0) if out else records
+    # block order, then the per-block order of pattern_detector (stable)
+    return merged[np.argsort(merged[:, 0], kind="stable")]
+
+
+def detect_blocks(blocks, kernel_config, kernel_matrix, detector=None, full=True, tsvd=None,
+                  loader=None, coords=None):
+    """Run pattern_detector on this rank's share of `blocks` and gather all tables.
+
+    blocks : list of contact-map-like objects, or of lightweight descriptors when `loader`
+        (a callable descriptor -> contact map) is given; every descriptor needs `.shape`,
+        `.max_dist`, `.inter` (the contact maps themselves are only built by the owning rank).
+    coords : optional list (one entry per block, or None) of coordinate arrays -> quantify mode.
+    Returns a float64 array of records (block, bin1, bin2, score, pvalue), identical on all ranks.
+    """
+    if detector is None:
+        from .utils.detection import pattern_detector as detector
+    dist, rank, world = _world()
+    costs = []
+    for b in blocks:
+        shape = b.shape if hasattr(b, "shape") and not hasattr(b, "matrix") else b.matrix.shape
+        costs.append(block_cost(shape, b.max_dist, b.inter))
+    mine = assign_blocks(costs, world)[rank]
+    rows = []
+    for idx in mine:
+        cmap = loader(blocks[idx]) if loader is not None else blocks[idx]
+        block_coords = None if coords is None else coords[idx]
+        if coords is not None and block_coords is None:
+            continue
+        table, _ = detector(cmap, kernel_config, kernel_matrix, coords=block_coords, full=full, tsvd=tsvd)
+        if table is None or len(table) == 0:
+            continue
+        rec = np.empty((len(table), len(RECORD_FIELDS)))
+        rec[:, 0] = idx
+        rec[:, 1] = table["bin1"].to_numpy(dtype=np.float64)
+        rec[:, 2] = table["bin2"].to_numpy(dtype=np.float64)
+        rec[:, 3] = table["score"].to_numpy(dtype=np.float64)
+        rec[:, 4] = table["pvalue"].to_numpy(dtype=np.float64)
+        rows.append(rec)
+    local = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(RECORD_FIELDS)))
+    return gather_records(local)

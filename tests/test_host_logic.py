@@ -1,0 +1,226 @@
+"""Host-side logic of the API mirror (no GPU): masks, trims, padding, foci labelling and picking,
+window validation, neighbour removal, template editing, statistics -- against the vectors
+generated from the reference (tests/golden/make_golden.py) and the known answers of the
+reference's own tests."""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+from chromosight_amd.utils import detection as cud
+from chromosight_amd.utils import preprocessing as cup
+from chromosight_amd.utils import stats as cus
+
+
+def coo(g, prefix):
+    shape = tuple(g[f"{prefix}_shape"])
+    return sp.coo_matrix((g[f"{prefix}_val"], (g[f"{prefix}_row"], g[f"{prefix}_col"])), shape=shape)
+
+
+# ------------------------------------------------------------------------------------------ masks
+def test_masks_match_reference(golden):
+    g = golden("masks")
+    for i in range(int(g["n_sym"])):
+        n = int(g[f"sym{i}_n"])
+        ks = tuple(int(x) for x in g[f"sym{i}_kshape"])
+        md = int(g[f"sym{i}_max_dist"])
+        md = None if md < 0 else md
+        valid = g[f"sym{i}_valid"]
+        mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+        ref = np.unpackbits(g[f"sym{i}_mask"])[:n * n].reshape(n, n).astype(bool)
+        assert mask.dtype == bool and np.array_equal(mask.toarray(), ref), i
+        framed = cup.frame_missing_mask(mask, ks, sym_upper=True, max_dist=md)
+        H, W = n + 2 * (ks[0] - 1), n + 2 * (ks[1] - 1)
+        ref = np.unpackbits(g[f"sym{i}_framed"])[:H * W].reshape(H, W).astype(bool)
+        assert np.array_equal(framed.toarray(), ref), i
+    for i in range(int(g["n_inter"])):
+        shape = tuple(int(x) for x in g[f"inter{i}_shape"])
+        ks = tuple(int(x) for x in g[f"inter{i}_kshape"])
+        mask = cup.make_missing_mask(shape, g[f"inter{i}_valid_rows"], g[f"inter{i}_valid_cols"])
+        ref = np.unpackbits(g[f"inter{i}_mask"])[:shape[0] * shape[1]].reshape(shape).astype(bool)
+        assert np.array_equal(mask.toarray(), ref)
+        framed = cup.frame_missing_mask(mask, ks, sym_upper=False, max_dist=None)
+        H, W = shape[0] + 2 * (ks[0] - 1), shape[1] + 2 * (ks[1] - 1)
+        ref = np.unpackbits(g[f"inter{i}_framed"])[:H * W].reshape(H, W).astype(bool)
+        assert np.array_equal(framed.toarray(), ref)
+
+
+def test_make_missing_mask_reference_example():
+    """Same expectations as the reference's test (tests/test_preprocessing.py:49-97)."""
+    missing = np.array([0, 4, 9])
+    valid = np.array([i for i in range(10) if i not in missing])
+    valid_cols = np.array([i for i in range(15) if i not in missing])
+    exp_sym = np.zeros((10, 10), dtype=bool)
+    exp_sym[:, missing] = True
+    exp_sym[missing, :] = True
+    exp_asym = np.zeros((10, 15), dtype=bool)
+    exp_asym[:, missing] = True
+    exp_asym[missing, :] = True
+    assert np.array_equal(cup.make_missing_mask((10, 10), valid, valid, sym_upper=False).toarray(), exp_sym)
+    assert np.array_equal(cup.make_missing_mask((10, 10), valid, valid, sym_upper=True).toarray(), np.triu(exp_sym))
+    assert np.array_equal(cup.make_missing_mask((10, 15), valid, valid_cols).toarray(), exp_asym)
+    with pytest.raises(ValueError):
+        cup.make_missing_mask((10, 15), valid, valid, sym_upper=True)
+    trimmed = cup.diag_trim(np.triu(exp_sym), 3 + 1)
+    got = cup.make_missing_mask((10, 10), valid, valid, sym_upper=True, max_dist=3)
+    assert np.array_equal(got.toarray(), trimmed)
+
+
+def test_check_missing_mask():
+    sig = sp.csr_matrix(np.array([[0.0, 1.0], [2.0, 0.0]]))
+    ok = sp.csr_matrix(np.array([[True, False], [False, True]]))
+    cup.check_missing_mask(sig, ok)
+    with pytest.raises(ValueError):
+        cup.check_missing_mask(sig, sp.csr_matrix(np.array([[True, True], [False, False]])))
+    with pytest.raises(ValueError):
+        cup.check_missing_mask(sig.toarray(), np.array([[1, 1], [0, 0]]))
+
+
+def test_diag_trim_and_pad():
+    rng = np.random.default_rng(0)
+    m = sp.csr_matrix(rng.random((30, 30)))
+    for d in (0, 1, 5, 29):
+        t = cup.diag_trim(m, d)
+        assert t.shape == m.shape
+        dense = t.toarray()
+        ii, jj = np.indices(dense.shape)
+        assert np.all(dense[(jj - ii < 0) | (jj - ii > d)] == 0)
+        assert np.array_equal(dense[(jj - ii >= 0) & (jj - ii <= d)], m.toarray()[(jj - ii >= 0) & (jj - ii <= d)])
+    with pytest.raises(ValueError):
+        cup.diag_trim(m.tocoo(), 3)
+    base = sp.coo_matrix(np.ones((10, 10)))
+    for hpad in range(4):
+        for vpad in range(4):
+            padded = cup.zero_pad_sparse(base, margin_h=hpad, margin_v=vpad)
+            assert padded.shape == (10 + 2 * vpad, 10 + 2 * hpad)
+            assert np.all(padded.toarray()[vpad:padded.shape[0] - vpad, hpad:padded.shape[1] - hpad] == 1)
+            assert padded.sum() == 100
+
+
+# ------------------------------------------------------------------------------------------ foci
+def test_label_foci_reference_example(golden):
+    g = golden("nms")
+    nf, lab = cud.label_foci(sp.coo_matrix(g["spec_in"]))
+    assert nf == int(g["spec_num"])
+    assert np.array_equal(lab.toarray(), g["spec_labels"])
+    n2, _ = cud.filter_foci(sp.coo_matrix(lab.toarray()), min_size=2)
+    n3, _ = cud.filter_foci(sp.coo_matrix(lab.toarray()), min_size=3)
+    assert (n2, n3) == (int(g["spec_num_min2"]), int(g["spec_num_min3"]))
+
+
+def test_pick_foci_matches_reference(golden):
+    g = golden("nms")
+    tags = sorted({k[:-len("_pearson")] for k in g if k.endswith("_pearson")})
+    assert len(tags) == 15
+    n_with_foci = 0
+    for tag in tags:
+        conv = coo(g, f"{tag}_conv")
+        foci, lab = cud.pick_foci(conv, float(g[f"{tag}_pearson"]))
+        ref = g[f"{tag}_foci"]
+        if ref.shape[0] == 0:
+            assert foci is None
+            continue
+        n_with_foci += 1
+        assert np.array_equal(foci, ref), tag          # same coordinates, same order
+        assert np.array_equal(lab.toarray(), coo(g, f"{tag}_labels").toarray()), tag
+    assert n_with_foci >= 10
+
+
+def test_pick_foci_speckles_and_index():
+    point = np.zeros((10, 10))
+    point[5, 5] = point[2, 2] = 0.3
+    coords, _ = cud.pick_foci(sp.coo_matrix(point), 0.1)
+    assert coords is None                               # isolated pixels are dropped
+    m = np.zeros((12, 12))
+    m[3, 4] = 0.5
+    m[3, 5] = 0.9
+    m[4, 5] = 0.9                                       # tie: first in row-major order wins
+    coords, _ = cud.pick_foci(sp.coo_matrix(m), 0.4)
+    assert coords.tolist() == [[3, 5]]
+
+
+def test_remove_neighbours_matches_reference(golden):
+    g = golden("nms")
+    pts = pd.DataFrame(g["rn_patterns"], columns=["bin1", "bin2", "score"])
+    assert np.array_equal(cud.remove_neighbours(pts, win_size=5), g["rn_keep_w5"])
+    assert np.array_equal(cud.remove_neighbours(pts, win_size=1), g["rn_keep_w1"])
+
+
+def test_validate_patterns_rules():
+    rng = np.random.default_rng(4)
+    mat = sp.csr_matrix(np.triu(rng.random((40, 40)) + 0.1))
+    conv = sp.csr_matrix(np.triu(rng.random((40, 40))))
+    det = (np.ones(40, dtype=bool), np.ones(40, dtype=bool))
+    kernel = np.ones((7, 7))
+    coords = np.array([[20, 25], [2, 30], [36, 39], [10, 10]])
+    tab, wins = cud.validate_patterns(coords, mat, conv, det, kernel, zero_tol=0.9, missing_tol=0.5)
+    # windows leaving the matrix are dropped (strict bound: low < shape)
+    assert tab[["bin1", "bin2"]].to_numpy().tolist() == [[20, 25], [10, 10]]
+    assert np.allclose(tab["score"].to_numpy(), [conv[20, 25], conv[10, 10]])
+    assert np.array_equal(wins[0], mat[17:24, 22:29].toarray())
+    tab, wins = cud.validate_patterns(coords, mat, conv, det, kernel, drop=False, zero_tol=0.9, missing_tol=0.5)
+    assert len(tab) == 4 and np.isnan(tab["score"].to_numpy()[[1, 2]]).all()
+    # missing bins -> NaN rows/cols, rejected above missing_tol
+    det2 = (np.setdiff1d(np.arange(40), [19, 20, 21, 22]), np.arange(40))
+    tab, _ = cud.validate_patterns(coords[:1], mat, conv, det2, kernel, zero_tol=0.9, missing_tol=0.5)
+    assert len(tab) == 0
+    assert np.isnan(cud.pileup_patterns(np.full((2, 3, 3), np.nan))).all()
+
+
+# ------------------------------------------------------------------------------------------ templates / stats
+def test_factorise_kernel(golden, templates):
+    g = golden("xcorr2")
+    u, v = cup.factorise_kernel(templates["loops"].copy(), prop_info=0.999)
+    assert u.shape == g["loops_tsvd999_u"].shape == (17, 2)
+    assert np.allclose(u @ v, g["loops_tsvd999_u"] @ g["loops_tsvd999_v"], atol=1e-12)
+
+
+def test_resize_and_crop_kernel():
+    m = 15
+    point = np.zeros((m, m))
+    point[m // 2, m // 2] = 10
+    for kernel_res in (3, 4, 6, 10):
+        for signal_res in (3, 4, 6, 10):
+            exp = int(m * kernel_res / signal_res)
+            exp -= 0 if exp % 2 else 1
+            a = cup.resize_kernel(point, kernel_res=kernel_res, signal_res=signal_res, min_size=5, quiet=True)
+            b = cup.resize_kernel(point, factor=kernel_res / signal_res, min_size=5, quiet=True)
+            assert a.shape == b.shape == (max(exp, 5),) * 2
+            assert a.max() == a[a.shape[0] // 2, a.shape[0] // 2]
+    for targ in range(20):
+        exp = targ if targ % 2 else targ + 1
+        assert cup.crop_kernel(point, (targ, targ)).shape[0] == min(exp, m)
+    with pytest.raises(ValueError):
+        cup.resize_kernel(np.ones((4, 4)), factor=1)
+
+
+def test_isotonic_smoothing():
+    assert np.allclose(cup._isotonic_non_increasing([3.0, 3.5, 4.0]), [3.5, 3.5, 3.5])
+    assert np.allclose(cup._isotonic_non_increasing([5, 4, 4.5, 1]), [5, 4.25, 4.25, 1])
+    sk = pytest.importorskip("sklearn.isotonic")
+    rng = np.random.default_rng(1)
+    y = np.sort(rng.random(200))[::-1] + rng.normal(0, 0.05, 200)
+    ref = sk.IsotonicRegression(increasing=False).fit_transform(range(200), y)
+    assert np.allclose(cup._isotonic_non_increasing(y), ref, atol=1e-12)
+
+
+def test_stats(golden):
+    g = golden("stats")
+    assert np.allclose(cus.fdr_correction(g["pvals"]), g["qvals"], rtol=0, atol=1e-15)
+    # Benjamini-Hochberg known answer of the reference's test (tests/test_stats.py:5-12)
+    assert np.allclose(cus.fdr_correction(np.array([0.01, 0.02, 0.03, 0.5])), [0.04, 0.04, 0.04, 0.5])
+    lp = cus.corr_to_pval(g["r"], g["n"].astype(float))
+    fin = np.isfinite(g["logp_vec"])
+    assert np.allclose(lp[fin], g["logp_vec"][fin], rtol=0, atol=1e-12)
+    assert np.allclose(cus.corr_to_pval(g["r"], 289)[fin], g["logp_289"][fin], rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        cus.corr_to_pval(np.zeros(3), np.zeros(4))
+    assert cus.fdr_correction(None) is None
+
+
+def test_kernels_module():
+    import chromosight_amd.kernels as ck
+    assert set(ck.kernel_names) >= {"loops", "borders", "hairpins", "loops_small", "centromeres"}
+    assert ck.loops["kernels"][0].shape == (17, 17) and len(ck.borders["kernels"]) == 3
+    assert ck.hairpins["kernels"][0].shape == (15, 15) and ck.loops["pearson"] == 0.3
+    assert ck.borders["max_dist"] == 0 and ck.loops["max_perc_undetected"] == 50.0

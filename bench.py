@@ -148,6 +148,25 @@ def cpu_baseline(workload, budget_s=12.0):
     }
 
 
+def detect_wallclock():
+    """Second half of the BASELINE.json metric: `detect` wall-clock (loops defaults) on the
+    reference's test map, data_test/example.cool (decoded fixture tests/golden/example_cool.npz),
+    whole pipeline: block assembly, detrend, correlation, foci, validation, post-filters."""
+    import copy
+    import chromosight_amd.kernels as ck
+    from chromosight_amd import pipeline
+    path = os.path.join(ROOT, "tests", "golden", "example_cool.npz")
+    if not os.path.exists(path):
+        return None
+    cool = dict(np.load(path))
+    pipeline.detect(cool, copy.deepcopy(ck.loops))          # warm-up (module imports, weight upload)
+    t0 = time.perf_counter()
+    table = pipeline.detect(cool, copy.deepcopy(ck.loops))
+    dt = time.perf_counter() - t0
+    return {"seconds": round(dt, 4), "patterns": int(len(table)), "expected_patterns": 89,
+            "input": "data_test/example.cool (720 bins, 3 chromosomes), loops defaults, 1 GPU"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -233,6 +252,10 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
         }
         if not args.no_cpu_baseline:
+            try:
+                out["detect_wallclock"] = detect_wallclock()
+            except Exception as exc:
+                out["detect_wallclock"] = {"error": repr(exc)}
             try:
                 out["cpu_baseline"] = cpu_baseline(wl)
             except Exception as exc:  # the baseline is a reported extra, never the measured path

@@ -157,11 +157,11 @@ template <>
 int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
-    if (allow_fast && A.mask_mode == 0 && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
-        cs::corr_fast_tile_k##KK(A.ms, A.ns, ctx->n_cu, &tw, &th);  \
+        cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
         fill_grid(A, tw, th);                \
         rc = cs::launch_corr_fast_f32_k##KK(A, stream); \
         break;
@@ -187,11 +187,11 @@ template <>
 int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
-    if (allow_fast && A.mask_mode == 0 && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
-        cs::corr_fast_tile_k##KK(A.ms, A.ns, ctx->n_cu, &tw, &th);  \
+        cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
         fill_grid(A, tw, th);                \
         rc = cs::launch_corr_fast_f64_k##KK(A, stream); \
         break;

@@ -40,15 +40,23 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.strips_x = A.tiles_x;
     S.strips_y = A.tiles_y;
     S.ks = A.ks;
+    S.mask_mode = A.mask_mode;
+    S.max_dist = A.max_dist;
+    S.miss_row = A.miss_row;
+    S.miss_col = A.miss_col;
+    S.mask = (const uint8_t*)A.mask.ptr;
     const int n_waves = A.tiles_x * A.tiles_y;
     const int blocks = (n_waves + G::NWAVES - 1) / G::NWAVES;
-    auto kern = corr_stream_kernel<TC, CS_K>;
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem, stream, S);
-    return (int)hipGetLastError();
+    auto launch = [&](auto kern) -> int {
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem, stream, S);
+        return (int)hipGetLastError();
+    };
+    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, true>);
+    return launch(corr_stream_kernel<TC, CS_K, false>);
 }
 
 #define CS_CAT_(a, b) a##b
@@ -58,14 +66,17 @@ int CS_CAT(launch_corr_fast_f32_k, CS_K)(const CorrArgs<float>& A, hipStream_t s
 int CS_CAT(launch_corr_fast_f64_k, CS_K)(const CorrArgs<double>& A, hipStream_t s) { return launch_fast<double>(A, s); }
 
 // strip geometry: 128 columns per wave; the strip height trades the K-1 warm-up rows of every
-// strip against having enough waves to fill 256 CUs x 4 SIMDs a few times over
-void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int n_cu, int* tw, int* th)
+// strip (and, for band outputs, the part of a rectangular strip that falls outside the diagonal
+// band) against having enough waves to fill 256 CUs x 4 SIMDs a few times over.
+// band_w = number of output diagonals (0 for dense outputs).
+void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int band_w, int n_cu, int* tw, int* th)
 {
     *tw = StreamGeom<CS_K>::TW;
-    int h = 256;
+    int h = band_w > 0 ? 64 : 256;
     const long long want = (long long)n_cu * 4 * 2;  // at least ~2 waves per SIMD
     while (h > 32) {
-        const long long waves = (long long)((ns + *tw - 1) / *tw) * ((ms + h - 1) / h);
+        const long long sx = band_w > 0 ? (band_w + h + *tw - 1) / *tw + 1 : (ns + *tw - 1) / *tw;
+        const long long waves = sx * ((ms + h - 1) / h);
         if (waves >= want) break;
         h >>= 1;
     }

@@ -50,6 +50,22 @@ using ConstPtr = const __attribute__((address_space(4))) TC*;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Missing pixels are carried inside the staged signal as -0.0: the reference guarantees that a
+// missing pixel holds no signal (check_missing_mask, preprocessing.py:501-532), -0.0 adds nothing
+// to any window sum, and the mask is recovered from the bit pattern, so the masked kernel needs no
+// second LDS ring.  Genuine zeros (either sign) are staged as +0.0.
+template <typename TC>
+__device__ __forceinline__ TC encode_pixel(TC v, bool missing)
+{
+    v = (v == TC(0)) ? TC(0) : v;
+    return missing ? -TC(0) : v;
+}
+__device__ __forceinline__ float missing_flag(float v) { return (__float_as_uint(v) == 0x80000000u) ? 1.0f : 0.0f; }
+__device__ __forceinline__ double missing_flag(double v)
+{
+    return ((unsigned long long)__double_as_longlong(v) == 0x8000000000000000ull) ? 1.0 : 0.0;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x8 __attribute__((ext_vector_type(8)));
 
@@ -164,6 +180,11 @@ struct RowRegs {
         out[1] = a1;
     }
     __device__ __forceinline__ TC at(int t) const { return v[t]; }
+    __device__ __forceinline__ void to_missing_flags()
+    {
+#pragma unroll
+        for (int t = 0; t < K + 1; ++t) v[t] = missing_flag(v[t]);
+    }
 };
 
 // float32: the row is kept as even pairs (v[2m], v[2m+1]) and odd pairs (v[2m+1], v[2m+2]) so
@@ -205,6 +226,19 @@ struct RowRegs<float, K> {
         out[1] = a.y;
     }
     __device__ __forceinline__ float at(int t) const { return (t & 1) ? e[t >> 1].y : e[t >> 1].x; }
+    __device__ __forceinline__ void to_missing_flags()
+    {
+#pragma unroll
+        for (int m = 0; m < NE; ++m) {
+            e[m].x = missing_flag(e[m].x);
+            e[m].y = missing_flag(e[m].y);
+        }
+#pragma unroll
+        for (int m = 0; m < NO; ++m) {
+            o[m].x = e[m].y;
+            o[m].y = e[m + 1].x;
+        }
+    }
 };
 
 // horizontal K-sums of one staged row for this lane's two columns
@@ -266,10 +300,52 @@ struct StreamArgs {
     int ms, ns;
     int full, sym_upper;
     int strip_h, strips_x, strips_y;
+    // missing mask (MASKED kernels only)
+    int mask_mode;                 // 1: per-bin flags, 2: explicit uint8 map with the signal's geometry
+    int max_dist;                  // -1: None
+    const uint8_t* miss_row;
+    const uint8_t* miss_col;
+    const uint8_t* mask;
     KernelStats<TC> ks;
 };
 
+// framed missing predicate (same rules as cs_device.h missing_pred) on the lean argument block
 template <typename TC, int K>
+__device__ __forceinline__ bool stream_missing(const StreamArgs<TC>& A, int p, int q, bool cflag, bool rflag,
+                                               long long sig_idx, bool stored)
+{
+    const bool in_r = (p >= 0) & (p < A.ms);
+    const bool in_c = (q >= 0) & (q < A.ns);
+    const int d = q - p;
+    const bool have_md = A.max_dist >= 0;
+    bool m;
+    if (in_r & in_c) {
+        if (A.mask_mode == 1) {
+            m = rflag | cflag;
+            if (A.sym_upper) {
+                const int md = have_md ? A.max_dist : min(A.ms, A.ns);
+                m = m & (d >= 0) & (d <= md);
+            }
+        } else {
+            m = stored ? (A.mask[sig_idx] != 0) : false;
+            if (A.full && A.sym_upper && have_md) m = m & (d >= 0) & (d <= A.max_dist + K);
+        }
+        if (!A.full) return m;
+    } else {
+        if (!A.full) return false;
+        if (A.sym_upper && have_md) {
+            if (q >= A.ns) m = p >= A.ms - A.max_dist - 2;
+            else if (p < 0) m = (q < 0) ? true : (q < A.max_dist + K);
+            else m = false;
+        } else {
+            m = true;
+        }
+    }
+    if (A.sym_upper) m = m | ((d <= -1) & (d >= -K));
+    return m;
+}
+
+template <typename TC, int K, bool MASKED>
 __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
@@ -316,9 +392,24 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A
     for (int e = 0; e < 4; ++e) col_ok[e] = (lane * 4 + e < G::LW) & (q_lane + e >= 0) & (q_lane + e < A.ns);
     const bool stage_lane = lane * 4 < G::LWP;
 
+    bool cflag[4] = {false, false, false, false};
+    if constexpr (MASKED) {
+        if (A.mask_mode == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = q_lane + e;
+                cflag[e] = (q >= 0 && q < A.ns) ? (A.miss_col[q] != 0) : false;
+            }
+        }
+    }
     auto fetch = [&](int t, TC (&x)[4]) {
         const int p = p_first + t;
-        const bool row_ok = (p >= 0) & (p < A.ms) & (t < n_staged);
+        const bool row_in = (p >= 0) & (p < A.ms);
+        const bool row_ok = row_in & (t < n_staged);
+        bool rflag = false;
+        if constexpr (MASKED) {
+            if (A.mask_mode == 1) rflag = row_in ? (A.miss_row[p] != 0) : false;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool ok = row_ok & col_ok[e] & (A.band_in ? ((unsigned)(dd + e) < bw) : true);
@@ -326,7 +417,13 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A
             TC val;
             if (A.sig_is_f64) val = (TC)((const double*)A.sig)[idx];
             else val = (TC)((const float*)A.sig)[idx];
-            x[e] = ok ? val : TC(0);
+            val = ok ? val : TC(0);
+            if constexpr (MASKED) {
+                const bool miss = (lane * 4 + e < G::LW) &&
+                                  stream_missing<TC, K>(A, p, q_lane + e, cflag[e], rflag, idx, ok);
+                val = encode_pixel(val, miss);
+            }
+            x[e] = val;
         }
         in_idx += in_step;
         dd += dd_step;
@@ -359,6 +456,11 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A
     // (row entering) - (row leaving).  The difference of the two float32 horizontal partials is
     // accumulated in float64, so the rounding does not grow with the strip height.
     double b1[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
+    // masked kernels: rotating accumulators of sum_missing Wa and sum_missing Wb, running count
+    TC ka[MASKED ? K : 1][2], kb[MASKED ? K : 1][2];
+    TC nmiss[2] = {TC(0), TC(0)};
+#pragma unroll
+    for (int s = 0; s < (MASKED ? K : 1); ++s) ka[s][0] = ka[s][1] = kb[s][0] = kb[s][1] = TC(0);
 
     {
         TC x[4];
@@ -388,11 +490,33 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A
                 b1[c] += (double)(h1[c] - g1[c]);
                 b2[c] += (double)(h2[c] - g2[c]);
             }
+            if constexpr (MASKED) {
+                // number of missing pixels in the window: same sliding scheme on the 0/1 flags
+                // (small integers, exact in floating point)
+                vo.to_missing_flags();
+                TC c0 = vo.at(0);
+#pragma unroll
+                for (int t = 1; t < K; ++t) c0 += vo.at(t);
+                nmiss[0] -= c0;
+                nmiss[1] -= (c0 - vo.at(0)) + vo.at(K);
+            }
         }
 
         // rotating accumulators, highest slot first so that acc[s] can be overwritten in place;
         // the weights of slot s-1 are in flight while slot s computes (two scalar buffers)
         slots<K - 1>(v, A.w, acc);
+        if constexpr (MASKED) {
+            // the row registers are dead: turn them into the 0/1 missing flags in place and run the
+            // same rotating scheme with the two mask weight sets
+            v.to_missing_flags();
+            TC c0 = v.at(0);
+#pragma unroll
+            for (int t = 1; t < K; ++t) c0 += v.at(t);
+            nmiss[0] += c0;
+            nmiss[1] += (c0 - v.at(0)) + v.at(K);
+            slots<K - 1>(v, A.w + (unsigned long long)(K * K * sizeof(TC)), ka);
+            slots<K - 1>(v, A.w + (unsigned long long)(2 * K * K * sizeof(TC)), kb);
+        }
 
         if (t >= K - 1) {
             const int oi = i0 + t - (K - 1);
@@ -403,7 +527,11 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A
                 const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi);
                 const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
                 TC r;
-                if constexpr (sizeof(TC) == 4) {
+                if constexpr (MASKED) {
+                    TC nobs;
+                    r = pearson_from_sums<TC>(acc[K - 1][c], (TC)b1[c], (TC)b2[c], nmiss[c], ka[K - 1][c],
+                                              kb[K - 1][c], A.ks, true, &nobs);
+                } else if constexpr (sizeof(TC) == 4) {
                     r = pearson_nomask_f32(acc[K - 1][c], (float)b1[c], (float)b2[c], A.ks);
                 } else {
                     TC nobs;

@@ -8,7 +8,7 @@ namespace cs {
 #define CS_DECL_FAST(K)                                                        \
     int launch_corr_fast_f32_k##K(const CorrArgs<float>& A, hipStream_t s);    \
     int launch_corr_fast_f64_k##K(const CorrArgs<double>& A, hipStream_t s);   \
-    void corr_fast_tile_k##K(int ms, int ns, int n_cu, int* tw, int* th);
+    void corr_fast_tile_k##K(int ms, int ns, int band_w, int n_cu, int* tw, int* th);
 CS_DECL_FAST(7)
 CS_DECL_FAST(9)
 CS_DECL_FAST(11)

@@ -9,11 +9,12 @@
 //     STRIP_H output rows.  No block-level barrier: each wave has a private LDS ring of the last
 //     RING staged rows.  Lane l reads its K+1 consecutive values of a row with aligned
 //     ds_read_b64 (conflict free).
-//   * K rotating accumulators per column: after staged row t, acc[s] holds the partial sum of
-//     output row t - s over template rows 0..s.  Row t+1 turns slot s into slot s+1
-//     (acc[s+1] = acc[s] + row * W[s+1], written in place by the first FMA, no moves), slot K-1
-//     completes an output row.  Every staged value is therefore loaded once and used K times
-//     per column from registers.
+//   * Rotating accumulators: X[s] is the partial sum of output row (t-1-s) over template rows
+//     0..s.  Each loop iteration consumes TWO staged rows (A = t, B = t+1) per template row s:
+//         y_s = X[s-1] + A * W[s]      z_s = y_(s-1) + B * W[s]      X'[s] = z_s
+//     so one scalar load of W[s] feeds 2*K packed FMAs in two independent dependency chains,
+//     y_(K-1) and z_(K-1) complete two output rows, and every staged value is loaded once and
+//     used K times per column from registers.
 //   * Template weights are wave-uniform: one s_load of a template row (K scalars) feeds K packed
 //     FMAs.  The float32 math is v_pk_fma_f32 on the lane's (column, column+1) accumulator pair
 //     with an SGPR weight: measured on MI355X (tools/ubench/fma_rate.hip) v_pk_fma_f32 with a
@@ -39,7 +40,7 @@ struct StreamGeom {
     static constexpr int TW = kWave * RW;           // 128 output columns per wave
     static constexpr int LW = TW + K - 1;           // staged columns per row
     static constexpr int LWP = ((LW + 3) / 4) * 4;  // row pitch in elements (16-byte multiple)
-    static constexpr int RING = K + 2;              // rows t-K .. t+1 are live
+    static constexpr int RING = K + 4;              // rows t-K .. t+3 are live (two rows per iteration)
     static constexpr int NWAVES = 4;                // independent waves per workgroup
 };
 
@@ -157,6 +158,38 @@ struct WRow<double, K> {
     }
 };
 
+// accumulator of the lane's two adjacent output columns
+template <typename TC>
+struct Pair2 {
+    TC x, y;
+};
+template <typename TC>
+struct AccSel {
+    using type = Pair2<TC>;
+};
+template <>
+struct AccSel<float> {
+    using type = f32x2;
+};
+template <typename TC>
+using acc_t = typename AccSel<TC>::type;
+
+__device__ __forceinline__ void pin_acc(f32x2& a) { asm volatile("" : "+v"(a)); }
+template <typename TC>
+__device__ __forceinline__ void pin_acc(Pair2<TC>& a)
+{
+    asm volatile("" : "+v"(a.x), "+v"(a.y));
+}
+
+template <typename TC>
+__device__ __forceinline__ acc_t<TC> acc_zero()
+{
+    acc_t<TC> a;
+    a.x = TC(0);
+    a.y = TC(0);
+    return a;
+}
+
 // Staged row of one lane: K+1 consecutive values v[0..K] starting at its first output column.
 template <typename TC, int K>
 struct RowRegs {
@@ -178,6 +211,13 @@ struct RowRegs {
         }
         out[0] = a0;
         out[1] = a1;
+    }
+    // a += (v[KJ], v[KJ+1]) * w[KJ]
+    template <int KJ>
+    __device__ __forceinline__ void fma(const WRow<TC, K>& wk, acc_t<TC>& a) const
+    {
+        a.x = cs_fma(v[KJ], wk.get(KJ), a.x);
+        a.y = cs_fma(v[KJ + 1], wk.get(KJ), a.y);
     }
     __device__ __forceinline__ TC at(int t) const { return v[t]; }
     __device__ __forceinline__ void to_missing_flags()
@@ -224,6 +264,13 @@ struct RowRegs<float, K> {
         a += b;
         out[0] = a.x;
         out[1] = a.y;
+    }
+    // a += (v[KJ], v[KJ+1]) * w[KJ]: one v_pk_fma_f32 on an aligned pair
+    template <int KJ>
+    __device__ __forceinline__ void fma(const WRow<float, K>& wk, f32x2& a) const
+    {
+        if constexpr (KJ & 1) a = pk_fma_w<KJ>(o[KJ >> 1], wk.template pair<KJ>(), a);
+        else a = pk_fma_w<KJ>(e[KJ >> 1], wk.template pair<KJ>(), a);
     }
     __device__ __forceinline__ float at(int t) const { return (t & 1) ? e[t >> 1].y : e[t >> 1].x; }
     __device__ __forceinline__ void to_missing_flags()
@@ -286,6 +333,62 @@ __device__ __forceinline__ void slots(const RowRegs<TC, K>& v, unsigned long lon
     slots_rec<STOP, TC, K>(v, w_base, acc, wa, wb);
 }
 
+// Two staged rows against template row S (ascending S): see the header comment.  Compile-time
+// recursion: every s_load has an immediate offset and the two scalar weight buffers alternate
+// statically.  The load of W[S+1] is issued right after the wait for W[S] and is in flight during
+// the 2*K packed FMAs of this step.
+template <int KJ, typename TC, int K>
+__device__ __forceinline__ void two_chains(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, const WRow<TC, K>& wk,
+                                           acc_t<TC>& y, acc_t<TC>& z)
+{
+    if constexpr (KJ < K) {
+        A.template fma<KJ>(wk, y);
+        B.template fma<KJ>(wk, z);
+        two_chains<KJ + 1, TC, K>(A, B, wk, y, z);
+    }
+}
+
+template <int S, typename TC, int K, int W_OFF>
+__device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
+                                           acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB,
+                                           acc_t<TC> yprev, acc_t<TC> zprev, WRow<TC, K>& cur, WRow<TC, K>& nxt)
+{
+    cur.wait();
+    if constexpr (S < K - 1) nxt.template issue<W_OFF + (S + 1) * K * (int)sizeof(TC)>(w_base);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_t<TC> y, z;
+    if constexpr (S > 0) {
+        y = X[S - 1];
+        z = yprev;
+    } else {
+        y = acc_zero<TC>();
+        z = acc_zero<TC>();
+    }
+    two_chains<0, TC, K>(A, B, cur, y, z);
+    if constexpr (S > 0) X[S - 1] = zprev;
+    // pin this step's FMAs between the two hand-placed scalar loads: without a (volatile) use of
+    // their results the optimiser sinks them below all K loads and spills the weights
+    pin_acc(y);
+    pin_acc(z);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S < K - 1) {
+        steps2_rec<S + 1, TC, K, W_OFF>(A, B, w_base, X, outA, outB, y, z, nxt, cur);
+    } else {
+        outA = y;
+        outB = z;
+    }
+}
+
+// W_OFF: byte offset of the weight set inside the weight buffer (0 = signal weights)
+template <typename TC, int K, int W_OFF>
+__device__ __forceinline__ void steps2(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
+                                       acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB)
+{
+    WRow<TC, K> wa, wb;
+    wa.template issue<W_OFF>(w_base);
+    steps2_rec<0, TC, K, W_OFF>(A, B, w_base, X, outA, outB, acc_zero<TC>(), acc_zero<TC>(), wa, wb);
+}
+
 // Lean view of the launch arguments (only what the row loop needs stays in registers).
 template <typename TC>
 struct StreamArgs {
@@ -346,7 +449,7 @@ __device__ __forceinline__ bool stream_missing(const StreamArgs<TC>& A, int p, i
 }
 
 template <typename TC, int K, bool MASKED>
-__global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A)
+__global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
     constexpr int KH = (K - 1) / 2;
@@ -449,108 +552,149 @@ __global__ __launch_bounds__(256) void corr_stream_kernel(const StreamArgs<TC> A
         ocol_margin[c] = !A.full && ((oj0 + c < KH) | (oj0 + c > A.ns - K + KH));
     }
 
-    TC acc[K][2];
+    acc_t<TC> X[K - 1];
 #pragma unroll
-    for (int s = 0; s < K; ++s) acc[s][0] = acc[s][1] = TC(0);
+    for (int s = 0; s < K - 1; ++s) X[s] = acc_zero<TC>();
     // running box sums (sum S, sum S^2 over the K staged rows of the window), updated by
     // (row entering) - (row leaving).  The difference of the two float32 horizontal partials is
     // accumulated in float64, so the rounding does not grow with the strip height.
     double b1[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
     // masked kernels: rotating accumulators of sum_missing Wa and sum_missing Wb, running count
-    TC ka[MASKED ? K : 1][2], kb[MASKED ? K : 1][2];
+    acc_t<TC> XA[MASKED ? K - 1 : 1], XB[MASKED ? K - 1 : 1];
     TC nmiss[2] = {TC(0), TC(0)};
 #pragma unroll
-    for (int s = 0; s < (MASKED ? K : 1); ++s) ka[s][0] = ka[s][1] = kb[s][0] = kb[s][1] = TC(0);
+    for (int s = 0; s < (MASKED ? K - 1 : 1); ++s) XA[s] = XB[s] = acc_zero<TC>();
 
     {
         TC x[4];
         fetch(0, x);
         commit(0, x);
+        fetch(1, x);
+        commit(1, x);
     }
-    int slot_new = 0;                // ring slot of row t
-    int slot_old = G::RING - K;      // ring slot of row t - K  ((t - K) mod RING)
+    auto ring_next = [](int slot, int by) {
+        slot += by;
+        return slot >= G::RING ? slot - G::RING : slot;
+    };
+    int slot_a = 0;                  // ring slot of row t (row t+1 is the next slot)
+    int slot_old = G::RING - K;      // ring slot of row t - K
 
-    for (int t = 0; t < n_staged; ++t) {
-        // issue the global loads of the next row now, commit them to LDS after this row's math
-        TC nx[4];
-        fetch(t + 1, nx);
-        int slot_next = slot_new + 1;
-        if (slot_next == G::RING) slot_next = 0;
+    // horizontal box sums of one ring row (and the number of missing flags in it)
+    auto row_sums = [&](int slot, TC (&h1)[2], TC (&h2)[2], TC (&cnt)[2]) {
+        RowRegs<TC, K> r;
+        r.load(ring + slot * G::LWP + lane * 2);
+        row_box<TC, K>(r, h1, h2);
+        if constexpr (MASKED) {
+            r.to_missing_flags();
+            TC c0 = r.at(0);
+#pragma unroll
+            for (int t = 1; t < K; ++t) c0 += r.at(t);
+            cnt[0] = c0;
+            cnt[1] = (c0 - r.at(0)) + r.at(K);
+        }
+    };
 
-        RowRegs<TC, K> v;
-        v.load(ring + slot_new * G::LWP + lane * 2);
+    auto row_flags = [&](const RowRegs<TC, K>& r, TC (&cnt)[2]) {
+        TC c0 = missing_flag(r.at(0));
+#pragma unroll
+        for (int q = 1; q < K; ++q) c0 += missing_flag(r.at(q));
+        cnt[0] = c0;
+        cnt[1] = (c0 - missing_flag(r.at(0))) + missing_flag(r.at(K));
+    };
+
+    auto emit = [&](int oi, const acc_t<TC>& cs2, const TC (&s1)[2], const TC (&s2)[2],
+                    const TC (&nm)[2], const acc_t<TC>& ka2, const acc_t<TC>& kb2) {
+        const bool row_margin = !A.full && ((oi < KH) | (oi > A.ms - K + KH));
+        const TC csv[2] = {cs2.x, cs2.y}, kav[2] = {ka2.x, ka2.y}, kbv[2] = {kb2.x, kb2.y};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int d = d_out + c;
+            const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.ms);
+            const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
+            TC r;
+            if constexpr (MASKED) {
+                TC nobs;
+                r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nm[c], kav[c], kbv[c], A.ks, true, &nobs);
+            } else if constexpr (sizeof(TC) == 4) {
+                r = pearson_nomask_f32(csv[c], s1[c], s2[c], A.ks);
+            } else {
+                TC nobs;
+                r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], TC(0), TC(0), TC(0), A.ks, false, &nobs);
+            }
+            r = zero ? TC(0) : r;
+            if (in_range) {
+                if (A.out_is_f64) ((double*)A.out)[out_idx + c] = (double)r;
+                else ((float*)A.out)[out_idx + c] = (float)r;
+            }
+        }
+        out_idx += out_step;
+        d_out -= 1;
+    };
+
+    // two staged rows (A = t, B = t + 1) per iteration; a virtual zero row pads an odd count
+    for (int t = 0; t < n_staged; t += 2) {
+        const int slot_b = ring_next(slot_a, 1);
+
+        // box sums of the two entering rows minus the two leaving rows; the registers of a
+        // leaving row die before the next row is loaded
+        RowRegs<TC, K> ra, rb;
+        TC sA1[2], sA2[2];
+        TC nmA[2] = {TC(0), TC(0)};
         {
-            TC h1[2], h2[2], g1[2], g2[2];
-            row_box<TC, K>(v, h1, h2);
-            RowRegs<TC, K> vo;
-            vo.load(ring + slot_old * G::LWP + lane * 2);
-            row_box<TC, K>(vo, g1, g2);
+            TC h1[2], h2[2], g1[2], g2[2], gc[2] = {TC(0), TC(0)}, hc[2] = {TC(0), TC(0)};
+            ra.load(ring + slot_a * G::LWP + lane * 2);
+            row_box<TC, K>(ra, h1, h2);
+            row_sums(slot_old, g1, g2, gc);
+            if constexpr (MASKED) row_flags(ra, hc);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 b1[c] += (double)(h1[c] - g1[c]);
                 b2[c] += (double)(h2[c] - g2[c]);
+                sA1[c] = (TC)b1[c];
+                sA2[c] = (TC)b2[c];
+                nmiss[c] += hc[c] - gc[c];
+                nmA[c] = nmiss[c];
             }
-            if constexpr (MASKED) {
-                // number of missing pixels in the window: same sliding scheme on the 0/1 flags
-                // (small integers, exact in floating point)
-                vo.to_missing_flags();
-                TC c0 = vo.at(0);
+            rb.load(ring + slot_b * G::LWP + lane * 2);
+            row_box<TC, K>(rb, h1, h2);
+            row_sums(ring_next(slot_old, 1), g1, g2, gc);
+            if constexpr (MASKED) row_flags(rb, hc);
 #pragma unroll
-                for (int t = 1; t < K; ++t) c0 += vo.at(t);
-                nmiss[0] -= c0;
-                nmiss[1] -= (c0 - vo.at(0)) + vo.at(K);
+            for (int c = 0; c < 2; ++c) {
+                b1[c] += (double)(h1[c] - g1[c]);
+                b2[c] += (double)(h2[c] - g2[c]);
+                nmiss[c] += hc[c] - gc[c];
             }
         }
 
-        // rotating accumulators, highest slot first so that acc[s] can be overwritten in place;
-        // the weights of slot s-1 are in flight while slot s computes (two scalar buffers)
-        slots<K - 1>(v, A.w, acc);
+        // issue the global loads of rows t+2, t+3 now, commit them to LDS after the FMAs
+        TC nx0[4], nx1[4];
+        fetch(t + 2, nx0);
+        fetch(t + 3, nx1);
+
+        acc_t<TC> outA, outB;
+        steps2<TC, K, 0>(ra, rb, A.w, X, outA, outB);
+
+        acc_t<TC> kaA = acc_zero<TC>(), kaB = acc_zero<TC>(), kbA = acc_zero<TC>(), kbB = acc_zero<TC>();
         if constexpr (MASKED) {
             // the row registers are dead: turn them into the 0/1 missing flags in place and run the
-            // same rotating scheme with the two mask weight sets
-            v.to_missing_flags();
-            TC c0 = v.at(0);
-#pragma unroll
-            for (int t = 1; t < K; ++t) c0 += v.at(t);
-            nmiss[0] += c0;
-            nmiss[1] += (c0 - v.at(0)) + v.at(K);
-            slots<K - 1>(v, A.w + (unsigned long long)(K * K * sizeof(TC)), ka);
-            slots<K - 1>(v, A.w + (unsigned long long)(2 * K * K * sizeof(TC)), kb);
+            // same scheme with the two mask weight sets
+            ra.to_missing_flags();
+            rb.to_missing_flags();
+            steps2<TC, K, K * K * (int)sizeof(TC)>(ra, rb, A.w, XA, kaA, kaB);
+            steps2<TC, K, 2 * K * K * (int)sizeof(TC)>(ra, rb, A.w, XB, kbA, kbB);
         }
 
         if (t >= K - 1) {
             const int oi = i0 + t - (K - 1);
-            const bool row_margin = !A.full && ((oi < KH) | (oi > A.ms - K + KH));
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int d = d_out + c;
-                const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi);
-                const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
-                TC r;
-                if constexpr (MASKED) {
-                    TC nobs;
-                    r = pearson_from_sums<TC>(acc[K - 1][c], (TC)b1[c], (TC)b2[c], nmiss[c], ka[K - 1][c],
-                                              kb[K - 1][c], A.ks, true, &nobs);
-                } else if constexpr (sizeof(TC) == 4) {
-                    r = pearson_nomask_f32(acc[K - 1][c], (float)b1[c], (float)b2[c], A.ks);
-                } else {
-                    TC nobs;
-                    r = pearson_from_sums<TC>(acc[K - 1][c], (TC)b1[c], (TC)b2[c], TC(0), TC(0), TC(0), A.ks,
-                                              false, &nobs);
-                }
-                r = zero ? TC(0) : r;
-                if (in_range) {
-                    if (A.out_is_f64) ((double*)A.out)[out_idx + c] = (double)r;
-                    else ((float*)A.out)[out_idx + c] = (float)r;
-                }
-            }
-            out_idx += out_step;
-            d_out -= 1;
+            const TC sB1[2] = {(TC)b1[0], (TC)b1[1]}, sB2[2] = {(TC)b2[0], (TC)b2[1]};
+            emit(oi, outA, sA1, sA2, nmA, kaA, kbA);
+            emit(oi + 1, outB, sB1, sB2, nmiss, kaB, kbB);
         }
-        commit(slot_next, nx);
-        slot_new = slot_next;
-        slot_old += 1;
-        if (slot_old == G::RING) slot_old = 0;
+        commit(ring_next(slot_a, 2), nx0);
+        commit(ring_next(slot_a, 3), nx1);
+        slot_a = ring_next(slot_a, 2);
+        slot_old = ring_next(slot_old, 2);
     }
 }
 

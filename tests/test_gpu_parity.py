@@ -257,3 +257,69 @@ def test_errors():
     small = sp.csr_matrix(np.random.default_rng(0).random((10, 10)))
     with pytest.raises(ValueError):
         cud.normxcorr2(small, k, missing_mask=sp.csr_matrix((10, 10), dtype=bool))
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded inputs spanning several strips / waves of the streaming kernel, against the C oracle
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(200, 300), (517, 261), (1100, 150)])
+@pytest.mark.parametrize("ksize", [7, 11, 17])
+def test_dense_multi_strip_vs_oracle(shape, ksize, precision):
+    from oracle import c_oracle
+    rng = np.random.default_rng(shape[0] + ksize)
+    sig = rng.gamma(4, 0.25, size=shape)
+    kern = chromosight_amd.kernels.loops["kernels"][0]
+    if ksize != 17:
+        kern = cup.resize_kernel(kern, factor=ksize / 17, quiet=True)
+    assert kern.shape == (ksize, ksize)
+    for full in (False, True):
+        got, _ = cud.normxcorr2(sig.astype(np.float32) if precision == "f32" else sig, kern, full=full)
+        ref_in = sig.astype(np.float32).astype(np.float64) if precision == "f32" else sig
+        want, _ = c_oracle.normxcorr2(ref_in, kern, full=full)
+        assert np.abs(got - want).max() < TOL[precision], (shape, ksize, full)
+
+
+@pytest.mark.parametrize("n,max_dist,ksize,tol", [(700, 60, 17, 0.5), (1500, 300, 17, 0.5), (900, 40, 15, 0.75),
+                                                  (400, 500, 7, 0.75), (650, 1, 17, 0.75)])
+def test_banded_masked_multi_strip_vs_oracle(n, max_dist, ksize, tol, precision):
+    """Upper-band maps with missing bins (clusters included), full mode, sym_upper: the production
+    configuration of pattern_detector, at sizes that span many strips."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(n + max_dist)
+    kern = {17: chromosight_amd.kernels.loops["kernels"][0], 15: chromosight_amd.kernels.hairpins["kernels"][0],
+            7: chromosight_amd.kernels.loops_small["kernels"][0]}[ksize]
+    keep = min(max_dist, n) + ksize
+    ii, jj = np.indices((n, n))
+    a = rng.gamma(4, 0.25, size=(n, n)) * (rng.random((n, n)) > 0.15)
+    a[(jj - ii < 0) | (jj - ii > keep)] = 0
+    miss = np.zeros(n, dtype=bool)
+    miss[rng.choice(n, size=n // 25, replace=False)] = True
+    miss[n // 3:n // 3 + 6] = True
+    miss[0] = miss[n - 1] = True
+    a[miss, :] = 0
+    a[:, miss] = 0
+    valid = np.flatnonzero(~miss)
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=max_dist, sym_upper=True)
+    got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, max_dist=max_dist, sym_upper=True, full=True,
+                            missing_mask=mask, missing_tol=tol)
+    want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True, miss_row=miss,
+                                  miss_col=miss, missing_tol=tol)
+    err = np.abs(got.toarray() - want)
+    assert err.max() < (2e-5 if precision == "f32" else 1e-10), (n, max_dist, err.max())
+
+    # the same map through pattern_detector's device path (per-bin flags instead of an explicit
+    # mask): thresholded pixels must be identical to the oracle's
+    class Map:
+        pass
+    cmap = Map()
+    cmap.matrix, cmap.detectable_bins, cmap.max_dist, cmap.inter = sp.csr_matrix(a), (valid, valid.copy()), max_dist, False
+    cfg = dict(pearson=0.2, max_perc_undetected=tol * 100, max_perc_zero=100.0, max_dist=5 * max_dist)
+    tab, _ = cud.pattern_detector(cmap, cfg, kern, full=True)
+    trimmed = np.where((jj - ii >= 0) & (jj - ii <= max_dist), want, 0.0)
+    foci, _ = cud.pick_foci(sp.coo_matrix(trimmed), 0.2)
+    if foci is None:
+        assert tab is None or len(tab) == 0
+    else:
+        got_set = set(map(tuple, tab[["bin1", "bin2"]].to_numpy().astype(int))) if tab is not None else set()
+        assert got_set <= set(map(tuple, foci))      # validation may drop some foci, never add
+        assert len(got_set) > 0

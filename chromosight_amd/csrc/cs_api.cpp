@@ -130,8 +130,10 @@ bool fast_available(int km, int kn, int* K)
 #endif
 }
 
+// aligned_x: the generic kernel starts the x tiles of a row block at a multiple of the tile width,
+// the streaming kernel at the block's first in-band column
 template <typename TC>
-void fill_grid(cs::CorrArgs<TC>& A, int tw, int th)
+void fill_grid(cs::CorrArgs<TC>& A, int tw, int th, bool aligned_x = true)
 {
     A.tile_w = tw;
     A.tile_h = th;
@@ -140,7 +142,7 @@ void fill_grid(cs::CorrArgs<TC>& A, int tw, int th)
         A.out_lo = A.out.band_lo;
         A.out_hi = A.out.band_lo + A.out.band_w - 1;
         const long long span = (long long)(A.out_hi - A.out_lo) + th + tw - 1;
-        A.tiles_x = (int)(span / tw) + 2;
+        A.tiles_x = aligned_x ? (int)(span / tw) + 2 : (int)(span / tw);
         const int max_x = (A.ns + tw - 1) / tw;
         if (A.tiles_x > max_x) A.tiles_x = max_x;
     } else {
@@ -162,7 +164,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 #define CS_CASE(KK)                          \
     case KK:                                 \
         cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
-        fill_grid(A, tw, th);                \
+        fill_grid(A, tw, th, false);         \
         rc = cs::launch_corr_fast_f32_k##KK(A, stream); \
         break;
         switch (K) {
@@ -192,7 +194,7 @@ int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream
 #define CS_CASE(KK)                          \
     case KK:                                 \
         cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
-        fill_grid(A, tw, th);                \
+        fill_grid(A, tw, th, false);         \
         rc = cs::launch_corr_fast_f64_k##KK(A, stream); \
         break;
         switch (K) {

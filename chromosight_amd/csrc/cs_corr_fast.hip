@@ -72,7 +72,7 @@ int CS_CAT(launch_corr_fast_f64_k, CS_K)(const CorrArgs<double>& A, hipStream_t 
 void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int band_w, int n_cu, int* tw, int* th)
 {
     *tw = StreamGeom<CS_K>::TW;
-    int h = band_w > 0 ? 64 : 256;
+    int h = band_w > 0 ? (band_w < 512 ? 32 : 64) : 256;
     const long long want = (long long)n_cu * 4 * 2;  // at least ~2 waves per SIMD
     while (h > 32) {
         const long long sx = band_w > 0 ? (band_w + h + *tw - 1) / *tw + 1 : (ns + *tw - 1) / *tw;

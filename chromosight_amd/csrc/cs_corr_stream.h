@@ -466,12 +466,13 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
     const int i0 = sy * A.strip_h;                        // first output row
     int j0 = sx * G::TW;                                  // first output column
     if (A.band_out) {
+        // band outputs: the strips of a row block start at the block's first in-band column
+        // (not at a multiple of 128), which saves one strip per row block
         int jmin = i0 + A.out_lo;
         if (jmin < 0) jmin = 0;
-        j0 += (jmin / G::TW) * G::TW;
-        const int dmax = (j0 + G::TW - 1) - i0;
+        j0 += jmin;
         const int dmin = j0 - (i0 + A.strip_h - 1);
-        if (j0 >= A.ns || dmax < A.out_lo || dmin > A.out_hi) return;
+        if (j0 >= A.ns || dmin > A.out_hi) return;
     }
     const int rows_out = min(A.strip_h, A.ms - i0);
     const int n_staged = rows_out + K - 1;

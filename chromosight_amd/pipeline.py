@@ -72,6 +72,39 @@ def prepare_intra_block(cool, chrom_idx, max_dist, largest_kernel, name=None):
     return ContactBlock(name or f"chrom{chrom_idx}", mat, (det, det.copy()), max_dist)
 
 
+def prepare_inter_block(cool, ca, cb, name=None):
+    """ContactMap.create_mat for a balanced inter-chromosomal block (contacts_map.py:598-601,
+    539-548): NaN -> 0, divide by the median of the stored values, drop zeros."""
+    off = cool["chrom_offset"]
+    s1, e1, s2, e2 = int(off[ca]), int(off[ca + 1]), int(off[cb]), int(off[cb + 1])
+    b1, b2, w = cool["bin1_id"], cool["bin2_id"], cool["weight"]
+    sel = (b1 >= s1) & (b1 < e1) & (b2 >= s2) & (b2 < e2)
+    vals = cool["count"][sel] * w[b1[sel]] * w[b2[sel]]
+    vals = np.where(np.isnan(vals), 0.0, vals)
+    with np.errstate(all="ignore"):
+        vals = vals / np.nanmedian(vals) if vals.size else vals
+    vals = np.where(np.isnan(vals), 0.0, vals)
+    mat = sp.coo_matrix((vals, (b1[sel] - s1, b2[sel] - s2)), shape=(e1 - s1, e2 - s2))
+    mat.eliminate_zeros()
+    det_all = np.flatnonzero(np.isfinite(w))
+    det_r = det_all[(det_all >= s1) & (det_all < e1)] - s1
+    det_c = det_all[(det_all >= s2) & (det_all < e2)] - s2
+    return ContactBlock(name or f"chrom{ca}-chrom{cb}", mat.tocsr(), (det_r, det_c), None, inter=True)
+
+
+def quantify_block(cool, ca, cb, coords, kernel_config, kernel, max_dist, largest_kernel, tsvd=None):
+    """One task of `chromosight quantify` (cli/chromosight.py:229-260): scores of the given
+    (bin1, bin2) block coordinates; rows that fail validation carry NaN scores."""
+    if np.asarray(coords).shape[0] == 0:
+        return None, None
+    if ca == cb:
+        block = prepare_intra_block(cool, ca, max_dist, largest_kernel)
+    else:
+        block = prepare_inter_block(cool, ca, cb)
+    return cid.pattern_detector(block, kernel_config, kernel, coords=np.array(coords, dtype=int), full=True,
+                                tsvd=tsvd)
+
+
 def detect(cool, kernel_config, tsvd=None):
     """`chromosight detect` (intra-chromosomal, balanced, default options) on a decoded cool.
     Returns the output table (same columns and row order as the reference's <prefix>.tsv)."""

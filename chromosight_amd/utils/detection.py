@@ -368,8 +368,8 @@ def _validate(coords, matrix, scores, missing_rows, missing_cols, kernel_shape, 
         n_zero = np.count_nonzero(win == 0)
         n_miss = np.count_nonzero(~np.isfinite(win))
         with np.errstate(all="ignore"):
-            prop_undetected = n_miss / tot
-            prop_zero = n_zero / (tot - n_miss)
+            prop_undetected = np.float64(n_miss) / np.float64(tot)
+            prop_zero = np.float64(n_zero) / np.float64(tot - n_miss)   # 0/0 -> nan -> rejected
         if (prop_undetected < missing_tol) and (prop_zero < zero_tol):
             out_scores[i] = scores[i]
             windows[i] = win

@@ -61,3 +61,41 @@ def test_committed_outputs(cool, name, overrides):
     assert np.allclose(got["score"], ref["score"], rtol=0, atol=2e-10)
     assert np.allclose(got["pvalue"], ref["pvalue"], rtol=0, atol=2e-10)
     assert np.allclose(got["qvalue"], ref["qvalue"], rtol=0, atol=2e-10)
+
+
+def test_c5_yeast_quantify_inter(golden):
+    """Config C5: quantify with the 11x11 (resized) borders templates on the real 17-chromosome
+    yeast map, intra blocks at the cohesin-peak pairs and inter blocks at seeded positions; scores
+    within 1e-5 of the reference run (BASELINE.json configs[4]); block assembly, detrend and
+    median scaling are redone here from the decoded .cool."""
+    cool = golden("yeast_cool")
+    g = golden("yeast_quantify")
+    max_dist = int(g["max_dist"])
+    cfg = dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0,
+               max_dist=int(g["cfg_max_dist_bp"]), min_dist=0)
+    n_rows = n_inter = 0
+    worst = 0.0
+    for bi in range(int(g["n_blocks"])):
+        ca, cb = (int(x) for x in g[f"b{bi}_chroms"])
+        coords = g[f"b{bi}_coords"]
+        for ki in range(3):
+            key = f"b{bi}_k{ki}_table"
+            if key not in g:
+                continue
+            ref = g[key]
+            tab, _ = pipeline.quantify_block(cool, ca, cb, coords, cfg, g[f"kernel{ki}"], max_dist, 11)
+            if ref.shape[0] == 0:
+                assert tab is None or len(tab) == 0
+                continue
+            got = tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+            assert np.array_equal(got[:, :2], ref[:, :2])
+            assert np.array_equal(np.isnan(got[:, 2]), np.isnan(ref[:, 2])), (bi, ki)
+            ok = ~np.isnan(ref[:, 2])
+            if ok.any():
+                worst = max(worst, np.abs(got[ok, 2] - ref[ok, 2]).max())
+            assert np.allclose(got[ok, 3], ref[ok, 3], rtol=1e-5, atol=1e-300)
+            n_rows += ref.shape[0]
+            n_inter += ref.shape[0] if ca != cb else 0
+    assert worst < 1e-5
+    assert n_rows > 6000 and n_inter > 500
+    print(f"C5: {n_rows} scored positions ({n_inter} inter), max |score - reference| = {worst:.2e}")

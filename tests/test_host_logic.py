@@ -164,6 +164,10 @@ def test_validate_patterns_rules():
     det2 = (np.setdiff1d(np.arange(40), [19, 20, 21, 22]), np.arange(40))
     tab, _ = cud.validate_patterns(coords[:1], mat, conv, det2, kernel, zero_tol=0.9, missing_tol=0.5)
     assert len(tab) == 0
+    # window made only of missing bins: 0/0 proportion of zeros -> rejected, no exception
+    det3 = (np.setdiff1d(np.arange(40), np.arange(14, 28)), np.setdiff1d(np.arange(40), np.arange(19, 33)))
+    tab, _ = cud.validate_patterns(coords[:1], mat, conv, det3, kernel, drop=False, zero_tol=0.9, missing_tol=1.5)
+    assert np.isnan(tab["score"].to_numpy()).all()
     assert np.isnan(cud.pileup_patterns(np.full((2, 3, 3), np.nan))).all()
 
 

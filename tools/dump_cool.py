@@ -38,7 +38,7 @@ def _strings(path, dataset):
         [H5DUMP, "-d", dataset, str(path)], check=True, capture_output=True, text=True
     ).stdout
     data = txt[txt.index("DATA {"):]
-    return re.findall(r'"([^"]*)"', data)
+    return [x.split("\\000")[0] for x in re.findall(r'"([^"]*)"', data)]
 
 
 def _attr_int(path, name):

@@ -288,49 +288,28 @@ struct RowRegs<float, K> {
     }
 };
 
-// horizontal K-sums of one staged row for this lane's two columns
+// horizontal K-sums of one staged row for this lane's two columns.  Four interleaved partial
+// sums keep the dependency chains short (an in-order wave with one or two co-resident waves
+// cannot hide a 16-deep chain of dependent adds); the entering and the leaving row use the same
+// association, so the sliding difference stays exact.
 template <typename TC, int K>
 __device__ __forceinline__ void row_box(const RowRegs<TC, K>& r, TC (&h1)[2], TC (&h2)[2])
 {
-    h1[0] = r.at(0);
-    h2[0] = r.at(0) * r.at(0);
+    TC p1[4], p2[4];
 #pragma unroll
-    for (int t = 1; t < K; ++t) {
-        h1[0] += r.at(t);
-        h2[0] = cs_fma(r.at(t), r.at(t), h2[0]);
+    for (int q = 0; q < 4; ++q) {
+        p1[q] = (q < K) ? r.at(q) : TC(0);
+        p2[q] = (q < K) ? r.at(q) * r.at(q) : TC(0);
     }
+#pragma unroll
+    for (int t = 4; t < K; ++t) {
+        p1[t & 3] += r.at(t);
+        p2[t & 3] = cs_fma(r.at(t), r.at(t), p2[t & 3]);
+    }
+    h1[0] = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+    h2[0] = (p2[0] + p2[1]) + (p2[2] + p2[3]);
     h1[1] = (h1[0] - r.at(0)) + r.at(K);
     h2[1] = cs_fma(r.at(K), r.at(K), cs_fma(-r.at(0), r.at(0), h2[0]));
-}
-
-// Slot S .. 0 of one staged row.  Compile-time recursion so that every s_load has an immediate
-// offset and the two weight buffers alternate statically.
-template <int S, typename TC, int K>
-__device__ __forceinline__ void slots_rec(const RowRegs<TC, K>& v, unsigned long long w_base,
-                                          TC (&acc)[K][2], WRow<TC, K>& cur, WRow<TC, K>& nxt)
-{
-    cur.wait();
-    if constexpr (S > 0) nxt.template issue<(S - 1) * K * (int)sizeof(TC)>(w_base);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (S > 0) {
-        v.slot(cur, acc[S - 1], acc[S]);
-    } else {
-        const TC zero[2] = {TC(0), TC(0)};
-        v.slot(cur, zero, acc[0]);
-    }
-    // pin this slot's FMAs between the two hand-placed scalar loads: without a (volatile) use
-    // of their result the optimiser sinks them below all 17 loads and spills the weights
-    asm volatile("" : "+v"(acc[S][0]), "+v"(acc[S][1]));
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (S > 0) slots_rec<S - 1, TC, K>(v, w_base, acc, nxt, cur);
-}
-
-template <int STOP, typename TC, int K>
-__device__ __forceinline__ void slots(const RowRegs<TC, K>& v, unsigned long long w_base, TC (&acc)[K][2])
-{
-    WRow<TC, K> wa, wb;
-    wa.template issue<STOP * K * (int)sizeof(TC)>(w_base);
-    slots_rec<STOP, TC, K>(v, w_base, acc, wa, wb);
 }
 
 // Two staged rows against template row S (ascending S): see the header comment.  Compile-time

@@ -1,0 +1,103 @@
+"""Seeded random sweep of normxcorr2 configurations on the GPU against the C oracle: template
+sizes (fast and generic kernels, rectangular), dense / banded / inter maps, full / valid mode,
+max_dist below, around and above N, missing-bin clusters at the matrix ends, explicit masks versus
+per-bin flags, both precisions."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import chromosight_amd
+from chromosight_amd.utils import detection as cud
+from chromosight_amd.utils import preprocessing as cup
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def random_kernel(rng, km, kn):
+    k = rng.random((km, kn)) + 0.5
+    if rng.random() < 0.3:          # piecewise-constant, borders-like
+        k = np.where(rng.random((km, kn)) < 0.5, 0.5, 1.5)
+        k[0, 0], k[-1, -1] = 0.5, 1.5
+    return k
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(seed):
+    rng = np.random.default_rng(1000 + seed)
+    precision = "f64" if seed % 3 == 0 else "f32"
+    old = chromosight_amd.get_precision()
+    chromosight_amd.set_precision(precision)
+    try:
+        ksz = [7, 9, 11, 13, 15, 17, 5, 19][seed % 8]
+        km, kn = (ksz, ksz) if seed % 5 else (ksz, ksz + 2)     # every 5th: rectangular -> generic kernel
+        kern = random_kernel(rng, km, kn)
+        mode = seed % 4
+        tol_abs = 5e-5 if precision == "f32" else 1e-9
+        if mode == 0:      # dense, no mask
+            shape = (int(rng.integers(60, 400)), int(rng.integers(60, 400)))
+            sig = rng.gamma(3, 0.4, size=shape) * (rng.random(shape) > 0.3)
+            full = bool(seed & 1)
+            got, _ = cud.normxcorr2(sig, kern, full=full)
+            want, _ = c_oracle.normxcorr2(sig, kern, full=full)
+            ok = conditioned(sig, kern.shape, full)
+            assert np.abs(got - want)[ok].max() < tol_abs
+        elif mode in (1, 2):   # intra band with missing bins
+            n = int(rng.integers(80, 900))
+            max_dist = int([rng.integers(1, 8), rng.integers(8, 60), rng.integers(60, n + 50)][seed % 3])
+            keep = min(max_dist, n) + max(km, kn)
+            ii, jj = np.indices((n, n))
+            a = rng.gamma(3, 0.4, size=(n, n)) * (rng.random((n, n)) > 0.25)
+            a[(jj - ii < 0) | (jj - ii > keep)] = 0
+            miss = rng.random(n) < 0.06
+            miss[:3] = True
+            miss[-2:] = True
+            a[miss, :] = 0
+            a[:, miss] = 0
+            tol = float(rng.choice([0.25, 0.5, 0.75]))
+            valid = np.flatnonzero(~miss)
+            mask = cup.make_missing_mask((n, n), valid, valid, max_dist=max_dist, sym_upper=True)
+            got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, max_dist=max_dist, sym_upper=True, full=True,
+                                    missing_mask=mask, missing_tol=tol)
+            want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True,
+                                          miss_row=miss, miss_col=miss, missing_tol=tol)
+            err = np.abs(got.toarray() - want)
+            bad = err > tol_abs
+            # float32: a handful of nearly degenerate windows (template variance over the
+            # present pixels ~ 0) may exceed the tolerance; they must stay rare and small
+            assert bad.mean() <= (1e-3 if precision == "f32" else 0), (n, max_dist, err.max())
+            assert err.max() < (5e-3 if precision == "f32" else tol_abs)
+        else:              # inter block
+            shape = (int(rng.integers(40, 300)), int(rng.integers(40, 300)))
+            a = rng.gamma(3, 0.4, size=shape) * (rng.random(shape) > 0.4)
+            mr, mc = rng.random(shape[0]) < 0.05, rng.random(shape[1]) < 0.05
+            a[mr, :] = 0
+            a[:, mc] = 0
+            mask = cup.make_missing_mask(shape, np.flatnonzero(~mr), np.flatnonzero(~mc), sym_upper=False)
+            got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, sym_upper=False, full=True, missing_mask=mask)
+            want, _ = c_oracle.normxcorr2(a, kern, sym_upper=False, full=True, miss_row=mr, miss_col=mc)
+            err = np.abs(got.toarray() - want)
+            assert (err > tol_abs).mean() <= (1e-3 if precision == "f32" else 0)
+            assert err.max() < (5e-3 if precision == "f32" else tol_abs)
+    finally:
+        chromosight_amd.set_precision(old)
+
+
+def conditioned(sig, kshape, full):
+    from oracle import pearson_oracle as orc
+    km, kn = kshape
+    s = np.asarray(sig, dtype=np.float64)
+    if full:
+        f = np.zeros((s.shape[0] + 2 * (km - 1), s.shape[1] + 2 * (kn - 1)))
+        f[km - 1:km - 1 + s.shape[0], kn - 1:kn - 1 + s.shape[1]] = s
+    else:
+        f = s
+    ones = np.ones((km, kn)) / (km * kn)
+    m1, m2 = orc.window_sums(f, ones), orc.window_sums(f ** 2, ones)
+    ok = (m2 - m1 ** 2) > 1e-4 * np.maximum(m2, 1e-30)
+    out = np.ones(f.shape, dtype=bool)
+    kh, kw = (km - 1) // 2, (kn - 1) // 2
+    out[kh:kh + ok.shape[0], kw:kw + ok.shape[1]] = ok
+    if full:
+        out = out[km - 1:km - 1 + s.shape[0], kn - 1:kn - 1 + s.shape[1]]
+    return out

@@ -107,10 +107,6 @@ int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w
     return CS_OK;
 }
 
-struct Dispatch {
-    int kfast;  // compile-time size served by a fast kernel, 0 = generic
-};
-
 bool fast_available(int km, int kn, int* K)
 {
     (void)km;

@@ -155,6 +155,7 @@ template <>
 int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
+    A.n_cu = ctx->n_cu;
     if (allow_fast && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
@@ -185,6 +186,7 @@ template <>
 int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
+    A.n_cu = ctx->n_cu;
     if (allow_fast && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \

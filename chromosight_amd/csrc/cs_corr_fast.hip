@@ -47,12 +47,24 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.mask = (const uint8_t*)A.mask.ptr;
     const int n_waves = A.tiles_x * A.tiles_y;
     const int blocks = (n_waves + G::NWAVES - 1) / G::NWAVES;
+    // A launch of at most two workgroups per CU is a single generation of waves: whatever the
+    // dispatcher packs three-deep on one CU leaves another CU short and sets the kernel time.
+    // Asking for more LDS than a third (half) of the 160 KB caps the residency at 2 (1) workgroups
+    // per CU, which spreads such launches evenly.
+    size_t smem_req = smem;
+    if (A.n_cu > 0) {
+        const int per_cu = (blocks + A.n_cu - 1) / A.n_cu;
+        if (per_cu <= 2) {
+            const size_t cap = (size_t)160 * 1024 / (per_cu + 1) + 1024;
+            if (cap > smem_req) smem_req = cap;
+        }
+    }
     auto launch = [&](auto kern) -> int {
-        if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (smem_req > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem, stream, S);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem_req, stream, S);
         return (int)hipGetLastError();
     };
     if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, true>);

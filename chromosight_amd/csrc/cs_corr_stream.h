@@ -158,6 +158,77 @@ struct WRow<double, K> {
     }
 };
 
+// ---- blocked packed FMAs ---------------------------------------------------------------------
+// hipcc puts an s_nop between any two dependent inline-asm statements (it cannot see that they are
+// plain VALU ops), which cost one issue slot per two packed FMAs when every FMA was its own asm
+// statement.  A block therefore covers up to 4 weight pairs (8 template columns) of BOTH chains:
+//   y += Ae[i] * w[i].lo;  z += Be[i] * w[i].lo;  y += Ao[i] * w[i].hi;  z += Bo[i] * w[i].hi
+// plus, at the end of a template row of odd length, the last (even) column.
+#define CS_PK_EVEN(acc, x, w) "v_pk_fma_f32 " acc ", " x ", " w ", " acc " op_sel_hi:[1,0,1]\n\t"
+#define CS_PK_ODD(acc, x, w) "v_pk_fma_f32 " acc ", " x ", " w ", " acc " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define CS_PK_MUL(acc, x, w) "v_pk_mul_f32 " acc ", " x ", " w " op_sel_hi:[1,0]\n\t"
+#define CS_PAIR(i)                                                                       \
+    CS_PK_EVEN("%[y]", "%[ae" #i "]", "%[w" #i "]") CS_PK_EVEN("%[z]", "%[be" #i "]", "%[w" #i "]") \
+    CS_PK_ODD("%[y]", "%[ao" #i "]", "%[w" #i "]") CS_PK_ODD("%[z]", "%[bo" #i "]", "%[w" #i "]")
+#define CS_PAIR_FIRST(i)                                                                 \
+    CS_PK_MUL("%[y]", "%[ae" #i "]", "%[w" #i "]") CS_PK_MUL("%[z]", "%[be" #i "]", "%[w" #i "]")   \
+    CS_PK_ODD("%[y]", "%[ao" #i "]", "%[w" #i "]") CS_PK_ODD("%[z]", "%[bo" #i "]", "%[w" #i "]")
+#define CS_TAIL CS_PK_EVEN("%[y]", "%[aet]", "%[wt]") CS_PK_EVEN("%[z]", "%[bet]", "%[wt]")
+#define CS_IN(i, m) [ae##i] "v"(A.e[m]), [be##i] "v"(B.e[m]), [ao##i] "v"(A.o[m]), [bo##i] "v"(B.o[m]), [w##i] "s"(wk.template pair<2 * (m)>())
+#define CS_IN_TAIL(m) [aet] "v"(A.e[m]), [bet] "v"(B.e[m]), [wt] "s"(wk.template pair<2 * (m)>())
+
+// pairs M0 .. M0+NPAIR-1 of a template row; TAIL: also the last (even) column K-1;
+// FIRST: the accumulators start at zero (first template row), so the first op is a multiply
+template <int M0, int NPAIR, bool TAIL, bool FIRST, typename ROW, typename W>
+__device__ __forceinline__ void pk_block(const ROW& A, const ROW& B, const W& wk, f32x2& y, f32x2& z)
+{
+    constexpr int MT = M0 + NPAIR;   // pair index holding column K-1 when TAIL
+    if constexpr (!FIRST) {
+        if constexpr (NPAIR == 4 && !TAIL)
+            asm(CS_PAIR(0) CS_PAIR(1) CS_PAIR(2) CS_PAIR(3) : [y] "+v"(y), [z] "+v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN(2, M0 + 2), CS_IN(3, M0 + 3));
+        else if constexpr (NPAIR == 4 && TAIL)
+            asm(CS_PAIR(0) CS_PAIR(1) CS_PAIR(2) CS_PAIR(3) CS_TAIL : [y] "+v"(y), [z] "+v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN(2, M0 + 2), CS_IN(3, M0 + 3), CS_IN_TAIL(MT));
+        else if constexpr (NPAIR == 3 && TAIL)
+            asm(CS_PAIR(0) CS_PAIR(1) CS_PAIR(2) CS_TAIL : [y] "+v"(y), [z] "+v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN(2, M0 + 2), CS_IN_TAIL(MT));
+        else if constexpr (NPAIR == 2 && TAIL)
+            asm(CS_PAIR(0) CS_PAIR(1) CS_TAIL : [y] "+v"(y), [z] "+v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN_TAIL(MT));
+        else if constexpr (NPAIR == 1 && TAIL)
+            asm(CS_PAIR(0) CS_TAIL : [y] "+v"(y), [z] "+v"(z) : CS_IN(0, M0), CS_IN_TAIL(MT));
+        else
+            static_assert(NPAIR == 4, "unsupported packed block shape");
+    } else {
+        if constexpr (NPAIR == 4 && !TAIL)
+            asm(CS_PAIR_FIRST(0) CS_PAIR(1) CS_PAIR(2) CS_PAIR(3) : [y] "=&v"(y), [z] "=&v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN(2, M0 + 2), CS_IN(3, M0 + 3));
+        else if constexpr (NPAIR == 4 && TAIL)
+            asm(CS_PAIR_FIRST(0) CS_PAIR(1) CS_PAIR(2) CS_PAIR(3) CS_TAIL : [y] "=&v"(y), [z] "=&v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN(2, M0 + 2), CS_IN(3, M0 + 3), CS_IN_TAIL(MT));
+        else if constexpr (NPAIR == 3 && TAIL)
+            asm(CS_PAIR_FIRST(0) CS_PAIR(1) CS_PAIR(2) CS_TAIL : [y] "=&v"(y), [z] "=&v"(z)
+                : CS_IN(0, M0), CS_IN(1, M0 + 1), CS_IN(2, M0 + 2), CS_IN_TAIL(MT));
+        else
+            static_assert(NPAIR == 4, "unsupported packed block shape");
+    }
+}
+
+// one template row (K odd) for both chains, in blocks of at most 4 weight pairs
+template <int K, bool FIRST, typename ROW, typename W>
+__device__ __forceinline__ void pk_row(const ROW& A, const ROW& B, const W& wk, f32x2& y, f32x2& z)
+{
+    static_assert(K % 2 == 1 && K >= 7 && K <= 17, "packed row blocks cover odd K in 7..17");
+    constexpr int NP = K / 2;
+    if constexpr (NP <= 4) {
+        pk_block<0, NP, true, FIRST>(A, B, wk, y, z);
+    } else {
+        pk_block<0, 4, false, FIRST>(A, B, wk, y, z);
+        pk_block<4, NP - 4, true, false>(A, B, wk, y, z);
+    }
+}
+
 // accumulator of the lane's two adjacent output columns
 template <typename TC>
 struct Pair2 {
@@ -339,11 +410,12 @@ __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowReg
     if constexpr (S > 0) {
         y = X[S - 1];
         z = yprev;
-    } else {
+    } else if constexpr (sizeof(TC) != 4) {
         y = acc_zero<TC>();
         z = acc_zero<TC>();
     }
-    two_chains<0, TC, K>(A, B, cur, y, z);
+    if constexpr (sizeof(TC) == 4) pk_row<K, S == 0>(A, B, cur, y, z);
+    else two_chains<0, TC, K>(A, B, cur, y, z);
     if constexpr (S > 0) X[S - 1] = zprev;
     // pin this step's FMAs between the two hand-placed scalar loads: without a (volatile) use of
     // their results the optimiser sinks them below all K loads and spills the weights

@@ -67,6 +67,7 @@ struct CorrArgs {
     int tiles_y;
     int tile_w, tile_h;
     int out_lo, out_hi;      // only pixels with out_lo <= j - i <= out_hi are produced
+    int n_cu;                // compute units of the device (launch shaping)
 };
 
 // ---------------------------------------------------------------------------------------

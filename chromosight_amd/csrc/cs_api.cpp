@@ -2,9 +2,11 @@
 // statistics, weight upload and kernel dispatch.  No torch types, no retained pointers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +25,9 @@ struct cs_ctx {
     size_t d_w_bytes = 0;
     // host copy of what d_w currently holds, to skip re-uploads of an unchanged template
     std::vector<unsigned char> w_cached;
+    // grow-only scratch for the mask tables of the streaming kernel (one call in flight per context)
+    void* d_ws = nullptr;
+    size_t d_ws_bytes = 0;
 };
 
 namespace {
@@ -148,6 +153,98 @@ void fill_grid(cs::CorrArgs<TC>& A, int tw, int th, bool aligned_x = true)
     }
 }
 
+// Decide whether the factorised per-bin mask path applies and, if so, build its tables in the
+// context's scratch buffer (cs_mask_prep.hip).  K = template size served by a streaming kernel.
+template <typename TC>
+int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t stream)
+{
+    A.reg_mode = 0;
+    A.fix_on = 0;
+    if (std::getenv("CHROMOSIGHT_HIP_DEBUG"))
+        fprintf(stderr, "[chromosight_hip] mask_mode=%d full=%d sym_upper=%d ms=%d ns=%d out_layout=%d out_lo=%d out_hi=%d max_dist=%d\n",
+                A.mask_mode, A.full, A.sym_upper, A.ms, A.ns, A.out.layout, A.out_lo, A.out_hi, A.max_dist);
+    if (A.mask_mode != CS_MASK_BINS || !A.full || std::getenv("CHROMOSIGHT_HIP_NO_REGULAR_MASK")) return CS_OK;
+    if (A.ms < 2 * K || A.ns < 2 * K) return CS_OK;
+    const int KH = (K - 1) / 2;
+    const bool band_out = A.out.layout == CS_LAYOUT_BAND;
+    int hi_d0 = 0, hi_w = 0, bot0, width, side = 0;
+    bool edge_tables = false;
+    if (A.sym_upper && !band_out) {
+        // small dense maps (API users, short chromosomes): one correction per pixel, all from the
+        // general predicate
+        if ((long long)A.ms * A.ns > (1 << 22)) return CS_OK;
+        bot0 = KH;
+        width = A.ns;
+    } else if (A.sym_upper) {
+        // band outputs that end near max_dist: the edge tables cover the diagonals whose windows
+        // leave 0..max_dist
+        if (A.max_dist < 0 || A.out_lo < 0) return CS_OK;
+        edge_tables = true;
+        hi_d0 = A.max_dist - K + 2;
+        hi_w = A.out_hi - hi_d0 + 1;
+        if (hi_w < 0) hi_w = 0;
+        if (hi_w > 64) return CS_OK;
+        // rows whose in-band pixels reach the right or the bottom frame
+        bot0 = std::max(KH, std::min(A.ms - KH, A.ns - KH - A.out_hi));
+        width = A.out.band_w;
+    } else {
+        if (band_out) return CS_OK;
+        bot0 = A.ms - KH;
+        width = A.ns;
+        side = KH;
+    }
+    const int top = KH;
+    auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };   // elements
+    const size_t n_row = align((size_t)A.ms * 64 + 64), n_col = align(3 * (size_t)A.ns);
+    const size_t n_lo = edge_tables ? align((size_t)A.ms * (K - 1) * 4) : 0;
+    const size_t n_hi = edge_tables ? align((size_t)A.ms * hi_w * 4 + 4) : 0;
+    const size_t n_frows = align((size_t)(top + A.ms - bot0) * width * 4);
+    const size_t n_fcols = side ? align((size_t)A.ms * 2 * side * 4) : 0;
+    const size_t n_bits = align(((size_t)A.ms + A.ns) * sizeof(unsigned) / sizeof(TC) + 2);
+    const size_t bytes = (n_row + n_col + n_lo + n_hi + n_frows + n_fcols + n_bits) * sizeof(TC);
+    if (bytes > ctx->d_ws_bytes) {
+        if (ctx->d_ws) CS_HIP(ctx, hipFree(ctx->d_ws));
+        ctx->d_ws = nullptr;
+        ctx->d_ws_bytes = 0;
+        CS_HIP(ctx, hipMalloc(&ctx->d_ws, bytes));
+        ctx->d_ws_bytes = bytes;
+    }
+    TC* rowtab = reinterpret_cast<TC*>(ctx->d_ws);
+    TC* coltab = rowtab + n_row;
+    TC* fix_lo = coltab + n_col;
+    TC* fix_hi = fix_lo + n_lo;
+    TC* fix_rows = fix_hi + n_hi;
+    TC* fix_cols = side ? fix_rows + n_frows : nullptr;
+    unsigned* rbits = reinterpret_cast<unsigned*>(fix_rows + n_frows + n_fcols);
+    unsigned* cbits = rbits + A.ms;
+    int rc = cs::launch_mask_tables<TC>(A.miss_row, A.miss_col, A.ms, A.ns, K, A.w, rowtab, coltab, rbits, cbits, stream);
+    if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
+    if (edge_tables) {
+        rc = cs::launch_mask_edge_fix<TC>(rbits, cbits, A.ms, A.ns, K, A.max_dist, hi_d0, hi_w, A.w, fix_lo, fix_hi, stream);
+        if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask edge kernel failed: %s", hipGetErrorString((hipError_t)rc));
+        A.fix_on = 1;
+    }
+    rc = cs::launch_mask_frame_fix<TC>(rbits, cbits, A.ms, A.ns, K, A.sym_upper, A.max_dist, A.w, top, bot0, width,
+                                       band_out ? 1 : 0, A.out_lo, side, fix_rows, fix_cols, stream);
+    if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask frame kernel failed: %s", hipGetErrorString((hipError_t)rc));
+    A.reg_mode = 1;
+    A.rowtab = rowtab;
+    A.coltab = coltab;
+    A.fix_lo = fix_lo;
+    A.fix_hi = fix_hi;
+    A.fix_hi_w = hi_w;
+    A.fix_hi_d0 = hi_d0;
+    A.fix_rows = fix_rows;
+    A.fix_cols = fix_cols;
+    A.fix_top = top;
+    A.fix_bot0 = bot0;
+    A.fix_width = width;
+    A.fix_xband = band_out ? 1 : 0;
+    A.fix_xlo = band_out ? A.out_lo : 0;
+    A.fix_side = side;
+    return CS_OK;
+}
+
 template <typename TC>
 int launch_corr(cs_ctx* ctx, cs::CorrArgs<TC>& A, hipStream_t stream, bool allow_fast);
 
@@ -162,6 +259,8 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
     case KK:                                 \
         cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
         fill_grid(A, tw, th, false);         \
+        rc = prepare_regular_mask<float>(ctx, A, KK, stream); \
+        if (rc != CS_OK) return rc;          \
         rc = cs::launch_corr_fast_f32_k##KK(A, stream); \
         break;
         switch (K) {
@@ -193,6 +292,8 @@ int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream
     case KK:                                 \
         cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
         fill_grid(A, tw, th, false);         \
+        rc = prepare_regular_mask<double>(ctx, A, KK, stream); \
+        if (rc != CS_OK) return rc;          \
         rc = cs::launch_corr_fast_f64_k##KK(A, stream); \
         break;
         switch (K) {
@@ -330,6 +431,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
 {
     if (!ctx) return;
     if (ctx->d_w) (void)hipFree(ctx->d_w);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     delete ctx;
 }
 

@@ -45,6 +45,21 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.miss_row = A.miss_row;
     S.miss_col = A.miss_col;
     S.mask = (const uint8_t*)A.mask.ptr;
+    S.fix_rows = A.fix_rows;
+    S.fix_cols = A.fix_cols;
+    S.fix_top = A.fix_top;
+    S.fix_bot0 = A.fix_bot0;
+    S.fix_width = A.fix_width;
+    S.fix_xband = A.fix_xband;
+    S.fix_xlo = A.fix_xlo;
+    S.fix_side = A.fix_side;
+    S.fix_on = A.fix_on;
+    S.fix_hi_w = A.fix_hi_w;
+    S.fix_hi_d0 = A.fix_hi_d0;
+    S.rowtab = A.rowtab;
+    S.coltab = A.coltab;
+    S.fix_lo = A.fix_lo;
+    S.fix_hi = A.fix_hi;
     const int n_waves = A.tiles_x * A.tiles_y;
     const int blocks = (n_waves + G::NWAVES - 1) / G::NWAVES;
     // A launch of at most two workgroups per CU is a single generation of waves: whatever the
@@ -67,8 +82,10 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem_req, stream, S);
         return (int)hipGetLastError();
     };
-    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, true>);
-    return launch(corr_stream_kernel<TC, CS_K, false>);
+    // per-bin mask: factorised mask sums (tables built by cs_api.cpp prepare_regular_mask)
+    if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2>);
+    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1>);
+    return launch(corr_stream_kernel<TC, CS_K, 0>);
 }
 
 #define CS_CAT_(a, b) a##b
@@ -84,14 +101,16 @@ int CS_CAT(launch_corr_fast_f64_k, CS_K)(const CorrArgs<double>& A, hipStream_t 
 void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int band_w, int n_cu, int* tw, int* th)
 {
     *tw = StreamGeom<CS_K>::TW;
-    int h = band_w > 0 ? (band_w < 512 ? 32 : 64) : 256;
+    int h = band_w > 0 ? (band_w < 512 ? 32 : 128) : 256;
+    auto n_waves = [&](int hh) {
+        const long long sx = band_w > 0 ? (band_w + hh + *tw - 1) / *tw + 1 : (ns + *tw - 1) / *tw;
+        return sx * ((ms + hh - 1) / hh);
+    };
     const long long want = (long long)n_cu * 4 * 2;  // at least ~2 waves per SIMD
-    while (h > 32) {
-        const long long sx = band_w > 0 ? (band_w + h + *tw - 1) / *tw + 1 : (ns + *tw - 1) / *tw;
-        const long long waves = sx * ((ms + h - 1) / h);
-        if (waves >= want) break;
-        h >>= 1;
-    }
+    while (h > 32 && n_waves(h) < want) h >>= 1;
+    // small maps cannot fill the chip anyway: their time is the latency of one strip, so shorter
+    // strips (more of them in parallel) win until every CU has a workgroup
+    while (h > 8 && n_waves(h) < (long long)n_cu * 4) h >>= 1;
     if (const char* e = getenv("CHROMOSIGHT_HIP_STRIP_H")) {
         const int v = atoi(e);
         if (v >= 1) h = v;

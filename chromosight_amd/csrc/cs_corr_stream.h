@@ -42,6 +42,7 @@ struct StreamGeom {
     static constexpr int LWP = ((LW + 3) / 4) * 4;  // row pitch in elements (16-byte multiple)
     static constexpr int RING = K + 4;              // rows t-K .. t+3 are live (two rows per iteration)
     static constexpr int NWAVES = 4;                // independent waves per workgroup
+    static constexpr int ROWS = RING + 1;           // LDS rows per wave: the ring + the column-flag row (MODE 2)
 };
 
 // weights are read through the constant address space so that the (wave-uniform) loads are
@@ -398,6 +399,16 @@ __device__ __forceinline__ void two_chains(const RowRegs<TC, K>& A, const RowReg
     }
 }
 
+// single chain: a += sum_kj (v[kj], v[kj+1]) * w[kj]   (MODE 2 cross product, off the hot path)
+template <int KJ, typename TC, int K>
+__device__ __forceinline__ void one_chain(const RowRegs<TC, K>& R, const WRow<TC, K>& wk, acc_t<TC>& a)
+{
+    if constexpr (KJ < K) {
+        R.template fma<KJ>(wk, a);
+        one_chain<KJ + 1, TC, K>(R, wk, a);
+    }
+}
+
 template <int S, typename TC, int K, int W_OFF>
 __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
                                            acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB,
@@ -460,8 +471,20 @@ struct StreamArgs {
     const uint8_t* miss_row;
     const uint8_t* miss_col;
     const uint8_t* mask;
+    // MODE 2 tables (cs_mask_prep.hip), see CorrArgs
+    int fix_on, fix_hi_w, fix_hi_d0;
+    const TC* rowtab;
+    const TC* coltab;
+    const TC* fix_lo;
+    const TC* fix_hi;
+    const TC* fix_rows;
+    const TC* fix_cols;
+    int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
     KernelStats<TC> ks;
 };
+
+constexpr int kRowTabStride = 64;   // elements per row of rowtab: nr, RA, RB, -, UA[K] at 4, UB[K] at 24
+constexpr int kRowTabUA = 4, kRowTabUB = 24;
 
 // framed missing predicate (same rules as cs_device.h missing_pred) on the lean argument block
 template <typename TC, int K>
@@ -499,15 +522,24 @@ __device__ __forceinline__ bool stream_missing(const StreamArgs<TC>& A, int p, i
     return m;
 }
 
-template <typename TC, int K, bool MASKED>
+// MODE 0: no missing mask.  MODE 1: any mask, carried as -0.0 in the staged signal, two extra sets
+// of rotating accumulators.  MODE 2: per-bin mask (missing = row flag | column flag): the mask sums
+// factorise,
+//     sum_missing W = RA[i] + CA[j] - sum_kj c[j+kj] * U_i[kj],   U_i[kj] = sum_ki r[i+ki] W[ki][kj],
+// into per-row / per-column tables (cs_mask_prep.hip) plus a K-term cross product that is only
+// needed on output rows with a flagged row in reach; pixels whose window leaves the matrix or the
+// diagonal range 0..max_dist get a precomputed correction.  The data path is that of MODE 0.
+template <typename TC, int K, int MODE>
 __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
     constexpr int KH = (K - 1) / 2;
+    constexpr bool MASKED = MODE == 1;
+    constexpr bool REG = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    TC* ring = reinterpret_cast<TC*>(smem_raw) + (size_t)wv * G::RING * G::LWP;
+    TC* ring = reinterpret_cast<TC*>(smem_raw) + (size_t)wv * G::ROWS * G::LWP;
 
     // strip of this wave (uniform per wave); x fastest so that neighbouring waves share halos
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * G::NWAVES + wv);
@@ -604,6 +636,27 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
         ocol_margin[c] = !A.full && ((oj0 + c < KH) | (oj0 + c > A.ns - K + KH));
     }
 
+    // MODE 2: column terms of the factorised mask sums (constant over the strip) and the strip's
+    // column flags as a staged row for the cross product
+    TC ncol[2] = {TC(0), TC(0)}, ca_col[2] = {TC(0), TC(0)}, cb_col[2] = {TC(0), TC(0)};
+    TC* cfl = ring + G::RING * G::LWP;
+    if constexpr (REG) {
+        for (int idx = lane; idx < G::LWP; idx += kWave) {
+            const int q = j0 - KH + idx;
+            const bool in = (q >= 0) & (q < A.ns) & (idx < G::LW);
+            cfl[idx] = (in && A.miss_col[in ? q : 0] != 0) ? TC(1) : TC(0);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = oj0 + c;
+            if (j < A.ns) {
+                ncol[c] = A.coltab[j];
+                ca_col[c] = A.coltab[(size_t)A.ns + j];
+                cb_col[c] = A.coltab[2 * (size_t)A.ns + j];
+            }
+        }
+    }
+
     acc_t<TC> X[K - 1];
 #pragma unroll
     for (int s = 0; s < K - 1; ++s) X[s] = acc_zero<TC>();
@@ -664,7 +717,32 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
             const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.ms);
             const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
             TC r;
-            if constexpr (MASKED) {
+            if constexpr (REG) {
+                // windows that leave the matrix (frame tables) or the diagonal range 0..max_dist
+                // (edge tables): precomputed correction of the factorised sums
+                TC nmv = nm[c], ka = kav[c], kb = kbv[c];
+                if (in_range) {
+                    const TC* f = nullptr;
+                    const int j = oj0 + c;
+                    const int x = A.fix_xband ? d - A.fix_xlo : j;
+                    if (oi < A.fix_top) f = A.fix_rows + ((size_t)oi * A.fix_width + x) * 4;
+                    else if (oi >= A.fix_bot0) f = A.fix_rows + ((size_t)(A.fix_top + oi - A.fix_bot0) * A.fix_width + x) * 4;
+                    else if (A.fix_cols && (j < A.fix_side || j >= A.ns - A.fix_side))
+                        f = A.fix_cols + ((size_t)oi * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side))) * 4;
+                    else if (A.fix_on) {
+                        if (d >= 0 && d < K - 1) f = A.fix_lo + ((size_t)oi * (K - 1) + d) * 4;
+                        else if (d >= A.fix_hi_d0 && d - A.fix_hi_d0 < A.fix_hi_w)
+                            f = A.fix_hi + ((size_t)oi * A.fix_hi_w + (d - A.fix_hi_d0)) * 4;
+                    }
+                    if (f) {
+                        nmv += f[0];
+                        ka += f[1];
+                        kb += f[2];
+                    }
+                }
+                TC nobs;
+                r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nmv, ka, kb, A.ks, true, &nobs);
+            } else if constexpr (MASKED) {
                 TC nobs;
                 r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nm[c], kav[c], kbv[c], A.ks, true, &nobs);
             } else if constexpr (sizeof(TC) == 4) {
@@ -740,8 +818,50 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
         if (t >= K - 1) {
             const int oi = i0 + t - (K - 1);
             const TC sB1[2] = {(TC)b1[0], (TC)b1[1]}, sB2[2] = {(TC)b2[0], (TC)b2[1]};
-            emit(oi, outA, sA1, sA2, nmA, kaA, kbA);
-            emit(oi + 1, outB, sB1, sB2, nmiss, kaB, kbB);
+            if constexpr (REG) {
+                // row terms (wave-uniform scalar loads); the cross product only where a flagged
+                // row is in reach of the output row
+                const int oiB = min(oi + 1, A.ms - 1);
+                ConstPtr<TC> rtA = (ConstPtr<TC>)(A.rowtab + (size_t)oi * kRowTabStride);
+                ConstPtr<TC> rtB = (ConstPtr<TC>)(A.rowtab + (size_t)oiB * kRowTabStride);
+                const TC nrA = rtA[0], raA = rtA[1], rbA = rtA[2];
+                const TC nrB = rtB[0], raB = rtB[1], rbB = rtB[2];
+                acc_t<TC> xaA = acc_zero<TC>(), xbA = acc_zero<TC>(), xaB = acc_zero<TC>(), xbB = acc_zero<TC>();
+                if ((nrA != TC(0)) | (nrB != TC(0))) {
+                    RowRegs<TC, K> cf;
+                    cf.load(cfl + lane * 2);
+                    WRow<TC, K> wu;
+                    const unsigned long long bA = (unsigned long long)(uintptr_t)(A.rowtab + (size_t)oi * kRowTabStride);
+                    const unsigned long long bB = (unsigned long long)(uintptr_t)(A.rowtab + (size_t)oiB * kRowTabStride);
+                    wu.template issue<kRowTabUA * (int)sizeof(TC)>(bA);
+                    wu.wait();
+                    one_chain<0, TC, K>(cf, wu, xaA);
+                    wu.template issue<kRowTabUB * (int)sizeof(TC)>(bA);
+                    wu.wait();
+                    one_chain<0, TC, K>(cf, wu, xbA);
+                    wu.template issue<kRowTabUA * (int)sizeof(TC)>(bB);
+                    wu.wait();
+                    one_chain<0, TC, K>(cf, wu, xaB);
+                    wu.template issue<kRowTabUB * (int)sizeof(TC)>(bB);
+                    wu.wait();
+                    one_chain<0, TC, K>(cf, wu, xbB);
+                }
+                TC nA[2], nB[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    nA[c] = TC(K) * nrA + (TC(K) - nrA) * ncol[c];
+                    nB[c] = TC(K) * nrB + (TC(K) - nrB) * ncol[c];
+                }
+                kaA.x = raA + ca_col[0] - xaA.x;  kaA.y = raA + ca_col[1] - xaA.y;
+                kbA.x = rbA + cb_col[0] - xbA.x;  kbA.y = rbA + cb_col[1] - xbA.y;
+                kaB.x = raB + ca_col[0] - xaB.x;  kaB.y = raB + ca_col[1] - xaB.y;
+                kbB.x = rbB + cb_col[0] - xbB.x;  kbB.y = rbB + cb_col[1] - xbB.y;
+                emit(oi, outA, sA1, sA2, nA, kaA, kbA);
+                emit(oi + 1, outB, sB1, sB2, nB, kaB, kbB);
+            } else {
+                emit(oi, outA, sA1, sA2, nmA, kaA, kbA);
+                emit(oi + 1, outB, sB1, sB2, nmiss, kaB, kbB);
+            }
         }
         commit(ring_next(slot_a, 2), nx0);
         commit(ring_next(slot_a, 3), nx1);
@@ -754,7 +874,7 @@ template <int K, typename TC>
 constexpr size_t corr_stream_smem_bytes()
 {
     using G = StreamGeom<K>;
-    return sizeof(TC) * G::NWAVES * G::RING * G::LWP;
+    return sizeof(TC) * G::NWAVES * G::ROWS * G::LWP;
 }
 
 }  // namespace cs

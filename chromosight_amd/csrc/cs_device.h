@@ -68,6 +68,19 @@ struct CorrArgs {
     int tile_w, tile_h;
     int out_lo, out_hi;      // only pixels with out_lo <= j - i <= out_hi are produced
     int n_cu;                // compute units of the device (launch shaping)
+    // factorised per-bin mask sums of the streaming kernel (cs_mask_prep.hip); reg_mode = 1:
+    // strips whose windows stay inside the matrix use the tables, the others the general path
+    int reg_mode;
+    int fix_on, fix_hi_w, fix_hi_d0;
+    const TC* rowtab;
+    const TC* coltab;
+    const TC* fix_lo;
+    const TC* fix_hi;
+    // frame corrections: rows < fix_top and rows >= fix_bot0 (fix_width entries each, indexed by
+    // column, or by diagonal - fix_xlo when fix_xband), first / last fix_side columns of every row
+    const TC* fix_rows;
+    const TC* fix_cols;
+    int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
 };
 
 // ---------------------------------------------------------------------------------------

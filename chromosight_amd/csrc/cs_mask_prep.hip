@@ -1,0 +1,339 @@
+// cs_mask_prep.hip -- tables for the factorised mask sums of the streaming kernel (MODE 2 of
+// cs_corr_stream.h).
+//
+// With a per-bin missing mask (reference preprocessing.py:535 make_missing_mask: a pixel is
+// missing when its row bin or its column bin is undetectable) the mask-weighted template sums of
+// the masked Pearson branch (detection.py:1020-1060) factorise for every window that lies inside
+// the matrix:
+//     sum_{ki,kj} (r[i+ki] | c[j+kj]) W[ki][kj] = RA[i] + CA[j] - sum_kj c[j+kj] U_i[kj]
+//     U_i[kj] = sum_ki r[i+ki] W[ki][kj],  RA[i] = sum_kj U_i[kj],  CA[j] = sum_kj c[j+kj] colsum_W[kj]
+// (window indices are centred: i + ki means i - (K-1)/2 + ki).  `mask_rowcol_tables_kernel`
+// builds the per-row and per-column tables for the two weight sets of the masked branch.
+//
+// In sym_upper mode the reference restricts that mask to diagonals 0..max_dist and flags the K
+// sub-diagonals -K..-1 (preprocessing.py:404 frame_missing_mask; cs_device.h missing_pred).
+// `mask_edge_fix_kernel` evaluates, for the output diagonals whose windows leave 0..max_dist,
+// the exact difference  sum_window (missing_true - (r|c)) * {1, Wa, Wb}  once per pixel.
+#include "cs_device.h"
+#include "cs_launch_aux.h"
+
+namespace cs {
+
+namespace {
+
+constexpr int kMaxK = 17;
+constexpr int kRowTabStride = 64, kRowTabUA = 4, kRowTabUB = 24;   // keep in sync with cs_corr_stream.h
+
+template <typename TC>
+__global__ __launch_bounds__(256) void mask_rowcol_tables_kernel(const uint8_t* __restrict__ rr,
+                                                                 const uint8_t* __restrict__ cc, int ms, int ns, int K,
+                                                                 const TC* __restrict__ w, TC* __restrict__ rowtab,
+                                                                 TC* __restrict__ coltab, unsigned* __restrict__ rbits,
+                                                                 unsigned* __restrict__ cbits)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int KH = (K - 1) / 2, kk = K * K;
+    const TC* wa = w + kk;
+    const TC* wb = w + 2 * kk;
+    if (id < ms) {
+        TC ua[kMaxK], ub[kMaxK];
+#pragma unroll
+        for (int kj = 0; kj < kMaxK; ++kj) ua[kj] = ub[kj] = TC(0);
+        int nr = 0;
+        unsigned bits = 0;
+        for (int ki = 0; ki < K; ++ki) {
+            const int p = id - KH + ki;
+            if (p < 0 || p >= ms || rr[p] == 0) continue;
+            ++nr;
+            bits |= 1u << ki;
+#pragma unroll
+            for (int kj = 0; kj < kMaxK; ++kj)
+                if (kj < K) {
+                    ua[kj] += wa[ki * K + kj];
+                    ub[kj] += wb[ki * K + kj];
+                }
+        }
+        TC ra = TC(0), rb = TC(0);
+#pragma unroll
+        for (int kj = 0; kj < kMaxK; ++kj) {
+            ra += ua[kj];
+            rb += ub[kj];
+        }
+        TC* row = rowtab + (size_t)id * kRowTabStride;
+        rbits[id] = bits;   // bit ki = flag of row id - KH + ki (0 outside the matrix)
+        row[0] = (TC)nr;
+        row[1] = ra;
+        row[2] = rb;
+        row[3] = TC(0);
+#pragma unroll
+        for (int kj = 0; kj < kMaxK; ++kj) {
+            row[kRowTabUA + kj] = ua[kj];
+            row[kRowTabUB + kj] = ub[kj];
+        }
+    } else if (id < ms + ns) {
+        const int j = id - ms;
+        int nc = 0;
+        unsigned bits = 0;
+        TC ca = TC(0), cb = TC(0);
+        for (int kj = 0; kj < K; ++kj) {
+            const int q = j - KH + kj;
+            if (q < 0 || q >= ns || cc[q] == 0) continue;
+            ++nc;
+            bits |= 1u << kj;
+            for (int ki = 0; ki < K; ++ki) {
+                ca += wa[ki * K + kj];
+                cb += wb[ki * K + kj];
+            }
+        }
+        cbits[j] = bits;
+        coltab[j] = (TC)nc;
+        coltab[(size_t)ns + j] = ca;
+        coltab[2 * (size_t)ns + j] = cb;
+    }
+}
+
+// one thread per (row i, edge slot e): e < K-1 -> diagonal e (lower edge), else diagonal
+// hi_d0 + (e - (K-1)) (upper edge).  Only pixels whose window lies inside the matrix (the others
+// are covered by the frame tables below).
+//
+// Window pixel (ki, kj) lies on diagonal d = D + kj - ki.  Row ki of the window has its first
+// L = clamp(ki - D, 0, K) pixels below the main diagonal (flagged stripes in the reference, r|c in
+// the regular model) and its pixels kj >= H = clamp(md - D + ki + 1, 0, K) beyond max_dist (never
+// missing in the reference).  With prefix sums of the weights along rows (PW) and columns (QW)
+// the correction is a per-diagonal constant minus one term per flagged row / column of the
+// window (0.7 flagged bins per window at 2 % missing bins), instead of a loop over the triangle.
+template <typename TC>
+__global__ __launch_bounds__(256) void mask_edge_fix_kernel(const unsigned* __restrict__ rbits_g,
+                                                            const unsigned* __restrict__ cbits_g, int ms, int ns, int K,
+                                                            int md, int hi_d0, int hi_w, const TC* __restrict__ w,
+                                                            TC* __restrict__ fix_lo, TC* __restrict__ fix_hi)
+{
+    constexpr int P = kMaxK + 1;
+    // [set 0 = Wa, 1 = Wb]; PW[ki][m] = sum_{kj < m} W[ki][kj], QW[kj][m] = sum_{ki < m} W[ki][kj]
+    __shared__ TC w_s[2][kMaxK * kMaxK], pw_s[2][kMaxK * P], qw_s[2][kMaxK * P], base_s[3][kMaxK];
+    const int kk = K * K;
+    for (int t = threadIdx.x; t < 2 * kk; t += blockDim.x) w_s[t / kk][t % kk] = w[kk + t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * K * (K + 1); t += blockDim.x) {
+        const int set = t / (K * (K + 1)), r = (t / (K + 1)) % K, m = t % (K + 1);
+        TC sp = TC(0), sq = TC(0);
+        for (int x = 0; x < m; ++x) {
+            sp += w_s[set][r * K + x];
+            sq += w_s[set][x * K + r];
+        }
+        pw_s[set][r * P + m] = sp;
+        qw_s[set][r * P + m] = sq;
+    }
+    __syncthreads();
+    // flag-free value of the lower triangle per diagonal D < K-1: all of it is flagged stripes
+    for (int t = threadIdx.x; t < K - 1; t += blockDim.x) {
+        TC n = TC(0), a = TC(0), b = TC(0);
+        for (int ki = 0; ki < K; ++ki) {
+            const int L = min(K, max(0, ki - t));
+            n += (TC)L;
+            a += pw_s[0][ki * P + L];
+            b += pw_s[1][ki * P + L];
+        }
+        base_s[0][t] = n;
+        base_s[1][t] = a;
+        base_s[2][t] = b;
+    }
+    __syncthreads();
+
+    const int per_row = (K - 1) + hi_w;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)ms * per_row) return;
+    const int i = (int)(id / per_row);
+    const int e = (int)(id - (long long)i * per_row);
+    const int KH = (K - 1) / 2;
+    int D;
+    TC* dst;
+    if (e < K - 1) {
+        D = e;
+        dst = fix_lo + ((size_t)i * (K - 1) + e) * 4;
+    } else {
+        D = hi_d0 + (e - (K - 1));
+        dst = fix_hi + ((size_t)i * hi_w + (e - (K - 1))) * 4;
+    }
+    const int j = i + D;
+    TC fn = TC(0), fa = TC(0), fb = TC(0);
+    if (i >= KH && i + KH < ms && j >= KH && j + KH < ns) {
+        if (D >= 0 && D < K - 1) {
+            fn = base_s[0][D];
+            fa = base_s[1][D];
+            fb = base_s[2][D];
+        }
+        const unsigned rbits = rbits_g[i], cbits = cbits_g[j];
+        // flagged rows: every pixel of the row that lies in either triangle
+        for (unsigned rb = rbits; rb; rb &= rb - 1) {
+            const int ki = __ffs(rb) - 1;
+            const int L = min(K, max(0, ki - D));
+            const int H = min(K, max(0, md - D + ki + 1));
+            fn -= (TC)(L + (K - H));
+            fa -= pw_s[0][ki * P + L] + (pw_s[0][ki * P + K] - pw_s[0][ki * P + H]);
+            fb -= pw_s[1][ki * P + L] + (pw_s[1][ki * P + K] - pw_s[1][ki * P + H]);
+        }
+        // flagged columns: the pixels of the column in either triangle whose row is not flagged.
+        // lower triangle: kj < ki - D  <=>  ki >= kj + D + 1; upper: ki < kj - (md - D)
+        for (unsigned cb = cbits; cb; cb &= cb - 1) {
+            const int kj = __ffs(cb) - 1;
+            const int lo_k = min(K, max(0, kj + D + 1));
+            const int hi_k = min(K, max(0, kj - (md - D)));
+            TC n = (TC)((K - lo_k) + hi_k);
+            TC a = (qw_s[0][kj * P + K] - qw_s[0][kj * P + lo_k]) + qw_s[0][kj * P + hi_k];
+            TC b = (qw_s[1][kj * P + K] - qw_s[1][kj * P + lo_k]) + qw_s[1][kj * P + hi_k];
+            for (unsigned rb = rbits; rb; rb &= rb - 1) {
+                const int ki = __ffs(rb) - 1;
+                if (ki >= lo_k || ki < hi_k) {
+                    n -= TC(1);
+                    a -= w_s[0][ki * K + kj];
+                    b -= w_s[1][ki * K + kj];
+                }
+            }
+            fn -= n;
+            fa -= a;
+            fb -= b;
+        }
+    }
+    dst[0] = fn;
+    dst[1] = fa;
+    dst[2] = fb;
+    dst[3] = TC(0);
+}
+
+// The framed per-bin predicate of cs_device.h missing_pred (mask_mode 1, full, square template)
+// with the two bin flags passed in.
+__device__ __forceinline__ bool missing_bins(int ms, int ns, int K, int sym_upper, int max_dist, int p, int q, bool rflag,
+                                             bool cflag)
+{
+    const bool in_r = (p >= 0) & (p < ms), in_c = (q >= 0) & (q < ns);
+    const int d = q - p;
+    const bool have_md = max_dist >= 0;
+    bool m;
+    if (in_r & in_c) {
+        m = rflag | cflag;
+        if (sym_upper) {
+            const int md = have_md ? max_dist : min(ms, ns);
+            m = m & (d >= 0) & (d <= md);
+        }
+    } else if (sym_upper && have_md) {
+        if (q >= ns) m = p >= ms - max_dist - 2;
+        else if (p < 0) m = (q < 0) ? true : (q < max_dist + K);
+        else m = false;
+    } else {
+        m = true;
+    }
+    if (sym_upper) m = m | ((d <= -1) & (d >= -K));
+    return m;
+}
+
+// Frame tables: complete correction  sum_window (missing - (r|c)) * {1, Wa, Wb}  for the pixels
+// whose window leaves the matrix (flags count as 0 outside the matrix in the regular model).
+//   rows table: the first `top` output rows and the rows >= bot0, `width` entries each
+//               (x = j for dense outputs, x = (j - i) - x_lo for band outputs)
+//   cols table: (dense outputs) the first and last `side` columns of every row
+template <typename TC>
+__global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __restrict__ rbits_g,
+                                                             const unsigned* __restrict__ cbits_g, int ms, int ns, int K,
+                                                             int sym_upper, int max_dist, const TC* __restrict__ w, int top,
+                                                             int bot0, int width, int x_band, int x_lo, int side,
+                                                             TC* __restrict__ fix_rows, TC* __restrict__ fix_cols)
+{
+    __shared__ TC wa_s[kMaxK * kMaxK], wb_s[kMaxK * kMaxK];
+    const int kk = K * K;
+    for (int t = threadIdx.x; t < kk; t += blockDim.x) {
+        wa_s[t] = w[kk + t];
+        wb_s[t] = w[2 * kk + t];
+    }
+    __syncthreads();
+    const int n_rows = top + (ms - bot0);
+    const long long n_row_px = (long long)n_rows * width;
+    const long long n_col_px = fix_cols ? (long long)ms * 2 * side : 0;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_row_px + n_col_px) return;
+    int i, j;
+    TC* dst;
+    if (id < n_row_px) {
+        const int r = (int)(id / width), x = (int)(id - (long long)r * width);
+        i = r < top ? r : bot0 + (r - top);
+        j = x_band ? i + x_lo + x : x;
+        dst = fix_rows + id * 4;
+    } else {
+        const long long c = id - n_row_px;
+        i = (int)(c / (2 * side));
+        const int x = (int)(c - (long long)i * 2 * side);
+        j = x < side ? x : ns - 2 * side + x;
+        dst = fix_cols + c * 4;
+    }
+    const int KH = (K - 1) / 2;
+    TC fn = TC(0), fa = TC(0), fb = TC(0);
+    if (j >= 0 && j < ns) {
+        const unsigned rbits = rbits_g[i], cbits = cbits_g[j];
+        for (int ki = 0; ki < K; ++ki) {
+            const int p = i - KH + ki;
+            const bool rflag = (rbits >> ki) & 1u;
+            for (int kj = 0; kj < K; ++kj) {
+                const bool cflag = (cbits >> kj) & 1u;
+                const int f = (missing_bins(ms, ns, K, sym_upper, max_dist, p, j - KH + kj, rflag, cflag) ? 1 : 0) -
+                              ((rflag | cflag) ? 1 : 0);
+                if (f != 0) {
+                    fn += (TC)f;
+                    fa += (TC)f * wa_s[ki * K + kj];
+                    fb += (TC)f * wb_s[ki * K + kj];
+                }
+            }
+        }
+    }
+    dst[0] = fn;
+    dst[1] = fa;
+    dst[2] = fb;
+    dst[3] = TC(0);
+}
+
+}  // namespace
+
+template <typename TC>
+int launch_mask_tables(const uint8_t* rr, const uint8_t* cc, int ms, int ns, int K, const TC* w, TC* rowtab, TC* coltab,
+                       unsigned* rbits, unsigned* cbits, hipStream_t stream)
+{
+    if (K > kMaxK) return -1;
+    const int n = ms + ns;
+    hipLaunchKernelGGL(mask_rowcol_tables_kernel<TC>, dim3((n + 255) / 256), dim3(256), 0, stream, rr, cc, ms, ns, K, w, rowtab,
+                       coltab, rbits, cbits);
+    return (int)hipGetLastError();
+}
+
+template <typename TC>
+int launch_mask_edge_fix(const unsigned* rbits, const unsigned* cbits, int ms, int ns, int K, int md, int hi_d0, int hi_w,
+                         const TC* w, TC* fix_lo, TC* fix_hi, hipStream_t stream)
+{
+    const long long n = (long long)ms * ((K - 1) + hi_w);
+    hipLaunchKernelGGL(mask_edge_fix_kernel<TC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rbits, cbits, ms, ns, K,
+                       md, hi_d0, hi_w, w, fix_lo, fix_hi);
+    return (int)hipGetLastError();
+}
+
+template <typename TC>
+int launch_mask_frame_fix(const unsigned* rbits, const unsigned* cbits, int ms, int ns, int K, int sym_upper, int max_dist,
+                          const TC* w, int top, int bot0, int width, int x_band, int x_lo, int side, TC* fix_rows, TC* fix_cols,
+                          hipStream_t stream)
+{
+    const long long n = (long long)(top + (ms - bot0)) * width + (fix_cols ? (long long)ms * 2 * side : 0);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mask_frame_fix_kernel<TC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rbits, cbits, ms, ns, K,
+                       sym_upper, max_dist, w, top, bot0, width, x_band, x_lo, side, fix_rows, fix_cols);
+    return (int)hipGetLastError();
+}
+
+#define CS_INST(TC)                                                                                                         \
+    template int launch_mask_tables<TC>(const uint8_t*, const uint8_t*, int, int, int, const TC*, TC*, TC*, unsigned*,      \
+                                        unsigned*, hipStream_t);                                                            \
+    template int launch_mask_edge_fix<TC>(const unsigned*, const unsigned*, int, int, int, int, int, int, const TC*, TC*,    \
+                                          TC*, hipStream_t);                                                                \
+    template int launch_mask_frame_fix<TC>(const unsigned*, const unsigned*, int, int, int, int, int, const TC*, int, int,   \
+                                           int, int, int, int, TC*, TC*, hipStream_t);
+CS_INST(float)
+CS_INST(double)
+#undef CS_INST
+
+}  // namespace cs

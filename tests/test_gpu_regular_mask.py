@@ -1,0 +1,186 @@
+"""The factorised per-bin mask path of the streaming kernel (MODE 2 of cs_corr_stream.h, tables of
+cs_mask_prep.hip) against (a) the general masked path of the same library
+(CHROMOSIGHT_HIP_NO_REGULAR_MASK=1) and (b) the C oracle, through the C ABI with device-resident
+band / dense operands as pattern_detector uses them (reference detection.py:253-263 with the
+masks of preprocessing.py:535, 404)."""
+import os
+
+import numpy as np
+import pytest
+
+from chromosight_amd import engine
+from chromosight_amd._lib import (LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, CsMatrix, get_device, np_dtype_code)
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_kernel(rng, k, flat=False):
+    if flat:   # borders-like, piecewise constant
+        kern = np.where(np.add.outer(np.arange(k), np.arange(k)) < k, 0.5, 1.5)
+    else:
+        kern = rng.random((k, k)) + 0.5
+    return kern
+
+
+def intra_map(rng, n, keep, miss_frac, clusters=True):
+    ii, jj = np.indices((n, n))
+    a = rng.gamma(3, 0.4, size=(n, n)) * (rng.random((n, n)) > 0.25)
+    a[(jj - ii < 0) | (jj - ii > keep)] = 0
+    miss = rng.random(n) < miss_frac
+    if clusters:
+        miss[:3] = True
+        miss[-2:] = True
+        c = n // 2
+        miss[c:c + 20] = True       # a run longer than the template
+    a[miss, :] = 0
+    a[:, miss] = 0
+    return a, miss
+
+
+def to_band(a, lo, width, dtype):
+    n = a.shape[0]
+    ld = (width + 63) // 64 * 64
+    band = np.zeros((n, ld), dtype=dtype)
+    for d in range(width):
+        off = lo + d
+        idx = np.arange(max(0, -off), min(n, a.shape[1] - off))
+        band[idx, d] = a[idx, idx + off]
+    return band, ld
+
+
+def from_band(band, lo, width, shape):
+    out = np.zeros(shape)
+    n = shape[0]
+    for d in range(width):
+        off = lo + d
+        idx = np.arange(max(0, -off), min(n, shape[1] - off))
+        out[idx, idx + off] = band[idx, d]
+    return out
+
+
+def run_band(a, miss, kern, max_dist, precision, missing_tol, general):
+    dev = get_device()
+    n = a.shape[0]
+    k = kern.shape[0]
+    keep = min(max_dist, n) + k
+    band, ld = to_band(a, 0, keep + 1, np.float32 if precision == "f32" else np.float64)
+    sig_buf = dev.to_device(band)
+    sig = CsMatrix(sig_buf.ptr, np_dtype_code(band.dtype), LAYOUT_BAND, ld, 0, keep + 1)
+    out_w = max_dist + 1
+    ld_out = (out_w + 63) // 64 * 64
+    out_dtype = np.float32 if precision == "f32" else np.float64
+    out_buf = dev.zeros((n, ld_out), out_dtype)
+    out = CsMatrix(out_buf.ptr, np_dtype_code(out_dtype), LAYOUT_BAND, ld_out, 0, out_w)
+    flags = dev.to_device(miss.astype(np.uint8))
+    if general:
+        os.environ["CHROMOSIGHT_HIP_NO_REGULAR_MASK"] = "1"
+    try:
+        engine.run_normxcorr2(dev, sig, (n, n), engine.KernelSpec(kern), out, full=True, sym_upper=True,
+                              max_dist=max_dist, mask_mode=MASK_BINS, miss_row=flags, miss_col=flags,
+                              missing_tol=missing_tol, precision=precision)
+    finally:
+        os.environ.pop("CHROMOSIGHT_HIP_NO_REGULAR_MASK", None)
+    return from_band(out_buf.download().astype(np.float64), 0, out_w, (n, n))
+
+
+def check(got, want, precision, rare=1e-3):
+    err = np.abs(got - want)
+    if precision == "f64":
+        assert err.max() < 1e-9, err.max()
+    else:
+        # float32: a few nearly degenerate windows (template variance over the present pixels ~ 0)
+        # may exceed the 1e-5 score tolerance; they must stay rare and small
+        assert (err > 2e-5).mean() <= rare, ((err > 2e-5).mean(), err.max())
+        assert err.max() < 5e-3, err.max()
+
+
+CASES = [
+    # n, K, max_dist, miss_frac, precision, flat template
+    (700, 17, 233, 0.02, "f32", False),
+    (700, 17, 233, 0.02, "f64", False),
+    (900, 17, 40, 0.06, "f32", False),
+    (500, 7, 5, 0.10, "f64", False),       # max_dist below the template size: the two edges overlap
+    (640, 11, 120, 0.20, "f32", True),     # many missing bins, piecewise-constant template
+    (420, 9, 600, 0.03, "f64", False),     # max_dist beyond the matrix
+    (1500, 13, 300, 0.02, "f32", False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}k{c[1]}md{c[2]}{c[4]}" for c in CASES])
+def test_band_regular_vs_general_and_oracle(case):
+    n, k, max_dist, miss_frac, precision, flat = case
+    rng = np.random.default_rng(n * 31 + k)
+    kern = make_kernel(rng, k, flat)
+    a, miss = intra_map(rng, n, min(max_dist, n) + k, miss_frac)
+    tol = 0.5
+    reg = run_band(a, miss, kern, max_dist, precision, tol, general=False)
+    gen = run_band(a, miss, kern, max_dist, precision, tol, general=True)
+    # both paths evaluate the same sums; float64 agrees to rounding of a few adds
+    check(reg, gen, precision, rare=2e-4)
+    want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True, miss_row=miss, miss_col=miss,
+                                  missing_tol=tol)
+    ii, jj = np.indices((n, n))
+    inband = (jj - ii >= 0) & (jj - ii <= max_dist)
+    check(np.where(inband, reg, 0), np.where(inband, want, 0), precision)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_inter_dense_regular_vs_oracle(precision):
+    dev = get_device()
+    rng = np.random.default_rng(77)
+    shape = (530, 710)
+    kern = make_kernel(rng, 17)
+    a = rng.gamma(3, 0.4, size=shape) * (rng.random(shape) > 0.4)
+    mr, mc = rng.random(shape[0]) < 0.05, rng.random(shape[1]) < 0.05
+    mr[:2] = True
+    mc[-9:] = True      # a flagged block that reaches the right frame
+    a[mr, :] = 0
+    a[:, mc] = 0
+    dt = np.float32 if precision == "f32" else np.float64
+    ld = (shape[1] + 15) // 16 * 16
+    host = np.zeros((shape[0], ld), dtype=dt)
+    host[:, :shape[1]] = a
+    sig_buf = dev.to_device(host)
+    sig = CsMatrix(sig_buf.ptr, np_dtype_code(dt), LAYOUT_DENSE, ld, 0, 0)
+    outs = []
+    for general in (False, True):
+        out_buf = dev.zeros((shape[0], ld), dt)
+        out = CsMatrix(out_buf.ptr, np_dtype_code(dt), LAYOUT_DENSE, ld, 0, 0)
+        if general:
+            os.environ["CHROMOSIGHT_HIP_NO_REGULAR_MASK"] = "1"
+        try:
+            engine.run_normxcorr2(dev, sig, shape, engine.KernelSpec(kern), out, full=True, sym_upper=False, max_dist=None,
+                                  mask_mode=MASK_BINS, miss_row=dev.to_device(mr.astype(np.uint8)),
+                                  miss_col=dev.to_device(mc.astype(np.uint8)), missing_tol=0.75, precision=precision)
+        finally:
+            os.environ.pop("CHROMOSIGHT_HIP_NO_REGULAR_MASK", None)
+        outs.append(out_buf.download().astype(np.float64)[:, :shape[1]])
+    check(outs[0], outs[1], precision, rare=2e-4)
+    want, _ = c_oracle.normxcorr2(a, kern, sym_upper=False, full=True, miss_row=mr, miss_col=mc, missing_tol=0.75)
+    check(outs[0], want, precision)
+
+
+def test_small_dense_sym_upper_regular_vs_oracle():
+    """Short chromosomes go through dense outputs (pattern_detector on data_test/example.cool):
+    every pixel takes its correction from the per-pixel table."""
+    dev = get_device()
+    rng = np.random.default_rng(5)
+    n, k = 171, 17
+    for max_dist in (2000, 60):
+        kern = make_kernel(rng, k)
+        a, miss = intra_map(rng, n, min(max_dist, n) + k, 0.05, clusters=False)
+        ld = (n + 15) // 16 * 16
+        host = np.zeros((n, ld))
+        host[:, :n] = a
+        sig_buf = dev.to_device(host)
+        sig = CsMatrix(sig_buf.ptr, np_dtype_code(np.float64), LAYOUT_DENSE, ld, 0, 0)
+        out_buf = dev.zeros((n, ld), np.float64)
+        out = CsMatrix(out_buf.ptr, np_dtype_code(np.float64), LAYOUT_DENSE, ld, 0, 0)
+        flags = dev.to_device(miss.astype(np.uint8))
+        engine.run_normxcorr2(dev, sig, (n, n), engine.KernelSpec(kern), out, full=True, sym_upper=True, max_dist=max_dist,
+                              mask_mode=MASK_BINS, miss_row=flags, miss_col=flags, missing_tol=0.75, precision="f64")
+        got = out_buf.download()[:, :n]
+        want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True, miss_row=miss, miss_col=miss,
+                                      missing_tol=0.75)
+        assert np.abs(got - want).max() < 1e-9

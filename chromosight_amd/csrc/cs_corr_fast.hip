@@ -94,23 +94,37 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
 int CS_CAT(launch_corr_fast_f32_k, CS_K)(const CorrArgs<float>& A, hipStream_t s) { return launch_fast<float>(A, s); }
 int CS_CAT(launch_corr_fast_f64_k, CS_K)(const CorrArgs<double>& A, hipStream_t s) { return launch_fast<double>(A, s); }
 
-// strip geometry: 128 columns per wave; the strip height trades the K-1 warm-up rows of every
-// strip (and, for band outputs, the part of a rectangular strip that falls outside the diagonal
-// band) against having enough waves to fill 256 CUs x 4 SIMDs a few times over.
+// strip geometry: 128 columns per wave, strip height chosen by a small cost model fitted to
+// measurements on MI355X (C2 / C3 / C4' height sweeps, profiles/r01_strip_height_sweep.txt):
+//   time ~ (h + 0.7 (K-1)) * w / eff(w),   w = waves per SIMD = ceil(strips / (4 n_cu))
+// h + K-1 staged rows per strip (the K-1 warm-up rows emit nothing and cost ~0.7 of a row); one
+// wave alone on a SIMD reaches ~55 % of the VALU rate of two or more.  For band outputs the
+// number of 128-column strips per row block jumps whenever band_w + h crosses a multiple of 128,
+// which is what makes e.g. h = 20 better than h = 32 for a 234-diagonal band.
 // band_w = number of output diagonals (0 for dense outputs).
 void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int band_w, int n_cu, int* tw, int* th)
 {
     *tw = StreamGeom<CS_K>::TW;
-    int h = band_w > 0 ? (band_w < 512 ? 32 : 128) : 256;
-    auto n_waves = [&](int hh) {
-        const long long sx = band_w > 0 ? (band_w + hh + *tw - 1) / *tw + 1 : (ns + *tw - 1) / *tw;
-        return sx * ((ms + hh - 1) / hh);
-    };
-    const long long want = (long long)n_cu * 4 * 2;  // at least ~2 waves per SIMD
-    while (h > 32 && n_waves(h) < want) h >>= 1;
-    // small maps cannot fill the chip anyway: their time is the latency of one strip, so shorter
-    // strips (more of them in parallel) win until every CU has a workgroup
-    while (h > 8 && n_waves(h) < (long long)n_cu * 4) h >>= 1;
+    const long long max_sx = (ns + *tw - 1) / *tw;
+    const long long n_simd = (long long)(n_cu > 0 ? n_cu : 256) * 4;
+    int h = 32;
+    double best = 1e300;
+    for (int hh = 8; hh <= 256; hh += 2) {
+        long long sx = max_sx;
+        if (band_w > 0) {
+            sx = (band_w - 1 + hh + *tw - 1) / *tw;   // same span as fill_grid (cs_api.cpp)
+            if (sx > max_sx) sx = max_sx;
+            if (sx < 1) sx = 1;
+        }
+        const long long waves = sx * ((ms + hh - 1) / hh);
+        const long long w = (waves + n_simd - 1) / n_simd;
+        const double eff = w <= 1 ? 0.55 : (w == 2 ? 0.95 : 1.0);
+        const double t = (hh + 0.7 * (CS_K - 1)) * (double)w / eff;
+        if (t <= best) {   // ties: the taller strip (fewer halo rows)
+            best = t;
+            h = hh;
+        }
+    }
     if (const char* e = getenv("CHROMOSIGHT_HIP_STRIP_H")) {
         const int v = atoi(e);
         if (v >= 1) h = v;

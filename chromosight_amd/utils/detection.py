@@ -352,29 +352,38 @@ def _validate(coords, matrix, scores, missing_rows, missing_cols, kernel_shape, 
     miss_c = np.zeros(matrix.shape[1], dtype=bool)
     miss_r[missing_rows] = True
     miss_c[missing_cols] = True
-    failed = np.zeros(n, dtype=bool)
-    for i in range(n):
-        p1, p2 = int(coords[i, 0]), int(coords[i, 1])
-        high, low = p1 - half_h + 1, p1 + half_h
-        left, right = p2 - half_w + 1, p2 + half_w
-        # strict upper bounds, as in the reference (detection.py:99-104)
-        if not (high >= 0 and low < matrix.shape[0] and left >= 0 and right < matrix.shape[1]):
-            failed[i] = True
-            continue
-        win = matrix[high:low, left:right].toarray().astype(np.float64)
-        win[miss_r[high:low], :] = np.nan
-        win[:, miss_c[left:right]] = np.nan
-        tot = win.size
-        n_zero = np.count_nonzero(win == 0)
-        n_miss = np.count_nonzero(~np.isfinite(win))
+    p1 = coords[:, 0].astype(np.int64)
+    p2 = coords[:, 1].astype(np.int64)
+    high, low = p1 - half_h + 1, p1 + half_h
+    left, right = p2 - half_w + 1, p2 + half_w
+    # strict upper bounds, as in the reference (detection.py:99-104)
+    inside = (high >= 0) & (low < matrix.shape[0]) & (left >= 0) & (right < matrix.shape[1])
+    failed = ~inside
+    scores = np.asarray(scores, dtype=np.float64)
+    # all windows of a chunk are read with one vectorised CSR lookup instead of one sparse slice
+    # per pattern (the reference slices in a Python loop, detection.py:96-141)
+    dr = np.arange(low[0] - high[0] if n else 0)[None, :, None]
+    dc = np.arange(right[0] - left[0] if n else 0)[None, None, :]
+    todo = np.flatnonzero(inside)
+    for c0 in range(0, todo.size, 16384):
+        sel = todo[c0:c0 + 16384]
+        rr = high[sel, None, None] + dr
+        cc = left[sel, None, None] + dc
+        shape = (sel.size, dr.shape[1], dc.shape[2])
+        flat_r = np.broadcast_to(rr, shape).ravel()
+        flat_c = np.broadcast_to(cc, shape).ravel()
+        win = np.asarray(matrix[flat_r, flat_c], dtype=np.float64).reshape(shape)
+        win[np.broadcast_to(miss_r[rr] | miss_c[cc], shape)] = np.nan
+        tot = win[0].size
+        n_zero = np.count_nonzero(win == 0, axis=(1, 2))
+        n_miss = np.count_nonzero(~np.isfinite(win), axis=(1, 2))
         with np.errstate(all="ignore"):
-            prop_undetected = np.float64(n_miss) / np.float64(tot)
-            prop_zero = np.float64(n_zero) / np.float64(tot - n_miss)   # 0/0 -> nan -> rejected
-        if (prop_undetected < missing_tol) and (prop_zero < zero_tol):
-            out_scores[i] = scores[i]
-            windows[i] = win
-        else:
-            failed[i] = True
+            prop_undetected = n_miss.astype(np.float64) / np.float64(tot)
+            prop_zero = n_zero.astype(np.float64) / (tot - n_miss).astype(np.float64)   # 0/0 -> nan -> rejected
+        ok = (prop_undetected < missing_tol) & (prop_zero < zero_tol)
+        out_scores[sel[ok]] = scores[sel[ok]]
+        windows[sel[ok]] = win[ok]
+        failed[sel[~ok]] = True
     table = pd.DataFrame({"bin1": coords[:, 0], "bin2": coords[:, 1], "score": out_scores})
     if drop:
         return table.loc[~failed, :], windows[~failed]

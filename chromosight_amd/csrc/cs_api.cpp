@@ -368,6 +368,26 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
             w[2 * kk + t] = k2 - 2.0 * st.kmean * kc + st.kmean * st.kmean;
         }
     }
+    // vertical symmetry of the template (loops, stripes): lets the streaming kernel fold template
+    // rows.  Rounding-level asymmetries (truncated-SVD reconstructions) are symmetrised for the
+    // float32 kernels, whose own rounding is 1e5 times larger; float64 needs exact symmetry.
+    bool sym = !std::getenv("CHROMOSIGHT_HIP_NO_SYMMETRY");
+    {
+        double wmax = 0;
+        for (size_t t = 0; t < w.size(); ++t) wmax = std::max(wmax, std::fabs(w[t]));
+        const double tol = sizeof(TC) == 8 ? 0.0 : 1e-12 * wmax;
+        for (int set = 0; set < 3 && sym; ++set)
+            for (int r = 0; r < km / 2 && sym; ++r)
+                for (int c = 0; c < kn; ++c)
+                    if (std::fabs(w[set * kk + r * kn + c] - w[set * kk + (km - 1 - r) * kn + c]) > tol) {
+                        sym = false;
+                        break;
+                    }
+        if (sym && sizeof(TC) == 4)
+            for (int set = 0; set < 3; ++set)
+                for (int r = 0; r < km / 2; ++r)
+                    for (int c = 0; c < kn; ++c) w[set * kk + (km - 1 - r) * kn + c] = w[set * kk + r * kn + c];
+    }
     rc = upload_weights<TC>(ctx, stream, w);
     if (rc) return rc;
 
@@ -399,6 +419,7 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.ks.eps = (TC)p->denom_eps;
     A.ks.cut = (TC)p->min_present;
     A.xcorr_only = 0;
+    A.w_sym = sym ? 1 : 0;
     *out = A;
     return CS_OK;
 }

@@ -82,10 +82,18 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem_req, stream, S);
         return (int)hipGetLastError();
     };
+    // vertically symmetric templates (float32 kernels only): folded template rows, see steps2_rec
+    if constexpr (sizeof(TC) == 4) {
+        if (A.w_sym) {
+            if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, true>);
+            if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, true>);
+            return launch(corr_stream_kernel<TC, CS_K, 0, true>);
+        }
+    }
     // per-bin mask: factorised mask sums (tables built by cs_api.cpp prepare_regular_mask)
-    if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2>);
-    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1>);
-    return launch(corr_stream_kernel<TC, CS_K, 0>);
+    if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, false>);
+    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, false>);
+    return launch(corr_stream_kernel<TC, CS_K, 0, false>);
 }
 
 #define CS_CAT_(a, b) a##b

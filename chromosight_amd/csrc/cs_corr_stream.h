@@ -409,24 +409,47 @@ __device__ __forceinline__ void one_chain(const RowRegs<TC, K>& R, const WRow<TC
     }
 }
 
-template <int S, typename TC, int K, int W_OFF>
+// SYM: the template is symmetric under a vertical flip (row s == row K-1-s; true for the loops and
+// stripes templates of the reference).  The horizontal product of a staged row with template row
+// s, Q_s = row (*) W[s], then serves the two slots s and K-1-s: it is computed once for
+// s <= (K-1)/2 (K packed ops) and added to both accumulators (one packed add each), so a staged
+// row costs (K+1)/2 * K + K-1 packed ops instead of K * K, and only (K+1)/2 weight rows are loaded.
+template <int S, typename TC, int K, int W_OFF, bool SYM>
 __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
                                            acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB,
-                                           acc_t<TC> yprev, acc_t<TC> zprev, WRow<TC, K>& cur, WRow<TC, K>& nxt)
+                                           acc_t<TC> yprev, acc_t<TC> zprev, WRow<TC, K>& cur, WRow<TC, K>& nxt,
+                                           acc_t<TC> (&QA)[(K + 1) / 2], acc_t<TC> (&QB)[(K + 1) / 2])
 {
-    cur.wait();
-    if constexpr (S < K - 1) nxt.template issue<W_OFF + (S + 1) * K * (int)sizeof(TC)>(w_base);
+    constexpr bool FOLD = SYM && sizeof(TC) == 4;
+    constexpr int KM = (K - 1) / 2;                 // middle template row
+    constexpr int LAST_W = FOLD ? KM : K - 1;       // last template row whose weights are loaded
+    if constexpr (S <= LAST_W) {
+        cur.wait();
+        if constexpr (S < LAST_W) nxt.template issue<W_OFF + (S + 1) * K * (int)sizeof(TC)>(w_base);
+    }
     __builtin_amdgcn_sched_barrier(0);
     acc_t<TC> y, z;
-    if constexpr (S > 0) {
-        y = X[S - 1];
-        z = yprev;
-    } else if constexpr (sizeof(TC) != 4) {
-        y = acc_zero<TC>();
-        z = acc_zero<TC>();
+    if constexpr (FOLD) {
+        if constexpr (S <= KM) pk_row<K, true>(A, B, cur, QA[S], QB[S]);
+        constexpr int F = S <= KM ? S : K - 1 - S;
+        if constexpr (S == 0) {
+            y = QA[0];
+            z = QB[0];
+        } else {
+            y = X[S - 1] + QA[F];
+            z = yprev + QB[F];
+        }
+    } else {
+        if constexpr (S > 0) {
+            y = X[S - 1];
+            z = yprev;
+        } else if constexpr (sizeof(TC) != 4) {
+            y = acc_zero<TC>();
+            z = acc_zero<TC>();
+        }
+        if constexpr (sizeof(TC) == 4) pk_row<K, S == 0>(A, B, cur, y, z);
+        else two_chains<0, TC, K>(A, B, cur, y, z);
     }
-    if constexpr (sizeof(TC) == 4) pk_row<K, S == 0>(A, B, cur, y, z);
-    else two_chains<0, TC, K>(A, B, cur, y, z);
     if constexpr (S > 0) X[S - 1] = zprev;
     // pin this step's FMAs between the two hand-placed scalar loads: without a (volatile) use of
     // their results the optimiser sinks them below all K loads and spills the weights
@@ -434,7 +457,7 @@ __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowReg
     pin_acc(z);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S < K - 1) {
-        steps2_rec<S + 1, TC, K, W_OFF>(A, B, w_base, X, outA, outB, y, z, nxt, cur);
+        steps2_rec<S + 1, TC, K, W_OFF, SYM>(A, B, w_base, X, outA, outB, y, z, nxt, cur, QA, QB);
     } else {
         outA = y;
         outB = z;
@@ -442,13 +465,14 @@ __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowReg
 }
 
 // W_OFF: byte offset of the weight set inside the weight buffer (0 = signal weights)
-template <typename TC, int K, int W_OFF>
+template <typename TC, int K, int W_OFF, bool SYM>
 __device__ __forceinline__ void steps2(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
                                        acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB)
 {
     WRow<TC, K> wa, wb;
+    acc_t<TC> QA[(K + 1) / 2], QB[(K + 1) / 2];
     wa.template issue<W_OFF>(w_base);
-    steps2_rec<0, TC, K, W_OFF>(A, B, w_base, X, outA, outB, acc_zero<TC>(), acc_zero<TC>(), wa, wb);
+    steps2_rec<0, TC, K, W_OFF, SYM>(A, B, w_base, X, outA, outB, acc_zero<TC>(), acc_zero<TC>(), wa, wb, QA, QB);
 }
 
 // Lean view of the launch arguments (only what the row loop needs stays in registers).
@@ -529,7 +553,7 @@ __device__ __forceinline__ bool stream_missing(const StreamArgs<TC>& A, int p, i
 // into per-row / per-column tables (cs_mask_prep.hip) plus a K-term cross product that is only
 // needed on output rows with a flagged row in reach; pixels whose window leaves the matrix or the
 // diagonal range 0..max_dist get a precomputed correction.  The data path is that of MODE 0.
-template <typename TC, int K, int MODE>
+template <typename TC, int K, int MODE, bool SYM>
 __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
@@ -803,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
         fetch(t + 3, nx1);
 
         acc_t<TC> outA, outB;
-        steps2<TC, K, 0>(ra, rb, A.w, X, outA, outB);
+        steps2<TC, K, 0, SYM>(ra, rb, A.w, X, outA, outB);
 
         acc_t<TC> kaA = acc_zero<TC>(), kaB = acc_zero<TC>(), kbA = acc_zero<TC>(), kbB = acc_zero<TC>();
         if constexpr (MASKED) {
@@ -811,8 +835,8 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
             // same scheme with the two mask weight sets
             ra.to_missing_flags();
             rb.to_missing_flags();
-            steps2<TC, K, K * K * (int)sizeof(TC)>(ra, rb, A.w, XA, kaA, kaB);
-            steps2<TC, K, 2 * K * K * (int)sizeof(TC)>(ra, rb, A.w, XB, kbA, kbB);
+            steps2<TC, K, K * K * (int)sizeof(TC), SYM>(ra, rb, A.w, XA, kaA, kaB);
+            steps2<TC, K, 2 * K * K * (int)sizeof(TC), SYM>(ra, rb, A.w, XB, kbA, kbB);
         }
 
         if (t >= K - 1) {

@@ -68,6 +68,7 @@ struct CorrArgs {
     int tile_w, tile_h;
     int out_lo, out_hi;      // only pixels with out_lo <= j - i <= out_hi are produced
     int n_cu;                // compute units of the device (launch shaping)
+    int w_sym;               // all three weight sets are symmetric under a vertical flip (row s == row km-1-s)
     // factorised per-bin mask sums of the streaming kernel (cs_mask_prep.hip); reg_mode = 1:
     // strips whose windows stay inside the matrix use the tables, the others the general path
     int reg_mode;

@@ -15,11 +15,13 @@ from oracle import c_oracle
 pytestmark = pytest.mark.gpu
 
 
-def make_kernel(rng, k, flat=False):
+def make_kernel(rng, k, flat=False, sym=False):
     if flat:   # borders-like, piecewise constant
         kern = np.where(np.add.outer(np.arange(k), np.arange(k)) < k, 0.5, 1.5)
     else:
         kern = rng.random((k, k)) + 0.5
+    if sym:    # loops-like: identical under a vertical flip (the device folds template rows)
+        kern = (kern + kern[::-1, :]) / 2
     return kern
 
 
@@ -96,8 +98,10 @@ def check(got, want, precision, rare=1e-3):
 
 
 CASES = [
-    # n, K, max_dist, miss_frac, precision, flat template
+    # n, K, max_dist, miss_frac, precision, flat template (2 = vertically symmetric instead)
     (700, 17, 233, 0.02, "f32", False),
+    (700, 17, 233, 0.02, "f32", 2),
+    (800, 11, 60, 0.05, "f32", 2),
     (700, 17, 233, 0.02, "f64", False),
     (900, 17, 40, 0.06, "f32", False),
     (500, 7, 5, 0.10, "f64", False),       # max_dist below the template size: the two edges overlap
@@ -107,11 +111,11 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}k{c[1]}md{c[2]}{c[4]}" for c in CASES])
+@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}k{c[1]}md{c[2]}{c[4]}{'sym' if c[5] == 2 else ''}" for c in CASES])
 def test_band_regular_vs_general_and_oracle(case):
     n, k, max_dist, miss_frac, precision, flat = case
     rng = np.random.default_rng(n * 31 + k)
-    kern = make_kernel(rng, k, flat)
+    kern = make_kernel(rng, k, flat is True, sym=(flat == 2))
     a, miss = intra_map(rng, n, min(max_dist, n) + k, miss_frac)
     tol = 0.5
     reg = run_band(a, miss, kern, max_dist, precision, tol, general=False)

@@ -167,6 +167,25 @@ def detect_wallclock():
             "input": "data_test/example.cool (720 bins, 3 chromosomes), loops defaults, 1 GPU"}
 
 
+def pmc_traffic(args, wl):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_counters.json, written by tools/summarize_profiles.py: FETCH_SIZE with its
+    measured calibration + WRITE_SIZE).  Counters cannot be read from inside the timed process, so
+    this is the figure of the profiled run of the same command; None when no such record exists."""
+    import glob
+    if args.workload != "c2" or args.size not in (None, 4096) or args.precision != "f32":
+        return None, "no PMC record for this workload"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
+    for path in reversed(files):
+        try:
+            rec = json.load(open(path)).get("c2_4096_f32", {})
+        except (OSError, ValueError):
+            continue
+        if "hbm_bytes_per_dispatch" in rec:
+            return int(rec["hbm_bytes_per_dispatch"]), f"{os.path.basename(path)}: {rec.get('hbm_bytes_note', '')}"
+    return None, "no PMC record"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -229,6 +248,7 @@ def main():
         achieved_tf = flop / (kernel_ms * 1e-3) / 1e12
         peak_tf = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
         achieved_gbs = wl.bytes_per_pixel * wl.pixels / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_note = pmc_traffic(args, wl)
         out = {
             "metric": "Mpixels/s normxcorr2 (17x17 loops kernel)",
             "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
@@ -239,7 +259,7 @@ def main():
                        "parallelism": f"{world} independent sub-matrices, one per GPU"},
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
+                "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "note": f"714 flop/pixel (SURVEY 8d) x {wl.pixels} pixels per launch / {kernel_ms:.4f} ms "
                         "(HIP events); the FP32 FMA roof binds before HBM at 17x17; peak = dense FP32 "
                         "matrix/vector peak",

@@ -16,7 +16,6 @@ template <typename TC>
 static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
 {
     using G = StreamGeom<CS_K>;
-    constexpr size_t smem = corr_stream_smem_bytes<CS_K, TC>();
     StreamArgs<TC> S;
     S.sig = A.sig.ptr;
     S.out = A.out.ptr;
@@ -66,15 +65,15 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     // dispatcher packs three-deep on one CU leaves another CU short and sets the kernel time.
     // Asking for more LDS than a third (half) of the 160 KB caps the residency at 2 (1) workgroups
     // per CU, which spreads such launches evenly.
-    size_t smem_req = smem;
-    if (A.n_cu > 0) {
-        const int per_cu = (blocks + A.n_cu - 1) / A.n_cu;
-        if (per_cu <= 2) {
-            const size_t cap = (size_t)160 * 1024 / (per_cu + 1) + 1024;
-            if (cap > smem_req) smem_req = cap;
+    auto launch = [&](auto kern, size_t smem) -> int {
+        size_t smem_req = smem;
+        if (A.n_cu > 0) {
+            const int per_cu = (blocks + A.n_cu - 1) / A.n_cu;
+            if (per_cu <= 2) {
+                const size_t cap = (size_t)160 * 1024 / (per_cu + 1) + 1024;
+                if (cap > smem_req) smem_req = cap;
+            }
         }
-    }
-    auto launch = [&](auto kern) -> int {
         if (smem_req > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req);
             if (e != hipSuccess) return (int)e;
@@ -82,18 +81,20 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem_req, stream, S);
         return (int)hipGetLastError();
     };
+    constexpr size_t smem0 = corr_stream_smem_bytes<CS_K, TC, 0>(), smem1 = corr_stream_smem_bytes<CS_K, TC, 1>(),
+                     smem2 = corr_stream_smem_bytes<CS_K, TC, 2>();
     // vertically symmetric templates (float32 kernels only): folded template rows, see steps2_rec
     if constexpr (sizeof(TC) == 4) {
         if (A.w_sym) {
-            if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, true>);
-            if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, true>);
-            return launch(corr_stream_kernel<TC, CS_K, 0, true>);
+            if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, true>, smem2);
+            if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, true>, smem1);
+            return launch(corr_stream_kernel<TC, CS_K, 0, true>, smem0);
         }
     }
     // per-bin mask: factorised mask sums (tables built by cs_api.cpp prepare_regular_mask)
-    if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, false>);
-    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, false>);
-    return launch(corr_stream_kernel<TC, CS_K, 0, false>);
+    if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, false>, smem2);
+    if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, false>, smem1);
+    return launch(corr_stream_kernel<TC, CS_K, 0, false>, smem0);
 }
 
 #define CS_CAT_(a, b) a##b

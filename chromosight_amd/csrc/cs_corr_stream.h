@@ -41,8 +41,19 @@ struct StreamGeom {
     static constexpr int LW = TW + K - 1;           // staged columns per row
     static constexpr int LWP = ((LW + 3) / 4) * 4;  // row pitch in elements (16-byte multiple)
     static constexpr int RING = K + 4;              // rows t-K .. t+3 are live (two rows per iteration)
-    static constexpr int NWAVES = 4;                // independent waves per workgroup
+    // Float32 kernels without the -0.0 mask encoding keep the horizontal box sums of the last K
+    // staged rows (4 floats per lane and row) instead of the rows themselves: the row leaving
+    // the window is then one 16-byte LDS read instead of a row reload and 40 VALU ops, and the
+    // data ring shrinks to the 4 rows in flight.
+    static constexpr int DATA_ROWS_HC = 4;
+    static constexpr int HC_FLOATS = K * kWave * 4;
+#ifndef CS_NWAVES
+#define CS_NWAVES 4
+#endif
+    static constexpr int NWAVES = CS_NWAVES;        // independent waves per workgroup
     static constexpr int ROWS = RING + 1;           // LDS rows per wave: the ring + the column-flag row (MODE 2)
+    // elements of LDS per wave
+    static constexpr int wave_elems(bool hcache) { return hcache ? (DATA_ROWS_HC + 1) * LWP + HC_FLOATS : ROWS * LWP; }
 };
 
 // weights are read through the constant address space so that the (wave-uniform) loads are
@@ -554,7 +565,7 @@ __device__ __forceinline__ bool stream_missing(const StreamArgs<TC>& A, int p, i
 // needed on output rows with a flagged row in reach; pixels whose window leaves the matrix or the
 // diagonal range 0..max_dist get a precomputed correction.  The data path is that of MODE 0.
 template <typename TC, int K, int MODE, bool SYM>
-__global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC> A)
+__global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
     constexpr int KH = (K - 1) / 2;
@@ -563,7 +574,9 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    TC* ring = reinterpret_cast<TC*>(smem_raw) + (size_t)wv * G::ROWS * G::LWP;
+    constexpr bool HCACHE = sizeof(TC) == 4 && !MASKED;
+    constexpr int DATA_ROWS = HCACHE ? G::DATA_ROWS_HC : G::RING;
+    TC* ring = reinterpret_cast<TC*>(smem_raw) + (size_t)wv * G::wave_elems(HCACHE);
 
     // strip of this wave (uniform per wave); x fastest so that neighbouring waves share halos
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * G::NWAVES + wv);
@@ -586,7 +599,12 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
 
     // zero the ring: rows "older" than the strip are read (and subtracted) as zeros, which
     // makes the row loop branch free
-    for (int idx = lane; idx < G::RING * G::LWP; idx += kWave) ring[idx] = TC(0);
+    TC* hcache = ring + (DATA_ROWS + 1) * G::LWP;      // after the data rows and the column-flag row
+    if constexpr (HCACHE) {
+        for (int idx = lane; idx < G::HC_FLOATS; idx += kWave) hcache[idx] = TC(0);
+    } else {
+        for (int idx = lane; idx < G::RING * G::LWP; idx += kWave) ring[idx] = TC(0);
+    }
 
     // ---- per-lane staging state: lanes 0..LWP/4-1 move 4 consecutive elements of each row ----
     // element (p, q) lives at p * ld + q - shift(p); dense: shift = 0, band: shift = p + lo
@@ -663,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
     // MODE 2: column terms of the factorised mask sums (constant over the strip) and the strip's
     // column flags as a staged row for the cross product
     TC ncol[2] = {TC(0), TC(0)}, ca_col[2] = {TC(0), TC(0)}, cb_col[2] = {TC(0), TC(0)};
-    TC* cfl = ring + G::RING * G::LWP;
+    TC* cfl = ring + DATA_ROWS * G::LWP;
     if constexpr (REG) {
         for (int idx = lane; idx < G::LWP; idx += kWave) {
             const int q = j0 - KH + idx;
@@ -703,10 +721,10 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
     }
     auto ring_next = [](int slot, int by) {
         slot += by;
-        return slot >= G::RING ? slot - G::RING : slot;
+        return slot >= DATA_ROWS ? slot - DATA_ROWS : slot;
     };
     int slot_a = 0;                  // ring slot of row t (row t+1 is the next slot)
-    int slot_old = G::RING - K;      // ring slot of row t - K
+    int slot_old = HCACHE ? 0 : G::RING - K;      // ring slot of row t - K; HCACHE: slot of row t in the box-sum cache
 
     // horizontal box sums of one ring row (and the number of missing flags in it)
     auto row_sums = [&](int slot, TC (&h1)[2], TC (&h2)[2], TC (&cnt)[2]) {
@@ -721,6 +739,24 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
             cnt[0] = c0;
             cnt[1] = (c0 - r.at(0)) + r.at(K);
         }
+    };
+
+    // box-sum cache: slot (row mod K) holds the sums of the row that leaves the window when the
+    // row with the same index mod K enters: read them, then store the entering row's sums
+    auto hcache_swap = [&](int slot, const TC (&h1)[2], const TC (&h2)[2], TC (&g1)[2], TC (&g2)[2]) {
+        typedef TC v4 __attribute__((ext_vector_type(4)));
+        v4* cell = reinterpret_cast<v4*>(hcache + (slot * kWave + lane) * 4);
+        const v4 old = *cell;
+        v4 cur;
+        cur.x = h1[0];
+        cur.y = h1[1];
+        cur.z = h2[0];
+        cur.w = h2[1];
+        *cell = cur;
+        g1[0] = old.x;
+        g1[1] = old.y;
+        g2[0] = old.z;
+        g2[1] = old.w;
     };
 
     auto row_flags = [&](const RowRegs<TC, K>& r, TC (&cnt)[2]) {
@@ -798,7 +834,8 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
             TC h1[2], h2[2], g1[2], g2[2], gc[2] = {TC(0), TC(0)}, hc[2] = {TC(0), TC(0)};
             ra.load(ring + slot_a * G::LWP + lane * 2);
             row_box<TC, K>(ra, h1, h2);
-            row_sums(slot_old, g1, g2, gc);
+            if constexpr (HCACHE) hcache_swap(slot_old, h1, h2, g1, g2);
+            else row_sums(slot_old, g1, g2, gc);
             if constexpr (MASKED) row_flags(ra, hc);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -811,7 +848,8 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
             }
             rb.load(ring + slot_b * G::LWP + lane * 2);
             row_box<TC, K>(rb, h1, h2);
-            row_sums(ring_next(slot_old, 1), g1, g2, gc);
+            if constexpr (HCACHE) hcache_swap(slot_old + 1 >= K ? slot_old + 1 - K : slot_old + 1, h1, h2, g1, g2);
+            else row_sums(ring_next(slot_old, 1), g1, g2, gc);
             if constexpr (MASKED) row_flags(rb, hc);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -890,15 +928,16 @@ __global__ __launch_bounds__(256, 2) void corr_stream_kernel(const StreamArgs<TC
         commit(ring_next(slot_a, 2), nx0);
         commit(ring_next(slot_a, 3), nx1);
         slot_a = ring_next(slot_a, 2);
-        slot_old = ring_next(slot_old, 2);
+        if constexpr (HCACHE) slot_old = slot_old + 2 >= K ? slot_old + 2 - K : slot_old + 2;
+        else slot_old = ring_next(slot_old, 2);
     }
 }
 
-template <int K, typename TC>
+template <int K, typename TC, int MODE>
 constexpr size_t corr_stream_smem_bytes()
 {
     using G = StreamGeom<K>;
-    return sizeof(TC) * G::NWAVES * G::ROWS * G::LWP;
+    return sizeof(TC) * G::NWAVES * G::wave_elems(sizeof(TC) == 4 && MODE != 1);
 }
 
 }  // namespace cs

@@ -1,6 +1,7 @@
 // cs_corr_fast.hip -- explicit instantiations of the streaming Pearson kernel
 // (cs_corr_stream.h) for one compile-time template size.  Compiled once per size with
 // -DCS_K=<odd K> so that the sizes build in parallel.
+#include <cstdio>
 #include <cstdlib>
 
 #include "cs_corr_stream.h"
@@ -38,6 +39,32 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.strip_h = A.tile_h;
     S.strips_x = A.tiles_x;
     S.strips_y = A.tiles_y;
+    S.split_sy = 0;
+    S.strip_h2 = A.tile_h;
+    // Single generation of two waves per SIMD (e.g. dense 4096^2 on 256 CUs): the arbiter favours
+    // the wave that started first.  Measured with per-wave clocks on C2 (uniform 64-row strips):
+    // on every SIMD the first wave finished after 214k cycles, the second after 290k, alone for the
+    // last quarter at ~60 % of the two-wave VALU rate.  Workgroups are placed in launch order, so
+    // giving the first half of the row blocks 5/4 and the second half 3/4 of the height makes each
+    // pair finish together: C2 110 -> 116 Gpixel/s (the reverse split loses 6 %, as it must).
+    {
+        const long long n_simd = (long long)(A.n_cu > 0 ? A.n_cu : 0) * 4;
+        const long long waves = (long long)A.tiles_x * A.tiles_y;
+        const char* e = getenv("CHROMOSIGHT_HIP_SPLIT");   // "h1,h2" forces a split, "0" disables it
+        int h1 = 0, h2 = 0;
+        if (e && sscanf(e, "%d,%d", &h1, &h2) == 2) {
+        } else if (!e && !S.band_out && n_simd > 0 && waves > n_simd && waves <= 2 * n_simd && A.tile_h >= 32) {
+            h1 = (A.tile_h * 5 / 4 + 1) & ~1;
+            h2 = 2 * A.tile_h - h1;
+        }
+        if (h1 > 0 && h2 > 0 && !S.band_out) {
+            const int pairs = (A.ms + h1 + h2 - 1) / (h1 + h2);
+            S.strip_h = h1;
+            S.strip_h2 = h2;
+            S.split_sy = pairs;
+            S.strips_y = 2 * pairs;
+        }
+    }
     S.ks = A.ks;
     S.mask_mode = A.mask_mode;
     S.max_dist = A.max_dist;
@@ -59,7 +86,7 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.coltab = A.coltab;
     S.fix_lo = A.fix_lo;
     S.fix_hi = A.fix_hi;
-    const int n_waves = A.tiles_x * A.tiles_y;
+    const int n_waves = S.strips_x * S.strips_y;
     const int blocks = (n_waves + G::NWAVES - 1) / G::NWAVES;
     // A launch of at most two workgroups per CU is a single generation of waves: whatever the
     // dispatcher packs three-deep on one CU leaves another CU short and sets the kernel time.

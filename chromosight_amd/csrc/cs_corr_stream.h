@@ -375,6 +375,36 @@ struct RowRegs<float, K> {
 // sums keep the dependency chains short (an in-order wave with one or two co-resident waves
 // cannot hide a 16-deep chain of dependent adds); the entering and the leaving row use the same
 // association, so the sliding difference stays exact.
+// float32 rows are held as aligned pairs: packed adds / FMAs over the (K+1)/2 pairs give the sums of
+// v[0..K] split by parity; the two windows drop v[K] and v[0] respectively.  Half the VALU ops of
+// the scalar form below.  (Any fixed association is fine: each row's sums are computed once.)
+template <int K>
+__device__ __forceinline__ void row_box_packed(const RowRegs<float, K>& r, float (&h1)[2], float (&h2)[2])
+{
+    static_assert(K % 2 == 1, "pairs cover v[0..K] exactly for odd K");
+    constexpr int NE = (K + 1) / 2;
+    f32x2 a = r.e[0], b = r.e[1];
+    f32x2 qa = r.e[0] * r.e[0], qb = r.e[1] * r.e[1];
+#pragma unroll
+    for (int m = 2; m < NE; ++m) {
+        if (m & 1) {
+            b += r.e[m];
+            qb = __builtin_elementwise_fma(r.e[m], r.e[m], qb);
+        } else {
+            a += r.e[m];
+            qa = __builtin_elementwise_fma(r.e[m], r.e[m], qa);
+        }
+    }
+    a += b;
+    qa += qb;
+    const float t1 = a.x + a.y, t2 = qa.x + qa.y;      // sums over v[0..K]
+    const float v0 = r.e[0].x, vk = r.e[NE - 1].y;
+    h1[0] = t1 - vk;
+    h1[1] = t1 - v0;
+    h2[0] = fmaf(-vk, vk, t2);
+    h2[1] = fmaf(-v0, v0, t2);
+}
+
 template <typename TC, int K>
 __device__ __forceinline__ void row_box(const RowRegs<TC, K>& r, TC (&h1)[2], TC (&h2)[2])
 {
@@ -500,6 +530,7 @@ struct StreamArgs {
     int ms, ns;
     int full, sym_upper;
     int strip_h, strips_x, strips_y;
+    int split_sy, strip_h2;        // row blocks >= split_sy have height strip_h2 (two-height tiling), 0 = uniform
     // missing mask (MASKED kernels only)
     int mask_mode;                 // 1: per-bin flags, 2: explicit uint8 map with the signal's geometry
     int max_dist;                  // -1: None
@@ -583,7 +614,11 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     if (wid >= A.strips_x * A.strips_y) return;
     const int sy = wid / A.strips_x;
     const int sx = wid - sy * A.strips_x;
-    const int i0 = sy * A.strip_h;                        // first output row
+    // two-height tiling: the row blocks of the second half of a single-generation launch are
+    // shorter (launch_fast in cs_corr_fast.hip): their waves start second on every SIMD
+    const bool late = A.split_sy > 0 && sy >= A.split_sy;
+    const int strip_h = late ? A.strip_h2 : A.strip_h;
+    const int i0 = late ? A.split_sy * A.strip_h + (sy - A.split_sy) * A.strip_h2 : sy * A.strip_h;   // first output row
     int j0 = sx * G::TW;                                  // first output column
     if (A.band_out) {
         // band outputs: the strips of a row block start at the block's first in-band column
@@ -591,10 +626,11 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         int jmin = i0 + A.out_lo;
         if (jmin < 0) jmin = 0;
         j0 += jmin;
-        const int dmin = j0 - (i0 + A.strip_h - 1);
+        const int dmin = j0 - (i0 + strip_h - 1);
         if (j0 >= A.ns || dmin > A.out_hi) return;
     }
-    const int rows_out = min(A.strip_h, A.ms - i0);
+    if (i0 >= A.ms) return;
+    const int rows_out = min(strip_h, A.ms - i0);
     const int n_staged = rows_out + K - 1;
 
     // zero the ring: rows "older" than the strip are read (and subtracted) as zeros, which
@@ -833,7 +869,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         {
             TC h1[2], h2[2], g1[2], g2[2], gc[2] = {TC(0), TC(0)}, hc[2] = {TC(0), TC(0)};
             ra.load(ring + slot_a * G::LWP + lane * 2);
-            row_box<TC, K>(ra, h1, h2);
+            if constexpr (HCACHE) row_box_packed<K>(ra, h1, h2);
+            else row_box<TC, K>(ra, h1, h2);
             if constexpr (HCACHE) hcache_swap(slot_old, h1, h2, g1, g2);
             else row_sums(slot_old, g1, g2, gc);
             if constexpr (MASKED) row_flags(ra, hc);
@@ -847,7 +884,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 nmA[c] = nmiss[c];
             }
             rb.load(ring + slot_b * G::LWP + lane * 2);
-            row_box<TC, K>(rb, h1, h2);
+            if constexpr (HCACHE) row_box_packed<K>(rb, h1, h2);
+            else row_box<TC, K>(rb, h1, h2);
             if constexpr (HCACHE) hcache_swap(slot_old + 1 >= K ? slot_old + 1 - K : slot_old + 1, h1, h2, g1, g2);
             else row_sums(ring_next(slot_old, 1), g1, g2, gc);
             if constexpr (MASKED) row_flags(rb, hc);

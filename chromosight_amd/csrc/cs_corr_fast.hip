@@ -113,9 +113,9 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     // vertically symmetric templates (float32 kernels only): folded template rows, see steps2_rec
     if constexpr (sizeof(TC) == 4) {
         if (A.w_sym) {
+            // (the general masked kernel has no registers left for the shared row products)
             if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, true>, smem2);
-            if (A.mask_mode != 0) return launch(corr_stream_kernel<TC, CS_K, 1, true>, smem1);
-            return launch(corr_stream_kernel<TC, CS_K, 0, true>, smem0);
+            if (A.mask_mode == 0) return launch(corr_stream_kernel<TC, CS_K, 0, true>, smem0);
         }
     }
     // per-bin mask: factorised mask sums (tables built by cs_api.cpp prepare_regular_mask)

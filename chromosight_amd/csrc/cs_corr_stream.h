@@ -857,18 +857,26 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         d_out -= 1;
     };
 
-    // two staged rows (A = t, B = t + 1) per iteration; a virtual zero row pads an odd count
+    // two staged rows (A = t, B = t + 1) per iteration; a virtual zero row pads an odd count.
+    // The row registers of the next iteration are loaded from LDS right after the FMAs of this one
+    // (before its epilogue), so the LDS latency is hidden behind the epilogue.
+    // (only the float32 unmasked / factorised kernels have the registers for that)
+    constexpr bool PIPE = HCACHE;
+    RowRegs<TC, K> ra, rb;
+    if constexpr (PIPE) {
+        ra.load(ring + slot_a * G::LWP + lane * 2);
+        rb.load(ring + ring_next(slot_a, 1) * G::LWP + lane * 2);
+    }
     for (int t = 0; t < n_staged; t += 2) {
-        const int slot_b = ring_next(slot_a, 1);
-
-        // box sums of the two entering rows minus the two leaving rows; the registers of a
-        // leaving row die before the next row is loaded
-        RowRegs<TC, K> ra, rb;
+        if constexpr (!PIPE) {
+            ra.load(ring + slot_a * G::LWP + lane * 2);
+            rb.load(ring + ring_next(slot_a, 1) * G::LWP + lane * 2);
+        }
+        // box sums of the two entering rows minus the two leaving rows
         TC sA1[2], sA2[2];
         TC nmA[2] = {TC(0), TC(0)};
         {
             TC h1[2], h2[2], g1[2], g2[2], gc[2] = {TC(0), TC(0)}, hc[2] = {TC(0), TC(0)};
-            ra.load(ring + slot_a * G::LWP + lane * 2);
             if constexpr (HCACHE) row_box_packed<K>(ra, h1, h2);
             else row_box<TC, K>(ra, h1, h2);
             if constexpr (HCACHE) hcache_swap(slot_old, h1, h2, g1, g2);
@@ -883,7 +891,6 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 nmiss[c] += hc[c] - gc[c];
                 nmA[c] = nmiss[c];
             }
-            rb.load(ring + slot_b * G::LWP + lane * 2);
             if constexpr (HCACHE) row_box_packed<K>(rb, h1, h2);
             else row_box<TC, K>(rb, h1, h2);
             if constexpr (HCACHE) hcache_swap(slot_old + 1 >= K ? slot_old + 1 - K : slot_old + 1, h1, h2, g1, g2);
@@ -913,6 +920,19 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
             rb.to_missing_flags();
             steps2<TC, K, K * K * (int)sizeof(TC), SYM>(ra, rb, A.w, XA, kaA, kaB);
             steps2<TC, K, 2 * K * K * (int)sizeof(TC), SYM>(ra, rb, A.w, XB, kbA, kbB);
+        }
+
+        auto advance = [&]() {
+            commit(ring_next(slot_a, 2), nx0);
+            commit(ring_next(slot_a, 3), nx1);
+            slot_a = ring_next(slot_a, 2);
+            if constexpr (HCACHE) slot_old = slot_old + 2 >= K ? slot_old + 2 - K : slot_old + 2;
+            else slot_old = ring_next(slot_old, 2);
+        };
+        if constexpr (PIPE) {   // rows t+2, t+3 for the next iteration (zeros past the strip)
+            advance();
+            ra.load(ring + slot_a * G::LWP + lane * 2);
+            rb.load(ring + ring_next(slot_a, 1) * G::LWP + lane * 2);
         }
 
         if (t >= K - 1) {
@@ -963,11 +983,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 emit(oi + 1, outB, sB1, sB2, nmiss, kaB, kbB);
             }
         }
-        commit(ring_next(slot_a, 2), nx0);
-        commit(ring_next(slot_a, 3), nx1);
-        slot_a = ring_next(slot_a, 2);
-        if constexpr (HCACHE) slot_old = slot_old + 2 >= K ? slot_old + 2 - K : slot_old + 2;
-        else slot_old = ring_next(slot_old, 2);
+        if constexpr (!PIPE) advance();
     }
 }
 

@@ -268,51 +268,69 @@ int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, doub
 }
 
 // ------------------------------------------------------------------------------------------
-// float64 evaluation of the coefficient at a list of pixels (one lane per pixel; the window is
-// read straight from HBM/L2 -- candidate lists are tiny compared with the map)
+// float64 evaluation of the coefficient at a list of pixels: one wave per pixel, the lanes stride
+// over the window (read straight from HBM/L2 -- candidate lists are tiny compared with the map),
+// fixed-order butterfly reduction.  Lists are short (tens to thousands of pixels), so one lane per
+// pixel left the chip empty and a call cost the latency of 289 dependent loads.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double> A, const int* __restrict__ rows,
                                                           const int* __restrict__ cols, long long n_px,
                                                           double* __restrict__ out_corr,
                                                           double* __restrict__ out_nobs)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= n_px) return;
     const int oi = rows[t], oj = cols[t];
     double r = 0.0, nobs = A.ks.n;
     const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
-    if (inside && !pixel_forced_zero(A, oi, oj)) {
+    if (inside && !pixel_forced_zero(A, oi, oj)) {       // wave-uniform
         const int km = A.km, kn = A.kn, kk = km * kn;
         const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
         const bool masked = A.mask_mode != 0;
         double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
-        for (int ki = 0; ki < km; ++ki) {
-            const int p = oi - kh + ki;
-            for (int kj = 0; kj < kn; ++kj) {
-                const int q = oj - kw + kj;
-                const double v = load_signal(A, p, q);
-                cs_ = fma(v, A.w[ki * kn + kj], cs_);
-                s1 += v;
-                s2 = fma(v, v, s2);
-                if (masked && missing_pred(A, p, q)) {
-                    nm += 1.0;
-                    ka += A.w[kk + ki * kn + kj];
-                    kb += A.w[2 * kk + ki * kn + kj];
-                }
+        for (int e = lane; e < kk; e += 64) {
+            const int ki = e / kn, kj = e - ki * kn;
+            const int p = oi - kh + ki, q = oj - kw + kj;
+            const double v = load_signal(A, p, q);
+            cs_ = fma(v, A.w[e], cs_);
+            s1 += v;
+            s2 = fma(v, v, s2);
+            if (masked && missing_pred(A, p, q)) {
+                nm += 1.0;
+                ka += A.w[kk + e];
+                kb += A.w[2 * kk + e];
             }
+        }
+        cs_ = wave_sum(cs_);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (masked) {
+            nm = wave_sum(nm);
+            ka = wave_sum(ka);
+            kb = wave_sum(kb);
         }
         r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
     }
-    out_corr[t] = r;
-    if (out_nobs) out_nobs[t] = nobs;
+    if (lane == 0) {
+        out_corr[t] = r;
+        if (out_nobs) out_nobs[t] = nobs;
+    }
 }
 
 int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* cols, long long n_px,
                        double* out_corr, double* out_nobs, hipStream_t stream)
 {
     if (n_px == 0) return 0;
-    const int blocks = (int)((n_px + 255) / 256);
-    hipLaunchKernelGGL(rescore_f64_kernel, dim3(blocks), dim3(256), 0, stream, A, rows, cols, n_px, out_corr,
+    const long long blocks = (n_px + 3) / 4;              // 4 waves = 4 pixels per block
+    hipLaunchKernelGGL(rescore_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, rows, cols, n_px, out_corr,
                        out_nobs);
     return (int)hipGetLastError();
 }

@@ -232,6 +232,10 @@ __device__ __forceinline__ bool missing_bins(int ms, int ns, int K, int sym_uppe
 //   rows table: the first `top` output rows and the rows >= bot0, `width` entries each
 //               (x = j for dense outputs, x = (j - i) - x_lo for band outputs)
 //   cols table: (dense outputs) the first and last `side` columns of every row
+// One thread per (pixel, window row): 15 pixels x 17 rows per 256-thread block, partial sums over
+// the window row in registers, then a fixed-order sum over the rows through LDS.
+constexpr int kFramePixPerBlock = 256 / kMaxK;
+
 template <typename TC>
 __global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __restrict__ rbits_g,
                                                              const unsigned* __restrict__ cbits_g, int ms, int ns, int K,
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __r
                                                              TC* __restrict__ fix_rows, TC* __restrict__ fix_cols)
 {
     __shared__ TC wa_s[kMaxK * kMaxK], wb_s[kMaxK * kMaxK];
+    __shared__ TC part[kFramePixPerBlock][kMaxK][3];
     const int kk = K * K;
     for (int t = threadIdx.x; t < kk; t += blockDim.x) {
         wa_s[t] = w[kk + t];
@@ -249,45 +254,60 @@ __global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __r
     const int n_rows = top + (ms - bot0);
     const long long n_row_px = (long long)n_rows * width;
     const long long n_col_px = fix_cols ? (long long)ms * 2 * side : 0;
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_row_px + n_col_px) return;
-    int i, j;
-    TC* dst;
-    if (id < n_row_px) {
-        const int r = (int)(id / width), x = (int)(id - (long long)r * width);
-        i = r < top ? r : bot0 + (r - top);
-        j = x_band ? i + x_lo + x : x;
-        dst = fix_rows + id * 4;
-    } else {
-        const long long c = id - n_row_px;
-        i = (int)(c / (2 * side));
-        const int x = (int)(c - (long long)i * 2 * side);
-        j = x < side ? x : ns - 2 * side + x;
-        dst = fix_cols + c * 4;
+    const int slot = threadIdx.x / kMaxK, ki = threadIdx.x % kMaxK;
+    const long long id = (long long)blockIdx.x * kFramePixPerBlock + slot;
+    const bool live = slot < kFramePixPerBlock && id < n_row_px + n_col_px;
+    int i = 0, j = -1;
+    TC* dst = nullptr;
+    if (live) {
+        if (id < n_row_px) {
+            const int r = (int)(id / width), x = (int)(id - (long long)r * width);
+            i = r < top ? r : bot0 + (r - top);
+            j = x_band ? i + x_lo + x : x;
+            dst = fix_rows + id * 4;
+        } else {
+            const long long c = id - n_row_px;
+            i = (int)(c / (2 * side));
+            const int x = (int)(c - (long long)i * 2 * side);
+            j = x < side ? x : ns - 2 * side + x;
+            dst = fix_cols + c * 4;
+        }
     }
     const int KH = (K - 1) / 2;
     TC fn = TC(0), fa = TC(0), fb = TC(0);
-    if (j >= 0 && j < ns) {
+    if (live && ki < K && j >= 0 && j < ns) {
         const unsigned rbits = rbits_g[i], cbits = cbits_g[j];
-        for (int ki = 0; ki < K; ++ki) {
-            const int p = i - KH + ki;
-            const bool rflag = (rbits >> ki) & 1u;
-            for (int kj = 0; kj < K; ++kj) {
-                const bool cflag = (cbits >> kj) & 1u;
-                const int f = (missing_bins(ms, ns, K, sym_upper, max_dist, p, j - KH + kj, rflag, cflag) ? 1 : 0) -
-                              ((rflag | cflag) ? 1 : 0);
-                if (f != 0) {
-                    fn += (TC)f;
-                    fa += (TC)f * wa_s[ki * K + kj];
-                    fb += (TC)f * wb_s[ki * K + kj];
-                }
+        const int p = i - KH + ki;
+        const bool rflag = (rbits >> ki) & 1u;
+        for (int kj = 0; kj < K; ++kj) {
+            const bool cflag = (cbits >> kj) & 1u;
+            const int f = (missing_bins(ms, ns, K, sym_upper, max_dist, p, j - KH + kj, rflag, cflag) ? 1 : 0) -
+                          ((rflag | cflag) ? 1 : 0);
+            if (f != 0) {
+                fn += (TC)f;
+                fa += (TC)f * wa_s[ki * K + kj];
+                fb += (TC)f * wb_s[ki * K + kj];
             }
         }
     }
-    dst[0] = fn;
-    dst[1] = fa;
-    dst[2] = fb;
-    dst[3] = TC(0);
+    if (slot < kFramePixPerBlock) {
+        part[slot][ki][0] = fn;
+        part[slot][ki][1] = fa;
+        part[slot][ki][2] = fb;
+    }
+    __syncthreads();
+    if (live && ki == 0) {
+        TC n = TC(0), a = TC(0), b = TC(0);
+        for (int r = 0; r < K; ++r) {
+            n += part[slot][r][0];
+            a += part[slot][r][1];
+            b += part[slot][r][2];
+        }
+        dst[0] = n;
+        dst[1] = a;
+        dst[2] = b;
+        dst[3] = TC(0);
+    }
 }
 
 }  // namespace
@@ -320,7 +340,8 @@ int launch_mask_frame_fix(const unsigned* rbits, const unsigned* cbits, int ms, 
 {
     const long long n = (long long)(top + (ms - bot0)) * width + (fix_cols ? (long long)ms * 2 * side : 0);
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mask_frame_fix_kernel<TC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rbits, cbits, ms, ns, K,
+    hipLaunchKernelGGL(mask_frame_fix_kernel<TC>, dim3((unsigned)((n + kFramePixPerBlock - 1) / kFramePixPerBlock)), dim3(256), 0,
+                       stream, rbits, cbits, ms, ns, K,
                        sym_upper, max_dist, w, top, bot0, width, x_band, x_lo, side, fix_rows, fix_cols);
     return (int)hipGetLastError();
 }

@@ -154,9 +154,18 @@ class DeviceCsr:
 
 def diag_range(mat):
     """(lo, hi) of col - row over the stored entries of a sparse matrix, or None if empty."""
-    coo = mat.tocoo()
-    if coo.nnz == 0:
+    if mat.nnz == 0:
         return None
+    if mat.format == "csr":
+        counts = np.diff(mat.indptr)
+        rows = np.flatnonzero(counts)
+        if mat.has_sorted_indices:       # first / last stored column of every non-empty row
+            first = mat.indices[mat.indptr[rows]].astype(np.int64)
+            last = mat.indices[mat.indptr[rows + 1] - 1].astype(np.int64)
+            return int((first - rows).min()), int((last - rows).max())
+        d = mat.indices.astype(np.int64) - np.repeat(np.arange(mat.shape[0], dtype=np.int64), counts)
+        return int(d.min()), int(d.max())
+    coo = mat.tocoo()
     d = coo.col.astype(np.int64) - coo.row.astype(np.int64)
     return int(d.min()), int(d.max())
 

@@ -340,16 +340,24 @@ def _argmax_per_label(rows, cols, labels, scores):
 # window validation / neighbours / pileup (host)
 # ============================================================================================
 def _validate(coords, matrix, scores, missing_rows, missing_cols, kernel_shape, drop, zero_tol,
-              missing_tol):
-    """Shared body of validate_patterns: `scores[i]` is the coefficient at coords[i]."""
+              missing_tol, pad=(0, 0), stripe_k=0):
+    """Shared body of validate_patterns: `scores[i]` is the coefficient at coords[i].
+
+    pad = (rows, cols) and stripe_k describe, without materialising it, the map pattern_detector
+    validates on in full mode (reference detection.py:287-310): `matrix` framed by `pad` zero rows /
+    columns on every side, with NaN on the stripe_k sub-diagonals -1..-stripe_k of the framed map;
+    coords and the missing rows / columns are then indices into that framed map."""
     matrix = sp.csr_matrix(matrix)
     win_h, win_w = kernel_shape
     half_h, half_w = win_h // 2 + 1, win_w // 2 + 1
     n = coords.shape[0]
     out_scores = np.full(n, np.nan)
     windows = np.full((n, win_h, win_w), np.nan)
-    miss_r = np.zeros(matrix.shape[0], dtype=bool)
-    miss_c = np.zeros(matrix.shape[1], dtype=bool)
+    pad_r, pad_c = pad
+    inner_shape = matrix.shape
+    framed_shape = (inner_shape[0] + 2 * pad_r, inner_shape[1] + 2 * pad_c)
+    miss_r = np.zeros(framed_shape[0], dtype=bool)
+    miss_c = np.zeros(framed_shape[1], dtype=bool)
     miss_r[missing_rows] = True
     miss_c[missing_cols] = True
     p1 = coords[:, 0].astype(np.int64)
@@ -357,7 +365,7 @@ def _validate(coords, matrix, scores, missing_rows, missing_cols, kernel_shape, 
     high, low = p1 - half_h + 1, p1 + half_h
     left, right = p2 - half_w + 1, p2 + half_w
     # strict upper bounds, as in the reference (detection.py:99-104)
-    inside = (high >= 0) & (low < matrix.shape[0]) & (left >= 0) & (right < matrix.shape[1])
+    inside = (high >= 0) & (low < framed_shape[0]) & (left >= 0) & (right < framed_shape[1])
     failed = ~inside
     scores = np.asarray(scores, dtype=np.float64)
     # all windows of a chunk are read with one vectorised CSR lookup instead of one sparse slice
@@ -372,7 +380,16 @@ def _validate(coords, matrix, scores, missing_rows, missing_cols, kernel_shape, 
         shape = (sel.size, dr.shape[1], dc.shape[2])
         flat_r = np.broadcast_to(rr, shape).ravel()
         flat_c = np.broadcast_to(cc, shape).ravel()
-        win = np.asarray(matrix[flat_r, flat_c], dtype=np.float64).reshape(shape)
+        if pad_r or pad_c:
+            src_r, src_c = flat_r - pad_r, flat_c - pad_c
+            stored = (src_r >= 0) & (src_r < inner_shape[0]) & (src_c >= 0) & (src_c < inner_shape[1])
+            win = np.asarray(matrix[np.where(stored, src_r, 0), np.where(stored, src_c, 0)], dtype=np.float64).ravel()
+            win = np.where(stored, win, 0.0).reshape(shape)
+        else:
+            win = np.asarray(matrix[flat_r, flat_c], dtype=np.float64).reshape(shape)
+        if stripe_k:
+            d = np.broadcast_to(cc - rr, shape)
+            win[(d <= -1) & (d >= -stripe_k)] = np.nan
         win[np.broadcast_to(miss_r[rr] | miss_c[cc], shape)] = np.nan
         tot = win[0].size
         n_zero = np.count_nonzero(win == 0, axis=(1, 2))
@@ -520,14 +537,15 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
     with np.errstate(all="ignore"):
         logp = np.where(r64 != 0, cus.corr_to_pval(r64, np.where(n_obs == 0, km * kn, n_obs)), 0.0)
 
-    # window validation on the (zero padded when full) contact map, detection.py:287-329
-    mat = csr
+    # window validation on the (zero padded when full) contact map with NaN sub-diagonals
+    # (detection.py:287-329); the padded map is described to _validate, not built
     missing_rows = preproc.valid_to_missing(contact_map.detectable_bins[0], ms)
     missing_cols = preproc.valid_to_missing(contact_map.detectable_bins[1], ns)
     vcoords = coords.copy()
+    pad = (0, 0)
     if full:
-        mat = preproc.zero_pad_sparse(mat, kh, kw, fmt="csr")
-        in_r = np.ones(ms + 2 * kw, dtype=bool)  # zero_pad_sparse(mat, kh, kw): kh columns, kw rows
+        pad = (kw, kh)                           # zero_pad_sparse(mat, kh, kw): kh columns, kw rows
+        in_r = np.ones(ms + 2 * kw, dtype=bool)
         in_c = np.ones(ns + 2 * kh, dtype=bool)
         det_r = np.asarray(contact_map.detectable_bins[0]) + kh
         det_c = np.asarray(contact_map.detectable_bins[1]) + kw
@@ -545,14 +563,9 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
                     coords_in[:, 0] = coords_in[:, 1]
             except (TypeError, ValueError, IndexError):
                 pass
-    if not inter:
-        big_k = max(km, kn)
-        mat = sp.csr_matrix(mat, dtype=np.float64)
-        stripes = sp.diags([np.full(mat.shape[0], np.nan)] * big_k, -np.arange(1, big_k + 1),
-                           shape=mat.shape, format="csr")
-        mat = mat + stripes
-    table, windows = _validate(vcoords, mat, conv_at, missing_rows, missing_cols, (km, kn),
-                               drop=(run_mode == "detect"), zero_tol=zero_tol, missing_tol=missing_tol)
+    table, windows = _validate(vcoords, csr, conv_at, missing_rows, missing_cols, (km, kn),
+                               drop=(run_mode == "detect"), zero_tol=zero_tol, missing_tol=missing_tol,
+                               pad=pad, stripe_k=0 if inter else max(km, kn))
     kept = table.index.to_numpy()
     if full:
         table.bin1 -= kh

@@ -56,17 +56,50 @@ def balanced_intra_block(cool, chrom_idx):
     return sp.coo_matrix((vals, (rows, cols)), shape=(e - s, e - s))
 
 
+def balanced_upper_band(cool, chrom_idx, keep):
+    """Upper band (diagonals 0..keep) of the balanced intra block as CSR, built straight from the
+    pixel table: cooler stores the upper triangle sorted by (bin1, bin2), so a chromosome is one
+    contiguous run of pixels and the CSR row pointer is a searchsorted.  Everything the path uses
+    downstream (distance law over diagonals >= 0, detrend, trim to 0..keep) only looks at this
+    band, so the symmetric block of balanced_intra_block never needs to exist."""
+    off = cool["chrom_offset"]
+    s, e = int(off[chrom_idx]), int(off[chrom_idx + 1])
+    n = e - s
+    b1, b2, w = cool["bin1_id"], cool["bin2_id"], cool["weight"]
+    if "_bin1_sorted" not in cool:
+        cool["_bin1_sorted"] = bool(np.all(b1[1:] >= b1[:-1]))
+    if cool["_bin1_sorted"]:
+        lo, hi = np.searchsorted(b1, [s, e])
+        r1, r2, cnt = b1[lo:hi], b2[lo:hi], cool["count"][lo:hi]
+    else:
+        sel = (b1 >= s) & (b1 < e)
+        r1, r2, cnt = b1[sel], b2[sel], cool["count"][sel]
+    d = r2 - r1
+    sel = (r2 < e) & (d >= 0) & (d <= keep)
+    r1, r2 = r1[sel], r2[sel]
+    v = cnt[sel] * w[r1] * w[r2]
+    r = (r1 - s).astype(np.int64)
+    c = (r2 - s).astype(np.int32)
+    if r.size == 0 or (np.all(r[1:] >= r[:-1]) and np.all((r[1:] > r[:-1]) | (c[1:] > c[:-1]))):
+        indptr = np.searchsorted(r, np.arange(n + 1)).astype(np.int32 if r.size < 2 ** 31 else np.int64)
+        return sp.csr_matrix((v, c, indptr), shape=(n, n))
+    m = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()     # unsorted / duplicated pixel table
+    return m
+
+
 def prepare_intra_block(cool, chrom_idx, max_dist, largest_kernel, name=None):
     """ContactMap.create_mat for a balanced intra block: detrend by the distance law on the
     first keep_distance diagonals, set >= 10 to 1, keep the upper band, NaN -> 0."""
     off = cool["chrom_offset"]
     s, e = int(off[chrom_idx]), int(off[chrom_idx + 1])
-    det_all = np.flatnonzero(np.isfinite(cool["weight"]))
-    det = det_all[(det_all >= s) & (det_all < e)] - s
-    block = balanced_intra_block(cool, chrom_idx)
-    keep = min(max_dist, block.shape[0]) + largest_kernel
-    mat = preproc.detrend(block, max_dist=keep, smooth=False, detectable_bins=det, max_val=10)
-    mat = preproc.diag_trim(mat.tocsr(), keep)
+    det_all = cool.get("_detectable")
+    if det_all is None:
+        det_all = cool["_detectable"] = np.flatnonzero(np.isfinite(cool["weight"]))
+    lo, hi = np.searchsorted(det_all, [s, e])
+    det = det_all[lo:hi] - s
+    keep = min(max_dist, e - s) + largest_kernel
+    band = balanced_upper_band(cool, chrom_idx, keep)
+    mat = preproc.detrend(band, max_dist=keep, smooth=False, detectable_bins=det, max_val=10)
     mat.data[np.isnan(mat.data)] = 0
     mat.eliminate_zeros()
     return ContactBlock(name or f"chrom{chrom_idx}", mat, (det, det.copy()), max_dist)

@@ -1,0 +1,60 @@
+"""Synthetic decoded-.cool dictionaries for scale tests and the C4 bench workload (BASELINE.md:
+total bins split over 23 blocks sized like hg38 chr1-22,X; upper band of Poisson counts with a
+1/(d+1) distance law, ICE-like weights with 2 % unbalanced bins, planted loop templates)."""
+import numpy as np
+
+HG38_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50, 156]
+
+
+def make_cool(total_bins=200_000, max_dist_bins=1000, binsize=2000, seed=2, loops_per_10k=300, template=None,
+              chrom_sizes=None, largest_kernel=17):
+    rng = np.random.default_rng(seed)
+    if chrom_sizes is None:
+        frac = np.asarray(HG38_MB, dtype=np.float64) / sum(HG38_MB)
+        chrom_sizes = np.maximum((frac * total_bins).astype(np.int64), 64)
+    sizes = np.asarray(chrom_sizes, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    keep = max_dist_bins + largest_kernel
+    d = np.arange(keep + 1)
+    lam = 200.0 / (d + 1.0)
+    b1l, b2l, cl, planted = [], [], [], []
+    for c, m in enumerate(sizes):
+        m = int(m)
+        w = min(keep + 1, m)
+        boost = np.ones((m, w))
+        if template is not None and loops_per_10k and m > 4 * template.shape[0]:
+            k = template.shape[0]
+            kh = k // 2
+            n_loops = max(1, int(m * loops_per_10k / 10_000))
+            li = rng.integers(kh + 1, m - kh - 1, size=n_loops)
+            ld = rng.integers(min(k + 2, w - kh - 2), max(min(max_dist_bins, w - kh - 2), k + 3), size=n_loops)
+            t = template / template.max()
+            for i, dd in zip(li, ld):
+                j = i + dd
+                if j + kh >= m:
+                    continue
+                rr = np.arange(i - kh, i + kh + 1)[:, None]
+                cc = np.arange(j - kh, j + kh + 1)[None, :]
+                diag = cc - rr
+                ok = (diag >= 0) & (diag < w)
+                np.multiply.at(boost, (np.broadcast_to(rr, diag.shape)[ok], diag[ok]), 1.0 + 3.0 * (t ** 3)[ok])
+                planted.append((int(off[c] + i), int(off[c] + j)))
+        counts = rng.poisson(lam[None, :w] * boost)
+        rows = np.repeat(np.arange(m), w)
+        cols = rows + np.tile(np.arange(w), m)
+        flat = counts.ravel()
+        ok = (cols < m) & (flat > 0)
+        b1l.append(rows[ok] + off[c])
+        b2l.append(cols[ok] + off[c])
+        cl.append(flat[ok])
+    n = int(off[-1])
+    weight = rng.normal(1.0, 0.05, n) * 0.07
+    weight[rng.choice(n, n // 50, replace=False)] = np.nan
+    cool = {
+        "binsize": binsize, "chrom_offset": off, "chrom_names": np.array([f"chr{c + 1}" for c in range(len(sizes))]),
+        "bin1_id": np.concatenate(b1l), "bin2_id": np.concatenate(b2l), "count": np.concatenate(cl).astype(np.float64),
+        "weight": weight,
+        "bin_start": np.concatenate([np.arange(s) * binsize for s in sizes]),
+        "bin_end": np.concatenate([(np.arange(s) + 1) * binsize for s in sizes]),
+    }
+    return cool, planted

@@ -54,3 +54,17 @@ def test_auto_split_ragged_rows():
     rows = slice(3300, 3500)
     want, _ = c_oracle.normxcorr2(sig[3200:].astype(np.float64), kern, full=False)
     assert np.abs(got[rows] - want[100:300]).max() < 2e-5
+
+
+@pytest.mark.parametrize("env", [{"CHROMOSIGHT_HIP_SPLIT": "20,12"}, {"CHROMOSIGHT_HIP_STRIP_H": "10"}], ids=["split", "h10"])
+def test_factorised_mask_path_under_forced_shapes(env):
+    """The per-bin mask path (row / column tables, frame corrections) with a two-height tiling and
+    with short strips: same answers as with the default launch shape."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("regular_mask_cases",
+                                                  pathlib.Path(__file__).with_name("test_gpu_regular_mask.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    run_env(env, lambda: mod.test_inter_dense_regular_vs_oracle("f32"))
+    run_env(env, lambda: mod.test_band_regular_vs_general_and_oracle(mod.CASES[1]))

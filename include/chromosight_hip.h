@@ -125,7 +125,10 @@ typedef struct {
 /* Coefficient map.  `signal`, `out_corr` (and `out_nobs` when d_ptr != NULL) share the
  * logical shape ms x ns; layouts may differ (e.g. band in, band out with another range).
  * out_nobs (CS_F32 only) receives the number of present pixels of each window.
- * Pixels outside the stored band of `out_corr` are not written. */
+ * Pixels outside the stored band of `out_corr` are not written.
+ * The call is asynchronous on `stream`.  The template weights and, for CS_MASK_BINS, the per-bin
+ * mask tables live in buffers owned by `ctx`, so one context serves one call in flight: use one
+ * context per stream / host thread (contexts are independent and cheap). */
 int cs_normxcorr2(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
                   const cs_normxcorr2_params* params, const cs_matrix* out_corr,
                   const cs_matrix* out_nobs);

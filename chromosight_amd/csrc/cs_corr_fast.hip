@@ -114,8 +114,14 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     if constexpr (sizeof(TC) == 4) {
         if (A.w_sym) {
             // (the general masked kernel has no registers left for the shared row products)
-            if (A.mask_mode != 0 && A.reg_mode) return launch(corr_stream_kernel<TC, CS_K, 2, true>, smem2);
-            if (A.mask_mode == 0) return launch(corr_stream_kernel<TC, CS_K, 0, true>, smem0);
+            // short strips: the variant that skips the row products of the halo rows (steps2_rec)
+            const bool skip = S.strip_h <= 96;
+            if (A.mask_mode != 0 && A.reg_mode)
+                return skip ? launch(corr_stream_kernel<TC, CS_K, 2, true, true>, smem2)
+                            : launch(corr_stream_kernel<TC, CS_K, 2, true, false>, smem2);
+            if (A.mask_mode == 0)
+                return skip ? launch(corr_stream_kernel<TC, CS_K, 0, true, true>, smem0)
+                            : launch(corr_stream_kernel<TC, CS_K, 0, true, false>, smem0);
         }
     }
     // per-bin mask: factorised mask sums (tables built by cs_api.cpp prepare_regular_mask)

@@ -455,23 +455,41 @@ __device__ __forceinline__ void one_chain(const RowRegs<TC, K>& R, const WRow<TC
 // s, Q_s = row (*) W[s], then serves the two slots s and K-1-s: it is computed once for
 // s <= (K-1)/2 (K packed ops) and added to both accumulators (one packed add each), so a staged
 // row costs (K+1)/2 * K + K-1 packed ops instead of K * K, and only (K+1)/2 weight rows are loaded.
-template <int S, typename TC, int K, int W_OFF, bool SYM>
+// SKIP / q_need (wave-uniform): only Q_0 .. Q_(q_need-1) feed output rows of the strip in this
+// iteration -- fewer than (K+1)/2 while the strip warms up (staged rows t, t+1 < K-1 reach slots
+// <= t+1 only) and in its last iterations (slots below t - rows_out + 1 belong to rows under the
+// strip).  The SKIP instance of the chain tests every product against q_need and leaves stale Q
+// values behind, which only reach accumulators of rows outside the strip; the row loop uses it in
+// exactly those iterations and the branch-free instance otherwise.  (The same skip on the unfolded
+// chain does not pay: there every slot renames an accumulator, and the register moves at the merge
+// points cost more than the skipped FMAs.)
+template <int S, typename TC, int K, int W_OFF, bool SYM, bool SKIP>
 __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
                                            acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB,
                                            acc_t<TC> yprev, acc_t<TC> zprev, WRow<TC, K>& cur, WRow<TC, K>& nxt,
-                                           acc_t<TC> (&QA)[(K + 1) / 2], acc_t<TC> (&QB)[(K + 1) / 2])
+                                           acc_t<TC> (&QA)[(K + 1) / 2], acc_t<TC> (&QB)[(K + 1) / 2], const int q_need)
 {
     constexpr bool FOLD = SYM && sizeof(TC) == 4;
     constexpr int KM = (K - 1) / 2;                 // middle template row
-    constexpr int LAST_W = FOLD ? KM : K - 1;       // last template row whose weights are loaded
-    if constexpr (S <= LAST_W) {
-        cur.wait();
-        if constexpr (S < LAST_W) nxt.template issue<W_OFF + (S + 1) * K * (int)sizeof(TC)>(w_base);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     acc_t<TC> y, z;
     if constexpr (FOLD) {
-        if constexpr (S <= KM) pk_row<K, true>(A, B, cur, QA[S], QB[S]);
+        if constexpr (S <= KM) {
+            if (!SKIP || S < q_need) {
+                cur.wait();
+                if constexpr (S < KM) {
+                    if (!SKIP || S + 1 < q_need) nxt.template issue<W_OFF + (S + 1) * K * (int)sizeof(TC)>(w_base);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                pk_row<K, true>(A, B, cur, QA[S], QB[S]);
+                if constexpr (SKIP) {
+                    pin_acc(QA[S]);
+                    pin_acc(QB[S]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+        }
         constexpr int F = S <= KM ? S : K - 1 - S;
         if constexpr (S == 0) {
             y = QA[0];
@@ -481,6 +499,9 @@ __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowReg
             z = yprev + QB[F];
         }
     } else {
+        cur.wait();
+        if constexpr (S < K - 1) nxt.template issue<W_OFF + (S + 1) * K * (int)sizeof(TC)>(w_base);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (S > 0) {
             y = X[S - 1];
             z = yprev;
@@ -498,7 +519,7 @@ __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowReg
     pin_acc(z);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S < K - 1) {
-        steps2_rec<S + 1, TC, K, W_OFF, SYM>(A, B, w_base, X, outA, outB, y, z, nxt, cur, QA, QB);
+        steps2_rec<S + 1, TC, K, W_OFF, SYM, SKIP>(A, B, w_base, X, outA, outB, y, z, nxt, cur, QA, QB, q_need);
     } else {
         outA = y;
         outB = z;
@@ -506,14 +527,15 @@ __device__ __forceinline__ void steps2_rec(const RowRegs<TC, K>& A, const RowReg
 }
 
 // W_OFF: byte offset of the weight set inside the weight buffer (0 = signal weights)
-template <typename TC, int K, int W_OFF, bool SYM>
+template <typename TC, int K, int W_OFF, bool SYM, bool SKIP>
 __device__ __forceinline__ void steps2(const RowRegs<TC, K>& A, const RowRegs<TC, K>& B, unsigned long long w_base,
-                                       acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB)
+                                       acc_t<TC> (&X)[K - 1], acc_t<TC>& outA, acc_t<TC>& outB,
+                                       acc_t<TC> (&QA)[(K + 1) / 2], acc_t<TC> (&QB)[(K + 1) / 2], const int q_need)
 {
     WRow<TC, K> wa, wb;
-    acc_t<TC> QA[(K + 1) / 2], QB[(K + 1) / 2];
     wa.template issue<W_OFF>(w_base);
-    steps2_rec<0, TC, K, W_OFF, SYM>(A, B, w_base, X, outA, outB, acc_zero<TC>(), acc_zero<TC>(), wa, wb, QA, QB);
+    steps2_rec<0, TC, K, W_OFF, SYM, SKIP && SYM && sizeof(TC) == 4>(A, B, w_base, X, outA, outB, acc_zero<TC>(),
+                                                                      acc_zero<TC>(), wa, wb, QA, QB, q_need);
 }
 
 // Lean view of the launch arguments (only what the row loop needs stays in registers).
@@ -595,7 +617,7 @@ __device__ __forceinline__ bool stream_missing(const StreamArgs<TC>& A, int p, i
 // into per-row / per-column tables (cs_mask_prep.hip) plus a K-term cross product that is only
 // needed on output rows with a flagged row in reach; pixels whose window leaves the matrix or the
 // diagonal range 0..max_dist get a precomputed correction.  The data path is that of MODE 0.
-template <typename TC, int K, int MODE, bool SYM>
+template <typename TC, int K, int MODE, bool SYM, bool SKIP = false>
 __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_kernel(const StreamArgs<TC> A)
 {
     using G = StreamGeom<K>;
@@ -738,6 +760,11 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     acc_t<TC> X[K - 1];
 #pragma unroll
     for (int s = 0; s < K - 1; ++s) X[s] = acc_zero<TC>();
+    // shared row products of the folded (SYM) chain; they persist across iterations so that a
+    // skipped product leaves a defined (stale) value behind
+    acc_t<TC> QA[(K + 1) / 2], QB[(K + 1) / 2];
+#pragma unroll
+    for (int s = 0; s < (K + 1) / 2; ++s) QA[s] = QB[s] = acc_zero<TC>();
     // running box sums (sum S, sum S^2 over the K staged rows of the window), updated by
     // (row entering) - (row leaving).  The difference of the two float32 horizontal partials is
     // accumulated in float64, so the rounding does not grow with the strip height.
@@ -910,7 +937,9 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         fetch(t + 3, nx1);
 
         acc_t<TC> outA, outB;
-        steps2<TC, K, 0, SYM>(ra, rb, A.w, X, outA, outB);
+        // template rows that reach output rows of the strip (see steps2_rec)
+        const int q_need = __builtin_amdgcn_readfirstlane(min(min((K + 1) / 2, t + 2), K - max(0, t - rows_out + 1)));
+        steps2<TC, K, 0, SYM, SKIP>(ra, rb, A.w, X, outA, outB, QA, QB, q_need);
 
         acc_t<TC> kaA = acc_zero<TC>(), kaB = acc_zero<TC>(), kbA = acc_zero<TC>(), kbB = acc_zero<TC>();
         if constexpr (MASKED) {
@@ -918,8 +947,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
             // same scheme with the two mask weight sets
             ra.to_missing_flags();
             rb.to_missing_flags();
-            steps2<TC, K, K * K * (int)sizeof(TC), SYM>(ra, rb, A.w, XA, kaA, kaB);
-            steps2<TC, K, 2 * K * K * (int)sizeof(TC), SYM>(ra, rb, A.w, XB, kbA, kbB);
+            steps2<TC, K, K * K * (int)sizeof(TC), SYM, false>(ra, rb, A.w, XA, kaA, kaB, QA, QB, q_need);
+            steps2<TC, K, 2 * K * K * (int)sizeof(TC), SYM, false>(ra, rb, A.w, XB, kbA, kbB, QA, QB, q_need);
         }
 
         auto advance = [&]() {

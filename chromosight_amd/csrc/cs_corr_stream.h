@@ -863,11 +863,19 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                         kb += f[2];
                     }
                 }
-                TC nobs;
-                r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nmv, ka, kb, A.ks, true, &nobs);
+                if constexpr (sizeof(TC) == 4) {
+                    r = pearson_masked_f32(csv[c], s1[c], s2[c], nmv, ka, kb, A.ks);
+                } else {
+                    TC nobs;
+                    r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nmv, ka, kb, A.ks, true, &nobs);
+                }
             } else if constexpr (MASKED) {
-                TC nobs;
-                r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nm[c], kav[c], kbv[c], A.ks, true, &nobs);
+                if constexpr (sizeof(TC) == 4) {
+                    r = pearson_masked_f32(csv[c], s1[c], s2[c], nm[c], kav[c], kbv[c], A.ks);
+                } else {
+                    TC nobs;
+                    r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nm[c], kav[c], kbv[c], A.ks, true, &nobs);
+                }
             } else if constexpr (sizeof(TC) == 4) {
                 r = pearson_nomask_f32(csv[c], s1[c], s2[c], A.ks);
             } else {

@@ -262,6 +262,52 @@ __device__ __forceinline__ float pearson_nomask_f32(float cs, float s1, float s2
     return fminf(fmaxf(r, -1.0f), 1.0f);
 }
 
+// Masked branch for the float32 streaming kernels: the arithmetic of pearson_from_sums<float>
+// (same thresholds, same centred mask sums, same snap of a degenerate template variance) with
+// selects instead of branches for windows without missing pixels, hardware 1-ulp reciprocal /
+// square root instead of the IEEE division and sqrt sequences (three of them per pixel made the
+// epilogue as expensive as the FMAs on banded maps), and the generic function only for the rare
+// windows whose mask-weighted template sums fall under the 1e-4 threshold.
+__device__ __forceinline__ float pearson_masked_f32(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                    const KernelStats<float>& K)
+{
+    const float m1 = s1 * K.inv_n;
+    const float m2 = s2 * K.inv_n;
+    const float c = fmaf(K.kmean, s1, cs) * K.inv_n;
+    const bool z1 = fabsf(m1) < K.thr;
+    const bool z2 = fabsf(m2) < K.thr;
+    const bool zc = fabsf(c) < K.thr;
+    const float m1z = z1 ? 0.0f : m1;
+    const float m2z = z2 ? 0.0f : m2;
+    const float cz = zc ? 0.0f : c;
+    const bool clean = nm < 0.5f;                      // window without missing pixels
+    const float np = K.n - nm;
+    const float inv_np = clean ? K.inv_n : __builtin_amdgcn_rcpf(np);
+    const float km_ = fmaf(K.kmean, nm, ka);
+    const float k2m = kb + 2.0f * K.kmean * ka + K.kmean * K.kmean * nm;
+    const bool rare = !clean && ((fabsf(km_) < K.thr) || (fabsf(k2m) < K.thr));
+    const float a = clean ? 0.0f : ka * inv_np;        // kmean - kmw
+    float kvw = fmaf(-a, a, (K.n * K.kvar - kb) * inv_np);
+    kvw = (kvw < 1e-5f * K.kvar) ? 0.0f : kvw;
+    kvw = clean ? K.kvar : kvw;
+    const float ratio = clean ? 1.0f : K.n * inv_np;
+    const float m1w = m1z * ratio;
+    const float m2w = m2z * ratio;
+    float den = __builtin_amdgcn_sqrtf(fmaf(-m1w, m1w, m2w) * kvw);   // NaN for a negative product
+    den = (np < K.cut) ? 0.0f : den;
+    const float kmw = K.kmean - a;
+    const float num = (z1 | zc) ? (cz - m1z * kmw) * ratio : fmaf(s1, a, cs) * inv_np;
+    float r = num * __builtin_amdgcn_rcpf(den);
+    r = (fabsf(den) < K.eps) ? 0.0f : r;
+    r = (fabsf(r) <= 3.0e38f) ? r : 0.0f;               // NaN / inf -> 0
+    r = fminf(fmaxf(r, -1.0f), 1.0f);
+    if (rare) {
+        float nobs;
+        r = pearson_from_sums<float>(cs, s1, s2, nm, ka, kb, K, true, &nobs);
+    }
+    return r;
+}
+
 // does output pixel (i, j) exist, and is its value forced to 0?
 //   valid-mode margins (detection.py:720-722, 797-801) and sym_upper triu (:1098-1099)
 template <typename TC>

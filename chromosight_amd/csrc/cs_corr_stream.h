@@ -987,21 +987,23 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 if ((nrA != TC(0)) | (nrB != TC(0))) {
                     RowRegs<TC, K> cf;
                     cf.load(cfl + lane * 2);
-                    WRow<TC, K> wu;
+                    // four K-term products against the row's U vectors; two scalar buffers so that
+                    // only two of the four scalar-load latencies are exposed
+                    WRow<TC, K> wu0, wu1;
                     const unsigned long long bA = (unsigned long long)(uintptr_t)(A.rowtab + (size_t)oi * kRowTabStride);
                     const unsigned long long bB = (unsigned long long)(uintptr_t)(A.rowtab + (size_t)oiB * kRowTabStride);
-                    wu.template issue<kRowTabUA * (int)sizeof(TC)>(bA);
-                    wu.wait();
-                    one_chain<0, TC, K>(cf, wu, xaA);
-                    wu.template issue<kRowTabUB * (int)sizeof(TC)>(bA);
-                    wu.wait();
-                    one_chain<0, TC, K>(cf, wu, xbA);
-                    wu.template issue<kRowTabUA * (int)sizeof(TC)>(bB);
-                    wu.wait();
-                    one_chain<0, TC, K>(cf, wu, xaB);
-                    wu.template issue<kRowTabUB * (int)sizeof(TC)>(bB);
-                    wu.wait();
-                    one_chain<0, TC, K>(cf, wu, xbB);
+                    wu0.template issue<kRowTabUA * (int)sizeof(TC)>(bA);
+                    wu1.template issue<kRowTabUB * (int)sizeof(TC)>(bA);
+                    wu0.wait();
+                    wu1.wait();
+                    one_chain<0, TC, K>(cf, wu0, xaA);
+                    wu0.template issue<kRowTabUA * (int)sizeof(TC)>(bB);
+                    one_chain<0, TC, K>(cf, wu1, xbA);
+                    wu1.template issue<kRowTabUB * (int)sizeof(TC)>(bB);
+                    wu0.wait();
+                    wu1.wait();
+                    one_chain<0, TC, K>(cf, wu0, xaB);
+                    one_chain<0, TC, K>(cf, wu1, xbB);
                 }
                 TC nA[2], nB[2];
 #pragma unroll

@@ -654,6 +654,15 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     if (i0 >= A.ms) return;
     const int rows_out = min(strip_h, A.ms - i0);
     const int n_staged = rows_out + K - 1;
+    // MODE 2: can any pixel of this strip need a correction table?  (wave-uniform; most strips of a
+    // wide band or of a large rectangular map cannot, and skip the per-pixel lookup logic)
+    bool strip_needs_fix = false;
+    if constexpr (REG) {
+        const int d_min = j0 - (i0 + rows_out - 1), d_max = j0 + G::TW - 1 - i0;
+        strip_needs_fix = (i0 < A.fix_top) | (i0 + rows_out > A.fix_bot0) |
+                          (A.fix_cols != nullptr && ((j0 < A.fix_side) | (j0 + G::TW > A.ns - A.fix_side))) |
+                          (A.fix_on && ((d_min < K - 1 && d_max >= 0) | (d_max >= A.fix_hi_d0 && d_min < A.fix_hi_d0 + A.fix_hi_w)));
+    }
 
     // zero the ring: rows "older" than the strip are read (and subtracted) as zeros, which
     // makes the row loop branch free
@@ -844,7 +853,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 // windows that leave the matrix (frame tables) or the diagonal range 0..max_dist
                 // (edge tables): precomputed correction of the factorised sums
                 TC nmv = nm[c], ka = kav[c], kb = kbv[c];
-                if (in_range) {
+                if (strip_needs_fix && in_range) {
                     const TC* f = nullptr;
                     const int j = oj0 + c;
                     const int x = A.fix_xband ? d - A.fix_xlo : j;

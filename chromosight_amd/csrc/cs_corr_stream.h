@@ -1,34 +1,34 @@
 // cs_corr_stream.h -- the hot kernel: streaming sliding-window Pearson correlation for a
-// K x K template (K odd, compile-time), no missing mask.
+// K x K template (K odd, compile-time), without mask (MODE 0), with any missing mask (MODE 1) or
+// with the factorised per-bin mask (MODE 2).
 //
-// Replaces the reference's three sparse/dense cross-correlations of the unmasked branch
-// (detection.py:1000-1018, 1213-1220: signal*1, signal^2*1, signal*K) by one pass.
+// Replaces the reference's sparse/dense cross-correlations of normxcorr2 (detection.py:1000-1085,
+// 1213-1220: signal*1, signal^2*1, signal*K and the three mask correlations) by one pass.
 //
-// Design (gfx950, wave64):
+// Design (gfx950, wave64; DESIGN.md section 4.1 has the measurements behind each choice):
 //   * One WAVE owns a strip of 128 output columns (2 adjacent columns per lane) and walks down
-//     STRIP_H output rows.  No block-level barrier: each wave has a private LDS ring of the last
-//     RING staged rows.  Lane l reads its K+1 consecutive values of a row with aligned
-//     ds_read_b64 (conflict free).
-//   * Rotating accumulators: X[s] is the partial sum of output row (t-1-s) over template rows
-//     0..s.  Each loop iteration consumes TWO staged rows (A = t, B = t+1) per template row s:
+//     strip_h output rows.  No block-level barrier: each wave has a private LDS ring of staged
+//     rows.  Lane l reads its K+1 consecutive values of a row with aligned ds_read_b64.
+//   * Rotating accumulators: X[s] is the partial sum of an output row over template rows 0..s.
+//     Each loop iteration consumes TWO staged rows (A = t, B = t+1) per template row s:
 //         y_s = X[s-1] + A * W[s]      z_s = y_(s-1) + B * W[s]      X'[s] = z_s
 //     so one scalar load of W[s] feeds 2*K packed FMAs in two independent dependency chains,
 //     y_(K-1) and z_(K-1) complete two output rows, and every staged value is loaded once and
 //     used K times per column from registers.
 //   * Template weights are wave-uniform: one s_load of a template row (K scalars) feeds K packed
-//     FMAs.  The float32 math is v_pk_fma_f32 on the lane's (column, column+1) accumulator pair
-//     with an SGPR weight: measured on MI355X (tools/ubench/fma_rate.hip) v_pk_fma_f32 with a
-//     scalar operand sustains 137 TFLOP/s, v_fma_f32 with a scalar operand only 73, v_fma_f32 on
-//     three VGPRs 117.  The row is therefore held twice in registers, as even-aligned pairs
-//     (v[2m], v[2m+1]) and odd-aligned pairs (v[2m+1], v[2m+2]), so that no operand needs a move.
-//     289 weights never fit the 102 SGPRs; they are re-streamed from the scalar cache once per
-//     staged row.
-//   * Box sums (sum S, sum S^2 over the window) are separable: horizontal K-sums of the new row
-//     are added to, and those of the row leaving the window subtracted from, float64 running
-//     sums (exact sliding; the float32 horizontal partials are recomputed bit-identically).
+//     FMAs (v_pk_fma_f32 on the lane's (column, column+1) accumulator pair with an SGPR weight,
+//     the fastest FP32 FMA form on this chip, tools/ubench/fma_rate.hip).  The row is held twice
+//     in registers, as even-aligned pairs (v[2m], v[2m+1]) and odd-aligned pairs (v[2m+1], v[2m+2]),
+//     so that no operand needs a move.  289 weights never fit the 102 SGPRs; they are re-streamed
+//     from the scalar cache once per pair of staged rows.
+//   * SYM: vertically symmetric templates share each horizontal row product between two template
+//     rows (steps2_rec).
+//   * Box sums (sum S, sum S^2 over the window) are separable: horizontal K-sums of the entering
+//     row minus those of the leaving row (kept in an LDS cache) go into float64 running sums.
 //
-// Work per output pixel at K = 17: 289 FMA + ~40 VALU (box sums, epilogue) => FP32-FMA bound
-// (SURVEY.md 8(d)); HBM traffic ~ (1 + 16/128)(1 + 16/STRIP_H) * 4 B in + 4 B out per pixel.
+// Work per output pixel at K = 17: 289 FMA (169 packed ops per column pair when SYM) + box sums and
+// epilogue => FP32-FMA bound; HBM traffic ~ (1 + 16/128)(1 + 16/strip_h) * 4 B
+// in + 4 B out per pixel.
 #pragma once
 #include "cs_device.h"
 
@@ -282,19 +282,6 @@ struct RowRegs {
 #pragma unroll
         for (int t = 0; t < K + 1; ++t) v[t] = p[t];
     }
-    // acc_out[c] = acc_in[c] + sum_kj v[kj + c] * wk[kj]
-    __device__ __forceinline__ void slot(const WRow<TC, K>& wk, const TC (&in)[2], TC (&out)[2]) const
-    {
-        TC a0 = cs_fma(v[0], wk.get(0), in[0]);
-        TC a1 = cs_fma(v[1], wk.get(0), in[1]);
-#pragma unroll
-        for (int kj = 1; kj < K; ++kj) {
-            a0 = cs_fma(v[kj], wk.get(kj), a0);
-            a1 = cs_fma(v[kj + 1], wk.get(kj), a1);
-        }
-        out[0] = a0;
-        out[1] = a1;
-    }
     // a += (v[KJ], v[KJ+1]) * w[KJ]
     template <int KJ>
     __device__ __forceinline__ void fma(const WRow<TC, K>& wk, acc_t<TC>& a) const
@@ -327,26 +314,6 @@ struct RowRegs<float, K> {
             o[m].x = p[2 * m + 1];
             o[m].y = p[2 * m + 2];
         }
-    }
-    // two independent dependency chains (even / odd template columns), summed at the end
-    template <int KJ>
-    __device__ __forceinline__ void chain(const WRow<float, K>& wk, f32x2& a, f32x2& b) const
-    {
-        if constexpr (KJ < K) {
-            if constexpr (KJ == 1) b = pk_mul_w<KJ>(o[0], wk.template pair<KJ>());
-            else if constexpr (KJ & 1) b = pk_fma_w<KJ>(o[KJ >> 1], wk.template pair<KJ>(), b);
-            else a = pk_fma_w<KJ>(e[KJ >> 1], wk.template pair<KJ>(), a);
-            chain<KJ + 1>(wk, a, b);
-        }
-    }
-    __device__ __forceinline__ void slot(const WRow<float, K>& wk, const float (&in)[2], float (&out)[2]) const
-    {
-        f32x2 a = {in[0], in[1]};
-        f32x2 b;
-        chain<0>(wk, a, b);
-        a += b;
-        out[0] = a.x;
-        out[1] = a.y;
     }
     // a += (v[KJ], v[KJ+1]) * w[KJ]: one v_pk_fma_f32 on an aligned pair
     template <int KJ>

@@ -344,7 +344,7 @@ def main():
             },
             "kernel_ms": round(kernel_ms, 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported extras: rank 0 at N = 1 only
             try:
                 out["detect_wallclock"] = detect_wallclock()
             except Exception as exc:

@@ -200,11 +200,20 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
     st = _Staged(dev, signal, (km, kn), sym_upper, full, extra_range=mask_range)
     mask_buf = None
     mask_mode = MASK_NONE
+    mask_kw = {}
     if missing_mask is not None:
         if full:
             _check_framed_signal(signal, missing_mask, (km, kn), sym_upper, max_dist)
-        mask_buf = st.stage_mask(missing_mask)
-        mask_mode = MASK_EXPLICIT
+        bins = _mask_as_bins(missing_mask, sym_upper, max_dist)
+        if bins is not None:
+            # the mask is exactly make_missing_mask's: two flag vectors describe it, and the
+            # device evaluates it analytically (factorised mask sums) instead of reading a map
+            mask_mode = MASK_BINS
+            mask_kw = dict(miss_row=dev.to_device(bins[0].astype(np.uint8)),
+                           miss_col=dev.to_device(bins[1].astype(np.uint8)))
+        else:
+            mask_buf = st.stage_mask(missing_mask)
+            mask_mode = MASK_EXPLICIT
     out_dtype = _out_dtype()
     out_buf, out_mat = st.alloc_out(out_dtype)
     want_nobs = pval and full and missing_mask is not None
@@ -213,7 +222,7 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         nobs_buf, nobs_mat = st.alloc_out(np.float32)
     engine.run_normxcorr2(dev, st.sig, (ms, ns), kspec, out_mat, full=full, sym_upper=sym_upper,
                           max_dist=max_dist, mask_mode=mask_mode, mask=mask_buf,
-                          missing_tol=missing_tol, nobs=nobs_mat)
+                          missing_tol=missing_tol, nobs=nobs_mat, **mask_kw)
     n = km * kn
     if st.sparse:
         rows, cols, vals = st.to_host_coo(out_buf)
@@ -242,6 +251,33 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         else:
             pvals = cus.corr_to_pval(corr.ravel(), n).reshape(corr.shape)
     return corr, pvals
+
+
+def _mask_as_bins(mask, sym_upper, max_dist):
+    """(missing_rows, missing_cols) boolean vectors if `mask` is exactly the mask make_missing_mask
+    builds from them (reference preprocessing.py:535-633), else None.  Candidate flags: the main
+    diagonal of an upper-symmetric mask, the completely flagged rows / columns of a rectangular one."""
+    ms, ns = mask.shape
+    m = sp.csr_matrix(mask)
+    if m.nnz == 0:
+        return np.zeros(ms, dtype=bool), np.zeros(ns, dtype=bool)
+    if sym_upper:
+        if ms != ns:
+            return None
+        miss_r = np.asarray(m.diagonal()).astype(bool)
+        miss_c = miss_r
+    else:
+        miss_r = np.diff(m.indptr) == ns
+        miss_c = np.asarray(m.sum(axis=0)).ravel() == ms
+    try:
+        want = preproc.make_missing_mask((ms, ns), np.flatnonzero(~miss_r), np.flatnonzero(~miss_c),
+                                         max_dist=max_dist, sym_upper=sym_upper)
+    except ValueError:
+        return None
+    want = sp.csr_matrix(want)
+    if want.nnz != m.nnz or (want != m).nnz != 0:
+        return None
+    return miss_r, miss_c
 
 
 def _check_framed_signal(signal, mask, kernel_shape, sym_upper, max_dist):

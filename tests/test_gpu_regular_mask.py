@@ -188,3 +188,33 @@ def test_small_dense_sym_upper_regular_vs_oracle():
         want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True, miss_row=miss, miss_col=miss,
                                       missing_tol=0.75)
         assert np.abs(got - want).max() < 1e-9
+
+
+def test_api_mask_routing():
+    """normxcorr2 with make_missing_mask's own output is routed to the per-bin path; a mask with one
+    more flagged (empty) pixel is not, goes through the explicit-mask kernel, and both agree with the
+    numpy oracle evaluated on the framed mask (preprocessing.py:404 frame_missing_mask)."""
+    import scipy.sparse as sp
+    from chromosight_amd.utils import detection as cud
+    from chromosight_amd.utils import preprocessing as cup
+    from oracle import pearson_oracle as orc
+    rng = np.random.default_rng(21)
+    n, k, max_dist = 160, 9, 30
+    kern = make_kernel(rng, k)
+    a, miss = intra_map(rng, n, max_dist + k, 0.05, clusters=False)
+    a[40, 45] = 0.0
+    valid = np.flatnonzero(~miss)
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=max_dist, sym_upper=True)
+    assert cud._mask_as_bins(mask, True, max_dist) is not None
+    odd = mask.tolil()
+    odd[40, 45] = True
+    odd = odd.tocsr()
+    assert cud._mask_as_bins(odd, True, max_dist) is None
+    for m in (mask, odd):
+        got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, max_dist=max_dist, sym_upper=True, full=True, missing_mask=m,
+                                missing_tol=0.5)
+        framed = cup.frame_missing_mask(m, kern.shape, sym_upper=True, max_dist=max_dist).toarray()
+        want, _ = orc.normxcorr2_oracle(a, kern, max_dist=max_dist, sym_upper=True, full=True, missing=framed,
+                                        missing_tol=0.5)
+        err = np.abs(got.toarray() - want)
+        assert (err > 2e-5).mean() <= 1e-3 and err.max() < 5e-3, err.max()

@@ -228,3 +228,68 @@ def test_kernels_module():
     assert ck.loops["kernels"][0].shape == (17, 17) and len(ck.borders["kernels"]) == 3
     assert ck.hairpins["kernels"][0].shape == (15, 15) and ck.loops["pearson"] == 0.3
     assert ck.borders["max_dist"] == 0 and ck.loops["max_perc_undetected"] == 50.0
+
+
+def test_mask_as_bins_recognises_only_structured_masks():
+    n = 300
+    miss = np.zeros(n, bool)
+    miss[[3, 50, 51, 299]] = True
+    valid = np.flatnonzero(~miss)
+    m = cup.make_missing_mask((n, n), valid, valid, max_dist=40, sym_upper=True)
+    got = cud._mask_as_bins(m, True, 40)
+    assert got is not None and np.array_equal(got[0], miss) and np.array_equal(got[1], miss)
+    assert cud._mask_as_bins(m, True, 39) is None                 # another max_dist: another mask
+    odd = m.tolil()
+    odd[10, 12] = True
+    assert cud._mask_as_bins(odd.tocsr(), True, 40) is None
+    mr = np.zeros(200, bool)
+    mc = np.zeros(310, bool)
+    mr[[1, 7]] = True
+    mc[[0, 100, 309]] = True
+    mi = cup.make_missing_mask((200, 310), np.flatnonzero(~mr), np.flatnonzero(~mc), sym_upper=False)
+    got = cud._mask_as_bins(mi, False, None)
+    assert got is not None and np.array_equal(got[0], mr) and np.array_equal(got[1], mc)
+    empty = sp.csr_matrix((50, 50), dtype=bool)
+    got = cud._mask_as_bins(empty, True, 10)
+    assert got is not None and not got[0].any()
+
+
+def test_validate_on_virtual_padded_map_equals_materialised():
+    """_validate(pad=, stripe_k=) must see exactly the map the reference builds with
+    zero_pad_sparse + NaN sub-diagonals (detection.py:287-310)."""
+    rng = np.random.default_rng(4)
+    n, k = 120, 9
+    kh = (k - 1) // 2
+    a = np.triu(rng.random((n, n)) * (rng.random((n, n)) > 0.5))
+    csr = sp.csr_matrix(a)
+    coords = np.column_stack([rng.integers(0, n, 60), rng.integers(0, n, 60)])
+    coords[:5] = [[0, 0], [n - 1, n - 1], [2, n - 1], [kh, kh], [50, 50]]
+    scores = rng.random(60)
+    miss = np.array([7, 8, 60])
+    padded = cup.zero_pad_sparse(csr, kh, kh, fmt="csr").astype(np.float64)
+    stripes = sp.diags([np.full(padded.shape[0], np.nan)] * k, -np.arange(1, k + 1), shape=padded.shape, format="csr")
+    ref_tab, ref_win = cud._validate(coords + kh, padded + stripes, scores, miss + kh, miss + kh, (k, k), drop=False,
+                                     zero_tol=0.6, missing_tol=0.5)
+    tab, win = cud._validate(coords + kh, csr, scores, miss + kh, miss + kh, (k, k), drop=False, zero_tol=0.6,
+                             missing_tol=0.5, pad=(kh, kh), stripe_k=k)
+    np.testing.assert_array_equal(np.isnan(tab.score), np.isnan(ref_tab.score))
+    np.testing.assert_allclose(tab.score.dropna(), ref_tab.score.dropna())
+    np.testing.assert_array_equal(np.isnan(win), np.isnan(ref_win))
+    np.testing.assert_allclose(np.nan_to_num(win), np.nan_to_num(ref_win))
+    assert np.isfinite(tab.score).any() and np.isnan(tab.score).any()
+
+
+def test_upper_band_block_equals_symmetric_block(golden):
+    """pipeline.balanced_upper_band (built straight from the pixel table) = upper band of the
+    symmetric balanced block cooler would return."""
+    from chromosight_amd import pipeline
+    cool = dict(golden("example_cool"))
+    for ci in range(len(cool["chrom_offset"]) - 1):
+        full = pipeline.balanced_intra_block(cool, ci).tocsr()
+        for keep in (5, 40, 10_000):
+            band = pipeline.balanced_upper_band(cool, ci, keep).toarray()
+            want = full.toarray()
+            ii, jj = np.indices(want.shape)
+            want[(jj - ii < 0) | (jj - ii > keep)] = 0
+            np.testing.assert_array_equal(np.isnan(band), np.isnan(want))
+            np.testing.assert_allclose(np.nan_to_num(band), np.nan_to_num(want), rtol=0, atol=0)

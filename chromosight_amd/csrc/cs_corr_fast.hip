@@ -13,6 +13,20 @@
 
 namespace cs {
 
+// Two-height tiling of a dense launch that is a single generation of two waves per SIMD (see
+// launch_fast): heights 5/4 h and 3/4 h for the first / second half of the row blocks.  Applies only
+// if the re-tiled launch still fits that single generation.
+static bool split_heights(int ms, long long strips_x, int h, long long n_simd, int* h1, int* h2, int* pairs)
+{
+    if (n_simd <= 0 || h < 32) return false;
+    const long long waves = strips_x * ((ms + h - 1) / h);
+    if (waves <= n_simd || waves > 2 * n_simd) return false;
+    *h1 = (h * 5 / 4 + 1) & ~1;
+    *h2 = 2 * h - *h1;
+    *pairs = (ms + *h1 + *h2 - 1) / (*h1 + *h2);
+    return 2LL * *pairs * strips_x <= 2 * n_simd;
+}
+
 template <typename TC>
 static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
 {
@@ -49,13 +63,11 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     // pair finish together: C2 110 -> 116 Gpixel/s (the reverse split loses 6 %, as it must).
     {
         const long long n_simd = (long long)(A.n_cu > 0 ? A.n_cu : 0) * 4;
-        const long long waves = (long long)A.tiles_x * A.tiles_y;
         const char* e = getenv("CHROMOSIGHT_HIP_SPLIT");   // "h1,h2" forces a split, "0" disables it
-        int h1 = 0, h2 = 0;
+        int h1 = 0, h2 = 0, auto_pairs = 0;
         if (e && sscanf(e, "%d,%d", &h1, &h2) == 2) {
-        } else if (!e && !S.band_out && n_simd > 0 && waves > n_simd && waves <= 2 * n_simd && A.tile_h >= 32) {
-            h1 = (A.tile_h * 5 / 4 + 1) & ~1;
-            h2 = 2 * A.tile_h - h1;
+        } else if (!e && !S.band_out && !split_heights(A.ms, A.tiles_x, A.tile_h, n_simd, &h1, &h2, &auto_pairs)) {
+            h1 = h2 = 0;
         }
         if (h1 > 0 && h2 > 0 && !S.band_out) {
             const int pairs = (A.ms + h1 + h2 - 1) / (h1 + h2);
@@ -137,11 +149,14 @@ int CS_CAT(launch_corr_fast_f32_k, CS_K)(const CorrArgs<float>& A, hipStream_t s
 int CS_CAT(launch_corr_fast_f64_k, CS_K)(const CorrArgs<double>& A, hipStream_t s) { return launch_fast<double>(A, s); }
 
 // strip geometry: 128 columns per wave, strip height chosen by a small cost model fitted to
-// measurements on MI355X (C2 / C3 / C4' height sweeps, profiles/r01_strip_height_sweep.txt):
-//   time ~ (h + 0.7 (K-1)) * w / eff(w),   w = waves per SIMD = ceil(strips / (4 n_cu))
-// h + K-1 staged rows per strip (the K-1 warm-up rows emit nothing and cost ~0.7 of a row); one
-// wave alone on a SIMD reaches ~55 % of the VALU rate of two or more.  For band outputs the
-// number of 128-column strips per row block jumps whenever band_w + h crosses a multiple of 128,
+// measurements on MI355X (height sweeps in profiles/r01_strip_height_sweep.txt):
+//   time per SIMD ~ c * (2 * floor(w / 2) / e2 + (w odd ? 1 / 0.55 : 0))  for w <= 3,  c * w beyond;  c = h + 0.7 (K-1)
+// w = strips per SIMD = ceil(strips / (4 n_cu)).  A strip stages h + K-1 rows (the K-1 warm-up rows
+// emit nothing and cost ~0.7 of a row).  Two waves are resident per SIMD (registers, LDS) and share
+// its VALU; a wave that is alone reaches ~55 % of the rate of a pair, so an odd w pays for one lone
+// round (6144^2: 150-row strips, w = 2, beat 96-row strips, w = 3, by 8 %).  e2 = 1 when the
+// two-height tiling of launch_fast applies (dense, single generation), else 0.95.  For band outputs
+// the number of 128-column strips per row block jumps whenever band_w + h crosses a multiple of 128,
 // which is what makes e.g. h = 20 better than h = 32 for a 234-diagonal band.
 // band_w = number of output diagonals (0 for dense outputs).
 void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int band_w, int n_cu, int* tw, int* th)
@@ -160,8 +175,12 @@ void CS_CAT(corr_fast_tile_k, CS_K)(int ms, int ns, int band_w, int n_cu, int* t
         }
         const long long waves = sx * ((ms + hh - 1) / hh);
         const long long w = (waves + n_simd - 1) / n_simd;
-        const double eff = w <= 1 ? 0.55 : (w == 2 ? 0.95 : 1.0);
-        const double t = (hh + 0.7 * (CS_K - 1)) * (double)w / eff;
+        int h1, h2, pairs;
+        const double e2 = (band_w == 0 && split_heights(ms, sx, hh, n_simd, &h1, &h2, &pairs)) ? 1.0 : 0.95;
+        // from four strips per SIMD on, finished waves are replaced continuously and the parity of w
+        // stops mattering
+        const double rounds = w >= 4 ? (double)w : 2.0 * (double)(w / 2) / e2 + ((w & 1) ? 1.0 / 0.55 : 0.0);
+        const double t = (hh + 0.7 * (CS_K - 1)) * rounds;
         if (t <= best) {   // ties: the taller strip (fewer halo rows)
             best = t;
             h = hh;

@@ -14,6 +14,8 @@
 // sub-diagonals -K..-1 (preprocessing.py:404 frame_missing_mask; cs_device.h missing_pred).
 // `mask_edge_fix_kernel` evaluates, for the output diagonals whose windows leave 0..max_dist,
 // the exact difference  sum_window (missing_true - (r|c)) * {1, Wa, Wb}  once per pixel.
+#include <algorithm>
+
 #include "cs_device.h"
 #include "cs_launch_aux.h"
 
@@ -141,11 +143,12 @@ __global__ __launch_bounds__(256) void mask_edge_fix_kernel(const unsigned* __re
     __syncthreads();
 
     const int per_row = (K - 1) + hi_w;
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (long long)ms * per_row) return;
+    const int KH = (K - 1) / 2;
+    // grid-stride: the prefix tables above are built once per block, so a block handles many pixels
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < (long long)ms * per_row;
+         id += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(id / per_row);
     const int e = (int)(id - (long long)i * per_row);
-    const int KH = (K - 1) / 2;
     int D;
     TC* dst;
     if (e < K - 1) {
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256) void mask_edge_fix_kernel(const unsigned* __re
     dst[1] = fa;
     dst[2] = fb;
     dst[3] = TC(0);
+    }
 }
 
 // The framed per-bin predicate of cs_device.h missing_pred (mask_mode 1, full, square template)
@@ -328,7 +332,8 @@ int launch_mask_edge_fix(const unsigned* rbits, const unsigned* cbits, int ms, i
                          const TC* w, TC* fix_lo, TC* fix_hi, hipStream_t stream)
 {
     const long long n = (long long)ms * ((K - 1) + hi_w);
-    hipLaunchKernelGGL(mask_edge_fix_kernel<TC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rbits, cbits, ms, ns, K,
+    const long long blocks = std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(mask_edge_fix_kernel<TC>, dim3((unsigned)blocks), dim3(256), 0, stream, rbits, cbits, ms, ns, K,
                        md, hi_d0, hi_w, w, fix_lo, fix_hi);
     return (int)hipGetLastError();
 }

@@ -76,8 +76,11 @@ class _Staged:
                 arr = arr.astype(np.float64, copy=False)
             self.layout = LAYOUT_DENSE
             ld = (ns + 15) // 16 * 16
-            padded = np.zeros((ms, ld), dtype=arr.dtype)
-            padded[:, :ns] = arr
+            if ld == ns:
+                padded = np.ascontiguousarray(arr)      # already a legal leading dimension: no copy
+            else:
+                padded = np.zeros((ms, ld), dtype=arr.dtype)
+                padded[:, :ns] = arr
             buf = dev.to_device(padded)
             self.sig_buf = buf
             self.keep.append(buf)
@@ -214,7 +217,9 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         else:
             mask_buf = st.stage_mask(missing_mask)
             mask_mode = MASK_EXPLICIT
-    out_dtype = _out_dtype()
+    # dense inputs come back as float64 arrays (as the reference returns them): the kernel stores
+    # float64 directly, which is cheaper than converting 8 bytes per pixel on the host
+    out_dtype = _out_dtype() if st.sparse else np.float64
     out_buf, out_mat = st.alloc_out(out_dtype)
     want_nobs = pval and full and missing_mask is not None
     nobs_buf = nobs_mat = None
@@ -242,7 +247,7 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
                 logp = cus.corr_to_pval(vals, n)
             pvals = sp.csr_matrix((logp, (rows, cols)), shape=(ms, ns))
         return corr, pvals
-    corr = st.to_host_dense(out_buf).astype(np.float64)
+    corr = st.to_host_dense(out_buf).astype(np.float64, copy=False)
     pvals = None
     if pval:
         if want_nobs:

@@ -335,7 +335,9 @@ def main():
                 "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "note": f"714 flop/pixel (SURVEY 8d) x {wl.pixels} pixels per launch / {kernel_ms:.4f} ms "
                         "(HIP events); the FP32 FMA roof binds before HBM at 17x17; peak = dense FP32 "
-                        "matrix/vector peak",
+                        "matrix/vector peak.  Algorithmic flops: the loops template is vertically symmetric and "
+                        "its kernel shares each row product between two template rows (169 instead of 289 packed "
+                        "products per column pair; CHROMOSIGHT_HIP_NO_SYMMETRY=1 runs the unfolded kernel)",
             },
             "roofline_hbm": {
                 "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

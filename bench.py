@@ -86,26 +86,10 @@ class Workload:
             self.desc = (f"C2: dense {n}x{n} float32 gamma(4,0.25) seed 0, 17x17 loops template, "
                          "normxcorr2(full=False, no mask)")
         else:
-            n, max_dist = (50000, 233) if name == "c3" else (200000, 1000)
+            from tools.synthetic_genome import band_workload
+            band, band_w_in, miss, n, max_dist = band_workload(name, rank)
             keep = max_dist + 17
-            rng = np.random.default_rng((1 if name == "c3" else 2) + rank)
-            band_w_in = keep + 1
-            ld_in = (band_w_in + 63) // 64 * 64
-            band = np.zeros((n, ld_in), dtype=np.float32)
-            d = np.arange(band_w_in)
-            # detrended-like contacts: poisson(200/(d+1)) / expectation, ~1 on average
-            lam = 200.0 / (d + 1.0)
-            chunk = 4096
-            for r0 in range(0, n, chunk):
-                r1 = min(n, r0 + chunk)
-                band[r0:r1, :band_w_in] = rng.poisson(lam, size=(r1 - r0, band_w_in)) / lam
-            cols = np.arange(n)[:, None] + d[None, :]
-            band[:, :band_w_in][cols >= n] = 0
-            miss = np.zeros(n, dtype=np.uint8)
-            miss[rng.choice(n, size=n // 50, replace=False)] = 1
-            band[miss.astype(bool), :] = 0
-            colmiss = miss[np.minimum(cols, n - 1)].astype(bool)
-            band[:, :band_w_in][colmiss] = 0
+            ld_in = band.shape[1]
             self.shape = (n, n)
             self.sig_buf = dev.to_device(band)
             self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_in, 0, band_w_in)
@@ -253,12 +237,28 @@ def run_c4(args, rank, local_rank, world, dist, torch):
         }))
 
 
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script with
+    torch.distributed.run on 127.0.0.1 (one process per GPU) and relay their output."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     torch = None

@@ -52,6 +52,14 @@ int fail(cs_ctx* ctx, int code, const char* fmt, ...)
             return fail(ctx, CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
     } while (0)
 
+// every entry point that launches, copies or allocates first makes the context's GPU current: a
+// process may hold contexts on several devices
+#define CS_ENTER(ctx)                                                                        \
+    do {                                                                                     \
+        if (!(ctx)) return CS_ERR_INVALID;                                                   \
+        CS_HIP(ctx, hipSetDevice((ctx)->device));                                            \
+    } while (0)
+
 cs::MatView view_of(const cs_matrix* m)
 {
     cs::MatView v;
@@ -461,29 +469,29 @@ int cs_device_cu_count(const cs_ctx* ctx) { return ctx ? ctx->n_cu : 0; }
 
 int cs_malloc(cs_ctx* ctx, size_t bytes, void** d_ptr)
 {
-    if (!ctx || !d_ptr) return CS_ERR_INVALID;
-    CS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!d_ptr) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     CS_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
     return CS_OK;
 }
 
 int cs_free(cs_ctx* ctx, void* d_ptr)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     if (d_ptr) CS_HIP(ctx, hipFree(d_ptr));
     return CS_OK;
 }
 
 int cs_memcpy_h2d(cs_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     if (bytes) CS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return CS_OK;
 }
 
 int cs_memcpy_d2h(cs_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     if (bytes) {
         CS_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
         CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
@@ -493,21 +501,22 @@ int cs_memcpy_d2h(cs_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, voi
 
 int cs_memset(cs_ctx* ctx, void* d_dst, int value, size_t bytes, void* stream)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     if (bytes) CS_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
     return CS_OK;
 }
 
 int cs_stream_sync(cs_ctx* ctx, void* stream)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return CS_OK;
 }
 
 int cs_stream_create(cs_ctx* ctx, void** stream)
 {
-    if (!ctx || !stream) return CS_ERR_INVALID;
+    if (!stream) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     hipStream_t s;
     CS_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *stream = (void*)s;
@@ -516,14 +525,15 @@ int cs_stream_create(cs_ctx* ctx, void** stream)
 
 int cs_stream_destroy(cs_ctx* ctx, void* stream)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     if (stream) CS_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
     return CS_OK;
 }
 
 int cs_event_create(cs_ctx* ctx, void** event)
 {
-    if (!ctx || !event) return CS_ERR_INVALID;
+    if (!event) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     hipEvent_t e;
     CS_HIP(ctx, hipEventCreate(&e));
     *event = (void*)e;
@@ -532,21 +542,23 @@ int cs_event_create(cs_ctx* ctx, void** event)
 
 int cs_event_destroy(cs_ctx* ctx, void* event)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     if (event) CS_HIP(ctx, hipEventDestroy((hipEvent_t)event));
     return CS_OK;
 }
 
 int cs_event_record(cs_ctx* ctx, void* event, void* stream)
 {
-    if (!ctx || !event) return CS_ERR_INVALID;
+    if (!event) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     CS_HIP(ctx, hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
     return CS_OK;
 }
 
 int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms)
 {
-    if (!ctx || !start || !stop || !ms) return CS_ERR_INVALID;
+    if (!start || !stop || !ms) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     CS_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
     CS_HIP(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return CS_OK;
@@ -556,7 +568,7 @@ int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms)
 int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
                   const cs_normxcorr2_params* p, const cs_matrix* out_corr, const cs_matrix* out_nobs)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (!p) return fail(ctx, CS_ERR_INVALID, "null params");
     int rc = check_matrix(ctx, out_corr, "out_corr", p->ns);
@@ -592,7 +604,7 @@ int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, i
               const double* h_weights, int32_t km, int32_t kn, double threshold, int32_t compute_dtype,
               const cs_matrix* out)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (!h_weights || km <= 0 || kn <= 0) return fail(ctx, CS_ERR_INVALID, "bad weights");
     if (ms < km || ns < kn) return fail(ctx, CS_ERR_INVALID, "signal smaller than kernel");
@@ -630,7 +642,7 @@ int cs_rescore_f64(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
                    const cs_normxcorr2_params* p, const int32_t* d_rows, const int32_t* d_cols,
                    int64_t n_px, double* d_out_corr, double* d_out_nobs)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (n_px < 0 || (n_px > 0 && (!d_rows || !d_cols || !d_out_corr)))
         return fail(ctx, CS_ERR_INVALID, "bad pixel list");
@@ -646,7 +658,7 @@ int cs_compact_ge(cs_ctx* ctx, void* stream_, const cs_matrix* corr, int32_t ms,
                   double threshold, int32_t lo_diag, int32_t hi_diag, int32_t* d_rows, int32_t* d_cols,
                   double* d_vals, int64_t cap, int64_t* d_count)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     int rc = check_matrix(ctx, corr, "corr", ns);
     if (rc) return rc;
     if (!d_rows || !d_cols || !d_vals || !d_count || cap < 0) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
@@ -675,7 +687,7 @@ static int csr_view(cs_ctx* ctx, const cs_csr* m, cs::CsrView* v)
 int cs_distance_law_csr(cs_ctx* ctx, void* stream_, const cs_csr* mat, const uint8_t* d_detectable,
                         int32_t n_diags, double* d_sum, int64_t* d_cnt)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     cs::CsrView v;
     int rc = csr_view(ctx, mat, &v);
     if (rc) return rc;
@@ -688,7 +700,7 @@ int cs_distance_law_csr(cs_ctx* ctx, void* stream_, const cs_csr* mat, const uin
 int cs_detrend_csr(cs_ctx* ctx, void* stream_, const cs_csr* mat, const double* d_law, int32_t n_law,
                    double max_val, void* d_out)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     cs::CsrView v;
     int rc = csr_view(ctx, mat, &v);
     if (rc) return rc;
@@ -701,7 +713,7 @@ int cs_detrend_csr(cs_ctx* ctx, void* stream_, const cs_csr* mat, const double* 
 int cs_csr_to_band(cs_ctx* ctx, void* stream_, const cs_csr* mat, const double* d_law, int32_t n_law,
                    double max_val, const cs_matrix* band)
 {
-    if (!ctx) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
     cs::CsrView v;
     int rc = csr_view(ctx, mat, &v);
     if (rc) return rc;

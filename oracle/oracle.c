@@ -60,6 +60,124 @@ static int missing_pred(const geom_t* g, int p, int q)
 
 static double thr(double x) { return fabs(x) < 1e-4 ? 0.0 : x; }
 
+/* signal accessor: dense row-major (ld = ns) or diagonal band, element (p, q) at
+ * p * ld + (q - p - lo) for lo <= q - p < lo + w (0 outside the stored band) */
+typedef struct {
+    const double* ptr;
+    long long ld;
+    int band, lo, w;
+} sig_t;
+
+static double sig_at(const sig_t* s, int p, int q)
+{
+    if (!s->band) return s->ptr[(size_t)p * s->ld + q];
+    int x = q - p - s->lo;
+    if (x < 0 || x >= s->w) return 0.0;
+    return s->ptr[(size_t)p * s->ld + x];
+}
+
+typedef struct {
+    double n, ksum, k2sum, kmean, kvar, kstd;
+    int cut;
+    const double* kc;
+    const double* kc2;
+} tmpl_t;
+
+/* one output pixel (i, j); *cond (optional) receives the conditioning of the quotient:
+ * min(window variance / window mean square, present-template variance / template variance),
+ * i.e. how far the two factors of the denominator are from an exactly degenerate window */
+static double pixel(const geom_t* g, const sig_t* sg, const tmpl_t* T, int i, int j, double* nobs_out,
+                    double* cond_out)
+{
+    const int ms = g->ms, ns = g->ns, km = g->km, kn = g->kn, full = g->full, masked = g->masked;
+    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+    const double n = T->n;
+    double r = 0.0, nobs = n, cond = 1.0;
+    int zero = 0;
+    if (!full) zero = (i < kh) || (i > ms - km + kh) || (j < kw) || (j > ns - kn + kw);
+    if (g->sym_upper && (j - i) + (full ? (kn - km) : 0) < 0) zero = 1;
+    if (!zero) {
+        double s1 = 0, s2 = 0, c = 0, nm = 0, km_ = 0, k2m = 0;
+        for (int a = 0; a < km; ++a) {
+            int p = i - kh + a;
+            for (int b = 0; b < kn; ++b) {
+                int q = j - kw + b;
+                double v = 0.0;
+                if (p >= 0 && p < ms && q >= 0 && q < ns) v = sig_at(sg, p, q);
+                s1 += v * (1.0 / n);
+                s2 += v * v * (1.0 / n);
+                c += v * (T->kc[a * kn + b] / n);
+                if (masked && missing_pred(g, p, q)) {
+                    nm += 1.0;
+                    km_ += T->kc[a * kn + b];
+                    k2m += T->kc2[a * kn + b];
+                }
+            }
+        }
+        double m1 = thr(s1), m2 = thr(s2), cz = thr(c), num, den;
+        double vs = m2 - m1 * m1, vk = T->kvar;
+        if (!masked) {
+            den = sqrt(m2 - m1 * m1) * T->kstd;
+            num = cz - m1 * T->kmean;
+        } else if (thr(nm) == 0.0) {
+            den = sqrt((m2 - m1 * m1) * T->kvar);
+            num = cz - m1 * T->kmean;
+        } else {
+            double np_ = n - nm;
+            double kmw = (T->ksum - thr(km_)) / np_;
+            double k2mw = (T->k2sum - thr(k2m)) / np_;
+            double m1w = m1 * n / np_, m2w = m2 * n / np_;
+            double dd = (m2w - m1w * m1w) * T->kvar;
+            dd = dd / T->kvar * (k2mw - kmw * kmw);
+            den = sqrt(dd);
+            if (np_ < T->cut) den = 0.0;
+            double o = m1w * T->kmean;
+            o = o * kmw * np_ / (T->kmean * n);
+            num = (cz - o) * n / np_;
+            nobs = np_;
+            vs = m2w - m1w * m1w;
+            vk = k2mw - kmw * kmw;
+            m2 = m2w;
+        }
+        r = (fabs(den) < 1e-10) ? 0.0 : num / den;
+        if (!isfinite(r)) r = 0.0;
+        if (r < -1.0) r = -1.0;
+        if (r > 1.0) r = 1.0;
+        {
+            double c1 = m2 > 0 ? vs / m2 : 0.0, c2 = T->kvar > 0 ? vk / T->kvar : 0.0;
+            cond = c1 < c2 ? c1 : c2;
+            if (!(cond == cond)) cond = 0.0;
+        }
+    }
+    if (nobs_out) *nobs_out = nobs;
+    if (cond_out) *cond_out = cond;
+    return r;
+}
+
+static void make_template(tmpl_t* T, const double* kernel, const double* kernel_conv, const double* kernel_sq,
+                          int km, int kn, double missing_tol, double* kc2)
+{
+    const int kk = km * kn;
+    const double n = (double)kk;
+    double ksum = 0, k2sum = 0, kstd = 0;
+    const double* kc = kernel_conv ? kernel_conv : kernel;
+    for (int t = 0; t < kk; ++t) {
+        ksum += kernel[t];
+        k2sum += kernel[t] * kernel[t];
+        kc2[t] = kernel_sq ? kernel_sq[t] : kc[t] * kc[t];
+    }
+    T->n = n;
+    T->ksum = ksum;
+    T->k2sum = k2sum;
+    T->kmean = ksum / n;
+    T->kvar = k2sum / n - T->kmean * T->kmean;
+    for (int t = 0; t < kk; ++t) kstd += (kernel[t] - T->kmean) * (kernel[t] - T->kmean);
+    T->kstd = sqrt(kstd / n);
+    T->cut = (int)((1.0 - missing_tol) * n);
+    T->kc = kc;
+    T->kc2 = kc2;
+}
+
 /*
  * sig: ms x ns row-major float64.  kernel / kernel_conv / kernel_sq: km x kn (kernel_conv and
  * kernel_sq may be NULL).  out_corr, out_nobs: ms x ns.  Returns 0.
@@ -71,80 +189,81 @@ int oracle_normxcorr2(const double* sig, int ms, int ns, const double* kernel,
                       int n_threads)
 {
     geom_t g = {ms, ns, km, kn, full, sym_upper, max_dist, masked, miss_row, miss_col};
-    const int kk = km * kn;
-    const double n = (double)kk;
-    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
-    double ksum = 0, k2sum = 0, kmean, k2mean, kstd = 0, kvar;
-    const double* kc = kernel_conv ? kernel_conv : kernel;
-    double* kc2 = (double*)malloc(sizeof(double) * kk);
-    int t;
-    for (t = 0; t < kk; ++t) {
-        ksum += kernel[t];
-        k2sum += kernel[t] * kernel[t];
-        kc2[t] = kernel_sq ? kernel_sq[t] : kc[t] * kc[t];
-    }
-    kmean = ksum / n;
-    k2mean = k2sum / n;
-    kvar = k2mean - kmean * kmean;
-    for (t = 0; t < kk; ++t) kstd += (kernel[t] - kmean) * (kernel[t] - kmean);
-    kstd = sqrt(kstd / n);
-    const int cut = (int)((1.0 - missing_tol) * n);
+    sig_t sg = {sig, ns, 0, 0, 0};
+    tmpl_t T;
+    double* kc2 = (double*)malloc(sizeof(double) * km * kn);
+    make_template(&T, kernel, kernel_conv, kernel_sq, km, kn, missing_tol, kc2);
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
     for (int i = 0; i < ms; ++i) {
         for (int j = 0; j < ns; ++j) {
-            double r = 0.0, nobs = n;
-            int zero = 0;
-            if (!full) zero = (i < kh) || (i > ms - km + kh) || (j < kw) || (j > ns - kn + kw);
-            if (sym_upper && (j - i) + (full ? (kn - km) : 0) < 0) zero = 1;
-            if (!zero) {
-                double s1 = 0, s2 = 0, c = 0, nm = 0, km_ = 0, k2m = 0;
-                for (int a = 0; a < km; ++a) {
-                    int p = i - kh + a;
-                    for (int b = 0; b < kn; ++b) {
-                        int q = j - kw + b;
-                        double v = 0.0;
-                        if (p >= 0 && p < ms && q >= 0 && q < ns) v = sig[(size_t)p * ns + q];
-                        s1 += v * (1.0 / n);
-                        s2 += v * v * (1.0 / n);
-                        c += v * (kc[a * kn + b] / n);
-                        if (masked && missing_pred(&g, p, q)) {
-                            nm += 1.0;
-                            km_ += kc[a * kn + b];
-                            k2m += kc2[a * kn + b];
-                        }
-                    }
-                }
-                double m1 = thr(s1), m2 = thr(s2), cz = thr(c), num, den;
-                if (!masked) {
-                    den = sqrt(m2 - m1 * m1) * kstd;
-                    num = cz - m1 * kmean;
-                } else if (thr(nm) == 0.0) {
-                    den = sqrt((m2 - m1 * m1) * kvar);
-                    num = cz - m1 * kmean;
-                } else {
-                    double np_ = n - nm;
-                    double kmw = (ksum - thr(km_)) / np_;
-                    double k2mw = (k2sum - thr(k2m)) / np_;
-                    double m1w = m1 * n / np_, m2w = m2 * n / np_;
-                    double dd = (m2w - m1w * m1w) * kvar;
-                    dd = dd / kvar * (k2mw - kmw * kmw);
-                    den = sqrt(dd);
-                    if (np_ < cut) den = 0.0;
-                    double o = m1w * kmean;
-                    o = o * kmw * np_ / (kmean * n);
-                    num = (cz - o) * n / np_;
-                    nobs = np_;
-                }
-                r = (fabs(den) < 1e-10) ? 0.0 : num / den;
-                if (!isfinite(r)) r = 0.0;
-                if (r < -1.0) r = -1.0;
-                if (r > 1.0) r = 1.0;
-            }
-            out_corr[(size_t)i * ns + j] = r;
+            double nobs;
+            out_corr[(size_t)i * ns + j] = pixel(&g, &sg, &T, i, j, &nobs, NULL);
             if (out_nobs) out_nobs[(size_t)i * ns + j] = nobs;
+        }
+    }
+    free(kc2);
+    return 0;
+}
+
+/*
+ * Dense map, rows [r0, r1) only, with the conditioning of every pixel (out_cond may be NULL):
+ * full-size parity checks of dense maps (C2) in bounded time.  Outputs (r1 - r0) x ns.
+ */
+int oracle_normxcorr2_rows(const double* sig, int ms, int ns, const double* kernel, int km, int kn, int full,
+                           int sym_upper, int max_dist, int masked, const uint8_t* miss_row,
+                           const uint8_t* miss_col, double missing_tol, int r0, int r1, double* out_corr,
+                           double* out_cond, int n_threads)
+{
+    geom_t g = {ms, ns, km, kn, full, sym_upper, max_dist, masked, miss_row, miss_col};
+    sig_t sg = {sig, ns, 0, 0, 0};
+    tmpl_t T;
+    double* kc2 = (double*)malloc(sizeof(double) * km * kn);
+    make_template(&T, kernel, NULL, NULL, km, kn, missing_tol, kc2);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int i = r0; i < r1; ++i) {
+        for (int j = 0; j < ns; ++j) {
+            double cond;
+            out_corr[(size_t)(i - r0) * ns + j] = pixel(&g, &sg, &T, i, j, NULL, &cond);
+            if (out_cond) out_cond[(size_t)(i - r0) * ns + j] = cond;
+        }
+    }
+    free(kc2);
+    return 0;
+}
+
+/*
+ * Square n x n map stored as a diagonal band (band[i * ld + (j - i - lo)], lo <= j - i < lo + w),
+ * rows [r0, r1) only: the coefficient of pixel (i, i + out_lo + x), 0 <= x < out_w, goes to
+ * out_corr[(i - r0) * out_w + x] (0 where the column falls outside the matrix).  For the band
+ * configurations of BASELINE.md (C3, C4') whose dense form does not fit in memory.
+ */
+int oracle_normxcorr2_band(const double* band, int n, long long ld, int lo, int w, const double* kernel, int km,
+                           int kn, int full, int sym_upper, int max_dist, int masked, const uint8_t* miss_row,
+                           const uint8_t* miss_col, double missing_tol, int r0, int r1, int out_lo, int out_w,
+                           double* out_corr, double* out_cond, int n_threads)
+{
+    geom_t g = {n, n, km, kn, full, sym_upper, max_dist, masked, miss_row, miss_col};
+    sig_t sg = {band, ld, 1, lo, w};
+    tmpl_t T;
+    double* kc2 = (double*)malloc(sizeof(double) * km * kn);
+    make_template(&T, kernel, NULL, NULL, km, kn, missing_tol, kc2);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int i = r0; i < r1; ++i) {
+        for (int x = 0; x < out_w; ++x) {
+            const int j = i + out_lo + x;
+            double r = 0.0, cond = 1.0;
+            if (j >= 0 && j < n) r = pixel(&g, &sg, &T, i, j, NULL, &cond);
+            out_corr[(size_t)(i - r0) * out_w + x] = r;
+            if (out_cond) out_cond[(size_t)(i - r0) * out_w + x] = cond;
         }
     }
     free(kc2);

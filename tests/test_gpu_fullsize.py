@@ -1,0 +1,110 @@
+"""Full-size parity of the benched launches (C2, C3, C4') against the C
+oracle, through the C ABI exactly as bench.py issues them (same generators, same resident
+float32 buffers, same launch shapes), at the north-star tolerance: float32 coefficient within
+1e-5 of the float64 oracle on every well-defined pixel.
+
+A pixel is *ill-defined* when one factor of its denominator is an (almost) exactly degenerate
+quantity -- the variance of the window, or the variance of the template over the present pixels,
+below COND_EPS of its scale (oracle.c: `cond`): there the float64 reference value itself is
+cancellation noise (the reference's dense and sparse paths disagree by 5e-8 on such windows,
+tests/test_oracle_golden.py).  Such pixels are counted, reported and bounded, never silently
+dropped."""
+import numpy as np
+import pytest
+
+import chromosight_amd
+from chromosight_amd import engine
+from chromosight_amd._lib import (LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_NONE, CsMatrix, get_device,
+                                  np_dtype_code)
+from oracle import c_oracle
+from tools.synthetic_genome import band_workload
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+COND_EPS = 1e-3
+
+
+def loops():
+    return np.asarray(chromosight_amd.kernels.loops["kernels"][0], dtype=np.float64)
+
+
+def check(got, want, cond, what):
+    err = np.abs(got.astype(np.float64) - want)
+    ill = cond < COND_EPS
+    n_ill = int(ill.sum())
+    worst = float(err[~ill].max())
+    print(f"{what}: {got.size} pixels, max |err| = {worst:.2e} on well-defined pixels, "
+          f"{n_ill} ill-defined (cond < {COND_EPS}) with max |err| = {float(err[ill].max()) if n_ill else 0:.2e}")
+    assert worst < TOL, what
+    assert n_ill <= 1e-4 * got.size, what
+    return worst
+
+
+def test_c2_dense_4096_full_map():
+    """C2 as benched: dense 4096^2 float32 gamma(4, 0.25) seed 0, loops 17x17, full=False, no mask."""
+    dev = get_device()
+    n = 4096
+    sig = np.random.default_rng(0).gamma(4.0, 0.25, size=(n, n)).astype(np.float32)
+    d_sig, d_out = dev.to_device(sig), dev.empty((n, n), np.float32)
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0), (n, n),
+                          engine.KernelSpec(loops()),
+                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0),
+                          full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE, precision="f32")
+    got = d_out.download()
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), loops(), 0, n, full=False)
+    check(got, want, cond, "C2 4096x4096")
+    assert np.all(got[:8] == 0) and np.all(got[:, -8:] == 0)      # valid-mode margins
+
+
+def run_band(name, n=None):
+    dev = get_device()
+    band, band_w, miss, n, max_dist = band_workload(name, n=n)
+    out_w = max_dist + 1
+    ld_out = (out_w + 63) // 64 * 64
+    d_sig, d_out = dev.to_device(band), dev.zeros((n, ld_out), np.float32)
+    d_miss = dev.to_device(miss)
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_BAND, band.shape[1], 0, band_w),
+                          (n, n), engine.KernelSpec(loops()),
+                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_out, 0, out_w),
+                          full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=d_miss,
+                          miss_col=d_miss, missing_tol=0.5, precision="f32")
+    return d_out.download()[:, :out_w], band, band_w, miss, n, max_dist
+
+
+def test_c3_band_50000_full_map():
+    """C3 as benched: N = 50 000, diagonals 0..250, 2 % missing bins, max_dist 233, full, sym_upper,
+    missing_tol 0.5 -- every pixel of the 11.7 M-pixel band."""
+    got, band, band_w, miss, n, max_dist = run_band("c3")
+    want, cond = c_oracle.normxcorr2_band(band.astype(np.float64), n, 0, band_w, loops(), 0, n, 0, max_dist + 1,
+                                          max_dist=max_dist, miss_row=miss, miss_col=miss, missing_tol=0.5)
+    check(got, want, cond, "C3 50000 x 234")
+
+
+def test_c4p_band_200000_row_windows():
+    """C4' as benched: N = 200 000 single block, max_dist 1000 -- seven windows of 2000 rows (both
+    matrix ends, the middle, strip-height boundaries), 14 M pixels against the oracle."""
+    got, band, band_w, miss, n, max_dist = run_band("c4p")
+    band64 = band.astype(np.float64)
+    del band
+    for r0 in (0, 1990, 49_000, 99_137, 150_000, 187_654, n - 2000):
+        want, cond = c_oracle.normxcorr2_band(band64, n, 0, band_w, loops(), r0, r0 + 2000, 0, max_dist + 1,
+                                              max_dist=max_dist, miss_row=miss, miss_col=miss, missing_tol=0.5)
+        check(got[r0:r0 + 2000], want, cond, f"C4' rows {r0}..{r0 + 2000}")
+
+
+@pytest.mark.parametrize("env", ["CHROMOSIGHT_HIP_FORCE_GENERIC", "CHROMOSIGHT_HIP_NO_SYMMETRY"])
+def test_c2_alternative_kernels(env, monkeypatch):
+    """The generic LDS-tiled kernel and the unfolded streaming kernel on a 1024-row slab of C2: the
+    in-library cross-checks of the benched kernel, against the same oracle."""
+    monkeypatch.setenv(env, "1")
+    dev = get_device()
+    n, rows = 4096, 1024
+    sig = np.random.default_rng(0).gamma(4.0, 0.25, size=(n, n)).astype(np.float32)[:rows]
+    d_sig, d_out = dev.to_device(sig), dev.empty((rows, n), np.float32)
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0), (rows, n),
+                          engine.KernelSpec(loops()),
+                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0),
+                          full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE, precision="f32")
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), loops(), 0, rows, full=False)
+    check(d_out.download(), want, cond, f"C2 slab, {env}")

@@ -58,3 +58,37 @@ def make_cool(total_bins=200_000, max_dist_bins=1000, binsize=2000, seed=2, loop
         "bin_end": np.concatenate([(np.arange(s) + 1) * binsize for s in sizes]),
     }
     return cool, planted
+
+
+BAND_WORKLOADS = {"c3": (50_000, 233, 1), "c4p": (200_000, 1000, 2)}
+
+
+def band_workload(name, rank=0, n=None):
+    """The banded kernel workloads of BASELINE.md section 4 as a float32 diagonal band
+    (band[i, d] = pixel (i, i + d), diagonals 0 .. max_dist + 17), already detrended-like:
+    poisson(200 / (d + 1)) counts divided by their expectation, 2 % missing bins zeroed.
+    Returns (band, band_w, miss uint8 flags, n, max_dist).  Shared by bench.py and the full-size
+    parity tests so that both run the same map."""
+    n0, max_dist, seed = BAND_WORKLOADS[name]
+    n = n0 if n is None else int(n)
+    keep = max_dist + 17
+    rng = np.random.default_rng(seed + rank)
+    band_w = keep + 1
+    ld = (band_w + 63) // 64 * 64
+    band = np.zeros((n, ld), dtype=np.float32)
+    d = np.arange(band_w)
+    lam = 200.0 / (d + 1.0)
+    chunk = 4096
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        band[r0:r1, :band_w] = rng.poisson(lam, size=(r1 - r0, band_w)) / lam
+    miss = np.zeros(n, dtype=np.uint8)
+    miss[rng.choice(n, size=n // 50, replace=False)] = 1
+    band[miss.astype(bool), :] = 0
+    for r0 in range(0, n, chunk):          # chunked: the column index table of C4' would take 1.6 GB
+        r1 = min(n, r0 + chunk)
+        cols = np.arange(r0, r1)[:, None] + d[None, :]
+        view = band[r0:r1, :band_w]
+        view[cols >= n] = 0
+        view[miss[np.minimum(cols, n - 1)].astype(bool)] = 0
+    return band, band_w, miss, n, max_dist

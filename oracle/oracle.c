@@ -144,7 +144,8 @@ static double pixel(const geom_t* g, const sig_t* sg, const tmpl_t* T, int i, in
         if (r < -1.0) r = -1.0;
         if (r > 1.0) r = 1.0;
         {
-            double c1 = m2 > 0 ? vs / m2 : 0.0, c2 = T->kvar > 0 ? vk / T->kvar : 0.0;
+            /* an empty window (m2 == 0) gives exactly 0 on every path: well defined */
+            double c1 = m2 > 0 ? vs / m2 : 1.0, c2 = T->kvar > 0 ? vk / T->kvar : 0.0;
             cond = c1 < c2 ? c1 : c2;
             if (!(cond == cond)) cond = 0.0;
         }

@@ -21,8 +21,7 @@ from tools.synthetic_genome import band_workload
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-5
-COND_EPS = 1e-3
+from parity_util import assert_parity
 
 
 def loops():
@@ -30,15 +29,7 @@ def loops():
 
 
 def check(got, want, cond, what):
-    err = np.abs(got.astype(np.float64) - want)
-    ill = cond < COND_EPS
-    n_ill = int(ill.sum())
-    worst = float(err[~ill].max())
-    print(f"{what}: {got.size} pixels, max |err| = {worst:.2e} on well-defined pixels, "
-          f"{n_ill} ill-defined (cond < {COND_EPS}) with max |err| = {float(err[ill].max()) if n_ill else 0:.2e}")
-    assert worst < TOL, what
-    assert n_ill <= 1e-4 * got.size, what
-    return worst
+    return assert_parity(got, want, cond, "f32", what, max_ill_frac=1e-4)
 
 
 def test_c2_dense_4096_full_map():

@@ -38,7 +38,7 @@ def test_dense_shapes(shape, env):
     for full in (False, True):
         got, _ = run_env(env, lambda: cud.normxcorr2(sig, kern, full=full))
         want, _ = c_oracle.normxcorr2(sig, kern, full=full)
-        assert np.abs(got - want).max() < 2e-5, (shape, env, full)
+        assert np.abs(got - want).max() < 1e-5, (shape, env, full)
 
 
 def test_auto_split_ragged_rows():
@@ -53,7 +53,7 @@ def test_auto_split_ragged_rows():
     assert np.abs(got - ref).max() < 1e-5
     rows = slice(3300, 3500)
     want, _ = c_oracle.normxcorr2(sig[3200:].astype(np.float64), kern, full=False)
-    assert np.abs(got[rows] - want[100:300]).max() < 2e-5
+    assert np.abs(got[rows] - want[100:300]).max() < 1e-5
 
 
 @pytest.mark.parametrize("env", [{"CHROMOSIGHT_HIP_SPLIT": "20,12"}, {"CHROMOSIGHT_HIP_STRIP_H": "10"}], ids=["split", "h10"])

@@ -8,7 +8,9 @@ import scipy.sparse as sp
 import chromosight_amd
 from chromosight_amd.utils import detection as cud
 from chromosight_amd.utils import preprocessing as cup
+from oracle import c_oracle
 from oracle import pearson_oracle as orc
+from parity_util import assert_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -28,26 +30,10 @@ def coo(g, prefix):
     return sp.coo_matrix((g[f"{prefix}_val"], (g[f"{prefix}_row"], g[f"{prefix}_col"])), shape=shape)
 
 
-def well_conditioned(signal, kernel_shape, full):
-    """Mask of output pixels whose window variance is not degenerate (the reference itself is
-    only reproducible to ~1e-7 on constant windows, see tests/test_oracle_golden.py)."""
-    s = np.asarray(signal, dtype=np.float64)
-    km, kn = kernel_shape
-    if full:
-        f = np.zeros((s.shape[0] + 2 * (km - 1), s.shape[1] + 2 * (kn - 1)))
-        f[km - 1:km - 1 + s.shape[0], kn - 1:kn - 1 + s.shape[1]] = s
-    else:
-        f = s
-    ones = np.ones((km, kn)) / (km * kn)
-    m1 = orc.window_sums(f, ones)
-    m2 = orc.window_sums(f ** 2, ones)
-    ok = (m2 - m1 ** 2) > 1e-6 * np.maximum(m2, 1e-30)
-    out = np.ones(f.shape, dtype=bool)
-    kh, kw = (km - 1) // 2, (kn - 1) // 2
-    out[kh:kh + ok.shape[0], kw:kw + ok.shape[1]] = ok
-    if full:
-        out = out[km - 1:km - 1 + s.shape[0], kn - 1:kn - 1 + s.shape[1]]
-    return out
+def oracle_cond(signal, kernel, **kw):
+    """Conditioning of every output pixel (oracle/oracle.c), for assert_parity."""
+    sig = np.asarray(signal.toarray() if sp.issparse(signal) else signal, dtype=np.float64)
+    return c_oracle.normxcorr2_rows(sig, np.asarray(kernel, dtype=np.float64), 0, sig.shape[0], **kw)[1]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -77,34 +63,32 @@ def test_xcorr2_golden(golden, precision):
 
 def test_normxcorr2_dense_golden(golden, templates, precision):
     g = golden("normxcorr2_dense")
-    tol = TOL[precision]
     for name in "ab":
         sig = g[f"sig_{name}"]
         for kname in ("loops", "small", "hairpin"):
             k = templates[kname]
             for full in (False, True):
                 tag = f"{name}_{kname}_{'full' if full else 'valid'}"
-                ok = well_conditioned(sig, k.shape, full)
+                cond = oracle_cond(sig, k, full=full)
                 cd, pd_ = cud.normxcorr2(sig, k, full=full, pval=not full)
                 cs_, ps = cud.normxcorr2(sp.csr_matrix(sig), k, full=full, pval=True)
                 assert isinstance(cd, np.ndarray) and sp.issparse(cs_)
-                assert np.abs(cd - g[f"dense_{tag}_corr"])[ok].max() < tol, tag
-                assert np.abs(cs_.toarray() - g[f"sparse_{tag}_corr"])[ok].max() < tol, tag
-                assert np.abs(cd).max() <= 1.0
+                assert_parity(cd, g[f"dense_{tag}_corr"], cond, precision, f"dense {tag}")
+                assert_parity(cs_.toarray(), g[f"sparse_{tag}_corr"], cond, precision, f"sparse {tag}")
                 ref_p = g[f"sparse_{tag}_pval"]
-                err = np.abs(ps.toarray() - ref_p)[ok]
+                err = np.abs(ps.toarray() - ref_p)[cond >= 1e-3]
                 # log10 p amplifies coefficient errors by up to ~ n / ln(10)
                 assert err.max() < (5e-3 if precision == "f32" else 1e-7), tag
         sq = sig[:80, :80]
-        ok = well_conditioned(np.triu(sq), (17, 17), True)
+        cond = oracle_cond(np.triu(sq), templates["loops"], sym_upper=True, full=True)
         c, p = cud.normxcorr2(sp.csr_matrix(np.triu(sq)), templates["loops"], sym_upper=True, full=True, pval=True)
-        assert np.abs(c.toarray() - g[f"sparse_{name}_loops_symfull_corr"])[ok].max() < tol
+        assert_parity(c.toarray(), g[f"sparse_{name}_loops_symfull_corr"], cond, precision, f"{name} symfull")
         assert np.all(np.tril(c.toarray(), -1) == 0)
-        ok = well_conditioned(np.triu(sq), (17, 17), False)
+        cond = oracle_cond(np.triu(sq), templates["loops"], sym_upper=True, full=False)
         c, _ = cud.normxcorr2(np.triu(sq), templates["loops"], sym_upper=True, full=False)
-        assert np.abs(c - g[f"dense_{name}_loops_symvalid_corr"])[ok].max() < tol
+        assert_parity(c, g[f"dense_{name}_loops_symvalid_corr"], cond, precision, f"{name} symvalid")
     c, _ = cud.normxcorr2(sp.csr_matrix(g["sig_a"]), templates["loops"], full=True, tsvd=0.999)
-    assert np.abs(c.toarray() - g["sparse_a_loops_full_tsvd999_corr"]).max() < tol
+    assert np.abs(c.toarray() - g["sparse_a_loops_full_tsvd999_corr"]).max() < TOL[precision]
 
 
 def test_normxcorr2_mask_golden(golden, templates, precision):
@@ -305,7 +289,7 @@ def test_banded_masked_multi_strip_vs_oracle(n, max_dist, ksize, tol, precision)
     want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True, miss_row=miss,
                                   miss_col=miss, missing_tol=tol)
     err = np.abs(got.toarray() - want)
-    assert err.max() < (2e-5 if precision == "f32" else 1e-10), (n, max_dist, err.max())
+    assert err.max() < TOL[precision], (n, max_dist, err.max())
 
     # the same map through pattern_detector's device path (per-bin flags instead of an explicit
     # mask): thresholded pixels must be identical to the oracle's
@@ -316,10 +300,12 @@ def test_banded_masked_multi_strip_vs_oracle(n, max_dist, ksize, tol, precision)
     cfg = dict(pearson=0.2, max_perc_undetected=tol * 100, max_perc_zero=100.0, max_dist=5 * max_dist)
     tab, _ = cud.pattern_detector(cmap, cfg, kern, full=True)
     trimmed = np.where((jj - ii >= 0) & (jj - ii <= max_dist), want, 0.0)
-    foci, _ = cud.pick_foci(sp.coo_matrix(trimmed), 0.2)
-    if foci is None:
+    from oracle import foci_oracle
+    want_tab = foci_oracle.detect_table(a, trimmed, miss, miss, kern.shape, pearson=0.2, zero_tol=1.0,
+                                        missing_tol=tol, inter=False)
+    if want_tab.shape[0] == 0:
         assert tab is None or len(tab) == 0
     else:
-        got_set = set(map(tuple, tab[["bin1", "bin2"]].to_numpy().astype(int))) if tab is not None else set()
-        assert got_set <= set(map(tuple, foci))      # validation may drop some foci, never add
-        assert len(got_set) > 0
+        got_tab = tab[["bin1", "bin2", "score"]].to_numpy(dtype=np.float64)
+        assert np.array_equal(got_tab[:, :2], want_tab[:, :2]), (n, max_dist)     # same foci, same order
+        assert np.abs(got_tab[:, 2] - want_tab[:, 2]).max() < 1e-9

@@ -151,3 +151,68 @@ def test_corr_to_pval(golden):
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(lp), fin)
     assert np.abs(lp[fin] - ref[fin]).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle/foci_oracle.py (focus picking + window validation) pinned to the reference's captures
+# ------------------------------------------------------------------------------------------------
+def _coo(g, prefix):
+    import scipy.sparse as sp
+    return sp.coo_matrix((g[f"{prefix}_val"], (g[f"{prefix}_row"], g[f"{prefix}_col"])),
+                         shape=tuple(g[f"{prefix}_shape"]))
+
+
+def test_foci_oracle_matches_reference_pick_foci(golden):
+    from oracle import foci_oracle
+    g = golden("nms")
+    tags = sorted({k[:-len("_pearson")] for k in g if k.endswith("_pearson")})
+    assert len(tags) == 15
+    for tag in tags:
+        conv = _coo(g, f"{tag}_conv").toarray()
+        foci = foci_oracle.pick_foci_dense(conv, float(g[f"{tag}_pearson"]))
+        assert np.array_equal(foci, g[f"{tag}_foci"].reshape(-1, 2)), tag
+        # the same map in band coordinates (diagonals 0 .. width-1)
+        n = conv.shape[0]
+        width = int(np.max(_coo(g, f"{tag}_conv").col - _coo(g, f"{tag}_conv").row)) + 1
+        band = np.zeros((n, width))
+        for d in range(width):
+            band[:n - d, d] = np.diagonal(conv, d)
+        assert np.array_equal(foci_oracle.pick_foci_band(band, 0, float(g[f"{tag}_pearson"])), foci), tag
+
+
+def test_foci_oracle_matches_reference_tables(golden, templates):
+    """pattern_detector tables and windows of the three example chromosomes x five templates,
+    rebuilt by the oracle from the reference's own coefficient maps."""
+    from oracle import foci_oracle
+    g = golden("example_blocks")
+    pats = {"loops": (0.3, 50.0, 10.0, False, [templates["loops"]]),
+            "borders": (0.15, 75.0, 10.0, True, templates["borders"]),
+            "hairpins": (0.1, 75.0, 10.0, True, [templates["hairpin"]])}
+    n_rows = 0
+    for ci in range(3):
+        det = g[f"chr{ci}_det"]
+        for pname, (pearson, pu, pz, diag_only, kernels) in pats.items():
+            m = _coo(g, f"chr{ci}_{pname}_prepared").toarray()
+            n = m.shape[0]
+            max_dist = int(g[f"chr{ci}_{pname}_max_dist"])
+            miss = np.ones(n, dtype=bool)
+            miss[det] = False
+            ii, jj = np.indices((n, n))
+            for ki, kern in enumerate(kernels):
+                tag = f"chr{ci}_{pname}{ki}"
+                corr = _coo(g, f"{tag}_corr").toarray()
+                trimmed = np.where((jj - ii >= 0) & (jj - ii <= max_dist), corr, 0.0)
+                tab = foci_oracle.detect_table(m, trimmed, miss, miss, np.shape(kern), pearson, pz / 100, pu / 100,
+                                               inter=False, diag_only=diag_only)
+                ref = g[f"{tag}_table"]
+                assert tab.shape[0] == ref.shape[0], tag
+                if ref.shape[0]:
+                    assert np.array_equal(tab[:, :2], ref[:, :2]), tag
+                    assert np.abs(tab[:, 2] - ref[:, 2]).max() < 1e-12, tag
+                    # windows of the validated patterns
+                    foci = tab[:, :2].astype(int)
+                    _, wins = foci_oracle.validate(foci, lambda p, q: m[p, q], m.shape, miss, miss, np.shape(kern),
+                                                   pz / 100, pu / 100, False)
+                    assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12), tag
+                n_rows += ref.shape[0]
+    assert n_rows > 200

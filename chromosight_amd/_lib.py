@@ -65,7 +65,43 @@ class CsCsr(C.Structure):
         ("d_indices", C.c_void_p),
         ("d_data", C.c_void_p),
         ("dtype", C.c_int32),
+        # view extensions (include/chromosight_hip.h): zero / NULL = plain CSR
+        ("col0", C.c_int32),
+        ("d_row_end", C.c_void_p),
+        ("d_row_weight", C.c_void_p),
+        ("d_col_weight", C.c_void_p),
     ]
+
+
+class CsFociParams(C.Structure):
+    _fields_ = [
+        ("pearson", C.c_double),
+        ("rescore_margin", C.c_double),
+        ("min_size", C.c_int32),
+        ("diag_only", C.c_int32),
+        ("lo_diag", C.c_int32),
+        ("hi_diag", C.c_int32),
+        ("inter", C.c_int32),
+        ("want_windows", C.c_int32),
+    ]
+
+
+class CsFocus(C.Structure):
+    _fields_ = [
+        ("bin1", C.c_int32),
+        ("bin2", C.c_int32),
+        ("inside", C.c_int32),
+        ("n_zero", C.c_int32),
+        ("n_missing", C.c_int32),
+        ("focus_size", C.c_int32),
+        ("score", C.c_double),
+        ("n_obs", C.c_double),
+    ]
+
+
+# numpy view of an array of cs_focus records
+FOCUS_DTYPE = np.dtype([("bin1", "<i4"), ("bin2", "<i4"), ("inside", "<i4"), ("n_zero", "<i4"), ("n_missing", "<i4"),
+                        ("focus_size", "<i4"), ("score", "<f8"), ("n_obs", "<f8")])
 
 
 # name -> (restype, argtypes); every symbol include/chromosight_hip.h declares
@@ -104,6 +140,17 @@ _PROTOTYPES = {
                                  C.c_double, C.c_void_p]),
     "cs_csr_to_band": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_void_p, C.c_int32,
                                  C.c_double, C.POINTER(CsMatrix)]),
+    "cs_csr_band_extent": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p]),
+    "cs_distance_law_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "cs_detect_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
+                                 C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_int64), C.c_void_p]),
+    "cs_quantify_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
+                                     C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "cs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 ABI_SYMBOLS = tuple(sorted(_PROTOTYPES))
@@ -185,6 +232,29 @@ class DeviceBuffer:
         return self
 
 
+class PinnedArray:
+    """Page-locked host buffer exposed as a numpy array; freed with the array's last reference."""
+
+    def __init__(self, device, shape, dtype):
+        shape = tuple(int(x) for x in np.atleast_1d(shape))
+        dtype = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
+        ptr = C.c_void_p()
+        device._check(device.lib.cs_host_alloc(device.ctx, nbytes, C.byref(ptr)))
+        self.device, self.ptr = device, ptr.value
+        raw = (C.c_char * nbytes).from_address(self.ptr)
+        raw._pinned_owner = self          # keeps this object (and the allocation) alive with the view
+        self.array = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) and self.device.ctx:
+                self.device.lib.cs_host_free(self.device.ctx, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
 class Device:
     """One context on one GPU (one per process in multi-GPU runs)."""
 
@@ -236,6 +306,10 @@ class Device:
 
     def sync(self, stream=None):
         self._check(self.lib.cs_stream_sync(self.ctx, stream))
+
+    def pinned_empty(self, shape, dtype):
+        """numpy array over page-locked host memory (cs_host_alloc): D2H / H2D at link speed."""
+        return PinnedArray(self, shape, dtype).array
 
     def new_stream(self):
         s = C.c_void_p()

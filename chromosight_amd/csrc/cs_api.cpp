@@ -20,11 +20,19 @@ struct cs_ctx {
     int device = 0;
     int n_cu = 0;
     std::string err;
-    // device buffer for the template weights of the call in flight (3 * kk elements)
-    void* d_w = nullptr;
-    size_t d_w_bytes = 0;
-    // host copy of what d_w currently holds, to skip re-uploads of an unchanged template
-    std::vector<unsigned char> w_cached;
+    // device buffers for the template weights of the call in flight (3 * kk elements), one per
+    // arithmetic type: a detect call runs the float32 map kernel and the float64 re-scoring with the
+    // same template, and neither upload should evict the other
+    void* d_w[2] = {nullptr, nullptr};
+    size_t d_w_bytes[2] = {0, 0};
+    // host copies of what d_w currently holds, to skip re-uploads of an unchanged template
+    std::vector<unsigned char> w_cached[2];
+    // cs_detect_foci: coefficient map and candidate / foci scratch (grow-only), pinned counters
+    void* d_map = nullptr;
+    size_t d_map_bytes = 0;
+    void* d_pool = nullptr;
+    size_t d_pool_bytes = 0;
+    long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
     // grow-only scratch for the mask tables of the streaming kernel (one call in flight per context)
     void* d_ws = nullptr;
     size_t d_ws_bytes = 0;
@@ -99,24 +107,28 @@ HostStats template_stats(const double* k, int kk)
 template <typename TC>
 int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w64)
 {
+    constexpr int slot = sizeof(TC) == 8 ? 1 : 0;
     std::vector<TC> w(w64.size());
     for (size_t t = 0; t < w64.size(); ++t) w[t] = (TC)w64[t];
     const size_t bytes = w.size() * sizeof(TC);
     // + 64 bytes of slack: the fast kernels' scalar row loads over-read (cs_corr_stream.h WRow)
-    if (bytes + 64 > ctx->d_w_bytes) {
-        if (ctx->d_w) CS_HIP(ctx, hipFree(ctx->d_w));
-        ctx->d_w = nullptr;
-        ctx->d_w_bytes = 0;
-        CS_HIP(ctx, hipMalloc(&ctx->d_w, bytes + 64));
-        CS_HIP(ctx, hipMemset(ctx->d_w, 0, bytes + 64));
-        ctx->d_w_bytes = bytes + 64;
-        ctx->w_cached.clear();
+    if (bytes + 64 > ctx->d_w_bytes[slot]) {
+        if (ctx->d_w[slot]) {
+            CS_HIP(ctx, hipDeviceSynchronize());   // a queued kernel may still read the old buffer
+            CS_HIP(ctx, hipFree(ctx->d_w[slot]));
+        }
+        ctx->d_w[slot] = nullptr;
+        ctx->d_w_bytes[slot] = 0;
+        CS_HIP(ctx, hipMalloc(&ctx->d_w[slot], bytes + 64));
+        CS_HIP(ctx, hipMemset(ctx->d_w[slot], 0, bytes + 64));
+        ctx->d_w_bytes[slot] = bytes + 64;
+        ctx->w_cached[slot].clear();
     }
-    if (ctx->w_cached.size() == bytes && std::memcmp(ctx->w_cached.data(), w.data(), bytes) == 0)
+    if (ctx->w_cached[slot].size() == bytes && std::memcmp(ctx->w_cached[slot].data(), w.data(), bytes) == 0)
         return CS_OK;
     // pageable source: the runtime stages it before returning, so `w` may die here
-    CS_HIP(ctx, hipMemcpyAsync(ctx->d_w, w.data(), bytes, hipMemcpyHostToDevice, stream));
-    ctx->w_cached.assign((unsigned char*)w.data(), (unsigned char*)w.data() + bytes);
+    CS_HIP(ctx, hipMemcpyAsync(ctx->d_w[slot], w.data(), bytes, hipMemcpyHostToDevice, stream));
+    ctx->w_cached[slot].assign((unsigned char*)w.data(), (unsigned char*)w.data() + bytes);
     return CS_OK;
 }
 
@@ -415,7 +427,7 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.miss_col = p->d_miss_col;
     A.mask = A.sig;
     A.mask.ptr = (void*)p->d_mask;
-    A.w = reinterpret_cast<const TC*>(ctx->d_w);
+    A.w = reinterpret_cast<const TC*>(ctx->d_w[sizeof(TC) == 8 ? 1 : 0]);
     A.ks.n = (TC)st.n;
     A.ks.inv_n = (TC)(1.0 / st.n);
     A.ks.kmean = (TC)st.kmean;
@@ -459,8 +471,13 @@ int cs_ctx_create(int device, cs_ctx** out)
 void cs_ctx_destroy(cs_ctx* ctx)
 {
     if (!ctx) return;
-    if (ctx->d_w) (void)hipFree(ctx->d_w);
+    (void)hipSetDevice(ctx->device);
+    for (int slot = 0; slot < 2; ++slot)
+        if (ctx->d_w[slot]) (void)hipFree(ctx->d_w[slot]);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_map) (void)hipFree(ctx->d_map);
+    if (ctx->d_pool) (void)hipFree(ctx->d_pool);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     delete ctx;
 }
 
@@ -627,7 +644,7 @@ int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, i
         A.out_is_f64 = out->dtype == CS_F64;                              \
         A.ms = ms; A.ns = ns; A.km = km; A.kn = kn;                       \
         A.max_dist = -1;                                                  \
-        A.w = reinterpret_cast<const TC*>(ctx->d_w);                      \
+        A.w = reinterpret_cast<const TC*>(ctx->d_w[sizeof(TC) == 8 ? 1 : 0]); \
         A.ks.n = (TC)kk; A.ks.thr = (TC)threshold;                        \
         A.xcorr_only = 1;                                                 \
         return launch_corr<TC>(ctx, A, stream, false);                    \
@@ -678,6 +695,11 @@ static int csr_view(cs_ctx* ctx, const cs_csr* m, cs::CsrView* v)
     v->n_cols = m->n_cols;
     v->nnz = m->nnz;
     v->indptr = (const long long*)m->d_indptr;
+    v->row_end = m->d_row_end ? (const long long*)m->d_row_end : (const long long*)m->d_indptr + 1;
+    v->col0 = m->col0;
+    v->row_w = m->d_row_weight;
+    v->col_w = m->d_row_weight ? m->d_col_weight : nullptr;
+    if (m->d_row_weight && !m->d_col_weight) return fail(ctx, CS_ERR_INVALID, "row weights without column weights");
     v->indices = m->d_indices;
     v->data = m->d_data;
     v->is_f64 = m->dtype == CS_F64;
@@ -725,6 +747,192 @@ int cs_csr_to_band(cs_ctx* ctx, void* stream_, const cs_csr* mat, const double* 
     rc = cs::launch_csr_to_band(v, d_law, n_law, max_val, view_of(band), band->dtype, ctx->n_cu,
                                 (hipStream_t)stream_);
     if (rc) return fail(ctx, CS_ERR_HIP, "csr_to_band launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+
+int cs_csr_band_extent(cs_ctx* ctx, void* stream_, const cs_csr* mat, int32_t lo_diag, int32_t hi_diag,
+                       int64_t* d_begin, int64_t* d_end)
+{
+    CS_ENTER(ctx);
+    cs::CsrView v;
+    int rc = csr_view(ctx, mat, &v);
+    if (rc) return rc;
+    if (v.n_rows > 0 && (!d_begin || !d_end)) return fail(ctx, CS_ERR_INVALID, "null extent buffers");
+    rc = cs::launch_csr_band_extent(v, lo_diag, hi_diag, (long long*)d_begin, (long long*)d_end, (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "band extent launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_distance_law_finish(cs_ctx* ctx, void* stream_, const double* d_sum, const int64_t* d_cnt, int32_t n_diags,
+                           double* d_law)
+{
+    CS_ENTER(ctx);
+    if (n_diags < 0 || (n_diags > 0 && (!d_sum || !d_cnt || !d_law))) return fail(ctx, CS_ERR_INVALID, "bad law buffers");
+    int rc = cs::launch_law_finish(d_sum, (const long long*)d_cnt, n_diags, d_law, (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "law finish launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr)
+{
+    if (!h_ptr) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
+    CS_HIP(ctx, hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return CS_OK;
+}
+
+int cs_host_free(cs_ctx* ctx, void* h_ptr)
+{
+    CS_ENTER(ctx);
+    if (h_ptr) CS_HIP(ctx, hipHostFree(h_ptr));
+    return CS_OK;
+}
+
+// grow-only device scratch; growing waits for the device, since queued work may still use the old block
+static int ensure_scratch(cs_ctx* ctx, void** buf, size_t* have, size_t need)
+{
+    if (need <= *have) return CS_OK;
+    if (*buf) {
+        CS_HIP(ctx, hipDeviceSynchronize());
+        CS_HIP(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    const size_t want = need + need / 4;
+    CS_HIP(ctx, hipMalloc(buf, want));
+    *have = want;
+    return CS_OK;
+}
+
+static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel* kernel, const cs_normxcorr2_params* p,
+                           const cs_foci_params* fp)
+{
+    if (!signal || !kernel || !p || !fp) return fail(ctx, CS_ERR_INVALID, "null argument");
+    if (p->mask_mode == CS_MASK_EXPLICIT) return fail(ctx, CS_ERR_UNSUPPORTED, "device foci need per-bin masks or none");
+    if (fp->min_size < 1) return fail(ctx, CS_ERR_INVALID, "min_size must be >= 1");
+    if (!ctx->h_counts) CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault));
+    return CS_OK;
+}
+
+int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                   const cs_normxcorr2_params* p, const cs_foci_params* fp, cs_focus* h_foci, int64_t cap,
+                   int64_t* n_foci, double* h_windows)
+{
+    CS_ENTER(ctx);
+    static_assert(sizeof(cs_focus) == sizeof(cs::FocusRec), "record layouts must agree");
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_foci_args(ctx, signal, kernel, p, fp);
+    if (rc) return rc;
+    if (!n_foci || cap < 0 || (cap > 0 && !h_foci)) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
+    *n_foci = 0;
+    const int kk = kernel->km * kernel->kn;
+    // ---- coefficient map in context-owned scratch, with the signal's layout
+    const bool f64 = p->compute_dtype == CS_F64;
+    cs_matrix map;
+    map.dtype = f64 ? CS_F64 : CS_F32;
+    map.layout = signal->layout;
+    if (signal->layout == CS_LAYOUT_BAND) {
+        if (fp->hi_diag < fp->lo_diag) return fail(ctx, CS_ERR_INVALID, "empty diagonal range");
+        map.band_lo = fp->lo_diag;
+        map.band_w = fp->hi_diag - fp->lo_diag + 1;
+        map.ld = ((int64_t)map.band_w + 63) / 64 * 64;
+    } else {
+        map.band_lo = map.band_w = 0;
+        map.ld = ((int64_t)p->ns + 15) / 16 * 16;
+    }
+    const size_t map_bytes = (size_t)p->ms * (size_t)map.ld * (f64 ? 8 : 4);
+    rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
+    if (rc) return rc;
+    map.d_ptr = ctx->d_map;
+    rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
+    if (rc) return rc;
+    // ---- candidates: thresholded compaction (with the re-scoring margin on float32 maps)
+    const double thr = f64 ? fp->pearson : fp->pearson - fp->rescore_margin;
+    long long n_cand = 0;
+    size_t c_cap = std::max<size_t>(1 << 16, (size_t)p->ms * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off_cols = 0, off_vals = 0, off_cnt = 0, off_win = 0, off_foci = 0;
+    const size_t win_pat = fp->want_windows ? (size_t)std::max<int64_t>(cap, 1) : 0;
+    while (true) {
+        if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
+        off_cols = al(4 * c_cap);
+        off_vals = off_cols + al(4 * c_cap);
+        off_cnt = off_vals + al(8 * c_cap);
+        off_win = off_cnt + 256;
+        off_foci = off_win + al(8 * win_pat * kk);
+        rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_foci + cs::foci_scratch_bytes((long long)c_cap));
+        if (rc) return rc;
+        char* pool = (char*)ctx->d_pool;
+        long long* d_cnt = (long long*)(pool + off_cnt);
+        CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        rc = cs::launch_compact_ge(view_of(&map), f64, p->ms, p->ns, thr, fp->lo_diag, fp->hi_diag, (int*)pool,
+                                   (int*)(pool + off_cols), (double*)(pool + off_vals), (long long)c_cap, d_cnt, ctx->n_cu,
+                                   stream);
+        if (rc) return fail(ctx, CS_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)rc));
+        CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        n_cand = ctx->h_counts[0];
+        if ((size_t)n_cand <= c_cap) break;
+        c_cap = (size_t)n_cand + (size_t)n_cand / 8;
+    }
+    if (n_cand == 0) return CS_OK;
+    // ---- foci
+    cs::CorrArgs<double> A64;
+    rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
+    if (rc) return rc;
+    char* pool = (char*)ctx->d_pool;
+    long long* d_cnt = (long long*)(pool + off_cnt);
+    double* d_win = fp->want_windows ? (double*)(pool + off_win) : nullptr;
+    cs::FocusRec* d_rec = nullptr;
+    rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + off_cols), n_cand, fp->pearson, fp->min_size,
+                          fp->diag_only, fp->inter, pool + off_foci, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts + 1, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream));
+    CS_HIP(ctx, hipStreamSynchronize(stream));
+    const long long n = ctx->h_counts[1];
+    *n_foci = n;
+    if (n > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", n, (long long)cap);
+    if (n > 0) {
+        CS_HIP(ctx, hipMemcpyAsync(h_foci, d_rec, sizeof(cs_focus) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        if (d_win && h_windows)
+            CS_HIP(ctx, hipMemcpyAsync(h_windows, d_win, 8 * (size_t)n * kk, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return CS_OK;
+}
+
+int cs_quantify_pixels(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                       const cs_normxcorr2_params* p, const cs_foci_params* fp, const int32_t* h_rows,
+                       const int32_t* h_cols, int64_t n, cs_focus* h_out, double* h_windows)
+{
+    CS_ENTER(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_foci_args(ctx, signal, kernel, p, fp);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!h_rows || !h_cols || !h_out))) return fail(ctx, CS_ERR_INVALID, "bad pixel list");
+    if (n == 0) return CS_OK;
+    const int kk = kernel->km * kernel->kn;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t un = (size_t)n;
+    const size_t off_cols = al(4 * un), off_score = off_cols + al(4 * un), off_nobs = off_score + al(8 * un),
+                 off_rec = off_nobs + al(8 * un), off_win = off_rec + al(sizeof(cs::FocusRec) * un),
+                 total = off_win + (fp->want_windows ? al(8 * un * kk) : 0);
+    rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, total);
+    if (rc) return rc;
+    char* pool = (char*)ctx->d_pool;
+    CS_HIP(ctx, hipMemcpyAsync(pool, h_rows, 4 * un, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_cols, h_cols, 4 * un, hipMemcpyHostToDevice, stream));
+    cs::CorrArgs<double> A64;
+    rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
+    if (rc) return rc;
+    double* d_win = fp->want_windows ? (double*)(pool + off_win) : nullptr;
+    rc = cs::enqueue_quantify(A64, (const int*)pool, (const int*)(pool + off_cols), n, fp->inter, (double*)(pool + off_score),
+                              (double*)(pool + off_nobs), (cs::FocusRec*)(pool + off_rec), d_win, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "quantify kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipMemcpyAsync(h_out, pool + off_rec, sizeof(cs_focus) * un, hipMemcpyDeviceToHost, stream));
+    if (d_win && h_windows) CS_HIP(ctx, hipMemcpyAsync(h_windows, d_win, 8 * un * kk, hipMemcpyDeviceToHost, stream));
+    CS_HIP(ctx, hipStreamSynchronize(stream));
     return CS_OK;
 }
 

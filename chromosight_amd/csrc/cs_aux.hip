@@ -37,13 +37,13 @@ __global__ __launch_bounds__(256) void distance_law_kernel(CsrView M, const uint
     const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
     for (int row = r_begin + wv; row < r_end; row += 4) {
         if (det && !det[row]) continue;
-        const long long b = M.indptr[row], e = M.indptr[row + 1];
+        const long long b = M.indptr[row], e = M.row_end[row];
         for (long long k = b + lane; k < e; k += 64) {
-            const int col = M.indices[k];
+            const int col = M.indices[k] - M.col0;
             const int d = col - row;
-            if (d < 0 || d >= n_diags) continue;
+            if (d < 0 || d >= n_diags || col >= M.n_cols) continue;
             if (det && !det[col]) continue;
-            const double v = (double)data[k];
+            const double v = csr_value(M, data, k, row, col);
             if (!(v > 0.0)) continue;  // also drops NaN (preprocessing.py:188)
             if (USE_LDS) {
                 atomicAdd(&l_sum[d], v);
@@ -127,10 +127,10 @@ __global__ __launch_bounds__(256) void detrend_csr_kernel(CsrView M, const doubl
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
     for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
-        const long long b = M.indptr[row], e = M.indptr[row + 1];
+        const long long b = M.indptr[row], e = M.row_end[row];
         for (long long k = b + lane; k < e; k += 64) {
-            const int d = M.indices[k] - row;
-            out[k] = (TV)detrend_value((double)data[k], d, law, n_law, max_val);
+            const int col = M.indices[k] - M.col0;
+            out[k] = (TV)detrend_value(csr_value(M, data, k, row, col), col - row, law, n_law, max_val);
         }
     }
 }
@@ -162,12 +162,13 @@ __global__ __launch_bounds__(256) void csr_to_band_kernel(CsrView M, const doubl
     const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
     TB* __restrict__ dst = reinterpret_cast<TB*>(band.ptr);
     for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
-        const long long b = M.indptr[row], e = M.indptr[row + 1];
+        const long long b = M.indptr[row], e = M.row_end[row];
         for (long long k = b + lane; k < e; k += 64) {
-            const int col = M.indices[k];
+            const int col = M.indices[k] - M.col0;
+            if (col < 0 || col >= M.n_cols) continue;
             const long long off = mat_offset(band, row, col);
             if (off < 0) continue;
-            double v = (double)data[k];
+            double v = csr_value(M, data, k, row, col);
             if (law) v = detrend_value(v, col - row, law, n_law, max_val);
             if (v != v) v = 0.0;
             if constexpr (sizeof(TB) == 1) dst[off] = (v != 0.0) ? 1 : 0;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void compact_ge_kernel(MatView corr, int ms, i
             if (j >= 0 && j < ns) {
                 const int d = j - i;
                 v = (double)src[(long long)i * corr.ld + x];
-                hit = (d >= lo_diag) && (d <= hi_diag) && (v >= threshold);
+                hit = (d >= lo_diag) && (d <= hi_diag) && (v >= threshold) && (v != 0.0);
             }
         }
         const unsigned long long ballot = __ballot(hit);
@@ -283,11 +284,12 @@ __device__ __forceinline__ double wave_sum(double v)
 __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double> A, const int* __restrict__ rows,
                                                           const int* __restrict__ cols, long long n_px,
                                                           double* __restrict__ out_corr,
-                                                          double* __restrict__ out_nobs)
+                                                          double* __restrict__ out_nobs,
+                                                          const long long* __restrict__ n_ptr)
 {
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (t >= n_px) return;
+    if (t >= n_px || (n_ptr && t >= *n_ptr)) return;
     const int oi = rows[t], oj = cols[t];
     double r = 0.0, nobs = A.ks.n;
     const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
@@ -326,12 +328,67 @@ __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double>
 }
 
 int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* cols, long long n_px,
-                       double* out_corr, double* out_nobs, hipStream_t stream)
+                       double* out_corr, double* out_nobs, hipStream_t stream, const long long* n_ptr)
 {
     if (n_px == 0) return 0;
     const long long blocks = (n_px + 3) / 4;              // 4 waves = 4 pixels per block
     hipLaunchKernelGGL(rescore_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, rows, cols, n_px, out_corr,
-                       out_nobs);
+                       out_nobs, n_ptr);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// view helpers: per-row entry range of a diagonal band of a (sub-)matrix, and the finished law
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_band_extent_kernel(CsrView M, int lo_diag, int hi_diag,
+                                                              long long* __restrict__ begin, long long* __restrict__ end)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M.n_rows) return;
+    const long long b = M.indptr[row], e = M.row_end[row];
+    // first entry with column >= c_lo, first entry with column > c_hi (columns sorted in a row)
+    long long c_lo = (long long)row + lo_diag, c_hi = (long long)row + hi_diag;
+    if (c_lo < 0) c_lo = 0;
+    if (c_hi > M.n_cols - 1) c_hi = M.n_cols - 1;
+    c_lo += M.col0;
+    c_hi += M.col0;
+    long long lo = b, hi = e;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (M.indices[mid] < c_lo) lo = mid + 1;
+        else hi = mid;
+    }
+    const long long first = lo;
+    hi = e;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (M.indices[mid] <= c_hi) lo = mid + 1;
+        else hi = mid;
+    }
+    begin[row] = first;
+    end[row] = lo < first ? first : lo;
+}
+
+int launch_csr_band_extent(const CsrView& M, int lo_diag, int hi_diag, long long* begin, long long* end,
+                           hipStream_t stream)
+{
+    if (M.n_rows == 0) return 0;
+    hipLaunchKernelGGL(csr_band_extent_kernel, dim3((M.n_rows + 255) / 256), dim3(256), 0, stream, M, lo_diag, hi_diag,
+                       begin, end);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void law_finish_kernel(const double* __restrict__ sum, const long long* __restrict__ cnt,
+                                                         int n, double* __restrict__ law)
+{
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d < n) law[d] = cnt[d] > 0 ? sum[d] / (double)cnt[d] : 0.0;
+}
+
+int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(law_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, cnt, n, law);
     return (int)hipGetLastError();
 }
 

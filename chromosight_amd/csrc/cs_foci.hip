@@ -1,0 +1,395 @@
+// cs_foci.hip -- the callers of the correlation on the device: focus picking and the window
+// statistics of the validation step, so that `detect` returns a few records per sub-matrix instead
+// of a coefficient map.
+//
+//   reference                                              here
+//   detection.py:387-456  pick_foci                        run_detect_foci (host orchestration below)
+//   detection.py:459-554  label_foci (4-way adjacency)     link_kernel: union-find over the sorted
+//                                                          candidate list (right neighbour = next
+//                                                          entry, lower neighbour = binary search)
+//   detection.py:557-592  filter_foci                      focus_stats_kernel + flag_roots_kernel
+//   detection.py:438-453  per-focus arg-max (Python loop)  focus_stats / focus_argbest kernels
+//   detection.py:18-155   validate_patterns (Python loop)  window_stats_kernel, one wave per pattern
+//
+// Candidate lists are small next to the map (10^3..10^6 pixels), so these kernels are latency
+// bound; what matters is that nothing per-candidate runs on the host and that the stages need no
+// host round trip between them (counts are read from device memory by the next kernel).
+#include <hipcub/hipcub.hpp>
+
+#include <climits>
+
+#include "cs_device.h"
+#include "cs_launch_aux.h"
+
+namespace cs {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+// ---- candidate keys ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void make_keys_kernel(const int* __restrict__ rows, const int* __restrict__ cols,
+                                                             long long n, int ns, long long* __restrict__ keys)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t < n) keys[t] = (long long)rows[t] * ns + cols[t];
+}
+
+__global__ __launch_bounds__(kThreads) void decode_keys_kernel(const long long* __restrict__ keys, long long n, int ns,
+                                                               int* __restrict__ rows, int* __restrict__ cols)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t < n) {
+        const long long k = keys[t];
+        rows[t] = (int)(k / ns);
+        cols[t] = (int)(k - (k / ns) * ns);
+    }
+}
+
+// candidates that pass the exact threshold: value >= pearson and != 0 (detection.py:417-421)
+__global__ __launch_bounds__(kThreads) void flag_keep_kernel(const double* __restrict__ vals, long long n, double pearson,
+                                                             int* __restrict__ flag)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t < n) flag[t] = (vals[t] >= pearson && vals[t] != 0.0) ? 1 : 0;
+}
+
+// stable compaction by the exclusive scan of the flags; the last thread publishes the count
+__global__ __launch_bounds__(kThreads) void scatter_keep_kernel(const long long* __restrict__ keys,
+                                                                const double* __restrict__ vals,
+                                                                const int* __restrict__ flag, const int* __restrict__ pos,
+                                                                long long n, long long* __restrict__ keys2,
+                                                                double* __restrict__ vals2, int* __restrict__ n_kept)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n) return;
+    if (flag[t]) {
+        keys2[pos[t]] = keys[t];
+        vals2[pos[t]] = vals[t];
+    }
+    if (t == n - 1) *n_kept = pos[t] + flag[t];
+}
+
+// ---- union-find over the candidate list (indices = row-major rank of the pixel) -----------------
+__device__ __forceinline__ int uf_load(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+
+__device__ __forceinline__ int uf_find(int* parent, int x)
+{
+    int p = uf_load(parent + x);
+    while (p != x) {
+        const int gp = uf_load(parent + p);
+        if (gp != p) __atomic_store_n(parent + x, gp, __ATOMIC_RELAXED);   // path halving (benign race)
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
+// the larger root is hooked under the smaller one, so the root of a focus is its first pixel in
+// row-major order -- the reference numbers foci in that order (label_foci)
+__device__ __forceinline__ void uf_union(int* parent, int a, int b)
+{
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(parent + a, a, b) == a) return;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void init_focus_kernel(const int* __restrict__ n_ptr, int* __restrict__ parent,
+                                                              int* __restrict__ size, unsigned long long* __restrict__ best_val,
+                                                              int* __restrict__ best_idx, long long cap)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t < cap && t < *n_ptr) {
+        parent[t] = (int)t;
+        size[t] = 0;
+        best_val[t] = 0ull;
+        best_idx[t] = INT_MAX;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void link_kernel(const long long* __restrict__ keys, const int* __restrict__ n_ptr,
+                                                        int ns, int* __restrict__ parent)
+{
+    const int n = *n_ptr;
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n) return;
+    const long long key = keys[t];
+    const int col = (int)(key % ns);
+    // right neighbour: the next candidate, if it is the next pixel of the same row
+    if (t + 1 < n && col + 1 < ns && keys[t + 1] == key + 1) uf_union(parent, (int)t, (int)t + 1);
+    // lower neighbour: the candidate with key + ns, if any
+    long long lo = t + 1, hi = n;
+    const long long want = key + ns;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo < n && keys[lo] == want) uf_union(parent, (int)t, (int)lo);
+}
+
+__global__ __launch_bounds__(kThreads) void flatten_kernel(const int* __restrict__ n_ptr, int* __restrict__ parent)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t < *n_ptr) parent[t] = uf_find(parent, (int)t);
+}
+
+// order-preserving map of a double onto unsigned integers (for atomicMax)
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(kThreads) void focus_stats_kernel(const int* __restrict__ n_ptr, const int* __restrict__ parent,
+                                                               const double* __restrict__ vals, int* __restrict__ size,
+                                                               unsigned long long* __restrict__ best_val)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= *n_ptr) return;
+    const int r = parent[t];
+    atomicAdd(size + r, 1);
+    atomicMax(best_val + r, order_key(vals[t]));
+}
+
+// first pixel (row-major) holding the focus' maximum: np.argmax over the focus' pixels in
+// coordinate order (detection.py:446-449)
+__global__ __launch_bounds__(kThreads) void focus_argbest_kernel(const int* __restrict__ n_ptr, const int* __restrict__ parent,
+                                                                 const double* __restrict__ vals,
+                                                                 const unsigned long long* __restrict__ best_val,
+                                                                 int* __restrict__ best_idx)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= *n_ptr) return;
+    const int r = parent[t];
+    if (order_key(vals[t]) == best_val[r]) atomicMin(best_idx + r, (int)t);
+}
+
+__global__ __launch_bounds__(kThreads) void flag_roots_kernel(const int* __restrict__ n_ptr, const int* __restrict__ parent,
+                                                              const int* __restrict__ size, int min_size, int* __restrict__ flag,
+                                                              long long cap)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= cap) return;
+    flag[t] = (t < *n_ptr && parent[t] == (int)t && size[t] >= min_size) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void emit_foci_kernel(const int* __restrict__ n_ptr, const int* __restrict__ flag,
+                                                             const int* __restrict__ pos, const int* __restrict__ best_idx,
+                                                             const int* __restrict__ size, const long long* __restrict__ keys,
+                                                             int ns, int diag_only, int* __restrict__ out_rows,
+                                                             int* __restrict__ out_cols, int* __restrict__ out_size,
+                                                             long long cap, long long* __restrict__ n_foci)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= cap) return;
+    const int n = *n_ptr;
+    if (t < n && flag[t]) {
+        const long long key = keys[best_idx[t]];
+        int row = (int)(key / ns);
+        const int col = (int)(key - (long long)row * ns);
+        if (diag_only) row = col;
+        out_rows[pos[t]] = row;
+        out_cols[pos[t]] = col;
+        out_size[pos[t]] = size[t];
+    }
+    if (t == cap - 1) *n_foci = pos[t] + flag[t];     // flags are 0 beyond n, so this is the total
+}
+
+// ---- window statistics of validate_patterns, one wave per pattern --------------------------------
+// The map pattern_detector validates on (detection.py:287-310) is never built: the contact map framed
+// by (kw rows, kh columns) of zeros when full, NaN on the max(km, kn) first sub-diagonals of intra
+// maps, NaN on every row / column that is not a detectable bin; coordinates shifted by (kh, kw).
+__global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<double> A, int inter,
+                                                                const int* __restrict__ rows, const int* __restrict__ cols,
+                                                                const int* __restrict__ focus_size,
+                                                                const double* __restrict__ score,
+                                                                const double* __restrict__ nobs,
+                                                                const long long* __restrict__ n_ptr, long long n_fixed,
+                                                                FocusRec* __restrict__ rec, double* __restrict__ windows,
+                                                                long long win_cap)
+{
+    const long long n = n_ptr ? *n_ptr : n_fixed;
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int km = A.km, kn = A.kn, kk = km * kn;
+    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+    const int half_h = km / 2 + 1, half_w = kn / 2 + 1;
+    const int pad_r = A.full ? kw : 0, pad_c = A.full ? kh : 0;     // zero_pad_sparse(mat, kh, kw)
+    const int sh_r = A.full ? kh : 0, sh_c = A.full ? kw : 0;       // coords += (kh, kw)
+    const int H = A.ms + 2 * pad_r, W = A.ns + 2 * pad_c;
+    const int big_k = inter ? 0 : max(km, kn);
+    const int row = rows[t], col = cols[t];
+    const int p1 = row + sh_r, p2 = col + sh_c;
+    const int high = p1 - half_h + 1, low = p1 + half_h;
+    const int left = p2 - half_w + 1, right = p2 + half_w;
+    const bool inside = (high >= 0) & (low < H) & (left >= 0) & (right < W);   // strict upper bounds (:99-104)
+    int n_zero = 0, n_miss = 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int e = lane; e < kk; e += 64) {
+        double v = nan;
+        if (inside) {
+            const int a = e / kn, b = e - a * kn;
+            const int rr = high + a, cc = left + b;
+            const int src_r = rr - pad_r, src_c = cc - pad_c;
+            v = load_signal(A, src_r, src_c);                     // 0 outside the matrix / stored band
+            const int d = cc - rr;
+            bool miss = (d <= -1) & (d >= -big_k);
+            // framed row rr is detectable iff rr - sh_r is a detectable bin
+            const int br = rr - sh_r, bc = cc - sh_c;
+            miss |= (br < 0) | (br >= A.ms) | (bc < 0) | (bc >= A.ns);
+            if (!miss && A.miss_row) miss = (A.miss_row[br] != 0) | (A.miss_col[bc] != 0);
+            if (miss) v = nan;
+            const bool fin = (v - v) == 0.0;                     // finite
+            n_zero += (fin && v == 0.0) ? 1 : 0;
+            n_miss += fin ? 0 : 1;
+        }
+        if (windows && t < win_cap) windows[t * kk + e] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_zero += __shfl_xor(n_zero, off, 64);
+        n_miss += __shfl_xor(n_miss, off, 64);
+    }
+    if (lane == 0) {
+        FocusRec r;
+        r.bin1 = row;
+        r.bin2 = col;
+        r.inside = inside ? 1 : 0;
+        r.n_zero = n_zero;
+        r.n_missing = n_miss;
+        r.focus_size = focus_size ? focus_size[t] : 0;
+        r.score = score[t];
+        r.n_obs = nobs[t];
+        rec[t] = r;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side
+// ================================================================================================
+size_t foci_scratch_bytes(long long n_cand)
+{
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)n_cand);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n_cand);
+    const size_t tmp = std::max(sort_tmp, scan_tmp);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n = (size_t)std::max<long long>(n_cand, 1);
+    // keys, keys sorted, keys kept (8 B) + vals, vals kept, best_val (8 B) + rows, cols, flag, pos, parent,
+    // size, best_idx, out rows / cols / size (4 B) + scores, nobs of the foci (8 B) + records + counters
+    return al(tmp) + 3 * al(8 * n) + 3 * al(8 * n) + 10 * al(4 * n) + 2 * al(8 * n) + al(sizeof(FocusRec) * n) + 1024;
+}
+
+namespace {
+struct Bump {
+    char* p;
+    template <typename T>
+    T* take(size_t n)
+    {
+        T* out = reinterpret_cast<T*>(p);
+        p += (n * sizeof(T) + 255) & ~(size_t)255;
+        return out;
+    }
+};
+}  // namespace
+
+// Candidate pixels (rows, cols; n_cand of them, any order) -> foci records.  `scratch` holds
+// foci_scratch_bytes(n_cand) bytes.  Everything is enqueued on `stream`; the host reads *h_n_foci
+// (pinned) after the stream has drained.  Returns a hipError_t as int.
+int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,
+                 int min_size, int diag_only, int inter, void* scratch, FocusRec** d_rec_out, double* d_windows,
+                 long long win_cap, long long* d_n_foci, hipStream_t stream)
+{
+    const int ns = A64.ns;
+    Bump b{(char*)scratch};
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)n_cand);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n_cand);
+    size_t tmp_bytes = std::max(sort_tmp, scan_tmp);
+    void* tmp = b.take<char>(tmp_bytes);
+    const size_t n = (size_t)n_cand;
+    long long* keys = b.take<long long>(n);
+    long long* keys_s = b.take<long long>(n);
+    long long* keys_k = b.take<long long>(n);
+    double* vals = b.take<double>(n);
+    double* vals_k = b.take<double>(n);
+    unsigned long long* best_val = b.take<unsigned long long>(n);
+    int* rows = b.take<int>(n);
+    int* cols = b.take<int>(n);
+    int* flag = b.take<int>(n);
+    int* pos = b.take<int>(n);
+    int* parent = b.take<int>(n);
+    int* size = b.take<int>(n);
+    int* best_idx = b.take<int>(n);
+    int* f_rows = b.take<int>(n);
+    int* f_cols = b.take<int>(n);
+    int* f_size = b.take<int>(n);
+    double* f_score = b.take<double>(n);
+    double* f_nobs = b.take<double>(n);
+    FocusRec* rec = b.take<FocusRec>(n);
+    int* n_kept = b.take<int>(64);
+    *d_rec_out = rec;
+    const unsigned g = blocks_for(n_cand);
+
+    // row-major order of the candidates
+    hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys);
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, 64, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
+    // exact coefficients, exact threshold
+    int rc = launch_rescore_f64(A64, rows, cols, n_cand, vals, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flag_keep_kernel, dim3(g), dim3(kThreads), 0, stream, vals, n_cand, pearson, flag);
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flag, pos, (int)n_cand, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(scatter_keep_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, vals, flag, pos, n_cand, keys_k,
+                       vals_k, n_kept);
+    // 4-connected foci of the kept pixels
+    hipLaunchKernelGGL(init_focus_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, parent, size, best_val, best_idx, n_cand);
+    hipLaunchKernelGGL(link_kernel, dim3(g), dim3(kThreads), 0, stream, keys_k, n_kept, ns, parent);
+    hipLaunchKernelGGL(flatten_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, parent);
+    hipLaunchKernelGGL(focus_stats_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, parent, vals_k, size, best_val);
+    hipLaunchKernelGGL(focus_argbest_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, parent, vals_k, best_val, best_idx);
+    hipLaunchKernelGGL(flag_roots_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, parent, size, min_size, flag, n_cand);
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flag, pos, (int)n_cand, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(emit_foci_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, flag, pos, best_idx, size, keys_k, ns,
+                       diag_only, f_rows, f_cols, f_size, n_cand, d_n_foci);
+    // score / n_obs at the final coordinates (they move for 1-D patterns), window statistics.
+    // The number of foci stays on the device: launched for the worst case (n_cand / min_size foci),
+    // surplus waves exit on the device-side count.
+    const long long max_foci = std::max<long long>(1, n_cand / std::max(min_size, 1));
+    rc = launch_rescore_f64(A64, f_rows, f_cols, max_foci, f_score, f_nobs, stream, d_n_foci);
+    if (rc) return rc;
+    hipLaunchKernelGGL(window_stats_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, A64, inter,
+                       f_rows, f_cols, f_size, f_score, f_nobs, d_n_foci, 0ll, rec, d_windows, win_cap);
+    return (int)hipGetLastError();
+}
+
+// quantify mode: records at n given pixels (device arrays)
+int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n, int inter,
+                     double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    int rc = launch_rescore_f64(A64, d_rows, d_cols, n, d_score, d_nobs, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(window_stats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kThreads), 0, stream, A64, inter, d_rows,
+                       d_cols, (const int*)nullptr, d_score, d_nobs, (const long long*)nullptr, n, d_rec, d_windows, n);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cs

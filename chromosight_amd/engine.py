@@ -9,8 +9,8 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
-                   CsCsr, CsKernel, CsMatrix, CsNormxcorr2Params, band_matrix, dense_matrix)
+from ._lib import (CS_F32, CS_F64, FOCUS_DTYPE, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
+                   CsCsr, CsFociParams, CsKernel, CsMatrix, CsNormxcorr2Params, band_matrix, dense_matrix)
 
 XCORR_THRESHOLD = 1e-4   # reference detection.py:595 (default `threshold` of xcorr2)
 DENOM_EPS = 1e-10        # reference detection.py:1010, 1088
@@ -108,6 +108,77 @@ def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist
     dev._check(dev.lib.cs_rescore_f64(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params),
                                       d_rows.ptr, d_cols.ptr, n, d_r.ptr, d_n.ptr))
     return d_r.download(stream), d_n.download(stream)
+
+
+# margin below the Pearson threshold within which float32 scores are re-evaluated in float64
+RESCORE_MARGIN = 2e-3
+
+
+def _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, mask, missing_tol, code):
+    return CsNormxcorr2Params(
+        int(shape[0]), int(shape[1]), int(bool(full)), int(bool(sym_upper)),
+        -1 if max_dist is None else int(max_dist), int(mask_mode),
+        miss_row.ptr if miss_row is not None else None,
+        miss_col.ptr if miss_col is not None else None,
+        mask.ptr if mask is not None else None,
+        min_present((kspec.km, kspec.kn), missing_tol), code, XCORR_THRESHOLD, DENOM_EPS)
+
+
+def _host_buffers(dev, cap, kk, want_windows):
+    """Pinned result buffers of a device (grow-only, reused by every call)."""
+    have = getattr(dev, "_foci_host", None)
+    if have is None or have[0].shape[0] < cap or (want_windows and have[1].shape[1] < kk):
+        cap = max(cap, 1024)
+        rec = dev.pinned_empty(cap, FOCUS_DTYPE)
+        win = dev.pinned_empty((cap, max(kk, 289)), np.float64)
+        have = dev._foci_host = (rec, win)
+    return have
+
+
+def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter, diag_only, full, sym_upper, max_dist,
+                    mask_mode=MASK_NONE, miss_row=None, miss_col=None, missing_tol=0.75, precision=None,
+                    want_windows=True, min_size=2, stream=None):
+    """detect mode of one sub-matrix x one template on the device (cs_detect_foci): records of the
+    foci in the reference's order (numpy structured array, _lib.FOCUS_DTYPE) and their windows."""
+    params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, None, missing_tol,
+                          compute_code(precision))
+    fp = CsFociParams(float(pearson), RESCORE_MARGIN, int(min_size), int(bool(diag_only)), int(lo_diag), int(hi_diag),
+                      int(bool(inter)), int(bool(want_windows)))
+    kk = kspec.km * kspec.kn
+    cap = 4096
+    while True:
+        rec, win = _host_buffers(dev, cap, kk, want_windows)
+        cap = rec.shape[0]
+        n = C.c_int64(0)
+        rc = dev.lib.cs_detect_foci(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params), C.byref(fp),
+                                    rec.ctypes.data, cap, C.byref(n), win.ctypes.data if want_windows else None)
+        if rc == -4 and n.value > cap:          # CS_ERR_OVERFLOW: more foci than records
+            cap = int(n.value) + int(n.value) // 4
+            continue
+        dev._check(rc)
+        break
+    k = int(n.value)
+    windows = None
+    if want_windows:
+        windows = win.reshape(-1)[:k * kk].reshape(k, kspec.km, kspec.kn).copy()
+    return rec[:k].copy(), windows
+
+
+def run_quantify_pixels(dev, sig, shape, kspec, rows, cols, *, inter, full, sym_upper, max_dist, mask_mode=MASK_NONE,
+                        miss_row=None, miss_col=None, missing_tol=0.75, want_windows=True, stream=None):
+    """quantify mode (cs_quantify_pixels): one record (and window) per given pixel, in input order."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    k = rows.size
+    params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, None, missing_tol, CS_F64)
+    fp = CsFociParams(0.0, 0.0, 1, 0, 0, 0, int(bool(inter)), int(bool(want_windows)))
+    kk = kspec.km * kspec.kn
+    rec, win = _host_buffers(dev, max(k, 1), kk, want_windows)
+    dev._check(dev.lib.cs_quantify_pixels(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params),
+                                          C.byref(fp), rows.ctypes.data, cols.ctypes.data, k, rec.ctypes.data,
+                                          win.ctypes.data if want_windows else None))
+    windows = win.reshape(-1)[:k * kk].reshape(k, kspec.km, kspec.kn).copy() if want_windows else None
+    return rec[:k].copy(), windows
 
 
 def run_compact(dev, corr, shape, threshold, lo_diag, hi_diag, stream=None, guess=1 << 16):

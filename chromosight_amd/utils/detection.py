@@ -24,8 +24,7 @@ from .. import engine
 from .._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
                     CsMatrix, get_device, np_dtype_code)
 
-# margin below the Pearson threshold within which float32 scores are re-evaluated in float64
-RESCORE_MARGIN = 2e-3
+RESCORE_MARGIN = engine.RESCORE_MARGIN
 
 
 # ============================================================================================
@@ -529,47 +528,70 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
     if not inter and max_dist is not None:
         out_range = (0, max_dist)       # diag_trim(mat_conv, max_dist), detection.py:269-270
     st = _Staged(dev, csr, (km, kn), sym_upper, full, out_diag_range=out_range)
-    mask_kw = dict(mask_mode=MASK_NONE)
+    miss_r = miss_c = None
     if full:
         miss_r = dev.to_device(preproc.missing_flags(contact_map.detectable_bins[0], ms))
         miss_c = dev.to_device(preproc.missing_flags(contact_map.detectable_bins[1], ns))
-        mask_kw = dict(mask_mode=MASK_BINS, miss_row=miss_r, miss_col=miss_c)
-    common = dict(full=full, sym_upper=sym_upper, max_dist=max_dist, missing_tol=missing_tol, **mask_kw)
-    lo_diag, hi_diag = (-(ms - 1), ns - 1) if out_range is None else out_range
-    if not inter and max_dist is None:
-        lo_diag = 0
+    return detect_on_device(dev, st.sig, (ms, ns), kspec, kernel_config, miss_r, miss_c, inter=inter,
+                            max_dist=max_dist, full=full, coords=coords)
 
-    if run_mode == "detect":
-        out_buf, out_mat = st.alloc_out(_out_dtype())
-        engine.run_normxcorr2(dev, st.sig, (ms, ns), kspec, out_mat, **common)
-        exact = engine.get_precision() == "f64"
-        thr = pearson if exact else pearson - RESCORE_MARGIN
-        rows, cols, vals = engine.run_compact(dev, out_mat, (ms, ns), thr, lo_diag, hi_diag)
-        if not exact and rows.size:
-            vals, _ = engine.run_rescore(dev, st.sig, (ms, ns), kspec, rows, cols, **common)
-        keep = (vals >= pearson) & (vals != 0)
-        rows, cols, vals = rows[keep], cols[keep], vals[keep]
-        if rows.size == 0:
-            return None, None
-        cand = sp.coo_matrix((vals, (rows, cols)), shape=(ms, ns))
-        coords, _ = pick_foci(cand, pearson)
-        if coords is None:
+
+def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, *, inter, max_dist, full,
+                     coords=None, want_windows=True):
+    """The part of pattern_detector that follows the staging of the contact map in HBM
+    (reference detection.py:240-345): correlation, foci, validation statistics -- one native call
+    (cs_detect_foci / cs_quantify_pixels) -- then the acceptance rules on the few returned records.
+
+    sig: CsMatrix of the staged (detrended) map; miss_row / miss_col: uint8 device flags of the
+    undetectable bins (None when full is False).  Returns (table, windows) or (None, None)."""
+    ms, ns = shape
+    km, kn = kspec.km, kspec.kn
+    kh, kw = (km - 1) // 2, (kn - 1) // 2
+    missing_tol = kernel_config["max_perc_undetected"] / 100
+    zero_tol = kernel_config["max_perc_zero"] / 100
+    pearson = kernel_config["pearson"]
+    sym_upper = not inter
+    diag_only = (not inter) and kernel_config["max_dist"] == 0       # 1-D patterns live on the diagonal (:311-315)
+    lo_diag, hi_diag = -(ms - 1), ns - 1
+    if not inter:
+        lo_diag = 0
+        if max_dist is not None:
+            hi_diag = max_dist
+    mask_kw = dict(mask_mode=MASK_NONE)
+    if full:
+        mask_kw = dict(mask_mode=MASK_BINS, miss_row=miss_row, miss_col=miss_col)
+    common = dict(inter=inter, full=full, sym_upper=sym_upper, max_dist=max_dist, missing_tol=missing_tol,
+                  want_windows=want_windows, **mask_kw)
+    if coords is None:
+        run_mode = "detect"
+        rec, windows = engine.run_detect_foci(dev, sig, shape, kspec, pearson=pearson, lo_diag=lo_diag, hi_diag=hi_diag,
+                                              diag_only=diag_only, **common)
+        if rec.shape[0] == 0:
             return None, None
     else:
+        run_mode = "quantify"
         coords_in = coords
-        coords = np.array(coords_in, dtype=int, copy=True)
-
-    # 1-D patterns live on the diagonal (detection.py:311-315)
-    if not inter and kernel_config["max_dist"] == 0:
-        coords[:, 0] = coords[:, 1]
-
-    # coefficient (trimmed map) and p-value (untrimmed map) at the final coordinates
-    rr, cc = coords[:, 0].astype(np.int64), coords[:, 1].astype(np.int64)
-    inside = (rr >= 0) & (rr < ms) & (cc >= 0) & (cc < ns)
-    r64, nobs = engine.run_rescore(dev, st.sig, (ms, ns), kspec, np.where(inside, rr, 0),
-                                   np.where(inside, cc, 0), **common)
-    r64 = np.where(inside, r64, 0.0)
-    in_band = inside.copy()
+        pts = np.array(coords_in, dtype=int, copy=True)
+        if diag_only:
+            pts[:, 0] = pts[:, 1]
+        rr, cc = pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64)
+        big = np.iinfo(np.int32).max // 2
+        rec, windows = engine.run_quantify_pixels(dev, sig, shape, kspec, np.clip(rr, -big, big), np.clip(cc, -big, big),
+                                                  **common)
+        # the reference shifts the caller's array in place when coords are given (:297-298)
+        if full:
+            try:
+                coords_in[:, 0] += kh
+                coords_in[:, 1] += kw
+                if diag_only:
+                    coords_in[:, 0] = coords_in[:, 1]
+            except (TypeError, ValueError, IndexError):
+                pass
+    if run_mode == "detect":
+        rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+    r64, nobs = rec["score"], rec["n_obs"]
+    # coefficient on the trimmed map (:269-270), p-value on the untrimmed one (:332-336)
+    in_band = (rr >= 0) & (rr < ms) & (cc >= 0) & (cc < ns)
     if not inter:
         d = cc - rr
         in_band &= (d >= 0) & ((d <= max_dist) if max_dist is not None else True)
@@ -577,40 +599,21 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
     n_obs = nobs if full else np.full(r64.shape, float(km * kn))
     with np.errstate(all="ignore"):
         logp = np.where(r64 != 0, cus.corr_to_pval(r64, np.where(n_obs == 0, km * kn, n_obs)), 0.0)
-
-    # window validation on the (zero padded when full) contact map with NaN sub-diagonals
-    # (detection.py:287-329); the padded map is described to _validate, not built
-    missing_rows = preproc.valid_to_missing(contact_map.detectable_bins[0], ms)
-    missing_cols = preproc.valid_to_missing(contact_map.detectable_bins[1], ns)
-    vcoords = coords.copy()
-    pad = (0, 0)
-    if full:
-        pad = (kw, kh)                           # zero_pad_sparse(mat, kh, kw): kh columns, kw rows
-        in_r = np.ones(ms + 2 * kw, dtype=bool)
-        in_c = np.ones(ns + 2 * kh, dtype=bool)
-        det_r = np.asarray(contact_map.detectable_bins[0]) + kh
-        det_c = np.asarray(contact_map.detectable_bins[1]) + kw
-        in_r[det_r[det_r < in_r.size]] = False
-        in_c[det_c[det_c < in_c.size]] = False
-        missing_rows, missing_cols = np.flatnonzero(in_r), np.flatnonzero(in_c)
-        vcoords[:, 0] += kh
-        vcoords[:, 1] += kw
-        # the reference shifts the caller's array in place when coords are given (:297-298)
-        if run_mode == "quantify":
-            try:
-                coords_in[:, 0] += kh
-                coords_in[:, 1] += kw
-                if not inter and kernel_config["max_dist"] == 0:
-                    coords_in[:, 0] = coords_in[:, 1]
-            except (TypeError, ValueError, IndexError):
-                pass
-    table, windows = _validate(vcoords, csr, conv_at, missing_rows, missing_cols, (km, kn),
-                               drop=(run_mode == "detect"), zero_tol=zero_tol, missing_tol=missing_tol,
-                               pad=pad, stripe_k=0 if inter else max(km, kn))
+    # acceptance rules of validate_patterns (:121-141) on the window statistics
+    tot = km * kn
+    n_zero, n_miss = rec["n_zero"], rec["n_missing"]
+    with np.errstate(all="ignore"):
+        prop_undetected = n_miss.astype(np.float64) / np.float64(tot)
+        prop_zero = n_zero.astype(np.float64) / (tot - n_miss).astype(np.float64)   # 0/0 -> nan -> rejected
+    ok = (rec["inside"] != 0) & (prop_undetected < missing_tol) & (prop_zero < zero_tol)
+    scores = np.where(ok, conv_at, np.nan)
+    table = pd.DataFrame({"bin1": rr, "bin2": cc, "score": scores})
+    if windows is not None:
+        windows[~ok] = np.nan
+    if run_mode == "detect":
+        table = table.loc[ok, :]
+        windows = windows[ok] if windows is not None else None
     kept = table.index.to_numpy()
-    if full:
-        table.bin1 -= kh
-        table.bin2 -= kw
     table["pvalue"] = 10 ** logp[kept] if len(kept) else None
     return table, windows
 

@@ -162,6 +162,17 @@ typedef struct {
     const int32_t* d_indices; /* nnz        */
     const void* d_data;       /* nnz values of `dtype` */
     int32_t dtype;
+    /* ---- optional view extensions; all zero / NULL = a plain CSR matrix -------------------------
+     * A whole-genome pixel table sorted by (bin1, bin2) (what a .cool stores, contacts_map.py:527
+     * create_mat reads it through cooler) IS a CSR of the genome's upper triangle.  One
+     * sub-matrix is then a view: d_indptr offset to its first row, col0 = its first column bin,
+     * per-row end offsets that stop at its last column / last kept diagonal (cs_csr_band_extent),
+     * and the ICE weights of its bins, so that balancing (count * w[bin1] * w[bin2]) happens on the
+     * fly and no per-block matrix is ever materialised. */
+    int32_t col0;                /* stored column index - col0 = column inside the block          */
+    const int64_t* d_row_end;    /* n_rows end offsets; NULL = d_indptr + 1                       */
+    const double* d_row_weight;  /* n_rows balancing weights (NaN = bin not detectable) or NULL   */
+    const double* d_col_weight;  /* n_cols weights (used only with d_row_weight)                  */
 } cs_csr;
 
 /* Per-diagonal sums and counts of the strictly positive stored values whose row and column
@@ -186,6 +197,64 @@ int cs_detrend_csr(cs_ctx* ctx, void* stream, const cs_csr* mat, const double* d
  * non-zero stored values.  Duplicated entries are not supported (canonical CSR). */
 int cs_csr_to_band(cs_ctx* ctx, void* stream, const cs_csr* mat, const double* d_law,
                    int32_t n_law, double max_val, const cs_matrix* band);
+
+/* Per-row entry ranges of the stored pixels with lo_diag <= (col - col0) - row <= hi_diag and
+ * 0 <= col - col0 < n_cols (columns sorted within a row): d_begin / d_end, n_rows int64 each, usable
+ * as d_indptr / d_row_end of a view on the same arrays.  This is diag_trim (preprocessing.py:93) and
+ * the sub-matrix slicing of contacts_map.py:531 without copying a pixel. */
+int cs_csr_band_extent(cs_ctx* ctx, void* stream, const cs_csr* mat, int32_t lo_diag, int32_t hi_diag,
+                       int64_t* d_begin, int64_t* d_end);
+
+/* law[d] = sum[d] / cnt[d], 0 where cnt[d] == 0 (the NaN of an empty diagonal, replaced by 0 as
+ * preprocessing.py:296 does before dividing).  Keeps the distance law on the device between
+ * cs_distance_law_csr and cs_csr_to_band. */
+int cs_distance_law_finish(cs_ctx* ctx, void* stream, const double* d_sum, const int64_t* d_cnt,
+                           int32_t n_diags, double* d_law);
+
+/* ---- device-side foci: detection.py:387 pick_foci + the statistics of :18 validate_patterns ---- */
+typedef struct {
+    double pearson;         /* candidate threshold: coefficient >= pearson and != 0 (detection.py:417-421) */
+    double rescore_margin;  /* float32 maps: every pixel >= pearson - margin is re-evaluated in float64
+                               before thresholding, so foci never depend on float32 rounding            */
+    int32_t min_size;       /* foci of fewer pixels are dropped (2; detection.py:557 filter_foci)        */
+    int32_t diag_only;      /* 1-D patterns: bin1 = bin2 after picking (detection.py:311-315)            */
+    int32_t lo_diag, hi_diag; /* scanned diagonals (diag_trim of the coefficient map, :269-270)          */
+    int32_t inter;          /* 1: inter-chromosomal block (no NaN sub-diagonals in the windows, :301)    */
+    int32_t want_windows;   /* 1: also return the km x kn window of every record                         */
+} cs_foci_params;
+
+typedef struct {
+    int32_t bin1, bin2;     /* matrix coordinates of the pattern                                         */
+    int32_t inside;         /* 1: its window lies inside the (zero padded) map, strict bounds (:99-104)  */
+    int32_t n_zero;         /* zero pixels of the window (missing ones excluded)                          */
+    int32_t n_missing;      /* non-finite pixels: missing bins, NaN sub-diagonals                         */
+    int32_t focus_size;     /* pixels of the focus (0 in quantify mode)                                   */
+    double score;           /* float64 coefficient at (bin1, bin2), untrimmed map                         */
+    double n_obs;           /* present pixels of that correlation window                                  */
+} cs_focus;
+
+/* One sub-matrix x one template, `detect` mode, entirely on the device: coefficient map (float32 or
+ * float64 arithmetic, context-owned scratch) -> thresholded candidates -> float64 re-scoring ->
+ * 4-connected foci (union-find over the sorted candidate list) -> size filter -> first row-major
+ * maximum of every focus -> window statistics.  Records come back in the reference's order (foci
+ * numbered by the row-major position of their first pixel).  h_foci: `cap` records; h_windows:
+ * cap * km * kn float64 (NaN = missing) or NULL.  *n_foci receives the number of foci; if it exceeds
+ * cap the call returns CS_ERR_OVERFLOW and the caller retries with larger buffers.  Synchronous.
+ * `signal` must stay float64 for bit-identical scores (float32 signals are scored as stored). */
+int cs_detect_foci(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
+                   const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci,
+                   int64_t cap, int64_t* n_foci, double* h_windows);
+
+/* `quantify` mode (detection.py:277, 297-298): score, n_obs and window statistics at n given pixels
+ * (host int32 arrays).  h_out: n records in input order; h_windows: n * km * kn float64 or NULL. */
+int cs_quantify_pixels(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
+                       const cs_normxcorr2_params* params, const cs_foci_params* foci,
+                       const int32_t* h_rows, const int32_t* h_cols, int64_t n, cs_focus* h_out,
+                       double* h_windows);
+
+/* ---- pinned host memory (PCIe side of the boundary: page-locked buffers copy at link speed) ---- */
+int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr);
+int cs_host_free(cs_ctx* ctx, void* h_ptr);
 
 #ifdef __cplusplus
 }

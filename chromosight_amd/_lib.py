@@ -149,6 +149,7 @@ _PROTOTYPES = {
     "cs_quantify_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_remove_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "cs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
 }

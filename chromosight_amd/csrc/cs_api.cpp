@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/chromosight_hip.h"
@@ -771,6 +772,42 @@ int cs_distance_law_finish(cs_ctx* ctx, void* stream_, const double* d_sum, cons
     if (n_diags < 0 || (n_diags > 0 && (!d_sum || !d_cnt || !d_law))) return fail(ctx, CS_ERR_INVALID, "bad law buffers");
     int rc = cs::launch_law_finish(d_sum, (const long long*)d_cnt, n_diags, d_law, (hipStream_t)stream_);
     if (rc) return fail(ctx, CS_ERR_HIP, "law finish launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_remove_neighbours(const int64_t* h_bin1, const int64_t* h_bin2, const int64_t* h_order, int64_t n, int64_t win,
+                         uint8_t* h_keep)
+{
+    if (n < 0 || win < 1 || (n > 0 && (!h_bin1 || !h_bin2 || !h_order || !h_keep))) return CS_ERR_INVALID;
+    // kept patterns bucketed by (bin1 / win, bin2 / win): a neighbour closer than win on both axes
+    // lies in one of the 3 x 3 surrounding cells
+    std::unordered_map<uint64_t, std::vector<int64_t>> grid;
+    grid.reserve((size_t)n);
+    auto cell = [](int64_t a, int64_t b) { return ((uint64_t)(a + (1ll << 30)) << 32) | (uint64_t)(uint32_t)(b + (1ll << 30)); };
+    for (int64_t t = 0; t < n; ++t) h_keep[t] = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        const int64_t i = h_order[t];
+        if (i < 0 || i >= n) return CS_ERR_INVALID;
+        const int64_t b1 = h_bin1[i], b2 = h_bin2[i];
+        const int64_t c1 = b1 >= 0 ? b1 / win : -((-b1 + win - 1) / win), c2 = b2 >= 0 ? b2 / win : -((-b2 + win - 1) / win);
+        bool close = false;
+        for (int64_t d1 = -1; d1 <= 1 && !close; ++d1)
+            for (int64_t d2 = -1; d2 <= 1 && !close; ++d2) {
+                auto it = grid.find(cell(c1 + d1, c2 + d2));
+                if (it == grid.end()) continue;
+                for (int64_t j : it->second) {
+                    const int64_t e1 = h_bin1[j] - b1, e2 = h_bin2[j] - b2;
+                    if ((e1 < 0 ? -e1 : e1) < win && (e2 < 0 ? -e2 : e2) < win) {
+                        close = true;
+                        break;
+                    }
+                }
+            }
+        if (!close) {
+            h_keep[i] = 1;
+            grid[cell(c1, c2)].push_back(i);
+        }
+    }
     return CS_OK;
 }
 

@@ -112,3 +112,110 @@ def detect_blocks(blocks, kernel_config, kernel_matrix, detector=None, full=True
         rows.append(rec)
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(RECORD_FIELDS)))
     return gather_records(local)
+
+
+# ================================================================================================
+# whole-genome detect, blocks sharded over the ranks
+# ================================================================================================
+GENOME_FIELDS = ("block", "bin1", "bin2", "score", "pvalue", "kernel_id", "iteration")
+
+
+def _allreduce_sum(array):
+    dist, rank, world = _world()
+    if dist is None or world == 1:
+        return array
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to(dev)
+    dist.all_reduce(t)
+    return t.cpu().numpy()
+
+
+def _gather(records, n_fields):
+    """gather_records for an arbitrary record width."""
+    dist, rank, world = _world()
+    records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, n_fields)
+    if dist is None or world == 1:
+        return records
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    count = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    padded = torch.zeros((width, n_fields), dtype=torch.float64, device=dev)
+    if records.shape[0]:
+        padded[:records.shape[0]] = torch.from_numpy(records).to(dev)
+    parts = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    merged = np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
+    return merged[np.argsort(merged[:, 0], kind="stable")]
+
+
+def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, stage=None, detect=None,
+                  owned=None):
+    """`chromosight detect` over all intra-chromosomal blocks of a DeviceCool, sharded over the ranks
+    like the reference's Pool.imap over sub-matrices (cli/chromosight.py:738-755): every rank stages
+    and scans its own blocks (LPT assignment by band pixels), the per-block tables are all-gathered
+    (count + padded all_gather: RCCL over xGMI with the "nccl" backend), and when the template is
+    refined over iterations the pileup is formed from an all-reduce of the per-rank window sums and
+    counts, so every rank continues with the same template (cli/chromosight.py:791).
+
+    `genome` needs n_chrom, chrom_size(ci), binsize; `stage(genome, ci, max_dist, largest)` and
+    `detect(genome, block, cfg, kernel, tsvd)` default to the device pipeline (injected in CPU tests).
+    `owned`: this rank's block indices when the caller fixed the assignment (e.g. a rank that only
+    holds the pixels of its own chromosomes); default: LPT by scanned pixels.
+    Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
+    bins, identical on all ranks, in the single-process order."""
+    if stage is None or detect is None:
+        from . import pipeline
+        stage = stage or (lambda g, ci, md, lk: g.stage_intra(ci, md, lk, smooth=smooth, band_dtype=band_dtype,
+                                                              resident=True))
+        detect = detect or (lambda g, blk, cfg, k, t: pipeline.detect_block(g, blk, cfg, k, tsvd=t))
+    dist, rank, world = _world()
+    max_dist = max(kernel_config["max_dist"] // genome.binsize, 1)
+    largest = max(np.shape(k)[0] for k in kernel_config["kernels"])
+    sizes = [genome.chrom_size(ci) for ci in range(genome.n_chrom)]
+    costs = [block_cost((n, n), max_dist, False) for n in sizes]
+    mine = list(owned) if owned is not None else assign_blocks(costs, world)[rank]
+    staged = {ci: stage(genome, ci, max_dist, largest) for ci in mine}
+    out = []
+    for kernel_id, kernel in enumerate(kernel_config["kernels"]):
+        kernel = np.asarray(kernel, dtype=np.float64)
+        for it in range(kernel_config["max_iterations"]):
+            rows, wins = [], []
+            for ci in mine:
+                table, windows = detect(genome, staged[ci], kernel_config, kernel, tsvd)
+                if table is None or len(table) == 0:
+                    continue
+                rec = np.empty((len(table), len(GENOME_FIELDS)))
+                rec[:, 0] = ci
+                rec[:, 1] = table["bin1"].to_numpy(dtype=np.float64)
+                rec[:, 2] = table["bin2"].to_numpy(dtype=np.float64)
+                rec[:, 3] = table["score"].to_numpy(dtype=np.float64)
+                rec[:, 4] = table["pvalue"].to_numpy(dtype=np.float64)
+                rec[:, 5] = kernel_id
+                rec[:, 6] = it
+                rows.append(rec)
+                if windows is not None:
+                    wins.append(windows)
+            local = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(GENOME_FIELDS)))
+            merged = _gather(local, len(GENOME_FIELDS))
+            if merged.shape[0] == 0:
+                break                                        # no pattern with this template: next one
+            out.append(merged)
+            if it + 1 < kernel_config["max_iterations"]:
+                # pileup = nanmean over ALL windows of this iteration (detection.py:158-174)
+                if world == 1:
+                    import warnings
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        kernel = np.nanmean(np.concatenate(wins, axis=0), axis=0)
+                else:
+                    stack = np.concatenate(wins, axis=0) if wins else np.zeros((0,) + kernel.shape)
+                    both = np.stack([np.nansum(stack, axis=0), np.sum(~np.isnan(stack), axis=0).astype(np.float64)])
+                    both = _allreduce_sum(both)
+                    with np.errstate(all="ignore"):
+                        kernel = both[0] / both[1]
+    return np.concatenate(out, axis=0) if out else np.zeros((0, len(GENOME_FIELDS)))

@@ -474,21 +474,23 @@ def pileup_patterns(pattern_windows):
 def remove_neighbours(patterns, win_size=8):
     """Greedy suppression by decreasing score: a kept pattern blacklists every other pattern
     closer than win_size bins on both axes (reference detection.py:348-384).  Returns a boolean
-    keep-mask aligned on the input rows."""
+    keep-mask aligned on the input rows.  The visiting order is the reference's own sort; the
+    scan is the library's grid-hashed cs_remove_neighbours (O(n) instead of O(n^2))."""
+    from .._lib import load_library
+    n = patterns.shape[0]
+    if n == 0:
+        return np.ones(0, dtype=bool)
     ordered = patterns.copy().sort_values("score", ascending=False)
-    idx = ordered.index.values
-    b1 = ordered.bin1.to_numpy()
-    b2 = ordered.bin2.to_numpy()
-    dropped = np.zeros(len(idx), dtype=bool)   # in sorted order
-    for k in range(len(idx)):
-        if dropped[k]:
-            continue
-        close = (np.abs(b1 - b1[k]) < win_size) & (np.abs(b2 - b2[k]) < win_size)
-        close[k] = False
-        dropped |= close
-    keep = np.ones(patterns.shape[0], dtype=bool)
-    keep[idx[dropped]] = False
-    return keep
+    pos = pd.Series(np.arange(n), index=patterns.index)
+    order = np.ascontiguousarray(pos.loc[ordered.index].to_numpy(), dtype=np.int64)
+    b1 = np.ascontiguousarray(patterns.bin1.to_numpy(), dtype=np.int64)
+    b2 = np.ascontiguousarray(patterns.bin2.to_numpy(), dtype=np.int64)
+    keep = np.zeros(n, dtype=np.uint8)
+    rc = load_library().cs_remove_neighbours(b1.ctypes.data, b2.ctypes.data, order.ctypes.data, n,
+                                             max(int(win_size), 1), keep.ctypes.data)
+    if rc != 0:
+        raise ValueError("cs_remove_neighbours: bad arguments")
+    return keep.astype(bool)
 
 
 # ============================================================================================

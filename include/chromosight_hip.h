@@ -252,6 +252,13 @@ int cs_quantify_pixels(cs_ctx* ctx, void* stream, const cs_matrix* signal, const
                        const int32_t* h_rows, const int32_t* h_cols, int64_t n, cs_focus* h_out,
                        double* h_windows);
 
+/* Greedy neighbour suppression of detection.py:348 remove_neighbours, on the host, in O(n) with a
+ * grid of win x win cells instead of the reference's O(n^2) scan: patterns are visited in `h_order`
+ * (indices by decreasing score, as the caller sorted them); a pattern is kept iff no pattern kept
+ * before it lies closer than `win` bins on both axes.  h_keep: n bytes, 1 = kept. */
+int cs_remove_neighbours(const int64_t* h_bin1, const int64_t* h_bin2, const int64_t* h_order, int64_t n,
+                         int64_t win, uint8_t* h_keep);
+
 /* ---- pinned host memory (PCIe side of the boundary: page-locked buffers copy at link speed) ---- */
 int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr);
 int cs_host_free(cs_ctx* ctx, void* h_ptr);

@@ -1,0 +1,217 @@
+"""The device-resident block pipeline (chromosight_amd/pipeline.py DeviceCool / detect_block,
+parallel.detect_genome): genome-wide pixel table in HBM -> band extents -> distance law -> fused
+detrend + CSR->band tiler -> correlation -> device foci and validation statistics.
+
+Checked against (a) the reference's own captures for data_test/example.cool (laws, prepared blocks,
+pattern tables) and (b) an independent CPU pipeline made of the pinned oracles
+(oracle/detrend_oracle.py, oracle/oracle.c, oracle/foci_oracle.py) on the synthetic C4 genome of
+BASELINE.md -- 200 000 bins in 23 blocks, loops + the three borders templates."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import chromosight_amd.kernels as ck
+from chromosight_amd import parallel, pipeline
+from chromosight_amd._lib import LAYOUT_BAND, get_device
+from oracle import c_oracle, detrend_oracle, foci_oracle
+from tools.synthetic_genome import make_cool
+
+pytestmark = pytest.mark.gpu
+
+
+def download_block(dcool, block):
+    """Staged block -> dense numpy (float64)."""
+    dev = dcool.dev
+    n = block.shape[0]
+    sig = block.sig
+    dt = np.float64 if sig.dtype == 1 else np.float32
+    host = np.empty((n, sig.ld), dtype=dt)
+    dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, host.ctypes.data, sig.d_ptr, host.nbytes, None))
+    if sig.layout == LAYOUT_BAND:
+        out = np.zeros((n, n))
+        for d in range(sig.band_w):
+            off = sig.band_lo + d
+            idx = np.arange(max(0, -off), min(n, n - off))
+            out[idx, idx + off] = host[idx, d]
+        return out
+    return host[:, :n].astype(np.float64)
+
+
+def coo(g, prefix):
+    return sp.coo_matrix((g[f"{prefix}_val"], (g[f"{prefix}_row"], g[f"{prefix}_col"])), shape=tuple(g[f"{prefix}_shape"]))
+
+
+def test_fused_tiler_matches_reference_prepared_blocks(golden):
+    """cs_csr_band_extent + cs_distance_law_csr/_finish + cs_csr_to_band(law) on views of the genome
+    CSR == ContactMap.create_mat of the reference (detrend, >= 10 -> 1, trim, NaN -> 0), <= 1e-11."""
+    dcool = pipeline.DeviceCool(golden("example_cool"))
+    g = golden("example_blocks")
+    for ci in range(3):
+        for pname in ("loops", "borders", "hairpins"):
+            max_dist = int(g[f"chr{ci}_{pname}_max_dist"])
+            keep = int(g[f"chr{ci}_{pname}_keep"])
+            n = dcool.chrom_size(ci)
+            largest = keep - min(max_dist, n)
+            block = dcool.stage_intra(ci, max_dist, largest)
+            assert block.keep == keep
+            got = download_block(dcool, block)
+            ref = coo(g, f"chr{ci}_{pname}_prepared").toarray()
+            assert np.abs(got - ref).max() < 1e-11, (ci, pname)
+            assert np.array_equal(dcool.block_bins(ci), g[f"chr{ci}_det"])
+
+
+def test_device_blocks_reproduce_reference_tables(golden, templates):
+    """detect_block on the staged example chromosomes: tables bit-identical to the reference's
+    pattern_detector captures (coordinates and order), scores <= 1e-9, windows <= 1e-12."""
+    dcool = pipeline.DeviceCool(golden("example_cool"))
+    g = golden("example_blocks")
+    pats = {
+        "loops": (dict(pearson=0.3, max_perc_undetected=50.0, max_perc_zero=10.0, max_dist=2000000), [templates["loops"]]),
+        "borders": (dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0), templates["borders"]),
+        "hairpins": (dict(pearson=0.1, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0), [templates["hairpin"]]),
+    }
+    n_rows = 0
+    for ci in range(3):
+        for pname, (cfg, kernels) in pats.items():
+            max_dist = int(g[f"chr{ci}_{pname}_max_dist"])
+            largest = int(g[f"chr{ci}_{pname}_keep"]) - min(max_dist, dcool.chrom_size(ci))
+            block = dcool.stage_intra(ci, max_dist, largest, resident=True)
+            for ki, kern in enumerate(kernels):
+                tag = f"chr{ci}_{pname}{ki}"
+                tab, wins = pipeline.detect_block(dcool, block, cfg, kern)
+                ref_tab = g[f"{tag}_table"]
+                if ref_tab.shape[0] == 0:
+                    assert tab is None or len(tab) == 0
+                    continue
+                got = tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+                assert np.array_equal(got[:, :2], ref_tab[:, :2]), tag
+                assert np.abs(got[:, 2] - ref_tab[:, 2]).max() < 1e-9, tag
+                assert np.allclose(got[:, 3], ref_tab[:, 3], rtol=1e-6, atol=1e-300), tag
+                assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12), tag
+                n_rows += ref_tab.shape[0]
+    assert n_rows > 200
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic genome: device pipeline == CPU pipeline made of the pinned oracles
+# ------------------------------------------------------------------------------------------------
+def oracle_block_tables(cool, ci, cfg, max_dist, kernels, binsize):
+    """(bin1, bin2, score) tables of one chromosome, one per template, from the CPU oracles."""
+    largest = max(k.shape[0] for k in kernels)
+    off = cool["chrom_offset"]
+    n = int(off[ci + 1] - off[ci])
+    md = max_dist
+    keep = min(md, n) + largest
+    band, det = detrend_oracle.balanced_band(cool, ci, keep)
+    prepared, _ = detrend_oracle.prepare_band(band, det)
+    miss = ~det
+    out = []
+    for kern in kernels:
+        if n <= max(kern.shape):
+            out.append(np.zeros((0, 3)))
+            continue
+        out_w = min(md, n - 1) + 1
+        corr, _ = c_oracle.normxcorr2_band(prepared, n, 0, prepared.shape[1], kern, 0, n, 0, out_w, max_dist=md,
+                                           miss_row=miss, miss_col=miss,
+                                           missing_tol=cfg["max_perc_undetected"] / 100)
+        out.append(foci_oracle.detect_table_band(prepared, 0, corr, 0, n, miss, kern.shape, cfg["pearson"],
+                                                 cfg["max_perc_zero"] / 100, cfg["max_perc_undetected"] / 100,
+                                                 diag_only=cfg["max_dist"] == 0))
+    return out
+
+
+def compare_genome(total_bins, max_dist_bins):
+    binsize = 2000
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, planted = make_cool(total_bins, max_dist_bins, binsize, seed=2, template=template)
+    dcool = pipeline.DeviceCool(cool)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = max_dist_bins * binsize
+    borders = copy.deepcopy(ck.borders)
+    n_found = {}
+    for name, cfg in (("loops", loops), ("borders", borders)):
+        rec = parallel.detect_genome(dcool, cfg)
+        md = max(cfg["max_dist"] // binsize, 1)
+        kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+        total = 0
+        for ci in range(dcool.n_chrom):
+            want = oracle_block_tables(cool, ci, cfg, md, kernels, binsize)
+            for ki, tab in enumerate(want):
+                got = rec[(rec[:, 0] == ci) & (rec[:, 5] == ki)]
+                assert got.shape[0] == tab.shape[0], (name, ci, ki, got.shape[0], tab.shape[0])
+                if tab.shape[0]:
+                    assert np.array_equal(got[:, 1:3], tab[:, :2]), (name, ci, ki)      # same foci, same order
+                    assert np.abs(got[:, 3] - tab[:, 2]).max() < 1e-9, (name, ci, ki)
+                total += tab.shape[0]
+        n_found[name] = total
+    return n_found, planted
+
+
+def test_synthetic_genome_small_vs_oracle_pipeline():
+    found, planted = compare_genome(30_000, 300)
+    print(f"30k-bin genome: {found} patterns, {len(planted)} planted loops")
+    assert found["loops"] > 100 and found["borders"] >= 0
+
+
+def test_c4_genome_200k_vs_oracle_pipeline():
+    """C4 of BASELINE.md at full size: 200 000 bins, 23 blocks, max_dist 1000, loops + 3 borders
+    templates; every pattern table equal to the CPU oracle pipeline's (coordinates bit-exact and in
+    order, scores <= 1e-9)."""
+    found, planted = compare_genome(200_000, 1000)
+    print(f"C4 genome: {found} patterns, {len(planted)} planted loops")
+    assert found["loops"] > 1000
+
+
+# ------------------------------------------------------------------------------------------------
+# two ranks, real detector: detect_genome over gloo with both ranks on this GPU
+# ------------------------------------------------------------------------------------------------
+WORKER = r"""
+import os, sys, copy, numpy as np
+sys.path.insert(0, os.environ["CS_ROOT"])
+import torch.distributed as dist
+import chromosight_amd.kernels as ck
+from chromosight_amd import parallel, pipeline
+from tools.synthetic_genome import make_cool
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+cool, _ = make_cool(12_000, 200, 2000, seed=5, template=template)
+dcool = pipeline.DeviceCool(cool)
+cfg = copy.deepcopy(ck.loops); cfg["max_dist"] = 200 * 2000; cfg["max_iterations"] = 2
+rec = parallel.detect_genome(dcool, cfg)
+if dist.get_rank() == 0:
+    np.save(os.environ["CS_OUT"], rec)
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    """parallel.detect_genome with the real device detector on 2 ranks (gloo rendezvous, both ranks on
+    this GPU) == the single-process tables, including the second iteration whose template is the
+    all-reduced pileup of the first."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(12_000, 200, 2000, seed=5, template=template)
+    cfg = copy.deepcopy(ck.loops)
+    cfg["max_dist"] = 200 * 2000
+    cfg["max_iterations"] = 2
+    single = parallel.detect_genome(pipeline.DeviceCool(cool), cfg)
+    assert single.shape[0] > 50 and (single[:, 6] == 1).any()
+    out = tmp_path / "rec.npy"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CS_ROOT=root, CS_OUT=str(out), CHROMOSIGHT_HIP_DEVICE="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    both = np.load(out)
+    assert both.shape == single.shape
+    assert np.array_equal(both[:, [0, 1, 2, 5, 6]], single[:, [0, 1, 2, 5, 6]])
+    # iteration 0 is bit-identical; iteration 1 uses a pileup summed in another order (1e-16 level)
+    assert np.array_equal(both[both[:, 6] == 0], single[single[:, 6] == 0])
+    assert np.abs(both[:, 3] - single[:, 3]).max() < 1e-9

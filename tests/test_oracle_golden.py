@@ -216,3 +216,27 @@ def test_foci_oracle_matches_reference_tables(golden, templates):
                     assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12), tag
                 n_rows += ref.shape[0]
     assert n_rows > 200
+
+
+def test_detrend_oracle_matches_reference_blocks(golden):
+    """oracle/detrend_oracle.py (balanced band, distance law, detrend, trim) against the laws and
+    prepared blocks the reference produced from data_test/example.cool."""
+    from oracle import detrend_oracle
+    cool = golden("example_cool")
+    g = golden("example_blocks")
+    for ci in range(3):
+        for pname in ("loops", "borders", "hairpins"):
+            keep = int(g[f"chr{ci}_{pname}_keep"])
+            band, det = detrend_oracle.balanced_band(cool, ci, keep)
+            assert np.array_equal(np.flatnonzero(det), g[f"chr{ci}_det"])
+            prepared, law = detrend_oracle.prepare_band(band, det)
+            ref_law = g[f"chr{ci}_{pname}_law"]
+            w = min(band.shape[1], band.shape[0])
+            assert np.array_equal(np.isnan(law[:w]), np.isnan(ref_law[:w]))
+            assert np.nanmax(np.abs(law[:w] - ref_law[:w]) / np.maximum(np.abs(ref_law[:w]), 1e-300)) < 1e-12
+            ref = _coo(g, f"chr{ci}_{pname}_prepared").toarray()
+            n = ref.shape[0]
+            dense = np.zeros((n, n))
+            for d in range(min(band.shape[1], n)):
+                dense[np.arange(n - d), np.arange(n - d) + d] = prepared[:n - d, d]
+            assert np.abs(dense - ref).max() < 1e-11, (ci, pname)

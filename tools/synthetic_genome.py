@@ -6,53 +6,76 @@ import numpy as np
 HG38_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50, 156]
 
 
-def make_cool(total_bins=200_000, max_dist_bins=1000, binsize=2000, seed=2, loops_per_10k=300, template=None,
-              chrom_sizes=None, largest_kernel=17):
-    rng = np.random.default_rng(seed)
+def genome_sizes(total_bins=200_000, chrom_sizes=None):
     if chrom_sizes is None:
         frac = np.asarray(HG38_MB, dtype=np.float64) / sum(HG38_MB)
         chrom_sizes = np.maximum((frac * total_bins).astype(np.int64), 64)
-    sizes = np.asarray(chrom_sizes, dtype=np.int64)
+    return np.asarray(chrom_sizes, dtype=np.int64)
+
+
+def make_cool(total_bins=200_000, max_dist_bins=1000, binsize=2000, seed=2, loops_per_10k=300, template=None,
+              chrom_sizes=None, largest_kernel=17, only=None):
+    """Decoded-.cool dictionary of a synthetic genome.  Every chromosome has its own random stream
+    (seed, chromosome), so `only` (a list of chromosome indices) generates just the pixels of those
+    chromosomes -- what one rank of a sharded run needs -- identical to the same chromosomes of the
+    full genome.  Weights (2 % unbalanced bins) are always generated for the whole genome."""
+    sizes = genome_sizes(total_bins, chrom_sizes)
     off = np.concatenate([[0], np.cumsum(sizes)])
     keep = max_dist_bins + largest_kernel
     d = np.arange(keep + 1)
     lam = 200.0 / (d + 1.0)
     b1l, b2l, cl, planted = [], [], [], []
     for c, m in enumerate(sizes):
+        if only is not None and c not in only:
+            continue
+        rng = np.random.default_rng([seed, c])
         m = int(m)
         w = min(keep + 1, m)
-        boost = np.ones((m, w))
+        planted_c = []
         if template is not None and loops_per_10k and m > 4 * template.shape[0]:
             k = template.shape[0]
             kh = k // 2
             n_loops = max(1, int(m * loops_per_10k / 10_000))
             li = rng.integers(kh + 1, m - kh - 1, size=n_loops)
             ld = rng.integers(min(k + 2, w - kh - 2), max(min(max_dist_bins, w - kh - 2), k + 3), size=n_loops)
-            t = template / template.max()
-            for i, dd in zip(li, ld):
-                j = i + dd
-                if j + kh >= m:
-                    continue
-                rr = np.arange(i - kh, i + kh + 1)[:, None]
-                cc = np.arange(j - kh, j + kh + 1)[None, :]
-                diag = cc - rr
-                ok = (diag >= 0) & (diag < w)
-                np.multiply.at(boost, (np.broadcast_to(rr, diag.shape)[ok], diag[ok]), 1.0 + 3.0 * (t ** 3)[ok])
-                planted.append((int(off[c] + i), int(off[c] + j)))
-        counts = rng.poisson(lam[None, :w] * boost)
-        rows = np.repeat(np.arange(m), w)
-        cols = rows + np.tile(np.arange(w), m)
-        flat = counts.ravel()
-        ok = (cols < m) & (flat > 0)
-        b1l.append(rows[ok] + off[c])
-        b2l.append(cols[ok] + off[c])
-        cl.append(flat[ok])
+            planted_c = [(int(i), int(i + dd)) for i, dd in zip(li, ld) if i + dd + kh < m]
+        rows_l, cols_l, cnt_l = [], [], []
+        chunk = 8192
+        t3 = None if template is None else (template / template.max()) ** 3
+        pl = np.array(planted_c, dtype=np.int64).reshape(-1, 2)
+        for r0 in range(0, m, chunk):                      # chunked: a 200 000-bin block is 1.6 GB of float64
+            r1 = min(m, r0 + chunk)
+            boost = np.ones((r1 - r0, w))
+            if pl.shape[0]:
+                kh = template.shape[0] // 2
+                near = pl[(pl[:, 0] + kh >= r0) & (pl[:, 0] - kh < r1)]
+                for i, j in near:
+                    rr = np.arange(i - kh, i + kh + 1)[:, None]
+                    cc = np.arange(j - kh, j + kh + 1)[None, :]
+                    diag = cc - rr
+                    ok = (diag >= 0) & (diag < w) & (rr >= r0) & (rr < r1)
+                    np.multiply.at(boost, (np.broadcast_to(rr - r0, diag.shape)[ok], diag[ok]), 1.0 + 3.0 * t3[ok])
+            counts = rng.poisson(lam[None, :w] * boost)
+            rows = np.repeat(np.arange(r0, r1), w)
+            cols = rows + np.tile(np.arange(w), r1 - r0)
+            flat = counts.ravel()
+            ok = (cols < m) & (flat > 0)
+            rows_l.append(rows[ok] + off[c])
+            cols_l.append(cols[ok] + off[c])
+            cnt_l.append(flat[ok].astype(np.int32))
+        b1l += rows_l
+        b2l += cols_l
+        cl += cnt_l
+        planted += [(int(off[c] + i), int(off[c] + j)) for i, j in planted_c]
     n = int(off[-1])
-    weight = rng.normal(1.0, 0.05, n) * 0.07
-    weight[rng.choice(n, n // 50, replace=False)] = np.nan
+    wrng = np.random.default_rng([seed, 10_000])
+    weight = wrng.normal(1.0, 0.05, n) * 0.07
+    weight[wrng.choice(n, n // 50, replace=False)] = np.nan
+    empty = np.zeros(0, dtype=np.int64)
     cool = {
         "binsize": binsize, "chrom_offset": off, "chrom_names": np.array([f"chr{c + 1}" for c in range(len(sizes))]),
-        "bin1_id": np.concatenate(b1l), "bin2_id": np.concatenate(b2l), "count": np.concatenate(cl).astype(np.float64),
+        "bin1_id": np.concatenate(b1l) if b1l else empty, "bin2_id": np.concatenate(b2l) if b2l else empty,
+        "count": np.concatenate(cl) if cl else empty.astype(np.int32),
         "weight": weight,
         "bin_start": np.concatenate([np.arange(s) * binsize for s in sizes]),
         "bin_end": np.concatenate([(np.arange(s) + 1) * binsize for s in sizes]),

@@ -164,7 +164,7 @@ def test_c4_genome_200k_vs_oracle_pipeline():
     order, scores <= 1e-9)."""
     found, planted = compare_genome(200_000, 1000)
     print(f"C4 genome: {found} patterns, {len(planted)} planted loops")
-    assert found["loops"] > 1000
+    assert found["loops"] > 500 and found["borders"] > 10000
 
 
 # ------------------------------------------------------------------------------------------------

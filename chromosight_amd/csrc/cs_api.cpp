@@ -439,6 +439,33 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.ks.thr = (TC)p->xcorr_threshold;
     A.ks.eps = (TC)p->denom_eps;
     A.ks.cut = (TC)p->min_present;
+    A.ks.thr_n = (TC)(p->xcorr_threshold * st.n);
+    A.ks.nkvar = (TC)(st.n * st.kvar);
+    A.ks.eps2 = (TC)(p->denom_eps * p->denom_eps);
+    A.ks.den2_min = (TC)(p->denom_eps * p->denom_eps * st.n * st.n);
+    {
+        // can sum_missing K' or sum_missing K'^2 of a non-empty set fall under the zeroing threshold?
+        // not if every entry alone exceeds it and all have one sign (the built-in templates: >= 0.5)
+        double lo = 1e300, lo2 = 1e300;
+        bool pos = true, pos2 = true;
+        std::vector<double> distinct;
+        for (int t = 0; t < kk; ++t) {
+            const double kc = kconv[t];
+            const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
+            lo = std::min(lo, std::fabs(kc));
+            lo2 = std::min(lo2, std::fabs(k2));
+            pos = pos && kc > 0;
+            pos2 = pos2 && k2 > 0;
+            bool seen = false;
+            for (double d : distinct) seen = seen || std::fabs(d - kc) <= 1e-9 * std::max(1.0, std::fabs(d));
+            if (!seen && distinct.size() < 64) distinct.push_back(kc);
+        }
+        A.ks.zk_possible = !(pos && pos2 && lo > 2 * p->xcorr_threshold && lo2 > 2 * p->xcorr_threshold);
+        // piecewise-constant templates (borders, hairpins: 2 levels) have windows whose present pixels
+        // are all equal; smooth templates never do, but with up to 75 % of a window missing a handful of
+        // levels can still coincide, so only clearly many-valued templates skip the snap
+        A.ks.snap_possible = distinct.size() < 64;
+    }
     A.xcorr_only = 0;
     A.w_sym = sym ? 1 : 0;
     *out = A;

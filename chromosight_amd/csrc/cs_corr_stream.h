@@ -103,6 +103,17 @@ struct WRow<float, K> {
         else
             asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "n"(BYTE_OFF));
     }
+    // same load with a run-time (wave-uniform) byte offset
+    __device__ __forceinline__ void issue_at(unsigned long long base, unsigned off)
+    {
+        if constexpr (K > 16) {
+            const unsigned off2 = off + 64;
+            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
+                         : "=&s"(a), "=&s"(b) : "s"(base), "s"(off), "s"(off2));
+        } else {
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "s"(off));
+        }
+    }
     __device__ __forceinline__ void wait()
     {
         if constexpr (K > 16) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
@@ -157,6 +168,18 @@ struct WRow<double, K> {
                          : "=&s"(a), "=&s"(b) : "s"(base), "n"(BYTE_OFF), "n"(BYTE_OFF + 64));
         else
             asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "n"(BYTE_OFF));
+    }
+    __device__ __forceinline__ void issue_at(unsigned long long base, unsigned off)
+    {
+        const unsigned off2 = off + 64, off3 = off + 128;
+        if constexpr (K > 16)
+            asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                         : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(base), "s"(off), "s"(off2), "s"(off3));
+        else if constexpr (K > 8)
+            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+                         : "=&s"(a), "=&s"(b) : "s"(base), "s"(off), "s"(off2));
+        else
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(a) : "s"(base), "s"(off));
     }
     __device__ __forceinline__ void wait()
     {
@@ -505,6 +528,19 @@ __device__ __forceinline__ void steps2(const RowRegs<TC, K>& A, const RowRegs<TC
                                                                       acc_zero<TC>(), wa, wb, QA, QB, q_need);
 }
 
+// value of lane `idx` (wave-uniform index) as a wave-uniform scalar
+__device__ __forceinline__ float lane_value(float v, int idx)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), idx));
+}
+__device__ __forceinline__ double lane_value(double v, int idx)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, idx);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), idx);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Lean view of the launch arguments (only what the row loop needs stays in registers).
 template <typename TC>
 struct StreamArgs {
@@ -806,8 +842,40 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         cnt[1] = (c0 - missing_flag(r.at(0))) + missing_flag(r.at(K));
     };
 
+    // MODE 2: correction of the factorised mask sums for the pixels whose window leaves the matrix
+    // (frame tables) or the diagonal range 0..max_dist (edge tables).  The table reads are issued by
+    // fix_fetch BEFORE the FMA block of the iteration and consumed by emit after it, so their latency
+    // is covered (every strip of a narrow band is an edge strip).  fx[c] = {d nm, d ka, d kb}.
+    auto fix_fetch = [&](int oi, int d_row, TC (&fx)[2][3]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            fx[c][0] = fx[c][1] = fx[c][2] = TC(0);
+            const int d = d_row + c;
+            const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.ms);
+            if (in_range) {
+                const TC* f = nullptr;
+                const int j = oj0 + c;
+                const int x = A.fix_xband ? d - A.fix_xlo : j;
+                if (oi < A.fix_top) f = A.fix_rows + ((size_t)oi * A.fix_width + x) * 4;
+                else if (oi >= A.fix_bot0) f = A.fix_rows + ((size_t)(A.fix_top + oi - A.fix_bot0) * A.fix_width + x) * 4;
+                else if (A.fix_cols && (j < A.fix_side || j >= A.ns - A.fix_side))
+                    f = A.fix_cols + ((size_t)oi * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side))) * 4;
+                else if (A.fix_on) {
+                    if (d >= 0 && d < K - 1) f = A.fix_lo + ((size_t)oi * (K - 1) + d) * 4;
+                    else if (d >= A.fix_hi_d0 && d - A.fix_hi_d0 < A.fix_hi_w)
+                        f = A.fix_hi + ((size_t)oi * A.fix_hi_w + (d - A.fix_hi_d0)) * 4;
+                }
+                if (f) {
+                    fx[c][0] = f[0];
+                    fx[c][1] = f[1];
+                    fx[c][2] = f[2];
+                }
+            }
+        }
+    };
+
     auto emit = [&](int oi, const acc_t<TC>& cs2, const TC (&s1)[2], const TC (&s2)[2],
-                    const TC (&nm)[2], const acc_t<TC>& ka2, const acc_t<TC>& kb2) {
+                    const TC (&nm)[2], const acc_t<TC>& ka2, const acc_t<TC>& kb2, const TC (&fx)[2][3]) {
         const bool row_margin = !A.full && ((oi < KH) | (oi > A.ms - K + KH));
         const TC csv[2] = {cs2.x, cs2.y}, kav[2] = {ka2.x, ka2.y}, kbv[2] = {kb2.x, kb2.y};
 #pragma unroll
@@ -817,43 +885,22 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
             const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
             TC r;
             if constexpr (REG) {
-                // windows that leave the matrix (frame tables) or the diagonal range 0..max_dist
-                // (edge tables): precomputed correction of the factorised sums
-                TC nmv = nm[c], ka = kav[c], kb = kbv[c];
-                if (strip_needs_fix && in_range) {
-                    const TC* f = nullptr;
-                    const int j = oj0 + c;
-                    const int x = A.fix_xband ? d - A.fix_xlo : j;
-                    if (oi < A.fix_top) f = A.fix_rows + ((size_t)oi * A.fix_width + x) * 4;
-                    else if (oi >= A.fix_bot0) f = A.fix_rows + ((size_t)(A.fix_top + oi - A.fix_bot0) * A.fix_width + x) * 4;
-                    else if (A.fix_cols && (j < A.fix_side || j >= A.ns - A.fix_side))
-                        f = A.fix_cols + ((size_t)oi * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side))) * 4;
-                    else if (A.fix_on) {
-                        if (d >= 0 && d < K - 1) f = A.fix_lo + ((size_t)oi * (K - 1) + d) * 4;
-                        else if (d >= A.fix_hi_d0 && d - A.fix_hi_d0 < A.fix_hi_w)
-                            f = A.fix_hi + ((size_t)oi * A.fix_hi_w + (d - A.fix_hi_d0)) * 4;
-                    }
-                    if (f) {
-                        nmv += f[0];
-                        ka += f[1];
-                        kb += f[2];
-                    }
-                }
+                const TC nmv = nm[c] + fx[c][0], ka = kav[c] + fx[c][1], kb = kbv[c] + fx[c][2];
                 if constexpr (sizeof(TC) == 4) {
-                    r = pearson_masked_f32(csv[c], s1[c], s2[c], nmv, ka, kb, A.ks);
+                    r = pearson_masked_lean(csv[c], s1[c], s2[c], nmv, ka, kb, A.ks);
                 } else {
                     TC nobs;
                     r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nmv, ka, kb, A.ks, true, &nobs);
                 }
             } else if constexpr (MASKED) {
                 if constexpr (sizeof(TC) == 4) {
-                    r = pearson_masked_f32(csv[c], s1[c], s2[c], nm[c], kav[c], kbv[c], A.ks);
+                    r = pearson_masked_lean(csv[c], s1[c], s2[c], nm[c], kav[c], kbv[c], A.ks);
                 } else {
                     TC nobs;
                     r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], nm[c], kav[c], kbv[c], A.ks, true, &nobs);
                 }
             } else if constexpr (sizeof(TC) == 4) {
-                r = pearson_nomask_f32(csv[c], s1[c], s2[c], A.ks);
+                r = pearson_nomask_lean(csv[c], s1[c], s2[c], A.ks);
             } else {
                 TC nobs;
                 r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], TC(0), TC(0), TC(0), A.ks, false, &nobs);
@@ -867,6 +914,22 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         out_idx += out_step;
         d_out -= 1;
     };
+
+    // MODE 2: per-row terms of the factorised mask sums {nr, RA, RB, window row flags} of 64
+    // consecutive output rows, one row per lane (cs_mask_prep.hip rowtab[row][0..3]); the row loop reads
+    // them with v_readlane instead of scalar loads from a table that never stays in the scalar cache
+    // (their full latency used to sit on the critical path of every iteration).
+    TC hdr[4] = {TC(0), TC(0), TC(0), TC(0)};
+    int hdr_base = i0;
+    auto hdr_load = [&]() {
+        if constexpr (REG) {
+            const int row = min(hdr_base + lane, A.ms - 1);
+            const TC* src = A.rowtab + (size_t)row * kRowTabStride;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hdr[e] = src[e];
+        }
+    };
+    hdr_load();
 
     // two staged rows (A = t, B = t + 1) per iteration; a virtual zero row pads an odd count.
     // The row registers of the next iteration are loaded from LDS right after the FMAs of this one
@@ -920,6 +983,15 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         fetch(t + 2, nx0);
         fetch(t + 3, nx1);
 
+        TC fxA[2][3] = {{TC(0), TC(0), TC(0)}, {TC(0), TC(0), TC(0)}}, fxB[2][3] = {{TC(0), TC(0), TC(0)}, {TC(0), TC(0), TC(0)}};
+        if constexpr (REG) {
+            if (strip_needs_fix && t >= K - 1) {
+                const int oi = i0 + t - (K - 1);
+                fix_fetch(oi, d_out, fxA);
+                fix_fetch(oi + 1, d_out - 1, fxB);
+            }
+        }
+
         acc_t<TC> outA, outB;
         // template rows that reach output rows of the strip (see steps2_rec)
         const int q_need = __builtin_amdgcn_readfirstlane(min(min((K + 1) / 2, t + 2), K - max(0, t - rows_out + 1)));
@@ -952,34 +1024,37 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
             const int oi = i0 + t - (K - 1);
             const TC sB1[2] = {(TC)b1[0], (TC)b1[1]}, sB2[2] = {(TC)b2[0], (TC)b2[1]};
             if constexpr (REG) {
-                // row terms (wave-uniform scalar loads); the cross product only where a flagged
-                // row is in reach of the output row
-                const int oiB = min(oi + 1, A.ms - 1);
-                ConstPtr<TC> rtA = (ConstPtr<TC>)(A.rowtab + (size_t)oi * kRowTabStride);
-                ConstPtr<TC> rtB = (ConstPtr<TC>)(A.rowtab + (size_t)oiB * kRowTabStride);
-                const TC nrA = rtA[0], raA = rtA[1], rbA = rtA[2];
-                const TC nrB = rtB[0], raB = rtB[1], rbB = rtB[2];
+                // row terms from the lane-resident header chunk
+                if (oi >= hdr_base + kWave) {            // wave-uniform: every 32 iterations
+                    hdr_base += kWave;
+                    hdr_load();
+                }
+                const int la = oi - hdr_base;            // even, so la + 1 stays inside the chunk
+                const TC nrA = lane_value(hdr[0], la), raA = lane_value(hdr[1], la), rbA = lane_value(hdr[2], la);
+                const TC nrB = lane_value(hdr[0], la + 1), raB = lane_value(hdr[1], la + 1), rbB = lane_value(hdr[2], la + 1);
+                const unsigned bitsA = (unsigned)lane_value(hdr[3], la), bitsB = (unsigned)lane_value(hdr[3], la + 1);
                 acc_t<TC> xaA = acc_zero<TC>(), xbA = acc_zero<TC>(), xaB = acc_zero<TC>(), xbB = acc_zero<TC>();
-                if ((nrA != TC(0)) | (nrB != TC(0))) {
+                if (bitsA | bitsB) {
+                    // cross term sum_kj c[j+kj] U_i[kj] = sum over the flagged rows ki of the window of
+                    // (column flags (*) template row ki), with the template rows read from the weight
+                    // sets themselves: they are hot in the scalar cache, the per-row U vectors were not
                     RowRegs<TC, K> cf;
                     cf.load(cfl + lane * 2);
-                    // four K-term products against the row's U vectors; two scalar buffers so that
-                    // only two of the four scalar-load latencies are exposed
-                    WRow<TC, K> wu0, wu1;
-                    const unsigned long long bA = (unsigned long long)(uintptr_t)(A.rowtab + (size_t)oi * kRowTabStride);
-                    const unsigned long long bB = (unsigned long long)(uintptr_t)(A.rowtab + (size_t)oiB * kRowTabStride);
-                    wu0.template issue<kRowTabUA * (int)sizeof(TC)>(bA);
-                    wu1.template issue<kRowTabUB * (int)sizeof(TC)>(bA);
-                    wu0.wait();
-                    wu1.wait();
-                    one_chain<0, TC, K>(cf, wu0, xaA);
-                    wu0.template issue<kRowTabUA * (int)sizeof(TC)>(bB);
-                    one_chain<0, TC, K>(cf, wu1, xbA);
-                    wu1.template issue<kRowTabUB * (int)sizeof(TC)>(bB);
-                    wu0.wait();
-                    wu1.wait();
-                    one_chain<0, TC, K>(cf, wu0, xaB);
-                    one_chain<0, TC, K>(cf, wu1, xbB);
+                    auto cross = [&](unsigned bits, acc_t<TC>& xa, acc_t<TC>& xb) {
+                        while (bits) {
+                            const int ki = __builtin_ctz(bits);
+                            bits &= bits - 1;
+                            WRow<TC, K> wa, wb;
+                            wa.issue_at(A.w, (unsigned)((K * K + ki * K) * sizeof(TC)));
+                            wb.issue_at(A.w, (unsigned)((2 * K * K + ki * K) * sizeof(TC)));
+                            wa.wait();
+                            wb.wait();
+                            one_chain<0, TC, K>(cf, wa, xa);
+                            one_chain<0, TC, K>(cf, wb, xb);
+                        }
+                    };
+                    cross(bitsA, xaA, xbA);
+                    cross(bitsB, xaB, xbB);
                 }
                 TC nA[2], nB[2];
 #pragma unroll
@@ -991,11 +1066,11 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 kbA.x = rbA + cb_col[0] - xbA.x;  kbA.y = rbA + cb_col[1] - xbA.y;
                 kaB.x = raB + ca_col[0] - xaB.x;  kaB.y = raB + ca_col[1] - xaB.y;
                 kbB.x = rbB + cb_col[0] - xbB.x;  kbB.y = rbB + cb_col[1] - xbB.y;
-                emit(oi, outA, sA1, sA2, nA, kaA, kbA);
-                emit(oi + 1, outB, sB1, sB2, nB, kaB, kbB);
+                emit(oi, outA, sA1, sA2, nA, kaA, kbA, fxA);
+                emit(oi + 1, outB, sB1, sB2, nB, kaB, kbB, fxB);
             } else {
-                emit(oi, outA, sA1, sA2, nmA, kaA, kbA);
-                emit(oi + 1, outB, sB1, sB2, nmiss, kaB, kbB);
+                emit(oi, outA, sA1, sA2, nmA, kaA, kbA, fxA);
+                emit(oi + 1, outB, sB1, sB2, nmiss, kaB, kbB, fxB);
             }
         }
         if constexpr (!PIPE) advance();

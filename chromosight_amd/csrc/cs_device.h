@@ -39,6 +39,13 @@ struct KernelStats {
     T thr;      // 1e-4
     T eps;      // 1e-10
     T cut;      // int((1 - missing_tol) * n) as a float
+    // derived constants of the lean float32 epilogues (filled by cs_api.cpp build_args)
+    T thr_n;    // thr * n: |sum| below it <=> |mean| below the reference's 1e-4 zeroing threshold
+    T nkvar;    // n * kvar = sum of the squared centred template
+    T eps2;     // eps^2
+    T den2_min; // eps^2 * n^2: (s2 n - s1^2) kvar below it <=> unmasked denominator below eps
+    int zk_possible;    // a mask-weighted template sum can fall under thr (some |K'| or K'^2 entry is tiny)
+    int snap_possible;  // the template variance over the present pixels can degenerate (few distinct values)
 };
 
 // Arguments of the tile kernels.  Weights live in a small device buffer:
@@ -260,6 +267,54 @@ __device__ __forceinline__ float pearson_nomask_f32(float cs, float s1, float s2
     r = (fabsf(den) < K.eps) ? 0.0f : r;
     r = (fabsf(r) <= 3.0e38f) ? r : 0.0f;                           // NaN / inf -> 0
     return fminf(fmaxf(r, -1.0f), 1.0f);
+}
+
+// Lean float32 epilogues of the streaming kernels.  Away from the reference's zeroing thresholds the
+// whole normalisation collapses into one reciprocal square root:
+//   no mask:  r = (cs / n) / (sqrt(s2/n - (s1/n)^2) kstd)       = cs * rsq((s2 n - s1^2) kvar)
+//   masked:   r = ((cs + s1 ka/np) / np) / sqrt(var_w kvar_w)   = (cs np + s1 ka) * rsq(A B),
+//             A = s2 np - s1^2,  B = (n kvar - kb) np - ka^2,   np = n - nm
+// (centred mask sums ka, kb as in pearson_from_sums<float>).  A pixel whose window mean, mean square
+// or raw correlation is under the 1e-4 threshold -- or, with a mask, whose mask-weighted template
+// sums are -- takes the literal per-pixel function instead; such pixels are rare (near-empty
+// windows), so the branch is almost never entered by any lane of a wave.
+__device__ __forceinline__ float pearson_nomask_f32(float cs, float s1, float s2, const KernelStats<float>& K);
+__device__ __forceinline__ float pearson_masked_f32(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                    const KernelStats<float>& K);
+
+__device__ __forceinline__ float pearson_nomask_lean(float cs, float s1, float s2, const KernelStats<float>& K)
+{
+    const float A = fmaf(s2, K.n, -s1 * s1);
+    const float den2 = A * K.kvar;
+    float r = cs * __builtin_amdgcn_rsqf(den2);
+    r = (den2 >= K.den2_min) ? r : 0.0f;                 // denominator under eps, NaN -> 0
+    r = __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
+    const bool normal = (int)(fabsf(s1) >= K.thr_n) & (int)(s2 >= K.thr_n) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= K.thr_n);
+    if (!normal) r = pearson_nomask_f32(cs, s1, s2, K);
+    return r;
+}
+
+__device__ __forceinline__ float pearson_masked_lean(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                     const KernelStats<float>& K)
+{
+    const float np = K.n - nm;
+    const float num = fmaf(cs, np, s1 * ka);
+    const float A = fmaf(s2, np, -s1 * s1);
+    float B = fmaf(K.nkvar - kb, np, -ka * ka);
+    const float np2 = np * np;
+    if (K.snap_possible) B = (B < 1e-5f * K.kvar * np2) ? 0.0f : B;    // wave-uniform branch
+    const float den2 = A * B;
+    float r = num * __builtin_amdgcn_rsqf(den2);
+    r = ((den2 >= K.eps2 * np2 * np2) & (np >= K.cut)) ? r : 0.0f;    // eps, missing_tol cut, NaN -> 0
+    r = __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
+    bool normal = (int)(fabsf(s1) >= K.thr_n) & (int)(s2 >= K.thr_n) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= K.thr_n);
+    if (K.zk_possible) {
+        const float km_ = fmaf(K.kmean, nm, ka);
+        const float k2m = kb + 2.0f * K.kmean * ka + K.kmean * K.kmean * nm;
+        normal &= (nm < 0.5f) || ((fabsf(km_) >= K.thr) && (fabsf(k2m) >= K.thr));
+    }
+    if (!normal) r = pearson_masked_f32(cs, s1, s2, nm, ka, kb, K);
+    return r;
 }
 
 // Masked branch for the float32 streaming kernels: the arithmetic of pearson_from_sums<float>

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void mask_rowcol_tables_kernel(const uint8_t* 
         row[0] = (TC)nr;
         row[1] = ra;
         row[2] = rb;
-        row[3] = TC(0);
+        row[3] = (TC)bits;   // flagged rows of the window as a number (17 bits: exact in float32)
 #pragma unroll
         for (int kj = 0; kj < kMaxK; ++kj) {
             row[kRowTabUA + kj] = ua[kj];

@@ -212,6 +212,7 @@ def test_two_ranks_equal_single_process(tmp_path):
     both = np.load(out)
     assert both.shape == single.shape
     assert np.array_equal(both[:, [0, 1, 2, 5, 6]], single[:, [0, 1, 2, 5, 6]])
-    # iteration 0 is bit-identical; iteration 1 uses a pileup summed in another order (1e-16 level)
-    assert np.array_equal(both[both[:, 6] == 0], single[single[:, 6] == 0])
+    # scores agree to rounding: the distance law is a float64 atomic reduction (order-dependent at the
+    # 1e-16 level) and the second template is a pileup summed in another order
     assert np.abs(both[:, 3] - single[:, 3]).max() < 1e-9
+    assert np.allclose(both[:, 4], single[:, 4], rtol=1e-6, atol=1e-300)

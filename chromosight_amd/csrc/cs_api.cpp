@@ -216,13 +216,12 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     }
     const int top = KH;
     auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };   // elements
-    const size_t n_row = align((size_t)A.ms * 64 + 64), n_col = align(3 * (size_t)A.ns);
+    const size_t n_row = align((size_t)A.ms * 4 + 64), n_col = align(3 * (size_t)A.ns);
     const size_t n_lo = edge_tables ? align((size_t)A.ms * (K - 1) * 4) : 0;
     const size_t n_hi = edge_tables ? align((size_t)A.ms * hi_w * 4 + 4) : 0;
     const size_t n_frows = align((size_t)(top + A.ms - bot0) * width * 4);
     const size_t n_fcols = side ? align((size_t)A.ms * 2 * side * 4) : 0;
-    const size_t n_bits = align(((size_t)A.ms + A.ns) * sizeof(unsigned) / sizeof(TC) + 2);
-    const size_t bytes = (n_row + n_col + n_lo + n_hi + n_frows + n_fcols + n_bits) * sizeof(TC);
+    const size_t bytes = (n_row + n_col + n_lo + n_hi + n_frows + n_fcols) * sizeof(TC);
     if (bytes > ctx->d_ws_bytes) {
         if (ctx->d_ws) CS_HIP(ctx, hipFree(ctx->d_ws));
         ctx->d_ws = nullptr;
@@ -236,18 +235,34 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     TC* fix_hi = fix_lo + n_lo;
     TC* fix_rows = fix_hi + n_hi;
     TC* fix_cols = side ? fix_rows + n_frows : nullptr;
-    unsigned* rbits = reinterpret_cast<unsigned*>(fix_rows + n_frows + n_fcols);
-    unsigned* cbits = rbits + A.ms;
-    int rc = cs::launch_mask_tables<TC>(A.miss_row, A.miss_col, A.ms, A.ns, K, A.w, rowtab, coltab, rbits, cbits, stream);
+    cs::MaskPrepArgs<TC> P;
+    std::memset(&P, 0, sizeof(P));
+    P.rr = A.miss_row;
+    P.cc = A.miss_col;
+    P.ms = A.ms;
+    P.ns = A.ns;
+    P.K = K;
+    P.sym_upper = A.sym_upper;
+    P.max_dist = A.max_dist;
+    P.w = A.w;
+    P.rowtab = rowtab;
+    P.coltab = coltab;
+    P.edge = edge_tables ? 1 : 0;
+    P.hi_d0 = hi_d0;
+    P.hi_w = hi_w;
+    P.fix_lo = fix_lo;
+    P.fix_hi = fix_hi;
+    P.top = top;
+    P.bot0 = bot0;
+    P.width = width;
+    P.x_band = band_out ? 1 : 0;
+    P.x_lo = A.out_lo;
+    P.side = side;
+    P.fix_rows = fix_rows;
+    P.fix_cols = fix_cols;
+    int rc = cs::launch_mask_prep<TC>(P, stream);
     if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
-    if (edge_tables) {
-        rc = cs::launch_mask_edge_fix<TC>(rbits, cbits, A.ms, A.ns, K, A.max_dist, hi_d0, hi_w, A.w, fix_lo, fix_hi, stream);
-        if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask edge kernel failed: %s", hipGetErrorString((hipError_t)rc));
-        A.fix_on = 1;
-    }
-    rc = cs::launch_mask_frame_fix<TC>(rbits, cbits, A.ms, A.ns, K, A.sym_upper, A.max_dist, A.w, top, bot0, width,
-                                       band_out ? 1 : 0, A.out_lo, side, fix_rows, fix_cols, stream);
-    if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask frame kernel failed: %s", hipGetErrorString((hipError_t)rc));
+    if (edge_tables) A.fix_on = 1;
     A.reg_mode = 1;
     A.rowtab = rowtab;
     A.coltab = coltab;

@@ -574,8 +574,7 @@ struct StreamArgs {
     KernelStats<TC> ks;
 };
 
-constexpr int kRowTabStride = 64;   // elements per row of rowtab: nr, RA, RB, -, UA[K] at 4, UB[K] at 24
-constexpr int kRowTabUA = 4, kRowTabUB = 24;
+constexpr int kRowTabStride = 4;    // elements per row of rowtab: nr, RA, RB, flags of the window rows
 
 // framed missing predicate (same rules as cs_device.h missing_pred) on the lean argument block
 template <typename TC, int K>
@@ -816,23 +815,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         }
     };
 
-    // box-sum cache: slot (row mod K) holds the sums of the row that leaves the window when the
-    // row with the same index mod K enters: read them, then store the entering row's sums
-    auto hcache_swap = [&](int slot, const TC (&h1)[2], const TC (&h2)[2], TC (&g1)[2], TC (&g2)[2]) {
-        typedef TC v4 __attribute__((ext_vector_type(4)));
-        v4* cell = reinterpret_cast<v4*>(hcache + (slot * kWave + lane) * 4);
-        const v4 old = *cell;
-        v4 cur;
-        cur.x = h1[0];
-        cur.y = h1[1];
-        cur.z = h2[0];
-        cur.w = h2[1];
-        *cell = cur;
-        g1[0] = old.x;
-        g1[1] = old.y;
-        g2[0] = old.z;
-        g2[1] = old.w;
-    };
+    // box-sum cache (HCACHE): slot (row mod K) holds the sums of the row that leaves the window when
+    // the row with the same index mod K enters; the row loop reads them, then stores the entering row's
 
     auto row_flags = [&](const RowRegs<TC, K>& r, TC (&cnt)[2]) {
         TC c0 = missing_flag(r.at(0));
@@ -857,7 +841,9 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 const int j = oj0 + c;
                 const int x = A.fix_xband ? d - A.fix_xlo : j;
                 if (oi < A.fix_top) f = A.fix_rows + ((size_t)oi * A.fix_width + x) * 4;
-                else if (oi >= A.fix_bot0) f = A.fix_rows + ((size_t)(A.fix_top + oi - A.fix_bot0) * A.fix_width + x) * 4;
+                // with edge tables the frame table only holds the pixels whose window leaves the matrix
+                else if (oi >= A.fix_bot0 && (!A.fix_on || (oi + KH >= A.ms) | (j + KH >= A.ns)))
+                    f = A.fix_rows + ((size_t)(A.fix_top + oi - A.fix_bot0) * A.fix_width + x) * 4;
                 else if (A.fix_cols && (j < A.fix_side || j >= A.ns - A.fix_side))
                     f = A.fix_cols + ((size_t)oi * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side))) * 4;
                 else if (A.fix_on) {
@@ -949,12 +935,39 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         // box sums of the two entering rows minus the two leaving rows
         TC sA1[2], sA2[2];
         TC nmA[2] = {TC(0), TC(0)};
-        {
+        if constexpr (HCACHE) {
+            // both cache cells are read before the sums of the entering rows are formed, so the LDS
+            // latency overlaps those ~50 VALU ops instead of preceding the running-sum update
+            typedef TC v4 __attribute__((ext_vector_type(4)));
+            const int slot_b = slot_old + 1 >= K ? slot_old + 1 - K : slot_old + 1;
+            v4* cell_a = reinterpret_cast<v4*>(hcache + (slot_old * kWave + lane) * 4);
+            v4* cell_b = reinterpret_cast<v4*>(hcache + (slot_b * kWave + lane) * 4);
+            const v4 old_a = *cell_a, old_b = *cell_b;
+            TC hA1[2], hA2[2], hB1[2], hB2[2];
+            row_box_packed<K>(ra, hA1, hA2);
+            row_box_packed<K>(rb, hB1, hB2);
+            v4 cur_a, cur_b;
+            cur_a.x = hA1[0]; cur_a.y = hA1[1]; cur_a.z = hA2[0]; cur_a.w = hA2[1];
+            cur_b.x = hB1[0]; cur_b.y = hB1[1]; cur_b.z = hB2[0]; cur_b.w = hB2[1];
+            *cell_a = cur_a;
+            *cell_b = cur_b;
+            b1[0] += (double)(hA1[0] - old_a.x);
+            b1[1] += (double)(hA1[1] - old_a.y);
+            b2[0] += (double)(hA2[0] - old_a.z);
+            b2[1] += (double)(hA2[1] - old_a.w);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                sA1[c] = (TC)b1[c];
+                sA2[c] = (TC)b2[c];
+            }
+            b1[0] += (double)(hB1[0] - old_b.x);
+            b1[1] += (double)(hB1[1] - old_b.y);
+            b2[0] += (double)(hB2[0] - old_b.z);
+            b2[1] += (double)(hB2[1] - old_b.w);
+        } else {
             TC h1[2], h2[2], g1[2], g2[2], gc[2] = {TC(0), TC(0)}, hc[2] = {TC(0), TC(0)};
-            if constexpr (HCACHE) row_box_packed<K>(ra, h1, h2);
-            else row_box<TC, K>(ra, h1, h2);
-            if constexpr (HCACHE) hcache_swap(slot_old, h1, h2, g1, g2);
-            else row_sums(slot_old, g1, g2, gc);
+            row_box<TC, K>(ra, h1, h2);
+            row_sums(slot_old, g1, g2, gc);
             if constexpr (MASKED) row_flags(ra, hc);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -965,10 +978,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 nmiss[c] += hc[c] - gc[c];
                 nmA[c] = nmiss[c];
             }
-            if constexpr (HCACHE) row_box_packed<K>(rb, h1, h2);
-            else row_box<TC, K>(rb, h1, h2);
-            if constexpr (HCACHE) hcache_swap(slot_old + 1 >= K ? slot_old + 1 - K : slot_old + 1, h1, h2, g1, g2);
-            else row_sums(ring_next(slot_old, 1), g1, g2, gc);
+            row_box<TC, K>(rb, h1, h2);
+            row_sums(ring_next(slot_old, 1), g1, g2, gc);
             if constexpr (MASKED) row_flags(rb, hc);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {

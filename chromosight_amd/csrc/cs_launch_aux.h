@@ -58,16 +58,24 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
 int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n, int inter,
                      double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream);
 
-// tables of the factorised per-bin mask sums (cs_mask_prep.hip)
+// tables of the factorised per-bin mask sums (cs_mask_prep.hip), one launch
 template <typename TC>
-int launch_mask_tables(const uint8_t* rr, const uint8_t* cc, int ms, int ns, int K, const TC* w, TC* rowtab, TC* coltab,
-                       unsigned* rbits, unsigned* cbits, hipStream_t stream);
+struct MaskPrepArgs {
+    const uint8_t* rr;
+    const uint8_t* cc;
+    int ms, ns, K, sym_upper, max_dist;
+    const TC* w;
+    TC* rowtab;
+    TC* coltab;
+    int edge, hi_d0, hi_w;          // edge corrections (band outputs ending near max_dist)
+    TC* fix_lo;
+    TC* fix_hi;
+    int top, bot0, width, x_band, x_lo, side;   // frame corrections
+    TC* fix_rows;
+    TC* fix_cols;
+    int b_tab, b_edge;              // block ranges (filled by the launcher)
+};
 template <typename TC>
-int launch_mask_edge_fix(const unsigned* rbits, const unsigned* cbits, int ms, int ns, int K, int md, int hi_d0, int hi_w,
-                         const TC* w, TC* fix_lo, TC* fix_hi, hipStream_t stream);
-template <typename TC>
-int launch_mask_frame_fix(const unsigned* rbits, const unsigned* cbits, int ms, int ns, int K, int sym_upper, int max_dist,
-                          const TC* w, int top, int bot0, int width, int x_band, int x_lo, int side, TC* fix_rows, TC* fix_cols,
-                          hipStream_t stream);
+int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream);
 
 }  // namespace cs

@@ -24,16 +24,26 @@ namespace cs {
 namespace {
 
 constexpr int kMaxK = 17;
-constexpr int kRowTabStride = 64, kRowTabUA = 4, kRowTabUB = 24;   // keep in sync with cs_corr_stream.h
+constexpr int kRowTabStride = 4;   // {nr, RA, RB, window row flags}; keep in sync with cs_corr_stream.h
+
+// flags of the K bins around `centre` as a bit mask (bit k = flag of bin centre - KH + k, 0 outside 0..n-1)
+__device__ __forceinline__ unsigned window_bits(const uint8_t* __restrict__ flags, int centre, int n, int K)
+{
+    const int KH = (K - 1) / 2;
+    unsigned bits = 0;
+    for (int k = 0; k < K; ++k) {
+        const int p = centre - KH + k;
+        if (p >= 0 && p < n && flags[p] != 0) bits |= 1u << k;
+    }
+    return bits;
+}
 
 template <typename TC>
-__global__ __launch_bounds__(256) void mask_rowcol_tables_kernel(const uint8_t* __restrict__ rr,
-                                                                 const uint8_t* __restrict__ cc, int ms, int ns, int K,
-                                                                 const TC* __restrict__ w, TC* __restrict__ rowtab,
-                                                                 TC* __restrict__ coltab, unsigned* __restrict__ rbits,
-                                                                 unsigned* __restrict__ cbits)
+__device__ __forceinline__ void mask_rowcol_tables(int block, const uint8_t* __restrict__ rr, const uint8_t* __restrict__ cc,
+                                                   int ms, int ns, int K, const TC* __restrict__ w, TC* __restrict__ rowtab,
+                                                   TC* __restrict__ coltab)
 {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int id = block * blockDim.x + threadIdx.x;
     const int KH = (K - 1) / 2, kk = K * K;
     const TC* wa = w + kk;
     const TC* wb = w + 2 * kk;
@@ -62,32 +72,23 @@ __global__ __launch_bounds__(256) void mask_rowcol_tables_kernel(const uint8_t* 
             rb += ub[kj];
         }
         TC* row = rowtab + (size_t)id * kRowTabStride;
-        rbits[id] = bits;   // bit ki = flag of row id - KH + ki (0 outside the matrix)
         row[0] = (TC)nr;
         row[1] = ra;
         row[2] = rb;
         row[3] = (TC)bits;   // flagged rows of the window as a number (17 bits: exact in float32)
-#pragma unroll
-        for (int kj = 0; kj < kMaxK; ++kj) {
-            row[kRowTabUA + kj] = ua[kj];
-            row[kRowTabUB + kj] = ub[kj];
-        }
     } else if (id < ms + ns) {
         const int j = id - ms;
         int nc = 0;
-        unsigned bits = 0;
         TC ca = TC(0), cb = TC(0);
         for (int kj = 0; kj < K; ++kj) {
             const int q = j - KH + kj;
             if (q < 0 || q >= ns || cc[q] == 0) continue;
             ++nc;
-            bits |= 1u << kj;
             for (int ki = 0; ki < K; ++ki) {
                 ca += wa[ki * K + kj];
                 cb += wb[ki * K + kj];
             }
         }
-        cbits[j] = bits;
         coltab[j] = (TC)nc;
         coltab[(size_t)ns + j] = ca;
         coltab[2 * (size_t)ns + j] = cb;
@@ -105,10 +106,9 @@ __global__ __launch_bounds__(256) void mask_rowcol_tables_kernel(const uint8_t* 
 // the correction is a per-diagonal constant minus one term per flagged row / column of the
 // window (0.7 flagged bins per window at 2 % missing bins), instead of a loop over the triangle.
 template <typename TC>
-__global__ __launch_bounds__(256) void mask_edge_fix_kernel(const unsigned* __restrict__ rbits_g,
-                                                            const unsigned* __restrict__ cbits_g, int ms, int ns, int K,
-                                                            int md, int hi_d0, int hi_w, const TC* __restrict__ w,
-                                                            TC* __restrict__ fix_lo, TC* __restrict__ fix_hi)
+__device__ __forceinline__ void mask_edge_fix(int block, int n_blocks, const uint8_t* __restrict__ rr,
+                                              const uint8_t* __restrict__ cc, int ms, int ns, int K, int md, int hi_d0, int hi_w,
+                                              const TC* __restrict__ w, TC* __restrict__ fix_lo, TC* __restrict__ fix_hi)
 {
     constexpr int P = kMaxK + 1;
     // [set 0 = Wa, 1 = Wb]; PW[ki][m] = sum_{kj < m} W[ki][kj], QW[kj][m] = sum_{ki < m} W[ki][kj]
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void mask_edge_fix_kernel(const unsigned* __re
     const int per_row = (K - 1) + hi_w;
     const int KH = (K - 1) / 2;
     // grid-stride: the prefix tables above are built once per block, so a block handles many pixels
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < (long long)ms * per_row;
-         id += (long long)gridDim.x * blockDim.x) {
+    for (long long id = (long long)block * blockDim.x + threadIdx.x; id < (long long)ms * per_row;
+         id += (long long)n_blocks * blockDim.x) {
     const int i = (int)(id / per_row);
     const int e = (int)(id - (long long)i * per_row);
     int D;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void mask_edge_fix_kernel(const unsigned* __re
             fa = base_s[1][D];
             fb = base_s[2][D];
         }
-        const unsigned rbits = rbits_g[i], cbits = cbits_g[j];
+        const unsigned rbits = window_bits(rr, i, ms, K), cbits = window_bits(cc, j, ns, K);
         // flagged rows: every pixel of the row that lies in either triangle
         for (unsigned rb = rbits; rb; rb &= rb - 1) {
             const int ki = __ffs(rb) - 1;
@@ -241,11 +241,10 @@ __device__ __forceinline__ bool missing_bins(int ms, int ns, int K, int sym_uppe
 constexpr int kFramePixPerBlock = 256 / kMaxK;
 
 template <typename TC>
-__global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __restrict__ rbits_g,
-                                                             const unsigned* __restrict__ cbits_g, int ms, int ns, int K,
-                                                             int sym_upper, int max_dist, const TC* __restrict__ w, int top,
-                                                             int bot0, int width, int x_band, int x_lo, int side,
-                                                             TC* __restrict__ fix_rows, TC* __restrict__ fix_cols)
+__device__ __forceinline__ void mask_frame_fix(int block, const uint8_t* __restrict__ rr, const uint8_t* __restrict__ cc, int ms,
+                                               int ns, int K, int sym_upper, int max_dist, const TC* __restrict__ w, int top,
+                                               int bot0, int width, int x_band, int x_lo, int side, int lazy,
+                                               TC* __restrict__ fix_rows, TC* __restrict__ fix_cols)
 {
     __shared__ TC wa_s[kMaxK * kMaxK], wb_s[kMaxK * kMaxK];
     __shared__ TC part[kFramePixPerBlock][kMaxK][3];
@@ -255,20 +254,34 @@ __global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __r
         wb_s[t] = w[2 * kk + t];
     }
     __syncthreads();
-    const int n_rows = top + (ms - bot0);
-    const long long n_row_px = (long long)n_rows * width;
+    const int KHf = (K - 1) / 2;
+    // lazy (band outputs with edge tables): below the top rows only the pixels whose window leaves the
+    // matrix are looked up in this table (cs_corr_stream.h fix_fetch), i.e. the last KH rows and, on the
+    // rows before them, the last KH columns; the other entries are never read and are not computed
+    const int full_bot = lazy ? min(KHf, ms - bot0) : ms - bot0;      // trailing rows computed entirely
+    const int right_rows = lazy ? (ms - bot0) - full_bot : 0;         // rows with only their last KH columns
+    const long long n_top_px = (long long)top * width, n_bot_px = (long long)full_bot * width;
+    const long long n_right_px = (long long)right_rows * KHf;
+    const long long n_row_px = n_top_px + n_bot_px + n_right_px;
     const long long n_col_px = fix_cols ? (long long)ms * 2 * side : 0;
     const int slot = threadIdx.x / kMaxK, ki = threadIdx.x % kMaxK;
-    const long long id = (long long)blockIdx.x * kFramePixPerBlock + slot;
-    const bool live = slot < kFramePixPerBlock && id < n_row_px + n_col_px;
+    const long long id = (long long)block * kFramePixPerBlock + slot;
+    bool live = slot < kFramePixPerBlock && id < n_row_px + n_col_px;
     int i = 0, j = -1;
     TC* dst = nullptr;
     if (live) {
-        if (id < n_row_px) {
+        if (id < n_top_px + n_bot_px) {
             const int r = (int)(id / width), x = (int)(id - (long long)r * width);
-            i = r < top ? r : bot0 + (r - top);
+            i = r < top ? r : (ms - full_bot) + (r - top);
             j = x_band ? i + x_lo + x : x;
-            dst = fix_rows + id * 4;
+            dst = fix_rows + ((long long)(i < top ? i : top + (i - bot0)) * width + x) * 4;
+        } else if (id < n_row_px) {
+            const long long c = id - n_top_px - n_bot_px;
+            i = bot0 + (int)(c / KHf);
+            j = ns - KHf + (int)(c % KHf);
+            const int x = x_band ? j - i - x_lo : j;
+            live = x >= 0 && x < width;
+            dst = fix_rows + ((long long)(top + (i - bot0)) * width + (live ? x : 0)) * 4;
         } else {
             const long long c = id - n_row_px;
             i = (int)(c / (2 * side));
@@ -280,9 +293,9 @@ __global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __r
     const int KH = (K - 1) / 2;
     TC fn = TC(0), fa = TC(0), fb = TC(0);
     if (live && ki < K && j >= 0 && j < ns) {
-        const unsigned rbits = rbits_g[i], cbits = cbits_g[j];
+        const unsigned cbits = window_bits(cc, j, ns, K);
         const int p = i - KH + ki;
-        const bool rflag = (rbits >> ki) & 1u;
+        const bool rflag = p >= 0 && p < ms && rr[p] != 0;
         for (int kj = 0; kj < K; ++kj) {
             const bool cflag = (cbits >> kj) & 1u;
             const int f = (missing_bins(ms, ns, K, sym_upper, max_dist, p, j - KH + kj, rflag, cflag) ? 1 : 0) -
@@ -314,52 +327,48 @@ __global__ __launch_bounds__(256) void mask_frame_fix_kernel(const unsigned* __r
     }
 }
 
+// All tables of one call in ONE launch: the three parts read only the flag vectors and the weights,
+// so their blocks are independent and run side by side (three dependent launches used to cost 60 us
+// of a 270 us call on a 50 000-bin band).  Blocks [0, b_tab) build the row / column tables,
+// [b_tab, b_tab + b_edge) the edge corrections, the rest the frame corrections.
+template <typename TC>
+__global__ __launch_bounds__(256) void mask_prep_kernel(MaskPrepArgs<TC> P)
+{
+    const int b = blockIdx.x;
+    if (b < P.b_tab) {
+        mask_rowcol_tables<TC>(b, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab);
+    } else if (b < P.b_tab + P.b_edge) {
+        mask_edge_fix<TC>(b - P.b_tab, P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.max_dist, P.hi_d0, P.hi_w, P.w, P.fix_lo,
+                          P.fix_hi);
+    } else {
+        mask_frame_fix<TC>(b - P.b_tab - P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.sym_upper, P.max_dist, P.w, P.top, P.bot0,
+                           P.width, P.x_band, P.x_lo, P.side, P.edge, P.fix_rows, P.fix_cols);
+    }
+}
+
 }  // namespace
 
 template <typename TC>
-int launch_mask_tables(const uint8_t* rr, const uint8_t* cc, int ms, int ns, int K, const TC* w, TC* rowtab, TC* coltab,
-                       unsigned* rbits, unsigned* cbits, hipStream_t stream)
+int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream)
 {
-    if (K > kMaxK) return -1;
-    const int n = ms + ns;
-    hipLaunchKernelGGL(mask_rowcol_tables_kernel<TC>, dim3((n + 255) / 256), dim3(256), 0, stream, rr, cc, ms, ns, K, w, rowtab,
-                       coltab, rbits, cbits);
+    if (P.K > kMaxK) return -1;
+    P.b_tab = (P.ms + P.ns + 255) / 256;
+    P.b_edge = 0;
+    if (P.edge) {
+        const long long n = (long long)P.ms * ((P.K - 1) + P.hi_w);
+        P.b_edge = (int)std::min<long long>((n + 255) / 256, 4096);
+    }
+    const int KH = (P.K - 1) / 2;
+    const int full_bot = P.edge ? std::min(KH, P.ms - P.bot0) : P.ms - P.bot0;
+    const long long n_frame = (long long)(P.top + full_bot) * P.width +
+                              (P.edge ? (long long)((P.ms - P.bot0) - full_bot) * KH : 0) +
+                              (P.fix_cols ? (long long)P.ms * 2 * P.side : 0);
+    const long long b_frame = n_frame > 0 ? (n_frame + kFramePixPerBlock - 1) / kFramePixPerBlock : 0;
+    hipLaunchKernelGGL(mask_prep_kernel<TC>, dim3((unsigned)(P.b_tab + P.b_edge + b_frame)), dim3(256), 0, stream, P);
     return (int)hipGetLastError();
 }
 
-template <typename TC>
-int launch_mask_edge_fix(const unsigned* rbits, const unsigned* cbits, int ms, int ns, int K, int md, int hi_d0, int hi_w,
-                         const TC* w, TC* fix_lo, TC* fix_hi, hipStream_t stream)
-{
-    const long long n = (long long)ms * ((K - 1) + hi_w);
-    const long long blocks = std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(mask_edge_fix_kernel<TC>, dim3((unsigned)blocks), dim3(256), 0, stream, rbits, cbits, ms, ns, K,
-                       md, hi_d0, hi_w, w, fix_lo, fix_hi);
-    return (int)hipGetLastError();
-}
-
-template <typename TC>
-int launch_mask_frame_fix(const unsigned* rbits, const unsigned* cbits, int ms, int ns, int K, int sym_upper, int max_dist,
-                          const TC* w, int top, int bot0, int width, int x_band, int x_lo, int side, TC* fix_rows, TC* fix_cols,
-                          hipStream_t stream)
-{
-    const long long n = (long long)(top + (ms - bot0)) * width + (fix_cols ? (long long)ms * 2 * side : 0);
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(mask_frame_fix_kernel<TC>, dim3((unsigned)((n + kFramePixPerBlock - 1) / kFramePixPerBlock)), dim3(256), 0,
-                       stream, rbits, cbits, ms, ns, K,
-                       sym_upper, max_dist, w, top, bot0, width, x_band, x_lo, side, fix_rows, fix_cols);
-    return (int)hipGetLastError();
-}
-
-#define CS_INST(TC)                                                                                                         \
-    template int launch_mask_tables<TC>(const uint8_t*, const uint8_t*, int, int, int, const TC*, TC*, TC*, unsigned*,      \
-                                        unsigned*, hipStream_t);                                                            \
-    template int launch_mask_edge_fix<TC>(const unsigned*, const unsigned*, int, int, int, int, int, int, const TC*, TC*,    \
-                                          TC*, hipStream_t);                                                                \
-    template int launch_mask_frame_fix<TC>(const unsigned*, const unsigned*, int, int, int, int, int, const TC*, int, int,   \
-                                           int, int, int, int, TC*, TC*, hipStream_t);
-CS_INST(float)
-CS_INST(double)
-#undef CS_INST
+template int launch_mask_prep<float>(MaskPrepArgs<float>, hipStream_t);
+template int launch_mask_prep<double>(MaskPrepArgs<double>, hipStream_t);
 
 }  // namespace cs

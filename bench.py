@@ -9,9 +9,11 @@ contact map already resident in HBM.
 
 Workloads:
   c2   (default) dense 4096x4096 float32, gamma(4, 0.25), seed 0; normxcorr2(full=False, no mask)
-  c3   N=50000 upper band (diagonals 0..249), 2 % missing bins, seed 1; band layout,
-       normxcorr2(full=True, sym_upper, mask, max_dist=233, missing_tol=0.5)
-  c4p  N=200000 single block, band to max_dist=1000 (+17), seed 2; same mode as c3
+  c3   C3 as BASELINE.md defines it: N=50000 pixel table (CSR) resident in HBM, raw poisson(200/(d+1))
+       counts on diagonals 0..250, 2 % unbalanced bins, seed 1; one step = band extents + distance law +
+       fused detrend / CSR->band tiler + normxcorr2(full=True, sym_upper, mask, max_dist=233)
+  c3k  the correlation call of c3 alone on a pre-tiled float32 band (kernel + mask tables)
+  c4p  N=200000 single block, band to max_dist=1000 (+17), seed 2; same call as c3k
   c4   end to end, not kernel-only: 200000 bins in 23 blocks (hg38 proportions), max_dist=1000,
        planted loops; one step = block preparation (balance, distance law, detrend) + pattern_detector
        (correlation, thresholding, foci, validation) of every block, blocks sharded over the GPUs,
@@ -46,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4p", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3k", "c4p", "c4"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=4096, help="c2 only: side of the dense map (default 4096)")
@@ -85,9 +87,31 @@ class Workload:
             self.bytes_per_pixel = 4 + np.dtype(out_dtype).itemsize
             self.desc = (f"C2: dense {n}x{n} float32 gamma(4,0.25) seed 0, 17x17 loops template, "
                          "normxcorr2(full=False, no mask)")
+        elif name == "c3":
+            # CSR in, detrend included (two passes over nnz * 8 B + 4 B per pixel written)
+            from chromosight_amd import pipeline
+            from tools.synthetic_genome import make_cool
+            n, max_dist = 50_000, 233
+            cool, _ = make_cool(n, max_dist, 2000, seed=1 + rank, loops_per_10k=0, chrom_sizes=[n])
+            self.dcool = pipeline.DeviceCool(cool, dev)
+            self.max_dist = max_dist
+            self.shape = (n, n)
+            out_w = max_dist + 1
+            ld_out = (out_w + 63) // 64 * 64
+            self.out_buf = dev.zeros((n, ld_out), out_dtype)
+            self.out = CsMatrix(self.out_buf.ptr, np_dtype_code(out_dtype), LAYOUT_BAND, ld_out, 0, out_w)
+            self.kwargs = dict(full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, missing_tol=0.5)
+            self.pixels = n * out_w
+            self.nnz = self.dcool.nnz
+            self.bytes_per_pixel = (2 * self.nnz * 8 + 4 * (n + 1) * 2) / self.pixels + np.dtype(out_dtype).itemsize
+            self.desc = (f"C3: N={n} pixel table (CSR, {self.nnz} stored pixels on diagonals 0..{max_dist + 17}, raw "
+                         "poisson counts, 2% unbalanced bins) resident in HBM; per step: band extents + distance law "
+                         "+ fused detrend/CSR->band tiler (float32 band) + normxcorr2(full=True, sym_upper, mask, "
+                         f"max_dist={max_dist}, missing_tol=0.5), 17x17 loops template")
+            self.host_sig = None
         else:
             from tools.synthetic_genome import band_workload
-            band, band_w_in, miss, n, max_dist = band_workload(name, rank)
+            band, band_w_in, miss, n, max_dist = band_workload("c3" if name == "c3k" else name, rank)
             keep = max_dist + 17
             ld_in = band.shape[1]
             self.shape = (n, n)
@@ -108,6 +132,11 @@ class Workload:
             self.host_sig = None
 
     def step(self):
+        if self.name == "c3":
+            block = self.dcool.stage_intra(0, self.max_dist, 17, band_dtype=np.float32)
+            self.engine.run_normxcorr2(self.dev, block.sig, self.shape, self.kspec, self.out, precision=self.precision,
+                                       miss_row=block.miss_row, miss_col=block.miss_col, **self.kwargs)
+            return
         self.engine.run_normxcorr2(self.dev, self.sig, self.shape, self.kspec, self.out,
                                    precision=self.precision, **self.kwargs)
 
@@ -134,6 +163,23 @@ def cpu_baseline(workload, budget_s=12.0):
         "sample": f"{passes} passes over the first {rows} rows of the same map ({sample.size / 1e6:.2f} Mpixel "
                   f"each), float64 C restatement oracle/oracle.c, OpenMP x{threads}, {dt:.1f} s",
     }
+
+
+def api_call_ms(workload):
+    """PCIe-inclusive cost of the reference-shaped Python call on the same map (host ndarray in, host
+    float64 ndarray out): never `value`, reported next to it."""
+    if workload.host_sig is None:
+        return None
+    from chromosight_amd.utils import detection as cud
+    k = loops_kernel()
+    cud.normxcorr2(workload.host_sig, k)
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        out, _ = cud.normxcorr2(workload.host_sig, k)
+        best = min(best, time.perf_counter() - t0)
+        del out
+    return round(best * 1e3, 3)
 
 
 def detect_wallclock():
@@ -218,8 +264,8 @@ class GenomeC4:
         return rec_l, rec_b
 
 
-def run_c4(args, rank, local_rank, world, dist, torch):
-    """C4 of BASELINE.md end to end, blocks sharded over the ranks (strong scaling)."""
+def time_genome(args, rank, local_rank, world, dist, torch, steps, warmup):
+    """Time `steps` passes of the sharded C4 genome; returns the summary dict (same on every rank)."""
     g = GenomeC4(args, rank, local_rank, world)
 
     def sync():
@@ -229,11 +275,11 @@ def run_c4(args, rank, local_rank, world, dist, torch):
             torch.cuda.synchronize(local_rank)
 
     rec = None
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         rec = g.step()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         rec = g.step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -241,25 +287,36 @@ def run_c4(args, rank, local_rank, world, dist, torch):
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    pixels = g.loop_pixels + g.border_pixels
+    return {
+        "value": round(pixels * steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "ms_per_genome": round(elapsed / steps * 1e3, 2),
+        "n_gpus": world, "steps": steps, "scaling": "strong",
+        "workload": "C4: 200000 bins in 23 blocks (hg38 proportions), 2 kb bins, max_dist 1000 bins, 2 % unbalanced bins, "
+                    "planted loops, pixel table resident in HBM; per step and per pattern (loops, borders x3): band "
+                    "extents + distance law + detrend/tiler of every block, correlation, device foci + validation "
+                    "statistics, all-gather of the records (RCCL); blocks sharded over the GPUs (LPT)",
+        "correlation_pixels_per_step": pixels, "loop_pixels": g.loop_pixels, "border_pixels": g.border_pixels,
+        "stored_pixels_rank0": g.stored_pixels, "blocks": g.n_chrom,
+        "patterns": {"loops": int(rec[0].shape[0]), "borders": int(rec[1].shape[0])},
+        "setup": {"generate_s": round(g.gen_s, 2), "upload_s": round(g.upload_s, 3),
+                  "upload_bytes_rank0": int(g.dcool.upload_bytes)},
+    }
+
+
+def run_c4(args, rank, local_rank, world, dist, torch):
+    """C4 of BASELINE.md end to end, blocks sharded over the ranks (strong scaling)."""
+    r = time_genome(args, rank, local_rank, world, dist, torch, args.steps, args.warmup)
     if rank == 0:
-        pixels = g.loop_pixels + g.border_pixels
         print(json.dumps({
             "metric": "Mpixels/s detect end to end (C4: 23 blocks, loops + 3 borders templates)",
-            "value": round(pixels * args.steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "n_gpus": world,
-            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic",
-            "config": {"workload": "C4: 200000 bins in 23 blocks (hg38 proportions), 2 kb bins, max_dist 1000 bins, "
-                                   "2 % unbalanced bins, planted loops, pixel table resident in HBM; per step and per "
-                                   "pattern (loops, borders x3): band extents + distance law + detrend/tiler of every "
-                                   "block, correlation, device foci + validation statistics, RCCL all-gather of the "
-                                   "records; blocks sharded over the GPUs (LPT)",
-                       "correlation_pixels_per_step": pixels, "loop_pixels": g.loop_pixels,
-                       "border_pixels": g.border_pixels, "stored_pixels_rank0": g.stored_pixels,
-                       "parallelism": f"{world} rank(s), {g.n_chrom} blocks"},
-            "patterns": {"loops": int(rec[0].shape[0]), "borders": int(rec[1].shape[0])},
-            "setup": {"generate_s": round(g.gen_s, 2), "upload_s": round(g.upload_s, 3),
-                      "upload_bytes_rank0": int(g.dcool.upload_bytes)},
+            "value": r["value"], "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": r["ms_per_genome"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": r["workload"], "correlation_pixels_per_step": r["correlation_pixels_per_step"],
+                       "loop_pixels": r["loop_pixels"], "border_pixels": r["border_pixels"],
+                       "stored_pixels_rank0": r["stored_pixels_rank0"],
+                       "parallelism": f"{world} rank(s), {r['blocks']} blocks"},
+            "patterns": r["patterns"], "setup": r["setup"],
         }))
 
 
@@ -340,6 +397,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    genome = None
+    if not args.no_cpu_baseline and args.workload == "c2":
+        # the sharded end-to-end genome next to the kernel figure, at every N (strong scaling, records
+        # gathered over RCCL): all ranks take part
+        try:
+            genome = time_genome(args, rank, local_rank, world, dist, torch, steps=3, warmup=1)
+        except Exception as exc:
+            genome = {"error": repr(exc)}
+
     if rank == 0:
         total_pixels = wl.pixels * args.steps * world
         value = total_pixels / elapsed / 1e6
@@ -372,11 +438,17 @@ def main():
             },
             "kernel_ms": round(kernel_ms, 4),
         }
+        if genome is not None:
+            out["sharded_genome"] = genome
         if not args.no_cpu_baseline and world == 1:     # reported extras: rank 0 at N = 1 only
             try:
                 out["detect_wallclock"] = detect_wallclock()
             except Exception as exc:
                 out["detect_wallclock"] = {"error": repr(exc)}
+            try:
+                out["api_call_ms"] = api_call_ms(wl)
+            except Exception as exc:
+                out["api_call_ms"] = {"error": repr(exc)}
             try:
                 out["cpu_baseline"] = cpu_baseline(wl)
             except Exception as exc:  # the baseline is a reported extra, never the measured path

@@ -222,8 +222,8 @@ class DeviceBuffer:
         # pageable host memory: the runtime has consumed `array` when the call returns
         return self
 
-    def download(self, stream=None):
-        out = np.empty(self.shape, dtype=self.dtype)
+    def download(self, stream=None, pinned=False):
+        out = self.device.pinned_result(self.shape, self.dtype) if pinned else np.empty(self.shape, dtype=self.dtype)
         self.device._check(self.device.lib.cs_memcpy_d2h(
             self.device.ctx, out.ctypes.data, self.ptr, self.nbytes, stream))
         return out
@@ -254,6 +254,20 @@ class PinnedArray:
         except Exception:
             pass
         self.ptr = None
+
+
+class _PinnedLease:
+    """Returns a pinned block to its pool when the numpy array built on it dies."""
+
+    def __init__(self, block, free_list):
+        self.block, self.free_list = block, free_list
+
+    def __del__(self):
+        try:
+            if len(self.free_list) < 4:
+                self.free_list.append(self.block)
+        except Exception:
+            pass
 
 
 class Device:
@@ -311,6 +325,21 @@ class Device:
     def pinned_empty(self, shape, dtype):
         """numpy array over page-locked host memory (cs_host_alloc): D2H / H2D at link speed."""
         return PinnedArray(self, shape, dtype).array
+
+    def pinned_result(self, shape, dtype):
+        """Like pinned_empty, from a pool: page-locking costs more than the copy it speeds up, so the
+        buffer of a result array goes back to the pool when the array is garbage collected and the
+        next call of the same size reuses it."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(x) for x in np.atleast_1d(shape))
+        nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        free = pool.setdefault(nbytes, [])
+        block = free.pop() if free else PinnedArray(self, nbytes, np.uint8)
+        lease = _PinnedLease(block, free)
+        raw = (C.c_char * nbytes).from_address(block.ptr)
+        raw._lease = lease
+        return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
     def new_stream(self):
         s = C.c_void_p()

@@ -284,12 +284,24 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
 template <typename TC>
 int launch_corr(cs_ctx* ctx, cs::CorrArgs<TC>& A, hipStream_t stream, bool allow_fast);
 
+// the streaming kernels write n_obs next to the coefficient (same index), so both maps must share
+// one geometry; plain cross-correlations run their unmasked instance
+template <typename TC>
+bool fast_compatible(const cs::CorrArgs<TC>& A)
+{
+    if (A.nobs.ptr && (A.nobs.layout != A.out.layout || A.nobs.ld != A.out.ld || A.nobs.band_lo != A.out.band_lo ||
+                       A.nobs.band_w != A.out.band_w))
+        return false;
+    if (A.xcorr_only && (A.mask_mode != 0 || A.full || A.sym_upper)) return false;
+    return true;
+}
+
 template <>
 int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
-    if (allow_fast && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
@@ -322,7 +334,7 @@ int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
-    if (allow_fast && !A.xcorr_only && !A.nobs.ptr && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
@@ -675,6 +687,14 @@ int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, i
     const int kk = km * kn;
     std::vector<double> w(3 * (size_t)kk, 0.0);
     for (int t = 0; t < kk; ++t) w[t] = h_weights[t];
+    // exactly vertically symmetric weights: the folded chain of the streaming kernel applies
+    bool sym = !std::getenv("CHROMOSIGHT_HIP_NO_SYMMETRY");
+    for (int r = 0; r < km / 2 && sym; ++r)
+        for (int c = 0; c < kn; ++c)
+            if (w[r * kn + c] != w[(km - 1 - r) * kn + c]) {
+                sym = false;
+                break;
+            }
 #define CS_XC(TC)                                                         \
     {                                                                     \
         rc = upload_weights<TC>(ctx, stream, w);                          \
@@ -690,7 +710,8 @@ int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, i
         A.w = reinterpret_cast<const TC*>(ctx->d_w[sizeof(TC) == 8 ? 1 : 0]); \
         A.ks.n = (TC)kk; A.ks.thr = (TC)threshold;                        \
         A.xcorr_only = 1;                                                 \
-        return launch_corr<TC>(ctx, A, stream, false);                    \
+        A.w_sym = sym ? 1 : 0;                                            \
+        return launch_corr<TC>(ctx, A, stream, getenv("CHROMOSIGHT_HIP_FORCE_GENERIC") == nullptr); \
     }
     if (compute_dtype == CS_F64) CS_XC(double)
     if (compute_dtype == CS_F32) CS_XC(float)

@@ -34,6 +34,8 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     StreamArgs<TC> S;
     S.sig = A.sig.ptr;
     S.out = A.out.ptr;
+    S.nobs = (float*)A.nobs.ptr;
+    S.xcorr_only = A.xcorr_only;
     S.w = (unsigned long long)(uintptr_t)A.w;
     S.ld_in = A.sig.ld;
     S.ld_out = A.out.ld;

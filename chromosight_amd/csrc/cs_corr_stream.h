@@ -546,6 +546,8 @@ template <typename TC>
 struct StreamArgs {
     const void* sig;        // input map
     void* out;              // coefficient map
+    float* nobs;            // optional: present pixels of every window, same geometry as `out`
+    int xcorr_only;         // plain cross-correlation (xcorr2): thresholded sum S*w instead of the coefficient
     unsigned long long w;   // device address of the centred template weights (K*K)
     long long ld_in, ld_out;
     int sig_is_f64, out_is_f64;
@@ -891,10 +893,19 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
                 TC nobs;
                 r = pearson_from_sums<TC>(csv[c], (TC)s1[c], (TC)s2[c], TC(0), TC(0), TC(0), A.ks, false, &nobs);
             }
+            if constexpr (!MASKED && !REG) {
+                if (A.xcorr_only) r = (cs_abs(csv[c]) < A.ks.thr) ? TC(0) : csv[c];   // detection.py:716-722
+            }
             r = zero ? TC(0) : r;
             if (in_range) {
                 if (A.out_is_f64) ((double*)A.out)[out_idx + c] = (double)r;
                 else ((float*)A.out)[out_idx + c] = (float)r;
+                if (A.nobs) {
+                    TC present = A.ks.n;
+                    if constexpr (REG) present = A.ks.n - (nm[c] + fx[c][0]);
+                    else if constexpr (MASKED) present = A.ks.n - nm[c];
+                    A.nobs[out_idx + c] = (float)present;
+                }
             }
         }
         out_idx += out_step;

@@ -143,6 +143,7 @@ _PROTOTYPES = {
     "cs_csr_band_extent": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
     "cs_distance_law_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "cs_csr_median": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(C.c_double)]),
     "cs_detect_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                  C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64), C.c_void_p]),

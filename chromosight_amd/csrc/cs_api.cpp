@@ -874,21 +874,6 @@ int cs_remove_neighbours(const int64_t* h_bin1, const int64_t* h_bin2, const int
     return CS_OK;
 }
 
-int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr)
-{
-    if (!h_ptr) return CS_ERR_INVALID;
-    CS_ENTER(ctx);
-    CS_HIP(ctx, hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
-    return CS_OK;
-}
-
-int cs_host_free(cs_ctx* ctx, void* h_ptr)
-{
-    CS_ENTER(ctx);
-    if (h_ptr) CS_HIP(ctx, hipHostFree(h_ptr));
-    return CS_OK;
-}
-
 // grow-only device scratch; growing waits for the device, since queued work may still use the old block
 static int ensure_scratch(cs_ctx* ctx, void** buf, size_t* have, size_t need)
 {
@@ -902,6 +887,37 @@ static int ensure_scratch(cs_ctx* ctx, void** buf, size_t* have, size_t need)
     const size_t want = need + need / 4;
     CS_HIP(ctx, hipMalloc(buf, want));
     *have = want;
+    return CS_OK;
+}
+
+int cs_csr_median(cs_ctx* ctx, void* stream_, const cs_csr* mat, double* h_median)
+{
+    CS_ENTER(ctx);
+    if (!h_median) return fail(ctx, CS_ERR_INVALID, "null output");
+    cs::CsrView v;
+    int rc = csr_view(ctx, mat, &v);
+    if (rc) return rc;
+    auto grow = [](void* user, size_t bytes) -> void* {
+        cs_ctx* c = (cs_ctx*)user;
+        return ensure_scratch(c, &c->d_pool, &c->d_pool_bytes, bytes) == CS_OK ? c->d_pool : nullptr;
+    };
+    rc = cs::csr_median(v, ctx->n_cu, (hipStream_t)stream_, grow, ctx, h_median);
+    if (rc) return fail(ctx, CS_ERR_HIP, "median failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr)
+{
+    if (!h_ptr) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
+    CS_HIP(ctx, hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return CS_OK;
+}
+
+int cs_host_free(cs_ctx* ctx, void* h_ptr)
+{
+    CS_ENTER(ctx);
+    if (h_ptr) CS_HIP(ctx, hipHostFree(h_ptr));
     return CS_OK;
 }
 

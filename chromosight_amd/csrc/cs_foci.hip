@@ -380,6 +380,94 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     return (int)hipGetLastError();
 }
 
+// ---- median of the stored values of a CSR view (inter-chromosomal blocks are scaled by it) -------
+namespace {
+__global__ __launch_bounds__(kThreads) void row_len_kernel(CsrView M, int* __restrict__ len)
+{
+    const int row = blockIdx.x * kThreads + threadIdx.x;
+    if (row < M.n_rows) len[row] = (int)(M.row_end[row] - M.indptr[row]);
+}
+
+template <typename TV>
+__global__ __launch_bounds__(kThreads) void gather_values_kernel(CsrView M, const int* __restrict__ off,
+                                                                 double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
+    for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
+        const long long b = M.indptr[row], e = M.row_end[row];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int col = M.indices[k] - M.col0;
+            double v = csr_value(M, data, k, row, col);
+            if (v != v) v = 0.0;                               // NaN -> 0 (contacts_map.py:599)
+            out[off[row] + (k - b)] = v;
+        }
+    }
+}
+}  // namespace
+
+// Median of the values of the view (host result; synchronous).  `grow(user, bytes)` returns device
+// scratch of at least `bytes` (it may move the block: the first pass is then simply repeated).
+int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_median)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    *h_median = __builtin_nan("");
+    if (M.n_rows <= 0) return 0;
+    size_t scan_tmp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, M.n_rows);
+    const size_t head = 2 * al(4 * ((size_t)M.n_rows + 1));
+    long long n_vals = -1;
+    size_t have = 0;
+    char* base = nullptr;
+    for (int pass = 0; pass < 3; ++pass) {
+        size_t sort_tmp = 0;
+        if (n_vals > 0)
+            (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const double*)nullptr, (double*)nullptr, (int)n_vals);
+        const size_t tmp_bytes = al(std::max(scan_tmp, sort_tmp));
+        const size_t need = head + tmp_bytes + (n_vals > 0 ? 2 * al(8 * (size_t)n_vals) : 0);
+        char* p = (char*)grow(user, need);
+        if (!p) return (int)hipErrorOutOfMemory;
+        const bool moved = p != base || need > have;
+        base = p;
+        have = need;
+        int* len = (int*)base;
+        int* off = (int*)(base + al(4 * ((size_t)M.n_rows + 1)));
+        void* tmp = base + head;
+        if (n_vals < 0 || moved) {
+            hipLaunchKernelGGL(row_len_kernel, dim3(blocks_for(M.n_rows)), dim3(kThreads), 0, stream, M, len);
+            size_t tb = tmp_bytes;
+            hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, len, off, M.n_rows, stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (n_vals < 0) {
+            int last[2] = {0, 0};
+            hipError_t e = hipMemcpyAsync(&last[0], off + (M.n_rows - 1), 4, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&last[1], len + (M.n_rows - 1), 4, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return (int)e;
+            n_vals = (long long)last[0] + last[1];
+            if (n_vals <= 0) return 0;
+            continue;                                          // size the second pass
+        }
+        double* vals = (double*)(base + head + tmp_bytes);
+        double* sorted = vals + al(8 * (size_t)n_vals) / 8;
+        const int blocks = std::max(1, std::min((M.n_rows + 3) / 4, n_cu * 16));
+        if (M.is_f64) hipLaunchKernelGGL(gather_values_kernel<double>, dim3(blocks), dim3(kThreads), 0, stream, M, off, vals);
+        else hipLaunchKernelGGL(gather_values_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, M, off, vals);
+        size_t tb = tmp_bytes;
+        hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tb, vals, sorted, (int)n_vals, 0, 64, stream);
+        if (e != hipSuccess) return (int)e;
+        double mid[2];
+        e = hipMemcpyAsync(&mid[0], sorted + (n_vals - 1) / 2, 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&mid[1], sorted + n_vals / 2, 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return (int)e;
+        *h_median = 0.5 * (mid[0] + mid[1]);                   // numpy: mean of the two middle values
+        return 0;
+    }
+    return 0;
+}
+
 // quantify mode: records at n given pixels (device arrays)
 int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n, int inter,
                      double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream)

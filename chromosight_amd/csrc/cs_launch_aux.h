@@ -50,6 +50,9 @@ int launch_csr_band_extent(const CsrView& M, int lo_diag, int hi_diag, long long
                            hipStream_t stream);
 int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream);
 
+// median of the stored values of a view (cs_foci.hip)
+int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_median);
+
 // device-side foci (cs_foci.hip)
 size_t foci_scratch_bytes(long long n_cand);
 int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,

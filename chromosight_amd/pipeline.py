@@ -214,6 +214,8 @@ class DeviceCool:
         self.miss_host = miss
         self.miss = dev.to_device(miss.astype(np.uint8))
         self.det = dev.to_device((~miss).astype(np.uint8))
+        self.host = {"binsize": self.binsize, "chrom_offset": off, "chrom_names": np.asarray(self.names), "bin1_id": b1,
+                     "bin2_id": b2, "count": cnt, "weight": weight, "bin_start": self.bin_start, "bin_end": self.bin_end}
         self.upload_bytes = self.indptr.nbytes + self.indices.nbytes + self.data.nbytes + self.weight.nbytes
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
@@ -280,6 +282,83 @@ class DeviceCool:
         block.buffer = own
         return block
 
+    def stage_inter(self, ca, cb, name=None, stream=None, resident=False, dtype=np.float64):
+        """ContactMap.create_mat of a balanced inter-chromosomal block (ca < cb), on the device:
+        NaN -> 0, divided by the median of its stored values (contacts_map.py:598-601), dense layout."""
+        dev, lib = self.dev, self.dev.lib
+        s1, e1 = int(self.offsets[ca]), int(self.offsets[ca + 1])
+        s2, e2 = int(self.offsets[cb]), int(self.offsets[cb + 1])
+        n_r, n_c = e1 - s1, e2 - s2
+        ext = self._ext.get(16 * n_r + 8 * max(n_r, n_c) + 512)
+        d_begin, d_end, d_law = ext, ext + 8 * n_r, ext + 16 * n_r
+        raw = self._view(s1, e1, s2, e2)
+        dev._check(lib.cs_csr_band_extent(dev.ctx, stream, C.byref(raw), -n_r, n_c, d_begin, d_end))
+        view = self._view(s1, e1, s2, e2, d_begin, d_end)
+        med = C.c_double(0.0)
+        dev._check(lib.cs_csr_median(dev.ctx, stream, C.byref(view), C.byref(med)))
+        scale = np.full(max(n_r, n_c), med.value)
+        dev._check(lib.cs_memcpy_h2d(dev.ctx, d_law, scale.ctypes.data, scale.nbytes, stream))
+        esz = np.dtype(dtype).itemsize
+        ld = (n_c + 15) // 16 * 16
+        own = dev.empty(n_r * ld * esz, np.uint8) if resident else None
+        ptr = own.ptr if resident else self._band.get(n_r * ld * esz)
+        sig = CsMatrix(ptr, np_dtype_code(dtype), LAYOUT_DENSE, ld, 0, 0)
+        # "law" = the median on every diagonal, no cap: value / median, NaN -> 0
+        dev._check(lib.cs_csr_to_band(dev.ctx, stream, C.byref(view), d_law, scale.size, 0.0, C.byref(sig)))
+        block = StagedBlock(name or f"{self.names[ca]}-{self.names[cb]}", sig, (n_r, n_c), _Ptr(self.miss.ptr + s1),
+                            _Ptr(self.miss.ptr + s2), None, True, None)
+        block.buffer = own
+        return block
+
+    def subsampled(self, sample, seed=0, inter=False):
+        """A DeviceCool whose counts are a random subsample of this one's, drawn per sub-matrix without
+        replacement like the reference's --subsample (contacts_map.py:552-596, preprocessing.py:359-401):
+        `sample` in (0, 1] is the proportion of the contacts of every sub-matrix to keep.  Intra blocks
+        are sampled as the reference sees them (symmetric matrix, both triangles drawn independently;
+        the path then only reads the upper one).  Unlike the reference's unseeded np.random.choice the
+        draw is reproducible: numpy Generator(seed), multivariate hypergeometric."""
+        sample = float(sample)
+        if sample < 0:
+            raise ValueError("Subsample must be strictly positive.")
+        if sample > 1:
+            raise ValueError("Subsample cannot be above 1")
+        rng = np.random.default_rng(seed)
+        h = self.host
+        b1, b2, cnt = h["bin1_id"], h["bin2_id"], np.asarray(h["count"]).astype(np.int64)
+        off = self.offsets
+        chrom_of = np.repeat(np.arange(self.n_chrom), np.diff(off))
+        c1, c2 = chrom_of[b1], chrom_of[b2]
+        new = np.zeros_like(cnt)
+        for ca in range(self.n_chrom):
+            for cb in range(ca, self.n_chrom if inter else ca + 1):
+                sel = np.flatnonzero((c1 == ca) & (c2 == cb))
+                if sel.size == 0:
+                    continue
+                x = cnt[sel]
+                if ca == cb:
+                    offd = b1[sel] != b2[sel]
+                    pool = np.concatenate([x, x[offd]])            # upper triangle + diagonal, then the mirror
+                    keep = int(sample * pool.sum())
+                    drawn = rng.multivariate_hypergeometric(pool, keep, method="marginals") if keep < pool.sum() else pool
+                    new[sel] = drawn[:x.size]
+                else:
+                    keep = int(sample * x.sum())
+                    new[sel] = rng.multivariate_hypergeometric(x, keep, method="marginals") if keep < x.sum() else x
+        cool = dict(h)
+        nz = new > 0
+        cool["bin1_id"], cool["bin2_id"], cool["count"] = b1[nz], b2[nz], new[nz]
+        return DeviceCool(cool, self.dev)
+
+    def bins_of(self, chroms, positions):
+        """Whole-genome bin of (chromosome name, base pair) pairs; -1 outside the genome
+        (HicGenome.coords_to_bins, contacts_map.py:404-450, for fixed-size bins)."""
+        index = {n: i for i, n in enumerate(self.names)}
+        ci = np.array([index.get(str(c), -1) for c in chroms], dtype=np.int64)
+        local = np.asarray(positions, dtype=np.int64) // self.binsize
+        sizes = np.diff(self.offsets)
+        ok = (ci >= 0) & (local >= 0) & (local < sizes[np.maximum(ci, 0)])
+        return np.where(ok, self.offsets[np.maximum(ci, 0)] + local, -1)
+
     def block_bins(self, ci):
         s, e = int(self.offsets[ci]), int(self.offsets[ci + 1])
         return np.flatnonzero(~self.miss_host[s:e])
@@ -296,31 +375,40 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
                                 want_windows=want_windows)
 
 
-def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64):
-    """`chromosight detect` (intra-chromosomal, balanced, default options) on a decoded cool (dict)
-    or a DeviceCool.  Every block is staged once in HBM (distance law, detrend, band) and stays
-    resident across templates and iterations; each (block, template) is one native call.
+def sub_matrices(dcool, inter):
+    """(chrom a, chrom b) of every sub-matrix in the reference's order (contacts_map.py:274-312)."""
+    return [(a, b) for a in range(dcool.n_chrom) for b in range(dcool.n_chrom) if a == b or (a < b and inter)]
+
+
+def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, inter=False, subsample=None, seed=0):
+    """`chromosight detect` (balanced matrix) on a decoded cool (dict) or a DeviceCool; options
+    --inter, --smooth-trend, --tsvd, --subsample (seeded), --iterations through the config.  Every
+    block is staged once in HBM (distance law, detrend, band / median scaling) and stays resident
+    across templates and iterations; each (block, template) is one native call.
     Returns the output table (same columns and row order as the reference's <prefix>.tsv)."""
     dcool = cool if isinstance(cool, DeviceCool) else DeviceCool(cool)
+    if subsample is not None:
+        dcool = dcool.subsampled(subsample, seed=seed, inter=inter)
     binsize = dcool.binsize
     off = dcool.offsets
     names = dcool.names
     n_chrom = dcool.n_chrom
     max_dist = max(kernel_config["max_dist"] // binsize, 1)
     largest = max(np.shape(k)[0] for k in kernel_config["kernels"])
-    blocks = [dcool.stage_intra(ci, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=True)
-              for ci in range(n_chrom)]
+    pairs = sub_matrices(dcool, inter)
+    blocks = [dcool.stage_intra(a, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=True) if a == b
+              else dcool.stage_inter(a, b, resident=True) for a, b in pairs]
     all_coords = []
     for kernel_id, kernel in enumerate(kernel_config["kernels"]):
         for it in range(kernel_config["max_iterations"]):
             tables, windows = [], []
-            for ci, block in enumerate(blocks):
+            for (ca, cb), block in zip(pairs, blocks):
                 tab, win = detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd)
                 if tab is None:
                     continue
                 tab = tab.copy()
-                tab["bin1"] += int(off[ci])
-                tab["bin2"] += int(off[ci])
+                tab["bin1"] += int(off[ca])
+                tab["bin2"] += int(off[cb])
                 tables.append(tab)
                 windows.append(win)
             if not tables:
@@ -356,3 +444,70 @@ def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end):
     coords = coords.loc[~coords.pvalue.isnull(), :]
     coords["qvalue"] = fdr_correction(coords["pvalue"])
     return coords.loc[:, OUTPUT_COLUMNS].reset_index(drop=True)
+
+
+def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=None, seed=0, smooth=False,
+             max_dist_bp=None):
+    """`chromosight quantify` (cli/chromosight.py:264-470): score the given 2-D positions with every
+    template of the config and keep, per position, the row the reference keeps (sorted by score,
+    last of each (chrom1, start1, chrom2, start2) group).  `positions`: DataFrame with chrom1, start1,
+    end1, chrom2, start2, end2.  Returns (table in the reference's output order and columns, windows)."""
+    dcool = cool if isinstance(cool, DeviceCool) else DeviceCool(cool)
+    if subsample is not None:
+        dcool = dcool.subsampled(subsample, seed=seed, inter=inter)
+    cfg = dict(kernel_config)
+    bed2d = positions.loc[:, ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]].reset_index(drop=True).copy()
+    furthest = np.max(bed2d.start2 - bed2d.start1)
+    cfg["max_dist"] = min(furthest, dcool.n_bins * dcool.binsize)       # scan up to the furthest pattern
+    if max_dist_bp is not None:
+        cfg["max_dist"] = int(max_dist_bp)                              # (tests: pin the scanning distance)
+    cfg["min_dist"] = 0
+    kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+    km, kn = kernels[0].shape
+    max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
+    largest = max(k.shape[0] for k in kernels)
+    bed2d["score"] = np.nan
+    bed2d["pvalue"] = np.nan
+    pos1 = (bed2d.start1 + bed2d.end1) // 2
+    pos2 = (bed2d.start2 + bed2d.end2) // 2
+    g1 = dcool.bins_of(bed2d.chrom1, pos1)
+    g2 = dcool.bins_of(bed2d.chrom2, pos2)
+    index = {n: i for i, n in enumerate(dcool.names)}
+    c1 = np.array([index.get(str(c), -1) for c in bed2d.chrom1])
+    c2 = np.array([index.get(str(c), -1) for c in bed2d.chrom2])
+    n_pos = len(bed2d)
+    bed_out = [bed2d.copy() for _ in kernels]
+    win_out = [np.full((n_pos, km, kn), np.nan) for _ in kernels]
+    pairs = sub_matrices(dcool, inter)
+    staged = {}
+    for kernel_id, kernel in enumerate(kernels):
+        for ca, cb in pairs:
+            sel = np.flatnonzero((c1 == ca) & (c2 == cb) & (g1 >= 0) & (g2 >= 0))
+            if sel.size == 0:
+                continue                                    # no pattern on this sub-matrix: not scanned (:240)
+            if (ca, cb) not in staged:
+                staged[(ca, cb)] = dcool.stage_intra(ca, max_dist, largest, smooth=smooth, resident=True) if ca == cb \
+                    else dcool.stage_inter(ca, cb, resident=True)
+            coords = np.column_stack([g1[sel] - dcool.offsets[ca], g2[sel] - dcool.offsets[cb]]).astype(int)
+            tab, wins = detect_block(dcool, staged[(ca, cb)], cfg, kernel, tsvd=tsvd, coords=coords)
+            if tab is None:
+                continue
+            bed_out[kernel_id].loc[sel, "score"] = tab["score"].to_numpy()
+            bed_out[kernel_id].loc[sel, "pvalue"] = tab["pvalue"].to_numpy()
+            win_out[kernel_id][sel] = wins
+    # best score of every coordinate among the templates, as the reference selects it (:432-441)
+    bed = pd.concat(bed_out, axis=0).reset_index(drop=True)
+    windows = np.concatenate(win_out, axis=0)
+    bed = bed.sort_values("score", ascending=True).groupby(["chrom1", "start1", "chrom2", "start2"], sort=False).tail(1)
+    windows = windows[bed.index, :, :]
+    which = bed.index.to_numpy() % n_pos
+    bed = bed.reset_index(drop=True)
+    bed["bin1"] = g1[which]
+    bed["bin2"] = g2[which]
+    bed["qvalue"] = fdr_correction(bed["pvalue"])
+    bed = bed.loc[:, ["chrom1", "start1", "end1", "chrom2", "start2", "end2", "bin1", "bin2", "score", "pvalue", "qvalue"]]
+    bad = np.isnan(bed.score.to_numpy(dtype=np.float64))
+    bed.loc[bad, "pvalue"] = np.nan
+    bed.loc[bad, "qvalue"] = np.nan
+    order = bed.sort_values(["bin1", "bin2"], ascending=True).index.to_numpy()
+    return bed.loc[order].reset_index(drop=True), windows

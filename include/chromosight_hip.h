@@ -211,6 +211,11 @@ int cs_csr_band_extent(cs_ctx* ctx, void* stream, const cs_csr* mat, int32_t lo_
 int cs_distance_law_finish(cs_ctx* ctx, void* stream, const double* d_sum, const int64_t* d_cnt,
                            int32_t n_diags, double* d_law);
 
+/* Median of the stored values of a CSR view, NaN counted as 0 (np.nanmedian after the NaN -> 0 of
+ * contacts_map.py:598-601 preprocess_inter_matrix, which divides an inter-chromosomal block by it).
+ * Balanced on the fly like every view.  *h_median = NaN for an empty view.  Synchronous. */
+int cs_csr_median(cs_ctx* ctx, void* stream, const cs_csr* mat, double* h_median);
+
 /* ---- device-side foci: detection.py:387 pick_foci + the statistics of :18 validate_patterns ---- */
 typedef struct {
     double pearson;         /* candidate threshold: coefficient >= pearson and != 0 (detection.py:417-421) */

@@ -99,3 +99,66 @@ def test_c5_yeast_quantify_inter(golden):
     assert worst < 1e-5
     assert n_rows > 6000 and n_inter > 500
     print(f"C5: {n_rows} scored positions ({n_inter} inter), max |score - reference| = {worst:.2e}")
+
+
+def test_quantify_harness_inter_best_of_kernels(golden):
+    """pipeline.quantify = cmd_quantify (cli/chromosight.py:264-470): every position scored with the
+    three 11x11 borders templates on intra and inter blocks staged on the device, the reference's
+    per-coordinate selection among templates (sort by score, last row of each group), whole-genome bins,
+    output order.  Expected values: the reference's per-block, per-template tables (yeast fixture)."""
+    cool = golden("yeast_cool")
+    g = golden("yeast_quantify")
+    off = cool["chrom_offset"]
+    names = [str(n) for n in cool["chrom_names"]]
+    binsize = int(cool["binsize"])
+    rows, want = [], []
+    for bi in range(int(g["n_blocks"])):
+        ca, cb = (int(x) for x in g[f"b{bi}_chroms"])
+        coords = g[f"b{bi}_coords"]
+        scores = np.full((coords.shape[0], 3), np.nan)
+        for ki in range(3):
+            key = f"b{bi}_k{ki}_table"
+            if key in g and g[key].shape[0]:
+                scores[:, ki] = g[key][:, 2]
+        for (r, c), sc in zip(coords, scores):
+            rows.append((names[ca], int(r) * binsize, (int(r) + 1) * binsize, names[cb], int(c) * binsize, (int(c) + 1) * binsize))
+            want.append((int(off[ca] + r), int(off[cb] + c)) + tuple(sc))
+    positions = pd.DataFrame(rows, columns=["chrom1", "start1", "end1", "chrom2", "start2", "end2"])
+    want = pd.DataFrame(want, columns=["bin1", "bin2", "s0", "s1", "s2"])
+    cfg = dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+               kernels=[g[f"kernel{ki}"] for ki in range(3)], max_iterations=1, min_separation=5000)
+    table, windows = pipeline.quantify(cool, positions, cfg, inter=True, max_dist_bp=int(g["cfg_max_dist_bp"]))
+    # the reference's selection rule applied to its own per-template scores
+    long = pd.concat([pd.DataFrame({"bin1": want.bin1, "bin2": want.bin2, "score": want[f"s{k}"]}) for k in range(3)],
+                     axis=0).reset_index(drop=True)
+    exp = long.sort_values("score", ascending=True).groupby(["bin1", "bin2"], sort=False).tail(1)
+    exp = exp.sort_values(["bin1", "bin2"]).reset_index(drop=True)
+    assert len(table) == len(exp) == len(want.drop_duplicates(["bin1", "bin2"]))
+    assert table["bin1"].tolist() == exp["bin1"].tolist() and table["bin2"].tolist() == exp["bin2"].tolist()
+    a, b = table["score"].to_numpy(dtype=np.float64), exp["score"].to_numpy(dtype=np.float64)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.nanmax(np.abs(a - b)) < 1e-9
+    assert windows.shape == (len(table), 11, 11)
+    assert np.isnan(table["pvalue"].to_numpy(dtype=np.float64)[np.isnan(a)]).all()
+    print(f"quantify: {len(table)} positions, {int(np.isnan(a).sum())} without a valid score")
+
+
+def test_detect_inter_and_subsample_run(golden):
+    """--inter and --subsample through pipeline.detect: inter blocks are staged (median scaling) and
+    scanned on the device; a seeded subsample is reproducible and keeps the requested proportion."""
+    cool = golden("yeast_cool")
+    cfg = copy.deepcopy(ck.loops)
+    dcool = pipeline.DeviceCool(cool)
+    sub_a = dcool.subsampled(0.5, seed=3, inter=True)
+    sub_b = dcool.subsampled(0.5, seed=3, inter=True)
+    assert np.array_equal(sub_a.host["count"], sub_b.host["count"])
+    kept = sub_a.host["count"].sum() / np.asarray(cool["count"]).sum()
+    assert 0.4 < kept < 0.62            # intra blocks draw from both triangles, only the upper one is stored
+    small = {k: v for k, v in cool.items()}
+    table = pipeline.detect(small, cfg, inter=True)
+    assert len(table) > 0
+    inter_rows = table[table.chrom1 != table.chrom2]
+    intra_only = pipeline.detect(small, cfg, inter=False)
+    assert len(table) - len(inter_rows) <= len(intra_only) + len(inter_rows)
+    print(f"detect --inter on the yeast map: {len(table)} patterns ({len(inter_rows)} inter-chromosomal), "
+          f"{len(intra_only)} without --inter")

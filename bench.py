@@ -207,12 +207,13 @@ def pmc_traffic(args, wl):
     measured calibration + WRITE_SIZE).  Counters cannot be read from inside the timed process, so
     this is the figure of the profiled run of the same command; None when no such record exists."""
     import glob
-    if args.workload != "c2" or args.size not in (None, 4096) or args.precision != "f32":
+    key = {"c2": "c2_4096_f32", "c3k": "c3k_band_50000x234", "c4p": "c4p_band_200000x1001"}.get(args.workload)
+    if key is None or (args.workload == "c2" and args.size not in (None, 4096)) or args.precision != "f32":
         return None, "no PMC record for this workload"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
     for path in reversed(files):
         try:
-            rec = json.load(open(path)).get("c2_4096_f32", {})
+            rec = json.load(open(path)).get(key, {})
         except (OSError, ValueError):
             continue
         if "hbm_bytes_per_dispatch" in rec:

@@ -429,7 +429,7 @@ def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end):
     genomic coordinates, min_dist and NaN-p filters, Benjamini-Hochberg q-values, column order."""
     n_chrom = len(names)
     separation = max(int(kernel_config["min_separation"] // binsize), 1)
-    coords = coords.loc[cid.remove_neighbours(coords, win_size=separation), :]
+    coords = coords.loc[cid.remove_neighbours(coords, win_size=separation), :].copy()
     # bins -> genomic coordinates
     bin_chrom = np.repeat(np.arange(n_chrom), np.diff(off))
     name_arr = np.asarray(names, dtype=object)

@@ -293,3 +293,33 @@ def test_upper_band_block_equals_symmetric_block(golden):
             want[(jj - ii < 0) | (jj - ii > keep)] = 0
             np.testing.assert_array_equal(np.isnan(band), np.isnan(want))
             np.testing.assert_allclose(np.nan_to_num(band), np.nan_to_num(want), rtol=0, atol=0)
+
+
+def test_remove_neighbours_grid_equals_quadratic_scan():
+    """cs_remove_neighbours (grid of win x win cells) against the reference's O(n^2) loop
+    (detection.py:348-384) restated here, on random clouds with ties in position."""
+    rng = np.random.default_rng(12)
+    for n, span, win in ((0, 10, 3), (1, 10, 3), (300, 40, 5), (2000, 300, 8), (500, 30, 1), (800, 25, 12)):
+        pts = pd.DataFrame({"bin1": rng.integers(0, span, n), "bin2": rng.integers(0, span, n), "score": rng.random(n)})
+        got = cud.remove_neighbours(pts, win_size=win)
+        ordered = pts.sort_values("score", ascending=False)
+        black = set()
+        for i, p in ordered.iterrows():
+            if i in black:
+                continue
+            close = np.flatnonzero((np.abs(ordered.bin1 - p.bin1) < win) & (np.abs(ordered.bin2 - p.bin2) < win))
+            for idx in ordered.index.values[close]:
+                if idx != i:
+                    black.add(idx)
+        want = np.ones(n, dtype=bool)
+        want[list(black)] = False
+        assert np.array_equal(got, want), (n, span, win)
+
+
+def test_sub_matrix_order_and_bins():
+    from chromosight_amd import pipeline
+
+    class G:
+        n_chrom = 3
+    assert pipeline.sub_matrices(G, False) == [(0, 0), (1, 1), (2, 2)]
+    assert pipeline.sub_matrices(G, True) == [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]   # contacts_map.py:274-279

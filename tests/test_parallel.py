@@ -100,3 +100,60 @@ def test_single_process_path():
     blocks = [_Block(40 + 7 * i, seed=i) for i in range(5)]
     got = parallel.detect_blocks(blocks, {}, None, detector=_fake_detector)
     assert np.array_equal(got, _expected(blocks))
+
+
+# ------------------------------------------------------------------------------------------------
+# detect_genome: templates x iterations, gathered tables, all-reduced pileup
+# ------------------------------------------------------------------------------------------------
+class _Genome:
+    binsize = 1000
+    n_chrom = 7
+
+    def chrom_size(self, ci):
+        return 50 + 13 * ci
+
+
+def _fake_stage(genome, ci, max_dist, largest):
+    return {"ci": ci, "n": genome.chrom_size(ci), "max_dist": max_dist, "largest": largest}
+
+
+def _fake_detect(genome, block, cfg, kernel, tsvd):
+    """The table depends on the block AND on the template (so that a wrong pileup shows)."""
+    import pandas as pd
+    rng = np.random.default_rng(block["ci"] * 1000 + int(round(float(np.nansum(kernel)) * 1e6)) % 997)
+    n = int(rng.integers(0, 5))
+    if n == 0:
+        return None, None
+    wins = rng.random((n, 3, 3))
+    wins[rng.random((n, 3, 3)) < 0.2] = np.nan
+    return pd.DataFrame({"bin1": rng.integers(0, block["n"], n), "bin2": rng.integers(0, block["n"], n),
+                         "score": rng.random(n), "pvalue": rng.random(n)}), wins
+
+
+_CFG = {"max_dist": 20_000, "max_iterations": 3, "kernels": [np.full((3, 3), 0.5), np.arange(9.0).reshape(3, 3) / 7]}
+
+
+def _genome_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        got = parallel.detect_genome(_Genome(), _CFG, stage=_fake_stage, detect=_fake_detect)
+        np.save(os.path.join(out_dir, f"genome{rank}.npy"), got)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_detect_genome_world2_equals_single(tmp_path):
+    single = parallel.detect_genome(_Genome(), _CFG, stage=_fake_stage, detect=_fake_detect)
+    assert single.shape[1] == len(parallel.GENOME_FIELDS) and single.shape[0] > 10
+    assert set(np.unique(single[:, 6])) >= {0.0, 1.0}         # the refined templates found patterns too
+    world = 2
+    mp.spawn(_genome_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"genome{r}.npy")
+        # the pileup of the sharded run is a sum over ranks: same template up to rounding, and the
+        # stand-in detector keys on it only through a rounded checksum
+        assert got.shape == single.shape
+        assert np.array_equal(got[:, [0, 1, 2, 5, 6]], single[:, [0, 1, 2, 5, 6]])
+        assert np.allclose(got[:, 3:5], single[:, 3:5], rtol=0, atol=1e-12)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Round measurement collection on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh r01
+#   tools/collect_profiles.sh r02
 # Writes raw profiler output under gpurun_out/<tag>/ ; tools/summarize_profiles.py copies the
 # summaries into profiles/ (tracked).  Counter passes are separate from the trace passes and from
 # each other (FETCH_SIZE and WRITE_SIZE do not fit one pass), as the MI355X guide prescribes.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
@@ -17,30 +17,47 @@ bench() { python bench.py "$@" 2>/dev/null | tail -1; }
 # 1. bench lines (the default command first: it is what the driver runs)
 bench > "$out/bench_c2.json"
 bench --workload c3 --no-cpu-baseline > "$out/bench_c3.json"
+bench --workload c3k --no-cpu-baseline > "$out/bench_c3k.json"
 bench --workload c4p --no-cpu-baseline > "$out/bench_c4p.json"
+bench --workload c4 --steps 5 --warmup 1 > "$out/bench_c4.json"
 bench --size 16384 --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_dense16384.json"
 bench --precision f64 --no-cpu-baseline > "$out/bench_c2_f64.json"
 CHROMOSIGHT_HIP_NO_SYMMETRY=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c2_nosym.json"
 
-# 2. kernel traces of the same commands
-for w in c2 c3 c4p; do
+# 2. kernel traces of the same commands (c3 and c4 show the helper kernels: band extents, distance law,
+#    tiler, mask tables, compaction, sort, foci, re-scoring)
+for w in c2 c3 c3k c4p; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$w" -o $w -- \
       python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > "$out/trace_$w.log" 2>&1
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c4" -o c4 -- \
+    python bench.py --workload c4 --steps 3 --warmup 1 > "$out/trace_c4.log" 2>&1
 
-# 3. HBM counters of the C2 kernel, one pass each
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -o c2 -- \
-      python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_$c.log" 2>&1
+# 3. HBM counters of the dominant kernel of the dense and the two banded workloads, one pass each
+for w in c2 c3k c4p; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_${w}_$c" -o $w -- \
+        python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_${w}_$c.log" 2>&1
+  done
+  # VALU / wave counters (own pass)
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY \
+      --kernel-trace --output-format csv -d "$out/pmc_${w}_sq" -o $w -- \
+      python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_${w}_sq.log" 2>&1
 done
-# VALU / wave counters (own pass)
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE \
-    --kernel-trace --output-format csv -d "$out/pmc_sq" -o c2 -- \
-    python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_sq.log" 2>&1
+# helper kernels of the CSR path: bytes moved by the distance law / tiler (c3)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c3_$c" -o c3 -- \
+      python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c3_$c.log" 2>&1
+done
 
-# 4. FETCH_SIZE calibration on a known byte count with the kernel's own load pattern
-if [ -x tools/ubench/build/fetch_calib ]; then
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o calib -- \
-      tools/ubench/build/fetch_calib > "$out/calib.log" 2>&1
-fi
-ls -R "$out" | head -60
+# 4. FETCH_SIZE calibration on a known byte count with the kernel's own load pattern, and the
+#    micro-benchmarks behind two design decisions (FMA forms; MFMA beside packed FMAs)
+mkdir -p tools/ubench/build
+for u in fetch_calib coexec fma_rate; do
+  [ -x tools/ubench/build/$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/build/$u 2>/dev/null
+done
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o calib -- \
+    tools/ubench/build/fetch_calib > "$out/calib.log" 2>&1
+tools/ubench/build/coexec > "$out/ubench_coexec.txt" 2>&1
+tools/ubench/build/fma_rate > "$out/ubench_fma_rate.txt" 2>&1
+ls "$out" | head -80

@@ -1,6 +1,7 @@
 """Copy the summaries of a tools/collect_profiles.sh run from gpurun_out/<tag>/ into profiles/
-(tracked): bench lines, per-kernel statistics, and the per-dispatch HBM counters of the C2 kernel
-with the FETCH_SIZE calibration applied.    python tools/summarize_profiles.py r01"""
+(tracked): bench lines, per-kernel statistics, micro-benchmark outputs, and the per-dispatch counters of
+the dominant kernel of the dense (c2) and banded (c3k, c4p) workloads with the FETCH_SIZE calibration
+applied, plus achieved GB/s of the helper kernels of the CSR path.    python tools/summarize_profiles.py r02"""
 import collections
 import csv
 import glob
@@ -9,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
@@ -20,14 +21,23 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in ("c2", "c3", "c4p", "dense16384", "c2_f64", "c2_nosym"):
+for name in ("c2", "c3", "c3k", "c4p", "c4", "dense16384", "c2_f64", "c2_nosym"):
     f = os.path.join(src, f"bench_{name}.json")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_bench_{name}.json"))
-for w in ("c2", "c3", "c4p"):
+for w in ("c2", "c3", "c3k", "c4p", "c4"):
     f = find(f"trace_{w}/**/*kernel_stats.csv")
     if f:
-        shutil.copy(f, os.path.join(dst, f"{tag}_{w}_kernel_stats.csv"))
+        # kernel names of the sort / scan library are hundreds of characters long: keep 160
+        rows = list(csv.reader(open(f)))
+        with open(os.path.join(dst, f"{tag}_{w}_kernel_stats.csv"), "w", newline="") as out:
+            wr = csv.writer(out)
+            for r in rows:
+                wr.writerow([r[0][:160]] + r[1:])
+for u in ("coexec", "fma_rate"):
+    f = os.path.join(src, f"ubench_{u}.txt")
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_ubench_{u}.txt"))
 
 
 def per_dispatch(path, kernel_substr):
@@ -41,7 +51,7 @@ def per_dispatch(path, kernel_substr):
 
 
 summary = {"note": "per-dispatch means from rocprofv3 --pmc passes (one counter group per pass) on "
-                   "`python bench.py --workload c2 --steps 5 --warmup 2`; FETCH_SIZE / WRITE_SIZE in KiB"}
+                   "`python bench.py --workload <w> --steps 5 --warmup 2`; FETCH_SIZE / WRITE_SIZE in KiB"}
 calib = per_dispatch(find("calib/**/*counter_collection.csv"), "read4x4")
 factor = None
 if calib.get("FETCH_SIZE"):
@@ -49,16 +59,39 @@ if calib.get("FETCH_SIZE"):
     summary["fetch_calibration"] = {
         "pattern": "4 x 4-byte global loads per lane over 2 GiB read once (tools/ubench/fetch_calib.hip)",
         "reported_KiB": calib["FETCH_SIZE"], "true_KiB": 2097152.0, "true_over_reported": factor}
-c2 = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    c2.update(per_dispatch(find(f"pmc_{c}/**/*counter_collection.csv"), "corr_stream_kernel"))
-c2.update(per_dispatch(find("pmc_sq/**/*counter_collection.csv"), "corr_stream_kernel"))
-if c2:
-    if "FETCH_SIZE" in c2 and "WRITE_SIZE" in c2:
-        f = factor if factor else 2.0
-        c2["hbm_bytes_per_dispatch"] = (c2["FETCH_SIZE"] * f + c2["WRITE_SIZE"]) * 1024.0
-        c2["hbm_bytes_note"] = (f"FETCH_SIZE x {f:.3f} (calibration) + WRITE_SIZE (equals the output size exactly, "
-                                "factor 1), KiB -> bytes")
-    summary["c2_4096_f32"] = c2
+f = factor if factor else 2.0
+for w, key in (("c2", "c2_4096_f32"), ("c3k", "c3k_band_50000x234"), ("c4p", "c4p_band_200000x1001")):
+    rec = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        rec.update(per_dispatch(find(f"pmc_{w}_{c}/**/*counter_collection.csv"), "corr_stream_kernel"))
+    rec.update(per_dispatch(find(f"pmc_{w}_sq/**/*counter_collection.csv"), "corr_stream_kernel"))
+    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+        rec["hbm_bytes_per_dispatch"] = (rec["FETCH_SIZE"] * f + rec["WRITE_SIZE"]) * 1024.0
+        rec["hbm_bytes_note"] = (f"FETCH_SIZE x {f:.3f} (calibration) + WRITE_SIZE, KiB -> bytes")
+    if rec:
+        summary[key] = rec
+
+# helper kernels of the CSR path (c3): bytes from the counters, time from the kernel trace
+helpers = {}
+stats = find("trace_c3/**/*kernel_stats.csv")
+avg_ns = {}
+if stats:
+    for r in csv.DictReader(open(stats)):
+        avg_ns[r["Name"]] = float(r["AverageNs"])
+for kname in ("distance_law_kernel", "csr_to_band_kernel", "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel"):
+    rec = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        rec.update(per_dispatch(find(f"pmc_c3_{c}/**/*counter_collection.csv"), kname))
+    t = [v for k, v in avg_ns.items() if kname in k]
+    if t:
+        rec["avg_us"] = t[0] / 1e3
+    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec and t:
+        rec["hbm_bytes"] = (rec["FETCH_SIZE"] * f + rec["WRITE_SIZE"]) * 1024.0
+        rec["achieved_GBps"] = rec["hbm_bytes"] / (t[0] * 1e-9) / 1e9
+        rec["frac_of_8TBps"] = rec["achieved_GBps"] / 8000.0
+    if rec:
+        helpers[kname] = rec
+if helpers:
+    summary["c3_helper_kernels"] = helpers
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1)[:1500])
+print(json.dumps(summary, indent=1)[:3000])

@@ -4,6 +4,8 @@
 //   * CSR -> diagonal-band tiler with fused detrend     (+ diag_trim, preprocessing.py:93-126)
 //   * threshold compaction of a coefficient map         (first step of pick_foci, detection.py:417-421)
 //   * float64 re-scoring of a list of pixels            (detection.py:917-1131 evaluated per pixel)
+#include <algorithm>
+
 #include "cs_device.h"
 #include "cs_launch_aux.h"
 
@@ -14,8 +16,13 @@ namespace cs {
 // detectable.  One wave per CSR row, lanes stride over the row's stored entries (coalesced);
 // per-block partial sums live in LDS (ds_add_f64), flushed with one global atomic per diagonal.
 // ------------------------------------------------------------------------------------------
+// Blocks of 16 waves, one block per CU: every block ends with one global atomic per diagonal, and the
+// atomics of all blocks on one diagonal serialise in L2 -- with 8 four-wave blocks per CU that tail
+// was most of the kernel (91 us for the 10 M pixels of C3, 1 TB/s).
+constexpr int kLawThreads = 1024;
+
 template <typename TV, bool USE_LDS>
-__global__ __launch_bounds__(256) void distance_law_kernel(CsrView M, const uint8_t* __restrict__ det,
+__global__ __launch_bounds__(kLawThreads) void distance_law_kernel(CsrView M, const uint8_t* __restrict__ det,
                                                            int n_diags, double* __restrict__ g_sum,
                                                            unsigned long long* __restrict__ g_cnt,
                                                            int rows_per_block)
@@ -25,7 +32,7 @@ __global__ __launch_bounds__(256) void distance_law_kernel(CsrView M, const uint
     unsigned int* l_cnt = reinterpret_cast<unsigned int*>(smem_raw + sizeof(double) * (size_t)n_diags);
     const int tid = threadIdx.x;
     if (USE_LDS) {
-        for (int d = tid; d < n_diags; d += 256) {
+        for (int d = tid; d < n_diags; d += kLawThreads) {
             l_sum[d] = 0.0;
             l_cnt[d] = 0u;
         }
@@ -35,7 +42,7 @@ __global__ __launch_bounds__(256) void distance_law_kernel(CsrView M, const uint
     const int r_begin = blockIdx.x * rows_per_block;
     const int r_end = min(r_begin + rows_per_block, M.n_rows);
     const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
-    for (int row = r_begin + wv; row < r_end; row += 4) {
+    for (int row = r_begin + wv; row < r_end; row += kLawThreads / 64) {
         if (det && !det[row]) continue;
         const long long b = M.indptr[row], e = M.row_end[row];
         for (long long k = b + lane; k < e; k += 64) {
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(256) void distance_law_kernel(CsrView M, const uint
     }
     if (USE_LDS) {
         __syncthreads();
-        for (int d = tid; d < n_diags; d += 256) {
+        for (int d = tid; d < n_diags; d += kLawThreads) {
             if (l_cnt[d]) {
                 atomicAdd(&g_sum[d], l_sum[d]);
                 atomicAdd(&g_cnt[d], (unsigned long long)l_cnt[d]);
@@ -75,13 +82,13 @@ int launch_distance_law(const CsrView& M, const uint8_t* det, int n_diags, doubl
     if (M.n_rows == 0 || M.nnz == 0 || n_diags == 0) return 0;
     const size_t smem = (sizeof(double) + sizeof(unsigned int)) * (size_t)n_diags;
     const bool use_lds = smem <= 64 * 1024;
-    int blocks = min((M.n_rows + 3) / 4, n_cu * 8);
+    int blocks = min((M.n_rows + 15) / 16, n_cu);
     if (blocks < 1) blocks = 1;
     const int rows_per_block = (M.n_rows + blocks - 1) / blocks;
     blocks = (M.n_rows + rows_per_block - 1) / rows_per_block;
     auto cnt = reinterpret_cast<unsigned long long*>(d_cnt);
 #define CS_DL(TV, L)                                                                             \
-    hipLaunchKernelGGL((distance_law_kernel<TV, L>), dim3(blocks), dim3(256), (L) ? smem : 0,     \
+    hipLaunchKernelGGL((distance_law_kernel<TV, L>), dim3(blocks), dim3(kLawThreads), (L) ? smem : 0, \
                        stream, M, det, n_diags, d_sum, cnt, rows_per_block)
     if (M.is_f64) {
         if (use_lds) {
@@ -177,10 +184,73 @@ __global__ __launch_bounds__(256) void csr_to_band_kernel(CsrView M, const doubl
     }
 }
 
+// Band outputs of moderate width: one wave builds a whole band row in LDS (zeros, then the row's
+// stored pixels) and writes it out in one coalesced sweep, so the output is written exactly once --
+// no zero-fill pass over the band before the scatter (for a 200 000-bin block with 1018 float64
+// diagonals that pass alone moved 1.6 GB).
+constexpr int kBandRowMax = 2048;
+
+template <typename TV, typename TB>
+__global__ __launch_bounds__(256) void csr_to_band_rows_kernel(CsrView M, const double* __restrict__ law, int n_law,
+                                                               double max_val, MatView band)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ld = (int)band.ld;
+    TB* row_buf = reinterpret_cast<TB*>(smem_raw) + (size_t)wv * ld;
+    const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
+    TB* __restrict__ dst = reinterpret_cast<TB*>(band.ptr);
+    for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
+        for (int x = lane; x < ld; x += 64) row_buf[x] = TB(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long long b = M.indptr[row], e = M.row_end[row];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int col = M.indices[k] - M.col0;
+            if (col < 0 || col >= M.n_cols) continue;
+            const int x = col - row - band.band_lo;
+            if (x < 0 || x >= band.band_w) continue;
+            double v = csr_value(M, data, k, row, col);
+            if (law) v = detrend_value(v, col - row, law, n_law, max_val);
+            if (v != v) v = 0.0;
+            if constexpr (sizeof(TB) == 1) row_buf[x] = (v != 0.0) ? 1 : 0;
+            else row_buf[x] = (TB)v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        TB* out = dst + (size_t)row * ld;
+        for (int x = lane; x < ld; x += 64) out[x] = row_buf[x];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int launch_csr_to_band(const CsrView& M, const double* law, int n_law, double max_val,
                        const MatView& band, int band_dtype, int n_cu, hipStream_t stream)
 {
     const size_t esz = band_dtype == 1 ? 8 : (band_dtype == 2 ? 1 : 4);
+    if (band.layout == 1 && band.ld <= kBandRowMax && M.n_rows > 0) {
+        const size_t smem = 4 * (size_t)band.ld * esz;
+        int blocks = std::max(1, std::min((M.n_rows + 3) / 4, n_cu * 8));
+#define CS_C2R(TV, TB)                                                                                                  \
+    {                                                                                                                   \
+        if (smem > 48 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void*)csr_to_band_rows_kernel<TV, TB>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
+        hipLaunchKernelGGL((csr_to_band_rows_kernel<TV, TB>), dim3(blocks), dim3(256), smem, stream, M, law, n_law,       \
+                           max_val, band);                                                                              \
+    }
+        if (M.is_f64) {
+            if (band_dtype == 1) CS_C2R(double, double)
+            else if (band_dtype == 2) CS_C2R(double, uint8_t)
+            else CS_C2R(double, float)
+        } else {
+            if (band_dtype == 1) CS_C2R(float, double)
+            else if (band_dtype == 2) CS_C2R(float, uint8_t)
+            else CS_C2R(float, float)
+        }
+#undef CS_C2R
+        return (int)hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(band.ptr, 0, esz * (size_t)band.ld * (size_t)M.n_rows, stream);
     if (e != hipSuccess) return (int)e;
     if (M.n_rows == 0 || M.nnz == 0) return 0;

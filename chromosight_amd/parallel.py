@@ -172,7 +172,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
         from . import pipeline
         stage = stage or (lambda g, ci, md, lk: g.stage_intra(ci, md, lk, smooth=smooth, band_dtype=band_dtype,
                                                               resident=True))
-        detect = detect or (lambda g, blk, cfg, k, t: pipeline.detect_block(g, blk, cfg, k, tsvd=t))
+        detect = detect or (lambda g, blk, cfg, k, t: pipeline.detect_block(g, blk, cfg, k, tsvd=t, raw=True))
     dist, rank, world = _world()
     max_dist = max(kernel_config["max_dist"] // genome.binsize, 1)
     largest = max(np.shape(k)[0] for k in kernel_config["kernels"])
@@ -191,10 +191,13 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                     continue
                 rec = np.empty((len(table), len(GENOME_FIELDS)))
                 rec[:, 0] = ci
-                rec[:, 1] = table["bin1"].to_numpy(dtype=np.float64)
-                rec[:, 2] = table["bin2"].to_numpy(dtype=np.float64)
-                rec[:, 3] = table["score"].to_numpy(dtype=np.float64)
-                rec[:, 4] = table["pvalue"].to_numpy(dtype=np.float64)
+                if isinstance(table, np.ndarray):              # raw records (bin1, bin2, score, pvalue)
+                    rec[:, 1:5] = table
+                else:
+                    rec[:, 1] = table["bin1"].to_numpy(dtype=np.float64)
+                    rec[:, 2] = table["bin2"].to_numpy(dtype=np.float64)
+                    rec[:, 3] = table["score"].to_numpy(dtype=np.float64)
+                    rec[:, 4] = table["pvalue"].to_numpy(dtype=np.float64)
                 rec[:, 5] = kernel_id
                 rec[:, 6] = it
                 rows.append(rec)

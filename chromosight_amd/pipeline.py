@@ -364,7 +364,7 @@ class DeviceCool:
         return np.flatnonzero(~self.miss_host[s:e])
 
 
-def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, want_windows=True):
+def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, want_windows=True, raw=False):
     """pattern_detector(full=True) on a staged block (cli/chromosight.py:601-614)."""
     kernel = np.asarray(kernel, dtype=np.float64)
     if min(block.shape) <= max(kernel.shape):
@@ -372,7 +372,7 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
     kspec = engine.KernelSpec(kernel, tsvd)
     return cid.detect_on_device(dcool.dev, block.sig, block.shape, kspec, kernel_config, block.miss_row,
                                 block.miss_col, inter=block.inter, max_dist=block.max_dist, full=True, coords=coords,
-                                want_windows=want_windows)
+                                want_windows=want_windows, raw=raw)
 
 
 def sub_matrices(dcool, inter):
@@ -403,17 +403,18 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
         for it in range(kernel_config["max_iterations"]):
             tables, windows = [], []
             for (ca, cb), block in zip(pairs, blocks):
-                tab, win = detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd)
-                if tab is None:
+                tab, win = detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd, raw=True)
+                if tab is None or len(tab) == 0:
                     continue
-                tab = tab.copy()
-                tab["bin1"] += int(off[ca])
-                tab["bin2"] += int(off[cb])
+                tab[:, 0] += int(off[ca])
+                tab[:, 1] += int(off[cb])
                 tables.append(tab)
                 windows.append(win)
             if not tables:
                 break
-            coords = pd.concat(tables, axis=0).reset_index(drop=True)
+            rec = np.concatenate(tables, axis=0)
+            coords = pd.DataFrame({"bin1": rec[:, 0].astype(np.int64), "bin2": rec[:, 1].astype(np.int64),
+                                   "score": rec[:, 2], "pvalue": rec[:, 3]})
             coords["kernel_id"] = kernel_id
             coords["iteration"] = it
             all_coords.append(coords)

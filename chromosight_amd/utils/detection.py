@@ -541,13 +541,16 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
 
 
 def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, *, inter, max_dist, full,
-                     coords=None, want_windows=True):
+                     coords=None, want_windows=True, raw=False):
     """The part of pattern_detector that follows the staging of the contact map in HBM
     (reference detection.py:240-345): correlation, foci, validation statistics -- one native call
     (cs_detect_foci / cs_quantify_pixels) -- then the acceptance rules on the few returned records.
 
     sig: CsMatrix of the staged (detrended) map; miss_row / miss_col: uint8 device flags of the
-    undetectable bins (None when full is False).  Returns (table, windows) or (None, None)."""
+    undetectable bins (None when full is False).  Returns (table, windows) or (None, None); with
+    raw=True the table is a (n, 4) float64 array (bin1, bin2, score, pvalue) instead of a DataFrame
+    (the whole-genome drivers call this once per block and template: pandas would cost more than the
+    GPU work of a small block)."""
     ms, ns = shape
     km, kn = kspec.km, kspec.kn
     kh, kw = (km - 1) // 2, (kn - 1) // 2
@@ -611,9 +614,16 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
         prop_zero = n_zero.astype(np.float64) / (tot - n_miss).astype(np.float64)   # 0/0 -> nan -> rejected
     ok = (rec["inside"] != 0) & (prop_undetected < missing_tol) & (prop_zero < zero_tol)
     scores = np.where(ok, conv_at, np.nan)
-    table = pd.DataFrame({"bin1": rr, "bin2": cc, "score": scores})
     if windows is not None:
         windows[~ok] = np.nan
+    if raw:
+        with np.errstate(all="ignore"):
+            rec4 = np.column_stack([rr.astype(np.float64), cc.astype(np.float64), scores, 10.0 ** logp])
+        if run_mode == "detect":
+            rec4 = rec4[ok]
+            windows = windows[ok] if windows is not None else None
+        return rec4, windows
+    table = pd.DataFrame({"bin1": rr, "bin2": cc, "score": scores})
     if run_mode == "detect":
         table = table.loc[ok, :]
         windows = windows[ok] if windows is not None else None

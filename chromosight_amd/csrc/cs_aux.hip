@@ -184,43 +184,71 @@ __global__ __launch_bounds__(256) void csr_to_band_kernel(CsrView M, const doubl
     }
 }
 
-// Band outputs of moderate width: one wave builds a whole band row in LDS (zeros, then the row's
-// stored pixels) and writes it out in one coalesced sweep, so the output is written exactly once --
-// no zero-fill pass over the band before the scatter (for a 200 000-bin block with 1018 float64
-// diagonals that pass alone moved 1.6 GB).
-constexpr int kBandRowMax = 2048;
-
+// Band outputs: every element of the band is written exactly once, with no zero-fill pass before the
+// scatter (for a 200 000-bin block with 1018 float64 diagonals that pass alone moved 1.6 GB).  The
+// columns of a CSR row are sorted, so the lane that holds stored pixel k writes its value at
+// x_k = col_k - row - lo and the zeros of the gap up to the next stored pixel (up to the row pitch after
+// the last one; the lane of the first pixel also writes the leading gap).  Near the diagonal rows are
+// dense and the gaps are empty: the stores of a wave are one contiguous run.
 template <typename TV, typename TB>
 __global__ __launch_bounds__(256) void csr_to_band_rows_kernel(CsrView M, const double* __restrict__ law, int n_law,
                                                                double max_val, MatView band)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // a row is a chain of dependent global round trips (row pointers -> columns / values -> store), so
+    // every wave works on R rows at once to keep R chains in flight
+    constexpr int R = 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ld = (int)band.ld;
-    TB* row_buf = reinterpret_cast<TB*>(smem_raw) + (size_t)wv * ld;
+    const int ld = (int)band.ld, W = band.band_w;
     const TV* __restrict__ data = reinterpret_cast<const TV*>(M.data);
     TB* __restrict__ dst = reinterpret_cast<TB*>(band.ptr);
-    for (int row = blockIdx.x * 4 + wv; row < M.n_rows; row += gridDim.x * 4) {
-        for (int x = lane; x < ld; x += 64) row_buf[x] = TB(0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const long long b = M.indptr[row], e = M.row_end[row];
-        for (long long k = b + lane; k < e; k += 64) {
-            const int col = M.indices[k] - M.col0;
-            if (col < 0 || col >= M.n_cols) continue;
-            const int x = col - row - band.band_lo;
-            if (x < 0 || x >= band.band_w) continue;
-            double v = csr_value(M, data, k, row, col);
-            if (law) v = detrend_value(v, col - row, law, n_law, max_val);
-            if (v != v) v = 0.0;
-            if constexpr (sizeof(TB) == 1) row_buf[x] = (v != 0.0) ? 1 : 0;
-            else row_buf[x] = (TB)v;
+    const int stride = gridDim.x * 4;
+    auto slot = [&](long long k, int row) {      // band slot of stored pixel k, clamped to [-1, W]
+        const int col = M.indices[k] - M.col0;
+        long long x = (long long)col - row - band.band_lo;
+        if (col < 0) x = -1;
+        if (col >= M.n_cols) x = W;
+        return (int)(x < -1 ? -1 : (x > W ? W : x));
+    };
+    for (int row0 = blockIdx.x * 4 + wv; row0 < M.n_rows; row0 += R * stride) {
+        long long b[R], e[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r * stride;
+            const bool live = row < M.n_rows;
+            b[r] = live ? M.indptr[row] : 0;
+            e[r] = live ? M.row_end[row] : 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        TB* out = dst + (size_t)row * ld;
-        for (int x = lane; x < ld; x += 64) out[x] = row_buf[x];
-        __builtin_amdgcn_wave_barrier();
+        long long len = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            len = max(len, e[r] - b[r]);
+            const int row = row0 + r * stride;
+            if (row < M.n_rows && e[r] == b[r])                        // empty row: all zeros
+                for (int x = lane; x < ld; x += 64) dst[(size_t)row * ld + x] = TB(0);
+        }
+        for (long long o = lane; o < len; o += 64) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const long long k = b[r] + o;
+                if (k >= e[r]) continue;
+                const int row = row0 + r * stride;
+                TB* out = dst + (size_t)row * ld;
+                const int x = slot(k, row);
+                const int nx = (k + 1 < e[r]) ? slot(k + 1, row) : ld;
+                if (x >= 0 && x < W) {
+                    const int col = M.indices[k] - M.col0;
+                    double v = csr_value(M, data, k, row, col);
+                    if (law) v = detrend_value(v, col - row, law, n_law, max_val);
+                    if (v != v) v = 0.0;
+                    if constexpr (sizeof(TB) == 1) out[x] = (v != 0.0) ? 1 : 0;
+                    else out[x] = (TB)v;
+                }
+                const int z1 = (k + 1 < e[r]) ? min(nx, W) : ld;      // zeros up to the next stored slot / the pitch
+                for (int z = (x >= W ? W : x + 1); z < z1; ++z) out[z] = TB(0);
+                if (k == b[r])
+                    for (int z = 0; z < min(x, W); ++z) out[z] = TB(0);   // leading gap
+            }
+        }
     }
 }
 
@@ -228,9 +256,9 @@ int launch_csr_to_band(const CsrView& M, const double* law, int n_law, double ma
                        const MatView& band, int band_dtype, int n_cu, hipStream_t stream)
 {
     const size_t esz = band_dtype == 1 ? 8 : (band_dtype == 2 ? 1 : 4);
-    if (band.layout == 1 && band.ld <= kBandRowMax && M.n_rows > 0) {
-        const size_t smem = 4 * (size_t)band.ld * esz;
-        int blocks = std::max(1, std::min((M.n_rows + 3) / 4, n_cu * 8));
+    if (band.layout == 1 && M.n_rows > 0) {
+        const size_t smem = 0;
+        int blocks = std::max(1, std::min((M.n_rows + 7) / 8, n_cu * 8));
 #define CS_C2R(TV, TB)                                                                                                  \
     {                                                                                                                   \
         if (smem > 48 * 1024)                                                                                           \

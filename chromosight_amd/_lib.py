@@ -14,7 +14,8 @@ CS_F32, CS_F64 = 0, 1
 LAYOUT_DENSE, LAYOUT_BAND = 0, 1
 MASK_NONE, MASK_BINS, MASK_EXPLICIT = 0, 1, 2
 
-_LIB_PATH = pathlib.Path(__file__).with_name("libchromosight_hip.so")
+# CHROMOSIGHT_HIP_LIBRARY: another build of the same library (diagnostics, e.g. the section-timing build)
+_LIB_PATH = pathlib.Path(os.environ.get("CHROMOSIGHT_HIP_LIBRARY") or pathlib.Path(__file__).with_name("libchromosight_hip.so"))
 
 
 class CsMatrix(C.Structure):

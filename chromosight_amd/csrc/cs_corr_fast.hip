@@ -144,6 +144,17 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     return launch(corr_stream_kernel<TC, CS_K, 0, false>, smem0);
 }
 
+#if defined(CS_PROFILE) && CS_K == 17
+// diagnostics build only: read and clear the section timers of cs_corr_stream.h
+extern "C" int cs_debug_profile(unsigned long long* out)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(cs_prof), sizeof(cs_prof));
+    if (e != hipSuccess) return (int)e;
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(cs_prof), zero, sizeof(zero));
+}
+#endif
+
 #define CS_CAT_(a, b) a##b
 #define CS_CAT(a, b) CS_CAT_(a, b)
 

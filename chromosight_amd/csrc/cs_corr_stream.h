@@ -541,6 +541,21 @@ __device__ __forceinline__ double lane_value(double v, int idx)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Optional section timing of the row loop (diagnostics build, -DCS_PROFILE): wave cycles between the
+// loop top, the start and the end of the FMA block, summed over all waves into cs_prof[].  s_memtime
+// waits for outstanding LDS / scalar loads, so the stamps sit where the loop waits anyway.
+#ifdef CS_PROFILE
+__device__ unsigned long long cs_prof[8];
+#define CS_STAMP(n)                                                 \
+    {                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof_[n] += now_ - tlast_;                                  \
+        tlast_ = now_;                                              \
+    }
+#else
+#define CS_STAMP(n)
+#endif
+
 // Lean view of the launch arguments (only what the row loop needs stays in registers).
 template <typename TC>
 struct StreamArgs {
@@ -862,10 +877,61 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         }
     };
 
+    // the common output (float32 map, no n_obs, not a plain cross-correlation) has a straight-line
+    // epilogue: both columns of the lane together, one divergent region for the rare pixels near a
+    // zeroing threshold, one store region.  Run pixel by pixel through the general code below, the four
+    // pixels of an iteration were a chain of ~40 scalar branches and took half of the iteration.
+    const bool fast_epi = (sizeof(TC) == 4) && !A.out_is_f64 && !A.nobs && !A.xcorr_only;
+
     auto emit = [&](int oi, const acc_t<TC>& cs2, const TC (&s1)[2], const TC (&s2)[2],
                     const TC (&nm)[2], const acc_t<TC>& ka2, const acc_t<TC>& kb2, const TC (&fx)[2][3]) {
         const bool row_margin = !A.full && ((oi < KH) | (oi > A.ms - K + KH));
         const TC csv[2] = {cs2.x, cs2.y}, kav[2] = {ka2.x, ka2.y}, kbv[2] = {kb2.x, kb2.y};
+        if constexpr (sizeof(TC) == 4) {
+            if (fast_epi) {
+                const bool in0 = ocol_ok[0] & (d_out >= A.out_lo) & (d_out <= A.out_hi) & (oi < A.ms);
+                const bool in1 = ocol_ok[1] & (d_out + 1 >= A.out_lo) & (d_out + 1 <= A.out_hi) & (oi < A.ms);
+                const bool z0 = row_margin | ocol_margin[0] | (A.sym_upper && d_out < 0);
+                const bool z1 = row_margin | ocol_margin[1] | (A.sym_upper && d_out + 1 < 0);
+                bool rare0, rare1;
+                float r0, r1;
+                if constexpr (REG || MASKED) {
+                    float n0 = nm[0], n1 = nm[1], a0 = kav[0], a1 = kav[1], b0 = kbv[0], b1 = kbv[1];
+                    if constexpr (REG) {
+                        n0 += fx[0][0]; a0 += fx[0][1]; b0 += fx[0][2];
+                        n1 += fx[1][0]; a1 += fx[1][1]; b1 += fx[1][2];
+                    }
+                    r0 = pearson_masked_core(csv[0], s1[0], s2[0], n0, a0, b0, A.ks, rare0);
+                    r1 = pearson_masked_core(csv[1], s1[1], s2[1], n1, a1, b1, A.ks, rare1);
+                    if (rare0 | rare1) {
+                        r0 = pearson_masked_f32(csv[0], s1[0], s2[0], n0, a0, b0, A.ks);
+                        r1 = pearson_masked_f32(csv[1], s1[1], s2[1], n1, a1, b1, A.ks);
+                    }
+                } else {
+                    r0 = pearson_nomask_core(csv[0], s1[0], s2[0], A.ks, rare0);
+                    r1 = pearson_nomask_core(csv[1], s1[1], s2[1], A.ks, rare1);
+                    if (rare0 | rare1) {
+                        r0 = pearson_nomask_f32(csv[0], s1[0], s2[0], A.ks);
+                        r1 = pearson_nomask_f32(csv[1], s1[1], s2[1], A.ks);
+                    }
+                }
+                r0 = z0 ? 0.0f : r0;
+                r1 = z1 ? 0.0f : r1;
+                float* o = (float*)A.out + out_idx;
+                if (!A.band_out && in0 && in1) {           // dense: the pair is 8-byte aligned
+                    f32x2 pr;
+                    pr.x = r0;
+                    pr.y = r1;
+                    *reinterpret_cast<f32x2*>(o) = pr;
+                } else {
+                    if (in0) o[0] = r0;
+                    if (in1) o[1] = r1;
+                }
+                out_idx += out_step;
+                d_out -= 1;
+                return;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int d = d_out + c;
@@ -938,7 +1004,13 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         ra.load(ring + slot_a * G::LWP + lane * 2);
         rb.load(ring + ring_next(slot_a, 1) * G::LWP + lane * 2);
     }
+#ifdef CS_PROFILE
+    unsigned long long prof_[4] = {0, 0, 0, 0};
+    unsigned long long tlast_ = __builtin_readcyclecounter();
+    const unsigned long long tstart_ = tlast_;
+#endif
     for (int t = 0; t < n_staged; t += 2) {
+        CS_STAMP(3)      // (loop back-edge, LDS row loads of a non-pipelined kernel)
         if constexpr (!PIPE) {
             ra.load(ring + slot_a * G::LWP + lane * 2);
             rb.load(ring + ring_next(slot_a, 1) * G::LWP + lane * 2);
@@ -1017,7 +1089,9 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         acc_t<TC> outA, outB;
         // template rows that reach output rows of the strip (see steps2_rec)
         const int q_need = __builtin_amdgcn_readfirstlane(min(min((K + 1) / 2, t + 2), K - max(0, t - rows_out + 1)));
+        CS_STAMP(0)      // box sums, cache swap, issue of the global loads
         steps2<TC, K, 0, SYM, SKIP>(ra, rb, A.w, X, outA, outB, QA, QB, q_need);
+        CS_STAMP(1)      // FMA block incl. the waits for the weight rows
 
         acc_t<TC> kaA = acc_zero<TC>(), kaB = acc_zero<TC>(), kbA = acc_zero<TC>(), kbB = acc_zero<TC>();
         if constexpr (MASKED) {
@@ -1096,7 +1170,19 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
             }
         }
         if constexpr (!PIPE) advance();
+        CS_STAMP(2)      // commit, LDS row loads, epilogue
     }
+#ifdef CS_PROFILE
+    if (lane == 0) {
+        atomicAdd(&cs_prof[0], prof_[0]);
+        atomicAdd(&cs_prof[1], prof_[1]);
+        atomicAdd(&cs_prof[2], prof_[2]);
+        atomicAdd(&cs_prof[3], prof_[3]);
+        atomicAdd(&cs_prof[4], __builtin_readcyclecounter() - tstart_);
+        atomicAdd(&cs_prof[5], (unsigned long long)(tstart_ != 0));
+        atomicAdd(&cs_prof[6], (unsigned long long)((n_staged + 1) / 2));
+    }
+#endif
 }
 
 template <int K, typename TC, int MODE>

@@ -282,20 +282,20 @@ __device__ __forceinline__ float pearson_nomask_f32(float cs, float s1, float s2
 __device__ __forceinline__ float pearson_masked_f32(float cs, float s1, float s2, float nm, float ka, float kb,
                                                     const KernelStats<float>& K);
 
-__device__ __forceinline__ float pearson_nomask_lean(float cs, float s1, float s2, const KernelStats<float>& K)
+// branch-free cores: coefficient by the one-rsq formula plus "this pixel is near a zeroing threshold"
+__device__ __forceinline__ float pearson_nomask_core(float cs, float s1, float s2, const KernelStats<float>& K, bool& rare)
 {
     const float A = fmaf(s2, K.n, -s1 * s1);
     const float den2 = A * K.kvar;
     float r = cs * __builtin_amdgcn_rsqf(den2);
     r = (den2 >= K.den2_min) ? r : 0.0f;                 // denominator under eps, NaN -> 0
     r = __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
-    const bool normal = (int)(fabsf(s1) >= K.thr_n) & (int)(s2 >= K.thr_n) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= K.thr_n);
-    if (!normal) r = pearson_nomask_f32(cs, s1, s2, K);
+    rare = !((int)(fabsf(s1) >= K.thr_n) & (int)(s2 >= K.thr_n) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= K.thr_n));
     return r;
 }
 
-__device__ __forceinline__ float pearson_masked_lean(float cs, float s1, float s2, float nm, float ka, float kb,
-                                                     const KernelStats<float>& K)
+__device__ __forceinline__ float pearson_masked_core(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                     const KernelStats<float>& K, bool& rare)
 {
     const float np = K.n - nm;
     const float num = fmaf(cs, np, s1 * ka);
@@ -313,7 +313,24 @@ __device__ __forceinline__ float pearson_masked_lean(float cs, float s1, float s
         const float k2m = kb + 2.0f * K.kmean * ka + K.kmean * K.kmean * nm;
         normal &= (nm < 0.5f) || ((fabsf(km_) >= K.thr) && (fabsf(k2m) >= K.thr));
     }
-    if (!normal) r = pearson_masked_f32(cs, s1, s2, nm, ka, kb, K);
+    rare = !normal;
+    return r;
+}
+
+__device__ __forceinline__ float pearson_nomask_lean(float cs, float s1, float s2, const KernelStats<float>& K)
+{
+    bool rare;
+    float r = pearson_nomask_core(cs, s1, s2, K, rare);
+    if (rare) r = pearson_nomask_f32(cs, s1, s2, K);
+    return r;
+}
+
+__device__ __forceinline__ float pearson_masked_lean(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                     const KernelStats<float>& K)
+{
+    bool rare;
+    float r = pearson_masked_core(cs, s1, s2, nm, ka, kb, K, rare);
+    if (rare) r = pearson_masked_f32(cs, s1, s2, nm, ka, kb, K);
     return r;
 }
 

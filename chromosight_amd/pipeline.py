@@ -186,6 +186,9 @@ class DeviceCool:
     band tiler all read the same arrays (cs_csr views, include/chromosight_hip.h)."""
 
     def __init__(self, cool, dev=None):
+        if isinstance(cool, (str, bytes)) or hasattr(cool, "__fspath__"):
+            from . import io as cio
+            cool = cio.load_cool(cool)                     # a .cool path: decoded here (chromosight_amd/io.py)
         self.dev = dev = dev or get_device()
         off = np.asarray(cool["chrom_offset"], dtype=np.int64)
         self.offsets = off

@@ -206,11 +206,12 @@ def distance_law(matrix, detectable_bins=None, max_dist=None, smooth=True, fun=n
     min(N, max_dist+1) upper diagonals, restricted to detectable bins; NaN for diagonals
     without such a pixel, 0 beyond (reference preprocessing.py:129-197).
 
-    The per-diagonal sums and counts are reduced on the GPU (cs_distance_law_csr); only
-    fun=np.nanmean / np.mean is available there."""
-    if fun not in (np.nanmean, np.mean):
-        raise NotImplementedError("the device distance law supports fun=np.nanmean only")
+    The per-diagonal sums and counts are reduced on the GPU (cs_distance_law_csr).  Any other
+    reducer (the reference accepts e.g. np.nanmedian) needs the pixels of a diagonal together and is
+    applied on the host, diagonal by diagonal, as the reference does."""
     matrix = sp.csr_matrix(matrix)
+    if fun not in (np.nanmean, np.mean):
+        return _distance_law_host(matrix, detectable_bins, max_dist, smooth, fun)
     mat_n = matrix.shape[0]
     if max_dist is None:
         max_dist = mat_n
@@ -231,6 +232,27 @@ def distance_law(matrix, detectable_bins=None, max_dist=None, smooth=True, fun=n
     return dist
 
 
+def _distance_law_host(matrix, detectable_bins, max_dist, smooth, fun):
+    """distance_law for an arbitrary reducer (reference preprocessing.py:173-188)."""
+    mat_n = matrix.shape[0]
+    if max_dist is None:
+        max_dist = mat_n
+    n_diags = min(mat_n, max_dist + 1)
+    flag = np.ones(mat_n, dtype=bool)
+    if detectable_bins is not None:
+        flag[:] = False
+        flag[detectable_bins] = True
+    dist = np.zeros(mat_n)
+    with np.errstate(all="ignore"):
+        for d in range(n_diags):
+            diag = matrix.diagonal(d)[flag[:mat_n - d] & flag[d:]]
+            dist[d] = fun(diag[diag > 0])
+    if smooth and mat_n > 2:
+        dist[~np.isfinite(dist)] = 0
+        dist = _isotonic_non_increasing(dist)
+    return dist
+
+
 def detrend(matrix, detectable_bins=None, max_dist=None, smooth=False, fun=np.nanmean, max_val=10):
     """Divide every stored pixel by the distance law of its diagonal, then set values
     >= max_val to 1 (reference preprocessing.py:256-310).  Returns CSR; the input is untouched."""
@@ -242,7 +264,11 @@ def detrend(matrix, detectable_bins=None, max_dist=None, smooth=False, fun=np.na
         matrix.sum_duplicates()
     dev = get_device()
     dcsr = engine.DeviceCsr(dev, matrix)
-    data = engine.detrend_values(dev, dcsr, y, max_val)
+    # the device cap is "max_val > 0"; None = no cap; an explicit non-positive cap (every value >= it
+    # becomes 1, reference :308-309) is applied here
+    data = engine.detrend_values(dev, dcsr, y, max_val if (max_val is not None and max_val > 0) else 0.0)
+    if max_val is not None and max_val <= 0:
+        data = np.where(data >= max_val, 1.0, data)
     return sp.csr_matrix((data, matrix.indices.copy(), matrix.indptr.copy()), shape=matrix.shape)
 
 

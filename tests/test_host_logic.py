@@ -323,3 +323,36 @@ def test_sub_matrix_order_and_bins():
         n_chrom = 3
     assert pipeline.sub_matrices(G, False) == [(0, 0), (1, 1), (2, 2)]
     assert pipeline.sub_matrices(G, True) == [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]   # contacts_map.py:274-279
+
+
+def test_load_cool_decodes_the_reference_fixture(golden):
+    """chromosight_amd.io.load_cool on data_test/example.cool (the reference's own test file, kept as
+    a data fixture) == the decoded arrays every pipeline test uses."""
+    from chromosight_amd import io as cio
+    try:
+        cio.find_h5dump()
+    except RuntimeError:
+        pytest.skip("no h5dump in this environment")
+    from conftest import GOLDEN
+    cool = cio.load_cool(GOLDEN / "example.cool")
+    ref = golden("example_cool")
+    for key in ("bin1_id", "bin2_id", "count", "bin_start", "bin_end", "chrom_offset", "binsize"):
+        assert np.array_equal(np.asarray(cool[key]).astype(np.int64), np.asarray(ref[key]).astype(np.int64)), key
+    assert np.array_equal(np.isnan(cool["weight"]), np.isnan(ref["weight"]))
+    assert np.allclose(cool["weight"], ref["weight"], equal_nan=True, rtol=0, atol=0)
+    assert [str(n) for n in cool["chrom_names"]] == [str(n) for n in ref["chrom_names"]]
+
+
+def test_distance_law_other_reducers_on_host():
+    """fun other than (nan)mean is evaluated diagonal by diagonal on the host (no device needed)."""
+    rng = np.random.default_rng(3)
+    m = np.triu(rng.gamma(2, 1, size=(30, 30))) * (rng.random((30, 30)) > 0.3)
+    det = np.setdiff1d(np.arange(30), [4, 17])
+    got = cup.distance_law(sp.csr_matrix(m), detectable_bins=det, max_dist=12, smooth=False, fun=np.nanmedian)
+    flag = np.zeros(30, bool)
+    flag[det] = True
+    for d in range(13):
+        diag = np.diagonal(m, d)[flag[:30 - d] & flag[d:]]
+        v = diag[diag > 0]
+        assert (np.isnan(got[d]) and v.size == 0) or got[d] == np.median(v)
+    assert np.all(got[13:] == 0)

@@ -957,40 +957,60 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
         map.band_lo = map.band_w = 0;
         map.ld = ((int64_t)p->ns + 15) / 16 * 16;
     }
-    const size_t map_bytes = (size_t)p->ms * (size_t)map.ld * (f64 ? 8 : 4);
-    rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
-    if (rc) return rc;
-    map.d_ptr = ctx->d_map;
-    rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
-    if (rc) return rc;
-    // ---- candidates: thresholded compaction (with the re-scoring margin on float32 maps)
-    const double thr = f64 ? fp->pearson : fp->pearson - fp->rescore_margin;
+    // 1-D patterns (borders, hairpins: max_dist = 0 in the config, 2 scanned diagonals): a streamed
+    // 128-column strip would compute 64 columns for every one it keeps.  Every pixel of the few diagonals
+    // is a candidate instead and goes straight to the float64 evaluation (one wave per pixel).
+    const bool narrow = signal->layout == CS_LAYOUT_BAND && map.band_w <= 4 && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW");
     long long n_cand = 0;
-    size_t c_cap = std::max<size_t>(1 << 16, (size_t)p->ms * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t off_cols = 0, off_vals = 0, off_cnt = 0, off_win = 0, off_foci = 0;
     const size_t win_pat = fp->want_windows ? (size_t)std::max<int64_t>(cap, 1) : 0;
-    while (true) {
-        if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
+    auto layout = [&](size_t c_cap) {
         off_cols = al(4 * c_cap);
         off_vals = off_cols + al(4 * c_cap);
         off_cnt = off_vals + al(8 * c_cap);
         off_win = off_cnt + 256;
         off_foci = off_win + al(8 * win_pat * kk);
-        rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_foci + cs::foci_scratch_bytes((long long)c_cap));
+        return ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_foci + cs::foci_scratch_bytes((long long)c_cap));
+    };
+    if (narrow) {
+        n_cand = cs::narrow_band_pixels(p->ms, p->ns, map.band_lo, map.band_w);
+        if (n_cand > INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%lld)", n_cand);
+        if (n_cand > 0) {
+            rc = layout((size_t)n_cand);
+            if (rc) return rc;
+            char* pool = (char*)ctx->d_pool;
+            rc = cs::enqueue_enumerate_band(p->ms, p->ns, map.band_lo, map.band_w, n_cand, (int*)pool, (int*)(pool + off_cols),
+                                            stream);
+            if (rc) return fail(ctx, CS_ERR_HIP, "enumerate launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
+    } else {
+        const size_t map_bytes = (size_t)p->ms * (size_t)map.ld * (f64 ? 8 : 4);
+        rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
         if (rc) return rc;
-        char* pool = (char*)ctx->d_pool;
-        long long* d_cnt = (long long*)(pool + off_cnt);
-        CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
-        rc = cs::launch_compact_ge(view_of(&map), f64, p->ms, p->ns, thr, fp->lo_diag, fp->hi_diag, (int*)pool,
-                                   (int*)(pool + off_cols), (double*)(pool + off_vals), (long long)c_cap, d_cnt, ctx->n_cu,
-                                   stream);
-        if (rc) return fail(ctx, CS_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)rc));
-        CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
-        CS_HIP(ctx, hipStreamSynchronize(stream));
-        n_cand = ctx->h_counts[0];
-        if ((size_t)n_cand <= c_cap) break;
-        c_cap = (size_t)n_cand + (size_t)n_cand / 8;
+        map.d_ptr = ctx->d_map;
+        rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
+        if (rc) return rc;
+        // ---- candidates: thresholded compaction (with the re-scoring margin on float32 maps)
+        const double thr = f64 ? fp->pearson : fp->pearson - fp->rescore_margin;
+        size_t c_cap = std::max<size_t>(1 << 16, (size_t)p->ms * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
+        while (true) {
+            if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
+            rc = layout(c_cap);
+            if (rc) return rc;
+            char* pool = (char*)ctx->d_pool;
+            long long* d_cnt = (long long*)(pool + off_cnt);
+            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+            rc = cs::launch_compact_ge(view_of(&map), f64, p->ms, p->ns, thr, fp->lo_diag, fp->hi_diag, (int*)pool,
+                                       (int*)(pool + off_cols), (double*)(pool + off_vals), (long long)c_cap, d_cnt,
+                                       ctx->n_cu, stream);
+            if (rc) return fail(ctx, CS_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)rc));
+            CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+            CS_HIP(ctx, hipStreamSynchronize(stream));
+            n_cand = ctx->h_counts[0];
+            if ((size_t)n_cand <= c_cap) break;
+            c_cap = (size_t)n_cand + (size_t)n_cand / 8;
+        }
     }
     if (n_cand == 0) return CS_OK;
     // ---- foci

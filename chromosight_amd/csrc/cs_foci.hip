@@ -380,6 +380,48 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     return (int)hipGetLastError();
 }
 
+// ---- 1-D patterns: every pixel of a band of at most 4 diagonals is a candidate ---------------------
+namespace {
+__global__ __launch_bounds__(kThreads) void enumerate_band_kernel(int ms, int ns, int lo, int w, long long n,
+                                                                  int* __restrict__ rows, int* __restrict__ cols)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n) return;
+    // diagonal-major enumeration: diagonal d = lo + x holds the rows max(0, -d) .. min(ms, ns - d) - 1
+    long long rest = t;
+    for (int x = 0; x < w; ++x) {
+        const int d = lo + x;
+        const int r0 = d < 0 ? -d : 0;
+        const long long cnt = (long long)min(ms, ns - d) - r0;
+        if (cnt <= 0) continue;
+        if (rest < cnt) {
+            rows[t] = r0 + (int)rest;
+            cols[t] = r0 + (int)rest + d;
+            return;
+        }
+        rest -= cnt;
+    }
+}
+}  // namespace
+
+long long narrow_band_pixels(int ms, int ns, int lo, int w)
+{
+    long long n = 0;
+    for (int x = 0; x < w; ++x) {
+        const int d = lo + x;
+        const long long cnt = (long long)std::min(ms, ns - d) - (d < 0 ? -d : 0);
+        if (cnt > 0) n += cnt;
+    }
+    return n;
+}
+
+int enqueue_enumerate_band(int ms, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(enumerate_band_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, ms, ns, lo, w, n, d_rows, d_cols);
+    return (int)hipGetLastError();
+}
+
 // ---- median of the stored values of a CSR view (inter-chromosomal blocks are scaled by it) -------
 namespace {
 __global__ __launch_bounds__(kThreads) void row_len_kernel(CsrView M, int* __restrict__ len)

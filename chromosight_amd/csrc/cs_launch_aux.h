@@ -53,6 +53,10 @@ int launch_law_finish(const double* sum, const long long* cnt, int n, double* la
 // median of the stored values of a view (cs_foci.hip)
 int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_median);
 
+// 1-D patterns: all pixels of a band of a few diagonals as the candidate list (cs_foci.hip)
+long long narrow_band_pixels(int ms, int ns, int lo, int w);
+int enqueue_enumerate_band(int ms, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream);
+
 // device-side foci (cs_foci.hip)
 size_t foci_scratch_bytes(long long n_cand);
 int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,

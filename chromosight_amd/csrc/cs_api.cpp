@@ -121,14 +121,16 @@ int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w
         ctx->d_w[slot] = nullptr;
         ctx->d_w_bytes[slot] = 0;
         CS_HIP(ctx, hipMalloc(&ctx->d_w[slot], bytes + 64));
-        CS_HIP(ctx, hipMemset(ctx->d_w[slot], 0, bytes + 64));
+        CS_HIP(ctx, hipMemsetAsync(ctx->d_w[slot], 0, bytes + 64, stream));   // same stream as the upload below
         ctx->d_w_bytes[slot] = bytes + 64;
         ctx->w_cached[slot].clear();
     }
     if (ctx->w_cached[slot].size() == bytes && std::memcmp(ctx->w_cached[slot].data(), w.data(), bytes) == 0)
         return CS_OK;
-    // pageable source: the runtime stages it before returning, so `w` may die here
     CS_HIP(ctx, hipMemcpyAsync(ctx->d_w[slot], w.data(), bytes, hipMemcpyHostToDevice, stream));
+    // `w` is pageable and dies here: on a non-default stream the runtime may still be reading it after
+    // the call returns, so wait (uploads only happen when the template changes)
+    CS_HIP(ctx, hipStreamSynchronize(stream));
     ctx->w_cached[slot].assign((unsigned char*)w.data(), (unsigned char*)w.data() + bytes);
     return CS_OK;
 }
@@ -557,7 +559,12 @@ int cs_free(cs_ctx* ctx, void* d_ptr)
 int cs_memcpy_h2d(cs_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream)
 {
     CS_ENTER(ctx);
-    if (bytes) CS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (bytes) {
+        CS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        // the caller may reuse h_src as soon as this returns (pageable sources are not always staged
+        // before an asynchronous copy returns)
+        CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    }
     return CS_OK;
 }
 

@@ -94,7 +94,7 @@ int launch_distance_law(const CsrView& M, const uint8_t* det, int n_diags, doubl
         if (use_lds) {
             if (smem > 48 * 1024)
                 (void)hipFuncSetAttribute((const void*)distance_law_kernel<double, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             CS_DL(double, true);
         } else {
             CS_DL(double, false);
@@ -103,7 +103,7 @@ int launch_distance_law(const CsrView& M, const uint8_t* det, int n_diags, doubl
         if (use_lds) {
             if (smem > 48 * 1024)
                 (void)hipFuncSetAttribute((const void*)distance_law_kernel<float, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             CS_DL(float, true);
         } else {
             CS_DL(float, false);
@@ -263,7 +263,7 @@ int launch_csr_to_band(const CsrView& M, const double* law, int n_law, double ma
     {                                                                                                                   \
         if (smem > 48 * 1024)                                                                                           \
             (void)hipFuncSetAttribute((const void*)csr_to_band_rows_kernel<TV, TB>,                                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
         hipLaunchKernelGGL((csr_to_band_rows_kernel<TV, TB>), dim3(blocks), dim3(256), smem, stream, M, law, n_law,       \
                            max_val, band);                                                                              \
     }

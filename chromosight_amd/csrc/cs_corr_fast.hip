@@ -116,7 +116,9 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
             }
         }
         if (smem_req > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req);
+            // process-wide property of the kernel: always the hardware maximum, so that launches from
+            // several host threads (pipeline._Workers) cannot undercut each other
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NWAVES * kWave), smem_req, stream, S);

@@ -115,7 +115,7 @@ static int launch_generic(const CorrArgs<TC>& A, hipStream_t stream)
     if (smem > 160 * 1024) return -3;
     auto kern = corr_generic_kernel<TC>;
     if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(A.tiles_x, A.tiles_y), block(256);

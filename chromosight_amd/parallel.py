@@ -168,6 +168,10 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     holds the pixels of its own chromosomes); default: LPT by scanned pixels.
     Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
     bins, identical on all ranks, in the single-process order."""
+    batch = None
+    if stage is None and detect is None:
+        from . import pipeline
+        batch = lambda g, blks, cfg, k, t: pipeline.detect_blocks(g, blks, cfg, k, tsvd=t, raw=True)
     if stage is None or detect is None:
         from . import pipeline
         stage = stage or (lambda g, ci, md, lk: g.stage_intra(ci, md, lk, smooth=smooth, band_dtype=band_dtype,
@@ -185,8 +189,10 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
         kernel = np.asarray(kernel, dtype=np.float64)
         for it in range(kernel_config["max_iterations"]):
             rows, wins = [], []
-            for ci in mine:
-                table, windows = detect(genome, staged[ci], kernel_config, kernel, tsvd)
+            results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd) if batch else None
+            for pos, ci in enumerate(mine):
+                table, windows = results[pos] if results is not None else detect(genome, staged[ci], kernel_config,
+                                                                                kernel, tsvd)
                 if table is None or len(table) == 0:
                     continue
                 rec = np.empty((len(table), len(GENOME_FIELDS)))

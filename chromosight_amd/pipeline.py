@@ -169,12 +169,48 @@ class _Scratch:
 
 class StagedBlock:
     """One sub-matrix staged in HBM (detrended band or dense map + the flags of its undetectable
-    bins): what pattern_detector works on after ContactMap.create_mat (contacts_map.py:527-548)."""
+    bins): what pattern_detector works on after ContactMap.create_mat (contacts_map.py:453-526)."""
 
     def __init__(self, name, sig, shape, miss_row, miss_col, max_dist, inter, keep):
         self.name, self.sig, self.shape = name, sig, shape
         self.miss_row, self.miss_col = miss_row, miss_col
         self.max_dist, self.inter, self.keep = max_dist, inter, keep
+        self.buffer, self.pool = None, None
+
+    def __del__(self):
+        # a resident block hands its HBM back to the genome's free list (hipFree synchronises and costs
+        # ~0.2 ms; a genome is restaged for every pattern configuration)
+        try:
+            if self.buffer is not None and self.pool is not None:
+                self.pool.append(self.buffer)
+        except Exception:
+            pass
+
+
+class _Workers:
+    """A few host threads, each with its own context (scratch, weights, pinned result buffers) and
+    stream on the same GPU.  One (block, template) call is a chain of ~25 small launches and three
+    host synchronisations; calls for different blocks are independent, so running several at once lets
+    the GPU overlap their latency-bound kernels (ctypes releases the GIL during the native call)."""
+
+    def __init__(self, index, n):
+        import concurrent.futures
+        import threading
+        from ._lib import Device
+        self.local = threading.local()
+        self.index = index
+        self.device_cls = Device
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=n)
+
+    def device(self):
+        dev = getattr(self.local, "dev", None)
+        if dev is None:
+            dev = self.local.dev = self.device_cls(self.index)
+            self.local.stream = dev.new_stream()
+        return dev, self.local.stream
+
+    def map(self, fn, items):
+        return list(self.pool.map(fn, items))
 
 
 class DeviceCool:
@@ -222,6 +258,22 @@ class DeviceCool:
         self.upload_bytes = self.indptr.nbytes + self.indices.nbytes + self.data.nbytes + self.weight.nbytes
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
+        self._free = []                 # HBM of released resident blocks, reused by the next staging
+        self._workers = None
+
+    def _resident(self, nbytes):
+        best = None
+        for k, buf in enumerate(self._free):
+            if buf.nbytes >= nbytes and (best is None or buf.nbytes < self._free[best].nbytes):
+                best = k
+        if best is not None:
+            return self._free.pop(best)
+        return self.dev.empty(nbytes, np.uint8)
+
+    def workers(self, n=4):
+        if self._workers is None:
+            self._workers = _Workers(self.dev.index, n)
+        return self._workers
 
     @property
     def n_chrom(self):
@@ -276,13 +328,13 @@ class DeviceCool:
         ld = (in_w + 63) // 64 * 64 if band else (n + 15) // 16 * 16
         # resident: the block owns its buffer (288 GB of HBM hold every block of a genome at once, so
         # blocks are staged once and reused by all templates / iterations); else a shared scratch
-        own = dev.empty(n * ld * esz, np.uint8) if resident else None
+        own = self._resident(n * ld * esz) if resident else None
         ptr = own.ptr if resident else self._band.get(n * ld * esz)
         sig = CsMatrix(ptr, np_dtype_code(band_dtype), LAYOUT_BAND if band else LAYOUT_DENSE, ld, 0, in_w if band else 0)
         dev._check(lib.cs_csr_to_band(dev.ctx, stream, C.byref(view), d_law, n_diags, 10.0, C.byref(sig)))
         flags = _Ptr(self.miss.ptr + s)
         block = StagedBlock(name or self.names[ci], sig, (n, n), flags, flags, max_dist, False, keep)
-        block.buffer = own
+        block.buffer, block.pool = own, self._free
         return block
 
     def stage_inter(self, ca, cb, name=None, stream=None, resident=False, dtype=np.float64):
@@ -303,14 +355,14 @@ class DeviceCool:
         dev._check(lib.cs_memcpy_h2d(dev.ctx, d_law, scale.ctypes.data, scale.nbytes, stream))
         esz = np.dtype(dtype).itemsize
         ld = (n_c + 15) // 16 * 16
-        own = dev.empty(n_r * ld * esz, np.uint8) if resident else None
+        own = self._resident(n_r * ld * esz) if resident else None
         ptr = own.ptr if resident else self._band.get(n_r * ld * esz)
         sig = CsMatrix(ptr, np_dtype_code(dtype), LAYOUT_DENSE, ld, 0, 0)
         # "law" = the median on every diagonal, no cap: value / median, NaN -> 0
         dev._check(lib.cs_csr_to_band(dev.ctx, stream, C.byref(view), d_law, scale.size, 0.0, C.byref(sig)))
         block = StagedBlock(name or f"{self.names[ca]}-{self.names[cb]}", sig, (n_r, n_c), _Ptr(self.miss.ptr + s1),
                             _Ptr(self.miss.ptr + s2), None, True, None)
-        block.buffer = own
+        block.buffer, block.pool = own, self._free
         return block
 
     def subsampled(self, sample, seed=0, inter=False):
@@ -367,15 +419,31 @@ class DeviceCool:
         return np.flatnonzero(~self.miss_host[s:e])
 
 
-def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, want_windows=True, raw=False):
+def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, want_windows=True, raw=False, dev=None,
+                 stream=None):
     """pattern_detector(full=True) on a staged block (cli/chromosight.py:601-614)."""
     kernel = np.asarray(kernel, dtype=np.float64)
     if min(block.shape) <= max(kernel.shape):
         return None, None
     kspec = engine.KernelSpec(kernel, tsvd)
-    return cid.detect_on_device(dcool.dev, block.sig, block.shape, kspec, kernel_config, block.miss_row,
+    return cid.detect_on_device(dev or dcool.dev, block.sig, block.shape, kspec, kernel_config, block.miss_row,
                                 block.miss_col, inter=block.inter, max_dist=block.max_dist, full=True, coords=coords,
-                                want_windows=want_windows, raw=raw)
+                                want_windows=want_windows, raw=raw, stream=stream)
+
+
+def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4):
+    """detect_block for every staged block of `blocks`, several at a time (see _Workers); results in
+    the order of `blocks`.  The staging of the blocks (default stream) is complete before they start."""
+    if workers <= 1 or len(blocks) <= 1:
+        return [detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw) for b in blocks]
+    dcool.dev.sync()
+    pool = dcool.workers(workers)
+
+    def one(block):
+        dev, stream = pool.device()
+        return detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd, raw=raw, dev=dev, stream=stream)
+
+    return pool.map(one, blocks)
 
 
 def sub_matrices(dcool, inter):
@@ -405,8 +473,8 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
     for kernel_id, kernel in enumerate(kernel_config["kernels"]):
         for it in range(kernel_config["max_iterations"]):
             tables, windows = [], []
-            for (ca, cb), block in zip(pairs, blocks):
-                tab, win = detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd, raw=True)
+            results = detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=tsvd, raw=True)
+            for (ca, cb), (tab, win) in zip(pairs, results):
                 if tab is None or len(tab) == 0:
                     continue
                 tab[:, 0] += int(off[ca])

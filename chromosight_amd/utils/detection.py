@@ -541,7 +541,7 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
 
 
 def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, *, inter, max_dist, full,
-                     coords=None, want_windows=True, raw=False):
+                     coords=None, want_windows=True, raw=False, stream=None):
     """The part of pattern_detector that follows the staging of the contact map in HBM
     (reference detection.py:240-345): correlation, foci, validation statistics -- one native call
     (cs_detect_foci / cs_quantify_pixels) -- then the acceptance rules on the few returned records.
@@ -568,7 +568,7 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
     if full:
         mask_kw = dict(mask_mode=MASK_BINS, miss_row=miss_row, miss_col=miss_col)
     common = dict(inter=inter, full=full, sym_upper=sym_upper, max_dist=max_dist, missing_tol=missing_tol,
-                  want_windows=want_windows, **mask_kw)
+                  want_windows=want_windows, stream=stream, **mask_kw)
     if coords is None:
         run_mode = "detect"
         rec, windows = engine.run_detect_foci(dev, sig, shape, kspec, pearson=pearson, lo_diag=lo_diag, hi_diag=hi_diag,

@@ -160,6 +160,10 @@ def cpu_baseline(workload, budget_s=12.0):
             break
     return {
         "value": round(passes * sample.size / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+        "reference_python": {"value": 1.94, "unit": "Mpixel/s", "cores": 1,
+                             "source": "BASELINE.md section 3: the reference's own normxcorr2 (scipy), dense 4096^2, "
+                                       "17x17 loops template, survey host (Xeon 2.1 GHz), not re-run here: the "
+                                       "reference cannot travel to the GPU box"},
         "sample": f"{passes} passes over the first {rows} rows of the same map ({sample.size / 1e6:.2f} Mpixel "
                   f"each), float64 C restatement oracle/oracle.c, OpenMP x{threads}, {dt:.1f} s",
     }

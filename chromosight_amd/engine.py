@@ -140,6 +140,10 @@ def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter,
                     want_windows=True, min_size=2, stream=None):
     """detect mode of one sub-matrix x one template on the device (cs_detect_foci): records of the
     foci in the reference's order (numpy structured array, _lib.FOCUS_DTYPE) and their windows."""
+    # a threshold within a few margins of zero would make every stored pixel of a float32 map a
+    # candidate for re-scoring: compute that map in float64 straight away (ADVICE r1)
+    if float(pearson) <= 4 * RESCORE_MARGIN:
+        precision = "f64"
     params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, None, missing_tol,
                           compute_code(precision))
     fp = CsFociParams(float(pearson), RESCORE_MARGIN, int(min_size), int(bool(diag_only)), int(lo_diag), int(hi_diag),

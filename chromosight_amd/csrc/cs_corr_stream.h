@@ -1081,8 +1081,16 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         if constexpr (REG) {
             if (strip_needs_fix && t >= K - 1) {
                 const int oi = i0 + t - (K - 1);
-                fix_fetch(oi, d_out, fxA);
-                fix_fetch(oi + 1, d_out - 1, fxB);
+                // wave-uniform: can a pixel of these two output rows need a correction at all?  (a tall
+                // strip of a wide band crosses an edge diagonal range only in part of its rows)
+                const int dmin = j0 - (oi + 1), dmax = j0 + G::TW - 1 - oi;
+                const bool rows_need = (oi < A.fix_top) | (oi + 1 >= A.fix_bot0) | (A.fix_cols != nullptr) |
+                                       (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
+                                                     (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w)));
+                if (rows_need) {
+                    fix_fetch(oi, d_out, fxA);
+                    fix_fetch(oi + 1, d_out - 1, fxB);
+                }
             }
         }
 

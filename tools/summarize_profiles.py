@@ -78,7 +78,7 @@ avg_ns = {}
 if stats:
     for r in csv.DictReader(open(stats)):
         avg_ns[r["Name"]] = float(r["AverageNs"])
-for kname in ("distance_law_kernel", "csr_to_band_kernel", "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel"):
+for kname in ("distance_law_kernel", "csr_to_band_rows_kernel", "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel"):
     rec = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         rec.update(per_dispatch(find(f"pmc_c3_{c}/**/*counter_collection.csv"), kname))

@@ -216,3 +216,46 @@ def test_two_ranks_equal_single_process(tmp_path):
     # 1e-16 level) and the second template is a pileup summed in another order
     assert np.abs(both[:, 3] - single[:, 3]).max() < 1e-9
     assert np.allclose(both[:, 4], single[:, 4], rtol=1e-6, atol=1e-300)
+
+
+# ------------------------------------------------------------------------------------------------
+# device foci under load: large and tangled foci, ties, low thresholds
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,max_dist,pearson,seed", [(900, 120, 0.02, 1), (1500, 400, 0.05, 2), (700, 699, 0.0, 3),
+                                                     (2500, 60, 0.08, 4), (600, 40, -0.05, 5)])
+def test_device_foci_tangled_components(n, max_dist, pearson, seed):
+    """Thresholds near zero make 10-50 % of the band candidate pixels: foci of thousands of pixels with
+    holes and long arms, where the union-find (concurrent hooks, path halving) has real contention.
+    Tables must equal the foci oracle run on the float64 oracle map: same foci, same order."""
+    from chromosight_amd.utils import detection as cud
+    rng = np.random.default_rng(seed)
+    kern = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    keep = min(max_dist, n) + 17
+    ii, jj = np.indices((n, n))
+    # smooth-ish signal so that the coefficient map has large connected regions above a low threshold
+    base = rng.gamma(4, 0.25, size=(n // 4 + 2, n // 4 + 2))
+    a = np.kron(base, np.ones((4, 4)))[:n, :n] * rng.gamma(20, 0.05, size=(n, n))
+    a = np.triu(a)
+    a[(jj - ii > keep)] = 0
+    miss = rng.random(n) < 0.03
+    a[miss, :] = 0
+    a[:, miss] = 0
+    valid = np.flatnonzero(~miss)
+
+    class Map:
+        pass
+    cmap = Map()
+    cmap.matrix, cmap.detectable_bins, cmap.max_dist, cmap.inter = sp.csr_matrix(a), (valid, valid.copy()), max_dist, False
+    cfg = dict(pearson=pearson, max_perc_undetected=50.0, max_perc_zero=100.0, max_dist=5 * max_dist)
+    tab, wins = cud.pattern_detector(cmap, cfg, kern, full=True)
+    want, _ = c_oracle.normxcorr2(a, kern, max_dist=max_dist, sym_upper=True, full=True, miss_row=miss, miss_col=miss,
+                                  missing_tol=0.5)
+    trimmed = np.where((jj - ii >= 0) & (jj - ii <= max_dist), want, 0.0)
+    n_cand = int(((trimmed >= pearson) & (trimmed != 0)).sum())
+    ref = foci_oracle.detect_table(a, trimmed, miss, miss, kern.shape, pearson=pearson, zero_tol=1.0, missing_tol=0.5)
+    got = np.zeros((0, 3)) if tab is None else tab[["bin1", "bin2", "score"]].to_numpy(dtype=np.float64)
+    print(f"n={n} max_dist={max_dist} pearson={pearson}: {n_cand} candidate pixels, {ref.shape[0]} validated foci")
+    assert n_cand > 0.05 * n * min(max_dist, n)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, :2], ref[:, :2])
+    assert np.abs(got[:, 2] - ref[:, 2]).max() < 1e-9

@@ -26,6 +26,7 @@ class CsMatrix(C.Structure):
         ("ld", C.c_int64),
         ("band_lo", C.c_int32),
         ("band_w", C.c_int32),
+        ("row0", C.c_int64),      # matrix row stored at d_ptr (row windows)
     ]
 
 
@@ -54,6 +55,8 @@ class CsNormxcorr2Params(C.Structure):
         ("compute_dtype", C.c_int32),
         ("xcorr_threshold", C.c_double),
         ("denom_eps", C.c_double),
+        ("row_begin", C.c_int32),  # output row window, (0, 0) = all rows
+        ("row_end", C.c_int32),
     ]
 
 
@@ -151,6 +154,12 @@ _PROTOTYPES = {
     "cs_quantify_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
+                                C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "cs_label_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.POINTER(C.c_int64)]),
     "cs_remove_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "cs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -77,6 +77,7 @@ cs::MatView view_of(const cs_matrix* m)
     v.layout = m ? m->layout : 0;
     v.band_lo = m ? m->band_lo : 0;
     v.band_w = m ? m->band_w : 0;
+    v.row0 = m ? m->row0 : 0;
     return v;
 }
 
@@ -161,7 +162,7 @@ void fill_grid(cs::CorrArgs<TC>& A, int tw, int th, bool aligned_x = true)
 {
     A.tile_w = tw;
     A.tile_h = th;
-    A.tiles_y = (A.ms + th - 1) / th;
+    A.tiles_y = (A.row_end - A.row_begin + th - 1) / th;
     if (A.out.layout == CS_LAYOUT_BAND) {
         A.out_lo = A.out.band_lo;
         A.out_hi = A.out.band_lo + A.out.band_w - 1;
@@ -292,7 +293,7 @@ template <typename TC>
 bool fast_compatible(const cs::CorrArgs<TC>& A)
 {
     if (A.nobs.ptr && (A.nobs.layout != A.out.layout || A.nobs.ld != A.out.ld || A.nobs.band_lo != A.out.band_lo ||
-                       A.nobs.band_w != A.out.band_w))
+                       A.nobs.band_w != A.out.band_w || A.nobs.row0 != A.out.row0))
         return false;
     if (A.xcorr_only && (A.mask_mode != 0 || A.full || A.sym_upper)) return false;
     return true;
@@ -307,7 +308,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
-        cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
+        cs::corr_fast_tile_k##KK(A.row_end - A.row_begin, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
         fill_grid(A, tw, th, false);         \
         rc = prepare_regular_mask<float>(ctx, A, KK, stream); \
         if (rc != CS_OK) return rc;          \
@@ -340,7 +341,7 @@ int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
-        cs::corr_fast_tile_k##KK(A.ms, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
+        cs::corr_fast_tile_k##KK(A.row_end - A.row_begin, A.ns, A.out.layout == 1 ? A.out.band_w : 0, ctx->n_cu, &tw, &th);  \
         fill_grid(A, tw, th, false);         \
         rc = prepare_regular_mask<double>(ctx, A, KK, stream); \
         if (rc != CS_OK) return rc;          \
@@ -497,6 +498,15 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     }
     A.xcorr_only = 0;
     A.w_sym = sym ? 1 : 0;
+    A.row_begin = 0;
+    A.row_end = p->ms;
+    if (p->row_end > p->row_begin) {
+        if (p->row_begin < 0 || p->row_end > p->ms) return fail(ctx, CS_ERR_INVALID, "row window outside the matrix");
+        if ((p->row_begin != 0 || p->row_end != p->ms) && (!p->full || p->mask_mode == CS_MASK_EXPLICIT))
+            return fail(ctx, CS_ERR_UNSUPPORTED, "row windows need full = 1 and per-bin masks or none");
+        A.row_begin = p->row_begin;
+        A.row_end = p->row_end;
+    }
     *out = A;
     return CS_OK;
 }
@@ -665,7 +675,7 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         if (rc) return rc;
         A.out = view_of(out_corr);
         A.out_is_f64 = out_corr->dtype == CS_F64;
-        A.nobs = want_nobs ? view_of(out_nobs) : cs::MatView{nullptr, 0, 0, 0, 0};
+        A.nobs = want_nobs ? view_of(out_nobs) : cs::MatView{nullptr, 0, 0, 0, 0, 0};
         return launch_corr<double>(ctx, A, stream, allow_fast);
     } else if (p->compute_dtype == CS_F32) {
         cs::CorrArgs<float> A;
@@ -673,7 +683,7 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         if (rc) return rc;
         A.out = view_of(out_corr);
         A.out_is_f64 = out_corr->dtype == CS_F64;
-        A.nobs = want_nobs ? view_of(out_nobs) : cs::MatView{nullptr, 0, 0, 0, 0};
+        A.nobs = want_nobs ? view_of(out_nobs) : cs::MatView{nullptr, 0, 0, 0, 0, 0};
         return launch_corr<float>(ctx, A, stream, allow_fast);
     }
     return fail(ctx, CS_ERR_INVALID, "bad compute dtype");
@@ -713,6 +723,7 @@ int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, i
         A.out = view_of(out);                                             \
         A.out_is_f64 = out->dtype == CS_F64;                              \
         A.ms = ms; A.ns = ns; A.km = km; A.kn = kn;                       \
+        A.row_begin = 0; A.row_end = ms;                                  \
         A.max_dist = -1;                                                  \
         A.w = reinterpret_cast<const TC*>(ctx->d_w[sizeof(TC) == 8 ? 1 : 0]); \
         A.ks.n = (TC)kk; A.ks.thr = (TC)threshold;                        \
@@ -938,23 +949,34 @@ static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel
     return CS_OK;
 }
 
-int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
-                   const cs_normxcorr2_params* p, const cs_foci_params* fp, cs_focus* h_foci, int64_t cap,
-                   int64_t* n_foci, double* h_windows)
+namespace {
+// Candidate stage shared by cs_detect_foci and cs_candidates: the coefficient map of the row window in
+// context scratch, thresholded compaction (or, for 1-D patterns, the enumeration of the few scanned
+// diagonals).  The pool is laid out as rows | cols | vals | counters | windows | tail.
+struct CandPlan {
+    size_t off_cols = 0, off_vals = 0, off_cnt = 0, off_win = 0, off_tail = 0;
+    long long n_cand = 0;
+};
+
+int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                    const cs_normxcorr2_params* p, const cs_foci_params* fp, size_t win_bytes,
+                    size_t (*tail_bytes)(long long), CandPlan* P)
 {
-    CS_ENTER(ctx);
-    static_assert(sizeof(cs_focus) == sizeof(cs::FocusRec), "record layouts must agree");
     hipStream_t stream = (hipStream_t)stream_;
-    int rc = check_foci_args(ctx, signal, kernel, p, fp);
-    if (rc) return rc;
-    if (!n_foci || cap < 0 || (cap > 0 && !h_foci)) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
-    *n_foci = 0;
-    const int kk = kernel->km * kernel->kn;
+    int rc;
+    int rb = 0, re = p->ms;
+    if (p->row_end > p->row_begin) {
+        if (p->row_begin < 0 || p->row_end > p->ms) return fail(ctx, CS_ERR_INVALID, "row window outside the matrix");
+        rb = p->row_begin;
+        re = p->row_end;
+    }
     // ---- coefficient map in context-owned scratch, with the signal's layout
     const bool f64 = p->compute_dtype == CS_F64;
     cs_matrix map;
+    map.d_ptr = nullptr;
     map.dtype = f64 ? CS_F64 : CS_F32;
     map.layout = signal->layout;
+    map.row0 = rb;
     if (signal->layout == CS_LAYOUT_BAND) {
         if (fp->hi_diag < fp->lo_diag) return fail(ctx, CS_ERR_INVALID, "empty diagonal range");
         map.band_lo = fp->lo_diag;
@@ -968,68 +990,90 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
     // 128-column strip would compute 64 columns for every one it keeps.  Every pixel of the few diagonals
     // is a candidate instead and goes straight to the float64 evaluation (one wave per pixel).
     const bool narrow = signal->layout == CS_LAYOUT_BAND && map.band_w <= 4 && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW");
-    long long n_cand = 0;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    size_t off_cols = 0, off_vals = 0, off_cnt = 0, off_win = 0, off_foci = 0;
-    const size_t win_pat = fp->want_windows ? (size_t)std::max<int64_t>(cap, 1) : 0;
     auto layout = [&](size_t c_cap) {
-        off_cols = al(4 * c_cap);
-        off_vals = off_cols + al(4 * c_cap);
-        off_cnt = off_vals + al(8 * c_cap);
-        off_win = off_cnt + 256;
-        off_foci = off_win + al(8 * win_pat * kk);
-        return ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_foci + cs::foci_scratch_bytes((long long)c_cap));
+        P->off_cols = al(4 * c_cap);
+        P->off_vals = P->off_cols + al(4 * c_cap);
+        P->off_cnt = P->off_vals + al(8 * c_cap);
+        P->off_win = P->off_cnt + 256;
+        P->off_tail = P->off_win + al(win_bytes);
+        return ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, P->off_tail + tail_bytes((long long)c_cap));
     };
+    P->n_cand = 0;
     if (narrow) {
-        n_cand = cs::narrow_band_pixels(p->ms, p->ns, map.band_lo, map.band_w);
+        const long long n_cand = cs::narrow_band_pixels(rb, re, p->ns, map.band_lo, map.band_w);
         if (n_cand > INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%lld)", n_cand);
         if (n_cand > 0) {
             rc = layout((size_t)n_cand);
             if (rc) return rc;
             char* pool = (char*)ctx->d_pool;
-            rc = cs::enqueue_enumerate_band(p->ms, p->ns, map.band_lo, map.band_w, n_cand, (int*)pool, (int*)(pool + off_cols),
-                                            stream);
+            rc = cs::enqueue_enumerate_band(rb, re, p->ns, map.band_lo, map.band_w, n_cand, (int*)pool,
+                                            (int*)(pool + P->off_cols), stream);
             if (rc) return fail(ctx, CS_ERR_HIP, "enumerate launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
-    } else {
-        const size_t map_bytes = (size_t)p->ms * (size_t)map.ld * (f64 ? 8 : 4);
-        rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
-        if (rc) return rc;
-        map.d_ptr = ctx->d_map;
-        rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
-        if (rc) return rc;
-        // ---- candidates: thresholded compaction (with the re-scoring margin on float32 maps)
-        const double thr = f64 ? fp->pearson : fp->pearson - fp->rescore_margin;
-        size_t c_cap = std::max<size_t>(1 << 16, (size_t)p->ms * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
-        while (true) {
-            if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
-            rc = layout(c_cap);
-            if (rc) return rc;
-            char* pool = (char*)ctx->d_pool;
-            long long* d_cnt = (long long*)(pool + off_cnt);
-            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
-            rc = cs::launch_compact_ge(view_of(&map), f64, p->ms, p->ns, thr, fp->lo_diag, fp->hi_diag, (int*)pool,
-                                       (int*)(pool + off_cols), (double*)(pool + off_vals), (long long)c_cap, d_cnt,
-                                       ctx->n_cu, stream);
-            if (rc) return fail(ctx, CS_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)rc));
-            CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
-            CS_HIP(ctx, hipStreamSynchronize(stream));
-            n_cand = ctx->h_counts[0];
-            if ((size_t)n_cand <= c_cap) break;
-            c_cap = (size_t)n_cand + (size_t)n_cand / 8;
-        }
+        P->n_cand = n_cand;
+        return CS_OK;
     }
+    const size_t map_bytes = (size_t)(re - rb) * (size_t)map.ld * (f64 ? 8 : 4);
+    rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
+    if (rc) return rc;
+    map.d_ptr = ctx->d_map;
+    rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
+    if (rc) return rc;
+    // ---- candidates: thresholded compaction (with the re-scoring margin on float32 maps)
+    const double thr = f64 ? fp->pearson : fp->pearson - fp->rescore_margin;
+    size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
+    while (true) {
+        if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
+        rc = layout(c_cap);
+        if (rc) return rc;
+        char* pool = (char*)ctx->d_pool;
+        long long* d_cnt = (long long*)(pool + P->off_cnt);
+        CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        rc = cs::launch_compact_ge(view_of(&map), f64, re, p->ns, thr, fp->lo_diag, fp->hi_diag, (int*)pool,
+                                   (int*)(pool + P->off_cols), (double*)(pool + P->off_vals), (long long)c_cap, d_cnt,
+                                   ctx->n_cu, stream);
+        if (rc) return fail(ctx, CS_ERR_HIP, "compact launch failed: %s", hipGetErrorString((hipError_t)rc));
+        CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        P->n_cand = ctx->h_counts[0];
+        if ((size_t)P->n_cand <= c_cap) break;
+        c_cap = (size_t)P->n_cand + (size_t)P->n_cand / 8;
+    }
+    return CS_OK;
+}
+}  // namespace
+
+int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                   const cs_normxcorr2_params* p, const cs_foci_params* fp, cs_focus* h_foci, int64_t cap,
+                   int64_t* n_foci, double* h_windows)
+{
+    CS_ENTER(ctx);
+    static_assert(sizeof(cs_focus) == sizeof(cs::FocusRec), "record layouts must agree");
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_foci_args(ctx, signal, kernel, p, fp);
+    if (rc) return rc;
+    if (!n_foci || cap < 0 || (cap > 0 && !h_foci)) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
+    if (p->row_end > p->row_begin && (p->row_begin != 0 || p->row_end != p->ms))
+        return fail(ctx, CS_ERR_INVALID, "foci of a row window: use cs_candidates + cs_label_foci");
+    *n_foci = 0;
+    const int kk = kernel->km * kernel->kn;
+    const size_t win_pat = fp->want_windows ? (size_t)std::max<int64_t>(cap, 1) : 0;
+    CandPlan P;
+    rc = find_candidates(ctx, stream_, signal, kernel, p, fp, 8 * win_pat * kk, cs::foci_scratch_bytes, &P);
+    if (rc) return rc;
+    const long long n_cand = P.n_cand;
     if (n_cand == 0) return CS_OK;
     // ---- foci
     cs::CorrArgs<double> A64;
     rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
     if (rc) return rc;
     char* pool = (char*)ctx->d_pool;
-    long long* d_cnt = (long long*)(pool + off_cnt);
-    double* d_win = fp->want_windows ? (double*)(pool + off_win) : nullptr;
+    long long* d_cnt = (long long*)(pool + P.off_cnt);
+    double* d_win = fp->want_windows ? (double*)(pool + P.off_win) : nullptr;
     cs::FocusRec* d_rec = nullptr;
-    rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + off_cols), n_cand, fp->pearson, fp->min_size,
-                          fp->diag_only, fp->inter, pool + off_foci, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream);
+    rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + P.off_cols), n_cand, fp->pearson, fp->min_size,
+                          fp->diag_only, fp->inter, pool + P.off_tail, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream);
     if (rc) return fail(ctx, CS_ERR_HIP, "foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts + 1, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream));
     CS_HIP(ctx, hipStreamSynchronize(stream));
@@ -1040,6 +1084,89 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
         CS_HIP(ctx, hipMemcpyAsync(h_foci, d_rec, sizeof(cs_focus) * (size_t)n, hipMemcpyDeviceToHost, stream));
         if (d_win && h_windows)
             CS_HIP(ctx, hipMemcpyAsync(h_windows, d_win, 8 * (size_t)n * kk, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return CS_OK;
+}
+
+int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
+                  const cs_normxcorr2_params* p, const cs_foci_params* fp, int32_t* h_rows, int32_t* h_cols,
+                  double* h_vals, int64_t cap, int64_t* n_out)
+{
+    CS_ENTER(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_foci_args(ctx, signal, kernel, p, fp);
+    if (rc) return rc;
+    if (!n_out || cap < 0 || (cap > 0 && (!h_rows || !h_cols || !h_vals))) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
+    *n_out = 0;
+    CandPlan P;
+    rc = find_candidates(ctx, stream_, signal, kernel, p, fp, 0, cs::keep_scratch_bytes, &P);
+    if (rc) return rc;
+    if (P.n_cand == 0) return CS_OK;
+    cs::CorrArgs<double> A64;
+    rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
+    if (rc) return rc;
+    char* pool = (char*)ctx->d_pool;
+    int *d_rows = nullptr, *d_cols = nullptr, *d_n = nullptr;
+    double* d_vals = nullptr;
+    rc = cs::enqueue_keep(A64, (const int*)pool, (const int*)(pool + P.off_cols), P.n_cand, fp->pearson, pool + P.off_tail,
+                          &d_rows, &d_cols, &d_vals, &d_n, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    int* h_n = reinterpret_cast<int*>(ctx->h_counts + 2);
+    CS_HIP(ctx, hipMemcpyAsync(h_n, d_n, 4, hipMemcpyDeviceToHost, stream));
+    CS_HIP(ctx, hipStreamSynchronize(stream));
+    const long long n = *h_n;
+    *n_out = n;
+    if (n > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld candidates, room for %lld", n, (long long)cap);
+    if (n > 0) {
+        CS_HIP(ctx, hipMemcpyAsync(h_rows, d_rows, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipMemcpyAsync(h_cols, d_cols, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipMemcpyAsync(h_vals, d_vals, 8 * (size_t)n, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return CS_OK;
+}
+
+int cs_label_foci(cs_ctx* ctx, void* stream_, int32_t ms, int32_t ns, const int32_t* h_rows, const int32_t* h_cols,
+                  const double* h_vals, int64_t n, int32_t min_size, int32_t diag_only, int32_t* h_foci_rows,
+                  int32_t* h_foci_cols, int32_t* h_foci_size, int64_t cap, int64_t* n_foci)
+{
+    CS_ENTER(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!n_foci || n < 0 || ms <= 0 || ns <= 0 || min_size < 1 || (n > 0 && (!h_rows || !h_cols || !h_vals)))
+        return fail(ctx, CS_ERR_INVALID, "bad candidate list");
+    if (cap < 0 || (cap > 0 && (!h_foci_rows || !h_foci_cols || !h_foci_size))) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
+    if (n > INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%lld)", (long long)n);
+    *n_foci = 0;
+    if (n == 0) return CS_OK;
+    if (!ctx->h_counts) CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault));
+    for (int64_t t = 0; t < n; ++t)
+        if (h_rows[t] < 0 || h_rows[t] >= ms || h_cols[t] < 0 || h_cols[t] >= ns)
+            return fail(ctx, CS_ERR_INVALID, "candidate %lld outside the matrix", (long long)t);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t un = (size_t)n;
+    const size_t off_cols = al(4 * un), off_vals = off_cols + al(4 * un), off_cnt = off_vals + al(8 * un),
+                 off_tail = off_cnt + 256;
+    int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_tail + cs::label_scratch_bytes(n));
+    if (rc) return rc;
+    char* pool = (char*)ctx->d_pool;
+    CS_HIP(ctx, hipMemcpyAsync(pool, h_rows, 4 * un, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_cols, h_cols, 4 * un, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_vals, h_vals, 8 * un, hipMemcpyHostToDevice, stream));
+    long long* d_cnt = (long long*)(pool + off_cnt);
+    int *f_rows = nullptr, *f_cols = nullptr, *f_size = nullptr;
+    rc = cs::enqueue_label((const int*)pool, (const int*)(pool + off_cols), (const double*)(pool + off_vals), n, ns, min_size,
+                           diag_only, pool + off_tail, &f_rows, &f_cols, &f_size, d_cnt, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "labelling kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts + 1, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+    CS_HIP(ctx, hipStreamSynchronize(stream));
+    const long long k = ctx->h_counts[1];
+    *n_foci = k;
+    if (k > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", k, (long long)cap);
+    if (k > 0) {
+        CS_HIP(ctx, hipMemcpyAsync(h_foci_rows, f_rows, 4 * (size_t)k, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipMemcpyAsync(h_foci_cols, f_cols, 4 * (size_t)k, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipMemcpyAsync(h_foci_size, f_size, 4 * (size_t)k, hipMemcpyDeviceToHost, stream));
         CS_HIP(ctx, hipStreamSynchronize(stream));
     }
     return CS_OK;

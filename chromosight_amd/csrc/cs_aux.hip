@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void compact_ge_kernel(MatView corr, int ms, i
                                                          int* __restrict__ cols, double* __restrict__ vals,
                                                          long long cap, unsigned long long* __restrict__ count)
 {
+    // the buffer holds the rows corr.row0 .. ms - 1 of the map
     const int width = (corr.layout == 1) ? corr.band_w : ns;
-    const long long total = (long long)ms * width;
+    const long long total = (long long)(ms - corr.row0) * width;
     const TV* __restrict__ src = reinterpret_cast<const TV*>(corr.ptr);
     const int lane = threadIdx.x & 63;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -320,12 +321,13 @@ __global__ __launch_bounds__(256) void compact_ge_kernel(MatView corr, int ms, i
         int i = 0, j = 0;
         double v = 0.0;
         if (idx < total) {
-            i = (int)(idx / width);
-            const int x = (int)(idx - (long long)i * width);
+            const long long li = idx / width;
+            i = (int)(li + corr.row0);
+            const int x = (int)(idx - li * width);
             j = (corr.layout == 1) ? (i + corr.band_lo + x) : x;
             if (j >= 0 && j < ns) {
                 const int d = j - i;
-                v = (double)src[(long long)i * corr.ld + x];
+                v = (double)src[li * corr.ld + x];
                 hit = (d >= lo_diag) && (d <= hi_diag) && (v >= threshold) && (v != 0.0);
             }
         }
@@ -352,8 +354,8 @@ int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, doub
                       long long* count, int n_cu, hipStream_t stream)
 {
     const int width = (corr.layout == 1) ? corr.band_w : ns;
-    const long long total = (long long)ms * width;
-    if (total == 0) return 0;
+    const long long total = (long long)(ms - corr.row0) * width;
+    if (total <= 0) return 0;
     long long want = (total + 255) / 256;
     int blocks = (int)(want < (long long)n_cu * 8 ? want : (long long)n_cu * 8);
     auto cnt = reinterpret_cast<unsigned long long*>(count);

@@ -56,6 +56,11 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.strips_x = A.tiles_x;
     S.strips_y = A.tiles_y;
     S.split_sy = 0;
+    S.row_begin = A.row_begin;
+    S.row_end = A.row_end;
+    S.row0_in = A.sig.row0;
+    S.row0_out = A.out.row0;
+    S.xcd_remap = (S.band_out && !getenv("CHROMOSIGHT_HIP_NO_XCD")) ? 1 : 0;
     S.strip_h2 = A.tile_h;
     // Single generation of two waves per SIMD (e.g. dense 4096^2 on 256 CUs): the arbiter favours
     // the wave that started first.  Measured with per-wave clocks on C2 (uniform 64-row strips):
@@ -68,11 +73,11 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
         const char* e = getenv("CHROMOSIGHT_HIP_SPLIT");   // "h1,h2" forces a split, "0" disables it
         int h1 = 0, h2 = 0, auto_pairs = 0;
         if (e && sscanf(e, "%d,%d", &h1, &h2) == 2) {
-        } else if (!e && !S.band_out && !split_heights(A.ms, A.tiles_x, A.tile_h, n_simd, &h1, &h2, &auto_pairs)) {
+        } else if (!e && !S.band_out && !split_heights(A.row_end - A.row_begin, A.tiles_x, A.tile_h, n_simd, &h1, &h2, &auto_pairs)) {
             h1 = h2 = 0;
         }
         if (h1 > 0 && h2 > 0 && !S.band_out) {
-            const int pairs = (A.ms + h1 + h2 - 1) / (h1 + h2);
+            const int pairs = (A.row_end - A.row_begin + h1 + h2 - 1) / (h1 + h2);
             S.strip_h = h1;
             S.strip_h2 = h2;
             S.split_sy = pairs;

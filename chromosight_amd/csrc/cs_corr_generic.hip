@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(const CorrArgs<TC> A)
     for (int i = 0; i < GEN_RG; ++i) {
         const int oi = i0 + tr0 + i;
         const int oj = j0 + lane;
-        if (oi >= A.ms || oj >= A.ns) continue;
+        if (oi >= A.row_end || oj >= A.ns) continue;
         const int d = oj - oi;
         if (d < A.out_lo || d > A.out_hi) continue;
         TC r, nobs = A.ks.n;

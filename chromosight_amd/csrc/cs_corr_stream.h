@@ -573,6 +573,9 @@ struct StreamArgs {
     int full, sym_upper;
     int strip_h, strips_x, strips_y;
     int split_sy, strip_h2;        // row blocks >= split_sy have height strip_h2 (two-height tiling), 0 = uniform
+    int xcd_remap;                 // 1: workgroup -> strip mapping that keeps neighbouring strips on one XCD
+    int row_begin, row_end;        // output row window (CorrArgs)
+    long long row0_in, row0_out;   // first matrix row held by the input / output buffers
     // missing mask (MASKED kernels only)
     int mask_mode;                 // 1: per-bin flags, 2: explicit uint8 map with the signal's geometry
     int max_dist;                  // -1: None
@@ -651,7 +654,17 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     TC* ring = reinterpret_cast<TC*>(smem_raw) + (size_t)wv * G::wave_elems(HCACHE);
 
     // strip of this wave (uniform per wave); x fastest so that neighbouring waves share halos
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * G::NWAVES + wv);
+    // XCD-aware order (band outputs): the hardware deals workgroups round-robin to the 8 XCDs, each
+    // with its own L2.  Neighbouring row blocks share K-1 halo rows (36 staged rows for 20 emitted on a
+    // 234-diagonal band) and the two or more strips of a row block share halo columns, so every XCD gets
+    // a contiguous range of strips instead of every 8th one: the halo is then re-read from its L2.
+    int bid = blockIdx.x;
+    if (A.xcd_remap) {
+        const int nb = gridDim.x, q = nb >> 3, rem = nb & 7;
+        const int x = bid & 7, r = bid >> 3;
+        bid = x * q + min(x, rem) + r;
+    }
+    const int wid = __builtin_amdgcn_readfirstlane(bid * G::NWAVES + wv);
     if (wid >= A.strips_x * A.strips_y) return;
     const int sy = wid / A.strips_x;
     const int sx = wid - sy * A.strips_x;
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     // shorter (launch_fast in cs_corr_fast.hip): their waves start second on every SIMD
     const bool late = A.split_sy > 0 && sy >= A.split_sy;
     const int strip_h = late ? A.strip_h2 : A.strip_h;
-    const int i0 = late ? A.split_sy * A.strip_h + (sy - A.split_sy) * A.strip_h2 : sy * A.strip_h;   // first output row
+    const int i0 = A.row_begin + (late ? A.split_sy * A.strip_h + (sy - A.split_sy) * A.strip_h2 : sy * A.strip_h);   // first output row
     int j0 = sx * G::TW;                                  // first output column
     if (A.band_out) {
         // band outputs: the strips of a row block start at the block's first in-band column
@@ -670,8 +683,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         const int dmin = j0 - (i0 + strip_h - 1);
         if (j0 >= A.ns || dmin > A.out_hi) return;
     }
-    if (i0 >= A.ms) return;
-    const int rows_out = min(strip_h, A.ms - i0);
+    if (i0 >= A.row_end) return;
+    const int rows_out = min(strip_h, A.row_end - i0);
     const int n_staged = rows_out + K - 1;
     // MODE 2: can any pixel of this strip need a correction table?  (wave-uniform; most strips of a
     // wide band or of a large rectangular map cannot, and skip the per-pixel lookup logic)
@@ -697,7 +710,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     const int q_lane = j0 - KH + lane * 4;
     const int p_first = i0 - KH;
     const int shift0 = A.band_in ? p_first + A.lo_in : 0;
-    long long in_idx = (long long)p_first * A.ld_in + (q_lane - shift0);   // element index of e = 0
+    long long in_idx = ((long long)p_first - A.row0_in) * A.ld_in + (q_lane - shift0);   // element index of e = 0
     const long long in_step = A.band_in ? A.ld_in - 1 : A.ld_in;          // per-row increment
     int dd = q_lane - shift0;                                              // stored-diagonal index
     const int dd_step = A.band_in ? -1 : 0;
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
     // ---- per-lane output state -------------------------------------------------------------
     const int oj0 = j0 + lane * 2;
     const int lo_o = A.band_out ? A.lo_out : 0;
-    long long out_idx = (long long)i0 * A.ld_out + (oj0 - (A.band_out ? i0 + lo_o : 0));
+    long long out_idx = ((long long)i0 - A.row0_out) * A.ld_out + (oj0 - (A.band_out ? i0 + lo_o : 0));
     const long long out_step = A.band_out ? A.ld_out - 1 : A.ld_out;
     int d_out = oj0 - i0;                                  // diagonal of column 0 at the first output row
     bool ocol_ok[2], ocol_margin[2];
@@ -852,7 +865,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         for (int c = 0; c < 2; ++c) {
             fx[c][0] = fx[c][1] = fx[c][2] = TC(0);
             const int d = d_row + c;
-            const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.ms);
+            const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.row_end);
             if (in_range) {
                 const TC* f = nullptr;
                 const int j = oj0 + c;
@@ -889,8 +902,8 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
         const TC csv[2] = {cs2.x, cs2.y}, kav[2] = {ka2.x, ka2.y}, kbv[2] = {kb2.x, kb2.y};
         if constexpr (sizeof(TC) == 4) {
             if (fast_epi) {
-                const bool in0 = ocol_ok[0] & (d_out >= A.out_lo) & (d_out <= A.out_hi) & (oi < A.ms);
-                const bool in1 = ocol_ok[1] & (d_out + 1 >= A.out_lo) & (d_out + 1 <= A.out_hi) & (oi < A.ms);
+                const bool in0 = ocol_ok[0] & (d_out >= A.out_lo) & (d_out <= A.out_hi) & (oi < A.row_end);
+                const bool in1 = ocol_ok[1] & (d_out + 1 >= A.out_lo) & (d_out + 1 <= A.out_hi) & (oi < A.row_end);
                 const bool z0 = row_margin | ocol_margin[0] | (A.sym_upper && d_out < 0);
                 const bool z1 = row_margin | ocol_margin[1] | (A.sym_upper && d_out + 1 < 0);
                 bool rare0, rare1;
@@ -935,7 +948,7 @@ __global__ __launch_bounds__(64 * CS_NWAVES, 8 / CS_NWAVES) void corr_stream_ker
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int d = d_out + c;
-            const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.ms);
+            const bool in_range = ocol_ok[c] & (d >= A.out_lo) & (d <= A.out_hi) & (oi < A.row_end);
             const bool zero = row_margin | ocol_margin[c] | (A.sym_upper && d < 0);
             TC r;
             if constexpr (REG) {

@@ -16,15 +16,16 @@ struct MatView {
     int layout;   // 0 dense row-major, 1 diagonal band
     int band_lo;  // first stored diagonal offset (band)
     int band_w;   // number of stored diagonals (band)
+    long long row0;  // matrix row stored at ptr: the buffer holds a window of rows (0 = the whole matrix)
 };
 
 // element offset of (p, q), or -1 if the pixel is not stored
 __device__ __forceinline__ long long mat_offset(const MatView& m, int p, int q)
 {
-    if (m.layout == 0) return (long long)p * m.ld + q;
+    if (m.layout == 0) return ((long long)p - m.row0) * m.ld + q;
     int d = q - p - m.band_lo;
     if (d < 0 || d >= m.band_w) return -1;
-    return (long long)p * m.ld + d;
+    return ((long long)p - m.row0) * m.ld + d;
 }
 
 template <typename T>
@@ -74,6 +75,9 @@ struct CorrArgs {
     int tiles_y;
     int tile_w, tile_h;
     int out_lo, out_hi;      // only pixels with out_lo <= j - i <= out_hi are produced
+    int row_begin, row_end;  // only output rows row_begin <= i < row_end are produced (a row window of the
+                             // map: API calls pipelined over PCIe, one block split over several GPUs);
+                             // the signal buffer must hold the rows row_begin - kh .. row_end + kh - 1
     int n_cu;                // compute units of the device (launch shaping)
     int w_sym;               // all three weight sets are symmetric under a vertical flip (row s == row km-1-s)
     // factorised per-bin mask sums of the streaming kernel (cs_mask_prep.hip); reg_mode = 1:
@@ -413,7 +417,7 @@ __device__ __forceinline__ void store_pixel(const CorrArgs<TC>& A, int i, int j,
 template <typename TC>
 __device__ __forceinline__ bool tile_origin(const CorrArgs<TC>& A, int bx, int by, int* i0, int* j0)
 {
-    *i0 = by * A.tile_h;
+    *i0 = A.row_begin + by * A.tile_h;
     int jbase = 0;
     if (A.out.layout == 1) {
         int jmin = *i0 + A.out_lo;
@@ -421,7 +425,7 @@ __device__ __forceinline__ bool tile_origin(const CorrArgs<TC>& A, int bx, int b
         jbase = (jmin / A.tile_w) * A.tile_w;
     }
     *j0 = jbase + bx * A.tile_w;
-    if (*i0 >= A.ms || *j0 >= A.ns) return false;
+    if (*i0 >= A.row_end || *j0 >= A.ns) return false;
     if (A.out.layout == 1) {
         // tile intersects the diagonal range [out_lo, out_hi]?
         const int dmax = (*j0 + A.tile_w - 1) - *i0;

@@ -380,19 +380,141 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     return (int)hipGetLastError();
 }
 
+// ---- one sub-matrix split over several GPUs: candidates per row window, labelled
+//      together.  Part A = candidates of a row window that pass the exact threshold, sorted; part B =
+//      foci of a (merged) candidate list with known float64 values.
+namespace {
+__global__ void store_int_kernel(int* p, int v) { *p = v; }
+}  // namespace
+
+size_t keep_scratch_bytes(long long n_cand)
+{
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)n_cand);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n_cand);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n = (size_t)std::max<long long>(n_cand, 1);
+    return al(std::max(sort_tmp, scan_tmp)) + 3 * al(8 * n) + 2 * al(8 * n) + 4 * al(4 * n) + 1024;
+}
+
+// candidates (any order) -> sorted keys / float64 values of those >= pearson; *n_kept on the device
+int enqueue_keep(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,
+                 void* scratch, int** rows_out, int** cols_out, double** vals_out, int** n_kept_out, hipStream_t stream)
+{
+    const int ns = A64.ns;
+    Bump b{(char*)scratch};
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)n_cand);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n_cand);
+    size_t tmp_bytes = std::max(sort_tmp, scan_tmp);
+    void* tmp = b.take<char>(tmp_bytes);
+    const size_t n = (size_t)n_cand;
+    long long* keys = b.take<long long>(n);
+    long long* keys_s = b.take<long long>(n);
+    long long* keys_k = b.take<long long>(n);
+    double* vals = b.take<double>(n);
+    double* vals_k = b.take<double>(n);
+    int* rows = b.take<int>(n);
+    int* cols = b.take<int>(n);
+    int* flag = b.take<int>(n);
+    int* pos = b.take<int>(n);
+    int* n_kept = b.take<int>(64);
+    *rows_out = rows;
+    *cols_out = cols;
+    *vals_out = vals_k;
+    *n_kept_out = n_kept;
+    const unsigned g = blocks_for(n_cand);
+    hipLaunchKernelGGL(store_int_kernel, dim3(1), dim3(1), 0, stream, n_kept, 0);
+    hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys);
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, 64, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
+    int rc = launch_rescore_f64(A64, rows, cols, n_cand, vals, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flag_keep_kernel, dim3(g), dim3(kThreads), 0, stream, vals, n_cand, pearson, flag);
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flag, pos, (int)n_cand, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(scatter_keep_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, vals, flag, pos, n_cand, keys_k,
+                       vals_k, n_kept);
+    // coordinates of the kept pixels (the entries beyond *n_kept are scratch)
+    hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_k, n_cand, ns, rows, cols);
+    return (int)hipGetLastError();
+}
+
+size_t label_scratch_bytes(long long n)
+{
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr,
+                                             (const double*)nullptr, (double*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t m = (size_t)std::max<long long>(n, 1);
+    return al(std::max(sort_tmp, scan_tmp)) + 2 * al(8 * m) + 3 * al(8 * m) + 10 * al(4 * m) + 1024;
+}
+
+// candidates with their float64 values (device arrays, any order) -> foci in the reference's order:
+// (row, col) of the maximum of every focus of >= min_size pixels and its size; *d_n_foci on the device
+int enqueue_label(const int* d_rows, const int* d_cols, const double* d_vals, long long n, int ns, int min_size,
+                  int diag_only, void* scratch, int** f_rows_out, int** f_cols_out, int** f_size_out,
+                  long long* d_n_foci, hipStream_t stream)
+{
+    Bump b{(char*)scratch};
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr,
+                                             (const double*)nullptr, (double*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n);
+    size_t tmp_bytes = std::max(sort_tmp, scan_tmp);
+    void* tmp = b.take<char>(tmp_bytes);
+    const size_t m = (size_t)n;
+    long long* keys = b.take<long long>(m);
+    long long* keys_s = b.take<long long>(m);
+    double* vals_s = b.take<double>(m);
+    unsigned long long* best_val = b.take<unsigned long long>(m);
+    double* spare = b.take<double>(m);
+    (void)spare;
+    int* flag = b.take<int>(m);
+    int* pos = b.take<int>(m);
+    int* parent = b.take<int>(m);
+    int* size = b.take<int>(m);
+    int* best_idx = b.take<int>(m);
+    int* f_rows = b.take<int>(m);
+    int* f_cols = b.take<int>(m);
+    int* f_size = b.take<int>(m);
+    int* n_dev = b.take<int>(64);
+    *f_rows_out = f_rows;
+    *f_cols_out = f_cols;
+    *f_size_out = f_size;
+    const unsigned g = blocks_for(n);
+    hipLaunchKernelGGL(store_int_kernel, dim3(1), dim3(1), 0, stream, n_dev, (int)n);
+    hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n, ns, keys);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_s, d_vals, vals_s, (int)n, 0, 64, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(init_focus_kernel, dim3(g), dim3(kThreads), 0, stream, n_dev, parent, size, best_val, best_idx, n);
+    hipLaunchKernelGGL(link_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_dev, ns, parent);
+    hipLaunchKernelGGL(flatten_kernel, dim3(g), dim3(kThreads), 0, stream, n_dev, parent);
+    hipLaunchKernelGGL(focus_stats_kernel, dim3(g), dim3(kThreads), 0, stream, n_dev, parent, vals_s, size, best_val);
+    hipLaunchKernelGGL(focus_argbest_kernel, dim3(g), dim3(kThreads), 0, stream, n_dev, parent, vals_s, best_val, best_idx);
+    hipLaunchKernelGGL(flag_roots_kernel, dim3(g), dim3(kThreads), 0, stream, n_dev, parent, size, min_size, flag, n);
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flag, pos, (int)n, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(emit_foci_kernel, dim3(g), dim3(kThreads), 0, stream, n_dev, flag, pos, best_idx, size, keys_s, ns,
+                       diag_only, f_rows, f_cols, f_size, n, d_n_foci);
+    return (int)hipGetLastError();
+}
+
 // ---- 1-D patterns: every pixel of a band of at most 4 diagonals is a candidate ---------------------
 namespace {
-__global__ __launch_bounds__(kThreads) void enumerate_band_kernel(int ms, int ns, int lo, int w, long long n,
+__global__ __launch_bounds__(kThreads) void enumerate_band_kernel(int rb, int re, int ns, int lo, int w, long long n,
                                                                   int* __restrict__ rows, int* __restrict__ cols)
 {
     const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (t >= n) return;
-    // diagonal-major enumeration: diagonal d = lo + x holds the rows max(0, -d) .. min(ms, ns - d) - 1
+    // diagonal-major enumeration: diagonal d = lo + x holds the rows max(rb, -d) .. min(re, ns - d) - 1
     long long rest = t;
     for (int x = 0; x < w; ++x) {
         const int d = lo + x;
-        const int r0 = d < 0 ? -d : 0;
-        const long long cnt = (long long)min(ms, ns - d) - r0;
+        const int r0 = max(rb, -d);
+        const long long cnt = (long long)min(re, ns - d) - r0;
         if (cnt <= 0) continue;
         if (rest < cnt) {
             rows[t] = r0 + (int)rest;
@@ -404,21 +526,21 @@ __global__ __launch_bounds__(kThreads) void enumerate_band_kernel(int ms, int ns
 }
 }  // namespace
 
-long long narrow_band_pixels(int ms, int ns, int lo, int w)
+long long narrow_band_pixels(int rb, int re, int ns, int lo, int w)
 {
     long long n = 0;
     for (int x = 0; x < w; ++x) {
         const int d = lo + x;
-        const long long cnt = (long long)std::min(ms, ns - d) - (d < 0 ? -d : 0);
+        const long long cnt = (long long)std::min(re, ns - d) - std::max(rb, -d);
         if (cnt > 0) n += cnt;
     }
     return n;
 }
 
-int enqueue_enumerate_band(int ms, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream)
+int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(enumerate_band_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, ms, ns, lo, w, n, d_rows, d_cols);
+    hipLaunchKernelGGL(enumerate_band_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, rb, re, ns, lo, w, n, d_rows, d_cols);
     return (int)hipGetLastError();
 }
 

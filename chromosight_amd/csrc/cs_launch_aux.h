@@ -53,9 +53,18 @@ int launch_law_finish(const double* sum, const long long* cnt, int n, double* la
 // median of the stored values of a view (cs_foci.hip)
 int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_median);
 
+// split blocks: candidates of a row window / foci of a merged candidate list (cs_foci.hip)
+size_t keep_scratch_bytes(long long n_cand);
+int enqueue_keep(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,
+                 void* scratch, int** rows_out, int** cols_out, double** vals_out, int** n_kept_out, hipStream_t stream);
+size_t label_scratch_bytes(long long n);
+int enqueue_label(const int* d_rows, const int* d_cols, const double* d_vals, long long n, int ns, int min_size,
+                  int diag_only, void* scratch, int** f_rows_out, int** f_cols_out, int** f_size_out,
+                  long long* d_n_foci, hipStream_t stream);
+
 // 1-D patterns: all pixels of a band of a few diagonals as the candidate list (cs_foci.hip)
-long long narrow_band_pixels(int ms, int ns, int lo, int w);
-int enqueue_enumerate_band(int ms, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream);
+long long narrow_band_pixels(int rb, int re, int ns, int lo, int w);      // rows rb <= i < re
+int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream);
 
 // device-side foci (cs_foci.hip)
 size_t foci_scratch_bytes(long long n_cand);

@@ -114,14 +114,16 @@ def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist
 RESCORE_MARGIN = 2e-3
 
 
-def _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, mask, missing_tol, code):
+def _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, mask, missing_tol, code,
+                 row_window=None):
+    rb, re = (0, 0) if row_window is None else (int(row_window[0]), int(row_window[1]))
     return CsNormxcorr2Params(
         int(shape[0]), int(shape[1]), int(bool(full)), int(bool(sym_upper)),
         -1 if max_dist is None else int(max_dist), int(mask_mode),
         miss_row.ptr if miss_row is not None else None,
         miss_col.ptr if miss_col is not None else None,
         mask.ptr if mask is not None else None,
-        min_present((kspec.km, kspec.kn), missing_tol), code, XCORR_THRESHOLD, DENOM_EPS)
+        min_present((kspec.km, kspec.kn), missing_tol), code, XCORR_THRESHOLD, DENOM_EPS, rb, re)
 
 
 def _host_buffers(dev, cap, kk, want_windows):
@@ -166,6 +168,50 @@ def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter,
     if want_windows:
         windows = win.reshape(-1)[:k * kk].reshape(k, kspec.km, kspec.kn).copy()
     return rec[:k].copy(), windows
+
+
+def run_candidates(dev, sig, shape, kspec, row_window, *, pearson, lo_diag, hi_diag, inter, full, sym_upper, max_dist,
+                   mask_mode=MASK_NONE, miss_row=None, miss_col=None, missing_tol=0.75, precision=None, stream=None,
+                   **_unused):
+    """First half of detect mode on a row window of a sub-matrix (cs_candidates): coordinates and
+    float64 coefficients of the pixels of rows row_window[0] <= i < row_window[1] that pass the
+    threshold, row-major.  `sig` holds those rows and the template's halo (CsMatrix.row0)."""
+    if float(pearson) <= 4 * RESCORE_MARGIN:
+        precision = "f64"
+    params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, None, missing_tol,
+                          compute_code(precision), row_window)
+    fp = CsFociParams(float(pearson), RESCORE_MARGIN, 1, 0, int(lo_diag), int(hi_diag), int(bool(inter)), 0)
+    cap = 1 << 14
+    while True:
+        rows, cols = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        vals = np.empty(cap, np.float64)
+        n = C.c_int64(0)
+        rc = dev.lib.cs_candidates(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params), C.byref(fp),
+                                   rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, cap, C.byref(n))
+        if rc == -4 and n.value > cap:
+            cap = int(n.value) + int(n.value) // 4
+            continue
+        dev._check(rc)
+        break
+    k = int(n.value)
+    return rows[:k], cols[:k], vals[:k]
+
+
+def run_label_foci(dev, shape, rows, cols, vals, *, min_size=2, diag_only=False, stream=None):
+    """Second half of detect mode (cs_label_foci): the 4-connected foci of a candidate list -- the
+    coordinates of each focus at its maximum and its size, in the order of cs_detect_foci."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    k = rows.size
+    cap = max(k // max(int(min_size), 1), 1)
+    f_rows, f_cols, f_size = (np.empty(cap, np.int32) for _ in range(3))
+    n = C.c_int64(0)
+    dev._check(dev.lib.cs_label_foci(dev.ctx, stream, int(shape[0]), int(shape[1]), rows.ctypes.data, cols.ctypes.data,
+                                     vals.ctypes.data, k, int(min_size), int(bool(diag_only)), f_rows.ctypes.data,
+                                     f_cols.ctypes.data, f_size.ctypes.data, cap, C.byref(n)))
+    m = int(n.value)
+    return f_rows[:m], f_cols[:m], f_size[:m]
 
 
 def run_quantify_pixels(dev, sig, shape, kspec, rows, cols, *, inter, full, sym_upper, max_dist, mask_mode=MASK_NONE,

@@ -131,6 +131,62 @@ def _allreduce_sum(array):
     return t.cpu().numpy()
 
 
+def all_gather_rows(array):
+    """Rank-order concatenation of every rank's float64 (n_i, w) array, on every rank (count exchange +
+    one padded all_gather).  Rows keep their order within a rank."""
+    dist, rank, world = _world()
+    array = np.ascontiguousarray(array, dtype=np.float64)
+    if array.ndim != 2:
+        raise ValueError("all_gather_rows needs a 2-D array")
+    if dist is None or world == 1:
+        return array
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    count = torch.tensor([array.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    padded = torch.zeros((max(max(counts), 1), array.shape[1]), dtype=torch.float64, device=dev)
+    if array.shape[0]:
+        padded[:array.shape[0]] = torch.from_numpy(array).to(dev)
+    parts = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
+
+
+def split_rows(n, world):
+    """Row windows of one n-row block over `world` ranks (equal rows: the band has the same number of
+    scanned pixels on every row)."""
+    return [(n * r // world, n * (r + 1) // world) for r in range(world)]
+
+
+def detect_split_block(genome, ci, kernel_config, kernel, tsvd=None, smooth=False, band_dtype=np.float64,
+                       want_windows=True, raw=False, staged=None):
+    """One intra-chromosomal block over ALL ranks (the single-block case, e.g. one
+    200 000-bin chromosome): every rank stages its row window of the block and the template's halo from
+    its copy of the pixel table -- no halo exchange --, the per-diagonal (sum, count) of the distance
+    law are all-reduced so every part is detrended by the same law, the thresholded pixels are
+    all-gathered and labelled identically everywhere, each rank scores the foci of its rows, and the
+    records are gathered.  Same (table, windows) as pipeline.detect_block on one GPU, on every rank.
+    `staged`: the block returned by an earlier call's stage_split (reused across templates)."""
+    from . import pipeline
+    block = staged if staged is not None else stage_split(genome, ci, kernel_config, smooth=smooth, band_dtype=band_dtype)
+    return pipeline.detect_block(genome, block, kernel_config, kernel, tsvd=tsvd, want_windows=want_windows, raw=raw,
+                                 all_gather=all_gather_rows)
+
+
+def stage_split(genome, ci, kernel_config, smooth=False, band_dtype=np.float64, resident=True):
+    """This rank's row window of block `ci`, detrended by the all-reduced distance law."""
+    dist, rank, world = _world()
+    max_dist = max(kernel_config["max_dist"] // genome.binsize, 1)
+    largest = max(np.shape(k)[0] for k in kernel_config["kernels"])
+    rows = split_rows(genome.chrom_size(ci), world)[rank]
+    if world == 1:
+        return genome.stage_intra(ci, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=resident)
+    return genome.stage_intra(ci, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=resident, rows=rows,
+                              reduce=_allreduce_sum)
+
+
 def _gather(records, n_fields):
     """gather_records for an arbitrary record width."""
     dist, rank, world = _world()

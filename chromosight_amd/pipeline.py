@@ -176,6 +176,7 @@ class StagedBlock:
         self.miss_row, self.miss_col = miss_row, miss_col
         self.max_dist, self.inter, self.keep = max_dist, inter, keep
         self.buffer, self.pool = None, None
+        self.row_window = None          # (a, b): the block holds only these rows (+ halo) of the sub-matrix
 
     def __del__(self):
         # a resident block hands its HBM back to the genome's free list (hipFree synchronises and costs
@@ -288,53 +289,77 @@ class DeviceCool:
                      np_dtype_code(self.val_dtype), cs, end, self.weight.ptr + 8 * s, self.weight.ptr + 8 * cs)
 
     def stage_intra(self, ci, max_dist, largest_kernel, smooth=False, band_dtype=np.float64, name=None, stream=None,
-                    resident=False):
+                    resident=False, rows=None, reduce=None):
         """ContactMap.create_mat of one balanced intra block, on the device: distance law over the
         first keep_distance diagonals of the detectable bins, detrend, >= 10 -> 1, NaN -> 0, upper
-        band only (contacts_map.py:527-548, 603-638; preprocessing.py:129-197, 256-310)."""
+        band only (contacts_map.py:527-548, 603-638; preprocessing.py:129-197, 256-310).
+
+        rows = (a, b): stage only the rows a <= i < b of the block plus the template's halo of
+        (largest_kernel - 1) // 2 rows on either side (one block split over several GPUs, SURVEY.md
+        8(e)); the distance law is then the sum of every part's per-diagonal (sum, count): `reduce`
+        maps this part's float64 array (2, n_diags) to the total (an all-reduce).  The block's
+        `row_window` is (a, b) and its matrix carries row0."""
         dev, lib = self.dev, self.dev.lib
         s, e = int(self.offsets[ci]), int(self.offsets[ci + 1])
         n = e - s
         keep = min(max_dist, n) + largest_kernel
-        ext = self._ext.get(16 * n + 16 * (keep + 2) + 512)
-        d_begin, d_end = ext, ext + 8 * n
-        d_sum = d_end + 8 * n
         n_diags = min(n, keep + 1)
+        in_w = min(keep, n - 1) + 1
+        out_w = min(max_dist, n - 1) + 1
+        # layout rule of the host path (_Staged): band when it is less than half of the dense map
+        band = 2 * max(in_w, out_w) < n
+        a, b = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+        if not (0 <= a < b <= n):
+            raise ValueError("row window outside the block")
+        split = (a, b) != (0, n)
+        if split and not band:
+            raise ValueError("only blocks staged as a band can be split by rows")
+        halo = (largest_kernel - 1) // 2 if split else 0
+        ra, rb = max(0, a - halo), min(n, b + halo)
+        m = rb - ra
+        ext = self._ext.get(16 * m + 16 * (keep + 2) + 512)
+        d_begin, d_end = ext, ext + 8 * m
+        d_sum = d_end + 8 * m
         d_cnt, d_law = d_sum + 8 * (keep + 2), None
-        raw = self._view(s, e, s, e)
+        # a view of the rows ra .. rb-1 whose column origin moves with it: diagonals are unchanged
+        raw = self._view(s + ra, s + rb, s + ra, e)
         dev._check(lib.cs_csr_band_extent(dev.ctx, stream, C.byref(raw), 0, keep, d_begin, d_end))
-        view = self._view(s, e, s, e, d_begin, d_end)
-        dev._check(lib.cs_distance_law_csr(dev.ctx, stream, C.byref(view), self.det.ptr + s, n_diags, d_sum, d_cnt))
-        if smooth and n > 2:
+        view = self._view(s + ra, s + rb, s + ra, e, d_begin, d_end)
+        own = self._view(s + a, s + b, s + a, e, d_begin + 8 * (a - ra), d_end + 8 * (a - ra)) if split else view
+        dev._check(lib.cs_distance_law_csr(dev.ctx, stream, C.byref(own), self.det.ptr + s + a, n_diags, d_sum, d_cnt))
+        if (smooth and n > 2) or reduce is not None:
             sums = np.empty(n_diags)
             cnts = np.empty(n_diags, dtype=np.int64)
             dev._check(lib.cs_memcpy_d2h(dev.ctx, sums.ctypes.data, d_sum, 8 * n_diags, stream))
             dev._check(lib.cs_memcpy_d2h(dev.ctx, cnts.ctypes.data, d_cnt, 8 * n_diags, stream))
-            law = np.zeros(n)
+            if reduce is not None:
+                total = np.asarray(reduce(np.stack([sums, cnts.astype(np.float64)])), dtype=np.float64)
+                sums, cnts = np.ascontiguousarray(total[0]), np.rint(total[1]).astype(np.int64)
             with np.errstate(invalid="ignore", divide="ignore"):
-                law[:n_diags] = np.where(cnts > 0, sums / np.maximum(cnts, 1), 0.0)
-            law = np.ascontiguousarray(preproc._isotonic_non_increasing(law)[:n_diags])
+                law = np.where(cnts > 0, sums / np.maximum(cnts, 1), 0.0)      # cs_distance_law_finish
+            if smooth and n > 2:
+                full_law = np.zeros(n)
+                full_law[:n_diags] = law
+                law = preproc._isotonic_non_increasing(full_law)[:n_diags]
+            law = np.ascontiguousarray(law, dtype=np.float64)
             law[np.isnan(law)] = 0.0
             dev._check(lib.cs_memcpy_h2d(dev.ctx, d_sum, law.ctypes.data, 8 * n_diags, stream))
             d_law = d_sum
         else:
             d_law = d_sum                                     # finished in place
             dev._check(lib.cs_distance_law_finish(dev.ctx, stream, d_sum, d_cnt, n_diags, d_law))
-        # layout rule of the host path (_Staged): band when it is less than half of the dense map
-        in_w = min(keep, n - 1) + 1
-        out_w = min(max_dist, n - 1) + 1
         esz = np.dtype(band_dtype).itemsize
-        band = 2 * max(in_w, out_w) < n
         ld = (in_w + 63) // 64 * 64 if band else (n + 15) // 16 * 16
         # resident: the block owns its buffer (288 GB of HBM hold every block of a genome at once, so
         # blocks are staged once and reused by all templates / iterations); else a shared scratch
-        own = self._resident(n * ld * esz) if resident else None
-        ptr = own.ptr if resident else self._band.get(n * ld * esz)
-        sig = CsMatrix(ptr, np_dtype_code(band_dtype), LAYOUT_BAND if band else LAYOUT_DENSE, ld, 0, in_w if band else 0)
+        buf = self._resident(m * ld * esz) if resident else None
+        ptr = buf.ptr if resident else self._band.get(m * ld * esz)
+        sig = CsMatrix(ptr, np_dtype_code(band_dtype), LAYOUT_BAND if band else LAYOUT_DENSE, ld, 0, in_w if band else 0, ra)
         dev._check(lib.cs_csr_to_band(dev.ctx, stream, C.byref(view), d_law, n_diags, 10.0, C.byref(sig)))
         flags = _Ptr(self.miss.ptr + s)
         block = StagedBlock(name or self.names[ci], sig, (n, n), flags, flags, max_dist, False, keep)
-        block.buffer, block.pool = own, self._free
+        block.buffer, block.pool = buf, self._free
+        block.row_window = (a, b) if split else None
         return block
 
     def stage_inter(self, ca, cb, name=None, stream=None, resident=False, dtype=np.float64):
@@ -420,12 +445,20 @@ class DeviceCool:
 
 
 def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, want_windows=True, raw=False, dev=None,
-                 stream=None):
-    """pattern_detector(full=True) on a staged block (cli/chromosight.py:601-614)."""
+                 stream=None, all_gather=None):
+    """pattern_detector(full=True) on a staged block (cli/chromosight.py:601-614).  A block staged as a
+    row window (stage_intra(rows=...)) is this rank's part of a sub-matrix split over several GPUs:
+    `all_gather` exchanges the candidate pixels and the records (detect_split_on_device)."""
     kernel = np.asarray(kernel, dtype=np.float64)
     if min(block.shape) <= max(kernel.shape):
         return None, None
     kspec = engine.KernelSpec(kernel, tsvd)
+    if getattr(block, "row_window", None) is not None:
+        if coords is not None or all_gather is None:
+            raise ValueError("a row window of a block needs detect mode and an all_gather")
+        return cid.detect_split_on_device(dev or dcool.dev, block.sig, block.shape, block.row_window, kspec,
+                                          kernel_config, block.miss_row, block.miss_col, max_dist=block.max_dist,
+                                          all_gather=all_gather, want_windows=want_windows, raw=raw, stream=stream)
     return cid.detect_on_device(dev or dcool.dev, block.sig, block.shape, kspec, kernel_config, block.miss_row,
                                 block.miss_col, inter=block.inter, max_dist=block.max_dist, full=True, coords=coords,
                                 want_windows=want_windows, raw=raw, stream=stream)

@@ -22,7 +22,7 @@ from . import preprocessing as preproc
 from . import stats as cus
 from .. import engine
 from .._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
-                    CsMatrix, get_device, np_dtype_code)
+                    FOCUS_DTYPE, CsMatrix, get_device, np_dtype_code)
 
 RESCORE_MARGIN = engine.RESCORE_MARGIN
 
@@ -596,6 +596,17 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
                 pass
     if run_mode == "detect":
         rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+    return _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, inter=inter, max_dist=max_dist,
+                           full=full, raw=raw)
+
+
+def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw):
+    """The acceptance rules of pattern_detector / validate_patterns on the records the device returned
+    (reference detection.py:121-141, 269-270, 332-336): (table, windows)."""
+    ms, ns = shape
+    km, kn = kspec.km, kspec.kn
+    missing_tol = kernel_config["max_perc_undetected"] / 100
+    zero_tol = kernel_config["max_perc_zero"] / 100
     r64, nobs = rec["score"], rec["n_obs"]
     # coefficient on the trimmed map (:269-270), p-value on the untrimmed one (:332-336)
     in_band = (rr >= 0) & (rr < ms) & (cc >= 0) & (cc < ns)
@@ -630,6 +641,59 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
     kept = table.index.to_numpy()
     table["pvalue"] = 10 ** logp[kept] if len(kept) else None
     return table, windows
+
+
+def detect_split_on_device(dev, sig, shape, row_window, kspec, kernel_config, miss_row, miss_col, *, max_dist, all_gather,
+                           full=True, want_windows=True, raw=False, stream=None):
+    """detect mode of ONE intra sub-matrix split over several GPUs by row windows.
+    This rank holds the rows row_window = (a, b) of the staged map plus the template's halo (`sig`,
+    CsMatrix.row0) and does the correlation, thresholding and float64 re-scoring of its rows
+    (cs_candidates); the candidate pixels of all ranks are exchanged (`all_gather(array2d)` returns the
+    rank-order concatenation on every rank -- a few thousand (row, col, value) triples) and every rank
+    labels the same merged list (cs_label_foci), so foci that straddle a cut come out exactly as on one
+    GPU; each rank then scores the foci whose final row it owns (cs_quantify_pixels) and the records are
+    gathered.  Returns what detect_on_device returns for the whole sub-matrix, on every rank."""
+    ms, ns = shape
+    a, b = int(row_window[0]), int(row_window[1])
+    km, kn = kspec.km, kspec.kn
+    kk = km * kn
+    missing_tol = kernel_config["max_perc_undetected"] / 100
+    diag_only = kernel_config["max_dist"] == 0
+    lo_diag, hi_diag = 0, (max_dist if max_dist is not None else ns - 1)
+    mask_kw = dict(mask_mode=MASK_BINS, miss_row=miss_row, miss_col=miss_col) if full else dict(mask_mode=MASK_NONE)
+    common = dict(inter=False, full=full, sym_upper=True, max_dist=max_dist, missing_tol=missing_tol, stream=stream,
+                  **mask_kw)
+    rows, cols, vals = engine.run_candidates(dev, sig, shape, kspec, (a, b), pearson=kernel_config["pearson"],
+                                             lo_diag=lo_diag, hi_diag=hi_diag, **common)
+    cand = all_gather(np.column_stack([rows.astype(np.float64), cols.astype(np.float64), vals]).reshape(-1, 3))
+    if cand.shape[0] == 0:
+        return None, None
+    f_rows, f_cols, f_size = engine.run_label_foci(dev, shape, cand[:, 0].astype(np.int32), cand[:, 1].astype(np.int32),
+                                                   cand[:, 2], min_size=2, diag_only=diag_only, stream=stream)
+    order = np.arange(f_rows.size)
+    mine = (f_rows >= a) & (f_rows < b)
+    width = len(FOCUS_DTYPE.names) + 1 + (kk if want_windows else 0)
+    local = np.zeros((int(mine.sum()), width))
+    if mine.any():
+        rec, win = engine.run_quantify_pixels(dev, sig, shape, kspec, f_rows[mine], f_cols[mine],
+                                              want_windows=want_windows, **common)
+        rec["focus_size"] = f_size[mine]
+        local[:, 0] = order[mine]
+        for k, name in enumerate(FOCUS_DTYPE.names):
+            local[:, 1 + k] = rec[name]
+        if want_windows:
+            local[:, 1 + len(FOCUS_DTYPE.names):] = win.reshape(-1, kk)
+    merged = all_gather(local)
+    if merged.shape[0] == 0:
+        return None, None
+    merged = merged[np.argsort(merged[:, 0], kind="stable")]
+    rec = np.zeros(merged.shape[0], dtype=FOCUS_DTYPE)
+    for k, name in enumerate(FOCUS_DTYPE.names):
+        rec[name] = merged[:, 1 + k]
+    windows = merged[:, 1 + len(FOCUS_DTYPE.names):].reshape(-1, km, kn).copy() if want_windows else None
+    rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+    return _accept_records(rec, windows, rr, cc, "detect", shape, kspec, kernel_config, inter=False, max_dist=max_dist,
+                           full=full, raw=raw)
 
 
 def _pattern_detector_dump(contact_map, kernel_config, kernel_matrix, coords, dump, full, tsvd):

@@ -87,6 +87,8 @@ typedef struct {
     int64_t ld;        /* leading dimension in elements                              */
     int32_t band_lo;   /* band layout: first stored diagonal offset (j - i)          */
     int32_t band_w;    /* band layout: number of stored diagonals                    */
+    int64_t row0;      /* matrix row stored at d_ptr: the buffer may hold a window of
+                          rows of the matrix (0 = from the first row)                */
 } cs_matrix;
 
 /* ---- pattern kernel (template) operand --------------------------------------------- */
@@ -120,6 +122,12 @@ typedef struct {
     int32_t compute_dtype;   /* CS_F32 or CS_F64 arithmetic                             */
     double xcorr_threshold;  /* 1e-4: xcorr2's zeroing threshold (detection.py:595,716)  */
     double denom_eps;        /* 1e-10 (detection.py:1088)                                */
+    int32_t row_begin, row_end; /* produce the output rows row_begin <= i < row_end only (0, 0 = all).
+                                The geometry (frame, masks, matrix edges) stays that of the ms x ns
+                                matrix; `signal` must hold the rows row_begin - (km-1)/2 ..
+                                row_end + (km-1)/2 - 1 that exist (cs_matrix.row0 says where its buffer
+                                starts).  Row windows let one map be pipelined over PCIe in slabs and
+                                one sub-matrix be split over several GPUs.         */
 } cs_normxcorr2_params;
 
 /* Coefficient map.  `signal`, `out_corr` (and `out_nobs` when d_ptr != NULL) share the
@@ -256,6 +264,25 @@ int cs_quantify_pixels(cs_ctx* ctx, void* stream, const cs_matrix* signal, const
                        const cs_normxcorr2_params* params, const cs_foci_params* foci,
                        const int32_t* h_rows, const int32_t* h_cols, int64_t n, cs_focus* h_out,
                        double* h_windows);
+
+/* One sub-matrix split over several GPUs by row windows: pick_foci (detection.py:387-592)
+ * needs the thresholded pixels of the whole map, so the two halves of cs_detect_foci are exposed.
+ *
+ * cs_candidates: the pixels of the rows params->row_begin <= i < row_end of the coefficient map that
+ * pass the exact (float64) threshold foci->pearson inside [lo_diag, hi_diag], in row-major order: int32
+ * coordinates and float64 coefficients into host arrays of `cap` entries; CS_ERR_OVERFLOW with *n set if
+ * cap is too small.  `signal` holds the window's rows plus the (km-1)/2 halo rows on either side.
+ *
+ * cs_label_foci: the 4-connected foci of a candidate list (the concatenation of every window's
+ * candidates, any order): coordinates of each focus of >= min_size pixels at its maximum (row = col when
+ * diag_only) and its size, in row-major order of the maxima's first pixels, exactly the foci cs_detect_foci
+ * finds on the whole map.  Their records follow from cs_quantify_pixels on the window that owns the row. */
+int cs_candidates(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
+                  const cs_normxcorr2_params* params, const cs_foci_params* foci, int32_t* h_rows,
+                  int32_t* h_cols, double* h_vals, int64_t cap, int64_t* n);
+int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32_t* h_rows,
+                  const int32_t* h_cols, const double* h_vals, int64_t n, int32_t min_size, int32_t diag_only,
+                  int32_t* h_foci_rows, int32_t* h_foci_cols, int32_t* h_foci_size, int64_t cap, int64_t* n_foci);
 
 /* Greedy neighbour suppression of detection.py:348 remove_neighbours, on the host, in O(n) with a
  * grid of win x win cells instead of the reference's O(n^2) scan: patterns are visited in `h_order`

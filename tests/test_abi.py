@@ -39,9 +39,9 @@ def test_no_cpu_fallback_without_gpu():
 
 def test_struct_layouts_match_header():
     # sizes implied by the field lists of include/chromosight_hip.h on LP64
-    assert ctypes.sizeof(_lib.CsMatrix) == 32
+    assert ctypes.sizeof(_lib.CsMatrix) == 40
     assert ctypes.sizeof(_lib.CsKernel) == 32
-    assert ctypes.sizeof(_lib.CsNormxcorr2Params) == 72
+    assert ctypes.sizeof(_lib.CsNormxcorr2Params) == 80
     assert ctypes.sizeof(_lib.CsCsr) == 72
     assert ctypes.sizeof(_lib.CsFociParams) == 40
     assert ctypes.sizeof(_lib.CsFocus) == 40 == _lib.FOCUS_DTYPE.itemsize

@@ -37,6 +37,11 @@ struct cs_ctx {
     // grow-only scratch for the mask tables of the streaming kernel (one call in flight per context)
     void* d_ws = nullptr;
     size_t d_ws_bytes = 0;
+    // matrix-core kernel: the float32 weight sets as float16 head / tail Toeplitz fragments
+    void* d_wfrag = nullptr;
+    std::vector<unsigned char> wfrag_key;     // the float32 weights the image was built from
+    int wfrag_km = 0, wfrag_kn = 0;
+    float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
 };
 
 namespace {
@@ -134,6 +139,112 @@ int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w
     CS_HIP(ctx, hipStreamSynchronize(stream));
     ctx->w_cached[slot].assign((unsigned char*)w.data(), (unsigned char*)w.data() + bytes);
     return CS_OK;
+}
+
+// ---- float16 head / tail fragments of the weight sets for the matrix-core kernel -----------------
+uint16_t f32_to_f16_bits(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t be = (x >> 23) & 0xffu;
+    uint32_t m = x & 0x7fffffu;
+    if (be == 0xffu) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
+    const int e = (int)be - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t half = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1u))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) ++half;     // may carry into the exponent: still right
+    return (uint16_t)(sign | half);
+}
+
+float f16_bits_to_f32(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const uint32_t m = h & 0x3ffu;
+    float out;
+    if (e == 0) {
+        out = std::ldexp((float)m, -24);
+    } else if (e == 31) {
+        uint32_t x = 0x7f800000u | (m << 13);
+        std::memcpy(&out, &x, 4);
+    } else {
+        out = std::ldexp((float)(m | 0x400u), e - 25);
+    }
+    uint32_t x;
+    std::memcpy(&x, &out, 4);
+    x |= sign;
+    std::memcpy(&out, &x, 4);
+    return out;
+}
+
+// Build (or reuse) the fragment image of the float32 weights currently in ctx->d_w[0] (layout in
+// cs_launch.h MfmaWeights).  Each set is scaled by the power of two that puts its largest magnitude in
+// [64, 128), so that heads and tails stay in float16's normal range.
+int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeights* E)
+{
+    const std::vector<unsigned char>& key = ctx->w_cached[0];
+    const int kk = km * kn;
+    const size_t n_floats = key.size() / 4;
+    if (kk <= 0 || n_floats < (size_t)kk) return fail(ctx, CS_ERR_INVALID, "weights missing for the matrix-core kernel");
+    const int nsets = (int)std::min<size_t>(3, n_floats / kk);
+    constexpr size_t kImage = 3 * 17 * 2 * 1024;
+    if (!ctx->d_wfrag) CS_HIP(ctx, hipMalloc(&ctx->d_wfrag, kImage));
+    if (!(ctx->wfrag_km == km && ctx->wfrag_kn == kn && ctx->wfrag_key == key)) {
+        const float* w = reinterpret_cast<const float*>(key.data());
+        std::vector<uint16_t> img(kImage / 2, 0);
+        for (int set = 0; set < nsets; ++set) {
+            float amax = 0.0f;
+            for (int t = 0; t < kk; ++t) amax = std::max(amax, std::fabs(w[set * kk + t]));
+            int ew = 0;
+            if (amax > 0.0f && std::isfinite(amax)) {
+                int e2;
+                (void)std::frexp(amax, &e2);          // amax = f * 2^e2, f in [0.5, 1)
+                ew = 7 - e2;                           // amax * 2^ew in [64, 128)
+            }
+            ew = std::max(-100, std::min(100, ew));
+            ctx->wfrag_unscale[set] = std::ldexp(1.0f, -ew);
+            for (int s = 0; s < km; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int t = 8 * (lane >> 4) + e - (lane & 15);
+                        if (t < 0 || t >= kn) continue;
+                        const float v = std::ldexp(w[set * kk + s * kn + t], ew);
+                        const uint16_t hb = f32_to_f16_bits(v);
+                        const uint16_t lb = f32_to_f16_bits(v - f16_bits_to_f32(hb));
+                        const size_t base = ((size_t)set * km + s) * 2 * 64 * 8;
+                        img[base + (size_t)lane * 8 + e] = hb;
+                        img[base + 64 * 8 + (size_t)lane * 8 + e] = lb;
+                    }
+        }
+        CS_HIP(ctx, hipMemcpyAsync(ctx->d_wfrag, img.data(), kImage, hipMemcpyHostToDevice, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));    // pageable source dies here
+        ctx->wfrag_key = key;
+        ctx->wfrag_km = km;
+        ctx->wfrag_kn = kn;
+    }
+    E->frag = reinterpret_cast<const uint4*>(ctx->d_wfrag);
+    for (int set = 0; set < 3; ++set) E->unscale[set] = ctx->wfrag_unscale[set];
+    return CS_OK;
+}
+
+bool mfma_available(int km, int kn)
+{
+    // opt-in while the kernel is slower than the streaming one (set per process, read per call so that
+    // tests can switch it)
+    const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA");
+    const bool on = e && e[0] == '1';
+    return on && km >= 1 && kn >= 1 && km <= 17 && kn <= 17;
 }
 
 bool fast_available(int km, int kn, int* K)
@@ -304,7 +415,12 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
-    if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
+    if (allow_fast && mfma_available(A.km, A.kn)) {
+        cs::MfmaWeights E;
+        rc = ensure_wfrag(ctx, stream, A.km, A.kn, &E);
+        if (rc != CS_OK) return rc;
+        rc = cs::launch_corr_mfma_f32(A, E, stream);
+    } else if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
@@ -542,6 +658,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     for (int slot = 0; slot < 2; ++slot)
         if (ctx->d_w[slot]) (void)hipFree(ctx->d_w[slot]);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);

@@ -148,6 +148,52 @@ __device__ __forceinline__ bool missing_pred(const CorrArgs<TC>& A, int p, int q
     return m;
 }
 
+// missing_pred with the mask values already loaded (rflag / cflag: per-bin flags of row p / column q,
+// mval: the explicit map's byte; each is ignored where (p, q) lies outside the matrix or the stored
+// band, so callers may load them from a clamped address without branching).
+template <typename TC>
+__device__ __forceinline__ bool missing_from_flags(const CorrArgs<TC>& A, int p, int q, bool rflag, bool cflag, bool mval,
+                                                   bool stored)
+{
+    if (A.mask_mode == 0) return false;
+    const bool in_r = (p >= 0) & (p < A.ms);
+    const bool in_c = (q >= 0) & (q < A.ns);
+    const int d = q - p;
+    const bool have_md = A.max_dist >= 0;
+    bool m;
+    if (in_r & in_c) {
+        if (A.mask_mode == 1) {
+            m = rflag | cflag;
+            if (A.sym_upper) {
+                const int md = have_md ? A.max_dist : min(A.ms, A.ns);
+                m = m & (d >= 0) & (d <= md);
+            }
+        } else {
+            m = stored & mval;
+            if (A.full && A.sym_upper && have_md) {
+                const int lim = A.max_dist + max(A.km, A.kn);
+                m = m & (d >= 0) & (d <= lim);
+            }
+        }
+        if (!A.full) return m;
+    } else {
+        if (!A.full) return false;
+        if (A.sym_upper && have_md) {
+            if (q >= A.ns) m = p >= A.ms - A.max_dist - 2;
+            else if (p < 0) m = (q < 0) ? true : (q < A.max_dist + A.kn);
+            else m = false;
+        } else {
+            m = true;
+        }
+    }
+    if (A.sym_upper) {
+        const int off = d + (A.kn - A.km);
+        const int big_k = max(A.km, A.kn);
+        m = m | ((off <= -1) & (off >= -big_k));
+    }
+    return m;
+}
+
 // load one signal pixel as TC (0 outside the matrix / outside the stored band)
 template <typename TC>
 __device__ __forceinline__ TC load_signal(const CorrArgs<TC>& A, int p, int q)

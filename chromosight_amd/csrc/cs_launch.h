@@ -22,4 +22,13 @@ int launch_corr_generic_f32(const CorrArgs<float>& A, hipStream_t s);
 int launch_corr_generic_f64(const CorrArgs<double>& A, hipStream_t s);
 void corr_generic_tile(int km, int kn, int* tw, int* th);
 
+// matrix-core kernel for templates up to 17 x 17, float32 class (cs_corr_mfma.hip).  The weight sets
+// arrive as ready-made B fragments: frag[set][s][head | tail][lane] = 8 float16 values
+// W_set[s][8 (lane >> 4) + e - (lane & 15)] * 2^ew (0 outside 0 .. kn-1); unscale[set] = 2^-ew.
+struct MfmaWeights {
+    const uint4* frag;
+    float unscale[3];
+};
+int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s);
+
 }  // namespace cs

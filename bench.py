@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PIXEL_17 = 714.0     # 2*k^2 + separable box sums + epilogue at 17x17
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector = FP32 matrix (dense) peak
 FP64_PEAK_TFLOPS = 78.6
+F16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense float16 / bfloat16 MFMA peak
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -419,6 +420,23 @@ def main():
         peak_tf = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
         achieved_gbs = wl.bytes_per_pixel * wl.pixels / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic(args, wl)
+        # which float32 kernel served the launch (cs_api.cpp mfma_wanted): unmasked dense maps run on the
+        # matrix cores with float16 head/tail operands, everything else on the packed-FMA streaming kernel
+        on_mfma = (args.precision == "f32" and not os.environ.get("CHROMOSIGHT_HIP_NO_MFMA")
+                   and (args.workload == "c2" or os.environ.get("CHROMOSIGHT_HIP_MFMA") == "1"))
+        if on_mfma:
+            kernel_note = ("kernel: corr_mfma_dense_kernel (v_mfma_f32_16x16x32_f16): signal and template split into "
+                           "float16 head + tail (3 products per term, float32 accumulation = float32-equivalent "
+                           "coefficients, parity 1e-5), template rows as 32x16 Toeplitz operands (17 of 32 k useful), "
+                           "box sums by two separable MFMA passes: 252 MFMAs per 16x64 output pixels = 4032 executed "
+                           "flop/pixel for 714 algorithmic.  `peak` stays the FP32 peak (157.3 TFLOP/s, vector FMA = "
+                           "f32 MFMA): the roof of a float32-exact evaluation; `mfma_f16` prices the executed matrix "
+                           "flops against the dense float16 MFMA peak")
+        else:
+            kernel_note = ("kernel: corr_stream_kernel (packed FP32 FMA).  Algorithmic flops: the loops template is "
+                           "vertically symmetric and its kernel shares each row product between two template rows (169 "
+                           "instead of 289 packed products per column pair; CHROMOSIGHT_HIP_NO_SYMMETRY=1 runs the "
+                           "unfolded kernel)")
         out = {
             "metric": "Mpixels/s normxcorr2 (17x17 loops kernel)",
             "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
@@ -432,9 +450,7 @@ def main():
                 "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "note": f"714 flop/pixel (SURVEY 8d) x {wl.pixels} pixels per launch / {kernel_ms:.4f} ms "
                         "(HIP events); the FP32 FMA roof binds before HBM at 17x17; peak = dense FP32 "
-                        "matrix/vector peak.  Algorithmic flops: the loops template is vertically symmetric and "
-                        "its kernel shares each row product between two template rows (169 instead of 289 packed "
-                        "products per column pair; CHROMOSIGHT_HIP_NO_SYMMETRY=1 runs the unfolded kernel)",
+                        "matrix/vector peak.  " + kernel_note,
             },
             "roofline_hbm": {
                 "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -443,6 +459,11 @@ def main():
             },
             "kernel_ms": round(kernel_ms, 4),
         }
+        if on_mfma:
+            executed_tf = achieved_tf * 4032.0 / FLOP_PER_PIXEL_17
+            out["roofline"]["mfma_f16"] = {"executed": round(executed_tf, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(executed_tf / F16_MFMA_PEAK_TFLOPS, 4),
+                                           "executed_flop_per_pixel": 4032}
         if genome is not None:
             out["sharded_genome"] = genome
         if not args.no_cpu_baseline and world == 1:     # reported extras: rank 0 at N = 1 only

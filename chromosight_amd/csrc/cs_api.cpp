@@ -42,6 +42,7 @@ struct cs_ctx {
     std::vector<unsigned char> wfrag_key;     // the float32 weights the image was built from
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
+    int last_kernel = 0;     // cs_last_kernel()
 };
 
 namespace {
@@ -238,13 +239,24 @@ int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeight
     return CS_OK;
 }
 
-bool mfma_available(int km, int kn)
+bool fast_available(int km, int kn, int* K);
+
+// Which float32 calls go to the matrix cores (cs_corr_mfma.hip).  Default: unmasked dense float32 maps
+// (cs_normxcorr2 without a mask: the API / benchmark configuration) whenever the template is large
+// (>= 13 x 13 entries: every template row costs a full 17-row pass there) or has no streaming kernel
+// (rectangular, even sizes).  CHROMOSIGHT_HIP_MFMA=1: every call with a template of up to 17 x 17
+// (masked / banded maps run the general, slower, matrix-core kernel -- a test switch);
+// CHROMOSIGHT_HIP_NO_MFMA=1: never.  Read per call so that tests can flip them.
+bool mfma_wanted(const cs::CorrArgs<float>& A)
 {
-    // opt-in while the kernel is slower than the streaming one (set per process, read per call so that
-    // tests can switch it)
+    if (A.km < 1 || A.kn < 1 || A.km > 17 || A.kn > 17) return false;
+    if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA");
-    const bool on = e && e[0] == '1';
-    return on && km >= 1 && kn >= 1 && km <= 17 && kn <= 17;
+    if (e && e[0] == '1') return true;
+    const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr &&
+                           !A.xcorr_only;
+    int K = 0;
+    return dense_f32 && (A.km * A.kn >= 169 || !fast_available(A.km, A.kn, &K));
 }
 
 bool fast_available(int km, int kn, int* K)
@@ -415,12 +427,15 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
-    if (allow_fast && mfma_available(A.km, A.kn)) {
+    if (allow_fast && mfma_wanted(A)) {
         cs::MfmaWeights E;
         rc = ensure_wfrag(ctx, stream, A.km, A.kn, &E);
         if (rc != CS_OK) return rc;
-        rc = cs::launch_corr_mfma_f32(A, E, stream);
+        int dense_path = 0;
+        rc = cs::launch_corr_mfma_f32(A, E, stream, &dense_path);
+        ctx->last_kernel = dense_path ? CS_KERNEL_MFMA_DENSE : CS_KERNEL_MFMA;
     } else if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
+        ctx->last_kernel = CS_KERNEL_STREAM;
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
@@ -439,6 +454,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         rc = -1;
 #endif
     } else {
+        ctx->last_kernel = CS_KERNEL_GENERIC;
         cs::corr_generic_tile(A.km, A.kn, &tw, &th);
         fill_grid(A, tw, th);
         rc = cs::launch_corr_generic_f32(A, stream);
@@ -453,7 +469,9 @@ int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
+    ctx->last_kernel = CS_KERNEL_GENERIC;
     if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
+        ctx->last_kernel = CS_KERNEL_STREAM;
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
     case KK:                                 \
@@ -633,6 +651,8 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
 extern "C" {
 
 const char* cs_version(void) { return "chromosight_hip 0.1 (gfx950)"; }
+
+int cs_last_kernel(const cs_ctx* ctx) { return ctx ? ctx->last_kernel : 0; }
 
 int cs_ctx_create(int device, cs_ctx** out)
 {

@@ -27,6 +27,9 @@
 // set as ready-made B fragments (17 rows x {head, tail} x 1 KiB, built on the host, cs_api.cpp) =
 // 73 KB, two workgroups per CU.  The epilogue is that of the other kernels (cs_device.h).
 #include "cs_device.h"
+#include <algorithm>
+#include <cstdlib>
+
 #include "cs_launch.h"
 
 namespace cs {
@@ -357,8 +360,447 @@ extern "C" int cs_debug_mfma_profile(unsigned long long* out)
 }
 #endif
 
-int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t stream)
+// ------------------------------------------------------------------------------------------------
+// Unmasked dense float32 maps (the headline configuration): persistent workgroups; the next tile is
+// fetched by LDS-DMA while the current one is in the MFMA phase; weight heads in registers, tails in
+// LDS; squares staged next to the signal; no workgroup barrier between the box sums and the stores.
+// ------------------------------------------------------------------------------------------------
+struct MfmaDenseArgs {
+    const float* sig;
+    void* out;               // float32, or float64 when out_is_f64 (the Python surface returns float64 maps)
+    int out_is_f64;
+    long long ld_in, ld_out, row0_in, row0_out;
+    int ms, ns, km, kn;
+    int row_begin, row_end;
+    int full, sym_upper;
+    int tiles_x, n_tiles;
+    const uint4* frag;
+    float w_unscale;
+    int dbg;                 // diagnostics (CHROMOSIGHT_HIP_MFMA_DBG): skip 1 stores, 2 prefetch, 4 box sums, 8 cross term
+    KernelStats<float> ks;
+};
+
+constexpr int MFD_ROWS_PER_THREAD = 14;       // staging: 240 threads = 40 column pairs x 6 row groups
+constexpr int MFD_WL = 4 * MF_PLANE;          // weight tails
+constexpr int MFD_SCR = MFD_WL + 17 * 1024;   // per wave: head / tail plane of the transposed sums
+constexpr int MFD_RED = MFD_SCR + 4 * 2 * MF_SCR_PLANE;
+constexpr int MFD_SMEM = MFD_RED + 64;
+
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b)
 {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v;
+    v[0] = a;
+    v[1] = b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): with
+// global stores or LDS-DMA transfers in flight it would stall every wave for a full memory round trip.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// maximum of a non-negative value over the wave, valid in lane 63 (DPP: no LDS round trips)
+__device__ __forceinline__ float wave_max_nonneg(float v)
+{
+#define CS_DPP_MAX(ctrl, rmask)                                                                                  \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true)))
+    CS_DPP_MAX(0x111, 0xf);      // row_shr:1
+    CS_DPP_MAX(0x112, 0xf);      // row_shr:2
+    CS_DPP_MAX(0x114, 0xf);      // row_shr:4
+    CS_DPP_MAX(0x118, 0xf);      // row_shr:8   -> lane 15 of every row holds the row's maximum
+    CS_DPP_MAX(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    CS_DPP_MAX(0x143, 0xc);      // row_bcast:31 into rows 2 and 3
+#undef CS_DPP_MAX
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDenseArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const pl_xh = smem;
+    char* const pl_xl = smem + MF_PLANE;
+    char* const pl_qh = smem + 2 * MF_PLANE;
+    char* const pl_ql = smem + 3 * MF_PLANE;
+    float* const raw = reinterpret_cast<float*>(smem + 2 * MF_PLANE);      // next tile's pixels: aliases the squares
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    char* const scr = smem + MFD_SCR + wv * (2 * MF_SCR_PLANE);
+    unsigned* const red = reinterpret_cast<unsigned*>(smem + MFD_RED);
+    const int km = A.km, kn = A.kn;
+    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+
+    // ---- weights: heads of all 17 template rows in registers (rows >= km are zero), tails in LDS
+    h8 wh[17];
+    {
+        const h8* frag = reinterpret_cast<const h8*>(A.frag);
+        h8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+#pragma unroll
+        for (int s = 0; s < 17; ++s) {
+            const int sc = min(s, km - 1);
+            const h8 a = frag[(2 * sc + 0) * 64 + lane];
+            wh[s] = s < km ? a : z;
+        }
+        for (int idx = tid; idx < 17 * 64; idx += 256) {
+            const int sr = idx >> 6;
+            const int sc = min(sr, km - 1);
+            const h8 b = frag[(2 * sc + 1) * 64 + (idx & 63)];
+            reinterpret_cast<h8*>(smem + MFD_WL)[idx] = sr < km ? b : z;
+        }
+    }
+    h8 ones_b, ones_a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = 8 * g + e - n;
+        ones_b[e] = (t >= 0 && t < kn) ? (_Float16)1.0f : (_Float16)0.0f;
+        ones_a[e] = (t >= 0 && t < km) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int wr0 = 16 * wv;
+    const int c2 = tid % 40, rg = tid / 40;         // staging: column pair, row group (threads >= 240 idle)
+    const bool stager = tid < 240;
+    // input rows that windows of [row_begin, row_end) reach and that exist
+    const int p_min = max(0, A.row_begin - kh), p_max = min(A.ms, A.row_end + (km - 1) - kh) - 1;
+
+    auto tile_origin = [&](int tile, int& I0, int& J0) {
+        const int by = tile / A.tiles_x;
+        I0 = A.row_begin + by * MF_T;
+        J0 = (tile - by * A.tiles_x) * MF_T;
+    };
+    // LDS-DMA of one tile's 80 x 80 pixels (clamped addresses; the reader masks what lies outside).
+    // The image is row-major; a wave-wide transfer moves 64 consecutive 4-byte (VEC4: 16-byte) pieces of
+    // it, wave w issues the transfers w, w + 4, ...  A lane's piece advances by 256 pieces per step.
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
+    constexpr int kPiecesPerRow = VEC4 ? MF_R / 4 : MF_R;
+    constexpr int kTransfers = VEC4 ? 25 : 100;
+    const int e0 = 64 * wv_u + lane;
+    const int r_first = e0 / kPiecesPerRow, c_first = e0 - r_first * kPiecesPerRow;
+    auto fetch = [&](int tile) {
+        int I0, J0;
+        tile_origin(tile, I0, J0);
+        const int P0 = I0 - kh, Q0 = J0 - kw;
+        int r = r_first, c = c_first;
+        const __attribute__((address_space(3))) char* dst =
+            (const __attribute__((address_space(3))) char*)(raw) + (VEC4 ? 1024 : 256) * wv_u;
+#pragma unroll 1
+        for (int i = wv_u; i < kTransfers; i += 4) {
+            const int p = min(max(P0 + r, p_min), p_max);
+            const float* row = A.sig + ((long long)p - A.row0_in) * A.ld_in;
+            if constexpr (VEC4) {
+                const int q = min(max(Q0 + 4 * c, 0), A.ns - 4);
+                __builtin_amdgcn_global_load_lds(row + q, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                dst += 4096;
+                c += 256 % kPiecesPerRow;
+                r += 256 / kPiecesPerRow;
+            } else {
+                const int q = min(max(Q0 + c, 0), A.ns - 1);
+                __builtin_amdgcn_global_load_lds(row + q, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+                dst += 1024;
+                c += 256 % kPiecesPerRow;
+                r += 256 / kPiecesPerRow;
+            }
+            if (c >= kPiecesPerRow) {
+                c -= kPiecesPerRow;
+                r += 1;
+            }
+        }
+    };
+
+    // epilogue of one tile (lane = row n of the wave's 16, columns 16 c + 4 g + v), run one iteration late:
+    // its stores then have the whole next tile to retire before the `vmcnt(0)` that awaits the DMA
+    auto emit = [&](int I0, int J0, float unscale, const f4 (&acc)[4], const f4 (&S1)[4], const f4 (&S2)[4]) {
+        const float u_cs = unscale * A.w_unscale;
+        const float u_s2 = 32.0f * unscale;
+        const bool plain = I0 + MF_T <= A.row_end && J0 + MF_T <= A.ns &&
+                           (A.full || (I0 >= kh && I0 + MF_T - 1 <= A.ms - km + kh && J0 >= kw && J0 + MF_T - 1 <= A.ns - kn + kw)) &&
+                           (!A.sym_upper || J0 - (I0 + MF_T - 1) + (A.full ? kn - km : 0) >= 0);
+        const int i = I0 + wr0 + n;
+        const long long o_idx = ((long long)i - A.row0_out) * A.ld_out + (J0 + 4 * g);
+        f4 rv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float cs = acc[c][v] * u_cs;
+                const float s1 = S1[c][v] * unscale;
+                const float s2 = (S2[c][v] * u_s2) * unscale;
+                rv[c][v] = (A.dbg & 32) ? cs + s1 + s2 : pearson_nomask_lean(cs, s1, s2, A.ks);
+            }
+        }
+        if (A.dbg & 1) {
+            if (rv[0][0] == 123.456f) reinterpret_cast<float*>(A.out)[o_idx] = rv[1][1] + rv[2][2] + rv[3][3];
+        } else if (plain && VEC4) {
+            // A lane holds 4 consecutive columns of ONE row per column tile: stored directly, every
+            // instruction would touch 16 rows with 64 bytes each (measured: 4x the cost of the same bytes
+            // at consecutive addresses).  Two column tiles at a time go through the wave's scratch
+            // (16 rows x 32 columns, pitch 36 floats) and leave as 8 rows x 128 contiguous bytes.
+            float* tb = reinterpret_cast<float*>(scr);
+            const long long r_idx = ((long long)(I0 + wr0 + (lane >> 3)) - A.row0_out) * A.ld_out + J0 + 4 * (lane & 7);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                wave_lds_sync();
+                *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = rv[2 * half];
+                *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = rv[2 * half + 1];
+                wave_lds_sync();
+                const f4 lo = *reinterpret_cast<const f4*>(tb + (lane >> 3) * 36 + 4 * (lane & 7));
+                const f4 hi = *reinterpret_cast<const f4*>(tb + ((lane >> 3) + 8) * 36 + 4 * (lane & 7));
+                if (A.out_is_f64) {
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    double* od = reinterpret_cast<double*>(A.out) + r_idx + 32 * half;
+                    d2 a, b;
+                    a[0] = lo[0]; a[1] = lo[1]; b[0] = lo[2]; b[1] = lo[3];
+                    *reinterpret_cast<d2*>(od) = a;
+                    *reinterpret_cast<d2*>(od + 2) = b;
+                    a[0] = hi[0]; a[1] = hi[1]; b[0] = hi[2]; b[1] = hi[3];
+                    *reinterpret_cast<d2*>(od + 8 * A.ld_out) = a;
+                    *reinterpret_cast<d2*>(od + 8 * A.ld_out + 2) = b;
+                } else {
+                    float* of = reinterpret_cast<float*>(A.out) + r_idx + 32 * half;
+                    *reinterpret_cast<f4*>(of) = lo;
+                    *reinterpret_cast<f4*>(of + 8 * A.ld_out) = hi;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int j = J0 + 16 * c + 4 * g + v;
+                    bool z = false;
+                    if (!A.full) z = (i < kh) | (i > A.ms - km + kh) | (j < kw) | (j > A.ns - kn + kw);
+                    if (A.sym_upper) z = z | ((j - i) + (A.full ? (kn - km) : 0) < 0);
+                    if (i < A.row_end && j < A.ns) {
+                        const float val = z ? 0.0f : rv[c][v];
+                        if (A.out_is_f64) reinterpret_cast<double*>(A.out)[o_idx + 16 * c + v] = (double)val;
+                        else reinterpret_cast<float*>(A.out)[o_idx + 16 * c + v] = val;
+                    }
+                }
+            }
+        }
+    };
+
+    f4 p_acc[4], p_S1[4], p_S2[4];
+    int p_I0 = 0, p_J0 = 0;
+    float p_unscale = 0.0f;
+    bool pending = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p_acc[c] = p_S1[c] = p_S2[c] = zero4;
+
+    int tile = blockIdx.x;
+    if (tile < A.n_tiles) fetch(tile);
+    for (; tile < A.n_tiles; tile += gridDim.x) {
+        int I0, J0;
+        tile_origin(tile, I0, J0);
+        const int P0 = I0 - kh, Q0 = J0 - kw;
+        const bool inside = P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
+#ifdef CS_MF_PROFILE
+        unsigned long long tprev_ = __builtin_readcyclecounter();
+        if (tid == 0) atomicAdd(&cs_mf_prof[15], 1ull);
+#endif
+
+        // ---- the tile's pixels have landed in `raw`: read this thread's 14 x 2, find the scale
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's DMA transfers (and long-retired stores)
+        lds_barrier();                           // everyone's transfers; the previous tile's plane readers are done
+        float xa[MFD_ROWS_PER_THREAD], xb[MFD_ROWS_PER_THREAD];
+        float amax = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
+            const int r = rg + 6 * k;
+            float a = 0.0f, b = 0.0f;
+            if (stager && r < MF_R) {
+                const float2 v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
+                a = v.x;
+                b = v.y;
+                if (!inside) {
+                    const int p = P0 + r, q = Q0 + 2 * c2;
+                    const bool rok = (p >= p_min) & (p <= p_max);
+                    a = (rok & (q >= 0) & (q < A.ns)) ? a : 0.0f;
+                    b = (rok & (q + 1 >= 0) & (q + 1 < A.ns)) ? b : 0.0f;
+                }
+            }
+            xa[k] = a;
+            xb[k] = b;
+            amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+        }
+        amax = wave_max_nonneg(amax);
+        if (lane == 63) red[wv] = __float_as_uint(amax);
+        MF_STAMP(0);
+        lds_barrier();                           // everyone has read `raw`: the squares may overwrite it
+        int ex = 0;
+        {
+            const uint4 m4 = *reinterpret_cast<const uint4*>(red);
+            const unsigned mx = max(max(m4.x, m4.y), max(m4.z, m4.w));     // non-negative floats order as integers
+            const int e = (int)((mx >> 23) & 0xffu);
+            if (e != 0 && e != 255) ex = 6 - (e - 127);
+            ex = max(-100, min(100, ex));
+        }
+        const float scale = __uint_as_float((unsigned)(ex + 127) << 23);
+        const float qscale = __uint_as_float((unsigned)(ex + 127 - 5) << 23);   // 2^-5: 17-sums of squares < 65504
+        const float unscale = __uint_as_float((unsigned)(127 - ex) << 23);
+        typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
+            const int r = rg + 6 * k;
+            if (stager && r < MF_R && !(A.dbg & 16)) {
+                // heads by truncation, tails exact differences: head + tail carries 21-22 bits either way
+                const float a = xa[k] * scale, b = xb[k] * scale;
+                const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+                const hv2 tt = __builtin_amdgcn_cvt_pkrtz(a - (float)hh[0], b - (float)hh[1]);
+                const float qa = (xa[k] * qscale) * a, qb = (xb[k] * qscale) * b;
+                const hv2 qh = __builtin_amdgcn_cvt_pkrtz(qa, qb);
+                const hv2 qt = __builtin_amdgcn_cvt_pkrtz(qa - (float)qh[0], qb - (float)qh[1]);
+                const int o = (r * MF_R + 2 * c2) * 2;
+                *reinterpret_cast<hv2*>(pl_xh + o) = hh;
+                *reinterpret_cast<hv2*>(pl_xl + o) = tt;
+                *reinterpret_cast<hv2*>(pl_qh + o) = qh;
+                *reinterpret_cast<hv2*>(pl_ql + o) = qt;
+            }
+        }
+        MF_STAMP(1);
+        // ---- the previous tile's coefficients and stores
+        if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2);
+        MF_STAMP(6);
+        lds_barrier();
+
+        // ---- box sums: horizontal pass over the wave's 32 input rows (all-ones Toeplitz as B), the
+        //      partial sums split again and transposed through the wave's scratch, vertical pass
+        //      (all-ones Toeplitz as B again: transposed tile).  8 steps (4 column tiles x {x, x^2}); the
+        //      fragments of step t + 1 are loaded before the scratch round trip of step t.
+        f4 S1[4], S2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S1[c] = S2[c] = zero4;
+        if (!(A.dbg & 4)) {
+            auto hfrag = [&](int t, h8 (&f)[4]) {
+                const int c = t >> 1;
+                const char* ph = (t & 1) ? pl_qh : pl_xh;
+                const char* pt = (t & 1) ? pl_ql : pl_xl;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const int off = ((wr0 + 16 * rb + n) * MF_R + 16 * c + 8 * g) * 2;
+                    f[2 * rb] = *reinterpret_cast<const h8*>(ph + off);
+                    f[2 * rb + 1] = *reinterpret_cast<const h8*>(pt + off);
+                }
+            };
+            h8 cur[4];
+            hfrag(0, cur);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                h8 nxt[4];
+                if (t + 1 < 8) hfrag(t + 1, nxt);
+                h4 th[2], tl[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    f4 h = mfma16(cur[2 * rb], ones_b, zero4);
+                    h = mfma16(cur[2 * rb + 1], ones_b, h);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        th[rb][v] = (_Float16)h[v];
+                        tl[rb][v] = (_Float16)(h[v] - (float)th[rb][v]);
+                    }
+                }
+                wave_lds_sync();                 // the previous step's scratch reads are issued
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const int so = (n * MF_SCR_PITCH + 16 * rb + 4 * g) * 2;
+                    *reinterpret_cast<h4*>(scr + so) = th[rb];
+                    *reinterpret_cast<h4*>(scr + MF_SCR_PLANE + so) = tl[rb];
+                }
+                wave_lds_sync();
+                const int ro = (n * MF_SCR_PITCH + 8 * g) * 2;
+                const h8 bh = *reinterpret_cast<const h8*>(scr + ro);
+                const h8 bl = *reinterpret_cast<const h8*>(scr + MF_SCR_PLANE + ro);
+                f4 sacc = mfma16(bh, ones_a, zero4);
+                sacc = mfma16(bl, ones_a, sacc);
+                if (t & 1) S2[t >> 1] = sacc;
+                else S1[t >> 1] = sacc;
+                if (t + 1 < 8) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+                }
+            }
+        }
+        MF_STAMP(2);
+        lds_barrier();                           // all waves are done with the squares
+        // ---- next tile's pixels -> `raw` while this tile's correlation runs
+        if (tile + (int)gridDim.x < A.n_tiles && !(A.dbg & 2)) fetch(tile + gridDim.x);
+
+        MF_STAMP(3);
+        // ---- cross term: 17 template rows x 4 column tiles, fragments of row s + 1 in flight during row s
+        f4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = zero4;
+        h8 ah[4], al[4], bl;
+        const int fo = ((wr0 + n) * MF_R + 8 * g) * 2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ah[c] = *reinterpret_cast<const h8*>(pl_xh + fo + 32 * c);
+            al[c] = *reinterpret_cast<const h8*>(pl_xl + fo + 32 * c);
+        }
+        bl = reinterpret_cast<const h8*>(smem + MFD_WL)[lane];
+        if (!(A.dbg & 8))
+#pragma unroll
+        for (int s = 0; s < 17; ++s) {
+            h8 nh[4], nl[4], nb;
+            if (s + 1 < 17) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    nh[c] = *reinterpret_cast<const h8*>(pl_xh + fo + (s + 1) * MF_R * 2 + 32 * c);
+                    nl[c] = *reinterpret_cast<const h8*>(pl_xl + fo + (s + 1) * MF_R * 2 + 32 * c);
+                }
+                nb = reinterpret_cast<const h8*>(smem + MFD_WL)[(s + 1) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[s], ah[c], acc[c]);     // weights as A: transposed tile
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(bl, ah[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[s], al[c], acc[c]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < 17) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ah[c] = nh[c];
+                    al[c] = nl[c];
+                }
+                bl = nb;
+            }
+        }
+        MF_STAMP(4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            p_acc[c] = acc[c];
+            p_S1[c] = S1[c];
+            p_S2[c] = S2[c];
+        }
+        p_I0 = I0;
+        p_J0 = J0;
+        p_unscale = unscale;
+        pending = true;
+    }
+    if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2);
+}
+
+int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t stream, int* dense_path)
+{
+    *dense_path = 0;
     A.tile_w = A.tile_h = MF_T;
     A.tiles_y = (A.row_end - A.row_begin + MF_T - 1) / MF_T;
     if (A.out.layout == 1) {
@@ -374,6 +816,45 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
     if (blocks <= 0) return 0;
     if (blocks > 0x7fffffffLL) return -3;
     const bool masked = A.mask_mode != 0;
+    const bool dense_f32 = !masked && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr && !A.xcorr_only &&
+                           A.ms > 0 && A.ns > 0;
+    if (dense_f32 && !getenv("CHROMOSIGHT_HIP_MFMA_V1")) {
+        *dense_path = 1;
+        MfmaDenseArgs D;
+        D.sig = reinterpret_cast<const float*>(A.sig.ptr);
+        D.out = A.out.ptr;
+        D.out_is_f64 = A.out_is_f64;
+        D.ld_in = A.sig.ld;
+        D.ld_out = A.out.ld;
+        D.row0_in = A.sig.row0;
+        D.row0_out = A.out.row0;
+        D.ms = A.ms;
+        D.ns = A.ns;
+        D.km = A.km;
+        D.kn = A.kn;
+        D.row_begin = A.row_begin;
+        D.row_end = A.row_end;
+        D.full = A.full;
+        D.sym_upper = A.sym_upper;
+        D.tiles_x = A.tiles_x;
+        D.n_tiles = (int)blocks;
+        D.frag = E.frag;
+        D.w_unscale = E.unscale[0];
+        D.dbg = getenv("CHROMOSIGHT_HIP_MFMA_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_DBG")) : 0;
+        D.ks = A.ks;
+        // 16-byte transfers and stores need aligned rows: base pointers, leading dimensions, the tile's
+        // first staged column (64 bx - kw) and the row length all multiples of 4 elements
+        const bool vec4 = ((uintptr_t)D.sig % 16 == 0) && ((uintptr_t)D.out % 32 == 0) && D.ld_in % 4 == 0 && D.ld_out % 4 == 0 &&
+                          ((A.kn - 1) / 2) % 4 == 0 && D.ns % 4 == 0 && D.ns >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
+        const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true> : (const void*)corr_mfma_dense_kernel<false>;
+        hipError_t e2 = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e2 != hipSuccess) return (int)e2;
+        const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+        const int grid = (int)std::min<long long>(blocks, (long long)per_cu * A.n_cu);
+        if (vec4) hipLaunchKernelGGL(corr_mfma_dense_kernel<true>, dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
+        else hipLaunchKernelGGL(corr_mfma_dense_kernel<false>, dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
+        return (int)hipGetLastError();
+    }
     const void* kern = masked ? (const void*)corr_mfma_kernel<true> : (const void*)corr_mfma_kernel<false>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;

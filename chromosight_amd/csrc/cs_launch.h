@@ -29,6 +29,6 @@ struct MfmaWeights {
     const uint4* frag;
     float unscale[3];
 };
-int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s);
+int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s, int* dense_path);
 
 }  // namespace cs

@@ -1,0 +1,194 @@
+"""The matrix-core kernels (chromosight_amd/csrc/cs_corr_mfma.hip) against the C oracle.
+
+Default dispatch sends unmasked dense float32 maps with large or odd-shaped templates to the
+persistent dense kernel; CHROMOSIGHT_HIP_MFMA=1 sends every float32 call with a template of up to
+17 x 17 to the matrix cores (general kernel: masks, bands, n_obs, float64 containers) and
+CHROMOSIGHT_HIP_NO_MFMA=1 none -- all three must give the oracle's map at the 1e-5 bar, and the two
+float32 kernels must agree with each other far below it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import chromosight_amd
+import chromosight_amd.kernels as ck
+from chromosight_amd import engine
+from chromosight_amd._lib import LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_NONE, CsMatrix, get_device, np_dtype_code
+from chromosight_amd.utils import detection as cud
+from chromosight_amd.utils import preprocessing as cup
+from oracle import c_oracle
+from parity_util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def f32_precision():
+    old = chromosight_amd.get_precision()
+    chromosight_amd.set_precision("f32")
+    yield
+    chromosight_amd.set_precision(old)
+
+
+KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE = 1, 2, 3, 4
+
+
+def last_kernel():
+    """Which native correlation kernel served the last call on the default context (cs_last_kernel)."""
+    dev = get_device()
+    return dev.lib.cs_last_kernel(dev.ctx)
+
+
+def loops():
+    return np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+
+
+def _signal(rng, shape, kind):
+    if kind == "gamma":
+        return rng.gamma(2.0, 1.0, size=shape)
+    if kind == "hic":                       # detrended-map like: around 1, capped
+        return np.minimum(rng.gamma(20, 0.05, size=shape), 10.0)
+    if kind == "tiny":                      # scale far from 1: the per-tile power-of-two scale must absorb it
+        return rng.gamma(2.0, 1.0, size=shape) * 3e-7
+    if kind == "huge":
+        return rng.gamma(2.0, 1.0, size=shape) * 7e8
+    if kind == "signed":
+        return rng.normal(size=shape)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("shape,kshape,kind", [
+    ((300, 300), (17, 17), "gamma"), ((513, 777), (17, 17), "hic"), ((130, 64), (17, 17), "signed"),
+    ((64, 70), (17, 17), "gamma"),          # row length not a multiple of 4: 4-byte transfers, scalar stores
+    ((200, 333), (5, 9), "gamma"), ((150, 150), (15, 11), "hic"), ((97, 201), (13, 15), "gamma"),
+    ((256, 256), (17, 17), "tiny"), ((256, 256), (17, 17), "huge"), ((90, 90), (3, 3), "gamma"),
+])
+@pytest.mark.parametrize("full", [True, False])
+def test_dense_kernel_matches_oracle(shape, kshape, kind, full, monkeypatch):
+    """Default dispatch (persistent dense kernel; forced for the small templates), every edge case of
+    the tiling: partial tiles, frames narrower than a tile, valid-mode margins, rectangular and even
+    templates, data far from unit scale."""
+    if kshape[0] * kshape[1] < 169:
+        monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA", "1")
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1] + kshape[0])
+    sig = _signal(rng, shape, kind).astype(np.float32)
+    kern = loops() if kshape == (17, 17) else rng.normal(size=kshape) + 0.3
+    if min(shape) < max(kshape) and not full:
+        pytest.skip("no valid window")
+    got, _ = cud.normxcorr2(sig, kern, full=full)
+    assert last_kernel() == KERNEL_MFMA_DENSE
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, shape[0], full=full)
+    assert_parity(got, want, cond, "f32", f"mfma dense {shape} {kshape} {kind} full={full}")
+
+
+def test_dense_kernel_equals_streaming_kernel(monkeypatch):
+    """The two float32 kernels (matrix cores / packed FMA) on one map: same coefficients to ~1e-6."""
+    rng = np.random.default_rng(5)
+    sig = rng.gamma(2.0, 1.0, size=(1000, 1100)).astype(np.float32)
+    a, _ = cud.normxcorr2(sig, loops(), full=True)
+    assert last_kernel() == KERNEL_MFMA_DENSE
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_MFMA", "1")
+    b, _ = cud.normxcorr2(sig, loops(), full=True)
+    assert last_kernel() == KERNEL_STREAM
+    assert np.abs(a - b).max() < 3e-6
+    assert not np.array_equal(a, b)          # they are different kernels
+
+
+def test_sym_upper_dense(monkeypatch):
+    rng = np.random.default_rng(9)
+    sig = np.triu(rng.gamma(2.0, 1.0, size=(260, 260))).astype(np.float32)
+    for full in (True, False):
+        got, _ = cud.normxcorr2(sig, loops(), sym_upper=True, full=full)
+        assert last_kernel() == KERNEL_MFMA_DENSE
+        want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), loops(), 0, 260, sym_upper=True, full=full)
+        assert_parity(got, want, cond, "f32", f"mfma dense sym_upper full={full}")
+        assert np.all(np.tril(got, -1) == 0)
+
+
+def test_general_kernel_masks_bands_nobs(monkeypatch):
+    """CHROMOSIGHT_HIP_MFMA=1: the general matrix-core kernel on banded maps with per-bin masks (detect
+    configuration, incl. n_obs), an explicit mask in valid mode and an inter-chromosomal block."""
+    monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA", "1")
+    rng = np.random.default_rng(21)
+    n, md = 900, 120
+    ii, jj = np.indices((n, n))
+    sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
+    sig[jj - ii > md + 17] = 0
+    valid = np.flatnonzero(rng.random(n) > 0.04)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    sig[miss, :] = 0
+    sig[:, miss] = 0
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+    for kern in (loops(), np.asarray(ck.borders["kernels"][0], dtype=np.float64)):
+        c, _ = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                              missing_tol=0.75, pval=True)
+        assert last_kernel() == KERNEL_MFMA
+        want, cond = c_oracle.normxcorr2_rows(sig, kern, 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss,
+                                              miss_col=miss)
+        band = (jj - ii >= 0) & (jj - ii <= md)
+        assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma general band {kern.shape}")
+    # inter-chromosomal block: dense, masks on both axes, no diagonal limits
+    shape = (300, 420)
+    inter = rng.gamma(2.0, 1.0, size=shape)
+    vr, vc = np.flatnonzero(rng.random(300) > 0.05), np.flatnonzero(rng.random(420) > 0.05)
+    mr, mc = np.ones(300, bool), np.ones(420, bool)
+    mr[vr] = False
+    mc[vc] = False
+    inter[mr, :] = 0
+    inter[:, mc] = 0
+    mask = cup.make_missing_mask(shape, vr, vc, max_dist=None, sym_upper=False)
+    c, _ = cud.normxcorr2(sp.csr_matrix(inter), loops(), max_dist=None, sym_upper=False, full=True, missing_mask=mask,
+                          missing_tol=0.75)
+    assert last_kernel() == KERNEL_MFMA
+    want, cond = c_oracle.normxcorr2_rows(inter, loops(), 0, 300, full=True, miss_row=mr, miss_col=mc)
+    assert_parity(c.toarray(), want, cond, "f32", "mfma general inter")
+
+
+def test_general_kernel_xcorr2_and_f64_containers(monkeypatch):
+    monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA", "1")
+    rng = np.random.default_rng(33)
+    sig = rng.gamma(2.0, 1.0, size=(210, 190))
+    k = rng.normal(size=(7, 11))
+    got = cud.xcorr2(sig, k, threshold=1e-4)                 # float64 container in, plain cross-correlation
+    assert last_kernel() == KERNEL_MFMA
+    from oracle import pearson_oracle as orc
+    want = orc.xcorr2_oracle(sig, k, threshold=0)
+    near = np.abs(np.abs(want) - 1e-4) < 1e-6
+    ref = np.where(np.abs(want) < 1e-4, 0.0, want)
+    assert np.abs(got - ref)[~near].max() < 3e-6 * np.abs(want).max()
+    c, _ = cud.normxcorr2(sig, loops(), full=True)            # float64 ndarray in
+    assert last_kernel() == KERNEL_MFMA
+    w, cond = c_oracle.normxcorr2_rows(sig, loops(), 0, 210, full=True)
+    assert_parity(c, w, cond, "f32", "mfma general f64 container")
+
+
+def test_dense_kernel_row_windows():
+    """Row windows through the persistent kernel (slab inputs): equal to the rows of the whole map."""
+    dev = get_device()
+    rng = np.random.default_rng(4)
+    n, cols = 700, 900
+    sig_h = rng.gamma(2.0, 1.0, size=(n, cols)).astype(np.float32)
+    kspec = engine.KernelSpec(loops(), None)
+    code = np_dtype_code(np.float32)
+
+    def run(sig, out, window=None):
+        params = engine._corr_params((n, cols), kspec, True, False, None, MASK_NONE, None, None, None, 0.75,
+                                     engine.compute_code("f32"), window)
+        dev._check(dev.lib.cs_normxcorr2(dev.ctx, None, C.byref(sig), C.byref(kspec.struct), C.byref(params), C.byref(out), None))
+
+    d_sig = dev.to_device(sig_h)
+    d_full = dev.zeros(n * cols, np.float32)
+    run(CsMatrix(d_sig.ptr, code, LAYOUT_DENSE, cols, 0, 0), CsMatrix(d_full.ptr, code, LAYOUT_DENSE, cols, 0, 0))
+    full = d_full.download().reshape(n, cols)
+    assert last_kernel() == KERNEL_MFMA_DENSE
+    want, cond = c_oracle.normxcorr2_rows(sig_h.astype(np.float64), loops(), 0, n, full=True)
+    assert_parity(full, want, cond, "f32", "mfma dense whole map")
+    for a, b in [(0, 37), (37, 200), (200, 201), (201, 695), (695, 700)]:
+        ra, rb = max(0, a - 8), min(n, b + 8)
+        d_slab = dev.to_device(np.ascontiguousarray(sig_h[ra:rb]))
+        d_out = dev.zeros((b - a) * cols, np.float32)
+        run(CsMatrix(d_slab.ptr, code, LAYOUT_DENSE, cols, 0, 0, ra), CsMatrix(d_out.ptr, code, LAYOUT_DENSE, cols, 0, 0, a), (a, b))
+        got = d_out.download().reshape(b - a, cols)
+        assert np.abs(got - full[a:b]).max() <= 2e-6, (a, b)

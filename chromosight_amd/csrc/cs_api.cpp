@@ -243,10 +243,23 @@ bool fast_available(int km, int kn, int* K);
 
 // Which float32 calls go to the matrix cores (cs_corr_mfma.hip).  Default: unmasked dense float32 maps
 // (cs_normxcorr2 without a mask: the API / benchmark configuration) whenever the template is large
-// (>= 13 x 13 entries: every template row costs a full 17-row pass there) or has no streaming kernel
-// (rectangular, even sizes).  CHROMOSIGHT_HIP_MFMA=1: every call with a template of up to 17 x 17
+// (>= 13 x 13 entries: every template costs a full 17-row pass there, so small ones are cheaper on the
+// packed-FMA kernel -- measured 4096^2: 17x17 0.115 vs 0.185 ms (no symmetry), 13x13 0.124 vs 0.127,
+// 11x11 0.129 vs 0.108), the map is small (the strips of the streaming kernel under-fill the chip:
+// 2048^2 11x11 0.035 vs 0.042 ms, 1024^2 9x9 0.014 vs 0.019) or the template has no streaming kernel
+// (rectangular sizes).  CHROMOSIGHT_HIP_MFMA=1: every call with a template of up to 17 x 17
 // (masked / banded maps run the general, slower, matrix-core kernel -- a test switch);
 // CHROMOSIGHT_HIP_NO_MFMA=1: never.  Read per call so that tests can flip them.
+// per-bin masks (detect / quantify configuration): opt-in for now (CHROMOSIGHT_HIP_MFMA_REG=1)
+bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
+{
+    if (A.mask_mode != CS_MASK_BINS || !A.full || A.km != A.kn || A.km > 17 || A.km < 3 || !(A.km & 1)) return false;
+    if (A.sig_is_f64 || A.xcorr_only) return false;
+    if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
+    const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA_REG");
+    return e && e[0] == '1';
+}
+
 bool mfma_wanted(const cs::CorrArgs<float>& A)
 {
     if (A.km < 1 || A.kn < 1 || A.km > 17 || A.kn > 17) return false;
@@ -256,7 +269,8 @@ bool mfma_wanted(const cs::CorrArgs<float>& A)
     const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr &&
                            !A.xcorr_only;
     int K = 0;
-    return dense_f32 && (A.km * A.kn >= 169 || !fast_available(A.km, A.kn, &K));
+    const long long px = (long long)(A.row_end - A.row_begin) * A.ns;
+    return dense_f32 && (A.km * A.kn >= 169 || px <= 6000000 || !fast_available(A.km, A.kn, &K));
 }
 
 bool fast_available(int km, int kn, int* K)
@@ -427,13 +441,36 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
+    A.reg_mode = 0;
+    // per-bin masks on the matrix cores: the factorised mask tables + the persistent tile kernel
+    if (allow_fast && mfma_reg_wanted(A)) {
+        if (A.out.layout == CS_LAYOUT_BAND) {
+            A.out_lo = A.out.band_lo;
+            A.out_hi = A.out.band_lo + A.out.band_w - 1;
+        } else {
+            A.out_lo = -(1 << 30);
+            A.out_hi = (1 << 30);
+        }
+        rc = prepare_regular_mask<float>(ctx, A, A.km, stream);
+        if (rc != CS_OK) return rc;
+        if (A.reg_mode == 1) {
+            cs::MfmaWeights E;
+            rc = ensure_wfrag(ctx, stream, A.km, A.kn, &E);
+            if (rc != CS_OK) return rc;
+            int path = 0;
+            rc = cs::launch_corr_mfma_f32(A, E, stream, &path);
+            ctx->last_kernel = path == 2 ? CS_KERNEL_MFMA_REG : CS_KERNEL_MFMA;
+            if (rc != 0) return fail(ctx, CS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            return CS_OK;
+        }
+    }
     if (allow_fast && mfma_wanted(A)) {
         cs::MfmaWeights E;
         rc = ensure_wfrag(ctx, stream, A.km, A.kn, &E);
         if (rc != CS_OK) return rc;
         int dense_path = 0;
         rc = cs::launch_corr_mfma_f32(A, E, stream, &dense_path);
-        ctx->last_kernel = dense_path ? CS_KERNEL_MFMA_DENSE : CS_KERNEL_MFMA;
+        ctx->last_kernel = dense_path == 1 ? CS_KERNEL_MFMA_DENSE : dense_path == 2 ? CS_KERNEL_MFMA_REG : CS_KERNEL_MFMA;
     } else if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
         ctx->last_kernel = CS_KERNEL_STREAM;
 #ifdef CS_HAVE_FAST

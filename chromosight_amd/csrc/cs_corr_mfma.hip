@@ -378,6 +378,22 @@ struct MfmaDenseArgs {
     float w_unscale;
     int dbg;                 // diagnostics (CHROMOSIGHT_HIP_MFMA_DBG): skip 1 stores, 2 prefetch, 4 box sums, 8 cross term
     KernelStats<float> ks;
+    // ---- REG instances: per-bin missing masks through the factorised tables of cs_mask_prep.hip, any
+    //      layout (band / dense) on either side, optional n_obs map
+    int band_in, lo_in, bw_in;       // input band: first stored diagonal, stored diagonals
+    int band_out, lo_out;            // output band: first stored diagonal
+    int out_lo, out_hi;              // produced diagonals
+    float* nobs;                     // same geometry as `out`, or nullptr
+    const float* w;                  // float32 weight sets (K*K each): centred template, Wa, Wb
+    const uint8_t* miss_col;
+    const float* rowtab;             // [row][4]: nr, RA, RB, flags of the window rows
+    const float* coltab;             // [3][ns]: ncol, CA, CB
+    int fix_on, fix_hi_w, fix_hi_d0;
+    const float* fix_lo;
+    const float* fix_hi;
+    const float* fix_rows;
+    const float* fix_cols;
+    int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
 };
 
 constexpr int MFD_ROWS_PER_THREAD = 14;       // staging: 240 threads = 40 column pairs x 6 row groups
@@ -385,6 +401,13 @@ constexpr int MFD_WL = 4 * MF_PLANE;          // weight tails
 constexpr int MFD_SCR = MFD_WL + 17 * 1024;   // per wave: head / tail plane of the transposed sums
 constexpr int MFD_RED = MFD_SCR + 4 * 2 * MF_SCR_PLANE;
 constexpr int MFD_SMEM = MFD_RED + 64;
+// REG: column terms (ncol, CA, CB of the tile's 64 columns) and the column flags of its 80 staged columns,
+// double-buffered (a tile's epilogue runs while the next tile's are already landing)
+constexpr int MFD_COL = MFD_RED + 64;
+constexpr int MFD_CFL = MFD_COL + 2 * 3 * 64 * 4;
+constexpr int MFD_CFB = MFD_CFL + 2 * 80 * 4;          // raw flag bytes as they arrive
+constexpr int MFD_SMEM_REG = MFD_CFB + 2 * 128;
+static_assert(MFD_SMEM_REG <= 80 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b)
 {
@@ -428,9 +451,10 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool VEC4>
+template <bool VEC4, bool REG>
 __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDenseArgs A)
 {
+    static_assert(!(VEC4 && REG), "REG instances address the signal pixel by pixel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const pl_xh = smem;
     char* const pl_xl = smem + MF_PLANE;
@@ -458,11 +482,16 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             const h8 a = frag[(2 * sc + 0) * 64 + lane];
             wh[s] = s < km ? a : z;
         }
-        for (int idx = tid; idx < 17 * 64; idx += 256) {
-            const int sr = idx >> 6;
-            const int sc = min(sr, km - 1);
-            const h8 b = frag[(2 * sc + 1) * 64 + (idx & 63)];
-            reinterpret_cast<h8*>(smem + MFD_WL)[idx] = sr < km ? b : z;
+        h8 tails[5];                                   // 17 x 64 fragments = 4.25 per thread: loads first
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = min(tid + 256 * k, 17 * 64 - 1);
+            tails[k] = frag[(2 * min(idx >> 6, km - 1) + 1) * 64 + (idx & 63)];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < 17 * 64) reinterpret_cast<h8*>(smem + MFD_WL)[idx] = (idx >> 6) < km ? tails[k] : z;
         }
     }
     h8 ones_b, ones_a;
@@ -483,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         const int by = tile / A.tiles_x;
         I0 = A.row_begin + by * MF_T;
         J0 = (tile - by * A.tiles_x) * MF_T;
+        if (REG && A.band_out) J0 += I0 + A.out_lo;       // the strip of tiles follows the band
     };
     // LDS-DMA of one tile's 80 x 80 pixels (clamped addresses; the reader masks what lies outside).
     // The image is row-major; a wave-wide transfer moves 64 consecutive 4-byte (VEC4: 16-byte) pieces of
@@ -492,11 +522,30 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
     constexpr int kTransfers = VEC4 ? 25 : 100;
     const int e0 = 64 * wv_u + lane;
     const int r_first = e0 / kPiecesPerRow, c_first = e0 - r_first * kPiecesPerRow;
-    auto fetch = [&](int tile) {
+    auto fetch = [&](int tile, int slot) {
         int I0, J0;
         tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
         int r = r_first, c = c_first;
+        if constexpr (REG) {
+            // column terms of the tile's 64 columns (waves 0..2) and the flags of its 80 staged columns (wave 3)
+            if (wv_u < 3) {
+                const float* src = A.coltab + (size_t)wv_u * A.ns + min(max(J0 + lane, 0), A.ns - 1);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(
+                    (__attribute__((address_space(3))) char*)(smem) + MFD_COL + (slot * 3 + wv_u) * 256), 4, 0, 0);
+            } else {
+                // the 80 flag bytes of columns Q0 .. Q0 + 79 as the <= 22 aligned dwords that hold them (lanes
+                // beyond are harmless repeats; addresses clamped to the dwords that overlap the array)
+                const long long base = (long long)(uintptr_t)A.miss_col;
+                const long long first = ((base + Q0) >> 2) << 2;
+                long long addr = first + 4 * min(lane, 31);
+                addr = min(max(addr, (base >> 2) << 2), ((base + A.ns - 1) >> 2) << 2);
+                if (lane < 32)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>((uintptr_t)addr),
+                                                     (__attribute__((address_space(3))) void*)(
+                                                         (__attribute__((address_space(3))) char*)(smem) + MFD_CFB + slot * 128), 4, 0, 0);
+            }
+        }
         const __attribute__((address_space(3))) char* dst =
             (const __attribute__((address_space(3))) char*)(raw) + (VEC4 ? 1024 : 256) * wv_u;
 #pragma unroll 1
@@ -510,7 +559,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 c += 256 % kPiecesPerRow;
                 r += 256 / kPiecesPerRow;
             } else {
-                const int q = min(max(Q0 + c, 0), A.ns - 1);
+                int q = min(max(Q0 + c, 0), A.ns - 1);
+                if (REG && A.band_in) q = min(max(q - p - A.lo_in, 0), A.bw_in - 1);      // stored diagonal index
                 __builtin_amdgcn_global_load_lds(row + q, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
                 dst += 1024;
                 c += 256 % kPiecesPerRow;
@@ -525,9 +575,132 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
 
     // epilogue of one tile (lane = row n of the wave's 16, columns 16 c + 4 g + v), run one iteration late:
     // its stores then have the whole next tile to retire before the `vmcnt(0)` that awaits the DMA
-    auto emit = [&](int I0, int J0, float unscale, const f4 (&acc)[4], const f4 (&S1)[4], const f4 (&S2)[4]) {
+    auto emit = [&](int I0, int J0, float unscale, const f4 (&acc)[4], const f4 (&S1)[4], const f4 (&S2)[4],
+                    const f4& hdr, int slot) {
         const float u_cs = unscale * A.w_unscale;
         const float u_s2 = 32.0f * unscale;
+        if constexpr (REG) {
+            // ---- per-bin masks: the factorised mask sums of cs_mask_prep.hip (see cs_corr_stream.h MODE 2)
+            //   n_missing = K nr[i] + (K - nr[i]) ncol[j],  sum_missing Wa = RA[i] + CA[j] - sum_kj c[j+kj] U_i[kj]
+            // plus the precomputed corrections of the pixels whose window leaves the matrix / 0..max_dist
+            const int K = km, KH = kh;
+            const int i = I0 + wr0 + n;
+            const float* colb = reinterpret_cast<const float*>(smem + MFD_COL) + slot * 3 * 64;
+            const float* cfl = reinterpret_cast<const float*>(smem + MFD_CFL) + slot * 80;
+            const float nr = hdr[0], ra = hdr[1], rb = hdr[2];
+            unsigned bits = (unsigned)hdr[3];
+            f4 xa[4], xb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xa[c] = xb[c] = zero4;
+            // cross term: for every flagged row ki of the window, (column flags (*) template row ki)
+            if (A.dbg & 128) bits = 0;
+            while (__builtin_amdgcn_ballot_w64(bits != 0)) {
+                if (bits) {
+                    const int ki = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const float* wa = A.w + K * K + ki * K;
+                    const float* wb = A.w + 2 * K * K + ki * K;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float fl[20];
+#pragma unroll
+                        for (int e = 0; e < 5; ++e) {
+                            const f4 t = *reinterpret_cast<const f4*>(cfl + 16 * c + 4 * g + 4 * e);
+                            fl[4 * e] = t[0]; fl[4 * e + 1] = t[1]; fl[4 * e + 2] = t[2]; fl[4 * e + 3] = t[3];
+                        }
+#pragma unroll
+                        for (int kj = 0; kj < 17; ++kj) {
+                            const float a = kj < K ? wa[min(kj, K - 1)] : 0.0f, b = kj < K ? wb[min(kj, K - 1)] : 0.0f;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                xa[c][v] = fmaf(fl[v + kj], a, xa[c][v]);
+                                xb[c][v] = fmaf(fl[v + kj], b, xb[c][v]);
+                            }
+                        }
+                    }
+                }
+            }
+            const int dmin = J0 - (I0 + MF_T - 1), dmax = J0 + MF_T - 1 - I0;
+            const bool needs_fix = !(A.dbg & 256) && (I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_cols != nullptr) |
+                                   (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
+                                                 (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w)));
+            float* tb = reinterpret_cast<float*>(scr);
+#pragma unroll
+            for (int pass = 0; pass < (A.nobs ? 2 : 1); ++pass) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f4 rv[2];
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int c = 2 * half + cc;
+                        const f4 ncol = *reinterpret_cast<const f4*>(colb + 16 * c + 4 * g);
+                        const f4 ca = *reinterpret_cast<const f4*>(colb + 64 + 16 * c + 4 * g);
+                        const f4 cb = *reinterpret_cast<const f4*>(colb + 128 + 16 * c + 4 * g);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int j = J0 + 16 * c + 4 * g + v;
+                            const int d = j - i;
+                            float nm = (float)K * nr + ((float)K - nr) * ncol[v];
+                            float ka = ra + ca[v] - xa[c][v];
+                            float kb = rb + cb[v] - xb[c][v];
+                            if (needs_fix) {
+                                const bool in_range = (j >= 0) & (j < A.ns) & (d >= A.out_lo) & (d <= A.out_hi) & (i < A.row_end);
+                                const float* f = nullptr;
+                                if (in_range) {
+                                    const int x = A.fix_xband ? d - A.fix_xlo : j;
+                                    if (i < A.fix_top) f = A.fix_rows + ((size_t)i * A.fix_width + x) * 4;
+                                    else if (i >= A.fix_bot0 && (!A.fix_on || (i + KH >= A.ms) | (j + KH >= A.ns)))
+                                        f = A.fix_rows + ((size_t)(A.fix_top + i - A.fix_bot0) * A.fix_width + x) * 4;
+                                    else if (A.fix_cols && (j < A.fix_side || j >= A.ns - A.fix_side))
+                                        f = A.fix_cols + ((size_t)i * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side))) * 4;
+                                    else if (A.fix_on) {
+                                        if (d >= 0 && d < K - 1) f = A.fix_lo + ((size_t)i * (K - 1) + d) * 4;
+                                        else if (d >= A.fix_hi_d0 && d - A.fix_hi_d0 < A.fix_hi_w)
+                                            f = A.fix_hi + ((size_t)i * A.fix_hi_w + (d - A.fix_hi_d0)) * 4;
+                                    }
+                                }
+                                if (f) {
+                                    nm += f[0];
+                                    ka += f[1];
+                                    kb += f[2];
+                                }
+                            }
+                            float val;
+                            if (pass == 0) {
+                                const float cs = acc[c][v] * u_cs;
+                                const float s1 = S1[c][v] * unscale;
+                                const float s2 = (S2[c][v] * u_s2) * unscale;
+                                val = pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks);
+                                if (A.sym_upper && d + (kn - km) < 0) val = 0.0f;      // full mode: triu in framed coordinates
+                            } else {
+                                val = A.ks.n - nm;
+                            }
+                            rv[cc][v] = val;
+                        }
+                    }
+                    // 16 rows x 32 columns through the wave's scratch, out as 2 rows x 32 consecutive floats per
+                    // instruction (band rows are shifted against each other: no wider aligned store exists)
+                    wave_lds_sync();
+                    *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = rv[0];
+                    *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = rv[1];
+                    wave_lds_sync();
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int rr = 2 * it + (lane >> 5), xx = lane & 31;
+                        const float val = tb[rr * 36 + xx];
+                        const int oi = I0 + wr0 + rr, oj = J0 + 32 * half + xx;
+                        const int d = oj - oi;
+                        if (!(A.dbg & 1) && oi < A.row_end && oj >= 0 && oj < A.ns && d >= A.out_lo && d <= A.out_hi) {
+                            const long long idx = ((long long)oi - A.row0_out) * A.ld_out + (A.band_out ? d - A.lo_out : oj);
+                            if (pass == 1) A.nobs[idx] = val;
+                            else if (A.out_is_f64) reinterpret_cast<double*>(A.out)[idx] = (double)val;
+                            else reinterpret_cast<float*>(A.out)[idx] = val;
+                        }
+                    }
+                }
+            }
+            return;
+        }
         const bool plain = I0 + MF_T <= A.row_end && J0 + MF_T <= A.ns &&
                            (A.full || (I0 >= kh && I0 + MF_T - 1 <= A.ms - km + kh && J0 >= kw && J0 + MF_T - 1 <= A.ns - kn + kw)) &&
                            (!A.sym_upper || J0 - (I0 + MF_T - 1) + (A.full ? kn - km : 0) >= 0);
@@ -596,20 +769,20 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         }
     };
 
-    f4 p_acc[4], p_S1[4], p_S2[4];
-    int p_I0 = 0, p_J0 = 0;
+    f4 p_acc[4], p_S1[4], p_S2[4], p_hdr = zero4;
+    int p_I0 = 0, p_J0 = 0, p_slot = 0, slot = 0;
     float p_unscale = 0.0f;
     bool pending = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) p_acc[c] = p_S1[c] = p_S2[c] = zero4;
 
     int tile = blockIdx.x;
-    if (tile < A.n_tiles) fetch(tile);
+    if (tile < A.n_tiles) fetch(tile, 0);
     for (; tile < A.n_tiles; tile += gridDim.x) {
         int I0, J0;
         tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
-        const bool inside = P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
+        const bool inside = !REG && P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
 #ifdef CS_MF_PROFILE
         unsigned long long tprev_ = __builtin_readcyclecounter();
         if (tid == 0) atomicAdd(&cs_mf_prof[15], 1ull);
@@ -631,8 +804,14 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 if (!inside) {
                     const int p = P0 + r, q = Q0 + 2 * c2;
                     const bool rok = (p >= p_min) & (p <= p_max);
-                    a = (rok & (q >= 0) & (q < A.ns)) ? a : 0.0f;
-                    b = (rok & (q + 1 >= 0) & (q + 1 < A.ns)) ? b : 0.0f;
+                    bool oka = rok & (q >= 0) & (q < A.ns), okb = rok & (q + 1 >= 0) & (q + 1 < A.ns);
+                    if (REG && A.band_in) {               // outside the stored diagonals: zero
+                        const int dd = q - p - A.lo_in;
+                        oka &= (dd >= 0) & (dd < A.bw_in);
+                        okb &= (dd + 1 >= 0) & (dd + 1 < A.bw_in);
+                    }
+                    a = oka ? a : 0.0f;
+                    b = okb ? b : 0.0f;
                 }
             }
             xa[k] = a;
@@ -641,6 +820,16 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         }
         amax = wave_max_nonneg(amax);
         if (lane == 63) red[wv] = __float_as_uint(amax);
+        if constexpr (REG) {
+            // the tile's column flags as floats, zero outside the matrix (the transfer clamped its addresses)
+            if (tid < 80) {
+                const int q = Q0 + tid;
+                const long long start = (long long)(uintptr_t)A.miss_col + Q0;
+                const int skew = (int)(start - ((start >> 2) << 2));           // bytes before column Q0 in the first dword
+                const uint8_t fb = reinterpret_cast<const uint8_t*>(smem + MFD_CFB)[slot * 128 + skew + tid];
+                reinterpret_cast<float*>(smem + MFD_CFL)[slot * 80 + tid] = (q >= 0 && q < A.ns && fb) ? 1.0f : 0.0f;
+            }
+        }
         MF_STAMP(0);
         lds_barrier();                           // everyone has read `raw`: the squares may overwrite it
         int ex = 0;
@@ -675,7 +864,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         }
         MF_STAMP(1);
         // ---- the previous tile's coefficients and stores
-        if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2);
+        if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
         MF_STAMP(6);
         lds_barrier();
 
@@ -739,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         MF_STAMP(2);
         lds_barrier();                           // all waves are done with the squares
         // ---- next tile's pixels -> `raw` while this tile's correlation runs
-        if (tile + (int)gridDim.x < A.n_tiles && !(A.dbg & 2)) fetch(tile + gridDim.x);
+        if (tile + (int)gridDim.x < A.n_tiles && !(A.dbg & 2)) fetch(tile + gridDim.x, slot ^ 1);
 
         MF_STAMP(3);
         // ---- cross term: 17 template rows x 4 column tiles, fragments of row s + 1 in flight during row s
@@ -793,9 +982,18 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         p_I0 = I0;
         p_J0 = J0;
         p_unscale = unscale;
+        p_slot = slot;
+        if constexpr (REG) p_hdr = *reinterpret_cast<const f4*>(A.rowtab + 4 * (size_t)min(I0 + wr0 + n, A.ms - 1));
+        slot ^= 1;
         pending = true;
     }
-    if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2);
+    if (pending) {
+        if constexpr (REG) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            lds_barrier();
+        }
+        emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
+    }
 }
 
 int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t stream, int* dense_path)
@@ -818,7 +1016,12 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
     const bool masked = A.mask_mode != 0;
     const bool dense_f32 = !masked && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr && !A.xcorr_only &&
                            A.ms > 0 && A.ns > 0;
-    if (dense_f32 && !getenv("CHROMOSIGHT_HIP_MFMA_V1")) {
+    // per-bin masks with the factorised tables in place (cs_api.cpp prepare_regular_mask), square template
+    const bool reg_f32 = A.mask_mode == 1 && A.reg_mode == 1 && A.km == A.kn && !A.sig_is_f64 && !A.xcorr_only && A.full &&
+                         A.ms > 0 && A.ns > 0 &&
+                         (!A.nobs.ptr || (A.nobs.layout == A.out.layout && A.nobs.ld == A.out.ld && A.nobs.band_lo == A.out.band_lo &&
+                                          A.nobs.band_w == A.out.band_w && A.nobs.row0 == A.out.row0));
+    if ((dense_f32 || reg_f32) && !getenv("CHROMOSIGHT_HIP_MFMA_V1")) {
         *dense_path = 1;
         MfmaDenseArgs D;
         D.sig = reinterpret_cast<const float*>(A.sig.ptr);
@@ -842,17 +1045,52 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.w_unscale = E.unscale[0];
         D.dbg = getenv("CHROMOSIGHT_HIP_MFMA_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_DBG")) : 0;
         D.ks = A.ks;
+        D.band_in = A.sig.layout == 1;
+        D.lo_in = A.sig.band_lo;
+        D.bw_in = A.sig.band_w;
+        D.band_out = A.out.layout == 1;
+        D.lo_out = A.out.band_lo;
+        D.out_lo = A.out_lo;
+        D.out_hi = A.out_hi;
+        D.nobs = reinterpret_cast<float*>(A.nobs.ptr);
+        D.w = A.w;
+        D.miss_col = A.miss_col;
+        D.rowtab = A.rowtab;
+        D.coltab = A.coltab;
+        D.fix_on = A.fix_on;
+        D.fix_hi_w = A.fix_hi_w;
+        D.fix_hi_d0 = A.fix_hi_d0;
+        D.fix_lo = A.fix_lo;
+        D.fix_hi = A.fix_hi;
+        D.fix_rows = A.fix_rows;
+        D.fix_cols = A.fix_cols;
+        D.fix_top = A.fix_top;
+        D.fix_bot0 = A.fix_bot0;
+        D.fix_width = A.fix_width;
+        D.fix_xband = A.fix_xband;
+        D.fix_xlo = A.fix_xlo;
+        D.fix_side = A.fix_side;
+        if (reg_f32) {
+            *dense_path = 2;
+            hipError_t e3 = hipFuncSetAttribute((const void*)corr_mfma_dense_kernel<false, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e3 != hipSuccess) return (int)e3;
+            const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+            const int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
+            hipLaunchKernelGGL((corr_mfma_dense_kernel<false, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            return (int)hipGetLastError();
+        }
         // 16-byte transfers and stores need aligned rows: base pointers, leading dimensions, the tile's
         // first staged column (64 bx - kw) and the row length all multiples of 4 elements
         const bool vec4 = ((uintptr_t)D.sig % 16 == 0) && ((uintptr_t)D.out % 32 == 0) && D.ld_in % 4 == 0 && D.ld_out % 4 == 0 &&
                           ((A.kn - 1) / 2) % 4 == 0 && D.ns % 4 == 0 && D.ns >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
-        const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true> : (const void*)corr_mfma_dense_kernel<false>;
+        const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true, false> : (const void*)corr_mfma_dense_kernel<false, false>;
         hipError_t e2 = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e2 != hipSuccess) return (int)e2;
         const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
         const int grid = (int)std::min<long long>(blocks, (long long)per_cu * A.n_cu);
-        if (vec4) hipLaunchKernelGGL(corr_mfma_dense_kernel<true>, dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
-        else hipLaunchKernelGGL(corr_mfma_dense_kernel<false>, dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
+        if (vec4) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, false>), dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
+        else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
         return (int)hipGetLastError();
     }
     const void* kern = masked ? (const void*)corr_mfma_kernel<true> : (const void*)corr_mfma_kernel<false>;

@@ -65,7 +65,8 @@ const char* cs_version(void);
 /* which correlation kernel served the last cs_normxcorr2 / cs_xcorr2 (or the map stage of
  * cs_detect_foci / cs_candidates) on this context: diagnostics, and what the tests use to make sure
  * the intended native path ran */
-enum { CS_KERNEL_NONE = 0, CS_KERNEL_GENERIC = 1, CS_KERNEL_STREAM = 2, CS_KERNEL_MFMA = 3, CS_KERNEL_MFMA_DENSE = 4 };
+enum { CS_KERNEL_NONE = 0, CS_KERNEL_GENERIC = 1, CS_KERNEL_STREAM = 2, CS_KERNEL_MFMA = 3, CS_KERNEL_MFMA_DENSE = 4,
+       CS_KERNEL_MFMA_REG = 5 };
 int cs_last_kernel(const cs_ctx* ctx);
 
 /* ---- device memory helpers (so a ctypes caller needs nothing but this library) ------ */

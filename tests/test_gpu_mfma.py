@@ -31,7 +31,7 @@ def f32_precision():
     chromosight_amd.set_precision(old)
 
 
-KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE = 1, 2, 3, 4
+KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE, KERNEL_MFMA_REG = 1, 2, 3, 4, 5
 
 
 def last_kernel():
@@ -144,6 +144,41 @@ def test_general_kernel_masks_bands_nobs(monkeypatch):
     assert last_kernel() == KERNEL_MFMA
     want, cond = c_oracle.normxcorr2_rows(inter, loops(), 0, 300, full=True, miss_row=mr, miss_col=mc)
     assert_parity(c.toarray(), want, cond, "f32", "mfma general inter")
+
+
+@pytest.mark.parametrize("n,md,ksize", [(900, 120, 17), (1500, 400, 17), (700, 60, 9), (400, 399, 13)])
+def test_tile_kernel_with_bin_masks(n, md, ksize, monkeypatch):
+    """CHROMOSIGHT_HIP_MFMA_REG=1: per-bin masks on the persistent tile kernel (factorised mask tables of
+    cs_mask_prep.hip, column flags x flagged-row cross term, edge / frame corrections), band in / band
+    out, coefficients and n_obs (through the p-values) against the oracle."""
+    monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "1")
+    rng = np.random.default_rng(n + md)
+    ii, jj = np.indices((n, n))
+    sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
+    sig[jj - ii > md + ksize] = 0
+    valid = np.flatnonzero(rng.random(n) > 0.04)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    sig[miss, :] = 0
+    sig[:, miss] = 0
+    sig = sig.astype(np.float32)             # float32 band in HBM: the tile kernel's input type
+    kern = loops() if ksize == 17 else rng.normal(size=(ksize, ksize)) + 0.3
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+    c, p = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                          missing_tol=0.75, pval=True)
+    assert last_kernel() == KERNEL_MFMA_REG
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, n, max_dist=md, sym_upper=True, full=True,
+                                          miss_row=miss, miss_col=miss)
+    band = (jj - ii >= 0) & (jj - ii <= md)
+    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma tile kernel, bin masks n={n} md={md} k={ksize}")
+    # same call on the streaming kernel: coefficients and p-values (n_obs) agree
+    monkeypatch.delenv("CHROMOSIGHT_HIP_MFMA_REG")
+    c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                            missing_tol=0.75, pval=True)
+    assert last_kernel() == KERNEL_STREAM
+    well = band & (cond >= 1e-3)
+    assert np.abs(c.toarray() - c2.toarray())[well].max() < 5e-6
+    assert np.abs(p.toarray() - p2.toarray())[well].max() < 5e-3
 
 
 def test_general_kernel_xcorr2_and_f64_containers(monkeypatch):

@@ -376,6 +376,7 @@ struct MfmaDenseArgs {
     int tiles_x, n_tiles;
     const uint4* frag;
     float w_unscale;
+    int xcd_order;           // 1: contiguous tile ranges per XCD
     int dbg;                 // diagnostics (CHROMOSIGHT_HIP_MFMA_DBG): skip 1 stores, 2 prefetch, 4 box sums, 8 cross term
     KernelStats<float> ks;
     // ---- REG instances: per-bin missing masks through the factorised tables of cs_mask_prep.hip, any
@@ -776,9 +777,22 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
 #pragma unroll
     for (int c = 0; c < 4; ++c) p_acc[c] = p_S1[c] = p_S2[c] = zero4;
 
-    int tile = blockIdx.x;
-    if (tile < A.n_tiles) fetch(tile, 0);
-    for (; tile < A.n_tiles; tile += gridDim.x) {
+    // Tile sequence of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs (own L2 each): XCD x
+    // takes the tiles [x n / 8, (x + 1) n / 8) and its workgroups walk that range side by side, so the 16
+    // halo rows / columns neighbouring tiles share are re-read from the XCD's own L2.
+    int tile, tile_end, tile_step;
+    if (A.xcd_order && gridDim.x % 8 == 0) {
+        const int x = blockIdx.x & 7, per = (A.n_tiles + 7) / 8;
+        tile = x * per + (blockIdx.x >> 3);
+        tile_end = min(A.n_tiles, (x + 1) * per);
+        tile_step = gridDim.x >> 3;
+    } else {
+        tile = blockIdx.x;
+        tile_end = A.n_tiles;
+        tile_step = gridDim.x;
+    }
+    if (tile < tile_end) fetch(tile, 0);
+    for (; tile < tile_end; tile += tile_step) {
         int I0, J0;
         tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
@@ -928,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         MF_STAMP(2);
         lds_barrier();                           // all waves are done with the squares
         // ---- next tile's pixels -> `raw` while this tile's correlation runs
-        if (tile + (int)gridDim.x < A.n_tiles && !(A.dbg & 2)) fetch(tile + gridDim.x, slot ^ 1);
+        if (tile + tile_step < tile_end && !(A.dbg & 2)) fetch(tile + tile_step, slot ^ 1);
 
         MF_STAMP(3);
         // ---- cross term: 17 template rows x 4 column tiles, fragments of row s + 1 in flight during row s
@@ -1044,6 +1058,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.frag = E.frag;
         D.w_unscale = E.unscale[0];
         D.dbg = getenv("CHROMOSIGHT_HIP_MFMA_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_DBG")) : 0;
+        D.xcd_order = getenv("CHROMOSIGHT_HIP_NO_XCD") ? 0 : 1;
         D.ks = A.ks;
         D.band_in = A.sig.layout == 1;
         D.lo_in = A.sig.band_lo;

@@ -7,6 +7,8 @@ handful of 1-D HDF5 datasets.  They are decoded with the HDF5 command line tool 
 dump of one dataset, any chunking / compression), located through $CHROMOSIGHT_H5DUMP, PATH or
 /opt/conda/bin.  Multi-resolution files: `path::/resolutions/2000`.
 """
+import csv
+import json
 import os
 import pathlib
 import re
@@ -93,3 +95,61 @@ def load_cool(uri, balance="weight"):
         if cool[key].size and cool[key].max() < 2 ** 31:
             cool[key] = cool[key].astype(np.int32)
     return cool
+
+
+# ------------------------------------------------------------------------------------------------
+# output side of `detect` / `quantify`: the files the reference writes
+# ------------------------------------------------------------------------------------------------
+def check_prefix_dir(prefix):
+    """The parent directory of an output prefix must exist (reference io.py:338-342: OSError)."""
+    parent = os.path.dirname(prefix)
+    if parent and not os.path.isdir(parent):
+        raise OSError(f"Directory {parent} does not exist.")
+
+
+def write_patterns(coords, output_prefix, dec=10):
+    """<prefix>.tsv of a pattern table (reference io.py:208-226): tab separated, no index, floats with
+    `dec` decimals -- byte-comparable with the reference's output for the same table."""
+    coords.to_csv(output_prefix + ".tsv", sep="\t", index=False, float_format=f"%.{int(dec)}f")
+
+
+def save_windows(windows, output_prefix, fmt="json"):
+    """The windows around the patterns, stacked on axis 0 (reference io.py:229-256): <prefix>.npy, or
+    <prefix>.json = {"0": [[...]], "1": ...} (NaN written as NaN, as json.dump does)."""
+    windows = np.asarray(windows)
+    if fmt == "npy":
+        np.save(output_prefix + ".npy", windows)
+    elif fmt == "json":
+        with open(output_prefix + ".json", "w") as handle:
+            json.dump({k: w.tolist() for k, w in enumerate(windows)}, handle, indent=4)
+    else:
+        raise ValueError("window format must be either npy or json.")
+
+
+BED2D_COLUMNS = ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]
+
+
+def load_bed2d(path):
+    """First six columns of a 2-D BED file as a DataFrame (reference io.py:284-326): a header line is
+    detected (csv.Sniffer, like the reference) or the standard names are given; chromosome names are
+    strings; intra-chromosomal pairs are oriented so that anchor 1 is the left one.  Reads the output of
+    `detect` as the input of `quantify`."""
+    import pandas as pd
+    with open(path) as handle:
+        has_header = csv.Sniffer().has_header(handle.read(65536))
+    if has_header:
+        bed = pd.read_csv(path, sep="\t", header=0, usecols=range(6))
+    else:
+        bed = pd.read_csv(path, sep="\t", header=None, names=BED2D_COLUMNS, usecols=range(6))
+    bed = bed.copy()
+    c1, c2 = bed.columns[0], bed.columns[3]
+    bed[c1] = bed[c1].astype(str)
+    bed[c2] = bed[c2].astype(str)
+    s1, e1, s2, e2 = bed.columns[1], bed.columns[2], bed.columns[4], bed.columns[5]
+    flip = ((bed[s2] < bed[s1]) & (bed[c1] == bed[c2])).to_numpy()
+    if flip.any():
+        a = bed.loc[flip, [s1, e1]].to_numpy()
+        b = bed.loc[flip, [s2, e2]].to_numpy()
+        bed.loc[flip, [s1, e1]] = b
+        bed.loc[flip, [s2, e2]] = a
+    return bed

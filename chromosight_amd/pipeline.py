@@ -484,12 +484,14 @@ def sub_matrices(dcool, inter):
     return [(a, b) for a in range(dcool.n_chrom) for b in range(dcool.n_chrom) if a == b or (a < b and inter)]
 
 
-def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, inter=False, subsample=None, seed=0):
+def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, inter=False, subsample=None, seed=0,
+           return_windows=False):
     """`chromosight detect` (balanced matrix) on a decoded cool (dict) or a DeviceCool; options
     --inter, --smooth-trend, --tsvd, --subsample (seeded), --iterations through the config.  Every
     block is staged once in HBM (distance law, detrend, band / median scaling) and stays resident
     across templates and iterations; each (block, template) is one native call.
-    Returns the output table (same columns and row order as the reference's <prefix>.tsv)."""
+    Returns the output table (same columns and row order as the reference's <prefix>.tsv); with
+    return_windows also the windows of its rows (what the reference saves as <prefix>.json / .npy)."""
     dcool = cool if isinstance(cool, DeviceCool) else DeviceCool(cool)
     if subsample is not None:
         dcool = dcool.subsampled(subsample, seed=seed, inter=inter)
@@ -502,7 +504,7 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
     pairs = sub_matrices(dcool, inter)
     blocks = [dcool.stage_intra(a, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=True) if a == b
               else dcool.stage_inter(a, b, resident=True) for a, b in pairs]
-    all_coords = []
+    all_coords, all_windows = [], []
     for kernel_id, kernel in enumerate(kernel_config["kernels"]):
         for it in range(kernel_config["max_iterations"]):
             tables, windows = [], []
@@ -522,19 +524,39 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
             coords["kernel_id"] = kernel_id
             coords["iteration"] = it
             all_coords.append(coords)
-            kernel = cid.pileup_patterns(np.concatenate(windows, axis=0))
+            kernel_windows = np.concatenate(windows, axis=0)
+            all_windows.append(kernel_windows)
+            kernel = cid.pileup_patterns(kernel_windows)
     if not all_coords:
-        return pd.DataFrame(columns=OUTPUT_COLUMNS)
+        empty = pd.DataFrame(columns=OUTPUT_COLUMNS)
+        return (empty, np.zeros((0,) + np.shape(kernel_config["kernels"][0]))) if return_windows else empty
     coords = pd.concat(all_coords, axis=0).reset_index(drop=True)
-    return postprocess(coords, kernel_config, binsize, off, names, dcool.bin_start, dcool.bin_end)
+    # windows of different templates may differ in size only across configs, never inside one
+    windows = np.concatenate(all_windows, axis=0) if return_windows else None
+    return postprocess(coords, kernel_config, binsize, off, names, dcool.bin_start, dcool.bin_end, windows=windows)
 
 
-def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end):
+def detect_to_files(cool, kernel_config, prefix, win_fmt="json", dec=10, **options):
+    """detect + the two files `chromosight detect` leaves behind (cli/chromosight.py:873-881):
+    <prefix>.tsv and <prefix>.json | .npy.  Returns the table."""
+    from . import io as cio
+    cio.check_prefix_dir(prefix)
+    table, windows = detect(cool, kernel_config, return_windows=True, **options)
+    cio.write_patterns(table, prefix, dec=dec)
+    cio.save_windows(windows, prefix, fmt=win_fmt)
+    return table
+
+
+def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end, windows=None):
     """cmd_detect after the per-block loop (cli/chromosight.py:806-871): neighbour removal, bins ->
-    genomic coordinates, min_dist and NaN-p filters, Benjamini-Hochberg q-values, column order."""
+    genomic coordinates, min_dist and NaN-p filters, Benjamini-Hochberg q-values, column order.
+    `windows` (one per row of coords) are filtered alongside and returned as a second value."""
     n_chrom = len(names)
     separation = max(int(kernel_config["min_separation"] // binsize), 1)
-    coords = coords.loc[cid.remove_neighbours(coords, win_size=separation), :].copy()
+    distinct = cid.remove_neighbours(coords, win_size=separation)
+    coords = coords.loc[distinct, :].copy()
+    if windows is not None:
+        windows = windows[np.asarray(distinct)]
     # bins -> genomic coordinates
     bin_chrom = np.repeat(np.arange(n_chrom), np.diff(off))
     name_arr = np.asarray(names, dtype=object)
@@ -545,10 +567,13 @@ def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end):
         coords[f"end{tag}"] = np.asarray(bin_end)[b]
     coords = coords.reset_index(drop=True)
     too_close = (coords.chrom1 == coords.chrom2) & (np.abs(coords.start2 - coords.start1) < kernel_config["min_dist"])
-    coords = coords.loc[~too_close, :]
-    coords = coords.loc[~coords.pvalue.isnull(), :]
+    keep = (~too_close & ~coords.pvalue.isnull()).to_numpy()
+    coords = coords.loc[keep, :].copy()
     coords["qvalue"] = fdr_correction(coords["pvalue"])
-    return coords.loc[:, OUTPUT_COLUMNS].reset_index(drop=True)
+    table = coords.loc[:, OUTPUT_COLUMNS].reset_index(drop=True)
+    if windows is not None:
+        return table, windows[keep]
+    return table
 
 
 def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=None, seed=0, smooth=False,

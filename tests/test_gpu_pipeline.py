@@ -63,6 +63,49 @@ def test_committed_outputs(cool, name, overrides):
     assert np.allclose(got["qvalue"], ref["qvalue"], rtol=0, atol=2e-10)
 
 
+def test_written_files_match_reference_bytes(cool, tmp_path):
+    """detect -> chromosight_amd.io.write_patterns: the .tsv the reference committed, line by line; a
+    score / p-value may differ in its 10th decimal (1 unit of the last printed digit), nothing else may."""
+    from conftest import GOLDEN
+    from chromosight_amd import io as cio
+    total = exact = 0
+    for name, overrides in [("example_loops", dict(pattern="loops", min_dist=8000, max_dist=50000, pearson=0.35)),
+                            ("example_borders", dict(pattern="borders")), ("example_hairpins", dict(pattern="hairpins"))]:
+        overrides = dict(overrides)
+        cfg = copy.deepcopy(getattr(ck, overrides.pop("pattern")))
+        cfg.update(overrides)
+        table = pipeline.detect_to_files(cool, cfg, str(tmp_path / name), win_fmt="npy")
+        wins = np.load(tmp_path / f"{name}.npy")
+        assert wins.shape == (len(table),) + np.shape(cfg["kernels"][0])
+        assert np.isfinite(wins).any(axis=(1, 2)).all()           # every kept pattern has a window with data
+        got = (tmp_path / f"{name}.tsv").read_text().splitlines()
+        ref = (GOLDEN / f"{name}.tsv").read_text().splitlines()
+        assert len(got) == len(ref) and got[0] == ref[0]
+        for a, b in zip(got[1:], ref[1:]):
+            total += 1
+            if a == b:
+                exact += 1
+                continue
+            fa, fb = a.split("\t"), b.split("\t")
+            assert fa[:10] == fb[:10], (a, b)
+            for x, y in zip(fa[10:], fb[10:]):
+                assert abs(float(x) - float(y)) <= 1.5e-10, (a, b)
+    print(f"{exact} of {total} lines byte-identical to the reference's committed .tsv files")
+    assert exact >= 0.95 * total
+    # quantify reads detect's output back (load_bed2d), windows are written in both formats
+    bed = cio.load_bed2d(str(tmp_path / "example_loops.tsv"))
+    n_loops = len((GOLDEN / "example_loops.tsv").read_text().splitlines()) - 1
+    assert list(bed.columns) == cio.BED2D_COLUMNS and len(bed) == n_loops
+    wins = np.arange(2 * 3 * 3, dtype=float).reshape(2, 3, 3)
+    wins[0, 0, 0] = np.nan
+    cio.save_windows(wins, str(tmp_path / "w"), fmt="json")
+    cio.save_windows(wins, str(tmp_path / "w"), fmt="npy")
+    import json
+    back = json.loads((tmp_path / "w.json").read_text())
+    assert sorted(back) == ["0", "1"] and back["1"] == wins[1].tolist()
+    assert np.array_equal(np.load(tmp_path / "w.npy"), wins, equal_nan=True)
+
+
 def test_c5_yeast_quantify_inter(golden):
     """Config C5: quantify with the 11x11 (resized) borders templates on the real 17-chromosome
     yeast map, intra blocks at the cohesin-peak pairs and inter blocks at seeded positions; scores

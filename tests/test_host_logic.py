@@ -356,3 +356,38 @@ def test_distance_law_other_reducers_on_host():
         v = diag[diag > 0]
         assert (np.isnan(got[d]) and v.size == 0) or got[d] == np.median(v)
     assert np.all(got[13:] == 0)
+
+
+def test_writers_and_bed2d(tmp_path):
+    """chromosight_amd.io output side (reference io.py:208-326): formats and the bed2d conventions."""
+    import json
+    import pandas as pd
+    from chromosight_amd import io as cio
+    table = pd.DataFrame({"chrom1": ["chr1", "chr2"], "start1": [1000, 5000], "end1": [2000, 6000],
+                          "chrom2": ["chr1", "chr2"], "start2": [34000, 3000], "end2": [35000, 4000],
+                          "bin1": [1, 5], "bin2": [34, 3], "kernel_id": [0, 0], "iteration": [0, 0],
+                          "score": [0.48979314123, 1 / 3], "pvalue": [1e-10, 0.5], "qvalue": [1.2e-10, 0.5]})
+    cio.write_patterns(table, str(tmp_path / "p"))
+    lines = (tmp_path / "p.tsv").read_text().splitlines()
+    assert lines[0].split("\t") == list(table.columns)
+    assert lines[1].split("\t")[-3:] == ["0.4897931412", "0.0000000001", "0.0000000001"]
+    assert lines[2].split("\t")[-3:] == ["0.3333333333", "0.5000000000", "0.5000000000"]
+    cio.write_patterns(table, str(tmp_path / "q"), dec=3)
+    assert (tmp_path / "q.tsv").read_text().splitlines()[2].endswith("0.333\t0.500\t0.500")
+    # header detected; the second pair is stored right anchor first and comes back oriented
+    bed = cio.load_bed2d(str(tmp_path / "p.tsv"))
+    assert list(bed.columns) == cio.BED2D_COLUMNS
+    assert bed.iloc[1].tolist() == ["chr2", 3000, 4000, "chr2", 5000, 6000]
+    # no header, numeric chromosome names become strings, inter-chromosomal pairs are left alone
+    (tmp_path / "n.bed2d").write_text("1\t100\t200\t1\t50\t60\n1\t900\t1000\t2\t10\t20\n")
+    bed = cio.load_bed2d(str(tmp_path / "n.bed2d"))
+    assert bed.iloc[0].tolist() == ["1", 50, 60, "1", 100, 200]
+    assert bed.iloc[1].tolist() == ["1", 900, 1000, "2", 10, 20]
+    wins = np.arange(8.0).reshape(2, 2, 2)
+    cio.save_windows(wins, str(tmp_path / "w"))
+    assert json.loads((tmp_path / "w.json").read_text()) == {"0": [[0.0, 1.0], [2.0, 3.0]], "1": [[4.0, 5.0], [6.0, 7.0]]}
+    with pytest.raises(ValueError):
+        cio.save_windows(wins, str(tmp_path / "w"), fmt="csv")
+    with pytest.raises(OSError):
+        cio.check_prefix_dir(str(tmp_path / "missing_dir" / "prefix"))
+    cio.check_prefix_dir(str(tmp_path / "prefix"))

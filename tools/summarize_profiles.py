@@ -21,7 +21,7 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in ("c2", "c3", "c3k", "c4p", "c4", "dense16384", "c2_f64", "c2_nosym"):
+for name in ("c2", "c3", "c3k", "c4p", "c4", "dense16384", "c2_f64", "c2_nosym", "c2_stream", "c3k_mfma_reg", "c4p_mfma_reg"):
     f = os.path.join(src, f"bench_{name}.json")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_bench_{name}.json"))
@@ -41,13 +41,18 @@ for u in ("coexec", "fma_rate"):
 
 
 def per_dispatch(path, kernel_substr):
+    """Mean per dispatch of every counter of the kernels whose name contains (one of) kernel_substr."""
+    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
     acc = collections.defaultdict(list)
     if not path:
         return {}
     for r in csv.DictReader(open(path)):
-        if kernel_substr in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in subs):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+CORR_KERNELS = ("corr_stream_kernel", "corr_mfma_dense_kernel")      # the dominant kernel of a correlation call
 
 
 summary = {"note": "per-dispatch means from rocprofv3 --pmc passes (one counter group per pass) on "
@@ -63,8 +68,14 @@ f = factor if factor else 2.0
 for w, key in (("c2", "c2_4096_f32"), ("c3k", "c3k_band_50000x234"), ("c4p", "c4p_band_200000x1001")):
     rec = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        rec.update(per_dispatch(find(f"pmc_{w}_{c}/**/*counter_collection.csv"), "corr_stream_kernel"))
-    rec.update(per_dispatch(find(f"pmc_{w}_sq/**/*counter_collection.csv"), "corr_stream_kernel"))
+        rec.update(per_dispatch(find(f"pmc_{w}_{c}/**/*counter_collection.csv"), CORR_KERNELS))
+    rec.update(per_dispatch(find(f"pmc_{w}_sq/**/*counter_collection.csv"), CORR_KERNELS))
+    if w == "c2":
+        rec.update(per_dispatch(find("pmc_c2_mfma/**/*counter_collection.csv"), CORR_KERNELS))
+        if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") and rec.get("GRBM_GUI_ACTIVE"):
+            # busy cycles are summed over the 1024 SIMDs, GUI_ACTIVE over the 8 XCDs
+            rec["mfma_pipe_busy_frac"] = (rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (rec["GRBM_GUI_ACTIVE"] / 8.0)
+        rec["kernel"] = "corr_mfma_dense_kernel (default for the dense map) -- see the kernel trace"
     if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
         rec["hbm_bytes_per_dispatch"] = (rec["FETCH_SIZE"] * f + rec["WRITE_SIZE"]) * 1024.0
         rec["hbm_bytes_note"] = (f"FETCH_SIZE x {f:.3f} (calibration) + WRITE_SIZE, KiB -> bytes")

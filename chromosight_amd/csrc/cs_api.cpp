@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -43,6 +45,15 @@ struct cs_ctx {
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
+    // cs_normxcorr2_host: device staging of the map, pinned bounce buffer of the float32 result, three
+    // streams (upload / kernels / download) and one event pair per row slab, all grow-only
+    void* d_host_in = nullptr;
+    void* d_host_out = nullptr;
+    size_t d_host_bytes = 0;
+    void* h_bounce = nullptr;
+    size_t h_bounce_bytes = 0;
+    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
+    std::vector<hipEvent_t> ev_up, ev_run, ev_down;
 };
 
 namespace {
@@ -673,8 +684,8 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.row_end = p->ms;
     if (p->row_end > p->row_begin) {
         if (p->row_begin < 0 || p->row_end > p->ms) return fail(ctx, CS_ERR_INVALID, "row window outside the matrix");
-        if ((p->row_begin != 0 || p->row_end != p->ms) && (!p->full || p->mask_mode == CS_MASK_EXPLICIT))
-            return fail(ctx, CS_ERR_UNSUPPORTED, "row windows need full = 1 and per-bin masks or none");
+        if ((p->row_begin != 0 || p->row_end != p->ms) && p->mask_mode == CS_MASK_EXPLICIT)
+            return fail(ctx, CS_ERR_UNSUPPORTED, "row windows need per-bin masks or none");
         A.row_begin = p->row_begin;
         A.row_end = p->row_end;
     }
@@ -719,6 +730,13 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->d_host_in) (void)hipFree(ctx->d_host_in);
+    if (ctx->d_host_out) (void)hipFree(ctx->d_host_out);
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    for (hipStream_t st : {ctx->s_up, ctx->s_run, ctx->s_down})
+        if (st) (void)hipStreamDestroy(st);
+    for (auto* v : {&ctx->ev_up, &ctx->ev_run, &ctx->ev_down})
+        for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -861,6 +879,155 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         return launch_corr<float>(ctx, A, stream, allow_fast);
     }
     return fail(ctx, CS_ERR_INVALID, "bad compute dtype");
+}
+
+// Host map in, host map out, pipelined over PCIe in row slabs (see the header).
+int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const cs_kernel* kernel,
+                       const cs_normxcorr2_params* p, void* h_out, int32_t out_dtype, int64_t ld_out)
+{
+    CS_ENTER(ctx);
+    if (!p || !h_signal || !h_out || !kernel) return fail(ctx, CS_ERR_INVALID, "null argument");
+    if (p->mask_mode != CS_MASK_NONE) return fail(ctx, CS_ERR_UNSUPPORTED, "cs_normxcorr2_host takes unmasked maps");
+    if (p->compute_dtype != CS_F32) return fail(ctx, CS_ERR_UNSUPPORTED, "cs_normxcorr2_host computes in float32");
+    if (out_dtype != CS_F32 && out_dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "bad output dtype");
+    const int ms = p->ms, ns = p->ns;
+    if (ms <= 0 || ns <= 0 || ld_in < ns || ld_out < ns) return fail(ctx, CS_ERR_INVALID, "bad geometry");
+    const int km = kernel->km;
+    const int kh = (km - 1) / 2, kt = km - 1 - kh;          // rows a window reaches above / below its pixel
+    const int64_t ld = ((int64_t)ns + 15) / 16 * 16;
+    const size_t map_bytes = (size_t)ms * (size_t)ld * 4;
+    if (map_bytes > ctx->d_host_bytes) {
+        CS_HIP(ctx, hipDeviceSynchronize());
+        if (ctx->d_host_in) CS_HIP(ctx, hipFree(ctx->d_host_in));
+        if (ctx->d_host_out) CS_HIP(ctx, hipFree(ctx->d_host_out));
+        ctx->d_host_in = ctx->d_host_out = nullptr;
+        ctx->d_host_bytes = 0;
+        CS_HIP(ctx, hipMalloc(&ctx->d_host_in, map_bytes));
+        CS_HIP(ctx, hipMalloc(&ctx->d_host_out, map_bytes));
+        ctx->d_host_bytes = map_bytes;
+    }
+    const size_t bounce_bytes = (size_t)ms * (size_t)ns * 4;
+    if (bounce_bytes > ctx->h_bounce_bytes) {
+        if (ctx->h_bounce) CS_HIP(ctx, hipHostFree(ctx->h_bounce));
+        ctx->h_bounce = nullptr;
+        ctx->h_bounce_bytes = 0;
+        CS_HIP(ctx, hipHostMalloc(&ctx->h_bounce, bounce_bytes, hipHostMallocDefault));
+        ctx->h_bounce_bytes = bounce_bytes;
+    }
+    if (!ctx->s_up) {
+        CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+        CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_run, hipStreamNonBlocking));
+        CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
+    }
+    // slabs of ~1/12 of the map, whole 64-row tiles
+    int rows = std::max(64, ((ms + 11) / 12 + 63) / 64 * 64);
+    const int n_slabs = (ms + rows - 1) / rows;
+    while ((int)ctx->ev_up.size() < n_slabs) {
+        hipEvent_t a, b, c;
+        CS_HIP(ctx, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        CS_HIP(ctx, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        CS_HIP(ctx, hipEventCreateWithFlags(&c, hipEventDisableTiming));
+        ctx->ev_up.push_back(a);
+        ctx->ev_run.push_back(b);
+        ctx->ev_down.push_back(c);
+    }
+    cs_matrix m_in{ctx->d_host_in, CS_F32, CS_LAYOUT_DENSE, ld, 0, 0, 0};
+    cs_matrix m_out{ctx->d_host_out, CS_F32, CS_LAYOUT_DENSE, ld, 0, 0, 0};
+    // warm the template upload (it synchronises) before the pipeline starts
+    {
+        cs_normxcorr2_params p0 = *p;
+        p0.row_begin = 0;
+        p0.row_end = 0;
+        cs::CorrArgs<float> A;
+        int rc0 = build_args<float>(ctx, ctx->s_run, &m_in, kernel, &p0, &A);
+        if (rc0) return rc0;
+    }
+    // ---- host side of the drain: workers convert / copy each slab out of the bounce buffer as soon as
+    //      its download has completed
+    const int n_workers = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> workers;
+    std::vector<int> worker_rc(n_workers, 0);
+    // slabs whose download has been ENQUEUED (an event that was never recorded, or still carries the
+    // previous call's record, would let hipEventSynchronize return at once); -1 = give up
+    std::atomic<int> enqueued{0};
+    const float* bounce = reinterpret_cast<const float*>(ctx->h_bounce);
+    const int device = ctx->device;
+    for (int w = 0; w < n_workers; ++w) {
+        workers.emplace_back([=, &worker_rc, &enqueued]() {
+            (void)hipSetDevice(device);
+            for (int k = 0; k < n_slabs; ++k) {
+                int seen;
+                while ((seen = enqueued.load(std::memory_order_acquire)) <= k && seen >= 0) std::this_thread::yield();
+                if (seen < 0) return;
+                if (hipEventSynchronize(ctx->ev_down[k]) != hipSuccess) {
+                    worker_rc[w] = 1;
+                    return;
+                }
+                const int r0 = k * rows, r1 = std::min(ms, r0 + rows);
+                const int span = r1 - r0, lo = r0 + (int)((long long)span * w / n_workers),
+                          hi = r0 + (int)((long long)span * (w + 1) / n_workers);
+                for (int r = lo; r < hi; ++r) {
+                    const float* src = bounce + (size_t)r * ns;
+                    if (out_dtype == CS_F64) {
+                        double* dst = reinterpret_cast<double*>(h_out) + (size_t)r * ld_out;
+                        for (int c = 0; c < ns; ++c) dst[c] = (double)src[c];
+                    } else {
+                        std::memcpy(reinterpret_cast<float*>(h_out) + (size_t)r * ld_out, src, (size_t)ns * 4);
+                    }
+                }
+            }
+        });
+    }
+    // ---- enqueue: upload slab k + 1, kernel of slab k (its windows reach into slab k + 1), download slab k
+    int rc = CS_OK;
+    auto upload = [&](int k) -> hipError_t {
+        const int r0 = k * rows, r1 = std::min(ms, r0 + rows);
+        hipError_t e;
+        if (ld_in == ns && ld == ns)
+            e = hipMemcpyAsync((char*)ctx->d_host_in + (size_t)r0 * ld * 4, h_signal + (size_t)r0 * ld_in,
+                               (size_t)(r1 - r0) * ns * 4, hipMemcpyHostToDevice, ctx->s_up);
+        else
+            e = hipMemcpy2DAsync((char*)ctx->d_host_in + (size_t)r0 * ld * 4, (size_t)ld * 4, h_signal + (size_t)r0 * ld_in,
+                                 (size_t)ld_in * 4, (size_t)ns * 4, (size_t)(r1 - r0), hipMemcpyHostToDevice, ctx->s_up);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(ctx->ev_up[k], ctx->s_up);
+    };
+    hipError_t he = upload(0);
+    for (int k = 0; k < n_slabs && he == hipSuccess && rc == CS_OK; ++k) {
+        if (k + 1 < n_slabs) he = upload(k + 1);
+        if (he != hipSuccess) break;
+        const int r0 = k * rows, r1 = std::min(ms, r0 + rows);
+        (void)kh;
+        (void)kt;
+        he = hipStreamWaitEvent(ctx->s_run, ctx->ev_up[std::min(k + 1, n_slabs - 1)], 0);
+        if (he != hipSuccess) break;
+        cs_normxcorr2_params pk = *p;
+        pk.row_begin = r0;
+        pk.row_end = r1;
+        rc = cs_normxcorr2(ctx, ctx->s_run, &m_in, kernel, &pk, &m_out, nullptr);
+        if (rc != CS_OK) break;
+        he = hipEventRecord(ctx->ev_run[k], ctx->s_run);
+        if (he != hipSuccess) break;
+        he = hipStreamWaitEvent(ctx->s_down, ctx->ev_run[k], 0);
+        if (he != hipSuccess) break;
+        if (ld == ns)
+            he = hipMemcpyAsync((char*)ctx->h_bounce + (size_t)r0 * ns * 4, (char*)ctx->d_host_out + (size_t)r0 * ld * 4,
+                                (size_t)(r1 - r0) * ns * 4, hipMemcpyDeviceToHost, ctx->s_down);
+        else
+            he = hipMemcpy2DAsync((char*)ctx->h_bounce + (size_t)r0 * ns * 4, (size_t)ns * 4,
+                                  (char*)ctx->d_host_out + (size_t)r0 * ld * 4, (size_t)ld * 4, (size_t)ns * 4,
+                                  (size_t)(r1 - r0), hipMemcpyDeviceToHost, ctx->s_down);
+        if (he != hipSuccess) break;
+        he = hipEventRecord(ctx->ev_down[k], ctx->s_down);
+        if (he == hipSuccess) enqueued.store(k + 1, std::memory_order_release);
+    }
+    if (he != hipSuccess || rc != CS_OK) enqueued.store(-1, std::memory_order_release);     // release the workers
+    for (auto& t : workers) t.join();
+    if (rc != CS_OK) return rc;
+    if (he != hipSuccess) return fail(ctx, CS_ERR_HIP, "pipelined call failed: %s", hipGetErrorString(he));
+    for (int w = 0; w < n_workers; ++w)
+        if (worker_rc[w]) return fail(ctx, CS_ERR_HIP, "download wait failed");
+    return CS_OK;
 }
 
 int cs_xcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, int32_t ms, int32_t ns,

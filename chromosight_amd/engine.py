@@ -87,6 +87,19 @@ def run_normxcorr2(dev, sig, shape, kspec, out, *, full, sym_upper, max_dist, ma
     return params
 
 
+def run_normxcorr2_host(dev, signal, kspec, *, full, sym_upper, max_dist, missing_tol=0.75, out_dtype=np.float64):
+    """Dense float32 host map -> coefficient map on the host through cs_normxcorr2_host (upload, kernel and
+    download of row slabs overlap; float64 widening on the library's host threads)."""
+    ms, ns = signal.shape
+    params = _corr_params((ms, ns), kspec, full, sym_upper, max_dist, MASK_NONE, None, None, None, missing_tol, CS_F32)
+    # result pages from the device's pool of page-locked buffers: a fresh 128 MB numpy array would be
+    # page-faulted in by the widening threads (measured: 7 ms of an 11 ms call)
+    out = dev.pinned_result((ms, ns), out_dtype)
+    dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, signal.ctypes.data, ns, C.byref(kspec.struct), C.byref(params),
+                                          out.ctypes.data, _lib.np_dtype_code(out_dtype), ns))
+    return out
+
+
 def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist, mask_mode=MASK_NONE,
                 miss_row=None, miss_col=None, mask=None, missing_tol=0.75, stream=None):
     """float64 coefficients (and present-pixel counts) at the given pixels."""

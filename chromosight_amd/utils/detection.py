@@ -200,6 +200,14 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         raise ValueError("cannot have kernel bigger than signal")
     dev = get_device()
     kspec = engine.KernelSpec(kernel, tsvd)
+    if (missing_mask is None and isinstance(signal, np.ndarray) and signal.dtype == np.float32 and signal.ndim == 2
+            and signal.flags.c_contiguous and engine.get_precision() == "f32" and signal.size >= (1 << 20)):
+        # large host map in, host map out: one native call that pipelines the map over PCIe in row slabs
+        # (cs_normxcorr2_host); the float64 array the reference returns is filled by the library's threads
+        corr = engine.run_normxcorr2_host(dev, signal, kspec, full=full, sym_upper=sym_upper, max_dist=max_dist,
+                                          missing_tol=missing_tol)
+        pvals = cus.corr_to_pval(corr.ravel(), km * kn).reshape(corr.shape) if pval else None
+        return corr, pvals
     mask_range = engine.diag_range(missing_mask) if missing_mask is not None else None
     st = _Staged(dev, signal, (km, kn), sym_upper, full, extra_range=mask_range)
     mask_buf = None

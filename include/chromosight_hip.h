@@ -128,7 +128,8 @@ typedef struct {
     int32_t compute_dtype;   /* CS_F32 or CS_F64 arithmetic                             */
     double xcorr_threshold;  /* 1e-4: xcorr2's zeroing threshold (detection.py:595,716)  */
     double denom_eps;        /* 1e-10 (detection.py:1088)                                */
-    int32_t row_begin, row_end; /* produce the output rows row_begin <= i < row_end only (0, 0 = all).
+    int32_t row_begin, row_end; /* produce the output rows row_begin <= i < row_end only (0, 0 = all;
+                                not with CS_MASK_EXPLICIT).
                                 The geometry (frame, masks, matrix edges) stays that of the ms x ns
                                 matrix; `signal` must hold the rows row_begin - (km-1)/2 ..
                                 row_end + (km-1)/2 - 1 that exist (cs_matrix.row0 says where its buffer
@@ -146,6 +147,17 @@ typedef struct {
 int cs_normxcorr2(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
                   const cs_normxcorr2_params* params, const cs_matrix* out_corr,
                   const cs_matrix* out_nobs);
+
+/* The same map call for a caller whose map lives in HOST memory (what chromosight's Python surface
+ * hands over: detection.py:807 takes and returns numpy / scipy containers): float32 ms x ns map in
+ * (row pitch ld_in elements), float32 or float64 coefficient map out (ld_out), no mask, float32
+ * arithmetic.  The map crosses PCIe in row slabs: upload of slab k + 1, the kernel on the row window of
+ * slab k (params->row_begin / row_end are set by the call) and the download of slab k - 1 overlap on three
+ * streams; the float32 result is widened to float64 on host threads while later slabs are still in
+ * flight (the link moves 4 bytes per pixel each way instead of 4 + 8).  Synchronous.  Device staging
+ * buffers, the pinned bounce buffer, streams and events belong to the context (grow-only). */
+int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const cs_kernel* kernel,
+                       const cs_normxcorr2_params* params, void* h_out, int32_t out_dtype, int64_t ld_out);
 
 /* Plain cross-correlation: centre-aligned, zero on the (k-1)/2 margins, |v| < threshold -> 0
  * (detection.py:716-722, 797-803).  `h_weights` = km*kn float64 host values. */

@@ -227,3 +227,35 @@ def test_dense_kernel_row_windows():
         run(CsMatrix(d_slab.ptr, code, LAYOUT_DENSE, cols, 0, 0, ra), CsMatrix(d_out.ptr, code, LAYOUT_DENSE, cols, 0, 0, a), (a, b))
         got = d_out.download().reshape(b - a, cols)
         assert np.abs(got - full[a:b]).max() <= 2e-6, (a, b)
+
+
+@pytest.mark.parametrize("shape,full", [((1500, 1111), True), ((1029, 1024), False), ((700, 2100), True)])
+def test_host_pipelined_call(shape, full):
+    """cs_normxcorr2_host: host map in, host map out, row slabs pipelined over PCIe -- equal to the oracle,
+    with strided inputs / outputs and both output types; the Python surface takes this route for large
+    float32 arrays."""
+    dev = get_device()
+    rng = np.random.default_rng(shape[0])
+    ms, ns = shape
+    kspec = engine.KernelSpec(loops(), None)
+    backing = rng.gamma(2.0, 1.0, size=(ms, ns + 5)).astype(np.float32)
+    sig = backing[:, :ns]                                    # row pitch ns + 5
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), loops(), 0, ms, full=full)
+    params = engine._corr_params((ms, ns), kspec, full, False, None, MASK_NONE, None, None, None, 0.75, engine.compute_code("f32"))
+    for dt, code in ((np.float64, 1), (np.float32, 0)):
+        out = np.full((ms, ns + 3), -7.0, dtype=dt)
+        dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, backing.ctypes.data, ns + 5, C.byref(kspec.struct), C.byref(params),
+                                              out.ctypes.data, code, ns + 3))
+        assert last_kernel() == KERNEL_MFMA_DENSE
+        assert_parity(out[:, :ns], want, cond, "f32", f"host pipelined {shape} full={full} {np.dtype(dt).name}")
+        assert np.all(out[:, ns:] == -7.0)                   # the padding of the caller's rows is untouched
+    # the Python surface: same numbers (float64 container), p-values from the plain template size
+    big = np.ascontiguousarray(sig)
+    got, pv = cud.normxcorr2(big, loops(), full=full, pval=True)
+    assert got.dtype == np.float64 and last_kernel() == KERNEL_MFMA_DENSE
+    assert_parity(got, want, cond, "f32", "python surface through the pipelined call")
+    assert pv.shape == got.shape
+    # masks are not served by this entry
+    params_m = engine._corr_params((ms, ns), kspec, True, False, None, MASK_BINS, None, None, None, 0.75, engine.compute_code("f32"))
+    out = np.zeros((ms, ns))
+    assert dev.lib.cs_normxcorr2_host(dev.ctx, big.ctypes.data, ns, C.byref(kspec.struct), C.byref(params_m), out.ctypes.data, 1, ns) == -3

@@ -133,10 +133,34 @@ def test_row_window_argument_errors():
         params = engine._corr_params((100, 100), kspec, True, False, None, MASK_NONE, None, None, None, 0.75,
                                      engine.compute_code("f32"), window)
         assert dev.lib.cs_normxcorr2(dev.ctx, None, C.byref(m), C.byref(kspec.struct), C.byref(params), C.byref(m), None) == -1
-    # valid mode has no row windows
-    params = engine._corr_params((100, 100), kspec, False, False, None, MASK_NONE, None, None, None, 0.75,
-                                 engine.compute_code("f32"), (10, 20))
-    assert dev.lib.cs_normxcorr2(dev.ctx, None, C.byref(m), C.byref(kspec.struct), C.byref(params), C.byref(m), None) != 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_valid_mode_row_windows(precision):
+    """full = False (zero margins of (k-1)/2, same geometry): windows == the whole map."""
+    dev = get_device()
+    rng = np.random.default_rng(12)
+    n, cols = 300, 420
+    dt = np.float32 if precision == "f32" else np.float64
+    sig_h = rng.gamma(2.0, 1.0, size=(n, cols)).astype(dt)
+    kspec = engine.KernelSpec(np.asarray(ck.loops["kernels"][0], dtype=np.float64), None)
+    d_sig = dev.to_device(sig_h)
+    sig = CsMatrix(d_sig.ptr, np_dtype_code(dt), LAYOUT_DENSE, cols, 0, 0)
+
+    def run(out, window=None):
+        params = engine._corr_params((n, cols), kspec, False, False, None, MASK_NONE, None, None, None, 0.75,
+                                     engine.compute_code(precision), window)
+        dev._check(dev.lib.cs_normxcorr2(dev.ctx, None, C.byref(sig), C.byref(kspec.struct), C.byref(params), C.byref(out), None))
+
+    d_full = dev.zeros(n * cols, dt)
+    run(CsMatrix(d_full.ptr, np_dtype_code(dt), LAYOUT_DENSE, cols, 0, 0))
+    full = d_full.download().reshape(n, cols)
+    assert np.all(full[:8] == 0) and np.all(full[-8:] == 0) and np.abs(full[8:-8, 8:-8]).max() > 0.05
+    for a, b in _windows(n, [5, 8, 150, n - 8]):
+        d_out = dev.zeros((b - a) * cols, dt)
+        run(CsMatrix(d_out.ptr, np_dtype_code(dt), LAYOUT_DENSE, cols, 0, 0, a), (a, b))
+        got = d_out.download().reshape(b - a, cols)
+        assert np.abs(got - full[a:b]).max() <= (2e-6 if precision == "f32" else 1e-12), (a, b)
 
 
 # ------------------------------------------------------------------------------------------------

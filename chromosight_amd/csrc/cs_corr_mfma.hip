@@ -452,10 +452,49 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Out-of-line pieces of the REG epilogue: 16 inlined copies of each made the kernel 100 KB of code.
+__device__ __attribute__((noinline)) float masked_coefficient_rare(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                                   const KernelStats<float>& K)
+{
+    return pearson_masked_f32(cs, s1, s2, nm, ka, kb, K);
+}
+
+__device__ __forceinline__ float masked_coefficient(float cs, float s1, float s2, float nm, float ka, float kb,
+                                                    const KernelStats<float>& K)
+{
+    bool rare;
+    float r = pearson_masked_core(cs, s1, s2, nm, ka, kb, K, rare);
+    if (rare) r = masked_coefficient_rare(cs, s1, s2, nm, ka, kb, K);
+    return r;
+}
+
+// correction {d n_missing, d ka, d kb} of a pixel whose window leaves the matrix or the diagonals 0..max_dist
+// (tables of cs_mask_prep.hip; same selection order as cs_corr_stream.h fix_fetch), or nullptr.  Select
+// chains instead of nested branches: 16 copies of this are inlined into the epilogue.
+__device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, int i, int j)
+{
+    const int K = A.km, KH = (A.km - 1) / 2;
+    const int d = j - i;
+    const bool in_range = (j >= 0) & (j < A.ns) & (d >= A.out_lo) & (d <= A.out_hi) & (i < A.row_end);
+    const int x = A.fix_xband ? d - A.fix_xlo : j;
+    const bool top = i < A.fix_top;
+    const bool bot = (i >= A.fix_bot0) & (!A.fix_on | (i + KH >= A.ms) | (j + KH >= A.ns));
+    const bool side = (A.fix_cols != nullptr) & ((j < A.fix_side) | (j >= A.ns - A.fix_side));
+    const bool lo = (A.fix_on != 0) & (d >= 0) & (d < K - 1);
+    const bool hi = (A.fix_on != 0) & (d >= A.fix_hi_d0) & (d - A.fix_hi_d0 < A.fix_hi_w);
+    const long long o_rows = (long long)(top ? i : A.fix_top + i - A.fix_bot0) * A.fix_width + x;
+    const long long o_side = (long long)i * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side));
+    const long long o_lo = (long long)i * (K - 1) + d;
+    const long long o_hi = (long long)i * A.fix_hi_w + (d - A.fix_hi_d0);
+    const float* base = (top | bot) ? A.fix_rows : side ? A.fix_cols : lo ? A.fix_lo : A.fix_hi;
+    const long long off = (top | bot) ? o_rows : side ? o_side : lo ? o_lo : o_hi;
+    return (in_range & (top | bot | side | lo | hi)) ? base + 4 * off : nullptr;
+}
+
 template <bool VEC4, bool REG>
 __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDenseArgs A)
 {
-    static_assert(!(VEC4 && REG), "REG instances address the signal pixel by pixel");
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const pl_xh = smem;
     char* const pl_xl = smem + MF_PLANE;
@@ -539,9 +578,11 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 // beyond are harmless repeats; addresses clamped to the dwords that overlap the array)
                 const long long base = (long long)(uintptr_t)A.miss_col;
                 const long long first = ((base + Q0) >> 2) << 2;
-                long long addr = first + 4 * min(lane, 31);
+                long long addr = first + 4 * min(lane, 23);
                 addr = min(max(addr, (base >> 2) << 2), ((base + A.ns - 1) >> 2) << 2);
-                if (lane < 32)
+                // word 31 of the slot = "the tile has a flagged column", set when the flags are unpacked
+                if (lane == 0) reinterpret_cast<volatile unsigned*>(smem + MFD_CFB)[slot * 32 + 31] = 0u;
+                if (lane < 24)
                     __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>((uintptr_t)addr),
                                                      (__attribute__((address_space(3))) void*)(
                                                          (__attribute__((address_space(3))) char*)(smem) + MFD_CFB + slot * 128), 4, 0, 0);
@@ -554,7 +595,11 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             const int p = min(max(P0 + r, p_min), p_max);
             const float* row = A.sig + ((long long)p - A.row0_in) * A.ld_in;
             if constexpr (VEC4) {
-                const int q = min(max(Q0 + 4 * c, 0), A.ns - 4);
+                // REG: the piece's first stored index (band: diagonal index q - p - lo), clamped into the row's
+                // stored range -- the reader undoes the shift (16-byte transfers need no 16-byte alignment)
+                int q = Q0 + 4 * c;
+                if (REG && A.band_in) q = min(max(q - p - A.lo_in, 0), A.bw_in - 4);
+                else q = min(max(q, 0), A.ns - 4);
                 __builtin_amdgcn_global_load_lds(row + q, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                 dst += 4096;
                 c += 256 % kPiecesPerRow;
@@ -584,106 +629,87 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             // ---- per-bin masks: the factorised mask sums of cs_mask_prep.hip (see cs_corr_stream.h MODE 2)
             //   n_missing = K nr[i] + (K - nr[i]) ncol[j],  sum_missing Wa = RA[i] + CA[j] - sum_kj c[j+kj] U_i[kj]
             // plus the precomputed corrections of the pixels whose window leaves the matrix / 0..max_dist
-            const int K = km, KH = kh;
+            const int K = km;
             const int i = I0 + wr0 + n;
             const float* colb = reinterpret_cast<const float*>(smem + MFD_COL) + slot * 3 * 64;
             const float* cfl = reinterpret_cast<const float*>(smem + MFD_CFL) + slot * 80;
             const float nr = hdr[0], ra = hdr[1], rb = hdr[2];
-            unsigned bits = (unsigned)hdr[3];
-            f4 xa[4], xb[4];
+            // the cross term exists only where a flagged row AND a flagged column reach the window
+            const bool tile_flags = reinterpret_cast<const unsigned*>(smem + MFD_CFB)[slot * 32 + 31] != 0;
+            const unsigned row_bits = (tile_flags && !(A.dbg & 128)) ? (unsigned)hdr[3] : 0u;
+            const int dmin = J0 - (I0 + MF_T - 1), dmax = J0 + MF_T - 1 - I0;
+            const bool needs_fix = !(A.dbg & 256) && ((I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_cols != nullptr) |
+                                   (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
+                                                 (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w))));
+            float* tb = reinterpret_cast<float*>(scr);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xa[c] = xb[c] = zero4;
-            // cross term: for every flagged row ki of the window, (column flags (*) template row ki)
-            if (A.dbg & 128) bits = 0;
-            while (__builtin_amdgcn_ballot_w64(bits != 0)) {
-                if (bits) {
-                    const int ki = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    const float* wa = A.w + K * K + ki * K;
-                    const float* wb = A.w + 2 * K * K + ki * K;
+            for (int half = 0; half < 2; ++half) {
+                f4 rv[2], nv[2];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = 2 * half + cc;
+                    // cross term of this column tile: for every flagged row ki of the window,
+                    // (column flags (*) template row ki); one weight pair in flight at a time
+                    f4 xa = zero4, xb = zero4;
+                    unsigned bits = row_bits;
+                    if (__builtin_amdgcn_ballot_w64(bits != 0)) {
                         float fl[20];
 #pragma unroll
                         for (int e = 0; e < 5; ++e) {
                             const f4 t = *reinterpret_cast<const f4*>(cfl + 16 * c + 4 * g + 4 * e);
                             fl[4 * e] = t[0]; fl[4 * e + 1] = t[1]; fl[4 * e + 2] = t[2]; fl[4 * e + 3] = t[3];
                         }
+                        while (__builtin_amdgcn_ballot_w64(bits != 0)) {
+                            if (bits) {
+                                const int ki = __builtin_ctz(bits);
+                                bits &= bits - 1;
+                                const float* wa = A.w + K * K + ki * K;
+                                const float* wb = A.w + 2 * K * K + ki * K;
 #pragma unroll
-                        for (int kj = 0; kj < 17; ++kj) {
-                            const float a = kj < K ? wa[min(kj, K - 1)] : 0.0f, b = kj < K ? wb[min(kj, K - 1)] : 0.0f;
+                                for (int kj = 0; kj < 17; ++kj) {
+                                    const float a = kj < K ? wa[min(kj, K - 1)] : 0.0f, b = kj < K ? wb[min(kj, K - 1)] : 0.0f;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                xa[c][v] = fmaf(fl[v + kj], a, xa[c][v]);
-                                xb[c][v] = fmaf(fl[v + kj], b, xb[c][v]);
-                            }
-                        }
-                    }
-                }
-            }
-            const int dmin = J0 - (I0 + MF_T - 1), dmax = J0 + MF_T - 1 - I0;
-            const bool needs_fix = !(A.dbg & 256) && (I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_cols != nullptr) |
-                                   (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
-                                                 (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w)));
-            float* tb = reinterpret_cast<float*>(scr);
-#pragma unroll
-            for (int pass = 0; pass < (A.nobs ? 2 : 1); ++pass) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f4 rv[2];
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        const int c = 2 * half + cc;
-                        const f4 ncol = *reinterpret_cast<const f4*>(colb + 16 * c + 4 * g);
-                        const f4 ca = *reinterpret_cast<const f4*>(colb + 64 + 16 * c + 4 * g);
-                        const f4 cb = *reinterpret_cast<const f4*>(colb + 128 + 16 * c + 4 * g);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int j = J0 + 16 * c + 4 * g + v;
-                            const int d = j - i;
-                            float nm = (float)K * nr + ((float)K - nr) * ncol[v];
-                            float ka = ra + ca[v] - xa[c][v];
-                            float kb = rb + cb[v] - xb[c][v];
-                            if (needs_fix) {
-                                const bool in_range = (j >= 0) & (j < A.ns) & (d >= A.out_lo) & (d <= A.out_hi) & (i < A.row_end);
-                                const float* f = nullptr;
-                                if (in_range) {
-                                    const int x = A.fix_xband ? d - A.fix_xlo : j;
-                                    if (i < A.fix_top) f = A.fix_rows + ((size_t)i * A.fix_width + x) * 4;
-                                    else if (i >= A.fix_bot0 && (!A.fix_on || (i + KH >= A.ms) | (j + KH >= A.ns)))
-                                        f = A.fix_rows + ((size_t)(A.fix_top + i - A.fix_bot0) * A.fix_width + x) * 4;
-                                    else if (A.fix_cols && (j < A.fix_side || j >= A.ns - A.fix_side))
-                                        f = A.fix_cols + ((size_t)i * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side))) * 4;
-                                    else if (A.fix_on) {
-                                        if (d >= 0 && d < K - 1) f = A.fix_lo + ((size_t)i * (K - 1) + d) * 4;
-                                        else if (d >= A.fix_hi_d0 && d - A.fix_hi_d0 < A.fix_hi_w)
-                                            f = A.fix_hi + ((size_t)i * A.fix_hi_w + (d - A.fix_hi_d0)) * 4;
+                                    for (int v = 0; v < 4; ++v) {
+                                        xa[v] = fmaf(fl[v + kj], a, xa[v]);
+                                        xb[v] = fmaf(fl[v + kj], b, xb[v]);
                                     }
                                 }
-                                if (f) {
-                                    nm += f[0];
-                                    ka += f[1];
-                                    kb += f[2];
-                                }
                             }
-                            float val;
-                            if (pass == 0) {
-                                const float cs = acc[c][v] * u_cs;
-                                const float s1 = S1[c][v] * unscale;
-                                const float s2 = (S2[c][v] * u_s2) * unscale;
-                                val = pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks);
-                                if (A.sym_upper && d + (kn - km) < 0) val = 0.0f;      // full mode: triu in framed coordinates
-                            } else {
-                                val = A.ks.n - nm;
-                            }
-                            rv[cc][v] = val;
                         }
                     }
-                    // 16 rows x 32 columns through the wave's scratch, out as 2 rows x 32 consecutive floats per
-                    // instruction (band rows are shifted against each other: no wider aligned store exists)
+                    const f4 ncol = *reinterpret_cast<const f4*>(colb + 16 * c + 4 * g);
+                    const f4 ca = *reinterpret_cast<const f4*>(colb + 64 + 16 * c + 4 * g);
+                    const f4 cb = *reinterpret_cast<const f4*>(colb + 128 + 16 * c + 4 * g);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int j = J0 + 16 * c + 4 * g + v;
+                        const int d = j - i;
+                        float nm = (float)K * nr + ((float)K - nr) * ncol[v];
+                        float ka = ra + ca[v] - xa[v];
+                        float kb = rb + cb[v] - xb[v];
+                        if (needs_fix) {
+                            const float* f = mask_fix_record(A, i, j);
+                            if (f) {
+                                nm += f[0];
+                                ka += f[1];
+                                kb += f[2];
+                            }
+                        }
+                        const float cs = acc[c][v] * u_cs;
+                        const float s1 = S1[c][v] * unscale;
+                        const float s2 = (S2[c][v] * u_s2) * unscale;
+                        float val = masked_coefficient(cs, s1, s2, nm, ka, kb, A.ks);
+                        if (A.sym_upper && d + (kn - km) < 0) val = 0.0f;      // full mode: triu in framed coordinates
+                        rv[cc][v] = val;
+                        nv[cc][v] = A.ks.n - nm;
+                    }
+                }
+                // 16 rows x 32 columns through the wave's scratch, out as 2 rows x 32 consecutive floats per
+                // instruction (band rows are shifted against each other: no wider aligned store exists)
+                for (int pass = 0; pass < (A.nobs ? 2 : 1); ++pass) {
                     wave_lds_sync();
-                    *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = rv[0];
-                    *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = rv[1];
+                    *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = pass ? nv[0] : rv[0];
+                    *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = pass ? nv[1] : rv[1];
                     wave_lds_sync();
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
@@ -811,7 +837,25 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
             const int r = rg + 6 * k;
             float a = 0.0f, b = 0.0f;
-            if (stager && r < MF_R) {
+            if (REG && VEC4) {
+                if (stager && r < MF_R) {
+                    // pieces of 4 whose start was clamped into the stored range of their row: element o of the
+                    // piece holds stored index idx_c + o
+                    const int p = P0 + r, q = Q0 + 2 * c2, cs = (2 * c2) & ~3;
+                    const int w = A.band_in ? A.bw_in : A.ns;
+                    const int off = A.band_in ? p + A.lo_in : 0;
+                    const int idx_s = Q0 + cs - off;
+                    const int idx_c = min(max(idx_s, 0), w - 4);
+                    const int oa = (2 * c2 - cs) + (idx_s - idx_c), ob = oa + 1;
+                    const int idx_a = q - off;
+                    const bool rok = (p >= p_min) & (p <= p_max);
+                    const bool oka = rok & (q >= 0) & (q < A.ns) & (idx_a >= 0) & (idx_a < w) & (oa >= 0) & (oa < 4);
+                    const bool okb = rok & (q + 1 >= 0) & (q + 1 < A.ns) & (idx_a + 1 >= 0) & (idx_a + 1 < w) & (ob >= 0) & (ob < 4);
+                    const float* piece = raw + r * MF_R + cs;
+                    a = oka ? piece[min(max(oa, 0), 3)] : 0.0f;
+                    b = okb ? piece[min(max(ob, 0), 3)] : 0.0f;
+                }
+            } else if (stager && r < MF_R) {
                 const float2 v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
                 a = v.x;
                 b = v.y;
@@ -841,7 +885,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 const long long start = (long long)(uintptr_t)A.miss_col + Q0;
                 const int skew = (int)(start - ((start >> 2) << 2));           // bytes before column Q0 in the first dword
                 const uint8_t fb = reinterpret_cast<const uint8_t*>(smem + MFD_CFB)[slot * 128 + skew + tid];
-                reinterpret_cast<float*>(smem + MFD_CFL)[slot * 80 + tid] = (q >= 0 && q < A.ns && fb) ? 1.0f : 0.0f;
+                const bool flagged = q >= 0 && q < A.ns && fb;
+                reinterpret_cast<float*>(smem + MFD_CFL)[slot * 80 + tid] = flagged ? 1.0f : 0.0f;
+                // word 31 of the slot (beyond the 22 transferred dwords): does the tile have a flagged column?
+                if (flagged) reinterpret_cast<volatile unsigned*>(smem + MFD_CFB)[slot * 32 + 31] = 1u;
             }
         }
         MF_STAMP(0);
@@ -1087,17 +1134,21 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.fix_side = A.fix_side;
         if (reg_f32) {
             *dense_path = 2;
-            hipError_t e3 = hipFuncSetAttribute((const void*)corr_mfma_dense_kernel<false, true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // 16-byte transfers whenever a row stores at least 4 values (no alignment needed)
+            const bool vec_r = (D.band_in ? D.bw_in : D.ns) >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
+            const void* kr = vec_r ? (const void*)corr_mfma_dense_kernel<true, true> : (const void*)corr_mfma_dense_kernel<false, true>;
+            hipError_t e3 = hipFuncSetAttribute(kr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e3 != hipSuccess) return (int)e3;
             const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
             const int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
-            hipLaunchKernelGGL((corr_mfma_dense_kernel<false, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            if (vec_r) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
             return (int)hipGetLastError();
         }
         // 16-byte transfers and stores need aligned rows: base pointers, leading dimensions, the tile's
         // first staged column (64 bx - kw) and the row length all multiples of 4 elements
-        const bool vec4 = ((uintptr_t)D.sig % 16 == 0) && ((uintptr_t)D.out % 32 == 0) && D.ld_in % 4 == 0 && D.ld_out % 4 == 0 &&
+        const bool force_in = getenv("CHROMOSIGHT_HIP_MFMA_FORCEVEC") != nullptr;      // experiment: unaligned 16-byte transfers
+        const bool vec4 = (force_in || ((uintptr_t)D.sig % 16 == 0 && D.ld_in % 4 == 0)) && ((uintptr_t)D.out % 32 == 0) && D.ld_out % 4 == 0 &&
                           ((A.kn - 1) / 2) % 4 == 0 && D.ns % 4 == 0 && D.ns >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
         const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true, false> : (const void*)corr_mfma_dense_kernel<false, false>;
         hipError_t e2 = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -1145,10 +1145,10 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
             return (int)hipGetLastError();
         }
-        // 16-byte transfers and stores need aligned rows: base pointers, leading dimensions, the tile's
-        // first staged column (64 bx - kw) and the row length all multiples of 4 elements
-        const bool force_in = getenv("CHROMOSIGHT_HIP_MFMA_FORCEVEC") != nullptr;      // experiment: unaligned 16-byte transfers
-        const bool vec4 = (force_in || ((uintptr_t)D.sig % 16 == 0 && D.ld_in % 4 == 0)) && ((uintptr_t)D.out % 32 == 0) && D.ld_out % 4 == 0 &&
+        // 16-byte pieces: the tile's first staged column (64 bx - kw) and the row length must be multiples
+        // of 4 so that no piece straddles the matrix edge; the transfers themselves need only 4-byte alignment
+        // (checked bit for bit against 4-byte transfers at every misalignment), the 16-byte stores aligned rows
+        const bool vec4 = ((uintptr_t)D.out % 32 == 0) && D.ld_out % 4 == 0 &&
                           ((A.kn - 1) / 2) % 4 == 0 && D.ns % 4 == 0 && D.ns >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
         const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true, false> : (const void*)corr_mfma_dense_kernel<false, false>;
         hipError_t e2 = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

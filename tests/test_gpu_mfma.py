@@ -259,3 +259,37 @@ def test_host_pipelined_call(shape, full):
     params_m = engine._corr_params((ms, ns), kspec, True, False, None, MASK_BINS, None, None, None, 0.75, engine.compute_code("f32"))
     out = np.zeros((ms, ns))
     assert dev.lib.cs_normxcorr2_host(dev.ctx, big.ctypes.data, ns, C.byref(kspec.struct), C.byref(params_m), out.ctypes.data, 1, ns) == -3
+
+
+def test_dense_kernel_unaligned_rows():
+    """16-byte tile transfers from rows that are only 4-byte aligned (odd row pitch, shifted base): same map
+    as with 4-byte transfers, bit for bit, and within 1e-5 of the oracle."""
+    dev = get_device()
+    rng = np.random.default_rng(8)
+    n, cols = 520, 516
+    kspec = engine.KernelSpec(loops(), None)
+    code = np_dtype_code(np.float32)
+    for shift in (1, 3):
+        ld = cols + 1
+        host = rng.gamma(2.0, 1.0, size=n * ld + 8).astype(np.float32)
+        d = dev.to_device(host)
+        sig_h = host[shift:shift + n * ld].reshape(n, ld)[:, :cols]
+        maps = {}
+        for novec in (False, True):
+            out = dev.zeros(n * cols, np.float32)
+            params = engine._corr_params((n, cols), kspec, True, False, None, MASK_NONE, None, None, None, 0.75,
+                                         engine.compute_code("f32"))
+            import os
+            if novec:
+                os.environ["CHROMOSIGHT_HIP_MFMA_NOVEC"] = "1"
+            try:
+                dev._check(dev.lib.cs_normxcorr2(dev.ctx, None, C.byref(CsMatrix(d.ptr + 4 * shift, code, LAYOUT_DENSE, ld, 0, 0)),
+                                                 C.byref(kspec.struct), C.byref(params),
+                                                 C.byref(CsMatrix(out.ptr, code, LAYOUT_DENSE, cols, 0, 0)), None))
+            finally:
+                os.environ.pop("CHROMOSIGHT_HIP_MFMA_NOVEC", None)
+            assert last_kernel() == KERNEL_MFMA_DENSE
+            maps[novec] = out.download().reshape(n, cols)
+        assert np.array_equal(maps[False], maps[True])
+        want, cond = c_oracle.normxcorr2_rows(sig_h.astype(np.float64), loops(), 0, n, full=True)
+        assert_parity(maps[False], want, cond, "f32", f"unaligned rows, shift {shift}")

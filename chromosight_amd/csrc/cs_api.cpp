@@ -277,8 +277,7 @@ bool mfma_wanted(const cs::CorrArgs<float>& A)
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA");
     if (e && e[0] == '1') return true;
-    const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr &&
-                           !A.xcorr_only;
+    const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr;
     int K = 0;
     const long long px = (long long)(A.row_end - A.row_begin) * A.ns;
     return dense_f32 && (A.km * A.kn >= 169 || px <= 6000000 || !fast_available(A.km, A.kn, &K));

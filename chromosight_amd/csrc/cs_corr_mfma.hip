@@ -373,6 +373,7 @@ struct MfmaDenseArgs {
     int ms, ns, km, kn;
     int row_begin, row_end;
     int full, sym_upper;
+    int xcorr_only;          // plain cross-correlation: out = thresholded sum S*w (no box sums, no normalisation)
     int tiles_x, n_tiles;
     const uint4* frag;
     float w_unscale;
@@ -509,31 +510,6 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
     const int km = A.km, kn = A.kn;
     const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
 
-    // ---- weights: heads of all 17 template rows in registers (rows >= km are zero), tails in LDS
-    h8 wh[17];
-    {
-        const h8* frag = reinterpret_cast<const h8*>(A.frag);
-        h8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
-#pragma unroll
-        for (int s = 0; s < 17; ++s) {
-            const int sc = min(s, km - 1);
-            const h8 a = frag[(2 * sc + 0) * 64 + lane];
-            wh[s] = s < km ? a : z;
-        }
-        h8 tails[5];                                   // 17 x 64 fragments = 4.25 per thread: loads first
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int idx = min(tid + 256 * k, 17 * 64 - 1);
-            tails[k] = frag[(2 * min(idx >> 6, km - 1) + 1) * 64 + (idx & 63)];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int idx = tid + 256 * k;
-            if (idx < 17 * 64) reinterpret_cast<h8*>(smem + MFD_WL)[idx] = (idx >> 6) < km ? tails[k] : z;
-        }
-    }
     h8 ones_b, ones_a;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -741,7 +717,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 const float cs = acc[c][v] * u_cs;
                 const float s1 = S1[c][v] * unscale;
                 const float s2 = (S2[c][v] * u_s2) * unscale;
-                rv[c][v] = (A.dbg & 32) ? cs + s1 + s2 : pearson_nomask_lean(cs, s1, s2, A.ks);
+                rv[c][v] = A.xcorr_only ? (fabsf(cs) < A.ks.thr ? 0.0f : cs)            // detection.py:716-722
+                                        : (A.dbg & 32) ? cs + s1 + s2 : pearson_nomask_lean(cs, s1, s2, A.ks);
             }
         }
         if (A.dbg & 1) {
@@ -817,7 +794,33 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         tile_end = A.n_tiles;
         tile_step = gridDim.x;
     }
-    if (tile < tile_end) fetch(tile, 0);
+    if (tile < tile_end) fetch(tile, 0);       // the first tile is on its way while the weights are loaded
+
+    // ---- weights: heads of all 17 template rows in registers (rows >= km are zero), tails in LDS
+    h8 wh[17];
+    {
+        const h8* frag = reinterpret_cast<const h8*>(A.frag);
+        h8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+#pragma unroll
+        for (int s = 0; s < 17; ++s) {
+            const int sc = min(s, km - 1);
+            const h8 a = frag[(2 * sc + 0) * 64 + lane];
+            wh[s] = s < km ? a : z;
+        }
+        h8 tails[5];                                   // 17 x 64 fragments = 4.25 per thread: loads first
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = min(tid + 256 * k, 17 * 64 - 1);
+            tails[k] = frag[(2 * min(idx >> 6, km - 1) + 1) * 64 + (idx & 63)];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < 17 * 64) reinterpret_cast<h8*>(smem + MFD_WL)[idx] = (idx >> 6) < km ? tails[k] : z;
+        }
+    }
     for (; tile < tile_end; tile += tile_step) {
         int I0, J0;
         tile_origin(tile, I0, J0);
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         f4 S1[4], S2[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) S1[c] = S2[c] = zero4;
-        if (!(A.dbg & 4)) {
+        if (!(A.dbg & 4) && !A.xcorr_only) {
             auto hfrag = [&](int t, h8 (&f)[4]) {
                 const int c = t >> 1;
                 const char* ph = (t & 1) ? pl_qh : pl_xh;
@@ -1075,8 +1078,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
     if (blocks <= 0) return 0;
     if (blocks > 0x7fffffffLL) return -3;
     const bool masked = A.mask_mode != 0;
-    const bool dense_f32 = !masked && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr && !A.xcorr_only &&
-                           A.ms > 0 && A.ns > 0;
+    const bool dense_f32 = !masked && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr && A.ms > 0 && A.ns > 0;
     // per-bin masks with the factorised tables in place (cs_api.cpp prepare_regular_mask), square template
     const bool reg_f32 = A.mask_mode == 1 && A.reg_mode == 1 && A.km == A.kn && !A.sig_is_f64 && !A.xcorr_only && A.full &&
                          A.ms > 0 && A.ns > 0 &&
@@ -1100,6 +1102,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.row_end = A.row_end;
         D.full = A.full;
         D.sym_upper = A.sym_upper;
+        D.xcorr_only = A.xcorr_only;
         D.tiles_x = A.tiles_x;
         D.n_tiles = (int)blocks;
         D.frag = E.frag;

@@ -293,3 +293,21 @@ def test_dense_kernel_unaligned_rows():
         assert np.array_equal(maps[False], maps[True])
         want, cond = c_oracle.normxcorr2_rows(sig_h.astype(np.float64), loops(), 0, n, full=True)
         assert_parity(maps[False], want, cond, "f32", f"unaligned rows, shift {shift}")
+
+
+@pytest.mark.parametrize("shape,kshape", [((700, 900), (17, 17)), ((300, 257), (7, 11)), ((130, 1500), (9, 9))])
+def test_dense_kernel_xcorr2(shape, kshape):
+    """Plain xcorr2 of a float32 array on the persistent kernel (no box sums, thresholded sum): equal to
+    the numpy oracle up to float32 rounding of the sum, zero margins, same threshold semantics."""
+    from oracle import pearson_oracle as orc
+    rng = np.random.default_rng(shape[1])
+    sig = rng.gamma(2.0, 1.0, size=shape).astype(np.float32)
+    k = rng.normal(size=kshape)
+    got = cud.xcorr2(sig, k, threshold=1e-4)
+    assert last_kernel() == KERNEL_MFMA_DENSE
+    want = orc.xcorr2_oracle(sig.astype(np.float64), k, threshold=0)
+    near = np.abs(np.abs(want) - 1e-4) < 1e-5
+    ref = np.where(np.abs(want) < 1e-4, 0.0, want)
+    assert np.abs(got - ref)[~near].max() < 3e-6 * np.abs(want).max()
+    kh, kw = (kshape[0] - 1) // 2, (kshape[1] - 1) // 2
+    assert np.all(got[:kh] == 0) and np.all(got[:, :kw] == 0) and np.all(got[-kh:] == 0) and np.all(got[:, -kw:] == 0)

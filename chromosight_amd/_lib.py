@@ -161,8 +161,8 @@ _PROTOTYPES = {
     "cs_label_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                 C.POINTER(C.c_int64)]),
-    "cs_normxcorr2_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(CsKernel), C.POINTER(CsNormxcorr2Params),
-                                     C.c_void_p, C.c_int32, C.c_int64]),
+    "cs_normxcorr2_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(CsKernel),
+                                     C.POINTER(CsNormxcorr2Params), C.c_void_p, C.c_int32, C.c_int64]),
     "cs_remove_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "cs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),

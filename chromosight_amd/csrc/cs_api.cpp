@@ -45,6 +45,8 @@ struct cs_ctx {
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
+    void* d_narrow = nullptr;       // float32 copy of a float64 dense signal for the matrix-core kernel
+    size_t d_narrow_bytes = 0;
     // cs_normxcorr2_host: device staging of the map, pinned bounce buffer of the float32 result, three
     // streams (upload / kernels / download) and one event pair per row slab, all grow-only
     void* d_host_in = nullptr;
@@ -55,6 +57,8 @@ struct cs_ctx {
     hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     std::vector<hipEvent_t> ev_up, ev_run, ev_down;
 };
+
+static int ensure_scratch(cs_ctx* ctx, void** buf, size_t* have, size_t need);
 
 namespace {
 
@@ -277,7 +281,7 @@ bool mfma_wanted(const cs::CorrArgs<float>& A)
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA");
     if (e && e[0] == '1') return true;
-    const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.sig_is_f64 && !A.nobs.ptr;
+    const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.nobs.ptr;
     int K = 0;
     const long long px = (long long)(A.row_end - A.row_begin) * A.ns;
     return dense_f32 && (A.km * A.kn >= 169 || px <= 6000000 || !fast_available(A.km, A.kn, &K));
@@ -475,6 +479,23 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         }
     }
     if (allow_fast && mfma_wanted(A)) {
+        if (A.sig_is_f64 && A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.nobs.ptr) {
+            // float64 container, float32 arithmetic: narrow the rows the windows reach into context scratch
+            // (what the kernels do pixel by pixel anyway) so that the persistent tile kernel can stage them
+            const int kh = (A.km - 1) / 2;
+            const int p_lo = std::max(0, A.row_begin - kh), p_hi = std::min(A.ms, A.row_end + (A.km - 1) - kh);
+            const long long ld = ((long long)A.ns + 15) / 16 * 16;
+            const size_t bytes = (size_t)(p_hi - p_lo) * (size_t)ld * 4;
+            rc = ensure_scratch(ctx, &ctx->d_narrow, &ctx->d_narrow_bytes, bytes);
+            if (rc != CS_OK) return rc;
+            const double* src = reinterpret_cast<const double*>(A.sig.ptr) + ((long long)p_lo - A.sig.row0) * A.sig.ld;
+            rc = cs::launch_narrow_rows(src, A.sig.ld, reinterpret_cast<float*>(ctx->d_narrow), ld, p_hi - p_lo, A.ns, ctx->n_cu, stream);
+            if (rc != 0) return fail(ctx, CS_ERR_HIP, "narrowing kernel failed: %s", hipGetErrorString((hipError_t)rc));
+            A.sig.ptr = ctx->d_narrow;
+            A.sig.ld = ld;
+            A.sig.row0 = p_lo;
+            A.sig_is_f64 = 0;
+        }
         cs::MfmaWeights E;
         rc = ensure_wfrag(ctx, stream, A.km, A.kn, &E);
         if (rc != CS_OK) return rc;
@@ -729,6 +750,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
     if (ctx->d_host_in) (void)hipFree(ctx->d_host_in);
     if (ctx->d_host_out) (void)hipFree(ctx->d_host_out);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
@@ -881,7 +903,7 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
 }
 
 // Host map in, host map out, pipelined over PCIe in row slabs (see the header).
-int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const cs_kernel* kernel,
+int cs_normxcorr2_host(cs_ctx* ctx, const void* h_signal, int32_t sig_dtype, int64_t ld_in, const cs_kernel* kernel,
                        const cs_normxcorr2_params* p, void* h_out, int32_t out_dtype, int64_t ld_out)
 {
     CS_ENTER(ctx);
@@ -889,12 +911,14 @@ int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const 
     if (p->mask_mode != CS_MASK_NONE) return fail(ctx, CS_ERR_UNSUPPORTED, "cs_normxcorr2_host takes unmasked maps");
     if (p->compute_dtype != CS_F32) return fail(ctx, CS_ERR_UNSUPPORTED, "cs_normxcorr2_host computes in float32");
     if (out_dtype != CS_F32 && out_dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "bad output dtype");
+    if (sig_dtype != CS_F32 && sig_dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "bad signal dtype");
+    const size_t esz = sig_dtype == CS_F64 ? 8 : 4;          // float64 maps are narrowed on the device, slab by slab
     const int ms = p->ms, ns = p->ns;
     if (ms <= 0 || ns <= 0 || ld_in < ns || ld_out < ns) return fail(ctx, CS_ERR_INVALID, "bad geometry");
     const int km = kernel->km;
     const int kh = (km - 1) / 2, kt = km - 1 - kh;          // rows a window reaches above / below its pixel
     const int64_t ld = ((int64_t)ns + 15) / 16 * 16;
-    const size_t map_bytes = (size_t)ms * (size_t)ld * 4;
+    const size_t map_bytes = (size_t)ms * (size_t)ld * 8;     // sized for either input type
     if (map_bytes > ctx->d_host_bytes) {
         CS_HIP(ctx, hipDeviceSynchronize());
         if (ctx->d_host_in) CS_HIP(ctx, hipFree(ctx->d_host_in));
@@ -930,7 +954,7 @@ int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const 
         ctx->ev_run.push_back(b);
         ctx->ev_down.push_back(c);
     }
-    cs_matrix m_in{ctx->d_host_in, CS_F32, CS_LAYOUT_DENSE, ld, 0, 0, 0};
+    cs_matrix m_in{ctx->d_host_in, sig_dtype, CS_LAYOUT_DENSE, ld, 0, 0, 0};
     cs_matrix m_out{ctx->d_host_out, CS_F32, CS_LAYOUT_DENSE, ld, 0, 0, 0};
     // warm the template upload (it synchronises) before the pipeline starts
     {
@@ -982,12 +1006,13 @@ int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const 
     auto upload = [&](int k) -> hipError_t {
         const int r0 = k * rows, r1 = std::min(ms, r0 + rows);
         hipError_t e;
+        const char* src = reinterpret_cast<const char*>(h_signal) + (size_t)r0 * ld_in * esz;
         if (ld_in == ns && ld == ns)
-            e = hipMemcpyAsync((char*)ctx->d_host_in + (size_t)r0 * ld * 4, h_signal + (size_t)r0 * ld_in,
-                               (size_t)(r1 - r0) * ns * 4, hipMemcpyHostToDevice, ctx->s_up);
+            e = hipMemcpyAsync((char*)ctx->d_host_in + (size_t)r0 * ld * esz, src, (size_t)(r1 - r0) * ns * esz,
+                               hipMemcpyHostToDevice, ctx->s_up);
         else
-            e = hipMemcpy2DAsync((char*)ctx->d_host_in + (size_t)r0 * ld * 4, (size_t)ld * 4, h_signal + (size_t)r0 * ld_in,
-                                 (size_t)ld_in * 4, (size_t)ns * 4, (size_t)(r1 - r0), hipMemcpyHostToDevice, ctx->s_up);
+            e = hipMemcpy2DAsync((char*)ctx->d_host_in + (size_t)r0 * ld * esz, (size_t)ld * esz, src, (size_t)ld_in * esz,
+                                 (size_t)ns * esz, (size_t)(r1 - r0), hipMemcpyHostToDevice, ctx->s_up);
         if (e != hipSuccess) return e;
         return hipEventRecord(ctx->ev_up[k], ctx->s_up);
     };

@@ -485,6 +485,28 @@ __global__ __launch_bounds__(256) void law_finish_kernel(const double* __restric
     if (d < n) law[d] = cnt[d] > 0 ? sum[d] / (double)cnt[d] : 0.0;
 }
 
+// float64 rows -> float32 rows (the matrix-core kernel stages float32 pixels by LDS-DMA; the float32
+// arithmetic class rounds every pixel to float32 first in any case): 12 B per pixel, HBM-bound
+__global__ __launch_bounds__(256) void narrow_rows_kernel(const double* __restrict__ src, long long ld_src,
+                                                          float* __restrict__ dst, long long ld_dst, int rows, int cols)
+{
+    const long long total = (long long)rows * cols;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
+        dst[(long long)r * ld_dst + c] = (float)src[(long long)r * ld_src + c];
+    }
+}
+
+int launch_narrow_rows(const double* src, long long ld_src, float* dst, long long ld_dst, int rows, int cols, int n_cu,
+                       hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    const long long want = ((long long)rows * cols + 255) / 256;
+    const int blocks = (int)std::min<long long>(want, (long long)n_cu * 16);
+    hipLaunchKernelGGL(narrow_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, cols);
+    return (int)hipGetLastError();
+}
+
 int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream)
 {
     if (n == 0) return 0;

@@ -49,6 +49,8 @@ int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* co
 int launch_csr_band_extent(const CsrView& M, int lo_diag, int hi_diag, long long* begin, long long* end,
                            hipStream_t stream);
 int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream);
+int launch_narrow_rows(const double* src, long long ld_src, float* dst, long long ld_dst, int rows, int cols, int n_cu,
+                       hipStream_t stream);
 
 // median of the stored values of a view (cs_foci.hip)
 int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_median);

@@ -95,8 +95,9 @@ def run_normxcorr2_host(dev, signal, kspec, *, full, sym_upper, max_dist, missin
     # result pages from the device's pool of page-locked buffers: a fresh 128 MB numpy array would be
     # page-faulted in by the widening threads (measured: 7 ms of an 11 ms call)
     out = dev.pinned_result((ms, ns), out_dtype)
-    dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, signal.ctypes.data, ns, C.byref(kspec.struct), C.byref(params),
-                                          out.ctypes.data, _lib.np_dtype_code(out_dtype), ns))
+    dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, signal.ctypes.data, _lib.np_dtype_code(signal.dtype), ns,
+                                          C.byref(kspec.struct), C.byref(params), out.ctypes.data,
+                                          _lib.np_dtype_code(out_dtype), ns))
     return out
 
 

@@ -200,7 +200,7 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         raise ValueError("cannot have kernel bigger than signal")
     dev = get_device()
     kspec = engine.KernelSpec(kernel, tsvd)
-    if (missing_mask is None and isinstance(signal, np.ndarray) and signal.dtype == np.float32 and signal.ndim == 2
+    if (missing_mask is None and isinstance(signal, np.ndarray) and signal.dtype in (np.float32, np.float64) and signal.ndim == 2
             and signal.flags.c_contiguous and engine.get_precision() == "f32" and signal.size >= (1 << 20)):
         # large host map in, host map out: one native call that pipelines the map over PCIe in row slabs
         # (cs_normxcorr2_host); the float64 array the reference returns is filled by the library's threads

@@ -149,14 +149,14 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_k
                   const cs_matrix* out_nobs);
 
 /* The same map call for a caller whose map lives in HOST memory (what chromosight's Python surface
- * hands over: detection.py:807 takes and returns numpy / scipy containers): float32 ms x ns map in
- * (row pitch ld_in elements), float32 or float64 coefficient map out (ld_out), no mask, float32
- * arithmetic.  The map crosses PCIe in row slabs: upload of slab k + 1, the kernel on the row window of
+ * hands over: detection.py:807 takes and returns numpy / scipy containers): float32 or float64 ms x ns
+ * map in (sig_dtype, row pitch ld_in elements; float64 rows are rounded to float32 on the device),
+ * float32 or float64 coefficient map out (ld_out), no mask, float32 arithmetic.  The map crosses PCIe in row slabs: upload of slab k + 1, the kernel on the row window of
  * slab k (params->row_begin / row_end are set by the call) and the download of slab k - 1 overlap on three
  * streams; the float32 result is widened to float64 on host threads while later slabs are still in
  * flight (the link moves 4 bytes per pixel each way instead of 4 + 8).  Synchronous.  Device staging
  * buffers, the pinned bounce buffer, streams and events belong to the context (grow-only). */
-int cs_normxcorr2_host(cs_ctx* ctx, const float* h_signal, int64_t ld_in, const cs_kernel* kernel,
+int cs_normxcorr2_host(cs_ctx* ctx, const void* h_signal, int32_t sig_dtype, int64_t ld_in, const cs_kernel* kernel,
                        const cs_normxcorr2_params* params, void* h_out, int32_t out_dtype, int64_t ld_out);
 
 /* Plain cross-correlation: centre-aligned, zero on the (k-1)/2 margins, |v| < threshold -> 0

@@ -181,20 +181,21 @@ def test_tile_kernel_with_bin_masks(n, md, ksize, monkeypatch):
     assert np.abs(p.toarray() - p2.toarray())[well].max() < 5e-3
 
 
-def test_general_kernel_xcorr2_and_f64_containers(monkeypatch):
-    monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA", "1")
+def test_f64_containers_are_narrowed_on_the_device():
+    """float64 arrays (numpy's default) with float32 arithmetic: the rows are rounded to float32 by a device
+    pass and take the persistent kernel, for normxcorr2 and xcorr2 alike."""
     rng = np.random.default_rng(33)
     sig = rng.gamma(2.0, 1.0, size=(210, 190))
     k = rng.normal(size=(7, 11))
     got = cud.xcorr2(sig, k, threshold=1e-4)                 # float64 container in, plain cross-correlation
-    assert last_kernel() == KERNEL_MFMA
+    assert last_kernel() == KERNEL_MFMA_DENSE                # narrowed to float32 rows on the device first
     from oracle import pearson_oracle as orc
     want = orc.xcorr2_oracle(sig, k, threshold=0)
     near = np.abs(np.abs(want) - 1e-4) < 1e-6
     ref = np.where(np.abs(want) < 1e-4, 0.0, want)
     assert np.abs(got - ref)[~near].max() < 3e-6 * np.abs(want).max()
     c, _ = cud.normxcorr2(sig, loops(), full=True)            # float64 ndarray in
-    assert last_kernel() == KERNEL_MFMA
+    assert last_kernel() == KERNEL_MFMA_DENSE
     w, cond = c_oracle.normxcorr2_rows(sig, loops(), 0, 210, full=True)
     assert_parity(c, w, cond, "f32", "mfma general f64 container")
 
@@ -244,7 +245,7 @@ def test_host_pipelined_call(shape, full):
     params = engine._corr_params((ms, ns), kspec, full, False, None, MASK_NONE, None, None, None, 0.75, engine.compute_code("f32"))
     for dt, code in ((np.float64, 1), (np.float32, 0)):
         out = np.full((ms, ns + 3), -7.0, dtype=dt)
-        dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, backing.ctypes.data, ns + 5, C.byref(kspec.struct), C.byref(params),
+        dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, backing.ctypes.data, 0, ns + 5, C.byref(kspec.struct), C.byref(params),
                                               out.ctypes.data, code, ns + 3))
         assert last_kernel() == KERNEL_MFMA_DENSE
         assert_parity(out[:, :ns], want, cond, "f32", f"host pipelined {shape} full={full} {np.dtype(dt).name}")
@@ -258,7 +259,12 @@ def test_host_pipelined_call(shape, full):
     # masks are not served by this entry
     params_m = engine._corr_params((ms, ns), kspec, True, False, None, MASK_BINS, None, None, None, 0.75, engine.compute_code("f32"))
     out = np.zeros((ms, ns))
-    assert dev.lib.cs_normxcorr2_host(dev.ctx, big.ctypes.data, ns, C.byref(kspec.struct), C.byref(params_m), out.ctypes.data, 1, ns) == -3
+    assert dev.lib.cs_normxcorr2_host(dev.ctx, big.ctypes.data, 0, ns, C.byref(kspec.struct), C.byref(params_m), out.ctypes.data, 1, ns) == -3
+    # float64 host map (numpy's default type): uploaded as it is, narrowed on the device slab by slab
+    big64 = big.astype(np.float64)
+    got64, _ = cud.normxcorr2(big64, loops(), full=full)
+    assert last_kernel() == KERNEL_MFMA_DENSE
+    assert np.array_equal(got64, got)
 
 
 def test_dense_kernel_unaligned_rows():

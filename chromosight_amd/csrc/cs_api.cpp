@@ -45,6 +45,15 @@ struct cs_ctx {
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
+    // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
+    // flags), per arithmetic type: a detect run calls with the same template thousands of times
+    struct TemplateCache {
+        std::vector<double> key;      // km, kn, flags, threshold, then the template arrays as passed
+        double stats[6] = {0, 0, 0, 0, 0, 0};
+        std::vector<double> w;
+        bool sym = false;
+        int zk_possible = 1, snap_possible = 1;
+    } tcache[2];
     void* d_narrow = nullptr;       // float32 copy of a float64 dense signal for the matrix-core kernel
     size_t d_narrow_bytes = 0;
     // cs_normxcorr2_host: device staging of the map, pinned bounce buffer of the float32 result, three
@@ -603,44 +612,91 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
         if (p->mask_mode == CS_MASK_EXPLICIT && !p->d_mask)
             return fail(ctx, CS_ERR_INVALID, "explicit mask is null");
     }
-    const HostStats st = template_stats(kernel->h_kernel, kk);
-    if (!(st.kstd > 0)) return fail(ctx, CS_ERR_INVALID, "Cannot have flat kernel.");  // detection.py:887-888
     const double* kconv = kernel->h_kernel_conv ? kernel->h_kernel_conv : kernel->h_kernel;
-    std::vector<double> w(3 * (size_t)kk);
-    for (int t = 0; t < kk; ++t) {
-        const double kc = kconv[t];
-        const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
-        w[t] = kc - st.kmean;
-        if (sizeof(TC) == 8) {
-            // float64 kernels use the reference's literal (un-centred) mask sums
-            w[kk + t] = kc;
-            w[2 * kk + t] = k2;
-        } else {
-            w[kk + t] = kc - st.kmean;
-            // chosen so that kb + 2*kmean*ka + kmean^2*nm == sum over missing pixels of k2
-            w[2 * kk + t] = k2 - 2.0 * st.kmean * kc + st.kmean * st.kmean;
+    const bool want_sym = !std::getenv("CHROMOSIGHT_HIP_NO_SYMMETRY");
+    cs_ctx::TemplateCache& tc = ctx->tcache[sizeof(TC) == 8 ? 1 : 0];
+    {
+        std::vector<double> key;
+        key.reserve(6 + 3 * (size_t)kk);
+        key.push_back(km);
+        key.push_back(kn);
+        key.push_back(kernel->h_kernel_conv ? 1 : 0);
+        key.push_back(kernel->h_kernel_sq ? 1 : 0);
+        key.push_back(want_sym ? 1 : 0);
+        key.push_back(p->xcorr_threshold);
+        key.insert(key.end(), kernel->h_kernel, kernel->h_kernel + kk);
+        if (kernel->h_kernel_conv) key.insert(key.end(), kernel->h_kernel_conv, kernel->h_kernel_conv + kk);
+        if (kernel->h_kernel_sq) key.insert(key.end(), kernel->h_kernel_sq, kernel->h_kernel_sq + kk);
+        const bool hit = key.size() == tc.key.size() && std::memcmp(key.data(), tc.key.data(), key.size() * sizeof(double)) == 0;
+        if (!hit) {
+            const HostStats st0 = template_stats(kernel->h_kernel, kk);
+            if (!(st0.kstd > 0)) return fail(ctx, CS_ERR_INVALID, "Cannot have flat kernel.");  // detection.py:887-888
+            tc.stats[0] = st0.n; tc.stats[1] = st0.kmean; tc.stats[2] = st0.kstd;
+            tc.stats[3] = st0.kvar; tc.stats[4] = st0.ksum; tc.stats[5] = st0.k2sum;
+            std::vector<double>& w0 = tc.w;
+            w0.assign(3 * (size_t)kk, 0.0);
+            for (int t = 0; t < kk; ++t) {
+                const double kc = kconv[t];
+                const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
+                w0[t] = kc - st0.kmean;
+                if (sizeof(TC) == 8) {
+                    // float64 kernels use the reference's literal (un-centred) mask sums
+                    w0[kk + t] = kc;
+                    w0[2 * kk + t] = k2;
+                } else {
+                    w0[kk + t] = kc - st0.kmean;
+                    // chosen so that kb + 2*kmean*ka + kmean^2*nm == sum over missing pixels of k2
+                    w0[2 * kk + t] = k2 - 2.0 * st0.kmean * kc + st0.kmean * st0.kmean;
+                }
+            }
+            // vertical symmetry of the template (loops, stripes): lets the streaming kernel fold template
+            // rows.  Rounding-level asymmetries (truncated-SVD reconstructions) are symmetrised for the
+            // float32 kernels, whose own rounding is 1e5 times larger; float64 needs exact symmetry.
+            bool sym0 = want_sym;
+            double wmax = 0;
+            for (size_t t = 0; t < w0.size(); ++t) wmax = std::max(wmax, std::fabs(w0[t]));
+            const double tol = sizeof(TC) == 8 ? 0.0 : 1e-12 * wmax;
+            for (int set = 0; set < 3 && sym0; ++set)
+                for (int r = 0; r < km / 2 && sym0; ++r)
+                    for (int c = 0; c < kn; ++c)
+                        if (std::fabs(w0[set * kk + r * kn + c] - w0[set * kk + (km - 1 - r) * kn + c]) > tol) {
+                            sym0 = false;
+                            break;
+                        }
+            if (sym0 && sizeof(TC) == 4)
+                for (int set = 0; set < 3; ++set)
+                    for (int r = 0; r < km / 2; ++r)
+                        for (int c = 0; c < kn; ++c) w0[set * kk + (km - 1 - r) * kn + c] = w0[set * kk + r * kn + c];
+            tc.sym = sym0;
+            // can sum_missing K' or sum_missing K'^2 of a non-empty set fall under the zeroing threshold?
+            // not if every entry alone exceeds it and all have one sign (the built-in templates: >= 0.5)
+            double lo = 1e300, lo2 = 1e300;
+            bool pos = true, pos2 = true;
+            std::vector<double> distinct;
+            for (int t = 0; t < kk; ++t) {
+                const double kc = kconv[t];
+                const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
+                lo = std::min(lo, std::fabs(kc));
+                lo2 = std::min(lo2, std::fabs(k2));
+                pos = pos && kc > 0;
+                pos2 = pos2 && k2 > 0;
+                bool seen = false;
+                for (double d : distinct) seen = seen || std::fabs(d - kc) <= 1e-9 * std::max(1.0, std::fabs(d));
+                if (!seen && distinct.size() < 64) distinct.push_back(kc);
+            }
+            tc.zk_possible = !(pos && pos2 && lo > 2 * p->xcorr_threshold && lo2 > 2 * p->xcorr_threshold);
+            // piecewise-constant templates (borders, hairpins: 2 levels) have windows whose present pixels
+            // are all equal; smooth templates never do, but with up to 75 % of a window missing a handful of
+            // levels can still coincide, so only clearly many-valued templates skip the snap
+            tc.snap_possible = distinct.size() < 64;
+            tc.key.swap(key);
         }
     }
-    // vertical symmetry of the template (loops, stripes): lets the streaming kernel fold template
-    // rows.  Rounding-level asymmetries (truncated-SVD reconstructions) are symmetrised for the
-    // float32 kernels, whose own rounding is 1e5 times larger; float64 needs exact symmetry.
-    bool sym = !std::getenv("CHROMOSIGHT_HIP_NO_SYMMETRY");
-    {
-        double wmax = 0;
-        for (size_t t = 0; t < w.size(); ++t) wmax = std::max(wmax, std::fabs(w[t]));
-        const double tol = sizeof(TC) == 8 ? 0.0 : 1e-12 * wmax;
-        for (int set = 0; set < 3 && sym; ++set)
-            for (int r = 0; r < km / 2 && sym; ++r)
-                for (int c = 0; c < kn; ++c)
-                    if (std::fabs(w[set * kk + r * kn + c] - w[set * kk + (km - 1 - r) * kn + c]) > tol) {
-                        sym = false;
-                        break;
-                    }
-        if (sym && sizeof(TC) == 4)
-            for (int set = 0; set < 3; ++set)
-                for (int r = 0; r < km / 2; ++r)
-                    for (int c = 0; c < kn; ++c) w[set * kk + (km - 1 - r) * kn + c] = w[set * kk + r * kn + c];
-    }
+    HostStats st;
+    st.n = tc.stats[0]; st.kmean = tc.stats[1]; st.kstd = tc.stats[2];
+    st.kvar = tc.stats[3]; st.ksum = tc.stats[4]; st.k2sum = tc.stats[5];
+    const std::vector<double>& w = tc.w;
+    const bool sym = tc.sym;
     rc = upload_weights<TC>(ctx, stream, w);
     if (rc) return rc;
 
@@ -675,29 +731,8 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.ks.nkvar = (TC)(st.n * st.kvar);
     A.ks.eps2 = (TC)(p->denom_eps * p->denom_eps);
     A.ks.den2_min = (TC)(p->denom_eps * p->denom_eps * st.n * st.n);
-    {
-        // can sum_missing K' or sum_missing K'^2 of a non-empty set fall under the zeroing threshold?
-        // not if every entry alone exceeds it and all have one sign (the built-in templates: >= 0.5)
-        double lo = 1e300, lo2 = 1e300;
-        bool pos = true, pos2 = true;
-        std::vector<double> distinct;
-        for (int t = 0; t < kk; ++t) {
-            const double kc = kconv[t];
-            const double k2 = kernel->h_kernel_sq ? kernel->h_kernel_sq[t] : kc * kc;
-            lo = std::min(lo, std::fabs(kc));
-            lo2 = std::min(lo2, std::fabs(k2));
-            pos = pos && kc > 0;
-            pos2 = pos2 && k2 > 0;
-            bool seen = false;
-            for (double d : distinct) seen = seen || std::fabs(d - kc) <= 1e-9 * std::max(1.0, std::fabs(d));
-            if (!seen && distinct.size() < 64) distinct.push_back(kc);
-        }
-        A.ks.zk_possible = !(pos && pos2 && lo > 2 * p->xcorr_threshold && lo2 > 2 * p->xcorr_threshold);
-        // piecewise-constant templates (borders, hairpins: 2 levels) have windows whose present pixels
-        // are all equal; smooth templates never do, but with up to 75 % of a window missing a handful of
-        // levels can still coincide, so only clearly many-valued templates skip the snap
-        A.ks.snap_possible = distinct.size() < 64;
-    }
+    A.ks.zk_possible = tc.zk_possible;
+    A.ks.snap_possible = tc.snap_possible;
     A.xcorr_only = 0;
     A.w_sym = sym ? 1 : 0;
     A.row_begin = 0;

@@ -29,6 +29,9 @@
 #include "cs_device.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "cs_launch.h"
 
@@ -794,6 +797,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         tile_end = A.n_tiles;
         tile_step = gridDim.x;
     }
+    if (A.dbg & 2048) return;                  // diagnostics: launch + dispatch only
     if (tile < tile_end) fetch(tile, 0);       // the first tile is on its way while the weights are loaded
 
     // ---- weights: heads of all 17 template rows in registers (rows >= km are zero), tails in LDS
@@ -826,6 +830,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
         const bool inside = !REG && P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
+        if (A.dbg & 1024) continue;            // diagnostics: prologue only
 #ifdef CS_MF_PROFILE
         unsigned long long tprev_ = __builtin_readcyclecounter();
         if (tid == 0) atomicAdd(&cs_mf_prof[15], 1ull);
@@ -1060,6 +1065,23 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
     }
 }
 
+// The 160 KB dynamic-LDS ceiling is a per-function, per-device attribute: set it the first time a kernel is
+// launched on a device (the call costs microseconds on every launch otherwise).
+static hipError_t allow_big_lds(const void* fn)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& d : done)
+        if (d.first == fn && d.second == dev) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.emplace_back(fn, dev);
+    return e;
+}
+
 int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t stream, int* dense_path)
 {
     *dense_path = 0;
@@ -1140,7 +1162,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             // 16-byte transfers whenever a row stores at least 4 values (no alignment needed)
             const bool vec_r = (D.band_in ? D.bw_in : D.ns) >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
             const void* kr = vec_r ? (const void*)corr_mfma_dense_kernel<true, true> : (const void*)corr_mfma_dense_kernel<false, true>;
-            hipError_t e3 = hipFuncSetAttribute(kr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e3 = allow_big_lds(kr);
             if (e3 != hipSuccess) return (int)e3;
             const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
             const int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
@@ -1154,7 +1176,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         const bool vec4 = ((uintptr_t)D.out % 32 == 0) && D.ld_out % 4 == 0 &&
                           ((A.kn - 1) / 2) % 4 == 0 && D.ns % 4 == 0 && D.ns >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
         const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true, false> : (const void*)corr_mfma_dense_kernel<false, false>;
-        hipError_t e2 = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e2 = allow_big_lds(kd);
         if (e2 != hipSuccess) return (int)e2;
         const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
         const int grid = (int)std::min<long long>(blocks, (long long)per_cu * A.n_cu);
@@ -1163,7 +1185,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         return (int)hipGetLastError();
     }
     const void* kern = masked ? (const void*)corr_mfma_kernel<true> : (const void*)corr_mfma_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = allow_big_lds(kern);
     if (e != hipSuccess) return (int)e;
     if (masked) hipLaunchKernelGGL(corr_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), MF_SMEM, stream, A, E);
     else hipLaunchKernelGGL(corr_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), MF_SMEM, stream, A, E);

@@ -310,6 +310,16 @@ struct Bump {
 // Candidate pixels (rows, cols; n_cand of them, any order) -> foci records.  `scratch` holds
 // foci_scratch_bytes(n_cand) bytes.  Everything is enqueued on `stream`; the host reads *h_n_foci
 // (pinned) after the stream has drained.  Returns a hipError_t as int.
+// radix passes that a row-major key (row * ns + col) needs: the keys of a 16 000 x 16 000 block have 28
+// significant bits, and every 8 bits less is one pass (three launches) less
+static inline int key_bits(long long ms, long long ns)
+{
+    unsigned long long top = (unsigned long long)(ms > 0 ? ms : 1) * (unsigned long long)(ns > 0 ? ns : 1);
+    int bits = 1;
+    while (bits < 63 && (1ull << bits) <= top) ++bits;
+    return bits;
+}
+
 int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,
                  int min_size, int diag_only, int inter, void* scratch, FocusRec** d_rec_out, double* d_windows,
                  long long win_cap, long long* d_n_foci, hipStream_t stream)
@@ -347,7 +357,7 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
 
     // row-major order of the candidates
     hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys);
-    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, 64, stream);
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, key_bits(A64.ms, ns), stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
     // exact coefficients, exact threshold
@@ -426,7 +436,7 @@ int enqueue_keep(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     const unsigned g = blocks_for(n_cand);
     hipLaunchKernelGGL(store_int_kernel, dim3(1), dim3(1), 0, stream, n_kept, 0);
     hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys);
-    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, 64, stream);
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, key_bits(A64.ms, ns), stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
     int rc = launch_rescore_f64(A64, rows, cols, n_cand, vals, nullptr, stream);

@@ -1356,6 +1356,7 @@ namespace {
 struct CandPlan {
     size_t off_cols = 0, off_vals = 0, off_cnt = 0, off_win = 0, off_tail = 0;
     long long n_cand = 0;
+    int row_major = 0;       // the candidate list is already sorted row-major (1-D patterns)
 };
 
 int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_kernel* kernel,
@@ -1408,7 +1409,7 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
             if (rc) return rc;
             char* pool = (char*)ctx->d_pool;
             rc = cs::enqueue_enumerate_band(rb, re, p->ns, map.band_lo, map.band_w, n_cand, (int*)pool,
-                                            (int*)(pool + P->off_cols), stream);
+                                            (int*)(pool + P->off_cols), stream, &P->row_major);
             if (rc) return fail(ctx, CS_ERR_HIP, "enumerate launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
         P->n_cand = n_cand;
@@ -1472,8 +1473,36 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
     long long* d_cnt = (long long*)(pool + P.off_cnt);
     double* d_win = fp->want_windows ? (double*)(pool + P.off_win) : nullptr;
     cs::FocusRec* d_rec = nullptr;
+    // Page-locked output buffers (what cs_host_alloc hands out) are written by the last kernel itself: one
+    // stream synchronisation per call instead of a count round trip plus two copies.
+    auto device_view = [&](const void* h) -> void* {
+        if (!h) return nullptr;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, h) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
+    };
+    cs::FocusRec* rec_direct = cap > 0 ? reinterpret_cast<cs::FocusRec*>(device_view(h_foci)) : nullptr;
+    double* win_direct = (fp->want_windows && h_windows) ? reinterpret_cast<double*>(device_view(h_windows)) : nullptr;
+    const bool direct = rec_direct && (!fp->want_windows || !h_windows || win_direct) && !std::getenv("CHROMOSIGHT_HIP_NO_DIRECT_RESULTS");
+    if (direct) {
+        ctx->h_counts[1] = -1;
+        rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + P.off_cols), n_cand, fp->pearson, fp->min_size,
+                              fp->diag_only, fp->inter, pool + P.off_tail, &d_rec, win_direct, win_direct ? (long long)cap : 0,
+                              d_cnt + 1, stream, P.row_major, rec_direct, (long long)cap, ctx->h_counts + 1);
+        if (rc) return fail(ctx, CS_ERR_HIP, "foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        const long long n = ctx->h_counts[1];
+        if (n < 0) return fail(ctx, CS_ERR_HIP, "foci kernels did not report a count");
+        *n_foci = n;
+        if (n > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", n, (long long)cap);
+        return CS_OK;
+    }
     rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + P.off_cols), n_cand, fp->pearson, fp->min_size,
-                          fp->diag_only, fp->inter, pool + P.off_tail, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream);
+                          fp->diag_only, fp->inter, pool + P.off_tail, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream,
+                          P.row_major, nullptr, 0, nullptr);
     if (rc) return fail(ctx, CS_ERR_HIP, "foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts + 1, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream));
     CS_HIP(ctx, hipStreamSynchronize(stream));

@@ -206,6 +206,113 @@ __global__ __launch_bounds__(kThreads) void emit_foci_kernel(const int* __restri
     if (t == cap - 1) *n_foci = pos[t] + flag[t];     // flags are 0 beyond n, so this is the total
 }
 
+// ---- short candidate lists: threshold, compaction, labelling, per-focus maximum in ONE launch -----
+// A detect call on one sub-matrix is a chain of ~35 dependent launches that process a few thousand
+// candidates; each of those kernels lasts 4-5 us however little it does, so 23 sub-matrices x 4 templates
+// were bound by the launch chain (borders: 4 ms per template for 1.2 Mpixel).  One workgroup of 1024
+// threads walks the same phases over the same global arrays with a workgroup barrier between them.
+constexpr int kSmallThreads = 1024;
+constexpr long long kSmallMax = 1 << 16;          // candidates a single workgroup takes (64 per thread)
+
+// exclusive scan of flag[0..n) into pos[0..n), total returned to every thread; chunk per thread
+__device__ __forceinline__ int block_scan_flags(const int* __restrict__ flag, int* __restrict__ pos, long long n,
+                                                int* __restrict__ lds_part)
+{
+    const int tid = threadIdx.x;
+    const long long chunk = (n + kSmallThreads - 1) / kSmallThreads;
+    const long long b = min(n, (long long)tid * chunk), e = min(n, b + chunk);
+    int cnt = 0;
+    for (long long t = b; t < e; ++t) cnt += flag[t];
+    lds_part[tid] = cnt;
+    __syncthreads();
+    // Hillis-Steele over the 1024 partial counts
+    for (int off = 1; off < kSmallThreads; off <<= 1) {
+        const int add = tid >= off ? lds_part[tid - off] : 0;
+        __syncthreads();
+        lds_part[tid] += add;
+        __syncthreads();
+    }
+    const int total = lds_part[kSmallThreads - 1];
+    int run = lds_part[tid] - cnt;
+    for (long long t = b; t < e; ++t) {
+        pos[t] = run;
+        run += flag[t];
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(kSmallThreads) void foci_small_kernel(
+    const long long* __restrict__ keys_s, const double* __restrict__ vals, long long n_cand, double pearson, int ns,
+    int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos, long long* __restrict__ keys_k,
+    double* __restrict__ vals_k, int* __restrict__ parent, int* __restrict__ size, unsigned long long* __restrict__ best_val,
+    int* __restrict__ best_idx, int* __restrict__ out_rows, int* __restrict__ out_cols, int* __restrict__ out_size,
+    int* __restrict__ n_kept_out, long long* __restrict__ n_foci)
+{
+    __shared__ int part[kSmallThreads];
+    const int tid = threadIdx.x;
+    // (1) exact threshold (detection.py:417-421), stable compaction
+    for (long long t = tid; t < n_cand; t += kSmallThreads) flag[t] = (vals[t] >= pearson && vals[t] != 0.0) ? 1 : 0;
+    __syncthreads();
+    const int n = block_scan_flags(flag, pos, n_cand, part);
+    for (long long t = tid; t < n_cand; t += kSmallThreads)
+        if (flag[t]) {
+            keys_k[pos[t]] = keys_s[t];
+            vals_k[pos[t]] = vals[t];
+        }
+    if (tid == 0) *n_kept_out = n;
+    // (2) 4-connected foci of the kept pixels: union-find, root = first pixel in row-major order
+    for (int t = tid; t < n; t += kSmallThreads) {
+        parent[t] = t;
+        size[t] = 0;
+        best_val[t] = 0ull;
+        best_idx[t] = INT_MAX;
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) {
+        const long long key = keys_k[t];
+        const int col = (int)(key % ns);
+        if (t + 1 < n && col + 1 < ns && keys_k[t + 1] == key + 1) uf_union(parent, t, t + 1);
+        long long lo = t + 1, hi = n;
+        const long long want = key + ns;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (keys_k[mid] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < n && keys_k[lo] == want) uf_union(parent, t, (int)lo);
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) parent[t] = uf_find(parent, t);
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) {
+        const int r = parent[t];
+        atomicAdd(size + r, 1);
+        atomicMax(best_val + r, order_key(vals_k[t]));
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) {
+        const int r = parent[t];
+        if (order_key(vals_k[t]) == best_val[r]) atomicMin(best_idx + r, t);
+    }
+    __syncthreads();
+    // (3) foci of at least min_size pixels, in the order of their first pixels
+    for (int t = tid; t < n; t += kSmallThreads) flag[t] = (parent[t] == t && size[t] >= min_size) ? 1 : 0;
+    __syncthreads();
+    const int n_out = block_scan_flags(flag, pos, n, part);
+    for (int t = tid; t < n; t += kSmallThreads)
+        if (flag[t]) {
+            const long long key = keys_k[best_idx[t]];
+            int row = (int)(key / ns);
+            const int col = (int)(key - (long long)row * ns);
+            if (diag_only) row = col;
+            out_rows[pos[t]] = row;
+            out_cols[pos[t]] = col;
+            out_size[pos[t]] = size[t];
+        }
+    if (tid == 0) *n_foci = n_out;
+}
+
 // ---- window statistics of validate_patterns, one wave per pattern --------------------------------
 // The map pattern_detector validates on (detection.py:287-310) is never built: the contact map framed
 // by (kw rows, kh columns) of zeros when full, NaN on the max(km, kn) first sub-diagonals of intra
@@ -217,11 +324,14 @@ __global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<d
                                                                 const double* __restrict__ nobs,
                                                                 const long long* __restrict__ n_ptr, long long n_fixed,
                                                                 FocusRec* __restrict__ rec, double* __restrict__ windows,
-                                                                long long win_cap)
+                                                                long long win_cap, long long rec_cap, long long* __restrict__ n_out)
 {
+    // rec / windows / n_out may be page-locked HOST memory (results written over the link, no copy call):
+    // nothing beyond the caller's capacities is touched, and the count is published even when it is 0
     const long long n = n_ptr ? *n_ptr : n_fixed;
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
+    if (t == 0 && lane == 0 && n_out) *n_out = n;
     if (t >= n) return;
     const int km = A.km, kn = A.kn, kk = km * kn;
     const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
@@ -272,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<d
         r.focus_size = focus_size ? focus_size[t] : 0;
         r.score = score[t];
         r.n_obs = nobs[t];
-        rec[t] = r;
+        if (t < rec_cap) rec[t] = r;
     }
 }
 
@@ -322,7 +432,8 @@ static inline int key_bits(long long ms, long long ns)
 
 int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,
                  int min_size, int diag_only, int inter, void* scratch, FocusRec** d_rec_out, double* d_windows,
-                 long long win_cap, long long* d_n_foci, hipStream_t stream)
+                 long long win_cap, long long* d_n_foci, hipStream_t stream, int presorted, FocusRec* rec_target,
+                 long long rec_cap, long long* n_out)
 {
     const int ns = A64.ns;
     Bump b{(char*)scratch};
@@ -352,17 +463,33 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     double* f_nobs = b.take<double>(n);
     FocusRec* rec = b.take<FocusRec>(n);
     int* n_kept = b.take<int>(64);
+    if (rec_target) rec = rec_target;          // caller's (page-locked host) records, rec_cap of them
+    else rec_cap = (long long)n;
     *d_rec_out = rec;
     const unsigned g = blocks_for(n_cand);
 
-    // row-major order of the candidates
-    hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys);
-    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, key_bits(A64.ms, ns), stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
+    // row-major order of the candidates (a list that already has it only needs its keys)
+    hipError_t e = hipSuccess;
+    const int* s_rows = rows;
+    const int* s_cols = cols;
+    if (presorted) {
+        hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys_s);
+        s_rows = d_rows;
+        s_cols = d_cols;
+    } else {
+        hipLaunchKernelGGL(make_keys_kernel, dim3(g), dim3(kThreads), 0, stream, d_rows, d_cols, n_cand, ns, keys);
+        e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_s, (int)n_cand, 0, key_bits(A64.ms, ns), stream);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
+    }
     // exact coefficients, exact threshold
-    int rc = launch_rescore_f64(A64, rows, cols, n_cand, vals, nullptr, stream);
+    int rc = launch_rescore_f64(A64, s_rows, s_cols, n_cand, vals, nullptr, stream);
     if (rc) return rc;
+    if (n_cand <= kSmallMax && !getenv("CHROMOSIGHT_HIP_NO_FUSED_FOCI")) {
+        hipLaunchKernelGGL(foci_small_kernel, dim3(1), dim3(kSmallThreads), 0, stream, keys_s, vals, n_cand, pearson, ns, min_size,
+                           diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, f_rows, f_cols, f_size, n_kept,
+                           d_n_foci);
+    } else {
     hipLaunchKernelGGL(flag_keep_kernel, dim3(g), dim3(kThreads), 0, stream, vals, n_cand, pearson, flag);
     e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flag, pos, (int)n_cand, stream);
     if (e != hipSuccess) return (int)e;
@@ -379,6 +506,7 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(emit_foci_kernel, dim3(g), dim3(kThreads), 0, stream, n_kept, flag, pos, best_idx, size, keys_k, ns,
                        diag_only, f_rows, f_cols, f_size, n_cand, d_n_foci);
+    }
     // score / n_obs at the final coordinates (they move for 1-D patterns), window statistics.
     // The number of foci stays on the device: launched for the worst case (n_cand / min_size foci),
     // surplus waves exit on the device-side count.
@@ -386,7 +514,7 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     rc = launch_rescore_f64(A64, f_rows, f_cols, max_foci, f_score, f_nobs, stream, d_n_foci);
     if (rc) return rc;
     hipLaunchKernelGGL(window_stats_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, A64, inter,
-                       f_rows, f_cols, f_size, f_score, f_nobs, d_n_foci, 0ll, rec, d_windows, win_cap);
+                       f_rows, f_cols, f_size, f_score, f_nobs, d_n_foci, 0ll, rec, d_windows, win_cap, rec_cap, n_out);
     return (int)hipGetLastError();
 }
 
@@ -514,6 +642,34 @@ int enqueue_label(const int* d_rows, const int* d_cols, const double* d_vals, lo
 
 // ---- 1-D patterns: every pixel of a band of at most 4 diagonals is a candidate ---------------------
 namespace {
+// row-major enumeration of the band lo .. lo + w - 1 (lo >= 0) over the rows rb .. re - 1: rows whose w
+// pixels all exist come first (w per row), the last rows lose one pixel each
+__global__ __launch_bounds__(kThreads) void enumerate_band_rowmajor_kernel(int rb, int re, int ns, int lo, int w, long long n,
+                                                                           int* __restrict__ rows, int* __restrict__ cols)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n) return;
+    const int last_full = min(re, ns - lo - w + 1);              // rows < last_full have all w pixels
+    const long long full = (long long)max(last_full - rb, 0) * w;
+    int row, x;
+    if (t < full) {
+        row = rb + (int)(t / w);
+        x = (int)(t - (long long)(row - rb) * w);
+    } else {
+        long long rest = t - full;
+        row = max(last_full, rb);
+        for (;;) {                                               // at most w - 1 short rows
+            const int cnt = max(0, min(w, ns - row - lo));
+            if (rest < cnt) break;
+            rest -= cnt;
+            ++row;
+        }
+        x = (int)rest;
+    }
+    rows[t] = row;
+    cols[t] = row + lo + x;
+}
+
 __global__ __launch_bounds__(kThreads) void enumerate_band_kernel(int rb, int re, int ns, int lo, int w, long long n,
                                                                   int* __restrict__ rows, int* __restrict__ cols)
 {
@@ -547,9 +703,18 @@ long long narrow_band_pixels(int rb, int re, int ns, int lo, int w)
     return n;
 }
 
-int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream)
+int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream,
+                           int* row_major)
 {
+    *row_major = 0;
     if (n <= 0) return 0;
+    if (lo >= 0) {
+        // the list comes out in the row-major order the foci stages need: no sort
+        *row_major = 1;
+        hipLaunchKernelGGL(enumerate_band_rowmajor_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, rb, re, ns, lo, w, n,
+                           d_rows, d_cols);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(enumerate_band_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, rb, re, ns, lo, w, n, d_rows, d_cols);
     return (int)hipGetLastError();
 }
@@ -650,7 +815,8 @@ int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* 
     int rc = launch_rescore_f64(A64, d_rows, d_cols, n, d_score, d_nobs, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(window_stats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kThreads), 0, stream, A64, inter, d_rows,
-                       d_cols, (const int*)nullptr, d_score, d_nobs, (const long long*)nullptr, n, d_rec, d_windows, n);
+                       d_cols, (const int*)nullptr, d_score, d_nobs, (const long long*)nullptr, n, d_rec, d_windows, n, n,
+                       (long long*)nullptr);
     return (int)hipGetLastError();
 }
 

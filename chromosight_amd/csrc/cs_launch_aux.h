@@ -66,13 +66,15 @@ int enqueue_label(const int* d_rows, const int* d_cols, const double* d_vals, lo
 
 // 1-D patterns: all pixels of a band of a few diagonals as the candidate list (cs_foci.hip)
 long long narrow_band_pixels(int rb, int re, int ns, int lo, int w);      // rows rb <= i < re
-int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream);
+int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, int* d_rows, int* d_cols, hipStream_t stream,
+                           int* row_major);      // *row_major = 1: the list is already in row-major order
 
 // device-side foci (cs_foci.hip)
 size_t foci_scratch_bytes(long long n_cand);
 int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n_cand, double pearson,
                  int min_size, int diag_only, int inter, void* scratch, FocusRec** d_rec_out, double* d_windows,
-                 long long win_cap, long long* d_n_foci, hipStream_t stream);
+                 long long win_cap, long long* d_n_foci, hipStream_t stream, int presorted, FocusRec* rec_target,
+                 long long rec_cap, long long* n_out);
 int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n, int inter,
                      double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream);
 

@@ -152,6 +152,8 @@ _PROTOTYPES = {
     "cs_detect_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                  C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64), C.c_void_p]),
+    "cs_detect_foci_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(CsKernel), C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cs_quantify_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),

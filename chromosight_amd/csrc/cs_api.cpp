@@ -54,6 +54,8 @@ struct cs_ctx {
         bool sym = false;
         int zk_possible = 1, snap_possible = 1;
     } tcache[2];
+    long long* h_blk_counts = nullptr;     // page-locked: total + per-block foci counts of cs_detect_foci_batch
+    size_t h_blk_bytes = 0;
     void* d_narrow = nullptr;       // float32 copy of a float64 dense signal for the matrix-core kernel
     size_t d_narrow_bytes = 0;
     // cs_normxcorr2_host: device staging of the map, pinned bounce buffer of the float32 result, three
@@ -786,6 +788,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
+    if (ctx->h_blk_counts) (void)hipHostFree(ctx->h_blk_counts);
     if (ctx->d_host_in) (void)hipFree(ctx->d_host_in);
     if (ctx->d_host_out) (void)hipFree(ctx->d_host_out);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
@@ -1515,6 +1518,78 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
             CS_HIP(ctx, hipMemcpyAsync(h_windows, d_win, 8 * (size_t)n * kk, hipMemcpyDeviceToHost, stream));
         CS_HIP(ctx, hipStreamSynchronize(stream));
     }
+    return CS_OK;
+}
+
+int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
+                         const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci, int64_t cap,
+                         int64_t* h_n_foci, double* h_windows)
+{
+    CS_ENTER(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_blocks <= 0 || !signals || !kernel || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
+        return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
+    const int kk = kernel->km * kernel->kn;
+    std::vector<cs::CorrArgs<double>> tab((size_t)n_blocks);
+    std::vector<long long> seg((size_t)n_blocks + 1, 0);
+    std::vector<int> lo_w(2 * (size_t)n_blocks);
+    for (int b = 0; b < n_blocks; ++b) {
+        const cs_normxcorr2_params* p = params + b;
+        const cs_foci_params* fp = foci + b;
+        int rc = check_foci_args(ctx, signals + b, kernel, p, fp);
+        if (rc) return rc;
+        const int w = fp->hi_diag - fp->lo_diag + 1;
+        if (signals[b].layout != CS_LAYOUT_BAND || w < 1 || w > 4 || fp->lo_diag < 0 || (p->row_end > p->row_begin))
+            return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry takes 1-D patterns (<= 4 scanned diagonals from 0 up) of whole banded blocks");
+        if (fp->pearson != foci[0].pearson || fp->min_size != foci[0].min_size || fp->diag_only != foci[0].diag_only ||
+            fp->inter != foci[0].inter || fp->want_windows != foci[0].want_windows)
+            return fail(ctx, CS_ERR_INVALID, "the blocks of a batch share the detection parameters");
+        const long long n_b = cs::narrow_band_pixels(0, p->ms, p->ns, fp->lo_diag, w);
+        if (n_b > cs::kFociSmallMax) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d has %lld candidate pixels", b, n_b);
+        seg[b + 1] = seg[b] + n_b;
+        lo_w[2 * b] = fp->lo_diag;
+        lo_w[2 * b + 1] = w;
+        rc = build_args<double>(ctx, stream, signals + b, kernel, p, &tab[b]);
+        if (rc) return rc;
+    }
+    const long long n_total = seg[n_blocks];
+    if (n_total > INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%lld)", n_total);
+    // results straight into page-locked caller buffers (cs_host_alloc); anything else goes through cs_detect_foci
+    auto device_view = [&](const void* h) -> void* {
+        if (!h) return nullptr;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, h) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
+    };
+    cs::FocusRec* rec = cap > 0 ? reinterpret_cast<cs::FocusRec*>(device_view(h_foci)) : nullptr;
+    double* win = (foci[0].want_windows && h_windows) ? reinterpret_cast<double*>(device_view(h_windows)) : nullptr;
+    if ((cap > 0 && !rec) || (foci[0].want_windows && h_windows && !win))
+        return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry writes into page-locked buffers (cs_host_alloc)");
+    // per-block counts through a page-locked array owned by the context
+    const size_t cnt_bytes = 8 * ((size_t)n_blocks + 2);
+    if (cnt_bytes > ctx->h_blk_bytes) {
+        if (ctx->h_blk_counts) CS_HIP(ctx, hipHostFree(ctx->h_blk_counts));
+        ctx->h_blk_counts = nullptr;
+        ctx->h_blk_bytes = 0;
+        CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_blk_counts, 2 * cnt_bytes, hipHostMallocDefault));
+        ctx->h_blk_bytes = 2 * cnt_bytes;
+    }
+    ctx->h_blk_counts[0] = -1;
+    int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, cs::narrow_batch_scratch_bytes(n_blocks, n_total));
+    if (rc) return rc;
+    rc = cs::enqueue_foci_narrow_batch(tab.data(), seg.data(), lo_w.data(), n_blocks, foci[0].pearson, foci[0].min_size,
+                                       foci[0].diag_only, foci[0].inter, ctx->d_pool, rec, (long long)cap, win,
+                                       win ? (long long)cap : 0, ctx->h_blk_counts, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host tables above were consumed
+    const long long total = ctx->h_blk_counts[0];
+    if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
+    for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
+    if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
+    (void)kk;
     return CS_OK;
 }
 

@@ -374,13 +374,6 @@ int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, doub
 // fixed-order butterfly reduction.  Lists are short (tens to thousands of pixels), so one lane per
 // pixel left the chip empty and a call cost the latency of 289 dependent loads.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double> A, const int* __restrict__ rows,
                                                           const int* __restrict__ cols, long long n_px,
                                                           double* __restrict__ out_corr,
@@ -390,37 +383,8 @@ __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double>
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= n_px || (n_ptr && t >= *n_ptr)) return;
-    const int oi = rows[t], oj = cols[t];
-    double r = 0.0, nobs = A.ks.n;
-    const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
-    if (inside && !pixel_forced_zero(A, oi, oj)) {       // wave-uniform
-        const int km = A.km, kn = A.kn, kk = km * kn;
-        const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
-        const bool masked = A.mask_mode != 0;
-        double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
-        for (int e = lane; e < kk; e += 64) {
-            const int ki = e / kn, kj = e - ki * kn;
-            const int p = oi - kh + ki, q = oj - kw + kj;
-            const double v = load_signal(A, p, q);
-            cs_ = fma(v, A.w[e], cs_);
-            s1 += v;
-            s2 = fma(v, v, s2);
-            if (masked && missing_pred(A, p, q)) {
-                nm += 1.0;
-                ka += A.w[kk + e];
-                kb += A.w[2 * kk + e];
-            }
-        }
-        cs_ = wave_sum(cs_);
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (masked) {
-            nm = wave_sum(nm);
-            ka = wave_sum(ka);
-            kb = wave_sum(kb);
-        }
-        r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
-    }
+    double r, nobs;
+    rescore_pixel(A, rows[t], cols[t], lane, r, nobs);
     if (lane == 0) {
         out_corr[t] = r;
         if (out_nobs) out_nobs[t] = nobs;

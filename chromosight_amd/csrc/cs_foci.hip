@@ -242,14 +242,13 @@ __device__ __forceinline__ int block_scan_flags(const int* __restrict__ flag, in
     return total;
 }
 
-__global__ __launch_bounds__(kSmallThreads) void foci_small_kernel(
+__device__ __forceinline__ void foci_small_body(
     const long long* __restrict__ keys_s, const double* __restrict__ vals, long long n_cand, double pearson, int ns,
     int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos, long long* __restrict__ keys_k,
     double* __restrict__ vals_k, int* __restrict__ parent, int* __restrict__ size, unsigned long long* __restrict__ best_val,
     int* __restrict__ best_idx, int* __restrict__ out_rows, int* __restrict__ out_cols, int* __restrict__ out_size,
-    int* __restrict__ n_kept_out, long long* __restrict__ n_foci)
+    int* __restrict__ n_kept_out, long long* __restrict__ n_foci, int* __restrict__ part)
 {
-    __shared__ int part[kSmallThreads];
     const int tid = threadIdx.x;
     // (1) exact threshold (detection.py:417-421), stable compaction
     for (long long t = tid; t < n_cand; t += kSmallThreads) flag[t] = (vals[t] >= pearson && vals[t] != 0.0) ? 1 : 0;
@@ -313,26 +312,143 @@ __global__ __launch_bounds__(kSmallThreads) void foci_small_kernel(
     if (tid == 0) *n_foci = n_out;
 }
 
+__global__ __launch_bounds__(kSmallThreads) void foci_small_kernel(
+    const long long* __restrict__ keys_s, const double* __restrict__ vals, long long n_cand, double pearson, int ns,
+    int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos, long long* __restrict__ keys_k,
+    double* __restrict__ vals_k, int* __restrict__ parent, int* __restrict__ size, unsigned long long* __restrict__ best_val,
+    int* __restrict__ best_idx, int* __restrict__ out_rows, int* __restrict__ out_cols, int* __restrict__ out_size,
+    int* __restrict__ n_kept_out, long long* __restrict__ n_foci)
+{
+    __shared__ int part[kSmallThreads];
+    foci_small_body(keys_s, vals, n_cand, pearson, ns, min_size, diag_only, flag, pos, keys_k, vals_k, parent, size, best_val,
+                    best_idx, out_rows, out_cols, out_size, n_kept_out, n_foci, part);
+}
+
+// ---- 1-D patterns of MANY sub-matrices with one launch chain (cs_detect_foci_batch) ----------------
+// A borders template scans 2 diagonals of every chromosome: per sub-matrix that is ~0.1 ms of tiny kernels
+// and a host synchronisation, and the calls of different host threads hardly overlap on the GPU.  Here the
+// candidate lists of all sub-matrices are one array with segment offsets; every kernel finds its
+// sub-matrix's arguments in a device table.
+__device__ __forceinline__ int segment_of(const long long* __restrict__ seg, int n_seg, long long t)
+{
+    int lo = 0, hi = n_seg - 1;                  // seg[lo] <= t < seg[hi + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kThreads) void narrow_enumerate_batch_kernel(const CorrArgs<double>* __restrict__ tab,
+                                                                         const long long* __restrict__ seg,
+                                                                         const int2* __restrict__ lo_w, int n_blocks,
+                                                                         int* __restrict__ rows, int* __restrict__ cols,
+                                                                         long long* __restrict__ keys, int* __restrict__ blk)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= seg[n_blocks]) return;
+    const int b = segment_of(seg, n_blocks, t);
+    const int rb = tab[b].row_begin, re = tab[b].row_end, ns = tab[b].ns, lo = lo_w[b].x, w = lo_w[b].y;
+    const long long local = t - seg[b];
+    const int last_full = min(re, ns - lo - w + 1);
+    const long long full = (long long)max(last_full - rb, 0) * w;
+    int row, x;
+    if (local < full) {
+        row = rb + (int)(local / w);
+        x = (int)(local - (long long)(row - rb) * w);
+    } else {
+        long long rest = local - full;
+        row = max(last_full, rb);
+        for (;;) {
+            const int cnt = max(0, min(w, ns - row - lo));
+            if (rest < cnt) break;
+            rest -= cnt;
+            ++row;
+        }
+        x = (int)rest;
+    }
+    rows[t] = row;
+    cols[t] = row + lo + x;
+    keys[t] = (long long)row * ns + (row + lo + x);
+    blk[t] = b;
+}
+
+__global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
+                                                            const int* __restrict__ rows, const int* __restrict__ cols,
+                                                            long long n_px, const long long* __restrict__ n_ptr,
+                                                            double* __restrict__ out_corr, double* __restrict__ out_nobs)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_px || (n_ptr && t >= *n_ptr)) return;
+    double r, nobs;
+    rescore_pixel(tab[blk[t]], rows[t], cols[t], lane, r, nobs);
+    if (lane == 0) {
+        out_corr[t] = r;
+        if (out_nobs) out_nobs[t] = nobs;
+    }
+}
+
+__global__ __launch_bounds__(kSmallThreads) void foci_small_batch_kernel(
+    const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ seg, const long long* __restrict__ keys_s,
+    const double* __restrict__ vals, double pearson, int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos,
+    long long* __restrict__ keys_k, double* __restrict__ vals_k, int* __restrict__ parent, int* __restrict__ size,
+    unsigned long long* __restrict__ best_val, int* __restrict__ best_idx, int* __restrict__ out_rows, int* __restrict__ out_cols,
+    int* __restrict__ out_size, int* __restrict__ n_kept, long long* __restrict__ n_foci_blk)
+{
+    __shared__ int part[kSmallThreads];
+    const int b = blockIdx.x;
+    const long long o = seg[b], n_cand = seg[b + 1] - o;
+    foci_small_body(keys_s + o, vals + o, n_cand, pearson, tab[b].ns, min_size, diag_only, flag + o, pos + o, keys_k + o, vals_k + o,
+                    parent + o, size + o, best_val + o, best_idx + o, out_rows + o, out_cols + o, out_size + o, n_kept + b,
+                    n_foci_blk + b, part);
+}
+
+// the foci of all sub-matrices, block after block: offsets from the per-block counts (one workgroup),
+// the per-block counts and the total also go to (page-locked) host memory
+__global__ __launch_bounds__(kSmallThreads) void gather_foci_batch_kernel(const long long* __restrict__ seg,
+                                                                         const long long* __restrict__ n_foci_blk, int n_blocks,
+                                                                         const int* __restrict__ seg_rows, const int* __restrict__ seg_cols,
+                                                                         const int* __restrict__ seg_size, int* __restrict__ f_rows,
+                                                                         int* __restrict__ f_cols, int* __restrict__ f_size,
+                                                                         int* __restrict__ f_blk, long long* __restrict__ f_off,
+                                                                         long long* __restrict__ d_total, long long* __restrict__ h_counts)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        long long acc = 0;
+        for (int b = 0; b < n_blocks; ++b) {
+            f_off[b] = acc;
+            acc += n_foci_blk[b];
+            if (h_counts) h_counts[1 + b] = n_foci_blk[b];
+        }
+        f_off[n_blocks] = acc;
+        *d_total = acc;
+        if (h_counts) h_counts[0] = acc;
+    }
+    __syncthreads();
+    for (int b = 0; b < n_blocks; ++b) {
+        const long long src = seg[b], dst = f_off[b], cnt = n_foci_blk[b];
+        for (long long t = tid; t < cnt; t += kSmallThreads) {
+            f_rows[dst + t] = seg_rows[src + t];
+            f_cols[dst + t] = seg_cols[src + t];
+            f_size[dst + t] = seg_size[src + t];
+            f_blk[dst + t] = b;
+        }
+    }
+}
+
+
 // ---- window statistics of validate_patterns, one wave per pattern --------------------------------
 // The map pattern_detector validates on (detection.py:287-310) is never built: the contact map framed
 // by (kw rows, kh columns) of zeros when full, NaN on the max(km, kn) first sub-diagonals of intra
 // maps, NaN on every row / column that is not a detectable bin; coordinates shifted by (kh, kw).
-__global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<double> A, int inter,
-                                                                const int* __restrict__ rows, const int* __restrict__ cols,
-                                                                const int* __restrict__ focus_size,
-                                                                const double* __restrict__ score,
-                                                                const double* __restrict__ nobs,
-                                                                const long long* __restrict__ n_ptr, long long n_fixed,
-                                                                FocusRec* __restrict__ rec, double* __restrict__ windows,
-                                                                long long win_cap, long long rec_cap, long long* __restrict__ n_out)
+// window statistics of one pattern by one wave (validate_patterns, detection.py:18-155); rec_out / win_out
+// may be nullptr (beyond the caller's capacity) or page-locked host memory
+__device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, int inter, int row, int col, int fsize, double score,
+                                                     double nobs, FocusRec* rec_out, double* win_out, int lane)
 {
-    // rec / windows / n_out may be page-locked HOST memory (results written over the link, no copy call):
-    // nothing beyond the caller's capacities is touched, and the count is published even when it is 0
-    const long long n = n_ptr ? *n_ptr : n_fixed;
-    const int lane = threadIdx.x & 63;
-    const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
-    if (t == 0 && lane == 0 && n_out) *n_out = n;
-    if (t >= n) return;
     const int km = A.km, kn = A.kn, kk = km * kn;
     const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
     const int half_h = km / 2 + 1, half_w = kn / 2 + 1;
@@ -340,7 +456,6 @@ __global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<d
     const int sh_r = A.full ? kh : 0, sh_c = A.full ? kw : 0;       // coords += (kh, kw)
     const int H = A.ms + 2 * pad_r, W = A.ns + 2 * pad_c;
     const int big_k = inter ? 0 : max(km, kn);
-    const int row = rows[t], col = cols[t];
     const int p1 = row + sh_r, p2 = col + sh_c;
     const int high = p1 - half_h + 1, low = p1 + half_h;
     const int left = p2 - half_w + 1, right = p2 + half_w;
@@ -365,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<d
             n_zero += (fin && v == 0.0) ? 1 : 0;
             n_miss += fin ? 0 : 1;
         }
-        if (windows && t < win_cap) windows[t * kk + e] = v;
+        if (win_out) win_out[e] = v;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -379,11 +494,49 @@ __global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<d
         r.inside = inside ? 1 : 0;
         r.n_zero = n_zero;
         r.n_missing = n_miss;
-        r.focus_size = focus_size ? focus_size[t] : 0;
-        r.score = score[t];
-        r.n_obs = nobs[t];
-        if (t < rec_cap) rec[t] = r;
+        r.focus_size = fsize;
+        r.score = score;
+        r.n_obs = nobs;
+        if (rec_out) *rec_out = r;
     }
+}
+
+__global__ __launch_bounds__(kThreads) void window_stats_kernel(const CorrArgs<double> A, int inter,
+                                                                const int* __restrict__ rows, const int* __restrict__ cols,
+                                                                const int* __restrict__ focus_size,
+                                                                const double* __restrict__ score,
+                                                                const double* __restrict__ nobs,
+                                                                const long long* __restrict__ n_ptr, long long n_fixed,
+                                                                FocusRec* __restrict__ rec, double* __restrict__ windows,
+                                                                long long win_cap, long long rec_cap, long long* __restrict__ n_out)
+{
+    // rec / windows / n_out may be page-locked HOST memory (results written over the link, no copy call):
+    // nothing beyond the caller's capacities is touched, and the count is published even when it is 0
+    const long long n = n_ptr ? *n_ptr : n_fixed;
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
+    if (t == 0 && lane == 0 && n_out) *n_out = n;
+    if (t >= n) return;
+    const int kk = A.km * A.kn;
+    window_stats_pattern(A, inter, rows[t], cols[t], focus_size ? focus_size[t] : 0, score[t], nobs[t],
+                         t < rec_cap ? rec + t : nullptr, (windows && t < win_cap) ? windows + t * kk : nullptr, lane);
+}
+
+__global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const CorrArgs<double>* __restrict__ tab, int inter,
+                                                                      const int* __restrict__ blk, const int* __restrict__ rows,
+                                                                      const int* __restrict__ cols, const int* __restrict__ focus_size,
+                                                                      const double* __restrict__ score, const double* __restrict__ nobs,
+                                                                      const long long* __restrict__ n_ptr, FocusRec* __restrict__ rec,
+                                                                      double* __restrict__ windows, long long win_cap, long long rec_cap)
+{
+    const long long n = *n_ptr;
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const CorrArgs<double>& A = tab[blk[t]];
+    const int kk = A.km * A.kn;
+    window_stats_pattern(A, inter, rows[t], cols[t], focus_size[t], score[t], nobs[t], t < rec_cap ? rec + t : nullptr,
+                         (windows && t < win_cap) ? windows + t * kk : nullptr, lane);
 }
 
 }  // namespace
@@ -716,6 +869,85 @@ int enqueue_enumerate_band(int rb, int re, int ns, int lo, int w, long long n, i
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(enumerate_band_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, rb, re, ns, lo, w, n, d_rows, d_cols);
+    return (int)hipGetLastError();
+}
+
+// ---- host side of the batched 1-D pattern chain ----------------------------------------------------
+size_t narrow_batch_scratch_bytes(int n_blocks, long long n_total)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
+    return al(sizeof(CorrArgs<double>) * nb) + al(8 * nb) + al(8 * nb) + 4 * al(8 * n) + 5 * al(8 * n) + 16 * al(4 * n) +
+           4 * al(8 * nb) + 4096;
+}
+
+// h_tab / h_seg / h_lo_w: host arrays of n_blocks (+1 for seg); results: records (and windows) block after
+// block into rec / windows (device-visible, capacities rec_cap / win_cap), h_counts[0] = total,
+// h_counts[1 + b] = foci of block b (device-visible page-locked memory)
+int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_seg, const int* h_lo_w, int n_blocks, double pearson,
+                              int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
+                              double* windows, long long win_cap, long long* h_counts, hipStream_t stream)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const long long n_total = h_seg[n_blocks];
+    const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
+    Bump b{(char*)scratch};
+    (void)al;
+    CorrArgs<double>* tab = b.take<CorrArgs<double>>(nb);
+    long long* seg = b.take<long long>(nb);
+    int2* lo_w = reinterpret_cast<int2*>(b.take<long long>(nb));
+    long long* keys = b.take<long long>(n);
+    long long* keys_k = b.take<long long>(n);
+    double* vals = b.take<double>(n);
+    double* vals_k = b.take<double>(n);
+    unsigned long long* best_val = b.take<unsigned long long>(n);
+    double* f_score = b.take<double>(n);
+    double* f_nobs = b.take<double>(n);
+    long long* spare64 = b.take<long long>(n);
+    (void)spare64;
+    int* rows = b.take<int>(n);
+    int* cols = b.take<int>(n);
+    int* blk = b.take<int>(n);
+    int* flag = b.take<int>(n);
+    int* pos = b.take<int>(n);
+    int* parent = b.take<int>(n);
+    int* size = b.take<int>(n);
+    int* best_idx = b.take<int>(n);
+    int* s_rows = b.take<int>(n);
+    int* s_cols = b.take<int>(n);
+    int* s_size = b.take<int>(n);
+    int* f_rows = b.take<int>(n);
+    int* f_cols = b.take<int>(n);
+    int* f_size = b.take<int>(n);
+    int* f_blk = b.take<int>(n);
+    int* n_kept = b.take<int>(nb);
+    long long* n_foci_blk = b.take<long long>(nb);
+    long long* f_off = b.take<long long>(nb);
+    long long* d_total = b.take<long long>(8);
+    hipError_t e = hipMemcpyAsync(tab, h_tab, sizeof(CorrArgs<double>) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(seg, h_seg, 8 * nb, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(lo_w, h_lo_w, 8 * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    if (n_total > 0) {
+        const unsigned g = blocks_for(n_total);
+        hipLaunchKernelGGL(narrow_enumerate_batch_kernel, dim3(g), dim3(kThreads), 0, stream, tab, seg, lo_w, n_blocks, rows, cols, keys,
+                           blk);
+        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
+                           (const long long*)nullptr, vals, (double*)nullptr);
+    }
+    hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, keys, vals, pearson, min_size,
+                       diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
+    hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
+                       f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
+    if (n_total > 0) {
+        const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
+        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(256), 0, stream, tab, f_blk, f_rows, f_cols,
+                           max_foci, d_total, f_score, f_nobs);
+        hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk,
+                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap);
+    }
     return (int)hipGetLastError();
 }
 

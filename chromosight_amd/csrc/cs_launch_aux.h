@@ -34,6 +34,53 @@ struct FocusRec {
     double score, n_obs;
 };
 
+#ifdef __HIPCC__
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// float64 coefficient (and present-pixel count) of one pixel by one wave: _normxcorr2_sparse per pixel
+// (detection.py:917-1131).  `A` may live in registers (kernel argument) or in global memory (a table of
+// per-sub-matrix arguments: the wave's loads are uniform).
+__device__ __forceinline__ void rescore_pixel(const CorrArgs<double>& A, int oi, int oj, int lane, double& r, double& nobs)
+{
+    r = 0.0;
+    nobs = A.ks.n;
+    const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
+    if (inside && !pixel_forced_zero(A, oi, oj)) {       // wave-uniform
+        const int km = A.km, kn = A.kn, kk = km * kn;
+        const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+        const bool masked = A.mask_mode != 0;
+        double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
+        for (int e = lane; e < kk; e += 64) {
+            const int ki = e / kn, kj = e - ki * kn;
+            const int p = oi - kh + ki, q = oj - kw + kj;
+            const double v = load_signal(A, p, q);
+            cs_ = fma(v, A.w[e], cs_);
+            s1 += v;
+            s2 = fma(v, v, s2);
+            if (masked && missing_pred(A, p, q)) {
+                nm += 1.0;
+                ka += A.w[kk + e];
+                kb += A.w[2 * kk + e];
+            }
+        }
+        cs_ = wave_sum(cs_);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (masked) {
+            nm = wave_sum(nm);
+            ka = wave_sum(ka);
+            kb = wave_sum(kb);
+        }
+        r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
+    }
+}
+#endif
+
 int launch_distance_law(const CsrView& M, const uint8_t* det, int n_diags, double* d_sum,
                         long long* d_cnt, int n_cu, hipStream_t stream);
 int launch_detrend_csr(const CsrView& M, const double* law, int n_law, double max_val, void* out,
@@ -77,6 +124,13 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
                  long long rec_cap, long long* n_out);
 int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n, int inter,
                      double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream);
+
+// 1-D patterns of many sub-matrices in one launch chain (cs_foci.hip)
+constexpr long long kFociSmallMax = 1 << 16;       // candidates of one sub-matrix a single workgroup labels
+size_t narrow_batch_scratch_bytes(int n_blocks, long long n_total);
+int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_seg, const int* h_lo_w, int n_blocks, double pearson,
+                              int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
+                              double* windows, long long win_cap, long long* h_counts, hipStream_t stream);
 
 // tables of the factorised per-bin mask sums (cs_mask_prep.hip), one launch
 template <typename TC>

@@ -184,6 +184,44 @@ def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter,
     return rec[:k].copy(), windows
 
 
+def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter, diag_only, max_dists, miss_rows, miss_cols,
+                          missing_tol=0.75, want_windows=True, min_size=2, stream=None):
+    """detect mode of a 1-D pattern (<= 4 scanned diagonals) on MANY banded sub-matrices with one native call
+    (cs_detect_foci_batch).  Returns a list of (records, windows) per sub-matrix, or None when the library
+    says a block does not qualify (the caller then goes block by block)."""
+    n_blocks = len(sigs)
+    sig_arr = (_lib.CsMatrix * n_blocks)(*sigs)
+    par_arr = (CsNormxcorr2Params * n_blocks)(*[
+        _corr_params(shapes[b], kspec, True, True, max_dists[b], MASK_BINS, miss_rows[b], miss_cols[b], None, missing_tol, CS_F64)
+        for b in range(n_blocks)])
+    fp_arr = (CsFociParams * n_blocks)(*[
+        CsFociParams(float(pearson), RESCORE_MARGIN, int(min_size), int(bool(diag_only)), 0, int(hi_diags[b]), int(bool(inter)),
+                     int(bool(want_windows))) for b in range(n_blocks)])
+    counts = (C.c_int64 * n_blocks)()
+    kk = kspec.km * kspec.kn
+    cap = 4096
+    while True:
+        rec, win = _host_buffers(dev, cap, kk, want_windows)
+        cap = rec.shape[0]
+        rc = dev.lib.cs_detect_foci_batch(dev.ctx, stream, n_blocks, sig_arr, C.byref(kspec.struct), par_arr, fp_arr,
+                                          rec.ctypes.data, cap, counts, win.ctypes.data if want_windows else None)
+        if rc == -3:
+            return None
+        if rc == -4 and sum(counts) > cap:
+            cap = int(sum(counts)) + int(sum(counts)) // 4
+            continue
+        dev._check(rc)
+        break
+    out, o = [], 0
+    flat = win.reshape(-1) if want_windows else None
+    for b in range(n_blocks):
+        k = int(counts[b])
+        windows = flat[o * kk:(o + k) * kk].reshape(k, kspec.km, kspec.kn).copy() if want_windows else None
+        out.append((rec[o:o + k].copy(), windows))
+        o += k
+    return out
+
+
 def run_candidates(dev, sig, shape, kspec, row_window, *, pearson, lo_diag, hi_diag, inter, full, sym_upper, max_dist,
                    mask_mode=MASK_NONE, miss_row=None, miss_col=None, missing_tol=0.75, precision=None, stream=None,
                    **_unused):

@@ -227,7 +227,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     batch = None
     if stage is None and detect is None:
         from . import pipeline
-        batch = lambda g, blks, cfg, k, t: pipeline.detect_blocks(g, blks, cfg, k, tsvd=t, raw=True)
+        batch = lambda g, blks, cfg, k, t, w=True: pipeline.detect_blocks(g, blks, cfg, k, tsvd=t, raw=True, want_windows=w)
     if stage is None or detect is None:
         from . import pipeline
         stage = stage or (lambda g, ci, md, lk: g.stage_intra(ci, md, lk, smooth=smooth, band_dtype=band_dtype,
@@ -245,7 +245,9 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
         kernel = np.asarray(kernel, dtype=np.float64)
         for it in range(kernel_config["max_iterations"]):
             rows, wins = [], []
-            results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd) if batch else None
+            # the windows only feed the pileup of the next iteration: the last one does not fetch them
+            need_windows = it + 1 < kernel_config["max_iterations"]
+            results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd, need_windows) if batch else None
             for pos, ci in enumerate(mine):
                 table, windows = results[pos] if results is not None else detect(genome, staged[ci], kernel_config,
                                                                                 kernel, tsvd)

@@ -464,17 +464,38 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
                                 want_windows=want_windows, raw=raw, stream=stream)
 
 
-def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4):
+def b_is_band(block):
+    return block.sig.layout == LAYOUT_BAND and not block.inter and getattr(block, "row_window", None) is None
+
+
+def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True):
     """detect_block for every staged block of `blocks`, several at a time (see _Workers); results in
     the order of `blocks`.  The staging of the blocks (default stream) is complete before they start."""
+    kernel = np.asarray(kernel, dtype=np.float64)
+    if len(blocks) > 1 and kernel_config["max_dist"] == 0 and batch:
+        # 1-D patterns: all banded sub-matrices in one native call; blocks too small for the template drop out
+        # as they do in detect_block, the few that are staged dense (very short chromosomes) go one by one
+        live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
+        banded = [k for k in live if b_is_band(blocks[k])]
+        res = cid.detect_many_on_device(dcool.dev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
+                                        raw=raw, want_windows=want_windows) if len(banded) > 1 else None
+        if res is not None:
+            out = [(None, None)] * len(blocks)
+            for k, r in zip(banded, res):
+                out[k] = r
+            for k in live:
+                if k not in banded:
+                    out[k] = detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
+            return out
     if workers <= 1 or len(blocks) <= 1:
-        return [detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw) for b in blocks]
+        return [detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows) for b in blocks]
     dcool.dev.sync()
     pool = dcool.workers(workers)
 
     def one(block):
         dev, stream = pool.device()
-        return detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd, raw=raw, dev=dev, stream=stream)
+        return detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd, raw=raw, dev=dev, stream=stream,
+                            want_windows=want_windows)
 
     return pool.map(one, blocks)
 
@@ -508,7 +529,9 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
     for kernel_id, kernel in enumerate(kernel_config["kernels"]):
         for it in range(kernel_config["max_iterations"]):
             tables, windows = [], []
-            results = detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=tsvd, raw=True)
+            # windows feed the next iteration's template and the optional output; otherwise they stay on the device
+            need_windows = return_windows or it + 1 < kernel_config["max_iterations"]
+            results = detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=tsvd, raw=True, want_windows=need_windows)
             for (ca, cb), (tab, win) in zip(pairs, results):
                 if tab is None or len(tab) == 0:
                     continue
@@ -524,9 +547,10 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
             coords["kernel_id"] = kernel_id
             coords["iteration"] = it
             all_coords.append(coords)
-            kernel_windows = np.concatenate(windows, axis=0)
-            all_windows.append(kernel_windows)
-            kernel = cid.pileup_patterns(kernel_windows)
+            if need_windows:
+                kernel_windows = np.concatenate(windows, axis=0)
+                all_windows.append(kernel_windows)
+                kernel = cid.pileup_patterns(kernel_windows)
     if not all_coords:
         empty = pd.DataFrame(columns=OUTPUT_COLUMNS)
         return (empty, np.zeros((0,) + np.shape(kernel_config["kernels"][0]))) if return_windows else empty

@@ -608,6 +608,35 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
                            full=full, raw=raw)
 
 
+def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None):
+    """detect_on_device for a 1-D pattern (kernel_config["max_dist"] == 0: borders, hairpins) on many intra
+    sub-matrices at once: `blocks` = objects with sig, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).
+    One native call (cs_detect_foci_batch) instead of one launch chain and synchronisation per sub-matrix.
+    Returns the list of (table, windows) detect_on_device would return, or None if the batch entry does not
+    apply (caller falls back to one call per block)."""
+    if kernel_config["max_dist"] != 0 or not blocks:
+        return None
+    if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None for b in blocks):
+        return None
+    missing_tol = kernel_config["max_perc_undetected"] / 100
+    res = engine.run_detect_foci_batch(
+        dev, [b.sig for b in blocks], [b.shape for b in blocks], kspec, pearson=kernel_config["pearson"],
+        hi_diags=[b.max_dist for b in blocks], inter=False, diag_only=True, max_dists=[b.max_dist for b in blocks],
+        miss_rows=[b.miss_row for b in blocks], miss_cols=[b.miss_col for b in blocks], missing_tol=missing_tol,
+        want_windows=want_windows, stream=stream)
+    if res is None:
+        return None
+    out = []
+    for b, (rec, windows) in zip(blocks, res):
+        if rec.shape[0] == 0:
+            out.append((None, None))
+            continue
+        rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+        out.append(_accept_records(rec, windows, rr, cc, "detect", b.shape, kspec, kernel_config, inter=False,
+                                   max_dist=b.max_dist, full=True, raw=raw))
+    return out
+
+
 def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw):
     """The acceptance rules of pattern_detector / validate_patterns on the records the device returned
     (reference detection.py:121-141, 269-270, 332-336): (table, windows)."""

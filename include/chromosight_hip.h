@@ -276,6 +276,18 @@ int cs_detect_foci(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_
                    const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci,
                    int64_t cap, int64_t* n_foci, double* h_windows);
 
+/* 1-D patterns (borders, hairpins: at most 4 scanned diagonals from the main one up) of MANY banded
+ * sub-matrices with one launch chain: per sub-matrix such a scan is a few thousand float64 evaluations,
+ * i.e. a fixed ~0.1 ms of tiny kernels and a synchronisation, 23 times per template on a human genome.
+ * signals / params / foci: arrays of n_blocks (whole blocks, no row windows; the detection parameters
+ * pearson, min_size, diag_only, inter, want_windows must agree).  Records (and windows) of all blocks, block
+ * after block, go to h_foci / h_windows, which must be page-locked (cs_host_alloc) -- the last kernel
+ * writes them; h_n_foci[b] = foci of block b.  CS_ERR_UNSUPPORTED when a block does not qualify (the
+ * caller then uses cs_detect_foci per block), CS_ERR_OVERFLOW when cap is too small (counts are set). */
+int cs_detect_foci_batch(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
+                         const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci, int64_t cap,
+                         int64_t* h_n_foci, double* h_windows);
+
 /* `quantify` mode (detection.py:277, 297-298): score, n_obs and window statistics at n given pixels
  * (host int32 arrays).  h_out: n records in input order; h_windows: n * km * kn float64 or NULL. */
 int cs_quantify_pixels(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,

@@ -259,3 +259,34 @@ def test_device_foci_tangled_components(n, max_dist, pearson, seed):
     assert got.shape == ref.shape
     assert np.array_equal(got[:, :2], ref[:, :2])
     assert np.abs(got[:, 2] - ref[:, 2]).max() < 1e-9
+
+
+def test_batched_1d_patterns_equal_per_block_calls():
+    """cs_detect_foci_batch (all sub-matrices of a 1-D pattern in one launch chain, results written into the
+    page-locked buffers by the last kernel) == one cs_detect_foci per sub-matrix: same records in the same
+    order, same windows; also without windows (the last iteration of a genome run does not fetch them)."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(30_000, 300, 2000, seed=7, template=template, chrom_sizes=[9000, 10, 6000, 15000, 60])
+    dcool = pipeline.DeviceCool(cool)
+    for name in ("borders", "hairpins"):
+        cfg = copy.deepcopy(getattr(ck, name))
+        max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
+        largest = max(np.shape(k)[0] for k in cfg["kernels"])
+        blocks = [dcool.stage_intra(ci, max_dist, largest, resident=True) for ci in range(dcool.n_chrom)]
+        for kernel in cfg["kernels"]:
+            kernel = np.asarray(kernel, dtype=np.float64)
+            one = pipeline.detect_blocks(dcool, blocks, cfg, kernel, raw=True, batch=False)
+            many = pipeline.detect_blocks(dcool, blocks, cfg, kernel, raw=True, batch=True)
+            bare = pipeline.detect_blocks(dcool, blocks, cfg, kernel, raw=True, batch=True, want_windows=False)
+            assert one[1][0] is None and many[1][0] is None      # the 10-bin block is skipped; the 60-bin one is dense
+            total = 0
+            for a, b, c in zip(one, many, bare):
+                if a[0] is None:
+                    assert b[0] is None and c[0] is None
+                    continue
+                total += len(a[0])
+                assert np.array_equal(a[0][:, :2], b[0][:, :2]) and np.array_equal(a[0][:, :2], c[0][:, :2])
+                assert np.allclose(a[0][:, 2:], b[0][:, 2:], rtol=0, atol=1e-12, equal_nan=True)
+                assert np.allclose(a[0][:, 2:], c[0][:, 2:], rtol=0, atol=1e-12, equal_nan=True)
+                assert np.allclose(a[1], b[1], rtol=0, atol=0, equal_nan=True) and c[1] is None
+            assert total > 50, (name, total)

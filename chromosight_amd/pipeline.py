@@ -214,6 +214,9 @@ class _Workers:
         return list(self.pool.map(fn, items))
 
 
+_WORKER_POOLS = {}
+
+
 class DeviceCool:
     """A decoded .cool resident in HBM.  cooler stores the upper triangle of the whole genome
     sorted by (bin1, bin2): that table IS a CSR matrix (row pointer = searchsorted of bin1), so it
@@ -272,9 +275,12 @@ class DeviceCool:
         return self.dev.empty(nbytes, np.uint8)
 
     def workers(self, n=4):
-        if self._workers is None:
-            self._workers = _Workers(self.dev.index, n)
-        return self._workers
+        # process-wide: the workers' contexts, streams and scratch outlive this DeviceCool (creating them costs
+        # several milliseconds, more than a whole detect on a small genome)
+        key = (self.dev.index, n)
+        if key not in _WORKER_POOLS:
+            _WORKER_POOLS[key] = _Workers(self.dev.index, n)
+        return _WORKER_POOLS[key]
 
     @property
     def n_chrom(self):
@@ -542,11 +548,9 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
             if not tables:
                 break
             rec = np.concatenate(tables, axis=0)
-            coords = pd.DataFrame({"bin1": rec[:, 0].astype(np.int64), "bin2": rec[:, 1].astype(np.int64),
-                                   "score": rec[:, 2], "pvalue": rec[:, 3]})
-            coords["kernel_id"] = kernel_id
-            coords["iteration"] = it
-            all_coords.append(coords)
+            all_coords.append({"bin1": rec[:, 0].astype(np.int64), "bin2": rec[:, 1].astype(np.int64), "score": rec[:, 2],
+                               "pvalue": rec[:, 3], "kernel_id": np.full(len(rec), kernel_id, dtype=np.int64),
+                               "iteration": np.full(len(rec), it, dtype=np.int64)})
             if need_windows:
                 kernel_windows = np.concatenate(windows, axis=0)
                 all_windows.append(kernel_windows)
@@ -554,7 +558,7 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
     if not all_coords:
         empty = pd.DataFrame(columns=OUTPUT_COLUMNS)
         return (empty, np.zeros((0,) + np.shape(kernel_config["kernels"][0]))) if return_windows else empty
-    coords = pd.concat(all_coords, axis=0).reset_index(drop=True)
+    coords = {k: np.concatenate([c[k] for c in all_coords]) for k in all_coords[0]}
     # windows of different templates may differ in size only across configs, never inside one
     windows = np.concatenate(all_windows, axis=0) if return_windows else None
     return postprocess(coords, kernel_config, binsize, off, names, dcool.bin_start, dcool.bin_end, windows=windows)
@@ -574,29 +578,33 @@ def detect_to_files(cool, kernel_config, prefix, win_fmt="json", dec=10, **optio
 def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end, windows=None):
     """cmd_detect after the per-block loop (cli/chromosight.py:806-871): neighbour removal, bins ->
     genomic coordinates, min_dist and NaN-p filters, Benjamini-Hochberg q-values, column order.
-    `windows` (one per row of coords) are filtered alongside and returned as a second value."""
-    n_chrom = len(names)
+    `coords`: DataFrame or dict of columns bin1, bin2, score, pvalue, kernel_id, iteration.
+    `windows` (one per row of coords) are filtered alongside and returned as a second value.
+    Column arithmetic is plain numpy and the table is built once (pandas' per-column inserts cost more
+    than the detection itself on a small genome)."""
+    col = {k: np.asarray(coords[k]) for k in ("bin1", "bin2", "score", "pvalue", "kernel_id", "iteration")}
+    b1 = col["bin1"].astype(np.int64, copy=False)
+    b2 = col["bin2"].astype(np.int64, copy=False)
     separation = max(int(kernel_config["min_separation"] // binsize), 1)
-    distinct = cid.remove_neighbours(coords, win_size=separation)
-    coords = coords.loc[distinct, :].copy()
-    if windows is not None:
-        windows = windows[np.asarray(distinct)]
+    sel = np.flatnonzero(cid.remove_neighbours_arrays(b1, b2, col["score"], win_size=separation))
     # bins -> genomic coordinates
-    bin_chrom = np.repeat(np.arange(n_chrom), np.diff(off))
+    bin_chrom = np.repeat(np.arange(len(names)), np.diff(off))
+    b1, b2 = b1[sel], b2[sel]
+    c1, c2 = bin_chrom[b1], bin_chrom[b2]
+    bin_start, bin_end = np.asarray(bin_start), np.asarray(bin_end)
+    s1, s2 = bin_start[b1], bin_start[b2]
+    pval = col["pvalue"][sel].astype(np.float64, copy=False)
+    too_close = (c1 == c2) & (np.abs(s2 - s1) < kernel_config["min_dist"])
+    keep = ~too_close & ~np.isnan(pval)
+    sel, b1, b2, c1, c2, pval = sel[keep], b1[keep], b2[keep], c1[keep], c2[keep], pval[keep]
     name_arr = np.asarray(names, dtype=object)
-    for tag in ("1", "2"):
-        b = coords[f"bin{tag}"].to_numpy(dtype=np.int64)
-        coords[f"chrom{tag}"] = name_arr[bin_chrom[b]]
-        coords[f"start{tag}"] = np.asarray(bin_start)[b]
-        coords[f"end{tag}"] = np.asarray(bin_end)[b]
-    coords = coords.reset_index(drop=True)
-    too_close = (coords.chrom1 == coords.chrom2) & (np.abs(coords.start2 - coords.start1) < kernel_config["min_dist"])
-    keep = (~too_close & ~coords.pvalue.isnull()).to_numpy()
-    coords = coords.loc[keep, :].copy()
-    coords["qvalue"] = fdr_correction(coords["pvalue"])
-    table = coords.loc[:, OUTPUT_COLUMNS].reset_index(drop=True)
+    table = pd.DataFrame({
+        "chrom1": name_arr[c1], "start1": bin_start[b1], "end1": bin_end[b1],
+        "chrom2": name_arr[c2], "start2": bin_start[b2], "end2": bin_end[b2],
+        "bin1": b1, "bin2": b2, "kernel_id": col["kernel_id"][sel], "iteration": col["iteration"][sel],
+        "score": col["score"][sel], "pvalue": pval, "qvalue": fdr_correction(pval)}, columns=OUTPUT_COLUMNS)
     if windows is not None:
-        return table, windows[keep]
+        return table, windows[sel]
     return table
 
 

@@ -486,15 +486,22 @@ def remove_neighbours(patterns, win_size=8):
     closer than win_size bins on both axes (reference detection.py:348-384).  Returns a boolean
     keep-mask aligned on the input rows.  The visiting order is the reference's own sort; the
     scan is the library's grid-hashed cs_remove_neighbours (O(n) instead of O(n^2))."""
+    return remove_neighbours_arrays(patterns.bin1.to_numpy(), patterns.bin2.to_numpy(), patterns.score.to_numpy(),
+                                    win_size=win_size)
+
+
+def remove_neighbours_arrays(bin1, bin2, score, win_size=8):
+    """remove_neighbours on plain columns."""
     from .._lib import load_library
-    n = patterns.shape[0]
+    n = len(score)
     if n == 0:
         return np.ones(0, dtype=bool)
-    ordered = patterns.copy().sort_values("score", ascending=False)
-    pos = pd.Series(np.arange(n), index=patterns.index)
-    order = np.ascontiguousarray(pos.loc[ordered.index].to_numpy(), dtype=np.int64)
-    b1 = np.ascontiguousarray(patterns.bin1.to_numpy(), dtype=np.int64)
-    b2 = np.ascontiguousarray(patterns.bin2.to_numpy(), dtype=np.int64)
+    # the reference's visiting order: pandas' sort of the score column, descending (detection.py:368); a one-column
+    # DataFrame sort and a Series sort go through the same nargsort, so ties come out in the same order
+    order = pd.Series(np.asarray(score)).sort_values(ascending=False).index.to_numpy()
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    b1 = np.ascontiguousarray(bin1, dtype=np.int64)
+    b2 = np.ascontiguousarray(bin2, dtype=np.int64)
     keep = np.zeros(n, dtype=np.uint8)
     rc = load_library().cs_remove_neighbours(b1.ctypes.data, b2.ctypes.data, order.ctypes.data, n,
                                              max(int(win_size), 1), keep.ctypes.data)

@@ -380,6 +380,7 @@ struct MfmaDenseArgs {
     int tiles_x, n_tiles;
     const uint4* frag;
     float w_unscale;
+    float wa_unscale, wb_unscale;    // REG: power-of-two scales of the Wa / Wb sets (float16 range)
     int xcd_order;           // 1: contiguous tile ranges per XCD
     int dbg;                 // diagnostics (CHROMOSIGHT_HIP_MFMA_DBG): skip 1 stores, 2 prefetch, 4 box sums, 8 cross term
     KernelStats<float> ks;
@@ -410,7 +411,7 @@ constexpr int MFD_SMEM = MFD_RED + 64;
 // double-buffered (a tile's epilogue runs while the next tile's are already landing)
 constexpr int MFD_COL = MFD_RED + 64;
 constexpr int MFD_CFL = MFD_COL + 2 * 3 * 64 * 4;
-constexpr int MFD_CFB = MFD_CFL + 2 * 80 * 4;          // raw flag bytes as they arrive
+constexpr int MFD_CFB = MFD_CFL + 2 * 16;              // (CFL: the 80 column flags as 3 mask words per slot) raw flag bytes as they arrive
 constexpr int MFD_SMEM_REG = MFD_CFB + 2 * 128;
 static_assert(MFD_SMEM_REG <= 80 * 1024, "two workgroups per CU");
 
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
         int r = r_first, c = c_first;
-        if constexpr (REG) {
+        if (REG && !(A.dbg & 16384)) {
             // column terms of the tile's 64 columns (waves 0..2) and the flags of its 80 staged columns (wave 3)
             if (wv_u < 3) {
                 const float* src = A.coltab + (size_t)wv_u * A.ns + min(max(J0 + lane, 0), A.ns - 1);
@@ -559,8 +560,6 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 const long long first = ((base + Q0) >> 2) << 2;
                 long long addr = first + 4 * min(lane, 23);
                 addr = min(max(addr, (base >> 2) << 2), ((base + A.ns - 1) >> 2) << 2);
-                // word 31 of the slot = "the tile has a flagged column", set when the flags are unpacked
-                if (lane == 0) reinterpret_cast<volatile unsigned*>(smem + MFD_CFB)[slot * 32 + 31] = 0u;
                 if (lane < 24)
                     __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>((uintptr_t)addr),
                                                      (__attribute__((address_space(3))) void*)(
@@ -611,97 +610,211 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             const int K = km;
             const int i = I0 + wr0 + n;
             const float* colb = reinterpret_cast<const float*>(smem + MFD_COL) + slot * 3 * 64;
-            const float* cfl = reinterpret_cast<const float*>(smem + MFD_CFL) + slot * 80;
             const float nr = hdr[0], ra = hdr[1], rb = hdr[2];
-            // the cross term exists only where a flagged row AND a flagged column reach the window
-            const bool tile_flags = reinterpret_cast<const unsigned*>(smem + MFD_CFB)[slot * 32 + 31] != 0;
+            // The cross term sum_kj c[j + kj] U_i[kj], U_i[kj] = sum over the flagged rows ki of row i's window of
+            // W[ki][kj], exists only where a flagged row AND a flagged column reach the window.  On the matrix
+            // cores: A = Hankel matrix of the column flags (exact in float16), B = U (head + tail), per column tile.
+            const unsigned* cfm = reinterpret_cast<const unsigned*>(smem + MFD_CFL) + slot * 4;
+            const unsigned m0 = __builtin_amdgcn_readfirstlane(cfm[0]), m1 = __builtin_amdgcn_readfirstlane(cfm[1]),
+                           m2 = __builtin_amdgcn_readfirstlane(cfm[2]);
+            const bool tile_flags = (m0 | m1 | m2) != 0;
             const unsigned row_bits = (tile_flags && !(A.dbg & 128)) ? (unsigned)hdr[3] : 0u;
+            const bool cross_on = __builtin_amdgcn_ballot_w64(row_bits != 0) != 0;
+            h8 ua_h, ua_t, ub_h, ub_t;
+            if (cross_on) {
+                float ua[8], ub[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ua[e] = ub[e] = 0.0f;
+                unsigned bits = row_bits;
+                while (__builtin_amdgcn_ballot_w64(bits != 0)) {
+                    if (bits) {
+                        const int ki = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        const float* wa = A.w + K * K + ki * K;
+                        const float* wb = A.w + 2 * K * K + ki * K;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int kj = 8 * g + e;
+                            const float in = kj < K ? 1.0f : 0.0f;
+                            ua[e] = fmaf(wa[min(kj, K - 1)], in, ua[e]);
+                            ub[e] = fmaf(wb[min(kj, K - 1)], in, ub[e]);
+                        }
+                    }
+                }
+                const float sa = __builtin_amdgcn_rcpf(A.wa_unscale), sb = __builtin_amdgcn_rcpf(A.wb_unscale);   // powers of two
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = ua[e] * sa, b = ub[e] * sb;
+                    ua_h[e] = (_Float16)a;
+                    ua_t[e] = (_Float16)(a - (float)ua_h[e]);
+                    ub_h[e] = (_Float16)b;
+                    ub_t[e] = (_Float16)(b - (float)ub_h[e]);
+                }
+            }
+            const unsigned kmask8 = (((1u << K) - 1u) >> (8 * g)) & 0xffu;      // template columns 8 g .. 8 g + 7 that exist
             const int dmin = J0 - (I0 + MF_T - 1), dmax = J0 + MF_T - 1 - I0;
             const bool needs_fix = !(A.dbg & 256) && ((I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_cols != nullptr) |
                                    (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
                                                  (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w))));
+            // every pixel of the tile is produced: rows below row_end, columns inside the matrix, diagonals inside the band
+            const bool plain_out = I0 + MF_T <= A.row_end && J0 >= 0 && J0 + MF_T <= A.ns && dmin >= A.out_lo && dmax <= A.out_hi;
             float* tb = reinterpret_cast<float*>(scr);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                f4 rv[2], nv[2];
+                f4 rv[2], nmv[2], kav[2], kbv[2];
+                unsigned rare_bits = 0u;
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
                     const int c = 2 * half + cc;
-                    // cross term of this column tile: for every flagged row ki of the window,
-                    // (column flags (*) template row ki); one weight pair in flight at a time
+                    __builtin_amdgcn_sched_barrier(0);       // one column tile at a time: keeps the live set small
+                    // cross term of this column tile
                     f4 xa = zero4, xb = zero4;
-                    unsigned bits = row_bits;
-                    if (__builtin_amdgcn_ballot_w64(bits != 0)) {
-                        float fl[20];
+#ifndef CS_X_NOCROSS
+                    if (cross_on) {
+                        // lane (m = n, k group g) of the Hankel operand: flags of staged columns 16 c + n + 8 g + e
+                        const int sh = 16 * c + n + 8 * g;                       // 0 .. 87
+                        const unsigned lo = sh < 32 ? m0 : sh < 64 ? m1 : m2;
+                        const unsigned hi = sh < 32 ? m1 : sh < 64 ? m2 : 0u;
+                        const unsigned w8 = (unsigned)((((unsigned long long)hi << 32) | lo) >> (sh & 31)) & kmask8;
+                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                        u4 fw;
 #pragma unroll
-                        for (int e = 0; e < 5; ++e) {
-                            const f4 t = *reinterpret_cast<const f4*>(cfl + 16 * c + 4 * g + 4 * e);
-                            fl[4 * e] = t[0]; fl[4 * e + 1] = t[1]; fl[4 * e + 2] = t[2]; fl[4 * e + 3] = t[3];
-                        }
-                        while (__builtin_amdgcn_ballot_w64(bits != 0)) {
-                            if (bits) {
-                                const int ki = __builtin_ctz(bits);
-                                bits &= bits - 1;
-                                const float* wa = A.w + K * K + ki * K;
-                                const float* wb = A.w + 2 * K * K + ki * K;
+                        for (int pr = 0; pr < 4; ++pr)
+                            fw[pr] = ((w8 >> (2 * pr)) & 1u) * 0x3C00u + ((w8 >> (2 * pr + 1)) & 1u) * 0x3C000000u;   // 1.0 in float16
+                        const h8 ff = __builtin_bit_cast(h8, fw);
+                        xa = mfma16(ff, ua_h, xa);
+                        xa = mfma16(ff, ua_t, xa);
+                        xb = mfma16(ff, ub_h, xb);
+                        xb = mfma16(ff, ub_t, xb);
 #pragma unroll
-                                for (int kj = 0; kj < 17; ++kj) {
-                                    const float a = kj < K ? wa[min(kj, K - 1)] : 0.0f, b = kj < K ? wb[min(kj, K - 1)] : 0.0f;
-#pragma unroll
-                                    for (int v = 0; v < 4; ++v) {
-                                        xa[v] = fmaf(fl[v + kj], a, xa[v]);
-                                        xb[v] = fmaf(fl[v + kj], b, xb[v]);
-                                    }
-                                }
-                            }
+                        for (int v = 0; v < 4; ++v) {
+                            xa[v] *= A.wa_unscale;
+                            xb[v] *= A.wb_unscale;
                         }
                     }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
                     const f4 ncol = *reinterpret_cast<const f4*>(colb + 16 * c + 4 * g);
                     const f4 ca = *reinterpret_cast<const f4*>(colb + 64 + 16 * c + 4 * g);
                     const f4 cb = *reinterpret_cast<const f4*>(colb + 128 + 16 * c + 4 * g);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int j = J0 + 16 * c + 4 * g + v;
-                        const int d = j - i;
-                        float nm = (float)K * nr + ((float)K - nr) * ncol[v];
-                        float ka = ra + ca[v] - xa[v];
-                        float kb = rb + cb[v] - xb[v];
-                        if (needs_fix) {
-                            const float* f = mask_fix_record(A, i, j);
-                            if (f) {
-                                nm += f[0];
-                                ka += f[1];
-                                kb += f[2];
+                        nmv[cc][v] = (float)K * nr + ((float)K - nr) * ncol[v];
+                        kav[cc][v] = ra + ca[v] - xa[v];
+                        kbv[cc][v] = rb + cb[v] - xb[v];
+                    }
+                }
+#ifndef CS_X_NOFIX
+                if (needs_fix) {
+                    // pixels whose window leaves the matrix or the diagonals 0 .. max_dist (tiles on the rim of the
+                    // band): one copy of the record lookup, rolled over the 8 pixels
+#pragma unroll 1
+                    for (int k = 0; k < 8; ++k) {
+                        const int j = J0 + 16 * (2 * half + (k >> 2)) + 4 * g + (k & 3);
+                        const float* f = mask_fix_record(A, i, j);
+                        float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+                        if (f) {
+                            d0 = f[0];
+                            d1 = f[1];
+                            d2 = f[2];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (e == k) {
+                                nmv[e >> 2][e & 3] += d0;
+                                kav[e >> 2][e & 3] += d1;
+                                kbv[e >> 2][e & 3] += d2;
                             }
                         }
+                    }
+                }
+#endif
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = 2 * half + cc;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int j = J0 + 16 * c + 4 * g + v;
+                        const int d = j - i;
+                        const float nm = nmv[cc][v], ka = kav[cc][v], kb = kbv[cc][v];
                         const float cs = acc[c][v] * u_cs;
                         const float s1 = S1[c][v] * unscale;
                         const float s2 = (S2[c][v] * u_s2) * unscale;
-                        float val = masked_coefficient(cs, s1, s2, nm, ka, kb, A.ks);
-                        if (A.sym_upper && d + (kn - km) < 0) val = 0.0f;      // full mode: triu in framed coordinates
+                        bool rare;
+                        float val = pearson_masked_core(cs, s1, s2, nm, ka, kb, A.ks, rare);
+                        if (A.dbg & 4096) {
+                            val = cs + s1 + s2 + nm + ka + kb;
+                            rare = false;
+                        }
+                        const bool forced = A.sym_upper && d + (kn - km) < 0;          // full mode: triu in framed coordinates
+                        if (forced) val = 0.0f;
+                        if (rare && !forced) rare_bits |= 1u << (4 * cc + v);
                         rv[cc][v] = val;
-                        nv[cc][v] = A.ks.n - nm;
+                    }
+                }
+                // windows whose sums fall under the 1e-4 thresholds (rare): ONE inlined copy of the exact function
+                // per half instead of one per pixel (16 copies: 100 KB of code; a call pins the epilogue to the stack)
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) {
+                    if (!__builtin_amdgcn_ballot_w64((rare_bits >> k) != 0)) break;
+                    if ((rare_bits >> k) & 1u) {
+                        float cs = 0.0f, s1 = 0.0f, s2 = 0.0f, nm = 0.0f, ka = 0.0f, kb = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = 2 * half + (e >> 2), v = e & 3;
+                            if (e == k) {
+                                cs = acc[c][v] * u_cs;
+                                s1 = S1[c][v] * unscale;
+                                s2 = (S2[c][v] * u_s2) * unscale;
+                                nm = nmv[e >> 2][v];
+                                ka = kav[e >> 2][v];
+                                kb = kbv[e >> 2][v];
+                            }
+                        }
+                        const float val = pearson_masked_f32(cs, s1, s2, nm, ka, kb, A.ks);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e == k) rv[e >> 2][e & 3] = val;
                     }
                 }
                 // 16 rows x 32 columns through the wave's scratch, out as 2 rows x 32 consecutive floats per
                 // instruction (band rows are shifted against each other: no wider aligned store exists)
-                for (int pass = 0; pass < (A.nobs ? 2 : 1); ++pass) {
+                const int pass_n = (A.dbg & 8192) ? (int)(rv[0][0] == 123.456f) : (A.nobs ? 2 : 1);
+                for (int pass = 0; pass < pass_n; ++pass) {
                     wave_lds_sync();
-                    *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = pass ? nv[0] : rv[0];
-                    *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = pass ? nv[1] : rv[1];
+                    f4 t0 = rv[0], t1 = rv[1];
+                    if (pass) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            t0[v] = A.ks.n - nmv[0][v];
+                            t1[v] = A.ks.n - nmv[1][v];
+                        }
+                    }
+                    *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = t0;
+                    *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = t1;
                     wave_lds_sync();
+                    const int xx = lane & 31;
+                    int oi = I0 + wr0 + (lane >> 5);
+                    const int oj = J0 + 32 * half + xx;
+                    // two rows further down: 2 ld, and on a banded output two diagonals to the left
+                    long long idx = ((long long)oi - A.row0_out) * A.ld_out + (A.band_out ? oj - oi - A.lo_out : oj);
+                    const long long step = 2 * (long long)A.ld_out - (A.band_out ? 2 : 0);
+                    const bool col_ok = oj >= 0 && oj < A.ns;
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
-                        const int rr = 2 * it + (lane >> 5), xx = lane & 31;
-                        const float val = tb[rr * 36 + xx];
-                        const int oi = I0 + wr0 + rr, oj = J0 + 32 * half + xx;
-                        const int d = oj - oi;
-                        if (!(A.dbg & 1) && oi < A.row_end && oj >= 0 && oj < A.ns && d >= A.out_lo && d <= A.out_hi) {
-                            const long long idx = ((long long)oi - A.row0_out) * A.ld_out + (A.band_out ? d - A.lo_out : oj);
+                        const float val = tb[(2 * it + (lane >> 5)) * 36 + xx];
+                        bool ok = !(A.dbg & 1);
+                        if (!plain_out) {
+                            const int d = oj - oi;
+                            ok = ok && oi < A.row_end && col_ok && d >= A.out_lo && d <= A.out_hi;
+                        }
+                        if (ok) {
                             if (pass == 1) A.nobs[idx] = val;
                             else if (A.out_is_f64) reinterpret_cast<double*>(A.out)[idx] = (double)val;
                             else reinterpret_cast<float*>(A.out)[idx] = val;
                         }
+                        oi += 2;
+                        idx += step;
                     }
                 }
             }
@@ -825,115 +938,144 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             if (idx < 17 * 64) reinterpret_cast<h8*>(smem + MFD_WL)[idx] = (idx >> 6) < km ? tails[k] : z;
         }
     }
-    for (; tile < tile_end; tile += tile_step) {
-        int I0, J0;
-        tile_origin(tile, I0, J0);
+    // One emit site: the loop runs one pass beyond the last tile, in which only the pending tile is emitted.
+    for (;; tile += tile_step) {
+        const bool have = tile < tile_end;              // uniform over the workgroup
+        if (!have && !pending) break;
+        int I0 = 0, J0 = 0;
+        if (have) tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
-        const bool inside = !REG && P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
-        if (A.dbg & 1024) continue;            // diagnostics: prologue only
+        // every staged pixel exists (rows, columns and, for a banded input, stored diagonals): the transfers were not
+        // clamped and the reader needs no masks
+        bool inside = P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
+        if (REG && A.band_in) inside = inside && Q0 - (P0 + MF_R - 1) - A.lo_in >= 0 && Q0 + MF_R - 1 - P0 - A.lo_in <= A.bw_in - 1;
+        if (REG && (A.dbg & 512)) inside = true;
+        if (A.dbg & 1024) {                    // diagnostics: prologue only
+            if (!have) break;
+            continue;
+        }
+        float unscale = 0.0f;
 #ifdef CS_MF_PROFILE
         unsigned long long tprev_ = __builtin_readcyclecounter();
-        if (tid == 0) atomicAdd(&cs_mf_prof[15], 1ull);
+        if (tid == 0 && have) atomicAdd(&cs_mf_prof[15], 1ull);
 #endif
+        if (have) {
 
-        // ---- the tile's pixels have landed in `raw`: read this thread's 14 x 2, find the scale
-        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's DMA transfers (and long-retired stores)
-        lds_barrier();                           // everyone's transfers; the previous tile's plane readers are done
-        float xa[MFD_ROWS_PER_THREAD], xb[MFD_ROWS_PER_THREAD];
-        float amax = 0.0f;
+            // ---- the tile's pixels have landed in `raw`: read this thread's 14 x 2, find the scale
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's DMA transfers (and long-retired stores)
+            lds_barrier();                           // everyone's transfers; the previous tile's plane readers are done
+            float xa[MFD_ROWS_PER_THREAD], xb[MFD_ROWS_PER_THREAD];
+            float amax = 0.0f;
+            if (inside) {
 #pragma unroll
-        for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
-            const int r = rg + 6 * k;
-            float a = 0.0f, b = 0.0f;
-            if (REG && VEC4) {
-                if (stager && r < MF_R) {
-                    // pieces of 4 whose start was clamped into the stored range of their row: element o of the
-                    // piece holds stored index idx_c + o
-                    const int p = P0 + r, q = Q0 + 2 * c2, cs = (2 * c2) & ~3;
-                    const int w = A.band_in ? A.bw_in : A.ns;
-                    const int off = A.band_in ? p + A.lo_in : 0;
-                    const int idx_s = Q0 + cs - off;
-                    const int idx_c = min(max(idx_s, 0), w - 4);
-                    const int oa = (2 * c2 - cs) + (idx_s - idx_c), ob = oa + 1;
-                    const int idx_a = q - off;
-                    const bool rok = (p >= p_min) & (p <= p_max);
-                    const bool oka = rok & (q >= 0) & (q < A.ns) & (idx_a >= 0) & (idx_a < w) & (oa >= 0) & (oa < 4);
-                    const bool okb = rok & (q + 1 >= 0) & (q + 1 < A.ns) & (idx_a + 1 >= 0) & (idx_a + 1 < w) & (ob >= 0) & (ob < 4);
-                    const float* piece = raw + r * MF_R + cs;
-                    a = oka ? piece[min(max(oa, 0), 3)] : 0.0f;
-                    b = okb ? piece[min(max(ob, 0), 3)] : 0.0f;
+                for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
+                    const int r = rg + 6 * k;
+                    float2 v = make_float2(0.0f, 0.0f);
+                    if (stager && r < MF_R) v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
+                    xa[k] = v.x;
+                    xb[k] = v.y;
+                    amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
                 }
-            } else if (stager && r < MF_R) {
-                const float2 v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
-                a = v.x;
-                b = v.y;
-                if (!inside) {
-                    const int p = P0 + r, q = Q0 + 2 * c2;
-                    const bool rok = (p >= p_min) & (p <= p_max);
-                    bool oka = rok & (q >= 0) & (q < A.ns), okb = rok & (q + 1 >= 0) & (q + 1 < A.ns);
-                    if (REG && A.band_in) {               // outside the stored diagonals: zero
-                        const int dd = q - p - A.lo_in;
-                        oka &= (dd >= 0) & (dd < A.bw_in);
-                        okb &= (dd + 1 >= 0) & (dd + 1 < A.bw_in);
+            } else {
+#pragma unroll
+                for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
+                    const int r = rg + 6 * k;
+                    float a = 0.0f, b = 0.0f;
+                    if (REG && VEC4) {
+                        if (stager && r < MF_R) {
+                            // pieces of 4 whose start was clamped into the stored range of their row: element o of the
+                            // piece holds stored index idx_c + o
+                            const int p = P0 + r, q = Q0 + 2 * c2, cs = (2 * c2) & ~3;
+                            const int w = A.band_in ? A.bw_in : A.ns;
+                            const int off = A.band_in ? p + A.lo_in : 0;
+                            const int idx_s = Q0 + cs - off;
+                            const int idx_c = min(max(idx_s, 0), w - 4);
+                            const int oa = (2 * c2 - cs) + (idx_s - idx_c), ob = oa + 1;
+                            const int idx_a = q - off;
+                            const bool rok = (p >= p_min) & (p <= p_max);
+                            const bool oka = rok & (q >= 0) & (q < A.ns) & (idx_a >= 0) & (idx_a < w) & (oa >= 0) & (oa < 4);
+                            const bool okb = rok & (q + 1 >= 0) & (q + 1 < A.ns) & (idx_a + 1 >= 0) & (idx_a + 1 < w) & (ob >= 0) & (ob < 4);
+                            const float* piece = raw + r * MF_R + cs;
+                            a = oka ? piece[min(max(oa, 0), 3)] : 0.0f;
+                            b = okb ? piece[min(max(ob, 0), 3)] : 0.0f;
+                        }
+                    } else if (stager && r < MF_R) {
+                        const float2 v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
+                        const int p = P0 + r, q = Q0 + 2 * c2;
+                        const bool rok = (p >= p_min) & (p <= p_max);
+                        bool oka = rok & (q >= 0) & (q < A.ns), okb = rok & (q + 1 >= 0) & (q + 1 < A.ns);
+                        if (REG && A.band_in) {               // outside the stored diagonals: zero
+                            const int dd = q - p - A.lo_in;
+                            oka &= (dd >= 0) & (dd < A.bw_in);
+                            okb &= (dd + 1 >= 0) & (dd + 1 < A.bw_in);
+                        }
+                        a = oka ? v.x : 0.0f;
+                        b = okb ? v.y : 0.0f;
                     }
-                    a = oka ? a : 0.0f;
-                    b = okb ? b : 0.0f;
+                    xa[k] = a;
+                    xb[k] = b;
+                    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
                 }
             }
-            xa[k] = a;
-            xb[k] = b;
-            amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
-        }
-        amax = wave_max_nonneg(amax);
-        if (lane == 63) red[wv] = __float_as_uint(amax);
-        if constexpr (REG) {
-            // the tile's column flags as floats, zero outside the matrix (the transfer clamped its addresses)
-            if (tid < 80) {
-                const int q = Q0 + tid;
-                const long long start = (long long)(uintptr_t)A.miss_col + Q0;
-                const int skew = (int)(start - ((start >> 2) << 2));           // bytes before column Q0 in the first dword
-                const uint8_t fb = reinterpret_cast<const uint8_t*>(smem + MFD_CFB)[slot * 128 + skew + tid];
-                const bool flagged = q >= 0 && q < A.ns && fb;
-                reinterpret_cast<float*>(smem + MFD_CFL)[slot * 80 + tid] = flagged ? 1.0f : 0.0f;
-                // word 31 of the slot (beyond the 22 transferred dwords): does the tile have a flagged column?
-                if (flagged) reinterpret_cast<volatile unsigned*>(smem + MFD_CFB)[slot * 32 + 31] = 1u;
+            amax = wave_max_nonneg(amax);
+            if (lane == 63) red[wv] = __float_as_uint(amax);
+            if constexpr (REG) {
+                // the tile's column flags as bit masks (bit t = staged column Q0 + t), zero outside the matrix (the
+                // transfer clamped its addresses)
+                if (wv < 2) {
+                    const int q = Q0 + tid;
+                    const long long start = (long long)(uintptr_t)A.miss_col + Q0;
+                    const int skew = (int)(start - ((start >> 2) << 2));           // bytes before column Q0 in the first dword
+                    const uint8_t fb = reinterpret_cast<const uint8_t*>(smem + MFD_CFB)[slot * 128 + skew + min(tid, 79)];
+                    const bool flagged = tid < 80 && q >= 0 && q < A.ns && fb;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(flagged);
+                    unsigned* cfm = reinterpret_cast<unsigned*>(smem + MFD_CFL) + slot * 4;
+                    if (lane == 0) {
+                        cfm[2 * wv] = (unsigned)m;
+                        if (wv == 0) cfm[1] = (unsigned)(m >> 32);
+                    }
+                }
             }
-        }
-        MF_STAMP(0);
-        lds_barrier();                           // everyone has read `raw`: the squares may overwrite it
-        int ex = 0;
-        {
-            const uint4 m4 = *reinterpret_cast<const uint4*>(red);
-            const unsigned mx = max(max(m4.x, m4.y), max(m4.z, m4.w));     // non-negative floats order as integers
-            const int e = (int)((mx >> 23) & 0xffu);
-            if (e != 0 && e != 255) ex = 6 - (e - 127);
-            ex = max(-100, min(100, ex));
-        }
-        const float scale = __uint_as_float((unsigned)(ex + 127) << 23);
-        const float qscale = __uint_as_float((unsigned)(ex + 127 - 5) << 23);   // 2^-5: 17-sums of squares < 65504
-        const float unscale = __uint_as_float((unsigned)(127 - ex) << 23);
-        typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+            MF_STAMP(0);
+            lds_barrier();                           // everyone has read `raw`: the squares may overwrite it
+            int ex = 0;
+            {
+                const uint4 m4 = *reinterpret_cast<const uint4*>(red);
+                const unsigned mx = max(max(m4.x, m4.y), max(m4.z, m4.w));     // non-negative floats order as integers
+                const int e = (int)((mx >> 23) & 0xffu);
+                if (e != 0 && e != 255) ex = 6 - (e - 127);
+                ex = max(-100, min(100, ex));
+            }
+            const float scale = __uint_as_float((unsigned)(ex + 127) << 23);
+            const float qscale = __uint_as_float((unsigned)(ex + 127 - 5) << 23);   // 2^-5: 17-sums of squares < 65504
+            unscale = __uint_as_float((unsigned)(127 - ex) << 23);
+            typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
-            const int r = rg + 6 * k;
-            if (stager && r < MF_R && !(A.dbg & 16)) {
-                // heads by truncation, tails exact differences: head + tail carries 21-22 bits either way
-                const float a = xa[k] * scale, b = xb[k] * scale;
-                const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
-                const hv2 tt = __builtin_amdgcn_cvt_pkrtz(a - (float)hh[0], b - (float)hh[1]);
-                const float qa = (xa[k] * qscale) * a, qb = (xb[k] * qscale) * b;
-                const hv2 qh = __builtin_amdgcn_cvt_pkrtz(qa, qb);
-                const hv2 qt = __builtin_amdgcn_cvt_pkrtz(qa - (float)qh[0], qb - (float)qh[1]);
-                const int o = (r * MF_R + 2 * c2) * 2;
-                *reinterpret_cast<hv2*>(pl_xh + o) = hh;
-                *reinterpret_cast<hv2*>(pl_xl + o) = tt;
-                *reinterpret_cast<hv2*>(pl_qh + o) = qh;
-                *reinterpret_cast<hv2*>(pl_ql + o) = qt;
+            for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
+                const int r = rg + 6 * k;
+                if (stager && r < MF_R && !(A.dbg & 16)) {
+                    // heads by truncation, tails exact differences: head + tail carries 21-22 bits either way
+                    const float a = xa[k] * scale, b = xb[k] * scale;
+                    const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+                    const hv2 tt = __builtin_amdgcn_cvt_pkrtz(a - (float)hh[0], b - (float)hh[1]);
+                    const float qa = (xa[k] * qscale) * a, qb = (xb[k] * qscale) * b;
+                    const hv2 qh = __builtin_amdgcn_cvt_pkrtz(qa, qb);
+                    const hv2 qt = __builtin_amdgcn_cvt_pkrtz(qa - (float)qh[0], qb - (float)qh[1]);
+                    const int o = (r * MF_R + 2 * c2) * 2;
+                    *reinterpret_cast<hv2*>(pl_xh + o) = hh;
+                    *reinterpret_cast<hv2*>(pl_xl + o) = tt;
+                    *reinterpret_cast<hv2*>(pl_qh + o) = qh;
+                    *reinterpret_cast<hv2*>(pl_ql + o) = qt;
+                }
             }
+            MF_STAMP(1);
+        } else if (REG) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            lds_barrier();
         }
-        MF_STAMP(1);
         // ---- the previous tile's coefficients and stores
         if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
+        if (!have) break;
         MF_STAMP(6);
         lds_barrier();
 
@@ -1056,13 +1198,6 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         slot ^= 1;
         pending = true;
     }
-    if (pending) {
-        if constexpr (REG) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            lds_barrier();
-        }
-        emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
-    }
 }
 
 // The 160 KB dynamic-LDS ceiling is a per-function, per-device attribute: set it the first time a kernel is
@@ -1129,6 +1264,8 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.n_tiles = (int)blocks;
         D.frag = E.frag;
         D.w_unscale = E.unscale[0];
+        D.wa_unscale = E.unscale[1];
+        D.wb_unscale = E.unscale[2];
         D.dbg = getenv("CHROMOSIGHT_HIP_MFMA_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_DBG")) : 0;
         D.xcd_order = getenv("CHROMOSIGHT_HIP_NO_XCD") ? 0 : 1;
         D.ks = A.ks;

@@ -281,6 +281,7 @@ bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
 {
     if (A.mask_mode != CS_MASK_BINS || !A.full || A.km != A.kn || A.km > 17 || A.km < 3 || !(A.km & 1)) return false;
     if (A.sig_is_f64 || A.xcorr_only) return false;
+    if ((A.sig.layout == CS_LAYOUT_BAND ? A.sig.band_w : A.ns) < 4) return false;      // 16-byte staging pieces
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA_REG");
     return e && e[0] == '1';

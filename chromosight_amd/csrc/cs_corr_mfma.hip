@@ -368,6 +368,19 @@ extern "C" int cs_debug_mfma_profile(unsigned long long* out)
 // fetched by LDS-DMA while the current one is in the MFMA phase; weight heads in registers, tails in
 // LDS; squares staged next to the signal; no workgroup barrier between the box sums and the stores.
 // ------------------------------------------------------------------------------------------------
+// Correction records of cs_mask_prep.hip (pixels whose window leaves the matrix or the diagonals 0 .. max_dist).
+// Only tiles on the rim of the band need them: the kernel reads this part of its arguments through a pointer the
+// compiler cannot see through (fix_args), so the 20 scalar registers load inside that branch instead of being
+// held -- spilled -- across the whole tile loop.
+struct MfmaFixArgs {
+    int fix_on, fix_hi_w, fix_hi_d0;
+    const float* fix_lo;
+    const float* fix_hi;
+    const float* fix_rows;
+    const float* fix_cols;
+    int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
+};
+
 struct MfmaDenseArgs {
     const float* sig;
     void* out;               // float32, or float64 when out_is_f64 (the Python surface returns float64 maps)
@@ -394,12 +407,8 @@ struct MfmaDenseArgs {
     const uint8_t* miss_col;
     const float* rowtab;             // [row][4]: nr, RA, RB, flags of the window rows
     const float* coltab;             // [3][ns]: ncol, CA, CB
-    int fix_on, fix_hi_w, fix_hi_d0;
-    const float* fix_lo;
-    const float* fix_hi;
-    const float* fix_rows;
-    const float* fix_cols;
-    int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
+    int fix_on, fix_hi_w, fix_hi_d0, fix_top, fix_bot0, fix_any_side;     // what decides whether a tile has records
+    MfmaFixArgs fx;          // read through fix_args() only
 };
 
 constexpr int MFD_ROWS_PER_THREAD = 14;       // staging: 240 threads = 40 column pairs x 6 row groups
@@ -476,27 +485,41 @@ __device__ __forceinline__ float masked_coefficient(float cs, float s1, float s2
 // correction {d n_missing, d ka, d kb} of a pixel whose window leaves the matrix or the diagonals 0..max_dist
 // (tables of cs_mask_prep.hip; same selection order as cs_corr_stream.h fix_fetch), or nullptr.  Select
 // chains instead of nested branches: 16 copies of this are inlined into the epilogue.
-__device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, int i, int j)
+typedef const __attribute__((address_space(4))) MfmaFixArgs* FixArgsPtr;
+
+__device__ __forceinline__ FixArgsPtr fix_args()
+{
+    unsigned long long kv = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kv));                  // opaque: loads through it are neither hoisted nor speculated
+    return (FixArgsPtr)(kv + offsetof(MfmaDenseArgs, fx));
+}
+
+__device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, FixArgsPtr F, int i, int j)
 {
     const int K = A.km, KH = (A.km - 1) / 2;
     const int d = j - i;
+    const int fix_on = F->fix_on, fix_side = F->fix_side, fix_top = F->fix_top, fix_bot0 = F->fix_bot0, fix_hi_d0 = F->fix_hi_d0,
+              fix_hi_w = F->fix_hi_w;
+    const float* fix_cols = F->fix_cols;
     const bool in_range = (j >= 0) & (j < A.ns) & (d >= A.out_lo) & (d <= A.out_hi) & (i < A.row_end);
-    const int x = A.fix_xband ? d - A.fix_xlo : j;
-    const bool top = i < A.fix_top;
-    const bool bot = (i >= A.fix_bot0) & (!A.fix_on | (i + KH >= A.ms) | (j + KH >= A.ns));
-    const bool side = (A.fix_cols != nullptr) & ((j < A.fix_side) | (j >= A.ns - A.fix_side));
-    const bool lo = (A.fix_on != 0) & (d >= 0) & (d < K - 1);
-    const bool hi = (A.fix_on != 0) & (d >= A.fix_hi_d0) & (d - A.fix_hi_d0 < A.fix_hi_w);
-    const long long o_rows = (long long)(top ? i : A.fix_top + i - A.fix_bot0) * A.fix_width + x;
-    const long long o_side = (long long)i * 2 * A.fix_side + (j < A.fix_side ? j : j - (A.ns - 2 * A.fix_side));
+    const int x = F->fix_xband ? d - F->fix_xlo : j;
+    const bool top = i < fix_top;
+    const bool bot = (i >= fix_bot0) & (!fix_on | (i + KH >= A.ms) | (j + KH >= A.ns));
+    const bool side = (fix_cols != nullptr) & ((j < fix_side) | (j >= A.ns - fix_side));
+    const bool lo = (fix_on != 0) & (d >= 0) & (d < K - 1);
+    const bool hi = (fix_on != 0) & (d >= fix_hi_d0) & (d - fix_hi_d0 < fix_hi_w);
+    const long long o_rows = (long long)(top ? i : fix_top + i - fix_bot0) * F->fix_width + x;
+    const long long o_side = (long long)i * 2 * fix_side + (j < fix_side ? j : j - (A.ns - 2 * fix_side));
     const long long o_lo = (long long)i * (K - 1) + d;
-    const long long o_hi = (long long)i * A.fix_hi_w + (d - A.fix_hi_d0);
-    const float* base = (top | bot) ? A.fix_rows : side ? A.fix_cols : lo ? A.fix_lo : A.fix_hi;
+    const long long o_hi = (long long)i * fix_hi_w + (d - fix_hi_d0);
+    const float* base = (top | bot) ? F->fix_rows : side ? fix_cols : lo ? F->fix_lo : F->fix_hi;
     const long long off = (top | bot) ? o_rows : side ? o_side : lo ? o_lo : o_hi;
     return (in_range & (top | bot | side | lo | hi)) ? base + 4 * off : nullptr;
 }
 
-template <bool VEC4, bool REG>
+// RSYM (REG only): 17 x 17 template whose rows mirror (row s == row 16 - s): 9 head fragments in registers
+// instead of 17 -- the masked epilogue needs the 32 registers.
+template <bool VEC4, bool REG, bool RSYM = false>
 __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDenseArgs A)
 {
 
@@ -653,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             }
             const unsigned kmask8 = (((1u << K) - 1u) >> (8 * g)) & 0xffu;      // template columns 8 g .. 8 g + 7 that exist
             const int dmin = J0 - (I0 + MF_T - 1), dmax = J0 + MF_T - 1 - I0;
-            const bool needs_fix = !(A.dbg & 256) && ((I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_cols != nullptr) |
+            const bool needs_fix = !(A.dbg & 256) && ((I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_any_side != 0) |
                                    (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
                                                  (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w))));
             // every pixel of the tile is produced: rows below row_end, columns inside the matrix, diagonals inside the band
@@ -708,10 +731,12 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 if (needs_fix) {
                     // pixels whose window leaves the matrix or the diagonals 0 .. max_dist (tiles on the rim of the
                     // band): one copy of the record lookup, rolled over the 8 pixels
+                    const FixArgsPtr F = fix_args();
 #pragma unroll 1
                     for (int k = 0; k < 8; ++k) {
                         const int j = J0 + 16 * (2 * half + (k >> 2)) + 4 * g + (k & 3);
-                        const float* f = mask_fix_record(A, i, j);
+                        const float* f = mask_fix_record(A, F, i, j);
+                        if (!__builtin_amdgcn_ballot_w64(f != nullptr)) continue;
                         float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
                         if (f) {
                             d0 = f[0];
@@ -914,14 +939,15 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
     if (tile < tile_end) fetch(tile, 0);       // the first tile is on its way while the weights are loaded
 
     // ---- weights: heads of all 17 template rows in registers (rows >= km are zero), tails in LDS
-    h8 wh[17];
+    constexpr int kHeads = RSYM ? 9 : 17;
+    h8 wh[kHeads];
     {
         const h8* frag = reinterpret_cast<const h8*>(A.frag);
         h8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
 #pragma unroll
-        for (int s = 0; s < 17; ++s) {
+        for (int s = 0; s < kHeads; ++s) {
             const int sc = min(s, km - 1);
             const h8 a = frag[(2 * sc + 0) * 64 + lane];
             wh[s] = s < km ? a : z;
@@ -1168,11 +1194,11 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[s], ah[c], acc[c]);     // weights as A: transposed tile
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[RSYM && s > 8 ? 16 - s : s], ah[c], acc[c]);     // weights as A: transposed tile
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = mfma16(bl, ah[c], acc[c]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[s], al[c], acc[c]);
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[RSYM && s > 8 ? 16 - s : s], al[c], acc[c]);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < 17) {
 #pragma unroll
@@ -1284,27 +1310,39 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.fix_on = A.fix_on;
         D.fix_hi_w = A.fix_hi_w;
         D.fix_hi_d0 = A.fix_hi_d0;
-        D.fix_lo = A.fix_lo;
-        D.fix_hi = A.fix_hi;
-        D.fix_rows = A.fix_rows;
-        D.fix_cols = A.fix_cols;
         D.fix_top = A.fix_top;
         D.fix_bot0 = A.fix_bot0;
-        D.fix_width = A.fix_width;
-        D.fix_xband = A.fix_xband;
-        D.fix_xlo = A.fix_xlo;
-        D.fix_side = A.fix_side;
+        D.fix_any_side = A.fix_cols != nullptr;
+        D.fx.fix_on = A.fix_on;
+        D.fx.fix_hi_w = A.fix_hi_w;
+        D.fx.fix_hi_d0 = A.fix_hi_d0;
+        D.fx.fix_lo = A.fix_lo;
+        D.fx.fix_hi = A.fix_hi;
+        D.fx.fix_rows = A.fix_rows;
+        D.fx.fix_cols = A.fix_cols;
+        D.fx.fix_top = A.fix_top;
+        D.fx.fix_bot0 = A.fix_bot0;
+        D.fx.fix_width = A.fix_width;
+        D.fx.fix_xband = A.fix_xband;
+        D.fx.fix_xlo = A.fix_xlo;
+        D.fx.fix_side = A.fix_side;
         if (reg_f32) {
             *dense_path = 2;
-            // 16-byte transfers whenever a row stores at least 4 values (no alignment needed)
-            const bool vec_r = (D.band_in ? D.bw_in : D.ns) >= 4 && !getenv("CHROMOSIGHT_HIP_MFMA_NOVEC");
-            const void* kr = vec_r ? (const void*)corr_mfma_dense_kernel<true, true> : (const void*)corr_mfma_dense_kernel<false, true>;
+            // 16-byte transfers need rows that store at least 4 values (no alignment needed); narrower maps take the
+            // streaming kernel
+            if ((D.band_in ? D.bw_in : D.ns) < 4) {
+                *dense_path = 0;
+                return -4;
+            }
+            *dense_path = 2;
+            const bool rsym = A.w_sym && A.km == 17 && A.kn == 17 && !getenv("CHROMOSIGHT_HIP_MFMA_NORSYM");
+            const void* kr = rsym ? (const void*)corr_mfma_dense_kernel<true, true, true> : (const void*)corr_mfma_dense_kernel<true, true, false>;
             hipError_t e3 = allow_big_lds(kr);
             if (e3 != hipSuccess) return (int)e3;
             const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
             const int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
-            if (vec_r) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
-            else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            if (rsym) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, true, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            else hipLaunchKernelGGL((corr_mfma_dense_kernel<true, true, false>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
             return (int)hipGetLastError();
         }
         // 16-byte pieces: the tile's first staged column (64 bx - kw) and the row length must be multiples

@@ -283,8 +283,12 @@ bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
     if (A.sig_is_f64 || A.xcorr_only) return false;
     if ((A.sig.layout == CS_LAYOUT_BAND ? A.sig.band_w : A.ns) < 4) return false;      // 16-byte staging pieces
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
+    // default: the spill-free instance (17 x 17 template with mirrored rows -- the loops template); CHROMOSIGHT_HIP_MFMA_REG=1
+    // sends every compatible call here, =0 none (the streaming kernel takes them)
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA_REG");
-    return e && e[0] == '1';
+    if (e && e[0] == '1') return true;
+    if (e && e[0] == '0') return false;
+    return A.w_sym && A.km == 17;
 }
 
 bool mfma_wanted(const cs::CorrArgs<float>& A)

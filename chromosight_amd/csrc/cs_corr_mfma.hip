@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
     const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int wr0 = 16 * wv;
     const int c2 = tid % 40, rg = tid / 40;         // staging: column pair, row group (threads >= 240 idle)
+    const int c2_ = c2, rg_ = rg;
     const bool stager = tid < 240;
     // input rows that windows of [row_begin, row_end) reach and that exist
     const int p_min = max(0, A.row_begin - kh), p_max = min(A.ms, A.row_end + (km - 1) - kh) - 1;
@@ -563,17 +564,20 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
     const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     constexpr int kPiecesPerRow = VEC4 ? MF_R / 4 : MF_R;
     constexpr int kTransfers = VEC4 ? 25 : 100;
-    const int e0 = 64 * wv_u + lane;
-    const int r_first = e0 / kPiecesPerRow, c_first = e0 - r_first * kPiecesPerRow;
     auto fetch = [&](int tile, int slot) {
         int I0, J0;
         tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
-        int r = r_first, c = c_first;
+        // The per-lane constants of the transfers are recomputed from an opaque copy of the lane index: hoisted out
+        // of the tile loop they are spilled, and a reload here waits (vmcnt) for the previous tile's stores.
+        int lane_f = lane;
+        if constexpr (REG) asm volatile("" : "+v"(lane_f));         // (the dense instances have registers to spare)
+        const int e0 = 64 * wv_u + lane_f;
+        int r = e0 / kPiecesPerRow, c = e0 - r * kPiecesPerRow;
         if (REG && !(A.dbg & 16384)) {
             // column terms of the tile's 64 columns (waves 0..2) and the flags of its 80 staged columns (wave 3)
             if (wv_u < 3) {
-                const float* src = A.coltab + (size_t)wv_u * A.ns + min(max(J0 + lane, 0), A.ns - 1);
+                const float* src = A.coltab + (size_t)wv_u * A.ns + min(max(J0 + lane_f, 0), A.ns - 1);
                 __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(
                     (__attribute__((address_space(3))) char*)(smem) + MFD_COL + (slot * 3 + wv_u) * 256), 4, 0, 0);
             } else {
@@ -581,9 +585,9 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 // beyond are harmless repeats; addresses clamped to the dwords that overlap the array)
                 const long long base = (long long)(uintptr_t)A.miss_col;
                 const long long first = ((base + Q0) >> 2) << 2;
-                long long addr = first + 4 * min(lane, 23);
+                long long addr = first + 4 * min(lane_f, 23);
                 addr = min(max(addr, (base >> 2) << 2), ((base + A.ns - 1) >> 2) << 2);
-                if (lane < 24)
+                if (lane_f < 24)
                     __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>((uintptr_t)addr),
                                                      (__attribute__((address_space(3))) void*)(
                                                          (__attribute__((address_space(3))) char*)(smem) + MFD_CFB + slot * 128), 4, 0, 0);
@@ -1003,6 +1007,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                     amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
                 }
             } else {
+                int c2 = c2_, rg = rg_;               // (opaque copies: see fetch)
+                if constexpr (REG) asm volatile("" : "+v"(c2), "+v"(rg));
 #pragma unroll
                 for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
                     const int r = rg + 6 * k;

@@ -148,7 +148,8 @@ def test_general_kernel_masks_bands_nobs(monkeypatch):
 
 @pytest.mark.parametrize("n,md,ksize", [(900, 120, 17), (1500, 400, 17), (700, 60, 9), (400, 399, 13)])
 def test_tile_kernel_with_bin_masks(n, md, ksize, monkeypatch):
-    """CHROMOSIGHT_HIP_MFMA_REG=1: per-bin masks on the persistent tile kernel (factorised mask tables of
+    """Per-bin masks on the persistent tile kernel (the default for the mirrored 17 x 17 loops template;
+    CHROMOSIGHT_HIP_MFMA_REG=1 sends the other template sizes there too) (factorised mask tables of
     cs_mask_prep.hip, column flags x flagged-row cross term, edge / frame corrections), band in / band
     out, coefficients and n_obs (through the p-values) against the oracle."""
     monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "1")
@@ -172,7 +173,7 @@ def test_tile_kernel_with_bin_masks(n, md, ksize, monkeypatch):
     band = (jj - ii >= 0) & (jj - ii <= md)
     assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma tile kernel, bin masks n={n} md={md} k={ksize}")
     # same call on the streaming kernel: coefficients and p-values (n_obs) agree
-    monkeypatch.delenv("CHROMOSIGHT_HIP_MFMA_REG")
+    monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "0")
     c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
                             missing_tol=0.75, pval=True)
     assert last_kernel() == KERNEL_STREAM

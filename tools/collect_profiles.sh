@@ -23,11 +23,11 @@ bench --workload c4 --steps 5 --warmup 1 > "$out/bench_c4.json"
 bench --size 16384 --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_dense16384.json"
 bench --precision f64 --no-cpu-baseline > "$out/bench_c2_f64.json"
 CHROMOSIGHT_HIP_NO_MFMA=1 CHROMOSIGHT_HIP_NO_SYMMETRY=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c2_nosym.json"
-# the packed-FMA streaming kernel on the dense map (the default there is the matrix-core kernel), and the
-# experimental matrix-core tile kernel with per-bin masks on the banded maps (the default there is streaming)
+# the packed-FMA streaming kernel on the workloads whose default is a matrix-core kernel (dense map; banded maps with
+# the mirrored 17 x 17 loops template)
 CHROMOSIGHT_HIP_NO_MFMA=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c2_stream.json"
-CHROMOSIGHT_HIP_MFMA_REG=1 python bench.py --workload c3k --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c3k_mfma_reg.json"
-CHROMOSIGHT_HIP_MFMA_REG=1 python bench.py --workload c4p --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c4p_mfma_reg.json"
+CHROMOSIGHT_HIP_MFMA_REG=0 python bench.py --workload c3k --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c3k_stream.json"
+CHROMOSIGHT_HIP_MFMA_REG=0 python bench.py --workload c4p --no-cpu-baseline 2>/dev/null | tail -1 > "$out/bench_c4p_stream.json"
 
 # 2. kernel traces of the same commands (c3 and c4 show the helper kernels: band extents, distance law,
 #    tiler, mask tables, compaction, sort, foci, re-scoring)
@@ -53,6 +53,9 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-trace --output-format csv -d "$out/pmc_c2_mfma" -o c2 -- \
     python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c2_mfma.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+    --kernel-trace --output-format csv -d "$out/pmc_c4p_mfma" -o c4p -- \
+    python bench.py --workload c4p --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c4p_mfma.log" 2>&1
 # helper kernels of the CSR path: bytes moved by the distance law / tiler (c3)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c3_$c" -o c3 -- \

@@ -21,7 +21,7 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in ("c2", "c3", "c3k", "c4p", "c4", "dense16384", "c2_f64", "c2_nosym", "c2_stream", "c3k_mfma_reg", "c4p_mfma_reg"):
+for name in ("c2", "c3", "c3k", "c4p", "c4", "dense16384", "c2_f64", "c2_nosym", "c2_stream", "c3k_stream", "c4p_stream"):
     f = os.path.join(src, f"bench_{name}.json")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_bench_{name}.json"))
@@ -70,12 +70,12 @@ for w, key in (("c2", "c2_4096_f32"), ("c3k", "c3k_band_50000x234"), ("c4p", "c4
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         rec.update(per_dispatch(find(f"pmc_{w}_{c}/**/*counter_collection.csv"), CORR_KERNELS))
     rec.update(per_dispatch(find(f"pmc_{w}_sq/**/*counter_collection.csv"), CORR_KERNELS))
-    if w == "c2":
-        rec.update(per_dispatch(find("pmc_c2_mfma/**/*counter_collection.csv"), CORR_KERNELS))
+    if w in ("c2", "c4p"):
+        rec.update(per_dispatch(find(f"pmc_{w}_mfma/**/*counter_collection.csv"), CORR_KERNELS))
         if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") and rec.get("GRBM_GUI_ACTIVE"):
             # busy cycles are summed over the 1024 SIMDs, GUI_ACTIVE over the 8 XCDs
             rec["mfma_pipe_busy_frac"] = (rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (rec["GRBM_GUI_ACTIVE"] / 8.0)
-        rec["kernel"] = "corr_mfma_dense_kernel (default for the dense map) -- see the kernel trace"
+    rec["kernel"] = "corr_mfma_dense_kernel (<VEC4, REG, RSYM> instance: see the kernel trace)"
     if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
         rec["hbm_bytes_per_dispatch"] = (rec["FETCH_SIZE"] * f + rec["WRITE_SIZE"]) * 1024.0
         rec["hbm_bytes_note"] = (f"FETCH_SIZE x {f:.3f} (calibration) + WRITE_SIZE, KiB -> bytes")

@@ -968,10 +968,15 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             if (idx < 17 * 64) reinterpret_cast<h8*>(smem + MFD_WL)[idx] = (idx >> 6) < km ? tails[k] : z;
         }
     }
-    // One emit site: the loop runs one pass beyond the last tile, in which only the pending tile is emitted.
+    // REG: one emit site (its epilogue is 4 K instructions) -- the loop runs one pass beyond the last tile, in which
+    // only the pending tile is emitted.  The dense instances emit the last tile after the loop.
     for (;; tile += tile_step) {
-        const bool have = tile < tile_end;              // uniform over the workgroup
-        if (!have && !pending) break;
+        const bool have = REG ? tile < tile_end : true;              // uniform over the workgroup
+        if constexpr (REG) {
+            if (!have && !pending) break;
+        } else {
+            if (tile >= tile_end) break;
+        }
         int I0 = 0, J0 = 0;
         if (have) tile_origin(tile, I0, J0);
         const int P0 = I0 - kh, Q0 = J0 - kw;
@@ -1229,6 +1234,9 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
         if constexpr (REG) p_hdr = *reinterpret_cast<const f4*>(A.rowtab + 4 * (size_t)min(I0 + wr0 + n, A.ms - 1));
         slot ^= 1;
         pending = true;
+    }
+    if constexpr (!REG) {
+        if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
     }
 }
 

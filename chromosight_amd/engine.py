@@ -185,7 +185,7 @@ def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter,
 
 
 def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter, diag_only, max_dists, miss_rows, miss_cols,
-                          missing_tol=0.75, want_windows=True, min_size=2, stream=None):
+                          missing_tol=0.75, want_windows=True, min_size=2, stream=None, flat=False):
     """detect mode of a 1-D pattern (<= 4 scanned diagonals) on MANY banded sub-matrices with one native call
     (cs_detect_foci_batch).  Returns a list of (records, windows) per sub-matrix, or None when the library
     says a block does not qualify (the caller then goes block by block)."""
@@ -212,11 +212,17 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
             continue
         dev._check(rc)
         break
+    cnt = np.frombuffer(counts, dtype=np.int64).copy()
+    total = int(cnt.sum())
+    if flat:
+        # all records (and windows) in block order + the per-block counts: the caller post-processes them in one go
+        windows = win.reshape(-1)[:total * kk].reshape(total, kspec.km, kspec.kn).copy() if want_windows else None
+        return rec[:total].copy(), windows, cnt
     out, o = [], 0
-    flat = win.reshape(-1) if want_windows else None
+    flat_w = win.reshape(-1) if want_windows else None
     for b in range(n_blocks):
-        k = int(counts[b])
-        windows = flat[o * kk:(o + k) * kk].reshape(k, kspec.km, kspec.kn).copy() if want_windows else None
+        k = int(cnt[b])
+        windows = flat_w[o * kk:(o + k) * kk].reshape(k, kspec.km, kspec.kn).copy() if want_windows else None
         out.append((rec[o:o + k].copy(), windows))
         o += k
     return out

@@ -630,9 +630,24 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
         dev, [b.sig for b in blocks], [b.shape for b in blocks], kspec, pearson=kernel_config["pearson"],
         hi_diags=[b.max_dist for b in blocks], inter=False, diag_only=True, max_dists=[b.max_dist for b in blocks],
         miss_rows=[b.miss_row for b in blocks], miss_cols=[b.miss_col for b in blocks], missing_tol=missing_tol,
-        want_windows=want_windows, stream=stream)
+        want_windows=want_windows, stream=stream, flat=raw)
     if res is None:
         return None
+    if raw:
+        # the acceptance rules on the records of ALL blocks at once (23 numpy passes over ~350 records each cost
+        # more than the native call), then cut at the block boundaries
+        rec, windows, counts = res
+        per = lambda values: np.repeat(np.asarray(values, dtype=np.int64), counts)
+        rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+        shape = (per([b.shape[0] for b in blocks]), per([b.shape[1] for b in blocks]))
+        rec4, windows, ok = _accept_records(rec, windows, rr, cc, "detect", shape, kspec, kernel_config, inter=False,
+                                            max_dist=per([b.max_dist for b in blocks]), full=True, raw=True, return_ok=True)
+        ends = np.cumsum(counts)
+        kept = np.concatenate([[0], np.cumsum(ok)])[ends]              # accepted records up to the end of each block
+        cuts = kept[:-1]
+        parts = np.split(rec4, cuts)
+        wparts = np.split(windows, cuts) if windows is not None else [None] * len(blocks)
+        return [(None, None) if n == 0 else (t, w) for n, t, w in zip(counts, parts, wparts)]
     out = []
     for b, (rec, windows) in zip(blocks, res):
         if rec.shape[0] == 0:
@@ -644,9 +659,10 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     return out
 
 
-def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw):
+def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw, return_ok=False):
     """The acceptance rules of pattern_detector / validate_patterns on the records the device returned
-    (reference detection.py:121-141, 269-270, 332-336): (table, windows)."""
+    (reference detection.py:121-141, 269-270, 332-336): (table, windows).  `shape` and `max_dist` may be
+    per-record arrays (records of several sub-matrices in one call)."""
     ms, ns = shape
     km, kn = kspec.km, kspec.kn
     missing_tol = kernel_config["max_perc_undetected"] / 100
@@ -677,7 +693,7 @@ def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config,
         if run_mode == "detect":
             rec4 = rec4[ok]
             windows = windows[ok] if windows is not None else None
-        return rec4, windows
+        return (rec4, windows, ok) if return_ok else (rec4, windows)
     table = pd.DataFrame({"bin1": rr, "bin2": cc, "score": scores})
     if run_mode == "detect":
         table = table.loc[ok, :]

@@ -225,6 +225,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
     bins, identical on all ranks, in the single-process order."""
     batch = None
+    stage_default = stage is None
     if stage is None and detect is None:
         from . import pipeline
         batch = lambda g, blks, cfg, k, t, w=True: pipeline.detect_blocks(g, blks, cfg, k, tsvd=t, raw=True, want_windows=w)
@@ -239,7 +240,11 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     sizes = [genome.chrom_size(ci) for ci in range(genome.n_chrom)]
     costs = [block_cost((n, n), max_dist, False) for n in sizes]
     mine = list(owned) if owned is not None else assign_blocks(costs, world)[rank]
-    staged = {ci: stage(genome, ci, max_dist, largest) for ci in mine}
+    if batch is not None and stage_default:
+        # the device pipeline stages its blocks a few at a time (pipeline.DeviceCool.stage_blocks)
+        staged = dict(zip(mine, genome.stage_blocks(mine, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
+    else:
+        staged = {ci: stage(genome, ci, max_dist, largest) for ci in mine}
     out = []
     for kernel_id, kernel in enumerate(kernel_config["kernels"]):
         kernel = np.asarray(kernel, dtype=np.float64)

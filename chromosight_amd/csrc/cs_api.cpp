@@ -288,6 +288,8 @@ bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA_REG");
     if (e && e[0] == '1') return true;
     if (e && e[0] == '0') return false;
+    const char* general = std::getenv("CHROMOSIGHT_HIP_MFMA");
+    if (general && general[0] == '1') return false;      // the general matrix-core kernel was asked for by name
     return A.w_sym && A.km == 17;
 }
 

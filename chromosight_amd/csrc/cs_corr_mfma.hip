@@ -736,9 +736,16 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                     // pixels whose window leaves the matrix or the diagonals 0 .. max_dist (tiles on the rim of the
                     // band): one copy of the record lookup, rolled over the 8 pixels
                     const FixArgsPtr F = fix_args();
+                    const int iw0 = I0 + wr0;                 // the wave's 16 rows
+                    const bool rows_hit = (iw0 < A.fix_top) | (iw0 + 15 >= A.fix_bot0) | (A.fix_any_side != 0);
 #pragma unroll 1
                     for (int k = 0; k < 8; ++k) {
-                        const int j = J0 + 16 * (2 * half + (k >> 2)) + 4 * g + (k & 3);
+                        // the wave's pixels of this step: columns j0 + 4 g, diagonals [j0 - iw0 - 15, j0 + 12 - iw0]
+                        const int j0 = J0 + 16 * (2 * half + (k >> 2)) + (k & 3);
+                        const int dlo = j0 - iw0 - 15, dhi = j0 + 12 - iw0;
+                        const bool diag_hit = A.fix_on && ((dlo < K - 1 && dhi >= 0) | (dhi >= A.fix_hi_d0 && dlo < A.fix_hi_d0 + A.fix_hi_w));
+                        if (!(rows_hit | diag_hit)) continue;
+                        const int j = j0 + 4 * g;
                         const float* f = mask_fix_record(A, F, i, j);
                         if (!__builtin_amdgcn_ballot_w64(f != nullptr)) continue;
                         float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;

@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3k", "c4p", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3k", "c4p", "c4", "c5"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=4096, help="c2 only: side of the dense map (default 4096)")
@@ -326,6 +326,52 @@ def run_c4(args, rank, local_rank, world, dist, torch):
         }))
 
 
+def run_c5(args, rank, world):
+    """C5 of BASELINE.md: `quantify --inter` with the three 11 x 11 borders templates on the committed 17-chromosome
+    yeast map (tests/golden/yeast_cool.npz, the decoded .cool; positions = the fixture's: cohesin-peak pairs on the
+    intra blocks, seeded positions on the inter blocks).  One step = pipeline.quantify end to end from the host
+    pixel table: upload, staging of every sub-matrix that holds a position (detrend / median scaling), 3 templates,
+    best-of-templates selection.  N > 1: every rank runs the same job (replicas; the job is 22 ms)."""
+    import pandas as pd
+    from chromosight_amd import pipeline
+    here = os.path.dirname(os.path.abspath(__file__))
+    cool = dict(np.load(os.path.join(here, "tests", "golden", "yeast_cool.npz"), allow_pickle=True))
+    g = dict(np.load(os.path.join(here, "tests", "golden", "yeast_quantify.npz"), allow_pickle=True))
+    names = [str(n) for n in cool["chrom_names"]]
+    binsize = int(cool["binsize"])
+    rows, n_inter = [], 0
+    for bi in range(int(g["n_blocks"])):
+        ca, cb = (int(x) for x in g[f"b{bi}_chroms"])
+        for r, c in g[f"b{bi}_coords"]:
+            rows.append((names[ca], int(r) * binsize, (int(r) + 1) * binsize, names[cb], int(c) * binsize, (int(c) + 1) * binsize))
+            n_inter += ca != cb
+    positions = pd.DataFrame(rows, columns=["chrom1", "start1", "end1", "chrom2", "start2", "end2"])
+    cfg = dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+               kernels=[g[f"kernel{ki}"] for ki in range(3)], max_iterations=1, min_separation=5000)
+    md = int(g["cfg_max_dist_bp"])
+    table = None
+    for _ in range(max(args.warmup, 1)):
+        table, _w = pipeline.quantify(cool, positions, cfg, inter=True, max_dist_bp=md)
+    pipeline.get_device().sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table, _w = pipeline.quantify(cool, positions, cfg, inter=True, max_dist_bp=md)
+    pipeline.get_device().sync()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "positions/s quantify end to end (C5: yeast, --inter, 3 x 11x11 borders templates)",
+            "value": round(len(positions) * 3 * world / (ms * 1e-3), 1), "unit": "scored (position, template) pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "tests/golden/yeast_cool.npz (real map, committed fixture)",
+            "config": {"workload": "C5: 17-chromosome yeast map (6074 bins), quantify --inter, win-size 11, "
+                                   f"{len(positions)} positions ({n_inter} on inter-chromosomal blocks)",
+                       "positions": len(positions), "templates": 3, "rows_out": int(len(table)),
+                       "parallelism": f"{world} replica(s)"},
+        }))
+
+
 def spawn_ranks(n_gpus):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script with
     torch.distributed.run on 127.0.0.1 (one process per GPU) and relay their output."""
@@ -364,6 +410,11 @@ def main():
         except Exception:
             torch = None
 
+    if args.workload == "c5":
+        run_c5(args, rank, world)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload == "c4":
         run_c4(args, rank, local_rank, world, dist, torch)
         if dist is not None:

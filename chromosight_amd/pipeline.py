@@ -663,8 +663,6 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     km, kn = kernels[0].shape
     max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
     largest = max(k.shape[0] for k in kernels)
-    bed2d["score"] = np.nan
-    bed2d["pvalue"] = np.nan
     pos1 = (bed2d.start1 + bed2d.end1) // 2
     pos2 = (bed2d.start2 + bed2d.end2) // 2
     g1 = dcool.bins_of(bed2d.chrom1, pos1)
@@ -673,25 +671,36 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     c1 = np.array([index.get(str(c), -1) for c in bed2d.chrom1])
     c2 = np.array([index.get(str(c), -1) for c in bed2d.chrom2])
     n_pos = len(bed2d)
-    bed_out = [bed2d.copy() for _ in kernels]
+    # plain arrays while the blocks are scanned (one pandas assignment per block and template cost more than the
+    # native calls); the tables are assembled once below
+    score_out = [np.full(n_pos, np.nan) for _ in kernels]
+    pval_out = [np.full(n_pos, np.nan) for _ in kernels]
     win_out = [np.full((n_pos, km, kn), np.nan) for _ in kernels]
-    pairs = sub_matrices(dcool, inter)
+    located = (g1 >= 0) & (g2 >= 0)
+    # positions of every sub-matrix, in input order: one stable sort by (chrom1, chrom2)
+    pair_key = np.where(located, c1.astype(np.int64) * (dcool.n_chrom + 1) + c2, -1)
+    order = np.argsort(pair_key, kind="stable")
+    keys_sorted = pair_key[order]
+    todo = []
+    for ca, cb in sub_matrices(dcool, inter):
+        key = ca * (dcool.n_chrom + 1) + cb
+        lo, hi = np.searchsorted(keys_sorted, key, "left"), np.searchsorted(keys_sorted, key, "right")
+        if hi > lo:                                         # (no pattern on a sub-matrix: it is not scanned, :240)
+            sel = order[lo:hi]
+            todo.append((ca, cb, sel, np.column_stack([g1[sel] - dcool.offsets[ca], g2[sel] - dcool.offsets[cb]]).astype(int)))
     staged = {}
     for kernel_id, kernel in enumerate(kernels):
-        for ca, cb in pairs:
-            sel = np.flatnonzero((c1 == ca) & (c2 == cb) & (g1 >= 0) & (g2 >= 0))
-            if sel.size == 0:
-                continue                                    # no pattern on this sub-matrix: not scanned (:240)
+        for ca, cb, sel, coords in todo:
             if (ca, cb) not in staged:
                 staged[(ca, cb)] = dcool.stage_intra(ca, max_dist, largest, smooth=smooth, resident=True) if ca == cb \
                     else dcool.stage_inter(ca, cb, resident=True)
-            coords = np.column_stack([g1[sel] - dcool.offsets[ca], g2[sel] - dcool.offsets[cb]]).astype(int)
-            tab, wins = detect_block(dcool, staged[(ca, cb)], cfg, kernel, tsvd=tsvd, coords=coords)
-            if tab is None:
+            rec, wins = detect_block(dcool, staged[(ca, cb)], cfg, kernel, tsvd=tsvd, coords=coords.copy(), raw=True)
+            if rec is None:
                 continue
-            bed_out[kernel_id].loc[sel, "score"] = tab["score"].to_numpy()
-            bed_out[kernel_id].loc[sel, "pvalue"] = tab["pvalue"].to_numpy()
+            score_out[kernel_id][sel] = rec[:, 2]
+            pval_out[kernel_id][sel] = rec[:, 3]
             win_out[kernel_id][sel] = wins
+    bed_out = [bed2d.assign(score=score_out[k], pvalue=pval_out[k]) for k in range(len(kernels))]
     # best score of every coordinate among the templates, as the reference selects it (:432-441)
     bed = pd.concat(bed_out, axis=0).reset_index(drop=True)
     windows = np.concatenate(win_out, axis=0)

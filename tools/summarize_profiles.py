@@ -21,7 +21,7 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in ("c2", "c3", "c3k", "c4p", "c4", "dense16384", "c2_f64", "c2_nosym", "c2_stream", "c3k_stream", "c4p_stream"):
+for name in ("c2", "c3", "c3k", "c4p", "c4", "c5", "dense16384", "c2_f64", "c2_nosym", "c2_stream", "c3k_stream", "c4p_stream"):
     f = os.path.join(src, f"bench_{name}.json")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_bench_{name}.json"))

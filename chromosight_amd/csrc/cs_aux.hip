@@ -391,10 +391,28 @@ __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double>
     }
 }
 
+__global__ __launch_bounds__(256) void rescore_f64_run_kernel(const CorrArgs<double> A, const int* __restrict__ rows,
+                                                              const int* __restrict__ cols, long long n_px,
+                                                              double* __restrict__ out_corr, double* __restrict__ out_nobs,
+                                                              const long long* __restrict__ n_ptr)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_px || (n_ptr && t >= *n_ptr)) return;
+    double r, nobs;
+    rescore_pixel_lane(A, rows[t], cols[t], r, nobs);
+    out_corr[t] = r;
+    if (out_nobs) out_nobs[t] = nobs;
+}
+
 int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* cols, long long n_px,
-                       double* out_corr, double* out_nobs, hipStream_t stream, const long long* n_ptr)
+                       double* out_corr, double* out_nobs, hipStream_t stream, const long long* n_ptr, int run)
 {
     if (n_px == 0) return 0;
+    if (run) {
+        hipLaunchKernelGGL(rescore_f64_run_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, A, rows, cols, n_px,
+                           out_corr, out_nobs, n_ptr);
+        return (int)hipGetLastError();
+    }
     const long long blocks = (n_px + 3) / 4;              // 4 waves = 4 pixels per block
     hipLaunchKernelGGL(rescore_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, rows, cols, n_px, out_corr,
                        out_nobs, n_ptr);

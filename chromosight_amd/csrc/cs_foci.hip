@@ -390,6 +390,101 @@ __global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<doubl
     }
 }
 
+// lane-per-pixel version for the enumerated diagonals (rescore_pixel_lane).  A workgroup's 256 list entries are
+// normally a run of 256 / w rows on w neighbouring diagonals of one sub-matrix: the rows and diagonals their
+// windows reach are staged in LDS once (coalesced) and every lane walks its window there -- straight from memory
+// the 64 lanes of a wave read 64 different rows per instruction and 24 waves per CU thrash L1 (measured 485 us for
+// 400 000 pixels; the wave-per-pixel kernel 714).  Workgroups that straddle two sub-matrices or whose entries are
+// not such a run take the direct route, a wave that straddles sub-matrices one after the other.
+constexpr int kRunWeights = 3 * 17 * 17;               // the three weight sets of a template of up to 289 entries
+
+// dynamic LDS: tile (tile_cap doubles), then the weights, then the row / column flags
+__global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
+                                                                const int* __restrict__ rows, const int* __restrict__ cols,
+                                                                long long n_px, double* __restrict__ out_corr, int tile_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) double run_smem[];
+    double* const tile = run_smem;
+    double* const wl = run_smem + tile_cap;
+    unsigned char* const rfl = reinterpret_cast<unsigned char*>(wl + kRunWeights);       // 512 row flags, 1024 column flags
+    unsigned char* const cfl = rfl + 512;
+    __shared__ int red[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long t = (long long)blockIdx.x * blockDim.x + tid;
+    const bool valid = t < n_px;
+    const int b = valid ? blk[t] : -1;
+    const int oi = valid ? rows[t] : 0, oj = valid ? cols[t] : 0;
+    // extent of the workgroup's entries (rows, diagonals, sub-matrices): wave reductions, then 4 partial results each
+    {
+        int v_lo[3] = {valid ? oi : 0x7fffffff, valid ? oj - oi : 0x7fffffff, valid ? b : 0x7fffffff};
+        int v_hi[3] = {valid ? oi : -0x7fffffff, valid ? oj - oi : -0x7fffffff, valid ? b : -0x7fffffff};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                v_lo[k] = min(v_lo[k], __shfl_xor(v_lo[k], o));
+                v_hi[k] = max(v_hi[k], __shfl_xor(v_hi[k], o));
+            }
+        }
+        __shared__ int part[4][6];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                part[tid >> 6][2 * k] = v_lo[k];
+                part[tid >> 6][2 * k + 1] = v_hi[k];
+            }
+        }
+        __syncthreads();
+        if (tid < 6) {
+            int v = part[0][tid];
+            for (int w = 1; w < 4; ++w) v = (tid & 1) ? max(v, part[w][tid]) : min(v, part[w][tid]);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    const int i_lo = red[0], i_hi = red[1], d_lo = red[2], d_hi = red[3], b_lo = red[4], b_hi = red[5];
+    double r = 0.0, nobs = 0.0;
+    bool staged = false;
+    if (b_lo == b_hi && b_lo >= 0 && tile_cap > 0) {
+        const CorrArgs<double>& A = tab[b_lo];
+        const int km = A.km, kn = A.kn, kh = (km - 1) / 2, kw = (kn - 1) / 2;
+        const int P0 = i_lo - kh, RN = (i_hi - i_lo) + km;
+        const int D0 = d_lo - kw - (km - 1 - kh), DN = (d_hi - d_lo) + (kn - 1) + (km - 1) + 1;
+        const int C0 = P0 + D0, CN = RN + DN;                  // columns the tile can reach
+        if ((long long)RN * DN <= tile_cap && RN <= 512 && CN <= 1024 && 3 * km * kn <= kRunWeights) {
+            staged = true;
+            for (int idx = tid; idx < 3 * km * kn; idx += 256) wl[idx] = A.w[idx];
+            const bool bins = A.mask_mode == 1;
+            for (int idx = tid; idx < RN; idx += 256) {
+                const int p = P0 + idx;
+                rfl[idx] = (bins && p >= 0 && p < A.ms) ? A.miss_row[p] : 0;
+            }
+            for (int idx = tid; idx < CN; idx += 256) {
+                const int q = C0 + idx;
+                cfl[idx] = (bins && q >= 0 && q < A.ns) ? A.miss_col[q] : 0;
+            }
+            for (int idx = tid; idx < RN * DN; idx += 256) {
+                const int rr = idx / DN, dd = idx - rr * DN;
+                const int p = P0 + rr;
+                tile[idx] = load_signal(A, p, p + D0 + dd);
+            }
+            __syncthreads();
+            if (valid) rescore_pixel_lane_lds(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+        }
+    }
+    if (!staged) {
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const int b0 = __builtin_amdgcn_readlane(b, first);
+            const bool mine = valid && b == b0;
+            if (mine) rescore_pixel_lane(tab[b0], oi, oj, r, nobs);
+            todo &= ~__builtin_amdgcn_ballot_w64(mine);
+        }
+    }
+    if (valid) out_corr[t] = r;
+}
+
 __global__ __launch_bounds__(kSmallThreads) void foci_small_batch_kernel(
     const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ seg, const long long* __restrict__ keys_s,
     const double* __restrict__ vals, double pearson, int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos,
@@ -636,7 +731,7 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
         hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
     }
     // exact coefficients, exact threshold
-    int rc = launch_rescore_f64(A64, s_rows, s_cols, n_cand, vals, nullptr, stream);
+    int rc = launch_rescore_f64(A64, s_rows, s_cols, n_cand, vals, nullptr, stream, nullptr, presorted && !getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE"));
     if (rc) return rc;
     if (n_cand <= kSmallMax && !getenv("CHROMOSIGHT_HIP_NO_FUSED_FOCI")) {
         hipLaunchKernelGGL(foci_small_kernel, dim3(1), dim3(kSmallThreads), 0, stream, keys_s, vals, n_cand, pearson, ns, min_size,
@@ -934,8 +1029,22 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
         const unsigned g = blocks_for(n_total);
         hipLaunchKernelGGL(narrow_enumerate_batch_kernel, dim3(g), dim3(kThreads), 0, stream, tab, seg, lo_w, n_blocks, rows, cols, keys,
                            blk);
-        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
-                           (const long long*)nullptr, vals, (double*)nullptr);
+        if (getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE"))
+            hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
+                               (const long long*)nullptr, vals, (double*)nullptr);
+        else {
+            // tile of a workgroup's 256 entries: 256 / w rows (+ halo) x (w + 32) diagonals, w = narrowest scanned band
+            int w_min = 1 << 30, w_max = 1;
+            for (int k = 0; k < n_blocks; ++k) {
+                w_min = std::min(w_min, std::max(h_lo_w[2 * k + 1], 1));
+                w_max = std::max(w_max, h_lo_w[2 * k + 1]);
+            }
+            int tile_cap = getenv("CHROMOSIGHT_HIP_RUN_NO_LDS") ? 0 : (256 / w_min + 1 + 17) * (w_max + 33);
+            if ((size_t)tile_cap * 8 > 48 * 1024) tile_cap = 48 * 1024 / 8;        // wider scans: the direct route where needed
+            const size_t smem = (size_t)tile_cap * 8 + kRunWeights * 8 + 512 + 1024;
+            hipLaunchKernelGGL(rescore_run_batch_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), smem, stream, tab, blk, rows,
+                               cols, n_total, vals, tile_cap);
+        }
     }
     hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, keys, vals, pearson, min_size,
                        diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);

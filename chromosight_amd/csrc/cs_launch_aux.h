@@ -79,6 +79,121 @@ __device__ __forceinline__ void rescore_pixel(const CorrArgs<double>& A, int oi,
         r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
     }
 }
+
+// per-bin flags of the rows p0 .. p0 + km - 1 and the columns q0 .. q0 + kn - 1 of a window as bit masks (bins outside
+// the matrix: 0); for templates of up to 32 x 32 -- larger ones evaluate missing_pred per pixel
+__device__ __forceinline__ void window_flag_bits(const CorrArgs<double>& A, int p0, int q0, unsigned& rbits, unsigned& cbits)
+{
+    rbits = cbits = 0u;
+    if (A.mask_mode != 1 || A.km > 32 || A.kn > 32) return;
+    for (int k = 0; k < A.km; ++k) {
+        const int p = p0 + k;
+        if (p >= 0 && p < A.ms && A.miss_row[p]) rbits |= 1u << k;
+    }
+    for (int k = 0; k < A.kn; ++k) {
+        const int q = q0 + k;
+        if (q >= 0 && q < A.ns && A.miss_col[q]) cbits |= 1u << k;
+    }
+}
+
+// The same coefficient by ONE LANE (it walks the whole window): for lists that are runs of neighbouring pixels --
+// the 2-4 scanned diagonals of a 1-D pattern, hundreds of thousands of pixels whose windows overlap in 16 of 17
+// rows, so the loads hit L1 -- a wave then scores 64 pixels instead of one (no reductions, 1/9 of the instructions).
+__device__ __forceinline__ void rescore_pixel_lane(const CorrArgs<double>& A, int oi, int oj, double& r, double& nobs)
+{
+    r = 0.0;
+    nobs = A.ks.n;
+    const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
+    if (inside && !pixel_forced_zero(A, oi, oj)) {
+        const int km = A.km, kn = A.kn, kk = km * kn;
+        const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+        const bool masked = A.mask_mode != 0;
+        double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
+        const bool bins = A.mask_mode == 1 && km <= 32 && kn <= 32;
+        unsigned rbits = 0, cbits = 0;
+        window_flag_bits(A, oi - kh, oj - kw, rbits, cbits);
+        int e = 0;
+        for (int ki = 0; ki < km; ++ki) {
+            const int p = oi - kh + ki;
+            for (int kj = 0; kj < kn; ++kj, ++e) {
+                const int q = oj - kw + kj;
+                const double v = load_signal(A, p, q);
+                cs_ = fma(v, A.w[e], cs_);
+                s1 += v;
+                s2 = fma(v, v, s2);
+                if (masked && (bins ? missing_from_flags(A, p, q, (rbits >> ki) & 1u, (cbits >> kj) & 1u, false, true)
+                                    : missing_pred(A, p, q))) {
+                    nm += 1.0;
+                    ka += A.w[kk + e];
+                    kb += A.w[2 * kk + e];
+                }
+            }
+        }
+        r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
+    }
+}
+
+// rescore_pixel_lane with everything the window loop touches staged in LDS by the workgroup:
+//   tile[(p - P0) * DN + (q - p - D0)] = load_signal(p, q) for P0 <= p < P0 + RN, D0 <= q - p < D0 + DN,
+//   wl = the three weight sets (copy of A.w), rfl[p - P0] / cfl[q - C0] = per-bin flags (0 outside the matrix).
+// A global load per window pixel, each awaited before the next, is what made the direct version slow (and the flags
+// alone cost 34 such round trips per pixel).  Same operations in the same order as rescore_pixel_lane: identical
+// results.  The predicate is missing_from_flags written without branches for the detection configuration
+// (per-bin masks, sym_upper, full, max_dist given); other configurations call the general function.
+__device__ __forceinline__ void rescore_pixel_lane_lds(const CorrArgs<double>& A, const double* tile, const double* wl,
+                                                       const unsigned char* rfl, const unsigned char* cfl, int P0, int C0, int D0,
+                                                       int DN, int oi, int oj, double& r, double& nobs)
+{
+    r = 0.0;
+    nobs = A.ks.n;
+    const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
+    if (inside && !pixel_forced_zero(A, oi, oj)) {
+        const int km = A.km, kn = A.kn, kk = km * kn;
+        const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+        const bool masked = A.mask_mode != 0;
+        const bool bins = A.mask_mode == 1;
+        const bool lean = bins && A.sym_upper && A.full && A.max_dist >= 0;
+        const int ms = A.ms, ns = A.ns, md = A.max_dist, big_k = max(km, kn), skew = kn - km;
+        double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
+        int e = 0;
+        for (int ki = 0; ki < km; ++ki) {
+            const int p = oi - kh + ki;
+            const double* row = tile + (p - P0) * DN + ((oj - kw) - p - D0);
+            const bool rf = bins && rfl[p - P0] != 0;
+            const bool in_r = (p >= 0) & (p < ms);
+            for (int kj = 0; kj < kn; ++kj, ++e) {
+                const int q = oj - kw + kj;
+                const double v = row[kj];
+                cs_ = fma(v, wl[e], cs_);
+                s1 += v;
+                s2 = fma(v, v, s2);
+                if (masked) {
+                    bool m;
+                    if (lean) {
+                        const bool cf = cfl[q - C0] != 0;
+                        const int d = q - p;
+                        const bool in_c = (q >= 0) & (q < ns);
+                        const bool m_in = (rf | cf) & (d >= 0) & (d <= md);
+                        const bool m_out = (q >= ns) ? (p >= ms - md - 2) : ((p < 0) & ((q < 0) | (q < md + kn)));
+                        m = (in_r & in_c) ? m_in : m_out;
+                        const int off = d + skew;
+                        m = m | ((off <= -1) & (off >= -big_k));
+                    } else if (bins) {
+                        m = missing_from_flags(A, p, q, rf, cfl[q - C0] != 0, false, true);
+                    } else {
+                        m = missing_pred(A, p, q);
+                    }
+                    if (m) {
+                        nm += 1.0;
+                        ka += wl[kk + e];
+                        kb += wl[2 * kk + e];
+                    }
+                }
+            }
+        }
+        r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);
+    }
+}
 #endif
 
 int launch_distance_law(const CsrView& M, const uint8_t* det, int n_diags, double* d_sum,
@@ -91,8 +206,9 @@ int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, doub
                       int lo_diag, int hi_diag, int* rows, int* cols, double* vals, long long cap,
                       long long* count, int n_cu, hipStream_t stream);
 // n_ptr (optional, device): the number of listed pixels actually valid; n_px then only sizes the launch
+// run != 0: the list is a run of neighbouring pixels (enumerated diagonals): one lane per pixel
 int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* cols, long long n_px,
-                       double* out_corr, double* out_nobs, hipStream_t stream, const long long* n_ptr = nullptr);
+                       double* out_corr, double* out_nobs, hipStream_t stream, const long long* n_ptr = nullptr, int run = 0);
 int launch_csr_band_extent(const CsrView& M, int lo_diag, int hi_diag, long long* begin, long long* end,
                            hipStream_t stream);
 int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream);

@@ -47,8 +47,8 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)       # a C2 step is 0.11 ms: 300 steps = 33 ms of kernel time
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3k", "c4p", "c4", "c5"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

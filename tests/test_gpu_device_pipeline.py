@@ -290,3 +290,36 @@ def test_batched_1d_patterns_equal_per_block_calls():
                 assert np.allclose(a[0][:, 2:], c[0][:, 2:], rtol=0, atol=1e-12, equal_nan=True)
                 assert np.allclose(a[1], b[1], rtol=0, atol=0, equal_nan=True) and c[1] is None
             assert total > 50, (name, total)
+
+
+def test_run_scoring_of_1d_patterns_equals_wave_per_pixel(monkeypatch):
+    """The float64 scoring of the enumerated diagonals one lane per pixel from an LDS tile
+    (rescore_run_batch_kernel; the direct route for workgroups that straddle two sub-matrices) against the
+    wave-per-pixel kernel (CHROMOSIGHT_HIP_NO_RUN_RESCORE=1) and against the direct lane route
+    (CHROMOSIGHT_HIP_RUN_NO_LDS=1): same foci, scores within float64 summation-order noise."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(30_000, 300, 2000, seed=11, template=template, chrom_sizes=[9000, 700, 6000, 14300])
+    dcool = pipeline.DeviceCool(cool)
+    for name in ("borders", "hairpins"):
+        cfg = copy.deepcopy(getattr(ck, name))
+        max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
+        largest = max(np.shape(k)[0] for k in cfg["kernels"])
+        blocks = [dcool.stage_intra(ci, max_dist, largest, resident=True) for ci in range(dcool.n_chrom)]
+        kernel = np.asarray(cfg["kernels"][0], dtype=np.float64)
+        got = pipeline.detect_blocks(dcool, blocks, cfg, kernel, raw=True, batch=True, want_windows=False)
+        results = {}
+        for switch in ("CHROMOSIGHT_HIP_NO_RUN_RESCORE", "CHROMOSIGHT_HIP_RUN_NO_LDS"):
+            monkeypatch.setenv(switch, "1")
+            results[switch] = pipeline.detect_blocks(dcool, blocks, cfg, kernel, raw=True, batch=True, want_windows=False)
+            monkeypatch.delenv(switch)
+        total = 0
+        for k, a in enumerate(got):
+            for other in results.values():
+                b = other[k]
+                assert (a[0] is None) == (b[0] is None)
+                if a[0] is None:
+                    continue
+                assert np.array_equal(a[0][:, :2], b[0][:, :2])
+                assert np.allclose(a[0][:, 2:], b[0][:, 2:], rtol=0, atol=1e-12, equal_nan=True)
+            total += 0 if a[0] is None else len(a[0])
+        assert total > 50, (name, total)

@@ -318,3 +318,37 @@ def test_dense_kernel_xcorr2(shape, kshape):
     assert np.abs(got - ref)[~near].max() < 3e-6 * np.abs(want).max()
     kh, kw = (kshape[0] - 1) // 2, (kshape[1] - 1) // 2
     assert np.all(got[:kh] == 0) and np.all(got[:, :kw] == 0) and np.all(got[-kh:] == 0) and np.all(got[:, -kw:] == 0)
+
+
+def test_mirrored_row_instance_equals_the_17_fragment_instance(monkeypatch):
+    """The default masked tile kernel for the loops template keeps 9 weight head fragments (rows s and 16 - s of the
+    template are equal); CHROMOSIGHT_HIP_MFMA_NORSYM=1 runs the general instance with 17: bit-identical maps
+    (same MFMA operands in the same order).  float64 band containers are narrowed on the way in."""
+    rng = np.random.default_rng(5)
+    n, md = 1300, 300
+    ii, jj = np.indices((n, n))
+    sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
+    sig[jj - ii > md + 17] = 0
+    valid = np.flatnonzero(rng.random(n) > 0.03)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    sig[miss, :] = 0
+    sig[:, miss] = 0
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+    out = {}
+    for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
+        for norsym in (False, True):
+            if norsym:
+                monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_NORSYM", "1")
+            c, p = cud.normxcorr2(sp.csr_matrix(sig.astype(dtype)), loops(), max_dist=md, sym_upper=True, full=True,
+                                  missing_mask=mask, missing_tol=0.75, pval=True)
+            assert last_kernel() == KERNEL_MFMA_REG
+            out[tag, norsym] = (c.toarray(), p.toarray())
+            if norsym:
+                monkeypatch.delenv("CHROMOSIGHT_HIP_MFMA_NORSYM")
+        assert np.array_equal(out[tag, False][0], out[tag, True][0])
+        assert np.array_equal(out[tag, False][1], out[tag, True][1])
+    # the float64 container holds float32-representable values here?  no: it is rounded on the way in
+    want, cond = c_oracle.normxcorr2_rows(sig, loops(), 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss, miss_col=miss)
+    band = (jj - ii >= 0) & (jj - ii <= md)
+    assert_parity(out["f64", False][0][band], want[band], cond[band], "f32", "masked tile kernel, float64 container")

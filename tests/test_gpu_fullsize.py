@@ -43,12 +43,21 @@ def test_c2_dense_4096_full_map():
                           CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0),
                           full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE, precision="f32")
     got = d_out.download()
+    assert last_kernel() == KERNEL_MFMA_DENSE            # the kernel bench.py times on this workload
     want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), loops(), 0, n, full=False)
     check(got, want, cond, "C2 4096x4096")
     assert np.all(got[:8] == 0) and np.all(got[:, -8:] == 0)      # valid-mode margins
 
 
-def run_band(name, n=None):
+KERNEL_STREAM, KERNEL_MFMA_DENSE, KERNEL_MFMA_REG = 2, 4, 5
+
+
+def last_kernel():
+    dev = get_device()
+    return dev.lib.cs_last_kernel(dev.ctx)
+
+
+def run_band(name, n=None, expect=KERNEL_MFMA_REG):
     dev = get_device()
     band, band_w, miss, n, max_dist = band_workload(name, n=n)
     out_w = max_dist + 1
@@ -60,22 +69,30 @@ def run_band(name, n=None):
                           CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_out, 0, out_w),
                           full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=d_miss,
                           miss_col=d_miss, missing_tol=0.5, precision="f32")
+    assert last_kernel() == expect
     return d_out.download()[:, :out_w], band, band_w, miss, n, max_dist
 
 
-def test_c3_band_50000_full_map():
+@pytest.mark.parametrize("kernel", ["tile", "stream"])
+def test_c3_band_50000_full_map(kernel, monkeypatch):
     """C3 as benched: N = 50 000, diagonals 0..250, 2 % missing bins, max_dist 233, full, sym_upper,
-    missing_tol 0.5 -- every pixel of the 11.7 M-pixel band."""
-    got, band, band_w, miss, n, max_dist = run_band("c3")
+    missing_tol 0.5 -- every pixel of the 11.7 M-pixel band, on the masked matrix-core tile kernel (the default,
+    what bench.py times) and on the packed-FMA streaming kernel (CHROMOSIGHT_HIP_MFMA_REG=0)."""
+    if kernel == "stream":
+        monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "0")
+    got, band, band_w, miss, n, max_dist = run_band("c3", expect=KERNEL_MFMA_REG if kernel == "tile" else KERNEL_STREAM)
     want, cond = c_oracle.normxcorr2_band(band.astype(np.float64), n, 0, band_w, loops(), 0, n, 0, max_dist + 1,
                                           max_dist=max_dist, miss_row=miss, miss_col=miss, missing_tol=0.5)
     check(got, want, cond, "C3 50000 x 234")
 
 
-def test_c4p_band_200000_row_windows():
+@pytest.mark.parametrize("kernel", ["tile", "stream"])
+def test_c4p_band_200000_row_windows(kernel, monkeypatch):
     """C4' as benched: N = 200 000 single block, max_dist 1000 -- seven windows of 2000 rows (both
-    matrix ends, the middle, strip-height boundaries), 14 M pixels against the oracle."""
-    got, band, band_w, miss, n, max_dist = run_band("c4p")
+    matrix ends, the middle, strip-height boundaries), 14 M pixels against the oracle; both kernels as above."""
+    if kernel == "stream":
+        monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "0")
+    got, band, band_w, miss, n, max_dist = run_band("c4p", expect=KERNEL_MFMA_REG if kernel == "tile" else KERNEL_STREAM)
     band64 = band.astype(np.float64)
     del band
     for r0 in (0, 1990, 49_000, 99_137, 150_000, 187_654, n - 2000):

@@ -52,6 +52,7 @@ struct cs_ctx {
         double stats[6] = {0, 0, 0, 0, 0, 0};
         std::vector<double> w;
         bool sym = false;
+        bool rank1 = false;           // template == u v^T exactly: u, v appended to w (float32 kernels)
         int zk_possible = 1, snap_possible = 1;
     } tcache[2];
     long long* h_blk_counts = nullptr;     // page-locked: total + per-block foci counts of cs_detect_foci_batch
@@ -557,6 +558,13 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 #else
         rc = -1;
 #endif
+    } else if (allow_fast && A.w_rank1 && !A.xcorr_only && !std::getenv("CHROMOSIGHT_HIP_NO_SEPARABLE") &&
+               cs::corr_sep_fits(A.km, A.kn, A.mask_mode != 0)) {
+        // templates without an unrolled instance that are an outer product (31 x 31 stripes): separable sums
+        ctx->last_kernel = CS_KERNEL_SEPARABLE;
+        cs::corr_sep_tile(&tw, &th);
+        fill_grid(A, tw, th);
+        rc = cs::launch_corr_sep_f32(A, stream);
     } else {
         ctx->last_kernel = CS_KERNEL_GENERIC;
         cs::corr_generic_tile(A.km, A.kn, &tw, &th);
@@ -695,6 +703,34 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
                     for (int r = 0; r < km / 2; ++r)
                         for (int c = 0; c < kn; ++c) w0[set * kk + (km - 1 - r) * kn + c] = w0[set * kk + r * kn + c];
             tc.sym = sym0;
+            // Exactly rank-1 templates (the 31 x 31 stripes templates): u and v for the separable kernel
+            // (cs_corr_sep.hip).  Pivot on the largest entry; the outer product must reproduce the template to
+            // rounding (1e-12 relative) -- truncated-SVD templates carry their own squares and stay on the full kernels.
+            tc.rank1 = false;
+            if (sizeof(TC) == 4 && !kernel->h_kernel_sq) {
+                int pa = 0, pb = 0;
+                double kmax = 0;
+                for (int a = 0; a < km; ++a)
+                    for (int b = 0; b < kn; ++b)
+                        if (std::fabs(kconv[a * kn + b]) > kmax) {
+                            kmax = std::fabs(kconv[a * kn + b]);
+                            pa = a;
+                            pb = b;
+                        }
+                if (kmax > 0) {
+                    std::vector<double> u(km), v(kn);
+                    for (int b = 0; b < kn; ++b) v[b] = kconv[pa * kn + b];
+                    for (int a = 0; a < km; ++a) u[a] = kconv[a * kn + pb] / kconv[pa * kn + pb];
+                    double worst = 0;
+                    for (int a = 0; a < km; ++a)
+                        for (int b = 0; b < kn; ++b) worst = std::max(worst, std::fabs(u[a] * v[b] - kconv[a * kn + b]));
+                    if (worst <= 1e-12 * kmax) {
+                        tc.rank1 = true;
+                        w0.insert(w0.end(), u.begin(), u.end());
+                        w0.insert(w0.end(), v.begin(), v.end());
+                    }
+                }
+            }
             // can sum_missing K' or sum_missing K'^2 of a non-empty set fall under the zeroing threshold?
             // not if every entry alone exceeds it and all have one sign (the built-in templates: >= 0.5)
             double lo = 1e300, lo2 = 1e300;
@@ -762,6 +798,7 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.ks.snap_possible = tc.snap_possible;
     A.xcorr_only = 0;
     A.w_sym = sym ? 1 : 0;
+    A.w_rank1 = tc.rank1 ? 1 : 0;
     A.row_begin = 0;
     A.row_end = p->ms;
     if (p->row_end > p->row_begin) {

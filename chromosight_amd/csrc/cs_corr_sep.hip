@@ -1,0 +1,181 @@
+// cs_corr_sep.hip -- separable evaluation for templates that are exactly an outer product, K'[a][b] = u[a] v[b].
+//
+// The reference has a factorised branch for --tsvd (detection.py:648-665, preprocessing.py:810-847); of the built-in
+// templates the two 31 x 31 stripes templates are rank 1 as they stand -- and too large for the unrolled / matrix-core
+// kernels, so the runtime-size kernel used to evaluate their 961 products (and, with a mask, the 2 x 961 mask-weighted
+// template sums) per pixel.  With K' = u v^T every window sum the coefficient needs separates:
+//     sum S K'              = sum_a u[a]    (sum_b v[b]   S[i+a][j+b])
+//     sum S, sum S^2, sum M = sum_a          (sum_b  ...           )            (box sums)
+//     sum M K', sum M K'^2  = sum_a u[a]^k  (sum_b v[b]^k M[i+a][j+b]),  k = 1, 2
+// and the centred weight sets of build_args (cs_api.cpp: Wc = Wa = K' - mean, Wb = (K' - mean)^2) follow from these
+// and the box sums.  A horizontal pass over the staged rows (6 sums per staged pixel, 3 without a mask) leaves its
+// results in LDS, a vertical pass over km rows finishes them: 2 * 6 * K multiply-adds per pixel instead of 6 * K^2.
+// Staging, mask predicate, epilogue and stores are those of the runtime-size kernel (cs_corr_generic.hip), so
+// edges, layouts and mask modes behave identically; only the order of the float32 additions differs.
+#include "cs_device.h"
+#include "cs_launch.h"
+
+namespace cs {
+
+constexpr int SEP_TW = 64;   // output columns per block (= lanes per wave)
+constexpr int SEP_RG = 4;    // output rows per lane
+constexpr int SEP_NW = 8;    // waves per block
+constexpr int SEP_TH = SEP_RG * SEP_NW;
+
+static size_t sep_smem(int km, int kn, bool masked)
+{
+    const size_t LH = SEP_TH + km - 1, LWP = (size_t)((SEP_TW + kn - 1 + 3) & ~3);
+    const size_t nq = masked ? 6 : 3;
+    return 4 * LH * LWP + ((LH * LWP + 15) & ~(size_t)15) + 4 * nq * LH * SEP_TW + 4 * (size_t)(km + kn) + (LH + LWP) + 64;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(512) void corr_sep_kernel(const CorrArgs<float> A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int km = A.km, kn = A.kn, kk = km * kn;
+    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+    const int LH = SEP_TH + km - 1;
+    const int LW = SEP_TW + kn - 1;
+    const int LWP = (LW + 3) & ~3;
+    constexpr int NQ = MASKED ? 6 : 3;
+    float* sS = reinterpret_cast<float*>(smem_raw);
+    uint8_t* sM = reinterpret_cast<uint8_t*>(sS + (size_t)LH * LWP);
+    float* H = reinterpret_cast<float*>(sM + (((size_t)LH * LWP + 15) & ~(size_t)15));      // [NQ][LH][SEP_TW]
+    float* su = H + (size_t)NQ * LH * SEP_TW;
+    float* sv = su + km;
+
+    int i0, j0;
+    if (!tile_origin(A, blockIdx.x, blockIdx.y, &i0, &j0)) return;
+    const int tid = threadIdx.x;
+
+    for (int idx = tid; idx < km + kn; idx += 512) su[idx] = A.w[3 * kk + idx];             // u, then v
+    // per-bin flags of the staged rows and columns first (two dependent byte loads per staged pixel made the staging
+    // the longest phase of a tile: one workgroup per CU, nothing to overlap it with)
+    const bool bins = MASKED && A.mask_mode == 1;
+    uint8_t* rfl = reinterpret_cast<uint8_t*>(sv + kn);
+    uint8_t* cfl = rfl + LH;
+    if (bins) {
+        for (int idx = tid; idx < LH + LW; idx += 512) {
+            const bool is_row = idx < LH;
+            const int x = is_row ? i0 - kh + idx : j0 - kw + (idx - LH);
+            const int n = is_row ? A.ms : A.ns;
+            const uint8_t* src = is_row ? A.miss_row : A.miss_col;
+            rfl[idx] = (x >= 0 && x < n) ? src[x] : 0;
+        }
+        __syncthreads();
+    }
+#pragma unroll 4
+    for (int idx = tid; idx < LH * LWP; idx += 512) {
+        const int tr = idx / LWP;
+        const int tc = idx - tr * LWP;
+        const int p = i0 - kh + tr;
+        const int q = j0 - kw + tc;
+        sS[idx] = load_signal(A, p, q);
+        if (MASKED) {
+            const bool m = bins ? missing_from_flags(A, p, q, rfl[tr] != 0, cfl[min(tc, LW - 1)] != 0, false, true) : missing_pred(A, p, q);
+            sM[idx] = (tc < LW && m) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    // ---- horizontal pass: every staged row, 64 output columns
+    for (int r = wv; r < LH; r += SEP_NW) {
+        const float* row = sS + r * LWP + lane;
+        const uint8_t* mrow = sM + r * LWP + lane;
+        float hv = 0.0f, h1 = 0.0f, h2 = 0.0f, g1 = 0.0f, gv = 0.0f, gw = 0.0f;
+        for (int b = 0; b < kn; ++b) {
+            const float x = row[b], vb = sv[b];
+            hv = fmaf(x, vb, hv);
+            h1 += x;
+            h2 = fmaf(x, x, h2);
+            if (MASKED) {
+                const float m = (float)mrow[b];
+                const float t = m * vb;
+                g1 += m;
+                gv += t;
+                gw = fmaf(t, vb, gw);
+            }
+        }
+        H[(0 * LH + r) * SEP_TW + lane] = hv;
+        H[(1 * LH + r) * SEP_TW + lane] = h1;
+        H[(2 * LH + r) * SEP_TW + lane] = h2;
+        if (MASKED) {
+            H[(3 * LH + r) * SEP_TW + lane] = g1;
+            H[(4 * LH + r) * SEP_TW + lane] = gv;
+            H[(5 * LH + r) * SEP_TW + lane] = gw;
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass: wave wv owns output rows SEP_RG wv .. SEP_RG wv + SEP_RG - 1
+    const int tr0 = wv * SEP_RG;
+    float a1[SEP_RG], s1[SEP_RG], s2[SEP_RG], nm[SEP_RG], b1[SEP_RG], b2[SEP_RG];
+#pragma unroll
+    for (int i = 0; i < SEP_RG; ++i) a1[i] = s1[i] = s2[i] = nm[i] = b1[i] = b2[i] = 0.0f;
+    for (int a = 0; a < km; ++a) {
+        const float ua = su[a], ua2 = ua * ua;
+#pragma unroll
+        for (int i = 0; i < SEP_RG; ++i) {
+            const int rr = tr0 + i + a;
+            a1[i] = fmaf(ua, H[(0 * LH + rr) * SEP_TW + lane], a1[i]);
+            s1[i] += H[(1 * LH + rr) * SEP_TW + lane];
+            s2[i] += H[(2 * LH + rr) * SEP_TW + lane];
+            if (MASKED) {
+                nm[i] += H[(3 * LH + rr) * SEP_TW + lane];
+                b1[i] = fmaf(ua, H[(4 * LH + rr) * SEP_TW + lane], b1[i]);
+                b2[i] = fmaf(ua2, H[(5 * LH + rr) * SEP_TW + lane], b2[i]);
+            }
+        }
+    }
+
+    const float mu = A.ks.kmean;
+#pragma unroll
+    for (int i = 0; i < SEP_RG; ++i) {
+        const int oi = i0 + tr0 + i;
+        const int oj = j0 + lane;
+        if (oi >= A.row_end || oj >= A.ns) continue;
+        const int d = oj - oi;
+        if (d < A.out_lo || d > A.out_hi) continue;
+        float r, nobs = A.ks.n;
+        if (pixel_forced_zero(A, oi, oj)) {
+            r = 0.0f;
+        } else {
+            // the centred sums the epilogue expects: Wc = Wa = K' - mean, Wb = (K' - mean)^2
+            const float cs_ = fmaf(-mu, s1[i], a1[i]);
+            const float ka = fmaf(-mu, nm[i], b1[i]);
+            const float kb = fmaf(mu * mu, nm[i], fmaf(-2.0f * mu, b1[i], b2[i]));
+            r = pearson_from_sums<float>(cs_, s1[i], s2[i], nm[i], ka, kb, A.ks, MASKED, &nobs);
+        }
+        store_pixel(A, oi, oj, r, nobs);
+    }
+}
+
+// 0 on success, -3: the template needs more LDS than a CU has (the caller falls back to the runtime-size kernel)
+int launch_corr_sep_f32(const CorrArgs<float>& A, hipStream_t stream)
+{
+    const bool masked = A.mask_mode != 0;
+    const size_t smem = sep_smem(A.km, A.kn, masked);
+    if (smem > 160 * 1024) return -3;
+    const void* kern = masked ? (const void*)corr_sep_kernel<true> : (const void*)corr_sep_kernel<false>;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(A.tiles_x, A.tiles_y), block(512);
+    if (masked) hipLaunchKernelGGL(corr_sep_kernel<true>, grid, block, smem, stream, A);
+    else hipLaunchKernelGGL(corr_sep_kernel<false>, grid, block, smem, stream, A);
+    return (int)hipGetLastError();
+}
+
+bool corr_sep_fits(int km, int kn, bool masked) { return sep_smem(km, kn, masked) <= 160 * 1024; }
+
+void corr_sep_tile(int* tw, int* th)
+{
+    *tw = SEP_TW;
+    *th = SEP_TH;
+}
+
+}  // namespace cs

@@ -80,6 +80,7 @@ struct CorrArgs {
                              // the signal buffer must hold the rows row_begin - kh .. row_end + kh - 1
     int n_cu;                // compute units of the device (launch shaping)
     int w_sym;               // all three weight sets are symmetric under a vertical flip (row s == row km-1-s)
+    int w_rank1;             // the template is exactly u v^T: u (km values) and v (kn) follow the three weight sets in `w`
     // factorised per-bin mask sums of the streaming kernel (cs_mask_prep.hip); reg_mode = 1:
     // strips whose windows stay inside the matrix use the tables, the others the general path
     int reg_mode;

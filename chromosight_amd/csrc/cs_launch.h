@@ -21,6 +21,10 @@ CS_DECL_FAST(17)
 int launch_corr_generic_f32(const CorrArgs<float>& A, hipStream_t s);
 int launch_corr_generic_f64(const CorrArgs<double>& A, hipStream_t s);
 void corr_generic_tile(int km, int kn, int* tw, int* th);
+// separable evaluation of exactly rank-1 templates (cs_corr_sep.hip): u at A.w + 3 km kn, v behind it
+int launch_corr_sep_f32(const CorrArgs<float>& A, hipStream_t s);
+bool corr_sep_fits(int km, int kn, bool masked);
+void corr_sep_tile(int* tw, int* th);
 
 // matrix-core kernel for templates up to 17 x 17, float32 class (cs_corr_mfma.hip).  The weight sets
 // arrive as ready-made B fragments: frag[set][s][head | tail][lane] = 8 float16 values

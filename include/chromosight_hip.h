@@ -66,7 +66,7 @@ const char* cs_version(void);
  * cs_detect_foci / cs_candidates) on this context: diagnostics, and what the tests use to make sure
  * the intended native path ran */
 enum { CS_KERNEL_NONE = 0, CS_KERNEL_GENERIC = 1, CS_KERNEL_STREAM = 2, CS_KERNEL_MFMA = 3, CS_KERNEL_MFMA_DENSE = 4,
-       CS_KERNEL_MFMA_REG = 5 };
+       CS_KERNEL_MFMA_REG = 5, CS_KERNEL_SEPARABLE = 6 };
 int cs_last_kernel(const cs_ctx* ctx);
 
 /* ---- device memory helpers (so a ctypes caller needs nothing but this library) ------ */

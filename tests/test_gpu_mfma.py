@@ -31,7 +31,7 @@ def f32_precision():
     chromosight_amd.set_precision(old)
 
 
-KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE, KERNEL_MFMA_REG = 1, 2, 3, 4, 5
+KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE, KERNEL_MFMA_REG, KERNEL_SEPARABLE = 1, 2, 3, 4, 5, 6
 
 
 def last_kernel():
@@ -352,3 +352,44 @@ def test_mirrored_row_instance_equals_the_17_fragment_instance(monkeypatch):
     want, cond = c_oracle.normxcorr2_rows(sig, loops(), 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss, miss_col=miss)
     band = (jj - ii >= 0) & (jj - ii <= md)
     assert_parity(out["f64", False][0][band], want[band], cond[band], "f32", "masked tile kernel, float64 container")
+
+
+@pytest.mark.parametrize("name", ["stripes_left", "stripes_right"])
+def test_separable_kernel_on_rank1_templates(name, monkeypatch):
+    """The 31 x 31 stripes templates are outer products u v^T: cs_corr_sep.hip forms every window sum from a
+    horizontal and a vertical 1-D pass (62 instead of 961 products per sum).  Banded map with per-bin masks and
+    n_obs (detect configuration) and a dense unmasked map, against the float64 oracle and against the runtime-size
+    kernel (CHROMOSIGHT_HIP_NO_SEPARABLE=1)."""
+    kern = np.asarray(getattr(ck, name)["kernels"][0], dtype=np.float64)
+    assert kern.shape == (31, 31) and np.linalg.matrix_rank(kern, tol=1e-12) == 1
+    rng = np.random.default_rng(31)
+    n, md = 700, 150
+    ii, jj = np.indices((n, n))
+    sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
+    sig[jj - ii > md + 31] = 0
+    valid = np.flatnonzero(rng.random(n) > 0.03)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    sig[miss, :] = 0
+    sig[:, miss] = 0
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+    c, p = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                          missing_tol=0.75, pval=True)
+    assert last_kernel() == KERNEL_SEPARABLE
+    want, cond = c_oracle.normxcorr2_rows(sig, kern, 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss, miss_col=miss)
+    band = (jj - ii >= 0) & (jj - ii <= md)
+    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"separable kernel, {name}, band + masks")
+    dense = rng.gamma(4.0, 0.25, size=(300, 411)).astype(np.float32)
+    cd, _ = cud.normxcorr2(dense, kern)
+    assert last_kernel() == KERNEL_SEPARABLE
+    wd, cond_d = c_oracle.normxcorr2_rows(dense.astype(np.float64), kern, 0, 300, full=False)
+    assert_parity(cd, wd, cond_d, "f32", f"separable kernel, {name}, dense")
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_SEPARABLE", "1")
+    c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                            missing_tol=0.75, pval=True)
+    assert last_kernel() == KERNEL_GENERIC
+    well = band & (cond >= 1e-3)
+    # the runtime-size kernel adds 961 float32 products per sum (observed 2.3e-5 from the oracle on this map, where the
+    # separable kernel's 31 + 31 stay within 2.2e-6): the cross-check is correspondingly loose
+    assert np.abs(c.toarray() - c2.toarray())[well].max() < 5e-5
+    assert np.abs(p.toarray() - p2.toarray())[well].max() < 5e-3

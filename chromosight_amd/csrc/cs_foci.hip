@@ -731,7 +731,8 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
         hipLaunchKernelGGL(decode_keys_kernel, dim3(g), dim3(kThreads), 0, stream, keys_s, n_cand, ns, rows, cols);
     }
     // exact coefficients, exact threshold
-    int rc = launch_rescore_f64(A64, s_rows, s_cols, n_cand, vals, nullptr, stream, nullptr, presorted && !getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE"));
+    int rc = launch_rescore_f64(A64, s_rows, s_cols, n_cand, vals, nullptr, stream, nullptr,
+                                presorted && A64.km * A64.kn <= 17 * 17 && !getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE"));
     if (rc) return rc;
     if (n_cand <= kSmallMax && !getenv("CHROMOSIGHT_HIP_NO_FUSED_FOCI")) {
         hipLaunchKernelGGL(foci_small_kernel, dim3(1), dim3(kSmallThreads), 0, stream, keys_s, vals, n_cand, pearson, ns, min_size,
@@ -1029,7 +1030,10 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
         const unsigned g = blocks_for(n_total);
         hipLaunchKernelGGL(narrow_enumerate_batch_kernel, dim3(g), dim3(kThreads), 0, stream, tab, seg, lo_w, n_blocks, rows, cols, keys,
                            blk);
-        if (getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE"))
+        // templates beyond 17 x 17 (81 x 81 centromeres) do not fit the run kernel's LDS tile: a lane would walk
+        // thousands of window pixels straight from memory, so they keep one wave per pixel
+        const bool big_template = 3LL * h_tab[0].km * h_tab[0].kn > kRunWeights;
+        if (getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE") || big_template)
             hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
                                (const long long*)nullptr, vals, (double*)nullptr);
         else {

@@ -284,14 +284,17 @@ bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
     if (A.xcorr_only) return false;            // (float64 containers are narrowed row by row first, see launch_corr)
     if ((A.sig.layout == CS_LAYOUT_BAND ? A.sig.band_w : A.ns) < 4) return false;      // 16-byte staging pieces
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
-    // default: the spill-free instance (17 x 17 template with mirrored rows -- the loops template); CHROMOSIGHT_HIP_MFMA_REG=1
-    // sends every compatible call here, =0 none (the streaming kernel takes them)
+    // default: templates of 15 x 15 and 17 x 17 -- measured on the 234- and 1001-diagonal bands (tools/time_templates.py,
+    // profiles/*_template_kernels.txt): 17 x 17 mirrored rows 2.01 vs 2.56 ms, 17 x 17 general 2.27 vs 3.01, 15 x 15 2.24 vs
+    // 2.72; at 13 x 13 it wins only on the wide band (2.29 vs 2.51, 0.251 vs 0.235 on the narrow one), below that the
+    // streaming kernel does (the tile kernel always walks 17 template rows).  CHROMOSIGHT_HIP_MFMA_REG=1 sends every
+    // compatible call here, =0 none
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA_REG");
     if (e && e[0] == '1') return true;
     if (e && e[0] == '0') return false;
     const char* general = std::getenv("CHROMOSIGHT_HIP_MFMA");
     if (general && general[0] == '1') return false;      // the general matrix-core kernel was asked for by name
-    return A.w_sym && A.km == 17;
+    return A.km >= 15;
 }
 
 bool mfma_wanted(const cs::CorrArgs<float>& A)

@@ -71,7 +71,8 @@ for u in fetch_calib coexec fma_rate; do
 done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o calib -- \
     tools/ubench/build/fetch_calib > "$out/calib.log" 2>&1
-python tools/time_templates.py > "$out/template_kernels.txt" 2>/dev/null
+python tools/time_templates.py c3 > "$out/template_kernels.txt" 2>/dev/null
+python tools/time_templates.py c4p >> "$out/template_kernels.txt" 2>/dev/null
 tools/ubench/build/coexec > "$out/ubench_coexec.txt" 2>&1
 tools/ubench/build/fma_rate > "$out/ubench_fma_rate.txt" 2>&1
 ls "$out" | head -80

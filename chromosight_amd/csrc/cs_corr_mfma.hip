@@ -494,6 +494,16 @@ __device__ __forceinline__ FixArgsPtr fix_args()
     return (FixArgsPtr)(kv + offsetof(MfmaDenseArgs, fx));
 }
 
+// the epilogue's statistics block through the same kind of pointer: 16 scalar words that only the emit phase reads
+typedef const __attribute__((address_space(4))) KernelStats<float>* StatsPtr;
+
+__device__ __forceinline__ StatsPtr stats_args()
+{
+    unsigned long long kv = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kv));
+    return (StatsPtr)(kv + offsetof(MfmaDenseArgs, ks));
+}
+
 __device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, FixArgsPtr F, int i, int j)
 {
     const int K = A.km, KH = (A.km - 1) / 2;
@@ -636,6 +646,14 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
             // plus the precomputed corrections of the pixels whose window leaves the matrix / 0..max_dist
             const int K = km;
             const int i = I0 + wr0 + n;
+            KernelStats<float> KS;                                // loaded here, not held across the tile loop
+            {
+                const StatsPtr sp = stats_args();
+                KS.n = sp->n; KS.inv_n = sp->inv_n; KS.kmean = sp->kmean; KS.kstd = sp->kstd; KS.kvar = sp->kvar;
+                KS.ksum = sp->ksum; KS.k2sum = sp->k2sum; KS.thr = sp->thr; KS.eps = sp->eps; KS.cut = sp->cut;
+                KS.thr_n = sp->thr_n; KS.nkvar = sp->nkvar; KS.eps2 = sp->eps2; KS.den2_min = sp->den2_min;
+                KS.zk_possible = sp->zk_possible; KS.snap_possible = sp->snap_possible;
+            }
             const float* colb = reinterpret_cast<const float*>(smem + MFD_COL) + slot * 3 * 64;
             const float nr = hdr[0], ra = hdr[1], rb = hdr[2];
             // The cross term sum_kj c[j + kj] U_i[kj], U_i[kj] = sum over the flagged rows ki of row i's window of
@@ -777,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                         const float s1 = S1[c][v] * unscale;
                         const float s2 = (S2[c][v] * u_s2) * unscale;
                         bool rare;
-                        float val = pearson_masked_core(cs, s1, s2, nm, ka, kb, A.ks, rare);
+                        float val = pearson_masked_core(cs, s1, s2, nm, ka, kb, KS, rare);
                         if (A.dbg & 4096) {
                             val = cs + s1 + s2 + nm + ka + kb;
                             rare = false;
@@ -807,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                                 kb = kbv[e >> 2][v];
                             }
                         }
-                        const float val = pearson_masked_f32(cs, s1, s2, nm, ka, kb, A.ks);
+                        const float val = pearson_masked_f32(cs, s1, s2, nm, ka, kb, KS);
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
                             if (e == k) rv[e >> 2][e & 3] = val;
@@ -822,8 +840,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                     if (pass) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            t0[v] = A.ks.n - nmv[0][v];
-                            t1[v] = A.ks.n - nmv[1][v];
+                            t0[v] = KS.n - nmv[0][v];
+                            t1[v] = KS.n - nmv[1][v];
                         }
                     }
                     *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = t0;

@@ -768,9 +768,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                         if (!__builtin_amdgcn_ballot_w64(f != nullptr)) continue;
                         float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
                         if (f) {
-                            d0 = f[0];
-                            d1 = f[1];
-                            d2 = f[2];
+                            const f4 rec = *reinterpret_cast<const f4*>(f);       // 16-byte records, 16-byte aligned tables
+                            d0 = rec[0];
+                            d1 = rec[1];
+                            d2 = rec[2];
                         }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {

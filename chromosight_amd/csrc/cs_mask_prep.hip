@@ -16,6 +16,7 @@
 // the exact difference  sum_window (missing_true - (r|c)) * {1, Wa, Wb}  once per pixel.
 #include <algorithm>
 
+#include <cstdlib>
 #include "cs_device.h"
 #include "cs_launch_aux.h"
 
@@ -105,6 +106,21 @@ __device__ __forceinline__ void mask_rowcol_tables(int block, const uint8_t* __r
 // missing in the reference).  With prefix sums of the weights along rows (PW) and columns (QW)
 // the correction is a per-diagonal constant minus one term per flagged row / column of the
 // window (0.7 flagged bins per window at 2 % missing bins), instead of a loop over the triangle.
+// one correction record {d n_missing, d ka, d kb, 0} as ONE 16-byte (float) / 32-byte (double) store: four scalar
+// stores per thread wrote 4 of every 16 bytes of a line at a time (the 100 MB of rim records of a 200 000-row band
+// took 100 us).  The tables start at multiples of 64 elements (cs_api.cpp prepare_regular_mask).
+template <typename TC>
+__device__ __forceinline__ void store_record(TC* dst, TC a, TC b, TC c)
+{
+    typedef TC v4 __attribute__((ext_vector_type(4)));
+    v4 r;
+    r[0] = a;
+    r[1] = b;
+    r[2] = c;
+    r[3] = TC(0);
+    *reinterpret_cast<v4*>(dst) = r;
+}
+
 template <typename TC>
 __device__ __forceinline__ void mask_edge_fix(int block, int n_blocks, const uint8_t* __restrict__ rr,
                                               const uint8_t* __restrict__ cc, int ms, int ns, int K, int md, int hi_d0, int hi_w,
@@ -198,10 +214,7 @@ __device__ __forceinline__ void mask_edge_fix(int block, int n_blocks, const uin
             fb -= b;
         }
     }
-    dst[0] = fn;
-    dst[1] = fa;
-    dst[2] = fb;
-    dst[3] = TC(0);
+    store_record(dst, fn, fa, fb);
     }
 }
 
@@ -320,10 +333,7 @@ __device__ __forceinline__ void mask_frame_fix(int block, const uint8_t* __restr
             a += part[slot][r][1];
             b += part[slot][r][2];
         }
-        dst[0] = n;
-        dst[1] = a;
-        dst[2] = b;
-        dst[3] = TC(0);
+        store_record(dst, n, a, b);
     }
 }
 
@@ -363,7 +373,12 @@ int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream)
     const long long n_frame = (long long)(P.top + full_bot) * P.width +
                               (P.edge ? (long long)((P.ms - P.bot0) - full_bot) * KH : 0) +
                               (P.fix_cols ? (long long)P.ms * 2 * P.side : 0);
-    const long long b_frame = n_frame > 0 ? (n_frame + kFramePixPerBlock - 1) / kFramePixPerBlock : 0;
+    long long b_frame = n_frame > 0 ? (n_frame + kFramePixPerBlock - 1) / kFramePixPerBlock : 0;
+    if (const char* dbg = getenv("CHROMOSIGHT_HIP_PREP_DBG")) {          // timing experiments only (tables incomplete)
+        if (dbg[0] == 'e') P.b_edge = 0;
+        if (dbg[0] == 'f') b_frame = 0;
+        if (dbg[0] == 'b') { P.b_edge = 0; b_frame = 0; }
+    }
     hipLaunchKernelGGL(mask_prep_kernel<TC>, dim3((unsigned)(P.b_tab + P.b_edge + b_frame)), dim3(256), 0, stream, P);
     return (int)hipGetLastError();
 }

@@ -160,11 +160,30 @@ __device__ __forceinline__ void mask_edge_fix(int block, int n_blocks, const uin
 
     const int per_row = (K - 1) + hi_w;
     const int KH = (K - 1) / 2;
+    // Half a wave per row when its records fit (K - 1 <= 16 lower, hi_w <= 16 upper): the flags of the row window and
+    // of the two 32-column stretches the records' column windows lie in are then loaded once per half wave -- one byte
+    // per lane, a ballot -- instead of 2 x 17 dependent byte loads per record (3 loads instead of 34; the records were
+    // 0.08 of the 0.11 ms of this kernel on a 200 000-row band).
+    const bool coop = (K - 1) <= 16 && hi_w <= 16;
+    const int slots = coop ? 32 : per_row;
     // grid-stride: the prefix tables above are built once per block, so a block handles many pixels
-    for (long long id = (long long)block * blockDim.x + threadIdx.x; id < (long long)ms * per_row;
+    for (long long id = (long long)block * blockDim.x + threadIdx.x; id < (long long)ms * slots;
          id += (long long)n_blocks * blockDim.x) {
-    const int i = (int)(id / per_row);
-    const int e = (int)(id - (long long)i * per_row);
+    const int i = (int)(id / slots);
+    const int e = (int)(id - (long long)i * slots);
+    unsigned co_r = 0, co_lo = 0, co_hi = 0;
+    if (coop) {
+        // lane l of the half wave: row flag i - KH + l, column flags i - KH + l and i + hi_d0 - KH + l
+        const int sh = (threadIdx.x & 32);
+        const int pr = i - KH + e, ql = i - KH + e, qh = i + hi_d0 - KH + e;
+        const bool fr = e < K && pr >= 0 && pr < ms && rr[min(max(pr, 0), ms - 1)] != 0;
+        const bool fl = ql >= 0 && ql < ns && cc[min(max(ql, 0), ns - 1)] != 0;
+        const bool fh = qh >= 0 && qh < ns && cc[min(max(qh, 0), ns - 1)] != 0;
+        co_r = (unsigned)(__builtin_amdgcn_ballot_w64(fr) >> sh);
+        co_lo = (unsigned)(__builtin_amdgcn_ballot_w64(fl) >> sh);
+        co_hi = (unsigned)(__builtin_amdgcn_ballot_w64(fh) >> sh);
+        if (e >= per_row) continue;
+    }
     int D;
     TC* dst;
     if (e < K - 1) {
@@ -182,7 +201,9 @@ __device__ __forceinline__ void mask_edge_fix(int block, int n_blocks, const uin
             fa = base_s[1][D];
             fb = base_s[2][D];
         }
-        const unsigned rbits = window_bits(rr, i, ms, K), cbits = window_bits(cc, j, ns, K);
+        const unsigned kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+        const unsigned rbits = coop ? (co_r & kmask) : window_bits(rr, i, ms, K);
+        const unsigned cbits = coop ? (((e < K - 1) ? (co_lo >> e) : (co_hi >> (e - (K - 1)))) & kmask) : window_bits(cc, j, ns, K);
         // flagged rows: every pixel of the row that lies in either triangle
         for (unsigned rb = rbits; rb; rb &= rb - 1) {
             const int ki = __ffs(rb) - 1;

@@ -263,7 +263,7 @@ struct MaskPrepArgs {
     int top, bot0, width, x_band, x_lo, side;   // frame corrections
     TC* fix_rows;
     TC* fix_cols;
-    int b_tab, b_edge;              // block ranges (filled by the launcher)
+    int b_tab, b_edge, b_rows;      // block ranges (filled by the launcher); b_tab = b_rows + blocks of the column table
 };
 template <typename TC>
 int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream);

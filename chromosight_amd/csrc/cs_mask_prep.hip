@@ -39,60 +39,55 @@ __device__ __forceinline__ unsigned window_bits(const uint8_t* __restrict__ flag
     return bits;
 }
 
+// Row table: {number of flagged rows of the window, their Wa row sums, their Wb row sums, the flags as a number};
+// column table: {number of flagged columns, their Wa column sums, their Wb column sums}.  Blocks [0, b_rows) take the
+// rows, the rest the columns, so a wave works on ONE flag vector: every lane loads the flag of bin (wave base - KH +
+// lane), the first 2 KH lanes a second one 64 bins further, and two ballots give every lane its window (2 byte loads
+// per lane instead of K dependent ones); the sums come from K row / column sums of the weights held in LDS instead
+// of 2 K loads per flagged bin.
 template <typename TC>
-__device__ __forceinline__ void mask_rowcol_tables(int block, const uint8_t* __restrict__ rr, const uint8_t* __restrict__ cc,
-                                                   int ms, int ns, int K, const TC* __restrict__ w, TC* __restrict__ rowtab,
-                                                   TC* __restrict__ coltab)
+__device__ __forceinline__ void mask_rowcol_tables(int block, int b_rows, const uint8_t* __restrict__ rr,
+                                                   const uint8_t* __restrict__ cc, int ms, int ns, int K,
+                                                   const TC* __restrict__ w, TC* __restrict__ rowtab, TC* __restrict__ coltab)
 {
-    const int id = block * blockDim.x + threadIdx.x;
+    __shared__ TC sums[2][kMaxK];               // of Wa / Wb along the other axis
+    const bool rows = block < b_rows;
     const int KH = (K - 1) / 2, kk = K * K;
-    const TC* wa = w + kk;
-    const TC* wb = w + 2 * kk;
-    if (id < ms) {
-        TC ua[kMaxK], ub[kMaxK];
-#pragma unroll
-        for (int kj = 0; kj < kMaxK; ++kj) ua[kj] = ub[kj] = TC(0);
-        int nr = 0;
-        unsigned bits = 0;
-        for (int ki = 0; ki < K; ++ki) {
-            const int p = id - KH + ki;
-            if (p < 0 || p >= ms || rr[p] == 0) continue;
-            ++nr;
-            bits |= 1u << ki;
-#pragma unroll
-            for (int kj = 0; kj < kMaxK; ++kj)
-                if (kj < K) {
-                    ua[kj] += wa[ki * K + kj];
-                    ub[kj] += wb[ki * K + kj];
-                }
-        }
-        TC ra = TC(0), rb = TC(0);
-#pragma unroll
-        for (int kj = 0; kj < kMaxK; ++kj) {
-            ra += ua[kj];
-            rb += ub[kj];
-        }
-        TC* row = rowtab + (size_t)id * kRowTabStride;
-        row[0] = (TC)nr;
-        row[1] = ra;
-        row[2] = rb;
+    if (threadIdx.x < 2 * K) {
+        const int set = threadIdx.x / K, k = threadIdx.x - set * K;
+        const TC* ws = w + (1 + set) * kk;
+        TC acc = TC(0);
+        for (int t = 0; t < K; ++t) acc += rows ? ws[k * K + t] : ws[t * K + k];
+        sums[set][k] = acc;
+    }
+    __syncthreads();
+    const int x = (rows ? block : block - b_rows) * blockDim.x + threadIdx.x;
+    const int n = rows ? ms : ns;
+    const uint8_t* __restrict__ flags = rows ? rr : cc;
+    const int lane = threadIdx.x & 63;
+    const int p0 = x - KH, p1 = x - KH + 64;
+    const bool f0 = p0 >= 0 && p0 < n && flags[min(max(p0, 0), n - 1)] != 0;
+    const bool f1 = lane < 2 * KH && p1 >= 0 && p1 < n && flags[min(max(p1, 0), n - 1)] != 0;
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
+    const unsigned long long win = (m0 >> lane) | (lane ? (m1 << (64 - lane)) : 0ull);
+    const unsigned bits = (unsigned)win & ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u));
+    if (x >= n) return;
+    TC sa = TC(0), sb = TC(0);
+    for (unsigned b = bits; b; b &= b - 1) {
+        const int k = __ffs(b) - 1;
+        sa += sums[0][k];
+        sb += sums[1][k];
+    }
+    if (rows) {
+        TC* row = rowtab + (size_t)x * kRowTabStride;
+        row[0] = (TC)__popc(bits);
+        row[1] = sa;
+        row[2] = sb;
         row[3] = (TC)bits;   // flagged rows of the window as a number (17 bits: exact in float32)
-    } else if (id < ms + ns) {
-        const int j = id - ms;
-        int nc = 0;
-        TC ca = TC(0), cb = TC(0);
-        for (int kj = 0; kj < K; ++kj) {
-            const int q = j - KH + kj;
-            if (q < 0 || q >= ns || cc[q] == 0) continue;
-            ++nc;
-            for (int ki = 0; ki < K; ++ki) {
-                ca += wa[ki * K + kj];
-                cb += wb[ki * K + kj];
-            }
-        }
-        coltab[j] = (TC)nc;
-        coltab[(size_t)ns + j] = ca;
-        coltab[2 * (size_t)ns + j] = cb;
+    } else {
+        coltab[x] = (TC)__popc(bits);
+        coltab[(size_t)ns + x] = sa;
+        coltab[2 * (size_t)ns + x] = sb;
     }
 }
 
@@ -367,7 +362,7 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(MaskPrepArgs<TC> P)
 {
     const int b = blockIdx.x;
     if (b < P.b_tab) {
-        mask_rowcol_tables<TC>(b, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab);
+        mask_rowcol_tables<TC>(b, P.b_rows, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab);
     } else if (b < P.b_tab + P.b_edge) {
         mask_edge_fix<TC>(b - P.b_tab, P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.max_dist, P.hi_d0, P.hi_w, P.w, P.fix_lo,
                           P.fix_hi);
@@ -383,7 +378,8 @@ template <typename TC>
 int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream)
 {
     if (P.K > kMaxK) return -1;
-    P.b_tab = (P.ms + P.ns + 255) / 256;
+    P.b_rows = (P.ms + 255) / 256;
+    P.b_tab = P.b_rows + (P.ns + 255) / 256;
     P.b_edge = 0;
     if (P.edge) {
         const long long n = (long long)P.ms * ((P.K - 1) + P.hi_w);

@@ -459,7 +459,7 @@ def main():
         # the sharded end-to-end genome next to the kernel figure, at every N (strong scaling, records
         # gathered over RCCL): all ranks take part
         try:
-            genome = time_genome(args, rank, local_rank, world, dist, torch, steps=3, warmup=1)
+            genome = time_genome(args, rank, local_rank, world, dist, torch, steps=8, warmup=3)
         except Exception as exc:
             genome = {"error": repr(exc)}
 

@@ -393,3 +393,30 @@ def test_separable_kernel_on_rank1_templates(name, monkeypatch):
     # separable kernel's 31 + 31 stay within 2.2e-6): the cross-check is correspondingly loose
     assert np.abs(c.toarray() - c2.toarray())[well].max() < 5e-5
     assert np.abs(p.toarray() - p2.toarray())[well].max() < 5e-3
+
+
+def test_default_dispatch_by_template():
+    """Which kernel serves a masked, banded detect-style call by default (cs_api.cpp launch_corr): the masked matrix-core
+    tile kernel for 15 x 15 and 17 x 17 templates, the streaming kernel below, the separable kernel for outer-product
+    templates without an unrolled instance, the runtime-size kernel for the rest; dense unmasked maps take the dense
+    tile kernel."""
+    rng = np.random.default_rng(8)
+    n, md = 500, 90
+    sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
+    valid = np.flatnonzero(rng.random(n) > 0.03)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    sig[miss, :] = 0
+    sig[:, miss] = 0
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+    u, v = rng.normal(size=21) + 0.5, rng.normal(size=21) + 0.5
+    cases = [(loops(), KERNEL_MFMA_REG), (np.asarray(ck.borders["kernels"][0], dtype=np.float64), KERNEL_MFMA_REG),
+             (np.asarray(ck.hairpins["kernels"][0], dtype=np.float64), KERNEL_MFMA_REG),
+             (rng.normal(size=(13, 13)) + 0.3, KERNEL_STREAM), (rng.normal(size=(7, 7)) + 0.3, KERNEL_STREAM),
+             (np.asarray(ck.stripes_left["kernels"][0], dtype=np.float64), KERNEL_SEPARABLE),
+             (np.outer(u, v), KERNEL_SEPARABLE), (rng.normal(size=(21, 21)) + 0.3, KERNEL_GENERIC)]
+    for kern, expected in cases:
+        cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask, missing_tol=0.75)
+        assert last_kernel() == expected, (kern.shape, last_kernel(), expected)
+    cud.normxcorr2(rng.gamma(4.0, 0.25, size=(300, 320)).astype(np.float32), loops())
+    assert last_kernel() == KERNEL_MFMA_DENSE

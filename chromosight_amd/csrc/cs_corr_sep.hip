@@ -92,19 +92,30 @@ __global__ __launch_bounds__(512) void corr_sep_kernel(const CorrArgs<float> A)
     float* H1 = H + (size_t)LH * SEP_TW;
     float* H2 = H + 2 * (size_t)LH * SEP_TW;
     // ---- signal: horizontal pass over every staged row (64 output columns), vertical pass over km rows
-    for (int r = wv; r < LH; r += SEP_NW) {
+    // two staged rows per step share the read of v[b] (and double the independent accumulation chains)
+    for (int r = wv; r < LH; r += 2 * SEP_NW) {
+        const int r2 = min(r + SEP_NW, LH - 1);
         const float* row = sS + r * LWP + lane;
-        float hv = 0.0f, h1 = 0.0f, h2 = 0.0f;
+        const float* row2 = sS + r2 * LWP + lane;
+        float hv = 0.0f, h1 = 0.0f, h2 = 0.0f, kv = 0.0f, k1 = 0.0f, k2 = 0.0f;
 #pragma unroll 4
         for (int b = 0; b < kn; ++b) {
-            const float x = row[b], vb = sv[b];
+            const float x = row[b], y = row2[b], vb = sv[b];
             hv = fmaf(x, vb, hv);
             h1 += x;
             h2 = fmaf(x, x, h2);
+            kv = fmaf(y, vb, kv);
+            k1 += y;
+            k2 = fmaf(y, y, k2);
         }
         H0[r * SEP_TW + lane] = hv;
         H1[r * SEP_TW + lane] = h1;
         H2[r * SEP_TW + lane] = h2;
+        if (r + SEP_NW < LH) {
+            H0[r2 * SEP_TW + lane] = kv;
+            H1[r2 * SEP_TW + lane] = k1;
+            H2[r2 * SEP_TW + lane] = k2;
+        }
     }
     __syncthreads();
 #pragma unroll 2
@@ -121,20 +132,30 @@ __global__ __launch_bounds__(512) void corr_sep_kernel(const CorrArgs<float> A)
     if (MASKED) {
         __syncthreads();
         // ---- mask: sum M, sum v M, sum v^2 M per staged row; then with 1, u, u^2 down the rows
-        for (int r = wv; r < LH; r += SEP_NW) {
+        for (int r = wv; r < LH; r += 2 * SEP_NW) {
+            const int r2 = min(r + SEP_NW, LH - 1);
             const uint8_t* mrow = sM + r * LWP + lane;
-            float g1 = 0.0f, gv = 0.0f, gw = 0.0f;
+            const uint8_t* mrow2 = sM + r2 * LWP + lane;
+            float g1 = 0.0f, gv = 0.0f, gw = 0.0f, q1 = 0.0f, qv = 0.0f, qw = 0.0f;
 #pragma unroll 4
             for (int b = 0; b < kn; ++b) {
-                const float m = (float)mrow[b], vb = sv[b];
-                const float t = m * vb;
+                const float m = (float)mrow[b], m2 = (float)mrow2[b], vb = sv[b];
+                const float t = m * vb, t2 = m2 * vb;
                 g1 += m;
                 gv += t;
                 gw = fmaf(t, vb, gw);
+                q1 += m2;
+                qv += t2;
+                qw = fmaf(t2, vb, qw);
             }
             H0[r * SEP_TW + lane] = g1;
             H1[r * SEP_TW + lane] = gv;
             H2[r * SEP_TW + lane] = gw;
+            if (r + SEP_NW < LH) {
+                H0[r2 * SEP_TW + lane] = q1;
+                H1[r2 * SEP_TW + lane] = qv;
+                H2[r2 * SEP_TW + lane] = qw;
+            }
         }
         __syncthreads();
 #pragma unroll 2

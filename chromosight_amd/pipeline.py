@@ -485,7 +485,7 @@ class DeviceCool:
 
 
 def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, want_windows=True, raw=False, dev=None,
-                 stream=None, all_gather=None):
+                 stream=None, all_gather=None, defer=False):
     """pattern_detector(full=True) on a staged block (cli/chromosight.py:601-614).  A block staged as a
     row window (stage_intra(rows=...)) is this rank's part of a sub-matrix split over several GPUs:
     `all_gather` exchanges the candidate pixels and the records (detect_split_on_device)."""
@@ -501,7 +501,7 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
                                           all_gather=all_gather, want_windows=want_windows, raw=raw, stream=stream)
     return cid.detect_on_device(dev or dcool.dev, block.sig, block.shape, kspec, kernel_config, block.miss_row,
                                 block.miss_col, inter=block.inter, max_dist=block.max_dist, full=True, coords=coords,
-                                want_windows=want_windows, raw=raw, stream=stream)
+                                want_windows=want_windows, raw=raw, stream=stream, defer=defer)
 
 
 def b_is_band(block):
@@ -532,12 +532,24 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
     dcool.dev.sync()
     pool = dcool.workers(workers)
 
+    # raw tables of banded intra blocks: the workers only run the native call; the acceptance rules are applied to all
+    # their records in one go (numpy under the interpreter lock was a good part of a worker's time on a small block)
+    deferred = raw and all(b_is_band(b) and min(b.shape) > max(kernel.shape) for b in blocks)
+
     def one(block):
         dev, stream = pool.device()
         return detect_block(dcool, block, kernel_config, kernel, tsvd=tsvd, raw=raw, dev=dev, stream=stream,
-                            want_windows=want_windows)
+                            want_windows=want_windows, defer=deferred)
 
-    return pool.map(one, blocks)
+    results = pool.map(one, blocks)
+    if not deferred:
+        return results
+    counts = [len(r[0]) for r in results]
+    if sum(counts) == 0:
+        return [(None, None)] * len(blocks)
+    rec = np.concatenate([r[0] for r in results])
+    windows = np.concatenate([r[1] for r in results]) if want_windows else None
+    return cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config)
 
 
 def sub_matrices(dcool, inter):

@@ -556,7 +556,7 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
 
 
 def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, *, inter, max_dist, full,
-                     coords=None, want_windows=True, raw=False, stream=None):
+                     coords=None, want_windows=True, raw=False, stream=None, defer=False):
     """The part of pattern_detector that follows the staging of the contact map in HBM
     (reference detection.py:240-345): correlation, foci, validation statistics -- one native call
     (cs_detect_foci / cs_quantify_pixels) -- then the acceptance rules on the few returned records.
@@ -588,6 +588,9 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
         run_mode = "detect"
         rec, windows = engine.run_detect_foci(dev, sig, shape, kspec, pearson=pearson, lo_diag=lo_diag, hi_diag=hi_diag,
                                               diag_only=diag_only, **common)
+        if defer:
+            # the caller applies the acceptance rules to the records of all its blocks at once (accept_many)
+            return rec, windows
         if rec.shape[0] == 0:
             return None, None
     else:
@@ -634,20 +637,8 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     if res is None:
         return None
     if raw:
-        # the acceptance rules on the records of ALL blocks at once (23 numpy passes over ~350 records each cost
-        # more than the native call), then cut at the block boundaries
         rec, windows, counts = res
-        per = lambda values: np.repeat(np.asarray(values, dtype=np.int64), counts)
-        rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
-        shape = (per([b.shape[0] for b in blocks]), per([b.shape[1] for b in blocks]))
-        rec4, windows, ok = _accept_records(rec, windows, rr, cc, "detect", shape, kspec, kernel_config, inter=False,
-                                            max_dist=per([b.max_dist for b in blocks]), full=True, raw=True, return_ok=True)
-        ends = np.cumsum(counts)
-        kept = np.concatenate([[0], np.cumsum(ok)])[ends]              # accepted records up to the end of each block
-        cuts = kept[:-1]
-        parts = np.split(rec4, cuts)
-        wparts = np.split(windows, cuts) if windows is not None else [None] * len(blocks)
-        return [(None, None) if n == 0 else (t, w) for n, t, w in zip(counts, parts, wparts)]
+        return accept_many(blocks, rec, windows, counts, kspec, kernel_config)
     out = []
     for b, (rec, windows) in zip(blocks, res):
         if rec.shape[0] == 0:
@@ -657,6 +648,25 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
         out.append(_accept_records(rec, windows, rr, cc, "detect", b.shape, kspec, kernel_config, inter=False,
                                    max_dist=b.max_dist, full=True, raw=raw))
     return out
+
+
+def accept_many(blocks, rec, windows, counts, kspec, kernel_config):
+    """The acceptance rules (detect mode, full maps) on the records of SEVERAL intra sub-matrices at once -- `rec` /
+    `windows`: the records of `blocks` one block after the other, `counts` per block -- then cut at the block
+    boundaries: the list of raw (table, windows) per block.  (23 numpy passes over a few hundred records each cost
+    more than the native calls that produced them.)"""
+    counts = np.asarray(counts, dtype=np.int64)
+    per = lambda values: np.repeat(np.asarray(values, dtype=np.int64), counts)
+    rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+    shape = (per([b.shape[0] for b in blocks]), per([b.shape[1] for b in blocks]))
+    rec4, windows, ok = _accept_records(rec, windows, rr, cc, "detect", shape, kspec, kernel_config, inter=False,
+                                        max_dist=per([b.max_dist for b in blocks]), full=True, raw=True, return_ok=True)
+    ends = np.cumsum(counts)
+    kept = np.concatenate([[0], np.cumsum(ok)])[ends]              # accepted records up to the end of each block
+    cuts = kept[:-1]
+    parts = np.split(rec4, cuts)
+    wparts = np.split(windows, cuts) if windows is not None else [None] * len(blocks)
+    return [(None, None) if n == 0 else (t, w) for n, t, w in zip(counts, parts, wparts)]
 
 
 def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw, return_ok=False):

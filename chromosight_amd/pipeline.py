@@ -286,11 +286,10 @@ class DeviceCool:
         return (dev or self.dev).empty(nbytes, np.uint8)
 
     def stage_blocks(self, chroms, max_dist, largest_kernel, workers=1, **options):
-        """stage_intra(resident=True) of several chromosomes.  workers > 1: host threads with their own contexts,
-        streams and extent scratch stage several blocks at a time (see _Workers) -- measured on the 23-block genome
-        this LOSES (staging 4.0 -> 5.7 ms per pass: the chains are dominated by clearing and filling 70 MB bands,
-        which already fill the chip, and the hand-over costs two synchronisations per block), so one stream is
-        the default.  Every block's staging is enqueued (workers > 1: complete) on return."""
+        """stage_intra(resident=True) of several chromosomes.  Default: one host thread deals the blocks to a few streams
+        (below).  workers > 1: host threads with their own contexts stage several blocks at a time (see _Workers) --
+        measured slower than ONE stream on the 23-block genome (the hand-over costs two synchronisations per block).
+        Every block's staging is complete on return."""
         chroms = list(chroms)
         if workers <= 1 or len(chroms) <= 1:
             # one host thread, the blocks dealt to a few streams of this context (each with its own extent scratch):

@@ -198,14 +198,15 @@ def _gather(records, n_fields):
     count = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)
-    counts = [int(c.item()) for c in counts]
+    counts = torch.cat(counts).cpu().tolist()                 # one device -> host copy, not one per rank
     width = max(max(counts), 1)
     padded = torch.zeros((width, n_fields), dtype=torch.float64, device=dev)
     if records.shape[0]:
         padded[:records.shape[0]] = torch.from_numpy(records).to(dev)
     parts = [torch.zeros_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded)
-    merged = np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
+    parts = torch.stack(parts).cpu().numpy()                   # likewise
+    merged = np.concatenate([parts[r, :c] for r, c in enumerate(counts)], axis=0)
     return merged[np.argsort(merged[:, 0], kind="stable")]
 
 
@@ -246,6 +247,8 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     else:
         staged = {ci: stage(genome, ci, max_dist, largest) for ci in mine}
     out = []
+    one_exchange = kernel_config["max_iterations"] == 1 and world > 1      # no template depends on another's records
+    pending = []
     for kernel_id, kernel in enumerate(kernel_config["kernels"]):
         kernel = np.asarray(kernel, dtype=np.float64)
         for it in range(kernel_config["max_iterations"]):
@@ -273,6 +276,9 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                 if windows is not None:
                     wins.append(windows)
             local = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(GENOME_FIELDS)))
+            if one_exchange:
+                pending.append(local)                        # a single iteration per template: gathered once, below
+                continue
             merged = _gather(local, len(GENOME_FIELDS))
             if merged.shape[0] == 0:
                 break                                        # no pattern with this template: next one
@@ -290,4 +296,12 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                     both = _allreduce_sum(both)
                     with np.errstate(all="ignore"):
                         kernel = both[0] / both[1]
+    if one_exchange:
+        # one count + one padded all_gather for all templates (each exchange is two collectives and two host round
+        # trips: with 3 blocks per GPU they were a good part of a pass); per template the rows then come in the
+        # order the per-template gathers gave -- ranks concatenated, stable by block
+        local = np.concatenate(pending, axis=0) if pending else np.zeros((0, len(GENOME_FIELDS)))
+        merged = _gather(local, len(GENOME_FIELDS))
+        out = [merged[merged[:, 5] == kernel_id] for kernel_id in range(len(kernel_config["kernels"]))]
+        out = [m for m in out if m.shape[0]]
     return np.concatenate(out, axis=0) if out else np.zeros((0, len(GENOME_FIELDS)))

@@ -133,6 +133,11 @@ def _fake_detect(genome, block, cfg, kernel, tsvd):
 _CFG = {"max_dist": 20_000, "max_iterations": 3, "kernels": [np.full((3, 3), 0.5), np.arange(9.0).reshape(3, 3) / 7]}
 
 
+# single iteration, three templates: every template's records travel in ONE exchange at the end of the call
+_CFG_ONE = {"max_dist": 20_000, "max_iterations": 1,
+            "kernels": [np.full((3, 3), 0.5), np.arange(9.0).reshape(3, 3) / 7, np.eye(3) + 0.25]}
+
+
 def _genome_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -140,6 +145,8 @@ def _genome_worker(rank, world, port, out_dir):
     try:
         got = parallel.detect_genome(_Genome(), _CFG, stage=_fake_stage, detect=_fake_detect)
         np.save(os.path.join(out_dir, f"genome{rank}.npy"), got)
+        got = parallel.detect_genome(_Genome(), _CFG_ONE, stage=_fake_stage, detect=_fake_detect)
+        np.save(os.path.join(out_dir, f"genome_one{rank}.npy"), got)
     finally:
         dist.destroy_process_group()
 
@@ -157,3 +164,7 @@ def test_detect_genome_world2_equals_single(tmp_path):
         assert got.shape == single.shape
         assert np.array_equal(got[:, [0, 1, 2, 5, 6]], single[:, [0, 1, 2, 5, 6]])
         assert np.allclose(got[:, 3:5], single[:, 3:5], rtol=0, atol=1e-12)
+    single_one = parallel.detect_genome(_Genome(), _CFG_ONE, stage=_fake_stage, detect=_fake_detect)
+    assert len(np.unique(single_one[:, 5])) == 3
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"genome_one{r}.npy"), single_one)      # same rows, same order

@@ -1418,6 +1418,16 @@ static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel
 }
 
 namespace {
+// 1-D patterns (cs_foci_params.diag_only): the reference forces bin1 = bin2 AFTER shifting the coordinates by (kh, kw)
+// into a map padded by (kw, kh) (detection.py:287-315, preprocessing.py:636-676), so with a non-square template in full
+// mode the row ends up kw - kh away from the column.  The kernels take an odd code whose upper bits hold that offset.
+inline int diag_code(const cs_foci_params* fp, const cs_kernel* kernel, const cs_normxcorr2_params* p)
+{
+    if (!fp->diag_only) return 0;
+    const int shift = p->full ? (kernel->kn - 1) / 2 - (kernel->km - 1) / 2 : 0;
+    return shift * 2 + 1;
+}
+
 // Candidate stage shared by cs_detect_foci and cs_candidates: the coefficient map of the row window in
 // context scratch, thresholded compaction (or, for 1-D patterns, the enumeration of the few scanned
 // diagonals).  The pool is laid out as rows | cols | vals | counters | windows | tail.
@@ -1558,7 +1568,7 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
     if (direct) {
         ctx->h_counts[1] = -1;
         rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + P.off_cols), n_cand, fp->pearson, fp->min_size,
-                              fp->diag_only, fp->inter, pool + P.off_tail, &d_rec, win_direct, win_direct ? (long long)cap : 0,
+                              diag_code(fp, kernel, p), fp->inter, pool + P.off_tail, &d_rec, win_direct, win_direct ? (long long)cap : 0,
                               d_cnt + 1, stream, P.row_major, rec_direct, (long long)cap, ctx->h_counts + 1);
         if (rc) return fail(ctx, CS_ERR_HIP, "foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
         CS_HIP(ctx, hipStreamSynchronize(stream));
@@ -1569,7 +1579,7 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
         return CS_OK;
     }
     rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + P.off_cols), n_cand, fp->pearson, fp->min_size,
-                          fp->diag_only, fp->inter, pool + P.off_tail, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream,
+                          diag_code(fp, kernel, p), fp->inter, pool + P.off_tail, &d_rec, d_win, (long long)win_pat, d_cnt + 1, stream,
                           P.row_major, nullptr, 0, nullptr);
     if (rc) return fail(ctx, CS_ERR_HIP, "foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts + 1, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream));
@@ -1646,7 +1656,7 @@ int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_
     int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, cs::narrow_batch_scratch_bytes(n_blocks, n_total));
     if (rc) return rc;
     rc = cs::enqueue_foci_narrow_batch(tab.data(), seg.data(), lo_w.data(), n_blocks, foci[0].pearson, foci[0].min_size,
-                                       foci[0].diag_only, foci[0].inter, ctx->d_pool, rec, (long long)cap, win,
+                                       diag_code(foci, kernel, params), foci[0].inter, ctx->d_pool, rec, (long long)cap, win,
                                        win ? (long long)cap : 0, ctx->h_blk_counts, stream);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host tables above were consumed

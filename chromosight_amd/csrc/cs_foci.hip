@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void emit_foci_kernel(const int* __restri
         const long long key = keys[best_idx[t]];
         int row = (int)(key / ns);
         const int col = (int)(key - (long long)row * ns);
-        if (diag_only) row = col;
+        if (diag_only) row = col + (diag_only >> 1);   // odd code: 1-D pattern, row offset in the upper bits
         out_rows[pos[t]] = row;
         out_cols[pos[t]] = col;
         out_size[pos[t]] = size[t];
@@ -304,7 +304,7 @@ __device__ __forceinline__ void foci_small_body(
             const long long key = keys_k[best_idx[t]];
             int row = (int)(key / ns);
             const int col = (int)(key - (long long)row * ns);
-            if (diag_only) row = col;
+            if (diag_only) row = col + (diag_only >> 1);   // odd code: 1-D pattern, row offset in the upper bits
             out_rows[pos[t]] = row;
             out_cols[pos[t]] = col;
             out_size[pos[t]] = size[t];

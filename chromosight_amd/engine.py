@@ -266,7 +266,7 @@ def run_label_foci(dev, shape, rows, cols, vals, *, min_size=2, diag_only=False,
     f_rows, f_cols, f_size = (np.empty(cap, np.int32) for _ in range(3))
     n = C.c_int64(0)
     dev._check(dev.lib.cs_label_foci(dev.ctx, stream, int(shape[0]), int(shape[1]), rows.ctypes.data, cols.ctypes.data,
-                                     vals.ctypes.data, k, int(min_size), int(bool(diag_only)), f_rows.ctypes.data,
+                                     vals.ctypes.data, k, int(min_size), int(diag_only), f_rows.ctypes.data,
                                      f_cols.ctypes.data, f_size.ctypes.data, cap, C.byref(n)))
     m = int(n.value)
     return f_rows[:m], f_cols[:m], f_size[:m]

@@ -510,6 +510,7 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
     kernel = np.asarray(kernel, dtype=np.float64)
     if min(block.shape) <= max(kernel.shape):
         return None, None
+    _check_template(kernel)
     kspec = engine.KernelSpec(kernel, tsvd)
     if getattr(block, "row_window", None) is not None:
         if coords is not None or all_gather is None:
@@ -522,6 +523,14 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
                                 want_windows=want_windows, raw=raw, stream=stream, defer=defer)
 
 
+def _check_template(kernel):
+    """normxcorr2's template check (detection.py:888-889).  It is what stops the reference when a 1-D pattern is
+    iterated: the windows of intra maps carry NaN on the first sub-diagonals (detection.py:300-310), so does their
+    pileup, and `kernel.std() > 0` is False for a template with NaN (tests/golden/iterations.npz: borders_error)."""
+    if not (np.std(kernel) > 0):
+        raise ValueError("Cannot have flat kernel.")
+
+
 def b_is_band(block):
     return block.sig.layout == LAYOUT_BAND and not block.inter and getattr(block, "row_window", None) is None
 
@@ -530,7 +539,9 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
     """detect_block for every staged block of `blocks`, several at a time (see _Workers); results in
     the order of `blocks`.  The staging of the blocks (default stream) is complete before they start."""
     kernel = np.asarray(kernel, dtype=np.float64)
-    if len(blocks) > 1 and kernel_config["max_dist"] == 0 and batch:
+    if any(min(b.shape) > max(kernel.shape) for b in blocks):
+        _check_template(kernel)
+    if len(blocks) > 1 and kernel_config["max_dist"] == 0 and batch and kernel.shape[0] == kernel.shape[1]:
         # 1-D patterns: all banded sub-matrices in one native call; blocks too small for the template drop out
         # as they do in detect_block, the few that are staged dense (very short chromosomes) go one by one
         live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
@@ -552,7 +563,7 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
 
     # raw tables of banded intra blocks: the workers only run the native call; the acceptance rules are applied to all
     # their records in one go (numpy under the interpreter lock was a good part of a worker's time on a small block)
-    deferred = raw and all(b_is_band(b) and min(b.shape) > max(kernel.shape) for b in blocks)
+    deferred = raw and kernel.shape[0] == kernel.shape[1] and all(b_is_band(b) and min(b.shape) > max(kernel.shape) for b in blocks)
 
     def one(block):
         dev, stream = pool.device()
@@ -736,10 +747,15 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     windows = np.concatenate(win_out, axis=0)
     bed = bed.sort_values("score", ascending=True).groupby(["chrom1", "start1", "chrom2", "start2"], sort=False).tail(1)
     windows = windows[bed.index, :, :]
-    which = bed.index.to_numpy() % n_pos
     bed = bed.reset_index(drop=True)
-    bed["bin1"] = g1[which]
-    bed["bin2"] = g2[which]
+    # the bin columns come from the interval STARTS (coords_to_bins of start1 / start2, :446-455), the scores from
+    # the interval midpoints: they differ for intervals wider than one bin
+    out1 = dcool.bins_of(bed.chrom1, bed.start1)
+    out2 = dcool.bins_of(bed.chrom2, bed.start2)
+    if (out1 < 0).any() or (out2 < 0).any():            # no such bin: NaN, as the reference's merge leaves it
+        out1, out2 = np.where(out1 < 0, np.nan, out1), np.where(out2 < 0, np.nan, out2)
+    bed["bin1"] = out1
+    bed["bin2"] = out2
     bed["qvalue"] = fdr_correction(bed["pvalue"])
     bed = bed.loc[:, ["chrom1", "start1", "end1", "chrom2", "start2", "end2", "bin1", "bin2", "score", "pvalue", "qvalue"]]
     bad = np.isnan(bed.score.to_numpy(dtype=np.float64))

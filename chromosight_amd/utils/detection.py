@@ -546,6 +546,12 @@ def pattern_detector(contact_map, kernel_config, kernel_matrix, coords=None, dum
     out_range = None
     if not inter and max_dist is not None:
         out_range = (0, max_dist)       # diag_trim(mat_conv, max_dist), detection.py:269-270
+    if full and sym_upper:
+        # normxcorr2's second safety check (detection.py:1022): stored pixels on the sub-diagonals the framed mask
+        # flags.  Upper-triangular maps can only trip it with a template taller than wide.
+        rng = engine.diag_range(csr)
+        if rng is not None and rng[0] + (kn - km) <= -1:
+            _check_framed_signal(csr, None, (km, kn), sym_upper, max_dist)
     st = _Staged(dev, csr, (km, kn), sym_upper, full, out_diag_range=out_range)
     miss_r = miss_c = None
     if full:
@@ -598,7 +604,7 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
         coords_in = coords
         pts = np.array(coords_in, dtype=int, copy=True)
         if diag_only:
-            pts[:, 0] = pts[:, 1]
+            pts[:, 0] = pts[:, 1] + ((kw - kh) if full else 0)      # forced on the diagonal AFTER the (kh, kw) shift
         rr, cc = pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64)
         big = np.iinfo(np.int32).max // 2
         rec, windows = engine.run_quantify_pixels(dev, sig, shape, kspec, np.clip(rr, -big, big), np.clip(cc, -big, big),
@@ -614,8 +620,22 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
                 pass
     if run_mode == "detect":
         rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+    conv = _offset_scores(dev, sig, shape, kspec, rr, cc, common) if (full and km != kn) else None
     return _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, inter=inter, max_dist=max_dist,
-                           full=full, raw=raw)
+                           full=full, raw=raw, conv=conv)
+
+
+def _offset_scores(dev, sig, shape, kspec, rr, cc, common):
+    """Non-square templates in full mode: pattern_detector pads the coefficient map by (kw rows, kh columns)
+    (zero_pad_sparse(mat_conv, kh, kw), preprocessing.py:636-676) yet shifts the coordinates by (kh, kw)
+    (detection.py:287-298), so validate_patterns reads the score of pattern (r, c) at (r + kh - kw, c + kw - kh).
+    Returns (rows, cols, float64 coefficients there)."""
+    d = (kspec.km - 1) // 2 - (kspec.kn - 1) // 2
+    big = np.iinfo(np.int32).max // 2
+    sr, sc = np.clip(rr + d, -big, big), np.clip(cc - d, -big, big)
+    keys = ("full", "sym_upper", "max_dist", "mask_mode", "miss_row", "miss_col", "missing_tol", "stream")
+    vals, _ = engine.run_rescore(dev, sig, shape, kspec, sr, sc, **{k: common[k] for k in keys if k in common})
+    return sr, sc, vals
 
 
 def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None):
@@ -624,7 +644,7 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     One native call (cs_detect_foci_batch) instead of one launch chain and synchronisation per sub-matrix.
     Returns the list of (table, windows) detect_on_device would return, or None if the batch entry does not
     apply (caller falls back to one call per block)."""
-    if kernel_config["max_dist"] != 0 or not blocks:
+    if kernel_config["max_dist"] != 0 or not blocks or kspec.km != kspec.kn:
         return None
     if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None for b in blocks):
         return None
@@ -669,21 +689,24 @@ def accept_many(blocks, rec, windows, counts, kspec, kernel_config):
     return [(None, None) if n == 0 else (t, w) for n, t, w in zip(counts, parts, wparts)]
 
 
-def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw, return_ok=False):
+def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw, return_ok=False,
+                    conv=None):
     """The acceptance rules of pattern_detector / validate_patterns on the records the device returned
     (reference detection.py:121-141, 269-270, 332-336): (table, windows).  `shape` and `max_dist` may be
-    per-record arrays (records of several sub-matrices in one call)."""
+    per-record arrays (records of several sub-matrices in one call).  conv = (rows, cols, coefficients): where the
+    reference reads the score when that is not (bin1, bin2) (_offset_scores)."""
     ms, ns = shape
     km, kn = kspec.km, kspec.kn
     missing_tol = kernel_config["max_perc_undetected"] / 100
     zero_tol = kernel_config["max_perc_zero"] / 100
     r64, nobs = rec["score"], rec["n_obs"]
     # coefficient on the trimmed map (:269-270), p-value on the untrimmed one (:332-336)
-    in_band = (rr >= 0) & (rr < ms) & (cc >= 0) & (cc < ns)
+    sr, sc, sv = (rr, cc, r64) if conv is None else conv
+    in_band = (sr >= 0) & (sr < ms) & (sc >= 0) & (sc < ns)
     if not inter:
-        d = cc - rr
+        d = sc - sr
         in_band &= (d >= 0) & ((d <= max_dist) if max_dist is not None else True)
-    conv_at = np.where(in_band, r64, 0.0)
+    conv_at = np.where(in_band, sv, 0.0)
     n_obs = nobs if full else np.full(r64.shape, float(km * kn))
     with np.errstate(all="ignore"):
         logp = np.where(r64 != 0, cus.corr_to_pval(r64, np.where(n_obs == 0, km * kn, n_obs)), 0.0)
@@ -738,8 +761,9 @@ def detect_split_on_device(dev, sig, shape, row_window, kspec, kernel_config, mi
     cand = all_gather(np.column_stack([rows.astype(np.float64), cols.astype(np.float64), vals]).reshape(-1, 3))
     if cand.shape[0] == 0:
         return None, None
+    diag_code = (2 * ((kn - 1) // 2 - (km - 1) // 2) + 1 if full else 1) if diag_only else 0
     f_rows, f_cols, f_size = engine.run_label_foci(dev, shape, cand[:, 0].astype(np.int32), cand[:, 1].astype(np.int32),
-                                                   cand[:, 2], min_size=2, diag_only=diag_only, stream=stream)
+                                                   cand[:, 2], min_size=2, diag_only=diag_code, stream=stream)
     order = np.arange(f_rows.size)
     mine = (f_rows >= a) & (f_rows < b)
     width = len(FOCUS_DTYPE.names) + 1 + (kk if want_windows else 0)
@@ -762,6 +786,8 @@ def detect_split_on_device(dev, sig, shape, row_window, kspec, kernel_config, mi
         rec[name] = merged[:, 1 + k]
     windows = merged[:, 1 + len(FOCUS_DTYPE.names):].reshape(-1, km, kn).copy() if want_windows else None
     rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+    if full and km != kn:
+        raise ValueError("a sub-matrix split by rows needs a square template in full mode")
     return _accept_records(rec, windows, rr, cc, "detect", shape, kspec, kernel_config, inter=False, max_dist=max_dist,
                            full=full, raw=raw)
 

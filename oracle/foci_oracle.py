@@ -105,19 +105,31 @@ def validate(coords, value_at, shape, miss_row, miss_col, kernel_shape, zero_tol
 
 
 def detect_table(matrix, corr_trimmed, miss_row, miss_col, kernel_shape, pearson, zero_tol, missing_tol,
-                 inter=False, diag_only=False):
+                 inter=False, diag_only=False, full=True, return_windows=False):
     """Dense test-sized maps: (bin1, bin2, score) of the validated foci in the reference's order.
-    corr_trimmed: coefficient map already restricted to the scanned diagonals (diag_trim)."""
+    corr_trimmed: coefficient map already restricted to the scanned diagonals (diag_trim).
+
+    Non-square templates in full mode (detection.py:287-298, preprocessing.py:636-676): the maps are padded by
+    (kw rows, kh columns) but the coordinates shifted by (kh, kw), so the score of pattern (r, c) is read at
+    (r + kh - kw, c + kw - kh) (0 outside the map) and a 1-D pattern, forced on the diagonal after the shift, ends
+    up at (c + kw - kh, c); validate() restates the same offsets for the windows."""
     matrix = np.asarray(matrix, dtype=np.float64)
-    foci = pick_foci_dense(np.asarray(corr_trimmed, dtype=np.float64), pearson)
+    corr_trimmed = np.asarray(corr_trimmed, dtype=np.float64)
+    km, kn = kernel_shape
+    shift = ((km - 1) // 2 - (kn - 1) // 2) if full else 0
+    foci = pick_foci_dense(corr_trimmed, pearson)
     if foci.shape[0] == 0:
-        return np.zeros((0, 3))
+        return (np.zeros((0, 3)), np.zeros((0, km, kn))) if return_windows else np.zeros((0, 3))
     if diag_only and not inter:
-        foci[:, 0] = foci[:, 1]
-    valid, _ = validate(foci, lambda p, q: matrix[p, q], matrix.shape, miss_row, miss_col, kernel_shape,
-                        zero_tol, missing_tol, inter)
+        foci[:, 0] = foci[:, 1] - shift
+    valid, wins = validate(foci, lambda p, q: matrix[p, q], matrix.shape, miss_row, miss_col, kernel_shape,
+                           zero_tol, missing_tol, inter, full=full)
     keep = foci[valid]
-    return np.column_stack([keep[:, 0], keep[:, 1], corr_trimmed[keep[:, 0], keep[:, 1]]]).astype(np.float64)
+    sr, sc = keep[:, 0] + shift, keep[:, 1] - shift
+    inside = (sr >= 0) & (sr < corr_trimmed.shape[0]) & (sc >= 0) & (sc < corr_trimmed.shape[1])
+    scores = np.where(inside, corr_trimmed[np.where(inside, sr, 0), np.where(inside, sc, 0)], 0.0)
+    table = np.column_stack([keep[:, 0], keep[:, 1], scores]).astype(np.float64)
+    return (table, wins[valid]) if return_windows else table
 
 
 def detect_table_band(band, band_lo, corr_band, out_lo, n, miss, kernel_shape, pearson, zero_tol, missing_tol,

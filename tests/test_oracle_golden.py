@@ -240,3 +240,61 @@ def test_detrend_oracle_matches_reference_blocks(golden):
             for d in range(min(band.shape[1], n)):
                 dense[np.arange(n - d), np.arange(n - d) + d] = prepared[:n - d, d]
             assert np.abs(dense - ref).max() < 1e-11, (ci, pname)
+
+
+def _nonsquare_case(g, tag):
+    import scipy.sparse as sp
+    n = int(g[f"{tag}_n"])
+    m = sp.coo_matrix((g[f"{tag}_prepared_val"], (g[f"{tag}_prepared_row"], g[f"{tag}_prepared_col"])), shape=(n, n)).toarray()
+    miss = np.ones(n, dtype=bool)
+    miss[g[f"{tag}_det"]] = False
+    pearson, pu, pz, md_bp = g[f"{tag}_cfg"]
+    return m, miss, g[f"{tag}_kernel"], float(pearson), pu / 100, pz / 100, int(g[f"{tag}_max_dist"]), md_bp == 0
+
+
+@pytest.mark.parametrize("tag", ["d2_59", "d1_37"])
+def test_oracles_match_reference_nonsquare_templates(golden, tag):
+    """Non-square templates in full mode (reference detection.py:287-345): the padding is (kw rows, kh columns), the
+    coordinate shift (kh, kw), so windows, scores and the row of 1-D patterns are offset by kh - kw.  The oracle
+    pipeline (pearson_oracle + foci_oracle) reproduces the reference's tables and windows."""
+    from oracle import foci_oracle
+    g = golden("nonsquare")
+    m, miss, kern, pearson, missing_tol, zero_tol, max_dist, diag_only = _nonsquare_case(g, tag)
+    n = m.shape[0]
+    pred = orc.framed_missing_predicate((n, n), kern.shape, miss, miss, True, max_dist)
+    corr, _ = orc.normxcorr2_oracle(m, kern, max_dist=max_dist, sym_upper=True, full=True, missing=pred, missing_tol=missing_tol)
+    ii, jj = np.indices((n, n))
+    trimmed = np.where((jj - ii >= 0) & (jj - ii <= max_dist), np.nan_to_num(corr), 0.0)
+    tab, wins = foci_oracle.detect_table(m, trimmed, miss, miss, kern.shape, pearson, zero_tol, missing_tol,
+                                         diag_only=diag_only, return_windows=True)
+    ref = g[f"{tag}_table"]
+    assert ref.shape[0] > 20 and tab.shape[0] == ref.shape[0]
+    assert np.array_equal(tab[:, :2], ref[:, :2])
+    assert np.abs(tab[:, 2] - ref[:, 2]).max() < 1e-12
+    assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12)
+    kh, kw = (kern.shape[0] - 1) // 2, (kern.shape[1] - 1) // 2
+    if diag_only:
+        assert np.array_equal(ref[:, 0], ref[:, 1] + kw - kh)          # the quirk is in the fixture
+
+
+@pytest.mark.parametrize("tag", ["inter59", "inter95"])
+def test_oracles_match_reference_nonsquare_inter(golden, tag):
+    import scipy.sparse as sp
+    from oracle import foci_oracle
+    g = golden("nonsquare")
+    shape = tuple(int(x) for x in g["inter_shape"])
+    m = sp.coo_matrix((g["inter_prepared_val"], (g["inter_prepared_row"], g["inter_prepared_col"])), shape=shape).toarray()
+    mr, mc = np.ones(shape[0], bool), np.ones(shape[1], bool)
+    mr[g["inter_det_rows"]] = False
+    mc[g["inter_det_cols"]] = False
+    kern = g[f"{tag}_kernel"]
+    pearson, pu, pz, _ = g["inter_cfg"]
+    pred = orc.framed_missing_predicate(shape, kern.shape, mr, mc, False, None)
+    corr, _ = orc.normxcorr2_oracle(m, kern, max_dist=None, sym_upper=False, full=True, missing=pred, missing_tol=pu / 100)
+    tab, wins = foci_oracle.detect_table(m, np.nan_to_num(corr), mr, mc, kern.shape, float(pearson), pz / 100, pu / 100,
+                                         inter=True, return_windows=True)
+    ref = g[f"{tag}_table"]
+    assert ref.shape[0] > 5 and tab.shape[0] == ref.shape[0]
+    assert np.array_equal(tab[:, :2], ref[:, :2])
+    assert np.abs(tab[:, 2] - ref[:, 2]).max() < 1e-12
+    assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12)

@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=4096, help="c2 only: side of the dense map (default 4096)")
+    ap.add_argument("--plan", action="store_true",
+                    help="no GPU work: print the block -> rank assignment of the sharded C4 genome for --gpus N and exit")
     return ap.parse_args()
 
 
@@ -140,6 +142,125 @@ class Workload:
             return
         self.engine.run_normxcorr2(self.dev, self.sig, self.shape, self.kspec, self.out,
                                    precision=self.precision, **self.kwargs)
+
+
+# cs_last_kernel() ids (include/chromosight_hip.h) -> what served the launch
+KERNELS = {
+    0: ("none", ""),
+    1: ("corr_generic_kernel", "runtime-size LDS-tiled kernel, float32 / float64 FMA"),
+    2: ("corr_stream_kernel", "packed FP32 FMA streaming kernel (v_pk_fma_f32); the loops template is vertically symmetric "
+                              "and shares each row product between two template rows (169 instead of 289 packed products "
+                              "per column pair)"),
+    3: ("corr_mfma_kernel", "first general matrix-core kernel (masks as a 0/1 plane), float16 head/tail operands"),
+    4: ("corr_mfma_dense_kernel<VEC4,false,false>",
+        "v_mfma_f32_16x16x32_f16: signal and template split into float16 head + tail (3 products per term, float32 "
+        "accumulation = float32-equivalent coefficients, parity 1e-5), template rows as 32x16 Toeplitz operands (17 of 32 k "
+        "useful), box sums by two separable MFMA passes: 252 MFMAs per 16x64 output pixels = 4032 executed flop/pixel for "
+        "714 algorithmic"),
+    5: ("corr_mfma_dense_kernel<true,true,RSYM>",
+        "masked matrix-core tile kernel: the same float16-pair contraction, per-bin missing masks factorised into per-row / "
+        "per-column template sums + correction records (mask_prep_kernel), cross term on the matrix cores"),
+    6: ("corr_sep_kernel", "separable evaluation of exactly rank-1 templates"),
+}
+MFMA_KERNELS = (3, 4, 5)
+
+
+def prewarm(step, sync, seconds=0.4):
+    """Untimed: run the step until the clocks have ramped (a 0.1 ms step timed right after an idle period runs
+    5-10 % slow: at 20 timed steps the ramp would be inside the timed region)."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(16):
+            step()
+        sync()
+
+
+def time_steps(dev, step, sync, steps, warmup, dist=None, local_rank=0):
+    """W untimed warm-up steps, then exactly `steps` steps between two HIP events on the launch stream and two full
+    synchronisations (+ barriers with N > 1).  Returns (wall seconds, kernel ms per step)."""
+    for _ in range(warmup):
+        step()
+    sync()
+    ev0, ev1 = dev.new_event(), dev.new_event()
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    sync()
+    t0 = time.perf_counter()
+    dev.record(ev0)
+    for _ in range(steps):
+        step()
+    dev.record(ev1)
+    sync()
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    elapsed = time.perf_counter() - t0
+    return elapsed, dev.elapsed_ms(ev0, ev1) / steps
+
+
+def roofline_of(wl, kernel_ms, kernel_id, precision, traffic=None, traffic_note=None):
+    """`roofline` object of one workload: algorithmic flops (714 per pixel at 17 x 17) per launch over the
+    launch's average duration, against the FP32 peak -- the roof of a float32-exact evaluation, vector FMA and f32-input
+    MFMA alike -- plus, when a matrix-core kernel served it, the flops it EXECUTES on float16 operands against the dense
+    float16 MFMA peak, and the bytes view."""
+    name, how = KERNELS.get(kernel_id, ("?", ""))
+    flop = FLOP_PER_PIXEL_17 * wl.pixels
+    achieved_tf = flop / (kernel_ms * 1e-3) / 1e12
+    peak_tf = FP64_PEAK_TFLOPS if precision == "f64" else FP32_PEAK_TFLOPS
+    achieved_gbs = wl.bytes_per_pixel * wl.pixels / (kernel_ms * 1e-3) / 1e9
+    roof = {
+        "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
+        "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic, "traffic_note": traffic_note,
+        "kernel": name, "kernel_id": kernel_id,
+        "peak_kind": ("FP32: dense f32 MFMA = vector FMA peak, the roof of a float32-exact evaluation of 714 flop/pixel; "
+                      "the flops actually executed are priced under `executed`" if precision == "f32" else "FP64 vector peak"),
+        "note": f"714 flop/pixel (SURVEY 8d) x {wl.pixels} pixels per launch / {kernel_ms:.4f} ms (HIP events on the launch "
+                f"stream); the arithmetic roof binds before HBM at 17x17 (89 flop/B).  Served by {name}: {how}",
+        "hbm": {"achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "bytes_per_pixel": round(wl.bytes_per_pixel, 2)},
+    }
+    if kernel_id in MFMA_KERNELS and precision == "f32":
+        executed_tf = achieved_tf * 4032.0 / FLOP_PER_PIXEL_17
+        roof["executed"] = {"pipe": "mfma_f16", "achieved": round(executed_tf, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(executed_tf / F16_MFMA_PEAK_TFLOPS, 4), "flop_per_pixel": 4032}
+    return roof
+
+
+def cpu_baseline_band(budget_s=8.0, rows=8192):
+    """CPU baseline of the north-star workload (C4': banded, masked, full mode): oracle/oracle.c's band entry point on a
+    block of `rows` bins from the same generator (same band, same 2 % missing bins), all host cores, and one pass of a
+    smaller window on ONE core -- the reference parallelises over sub-matrices only (cli/chromosight.py:748-752), so on
+    a single 200 000-bin block it has one core whatever --threads says."""
+    from oracle import c_oracle
+    from tools.synthetic_genome import band_workload
+    band, band_w, miss, n, max_dist = band_workload("c4p", 0, n=rows)
+    band = band.astype(np.float64)
+    out_w = max_dist + 1
+    threads = c_oracle.max_threads()
+    kern = loops_kernel()
+    args = dict(max_dist=max_dist, sym_upper=True, full=True, miss_row=miss, miss_col=miss, missing_tol=0.5)
+    c_oracle.normxcorr2_band(band, n, 0, band_w, kern, 0, 64, 0, out_w, n_threads=threads, **args)
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.normxcorr2_band(band, n, 0, band_w, kern, 0, n, 0, out_w, n_threads=threads, **args)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or passes >= 100:
+            break
+    t1 = time.perf_counter()
+    one_rows = 256
+    c_oracle.normxcorr2_band(band, n, 0, band_w, kern, 1024, 1024 + one_rows, 0, out_w, n_threads=1, **args)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": round(passes * n * out_w / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+        "single_core": {"value": round(one_rows * out_w / dt1 / 1e6, 3), "unit": "Mpixel/s", "cores": 1,
+                        "note": "what a single sub-matrix can use in the reference (one process per sub-matrix)"},
+        "reference_python": {"value": 0.27, "unit": "Mpixel/s", "cores": 1,
+                             "source": "BASELINE.md section 3: the reference's banded full-mode normxcorr2 on the survey "
+                                       "host (0.25-0.29 Mpixel/s), not re-run here: the reference cannot travel"},
+        "sample": f"{passes} passes over a {n}-bin block of the C4' generator (band 0..{max_dist + 17}, 2 % missing bins, "
+                  f"{n * out_w / 1e6:.1f} Mpixel each), float64 C restatement oracle/oracle.c (band entry), OpenMP x{threads}, "
+                  f"{dt:.1f} s; single core: {one_rows} rows, {dt1:.1f} s",
+    }
 
 
 def cpu_baseline(workload, budget_s=12.0):
@@ -388,6 +509,8 @@ def spawn_ranks(n_gpus):
 
 def main():
     args = parse()
+    if args.plan:
+        return print_plan(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -432,27 +555,38 @@ def main():
             torch.cuda.synchronize(local_rank)
         dev.sync()
 
-    for _ in range(args.warmup):
-        wl.step()
-    full_sync()
-    ev0, ev1 = dev.new_event(), dev.new_event()
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-    full_sync()
-    t0 = time.perf_counter()
-    dev.record(ev0)
-    for _ in range(args.steps):
-        wl.step()
-    dev.record(ev1)
-    full_sync()
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-    elapsed = time.perf_counter() - t0
-    kernel_ms = dev.elapsed_ms(ev0, ev1) / args.steps   # HIP events on the launch stream
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    prewarm(wl.step, full_sync)
+    elapsed, kernel_ms = time_steps(dev, wl.step, full_sync, args.steps, args.warmup, dist, local_rank)
+    kernel_id = int(dev.lib.cs_last_kernel(dev.ctx))
+    elapsed = reduce_max(elapsed)
+
+    # the north-star configuration next to the headline one, kernel only, at every N (each rank its own 200 000-bin
+    # block: weak scaling like `value`): C4' = one 200 000-bin block, band to 1000 bins, masks, full mode
+    c4p = None
+    if args.workload == "c2" and args.size == 4096 and not args.no_cpu_baseline:
+        try:
+            del wl.out_buf
+            w4 = Workload("c4p", dev, rank, args.precision)
+            prewarm(w4.step, full_sync, 0.2)
+            steps4 = 20
+            el4, ms4 = time_steps(dev, w4.step, full_sync, steps4, 3, dist, local_rank)
+            id4 = int(dev.lib.cs_last_kernel(dev.ctx))
+            el4 = reduce_max(el4)
+            t4, t4_note = pmc_traffic(argparse.Namespace(workload="c4p", size=None, precision=args.precision), w4)
+            c4p = {"value": round(w4.pixels * steps4 * world / el4 / 1e6, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": steps4,
+                   "warmup": 3, "ms_per_step": round(el4 / steps4 * 1e3, 4), "kernel_ms": round(ms4, 4), "scaling": "weak",
+                   "workload": w4.desc, "pixels_per_step_per_gpu": w4.pixels,
+                   "roofline": roofline_of(w4, ms4, id4, args.precision, t4, t4_note)}
+            del w4
+        except Exception as exc:
+            c4p = {"error": repr(exc)}
 
     genome = None
     if not args.no_cpu_baseline and args.workload == "c2":
@@ -466,28 +600,8 @@ def main():
     if rank == 0:
         total_pixels = wl.pixels * args.steps * world
         value = total_pixels / elapsed / 1e6
-        flop = FLOP_PER_PIXEL_17 * wl.pixels
-        achieved_tf = flop / (kernel_ms * 1e-3) / 1e12
-        peak_tf = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
-        achieved_gbs = wl.bytes_per_pixel * wl.pixels / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic(args, wl)
-        # which float32 kernel served the launch (cs_api.cpp mfma_wanted): unmasked dense maps run on the
-        # matrix cores with float16 head/tail operands, everything else on the packed-FMA streaming kernel
-        on_mfma = (args.precision == "f32" and not os.environ.get("CHROMOSIGHT_HIP_NO_MFMA")
-                   and (args.workload == "c2" or os.environ.get("CHROMOSIGHT_HIP_MFMA") == "1"))
-        if on_mfma:
-            kernel_note = ("kernel: corr_mfma_dense_kernel (v_mfma_f32_16x16x32_f16): signal and template split into "
-                           "float16 head + tail (3 products per term, float32 accumulation = float32-equivalent "
-                           "coefficients, parity 1e-5), template rows as 32x16 Toeplitz operands (17 of 32 k useful), "
-                           "box sums by two separable MFMA passes: 252 MFMAs per 16x64 output pixels = 4032 executed "
-                           "flop/pixel for 714 algorithmic.  `peak` stays the FP32 peak (157.3 TFLOP/s, vector FMA = "
-                           "f32 MFMA): the roof of a float32-exact evaluation; `mfma_f16` prices the executed matrix "
-                           "flops against the dense float16 MFMA peak")
-        else:
-            kernel_note = ("kernel: corr_stream_kernel (packed FP32 FMA).  Algorithmic flops: the loops template is "
-                           "vertically symmetric and its kernel shares each row product between two template rows (169 "
-                           "instead of 289 packed products per column pair; CHROMOSIGHT_HIP_NO_SYMMETRY=1 runs the "
-                           "unfolded kernel)")
+        roof = roofline_of(wl, kernel_ms, kernel_id, args.precision, traffic, traffic_note)
         out = {
             "metric": "Mpixels/s normxcorr2 (17x17 loops kernel)",
             "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
@@ -496,25 +610,12 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": wl.desc, "pixels_per_step_per_gpu": wl.pixels,
                        "parallelism": f"{world} independent sub-matrices, one per GPU"},
-            "roofline": {
-                "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic, "traffic_note": traffic_note,
-                "note": f"714 flop/pixel (SURVEY 8d) x {wl.pixels} pixels per launch / {kernel_ms:.4f} ms "
-                        "(HIP events); the FP32 FMA roof binds before HBM at 17x17; peak = dense FP32 "
-                        "matrix/vector peak.  " + kernel_note,
-            },
-            "roofline_hbm": {
-                "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                "bytes_per_pixel": round(wl.bytes_per_pixel, 2),
-            },
+            "roofline": roof,
+            "roofline_hbm": dict(roof["hbm"], bound="hbm"),
             "kernel_ms": round(kernel_ms, 4),
         }
-        if on_mfma:
-            executed_tf = achieved_tf * 4032.0 / FLOP_PER_PIXEL_17
-            out["roofline"]["mfma_f16"] = {"executed": round(executed_tf, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": round(executed_tf / F16_MFMA_PEAK_TFLOPS, 4),
-                                           "executed_flop_per_pixel": 4032}
+        if c4p is not None:
+            out["north_star_c4p"] = c4p
         if genome is not None:
             out["sharded_genome"] = genome
         if not args.no_cpu_baseline and world == 1:     # reported extras: rank 0 at N = 1 only
@@ -530,9 +631,35 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(wl)
             except Exception as exc:  # the baseline is a reported extra, never the measured path
                 out["cpu_baseline"] = {"error": repr(exc)}
+            if isinstance(c4p, dict) and "error" not in c4p:
+                try:
+                    c4p["cpu_baseline"] = cpu_baseline_band()
+                    cb = c4p["cpu_baseline"]
+                    c4p["vs_cpu"] = {"all_cores": round(c4p["value"] / cb["value"], 1),
+                                     "one_core": round(c4p["value"] / cb["single_core"]["value"], 1),
+                                     "note": "north star: >= 50x the reference's --threads=<cores> CPU throughput on this block"}
+                except Exception as exc:
+                    c4p["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def print_plan(args):
+    """--plan: what `--gpus N` will do with the sharded C4 genome, without touching a GPU: the LPT assignment
+    (parallel.assign_blocks) and the scanned pixels per rank, so that the first multi-GPU run can be checked from its log."""
+    from chromosight_amd import parallel
+    from tools.synthetic_genome import genome_sizes
+    sizes = [int(n) for n in genome_sizes(200_000)]
+    max_dist = 1000
+    costs = [parallel.block_cost((n, n), max_dist, False) for n in sizes]
+    owned = parallel.assign_blocks(costs, args.gpus)
+    per_rank = [int(sum(costs[i] for i in o)) for o in owned]
+    print(json.dumps({"plan": "C4 genome, 23 blocks, LPT by scanned pixels", "n_gpus": args.gpus, "blocks": sizes,
+                      "owned": owned, "loop_pixels_per_rank": per_rank, "total": int(sum(costs)),
+                      "balance": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 3),
+                      "speedup_bound": round(sum(per_rank) / max(per_rank), 2),
+                      "exchange": "one record exchange per detect_genome call (count + padded all-gather, RCCL)"}))
 
 
 if __name__ == "__main__":

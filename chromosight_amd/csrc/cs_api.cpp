@@ -45,6 +45,8 @@ struct cs_ctx {
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
+    double cand_margin = 0.0;   // > 0 while find_candidates runs its float32 map: build_args turns on candidate mode
+    double cand_thr = 0.0;
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
     // flags), per arithmetic type: a detect run calls with the same template thousands of times
     struct TemplateCache {
@@ -799,6 +801,10 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.ks.den2_min = (TC)(p->denom_eps * p->denom_eps * st.n * st.n);
     A.ks.zk_possible = tc.zk_possible;
     A.ks.snap_possible = tc.snap_possible;
+    // candidate mode of the float32 kernels (find_candidates below; cs_device.h cand_screen_*): windows conditioned at
+    // least 8 n 2^-24 / margin have a float32 error below margin / 4 (2 gamma / conditioning, gamma = n 2^-24)
+    A.ks.cand_cmin = (sizeof(TC) == 4 && ctx->cand_margin > 0) ? (TC)std::min(0.5, 8.0 * st.n * 0x1p-24 / ctx->cand_margin) : (TC)0;
+    A.ks.cand_thr = (TC)ctx->cand_thr;
     A.xcorr_only = 0;
     A.w_sym = sym ? 1 : 0;
     A.w_rank1 = tc.rank1 ? 1 : 0;
@@ -1497,10 +1503,17 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
     rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
     if (rc) return rc;
     map.d_ptr = ctx->d_map;
+    // float32 maps are computed in candidate mode (cs_device.h cand_screen_*): a pixel keeps its value only if that is
+    // below pearson - margin on a window conditioned well enough for the float32 error to stay under margin / 4; every
+    // other pixel holds 2.0 and is re-evaluated.  float64 maps hold the coefficient.
+    const double margin = std::max(fp->rescore_margin, 1e-4);
+    ctx->cand_margin = f64 ? 0.0 : margin;
+    ctx->cand_thr = fp->pearson - margin;
     rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
+    ctx->cand_margin = 0.0;
     if (rc) return rc;
-    // ---- candidates: thresholded compaction (with the re-scoring margin on float32 maps)
-    const double thr = f64 ? fp->pearson : fp->pearson - fp->rescore_margin;
+    // ---- candidates: thresholded compaction
+    const double thr = f64 ? fp->pearson : fp->pearson - margin;
     size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
     while (true) {
         if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);

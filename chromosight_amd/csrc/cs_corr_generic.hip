@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(const CorrArgs<TC> A)
             if (cs_abs(r) < A.ks.thr) r = TC(0);
         } else {
             r = pearson_from_sums<TC>(cs_[i], s1[i], s2[i], nm[i], ka[i], kb[i], A.ks, masked, &nobs);
+            if constexpr (sizeof(TC) == 4) r = cand_upper_from_sums(r, cs_[i], s1[i], s2[i], nm[i], ka[i], kb[i], A.ks, masked);
         }
         store_pixel(A, oi, oj, r, nobs);
     }

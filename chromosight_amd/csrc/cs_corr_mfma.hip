@@ -38,6 +38,8 @@
 namespace cs {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float cand_range_guard(float r, float s2, float unscale, const KernelStats<float>& K);
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -342,10 +344,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_kernel(const CorrArgs<float>
             } else if constexpr (MASKED) {
                 const float nm = NM[c][v];
                 const float ka = KA[c][v] * E.unscale[1], kb = KB[c][v] * E.unscale[2];
-                r = pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks);
+                r = cand_range_guard(pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks), s2, unscale, A.ks);
                 nobs = A.ks.n - nm;
             } else {
-                r = pearson_nomask_lean(cs, s1, s2, A.ks);
+                r = cand_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
             }
             store_pixel(A, i, j, r, nobs);
         }
@@ -466,6 +468,16 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Candidate mode (cs_device.h: cand_screen_*): the float16 pairs carry 21-22 bits of every pixel only down to 2^-10 of
+// the tile's largest value (the tails leave the normal float16 range below that) and the squares down to 2^-6 of it,
+// so a window whose mean square is below 2^-18 of the largest square of its tile is outside the error model of the
+// bound and takes the sentinel.  `unscale` = 2^-ex with the tile's largest |x| in [64, 128) / 2^ex.
+__device__ __forceinline__ float cand_range_guard(float r, float s2, float unscale, const KernelStats<float>& K)
+{
+    if (K.cand_cmin > 0.0f) r = ((int)(s2 > 0.0f) & (int)(s2 < K.n * (unscale * unscale) * 0.0625f)) ? 2.0f : r;
+    return r;
+}
+
 // Out-of-line pieces of the REG epilogue: 16 inlined copies of each made the kernel 100 KB of code.
 __device__ __attribute__((noinline)) float masked_coefficient_rare(float cs, float s1, float s2, float nm, float ka, float kb,
                                                                    const KernelStats<float>& K)
@@ -529,7 +541,10 @@ __device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, 
 
 // RSYM (REG only): 17 x 17 template whose rows mirror (row s == row 16 - s): 9 head fragments in registers
 // instead of 17 -- the masked epilogue needs the 32 registers.
-template <bool VEC4, bool REG, bool RSYM = false>
+// CAND (REG instances only): candidate mode of cs_detect_foci compiled in (cs_device.h cand_screen_*); the plain REG
+// instances compile it out -- the masked tile sits at 256 registers and seven more spilled ones cost 8 % of C4'.
+// The unmasked instances decide at run time (they have room).
+template <bool VEC4, bool REG, bool RSYM = false, bool CAND = false>
 __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDenseArgs A)
 {
 
@@ -653,6 +668,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 KS.ksum = sp->ksum; KS.k2sum = sp->k2sum; KS.thr = sp->thr; KS.eps = sp->eps; KS.cut = sp->cut;
                 KS.thr_n = sp->thr_n; KS.nkvar = sp->nkvar; KS.eps2 = sp->eps2; KS.den2_min = sp->den2_min;
                 KS.zk_possible = sp->zk_possible; KS.snap_possible = sp->snap_possible;
+                KS.cand_cmin = CAND ? sp->cand_cmin : 0.0f;
+                KS.cand_thr = CAND ? sp->cand_thr : 0.0f;
             }
             const float* colb = reinterpret_cast<const float*>(smem + MFD_COL) + slot * 3 * 64;
             const float nr = hdr[0], ra = hdr[1], rb = hdr[2];
@@ -797,7 +814,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                         const float s1 = S1[c][v] * unscale;
                         const float s2 = (S2[c][v] * u_s2) * unscale;
                         bool rare;
-                        float val = pearson_masked_core(cs, s1, s2, nm, ka, kb, KS, rare);
+                        float val = pearson_masked_core<CAND ? 1 : 0>(cs, s1, s2, nm, ka, kb, KS, rare);
+                        if constexpr (CAND) val = cand_range_guard(val, s2, unscale, KS);
                         if (A.dbg & 4096) {
                             val = cs + s1 + s2 + nm + ka + kb;
                             rare = false;
@@ -890,7 +908,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 const float s1 = S1[c][v] * unscale;
                 const float s2 = (S2[c][v] * u_s2) * unscale;
                 rv[c][v] = A.xcorr_only ? (fabsf(cs) < A.ks.thr ? 0.0f : cs)            // detection.py:716-722
-                                        : (A.dbg & 32) ? cs + s1 + s2 : pearson_nomask_lean(cs, s1, s2, A.ks);
+                                        : (A.dbg & 32) ? cs + s1 + s2
+                                                       : cand_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
             }
         }
         if (A.dbg & 1) {
@@ -1377,13 +1396,15 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             }
             *dense_path = 2;
             const bool rsym = A.w_sym && A.km == 17 && A.kn == 17 && !getenv("CHROMOSIGHT_HIP_MFMA_NORSYM");
-            const void* kr = rsym ? (const void*)corr_mfma_dense_kernel<true, true, true> : (const void*)corr_mfma_dense_kernel<true, true, false>;
-            hipError_t e3 = allow_big_lds(kr);
+            const bool cand = A.ks.cand_cmin > 0.0f;
+            typedef void (*reg_kernel_t)(const MfmaDenseArgs);
+            const reg_kernel_t kr = rsym ? (cand ? corr_mfma_dense_kernel<true, true, true, true> : corr_mfma_dense_kernel<true, true, true, false>)
+                                         : (cand ? corr_mfma_dense_kernel<true, true, false, true> : corr_mfma_dense_kernel<true, true, false, false>);
+            hipError_t e3 = allow_big_lds((const void*)kr);
             if (e3 != hipSuccess) return (int)e3;
             const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
             const int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
-            if (rsym) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, true, true>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
-            else hipLaunchKernelGGL((corr_mfma_dense_kernel<true, true, false>), dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
             return (int)hipGetLastError();
         }
         // 16-byte pieces: the tile's first staged column (64 bx - kw) and the row length must be multiples

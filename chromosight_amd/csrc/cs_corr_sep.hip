@@ -188,6 +188,7 @@ __global__ __launch_bounds__(512) void corr_sep_kernel(const CorrArgs<float> A)
             const float ka = fmaf(-mu, nm[i], b1[i]);
             const float kb = fmaf(mu * mu, nm[i], fmaf(-2.0f * mu, b1[i], b2[i]));
             r = pearson_from_sums<float>(cs_, s1[i], s2[i], nm[i], ka, kb, A.ks, MASKED, &nobs);
+            r = cand_upper_from_sums(r, cs_, s1[i], s2[i], nm[i], ka, kb, A.ks, MASKED);
         }
         store_pixel(A, oi, oj, r, nobs);
     }

@@ -47,6 +47,10 @@ struct KernelStats {
     T den2_min; // eps^2 * n^2: (s2 n - s1^2) kvar below it <=> unmasked denominator below eps
     int zk_possible;    // a mask-weighted template sum can fall under thr (some |K'| or K'^2 entry is tiny)
     int snap_possible;  // the template variance over the present pixels can degenerate (few distinct values)
+    // cand_cmin > 0: candidate mode of the float32 kernels (cs_detect_foci / cs_candidates, see cand_screen_* below): a
+    // pixel keeps its value only if it is below cand_thr on a window conditioned at least cand_cmin, else it stores 2.0
+    T cand_cmin;
+    T cand_thr;
 };
 
 // Arguments of the tile kernels.  Weights live in a small device buffer:
@@ -333,7 +337,55 @@ __device__ __forceinline__ float pearson_nomask_f32(float cs, float s1, float s2
 __device__ __forceinline__ float pearson_masked_f32(float cs, float s1, float s2, float nm, float ka, float kb,
                                                     const KernelStats<float>& K);
 
-// branch-free cores: coefficient by the one-rsq formula plus "this pixel is near a zeroing threshold"
+// ---- candidate mode (KernelStats::cand_cmin > 0) ----------------------------------------------------------------
+// cs_detect_foci thresholds a float32 map and re-evaluates the survivors in float64, so the float32 pass must never
+// lose a pixel whose exact coefficient reaches the threshold.  A margin below the threshold alone cannot promise that:
+// the float32 error of r = cs / sqrt(A B) grows like 1 / conditioning, where the conditioning of a window is
+// A / (np s2) -- its variance relative to its mean square -- and that of the template over the present pixels
+// B / (np X).  With sums accurate to gamma (gamma <= n 2^-24 for an n-term float32 chain; the float16-pair operands of
+// the matrix-core kernels stay inside that, cs_corr_mfma.hip cand_range_guard) the first-order bound is
+// |r32 - r64| <= 2 gamma / min(condA, condB).  In candidate mode a pixel therefore keeps its float32 value only when
+//   * both conditionings are at least cand_cmin = 8 n 2^-24 / margin, i.e. the error is below margin / 4, AND
+//   * that value is below cand_thr = threshold - margin, AND
+//   * none of its sums is within 0.1 % of one of the reference's zeroing thresholds (the exact sums may fall on the
+//     other side: detection.py:1004-1018, 1051-1064), its denominator is clear of the eps cut (:1088-1101) and its
+//     template variance was not snapped to zero;
+// every other pixel stores the sentinel 2.0 and becomes a candidate (the compaction keeps values >= cand_thr).  Windows
+// without signal (s2 == 0) and windows with too few present pixels (np < cut, exact integer arithmetic) are exactly 0
+// in both precisions and stay 0.  No extra transcendental, a handful of compares per pixel.
+constexpr float kCandGuard = 1.001f;
+
+__device__ __forceinline__ float cand_screen_nomask(float r, float cs, float s1, float s2, float A, float den2,
+                                                    const KernelStats<float>& K)
+{
+    const float g = K.thr_n * kCandGuard;
+    const bool keep = (int)(r < K.cand_thr) & (int)(A > s2 * K.n * K.cand_cmin) & (int)(den2 >= 16.0f * K.den2_min) &
+                      (int)(fabsf(s1) >= g) & (int)(s2 >= g) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= g);
+    const float out = keep ? r : 2.0f;
+    return (s2 > 0.0f) ? out : 0.0f;
+}
+
+__device__ __forceinline__ float cand_screen_masked(float r, float cs, float s1, float s2, float nm, float ka, float kb, float np,
+                                                    float A, float B, float den2, const KernelStats<float>& K)
+{
+    const float c = np * K.cand_cmin;
+    const float np2 = np * np;
+    const float g = K.thr_n * kCandGuard;
+    bool keep = (int)(r < K.cand_thr) & (int)(A > s2 * c) & (int)(B > (K.nkvar - kb) * c) & (int)(den2 >= 16.0f * K.eps2 * np2 * np2) &
+                (int)(fabsf(s1) >= g) & (int)(s2 >= g) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= g);
+    if (K.zk_possible) {
+        const float km_ = fmaf(K.kmean, nm, ka);
+        const float k2m = kb + 2.0f * K.kmean * ka + K.kmean * K.kmean * nm;
+        keep &= (nm < 0.5f) || ((fabsf(km_) >= K.thr * kCandGuard) && (fabsf(k2m) >= K.thr * kCandGuard));
+    }
+    const float out = keep ? r : 2.0f;
+    return ((int)(s2 > 0.0f) & (int)(np >= K.cut)) ? out : 0.0f;
+}
+
+// branch-free cores: coefficient by the one-rsq formula plus "this pixel is near a zeroing threshold".
+// CAND: candidate mode decided at run time from K.cand_cmin (-1, default), compiled out (0) or compiled in (1) -- the masked
+// matrix-core tile kernel sits at its register budget and instantiates both forms
+template <int CAND = -1>
 __device__ __forceinline__ float pearson_nomask_core(float cs, float s1, float s2, const KernelStats<float>& K, bool& rare)
 {
     const float A = fmaf(s2, K.n, -s1 * s1);
@@ -342,9 +394,14 @@ __device__ __forceinline__ float pearson_nomask_core(float cs, float s1, float s
     r = (den2 >= K.den2_min) ? r : 0.0f;                 // denominator under eps, NaN -> 0
     r = __builtin_amdgcn_fmed3f(r, -1.0f, 1.0f);
     rare = !((int)(fabsf(s1) >= K.thr_n) & (int)(s2 >= K.thr_n) & (int)(fabsf(fmaf(K.kmean, s1, cs)) >= K.thr_n));
+    if (CAND > 0 || (CAND < 0 && K.cand_cmin > 0.0f)) {  // wave-uniform
+        r = cand_screen_nomask(r, cs, s1, s2, A, den2, K);
+        rare = false;                                    // near-threshold pixels already carry the sentinel
+    }
     return r;
 }
 
+template <int CAND = -1>
 __device__ __forceinline__ float pearson_masked_core(float cs, float s1, float s2, float nm, float ka, float kb,
                                                      const KernelStats<float>& K, bool& rare)
 {
@@ -365,7 +422,20 @@ __device__ __forceinline__ float pearson_masked_core(float cs, float s1, float s
         normal &= (nm < 0.5f) || ((fabsf(km_) >= K.thr) && (fabsf(k2m) >= K.thr));
     }
     rare = !normal;
+    if (CAND > 0 || (CAND < 0 && K.cand_cmin > 0.0f)) {  // wave-uniform
+        r = cand_screen_masked(r, cs, s1, s2, nm, ka, kb, np, A, B, den2, K);
+        rare = false;
+    }
     return r;
+}
+
+// the same screen for the kernels that evaluate pearson_from_sums<float> directly (runtime-size and separable)
+__device__ __forceinline__ float cand_upper_from_sums(float r, float cs, float s1, float s2, float nm, float ka, float kb,
+                                                      const KernelStats<float>& K, bool masked)
+{
+    if (!(K.cand_cmin > 0.0f)) return r;
+    bool rare;
+    return masked ? pearson_masked_core(cs, s1, s2, nm, ka, kb, K, rare) : pearson_nomask_core(cs, s1, s2, K, rare);
 }
 
 __device__ __forceinline__ float pearson_nomask_lean(float cs, float s1, float s2, const KernelStats<float>& K)

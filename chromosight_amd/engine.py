@@ -124,8 +124,19 @@ def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist
     return d_r.download(stream), d_n.download(stream)
 
 
-# margin below the Pearson threshold within which float32 scores are re-evaluated in float64
-RESCORE_MARGIN = 2e-3
+# Detect mode on float32 maps (csrc/cs_device.h cand_screen_*): a pixel is re-evaluated in float64 on the device when its
+# float32 coefficient is within RESCORE_MARGIN of the threshold, OR when its window is too ill-conditioned for the float32
+# error to stay below a quarter of that margin (variance of the window relative to its mean square, or of the template over
+# the present pixels, below 8 n 2^-24 / margin = 2.8e-3 for a 17 x 17 template), OR when one of its sums sits next to one of
+# the reference's zeroing thresholds; the exact values are then thresholded.  The candidate set is a superset of the pixels
+# whose exact coefficient passes whatever the data look like (tests/test_gpu_margin.py).
+RESCORE_MARGIN = 0.05
+# below this threshold most pixels of a float32 map would be candidates: such maps are computed in float64
+LOW_PEARSON_F64 = 0.1
+
+
+def rescore_margin(pearson):
+    return min(RESCORE_MARGIN, 0.25 * float(pearson))
 
 
 def _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, mask, missing_tol, code,
@@ -156,13 +167,11 @@ def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter,
                     want_windows=True, min_size=2, stream=None):
     """detect mode of one sub-matrix x one template on the device (cs_detect_foci): records of the
     foci in the reference's order (numpy structured array, _lib.FOCUS_DTYPE) and their windows."""
-    # a threshold within a few margins of zero would make every stored pixel of a float32 map a
-    # candidate for re-scoring: compute that map in float64 straight away (ADVICE r1)
-    if float(pearson) <= 4 * RESCORE_MARGIN:
+    if float(pearson) <= LOW_PEARSON_F64:
         precision = "f64"
     params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, None, missing_tol,
                           compute_code(precision))
-    fp = CsFociParams(float(pearson), RESCORE_MARGIN, int(min_size), int(bool(diag_only)), int(lo_diag), int(hi_diag),
+    fp = CsFociParams(float(pearson), rescore_margin(pearson), int(min_size), int(bool(diag_only)), int(lo_diag), int(hi_diag),
                       int(bool(inter)), int(bool(want_windows)))
     kk = kspec.km * kspec.kn
     cap = 4096
@@ -195,7 +204,7 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
         _corr_params(shapes[b], kspec, True, True, max_dists[b], MASK_BINS, miss_rows[b], miss_cols[b], None, missing_tol, CS_F64)
         for b in range(n_blocks)])
     fp_arr = (CsFociParams * n_blocks)(*[
-        CsFociParams(float(pearson), RESCORE_MARGIN, int(min_size), int(bool(diag_only)), 0, int(hi_diags[b]), int(bool(inter)),
+        CsFociParams(float(pearson), rescore_margin(pearson), int(min_size), int(bool(diag_only)), 0, int(hi_diags[b]), int(bool(inter)),
                      int(bool(want_windows))) for b in range(n_blocks)])
     counts = (C.c_int64 * n_blocks)()
     kk = kspec.km * kspec.kn
@@ -234,11 +243,11 @@ def run_candidates(dev, sig, shape, kspec, row_window, *, pearson, lo_diag, hi_d
     """First half of detect mode on a row window of a sub-matrix (cs_candidates): coordinates and
     float64 coefficients of the pixels of rows row_window[0] <= i < row_window[1] that pass the
     threshold, row-major.  `sig` holds those rows and the template's halo (CsMatrix.row0)."""
-    if float(pearson) <= 4 * RESCORE_MARGIN:
+    if float(pearson) <= LOW_PEARSON_F64:
         precision = "f64"
     params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, None, missing_tol,
                           compute_code(precision), row_window)
-    fp = CsFociParams(float(pearson), RESCORE_MARGIN, 1, 0, int(lo_diag), int(hi_diag), int(bool(inter)), 0)
+    fp = CsFociParams(float(pearson), rescore_margin(pearson), 1, 0, int(lo_diag), int(hi_diag), int(bool(inter)), 0)
     cap = 1 << 14
     while True:
         rows, cols = np.empty(cap, np.int32), np.empty(cap, np.int32)

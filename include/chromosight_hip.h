@@ -245,8 +245,12 @@ int cs_csr_median(cs_ctx* ctx, void* stream, const cs_csr* mat, double* h_median
 /* ---- device-side foci: detection.py:387 pick_foci + the statistics of :18 validate_patterns ---- */
 typedef struct {
     double pearson;         /* candidate threshold: coefficient >= pearson and != 0 (detection.py:417-421) */
-    double rescore_margin;  /* float32 maps: every pixel >= pearson - margin is re-evaluated in float64
-                               before thresholding, so foci never depend on float32 rounding            */
+    double rescore_margin;  /* float32 maps: every pixel whose float32 coefficient is >= pearson - margin is
+                               re-evaluated in float64 before thresholding -- and so is every pixel whose
+                               window is too ill-conditioned for the float32 error to stay below margin / 4
+                               (variance of the window relative to its mean square, or of the template over
+                               the present pixels, below 8 km kn 2^-24 / margin) or whose sums sit next to one
+                               of the reference's zeroing thresholds: foci never depend on float32 rounding */
     int32_t min_size;       /* foci of fewer pixels are dropped (2; detection.py:557 filter_foci)        */
     int32_t diag_only;      /* 1-D patterns: bin1 = bin2 after picking (detection.py:311-315)            */
     int32_t lo_diag, hi_diag; /* scanned diagonals (diag_trim of the coefficient map, :269-270)          */

@@ -20,6 +20,10 @@ from chromosight_amd.utils import preprocessing as cup
 from oracle import c_oracle
 from parity_util import assert_parity
 
+# maps with missing bins: windows that lose (almost) all their present pixels, or whose present template pixels are all
+# equal (piecewise-constant templates), are ill-defined; how many a test may hold, what they may do: tests/parity_util.py
+ILL_MASKED = 0.1
+
 pytestmark = pytest.mark.gpu
 
 
@@ -128,7 +132,7 @@ def test_general_kernel_masks_bands_nobs(monkeypatch):
         want, cond = c_oracle.normxcorr2_rows(sig, kern, 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss,
                                               miss_col=miss)
         band = (jj - ii >= 0) & (jj - ii <= md)
-        assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma general band {kern.shape}")
+        assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma general band {kern.shape}", max_ill_frac=ILL_MASKED)
     # inter-chromosomal block: dense, masks on both axes, no diagonal limits
     shape = (300, 420)
     inter = rng.gamma(2.0, 1.0, size=shape)
@@ -143,7 +147,7 @@ def test_general_kernel_masks_bands_nobs(monkeypatch):
                           missing_tol=0.75)
     assert last_kernel() == KERNEL_MFMA
     want, cond = c_oracle.normxcorr2_rows(inter, loops(), 0, 300, full=True, miss_row=mr, miss_col=mc)
-    assert_parity(c.toarray(), want, cond, "f32", "mfma general inter")
+    assert_parity(c.toarray(), want, cond, "f32", "mfma general inter", max_ill_frac=ILL_MASKED)
 
 
 @pytest.mark.parametrize("n,md,ksize", [(900, 120, 17), (1500, 400, 17), (700, 60, 9), (400, 399, 13)])
@@ -171,7 +175,7 @@ def test_tile_kernel_with_bin_masks(n, md, ksize, monkeypatch):
     want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, n, max_dist=md, sym_upper=True, full=True,
                                           miss_row=miss, miss_col=miss)
     band = (jj - ii >= 0) & (jj - ii <= md)
-    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma tile kernel, bin masks n={n} md={md} k={ksize}")
+    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"mfma tile kernel, bin masks n={n} md={md} k={ksize}", max_ill_frac=ILL_MASKED)
     # same call on the streaming kernel: coefficients and p-values (n_obs) agree
     monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "0")
     c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
@@ -351,7 +355,7 @@ def test_mirrored_row_instance_equals_the_17_fragment_instance(monkeypatch):
     # the float64 container holds float32-representable values here?  no: it is rounded on the way in
     want, cond = c_oracle.normxcorr2_rows(sig, loops(), 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss, miss_col=miss)
     band = (jj - ii >= 0) & (jj - ii <= md)
-    assert_parity(out["f64", False][0][band], want[band], cond[band], "f32", "masked tile kernel, float64 container")
+    assert_parity(out["f64", False][0][band], want[band], cond[band], "f32", "masked tile kernel, float64 container", max_ill_frac=ILL_MASKED)
 
 
 @pytest.mark.parametrize("name", ["stripes_left", "stripes_right"])
@@ -378,12 +382,12 @@ def test_separable_kernel_on_rank1_templates(name, monkeypatch):
     assert last_kernel() == KERNEL_SEPARABLE
     want, cond = c_oracle.normxcorr2_rows(sig, kern, 0, n, max_dist=md, sym_upper=True, full=True, miss_row=miss, miss_col=miss)
     band = (jj - ii >= 0) & (jj - ii <= md)
-    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"separable kernel, {name}, band + masks")
+    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"separable kernel, {name}, band + masks", max_ill_frac=ILL_MASKED)
     dense = rng.gamma(4.0, 0.25, size=(300, 411)).astype(np.float32)
     cd, _ = cud.normxcorr2(dense, kern)
     assert last_kernel() == KERNEL_SEPARABLE
     wd, cond_d = c_oracle.normxcorr2_rows(dense.astype(np.float64), kern, 0, 300, full=False)
-    assert_parity(cd, wd, cond_d, "f32", f"separable kernel, {name}, dense")
+    assert_parity(cd, wd, cond_d, "f32", f"separable kernel, {name}, dense", max_ill_frac=ILL_MASKED)
     monkeypatch.setenv("CHROMOSIGHT_HIP_NO_SEPARABLE", "1")
     c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
                             missing_tol=0.75, pval=True)

@@ -63,6 +63,8 @@ def test_xcorr2_golden(golden, precision):
 
 def test_normxcorr2_dense_golden(golden, templates, precision):
     g = golden("normxcorr2_dense")
+    # sig_b holds an all-zero 30 x 30 region and a constant 20 x 23 patch (make_golden.py): flat windows by design
+    flat = {"a": 0.0, "b": 0.35}
     for name in "ab":
         sig = g[f"sig_{name}"]
         for kname in ("loops", "small", "hairpin"):
@@ -73,8 +75,8 @@ def test_normxcorr2_dense_golden(golden, templates, precision):
                 cd, pd_ = cud.normxcorr2(sig, k, full=full, pval=not full)
                 cs_, ps = cud.normxcorr2(sp.csr_matrix(sig), k, full=full, pval=True)
                 assert isinstance(cd, np.ndarray) and sp.issparse(cs_)
-                assert_parity(cd, g[f"dense_{tag}_corr"], cond, precision, f"dense {tag}")
-                assert_parity(cs_.toarray(), g[f"sparse_{tag}_corr"], cond, precision, f"sparse {tag}")
+                assert_parity(cd, g[f"dense_{tag}_corr"], cond, precision, f"dense {tag}", max_ill_frac=flat[name])
+                assert_parity(cs_.toarray(), g[f"sparse_{tag}_corr"], cond, precision, f"sparse {tag}", max_ill_frac=flat[name])
                 ref_p = g[f"sparse_{tag}_pval"]
                 err = np.abs(ps.toarray() - ref_p)[cond >= 1e-3]
                 # log10 p amplifies coefficient errors by up to ~ n / ln(10)
@@ -82,11 +84,11 @@ def test_normxcorr2_dense_golden(golden, templates, precision):
         sq = sig[:80, :80]
         cond = oracle_cond(np.triu(sq), templates["loops"], sym_upper=True, full=True)
         c, p = cud.normxcorr2(sp.csr_matrix(np.triu(sq)), templates["loops"], sym_upper=True, full=True, pval=True)
-        assert_parity(c.toarray(), g[f"sparse_{name}_loops_symfull_corr"], cond, precision, f"{name} symfull")
+        assert_parity(c.toarray(), g[f"sparse_{name}_loops_symfull_corr"], cond, precision, f"{name} symfull", max_ill_frac=flat[name])
         assert np.all(np.tril(c.toarray(), -1) == 0)
         cond = oracle_cond(np.triu(sq), templates["loops"], sym_upper=True, full=False)
         c, _ = cud.normxcorr2(np.triu(sq), templates["loops"], sym_upper=True, full=False)
-        assert_parity(c, g[f"dense_{name}_loops_symvalid_corr"], cond, precision, f"{name} symvalid")
+        assert_parity(c, g[f"dense_{name}_loops_symvalid_corr"], cond, precision, f"{name} symvalid", max_ill_frac=flat[name])
     c, _ = cud.normxcorr2(sp.csr_matrix(g["sig_a"]), templates["loops"], full=True, tsvd=0.999)
     assert np.abs(c.toarray() - g["sparse_a_loops_full_tsvd999_corr"]).max() < TOL[precision]
 

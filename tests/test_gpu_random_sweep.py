@@ -12,6 +12,11 @@ from chromosight_amd.utils import preprocessing as cup
 from oracle import c_oracle
 from parity_util import assert_parity
 
+# 25-40 % of the pixels of these maps are exact zeros and 5-6 % of the bins are missing: a few windows have (almost) no
+# signal or no present template pixel left.  What is allowed of them: tests/parity_util.py.
+ILL_MASKED = 0.05
+ILL_SPARSE = 0.01
+
 pytestmark = pytest.mark.gpu
 
 
@@ -42,7 +47,7 @@ def test_random_configuration(seed):
             full = bool(seed & 1)
             got, _ = cud.normxcorr2(sig, kern, full=full)
             want, cond = c_oracle.normxcorr2_rows(sig, kern, 0, shape[0], full=full)
-            assert_parity(got, want, cond, precision, f"seed {seed} dense")
+            assert_parity(got, want, cond, precision, f"seed {seed} dense", max_ill_frac=ILL_SPARSE)
         elif mode in (1, 2):   # intra band with missing bins
             n = int(rng.integers(80, 900))
             max_dist = int([rng.integers(1, 8), rng.integers(8, 60), rng.integers(60, n + 50)][seed % 3])
@@ -62,7 +67,7 @@ def test_random_configuration(seed):
                                     missing_mask=mask, missing_tol=tol)
             want, cond = c_oracle.normxcorr2_rows(a, kern, 0, n, max_dist=max_dist, sym_upper=True, full=True,
                                                   miss_row=miss, miss_col=miss, missing_tol=tol)
-            assert_parity(got.toarray(), want, cond, precision, f"seed {seed} band n={n} max_dist={max_dist}")
+            assert_parity(got.toarray(), want, cond, precision, f"seed {seed} band n={n} max_dist={max_dist}", max_ill_frac=ILL_MASKED)
         else:              # inter block
             shape = (int(rng.integers(40, 300)), int(rng.integers(40, 300)))
             a = rng.gamma(3, 0.4, size=shape) * (rng.random(shape) > 0.4)
@@ -73,6 +78,6 @@ def test_random_configuration(seed):
             got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, sym_upper=False, full=True, missing_mask=mask)
             want, cond = c_oracle.normxcorr2_rows(a, kern, 0, shape[0], sym_upper=False, full=True, miss_row=mr,
                                                   miss_col=mc)
-            assert_parity(got.toarray(), want, cond, precision, f"seed {seed} inter")
+            assert_parity(got.toarray(), want, cond, precision, f"seed {seed} inter", max_ill_frac=ILL_MASKED)
     finally:
         chromosight_amd.set_precision(old)

@@ -174,41 +174,52 @@ def test_yeast_detect_matches_reference(golden, pattern):
 
 
 def test_yeast_float32_prefilter_margin(golden):
-    """How close the float32 pre-filter comes to losing a pixel on real data: on every yeast chromosome, the pixels
-    whose exact (float64) coefficient passes the loops threshold, and their float32 coefficients."""
+    """How much of the float32 pre-filter's per-pixel bound real data uses: on every yeast chromosome, the float32
+    coefficient map against the float64 oracle on the staged (detrended) block; for the pixels whose exact coefficient
+    passes the loops threshold, the float32 error against the model behind the pre-filter's conditioning screen
+    (|r32 - r64| <= 2 n 2^-24 / conditioning, csrc/cs_device.h cand_screen_*)."""
+    from oracle import c_oracle
     from chromosight_amd import engine
-    from chromosight_amd._lib import CsMatrix, LAYOUT_BAND, MASK_BINS, np_dtype_code
+    from chromosight_amd._lib import CsMatrix, LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, np_dtype_code
     cool = golden("yeast_cool")
     cfg = copy.deepcopy(ck.loops)
     dcool = pipeline.DeviceCool(cool)
     dev = dcool.dev
     max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
-    kspec = engine.KernelSpec(cfg["kernels"][0])
-    worst, n_pass, n_total = 0.0, 0, 0
+    kern = cfg["kernels"][0]
+    kspec = engine.KernelSpec(kern)
+    tol = cfg["max_perc_undetected"] / 100
+    used, short, n_pass, n_total, worst_err = 0.0, 0.0, 0, 0, 0.0
     for ci in range(dcool.n_chrom):
         blk = dcool.stage_intra(ci, max_dist, 17, resident=True)
         n = blk.shape[0]
-        if blk.sig.layout != LAYOUT_BAND:
-            continue
-        w = min(max_dist, n - 1) + 1
-        ld = (w + 63) // 64 * 64
-        outs = {}
-        for prec, dt in (("f32", np.float32), ("f64", np.float64)):
-            buf = dev.zeros((n, ld), dt)
-            out = CsMatrix(buf.ptr, np_dtype_code(dt), LAYOUT_BAND, ld, 0, w)
-            engine.run_normxcorr2(dev, blk.sig, (n, n), kspec, out, full=True, sym_upper=True, max_dist=max_dist,
-                                  mask_mode=MASK_BINS, miss_row=blk.miss_row, miss_col=blk.miss_col,
-                                  missing_tol=cfg["max_perc_undetected"] / 100, precision=prec)
-            outs[prec] = buf.download()[:, :w].astype(np.float64)
-        passing = outs["f64"] >= cfg["pearson"]
+        assert blk.sig.layout == LAYOUT_DENSE            # yeast chromosomes are shorter than twice the scanned band
+        ld = (n + 15) // 16 * 16
+        dev.sync()
+        m = blk.buffer.download().view(np.float64).reshape(-1)[:n * ld].reshape(n, ld)[:, :n]
+        buf = dev.zeros((n, ld), np.float32)
+        out = CsMatrix(buf.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, ld, 0, 0)
+        engine.run_normxcorr2(dev, blk.sig, (n, n), kspec, out, full=True, sym_upper=True, max_dist=max_dist,
+                              mask_mode=MASK_BINS, miss_row=blk.miss_row, miss_col=blk.miss_col, missing_tol=tol, precision="f32")
+        r32 = buf.download()[:, :n].astype(np.float64)
+        miss = dcool.miss_host[dcool.offsets[ci]:dcool.offsets[ci + 1]]
+        want, cond = c_oracle.normxcorr2_rows(np.triu(m), kern, 0, n, max_dist=max_dist, sym_upper=True, full=True,
+                                              miss_row=miss, miss_col=miss, missing_tol=tol)
+        ii, jj = np.indices((n, n))
+        band = (jj - ii >= 0) & (jj - ii <= max_dist)
+        passing = band & (want >= cfg["pearson"])
         n_pass += int(passing.sum())
-        n_total += passing.size
+        n_total += int(band.sum())
         if passing.any():
-            worst = max(worst, float((cfg["pearson"] - outs["f32"][passing]).max()))
-    print(f"yeast loops: {n_pass} of {n_total} pixels pass the exact threshold; the lowest float32 value among them sits "
-          f"{worst:.2e} below it (pre-filter margin {engine.RESCORE_MARGIN:g})")
+            err = np.abs(r32 - want)[passing]
+            worst_err = max(worst_err, float(err.max()))
+            used = max(used, float((err * np.maximum(cond[passing], 1e-12) / (2 * 289 * 2.0 ** -24)).max()))
+            short = max(short, float((cfg["pearson"] - r32[passing]).max()))
+    print(f"yeast loops: {n_pass} of {n_total} scanned pixels pass the exact threshold; float32 error on them <= {worst_err:.1e}, "
+          f"the lowest float32 value sits {short:.1e} under the threshold (margin {engine.RESCORE_MARGIN:g}); at most "
+          f"{100 * used:.2f} % of the error model 2 n 2^-24 / conditioning is used")
     assert n_pass > 100
-    assert worst < 0.1 * engine.RESCORE_MARGIN
+    assert used < 0.5
 
 
 # ------------------------------------------------------------------------------------------------

@@ -89,7 +89,8 @@ def run_band(a, miss, kern, max_dist, precision, missing_tol, general):
 
 def check(got, want, precision, cond, what=""):
     """1e-5 (float32) / 1e-10 (float64) on every well-defined pixel, see tests/parity_util.py"""
-    assert_parity(got, want, cond, precision, what)
+    # missing-bin clusters longer than the template leave windows with (almost) no present pixel
+    assert_parity(got, want, cond, precision, what, max_ill_frac=0.05)
 
 
 def oracle(a, kern, **kw):

@@ -1125,14 +1125,19 @@ int cs_normxcorr2_host(cs_ctx* ctx, const void* h_signal, int32_t sig_dtype, int
         if (e != hipSuccess) return e;
         return hipEventRecord(ctx->ev_up[k], ctx->s_up);
     };
-    hipError_t he = upload(0);
+    // the windows of slab k's last row reach kt rows down: with slabs of `rows` rows that is `ahead` slabs (1 unless the
+    // template is taller than two slabs), all of which must have landed before the kernel of slab k starts (uploads are
+    // issued in order on one stream, so waiting for the furthest one covers the others)
+    (void)kh;
+    const int ahead = std::max(1, (kt + rows - 1) / rows);
+    int uploaded = -1;
+    hipError_t he = hipSuccess;
     for (int k = 0; k < n_slabs && he == hipSuccess && rc == CS_OK; ++k) {
-        if (k + 1 < n_slabs) he = upload(k + 1);
+        const int need = std::min(k + ahead, n_slabs - 1);
+        while (uploaded < need && he == hipSuccess) he = upload(++uploaded);
         if (he != hipSuccess) break;
         const int r0 = k * rows, r1 = std::min(ms, r0 + rows);
-        (void)kh;
-        (void)kt;
-        he = hipStreamWaitEvent(ctx->s_run, ctx->ev_up[std::min(k + 1, n_slabs - 1)], 0);
+        he = hipStreamWaitEvent(ctx->s_run, ctx->ev_up[need], 0);
         if (he != hipSuccess) break;
         cs_normxcorr2_params pk = *p;
         pk.row_begin = r0;

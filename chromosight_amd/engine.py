@@ -152,14 +152,19 @@ def _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, m
 
 
 def _host_buffers(dev, cap, kk, want_windows):
-    """Pinned result buffers of a device (grow-only, reused by every call)."""
-    have = getattr(dev, "_foci_host", None)
-    if have is None or have[0].shape[0] < cap or (want_windows and have[1].shape[1] < kk):
+    """Pinned result buffers of a device (grow-only, reused by every call): records always, the window buffer only for
+    callers that fetch windows -- cap * kk float64, sized for the template at hand (an 81 x 81 template at cap = 4096 is
+    215 MB of page-locked memory per context; hipHostMalloc of that costs more than the detection it would serve)."""
+    have = getattr(dev, "_foci_host", None) or (None, None)
+    rec, win = have
+    if rec is None or rec.shape[0] < cap:
         cap = max(cap, 1024)
         rec = dev.pinned_empty(cap, FOCUS_DTYPE)
-        win = dev.pinned_empty((cap, max(kk, 289)), np.float64)
-        have = dev._foci_host = (rec, win)
-    return have
+        win = None                                   # its capacity follows the records'
+    if want_windows and (win is None or win.shape[0] < rec.shape[0] or win.shape[1] < kk):
+        win = dev.pinned_empty((rec.shape[0], max(kk, win.shape[1] if win is not None else 0)), np.float64)
+    dev._foci_host = (rec, win)
+    return rec, win
 
 
 def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter, diag_only, full, sym_upper, max_dist,

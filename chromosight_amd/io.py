@@ -66,11 +66,27 @@ def _attr_int(tool, path, group, name):
     return int(re.search(r"\(0\):\s*(-?\d+)", txt).group(1))
 
 
-def load_cool(uri, balance="weight"):
+def _has_dataset(tool, path, dataset):
+    """Is `dataset` an object of the file?  (`h5dump -n` lists every group and dataset.)"""
+    listing = _run([tool, "-n", str(path)])
+    return re.search(r"^\s*dataset\s+" + re.escape(dataset) + r"\s*$", listing, flags=re.M) is not None
+
+
+def load_cool(uri, balance="weight", norm="auto"):
     """Decode a .cool (or `file.mcool::/resolutions/<binsize>`) into the dictionary of arrays the
-    device pipeline takes: bin1_id, bin2_id, count, weight (NaN = bin without a balancing weight; all
-    ones when the file holds no `balance` column), bin_start, bin_end, chrom_offset, chrom_names,
-    binsize.  The pixel table comes back in the file's order (cooler: sorted by bin1, bin2)."""
+    device pipeline takes: bin1_id, bin2_id, count, weight (NaN = bin without a balancing weight),
+    bin_start, bin_end, chrom_offset, chrom_names, binsize.  The pixel table comes back in the file's
+    order (cooler: sorted by bin1, bin2).
+
+    The file must be balanced: the reference balances an unbalanced file itself (cooler.balance_cooler,
+    contacts_map.py:203-221) and ALWAYS takes the detectable bins from the finite weights (:227); ICE balancing is
+    outside this package, so a file without a `bins/<balance>` column is refused (ValueError) instead of being
+    scanned as raw counts with every bin detectable.  norm="raw" is the explicit opt-in for exactly that
+    (all-ones weights; the reference's --norm raw still balances first to find the detectable bins, so results on
+    an unbalanced file differ from it in the bins it would have masked).  Read errors of an existing weight
+    column (h5dump failure, unsupported type) propagate."""
+    if norm not in ("auto", "raw"):
+        raise ValueError("norm must be one of: auto, raw ('force' re-balances the file: not part of this package)")
     path, _, group = str(uri).partition("::")
     group = "/" + group.strip("/") if group else ""
     tool = find_h5dump()
@@ -87,10 +103,15 @@ def load_cool(uri, balance="weight"):
         "binsize": np.int64(_attr_int(tool, path, group or "/", "bin-size")),
     }
     n_bins = cool["bin_start"].size
-    try:
-        cool["weight"] = _numeric(tool, path, ds(f"bins/{balance}")).astype(np.float64)
-    except (subprocess.CalledProcessError, ValueError):
-        cool["weight"] = np.ones(n_bins)          # unbalanced file: raw counts (reference --norm raw)
+    if _has_dataset(tool, path, ds(f"bins/{balance}")):
+        weight = _numeric(tool, path, ds(f"bins/{balance}")).astype(np.float64)
+        cool["weight"] = np.where(np.isfinite(weight), 1.0, np.nan) if norm == "raw" else weight
+    elif norm == "raw":
+        cool["weight"] = np.ones(n_bins)
+    else:
+        raise ValueError(f"{uri}: no balancing weights (bins/{balance}).  Balance the file first (cooler balance; the "
+                         "reference does it with cooler.balance_cooler) or pass norm='raw' to scan raw counts with every "
+                         "bin detectable")
     for key in ("bin1_id", "bin2_id"):
         if cool[key].size and cool[key].max() < 2 ** 31:
             cool[key] = cool[key].astype(np.int32)

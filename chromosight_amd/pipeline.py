@@ -170,6 +170,27 @@ class _Scratch:
         return self.buf.ptr
 
 
+class _FreeList:
+    """Device buffers of released blocks, best fit first; every access under one lock (blocks are released by the
+    garbage collector on whatever thread drops the last reference, taken by the staging threads)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._bufs = []
+
+    def release(self, buf):
+        with self._lock:
+            self._bufs.append(buf)
+
+    def take(self, nbytes):
+        with self._lock:
+            best = None
+            for k, buf in enumerate(self._bufs):
+                if buf.nbytes >= nbytes and (best is None or buf.nbytes < self._bufs[best].nbytes):
+                    best = k
+            return self._bufs.pop(best) if best is not None else None
+
+
 class StagedBlock:
     """One sub-matrix staged in HBM (detrended band or dense map + the flags of its undetectable
     bins): what pattern_detector works on after ContactMap.create_mat (contacts_map.py:453-526)."""
@@ -183,10 +204,13 @@ class StagedBlock:
 
     def __del__(self):
         # a resident block hands its HBM back to the genome's free list (hipFree synchronises and costs
-        # ~0.2 ms; a genome is restaged for every pattern configuration)
+        # ~0.2 ms; a genome is restaged for every pattern configuration).  The list is shared with the worker
+        # threads (_resident pops under the same lock).  Reuse needs no event: every path that drops a block has
+        # synchronised the streams that read it (detect / quantify return host tables), and the next staging of the
+        # buffer is ordered after that synchronisation.
         try:
             if self.buffer is not None and self.pool is not None:
-                self.pool.append(self.buffer)
+                self.pool.release(self.buffer)
         except Exception:
             pass
 
@@ -271,19 +295,12 @@ class DeviceCool:
         self.upload_bytes = self.indptr.nbytes + self.indices.nbytes + self.data.nbytes + self.weight.nbytes
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
-        self._free = []                 # HBM of released resident blocks, reused by the next staging
-        self._free_lock = threading.Lock()
+        self._free = _FreeList()        # HBM of released resident blocks, reused by the next staging
         self._workers = None
 
     def _resident(self, nbytes, dev=None):
-        with self._free_lock:
-            best = None
-            for k, buf in enumerate(self._free):
-                if buf.nbytes >= nbytes and (best is None or buf.nbytes < self._free[best].nbytes):
-                    best = k
-            if best is not None:
-                return self._free.pop(best)
-        return (dev or self.dev).empty(nbytes, np.uint8)
+        buf = self._free.take(nbytes)
+        return buf if buf is not None else (dev or self.dev).empty(nbytes, np.uint8)
 
     def stage_blocks(self, chroms, max_dist, largest_kernel, workers=1, **options):
         """stage_intra(resident=True) of several chromosomes.  Default: one host thread deals the blocks to a few streams

@@ -386,8 +386,11 @@ class GenomeC4:
         self.border_pixels = int(sum(3 * int(n) * 2 for n in sizes))
 
     def step(self):
-        rec_l = self.parallel.detect_genome(self.dcool, self.loops, owned=self.mine)
-        rec_b = self.parallel.detect_genome(self.dcool, self.borders, owned=self.mine)
+        # every owned block is staged ONCE per step, at the loops' keep distance; the borders templates scan band views of
+        # the same blocks (the law of a diagonal does not depend on how many diagonals are kept: identical values)
+        staged = self.parallel.stage_genome(self.dcool, [self.loops, self.borders], owned=self.mine)
+        rec_l = self.parallel.detect_genome(self.dcool, self.loops, owned=self.mine, staged=staged)
+        rec_b = self.parallel.detect_genome(self.dcool, self.borders, owned=self.mine, staged=staged)
         return rec_l, rec_b
 
 

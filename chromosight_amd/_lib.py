@@ -77,6 +77,20 @@ class CsCsr(C.Structure):
     ]
 
 
+class CsStageBlock(C.Structure):
+    _fields_ = [
+        ("row0", C.c_int64),
+        ("n", C.c_int32),
+        ("keep", C.c_int32),
+        ("layout", C.c_int32),
+        ("band_w", C.c_int32),
+        ("ld", C.c_int64),
+        ("d_band64", C.c_void_p),
+        ("d_band32", C.c_void_p),
+        ("d_law", C.c_void_p),
+    ]
+
+
 class CsFociParams(C.Structure):
     _fields_ = [
         ("pearson", C.c_double),
@@ -148,6 +162,9 @@ _PROTOTYPES = {
     "cs_csr_band_extent": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
     "cs_distance_law_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "cs_detect_foci_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(CsKernel),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_stage_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(CsStageBlock), C.c_int32, C.c_double]),
     "cs_csr_median": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(C.c_double)]),
     "cs_detect_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                  C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_int64,

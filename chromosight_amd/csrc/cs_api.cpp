@@ -33,6 +33,8 @@ struct cs_ctx {
     // cs_detect_foci: coefficient map and candidate / foci scratch (grow-only), pinned counters
     void* d_map = nullptr;
     size_t d_map_bytes = 0;
+    void* d_stage = nullptr;         // cs_stage_blocks: tables, per-group partial sums, row extents
+    size_t d_stage_bytes = 0;
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
@@ -45,8 +47,7 @@ struct cs_ctx {
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
-    double cand_margin = 0.0;   // > 0 while find_candidates runs its float32 map: build_args turns on candidate mode
-    double cand_thr = 0.0;
+    bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
     // flags), per arithmetic type: a detect run calls with the same template thousands of times
     struct TemplateCache {
@@ -462,6 +463,10 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
 template <typename TC>
 int launch_corr(cs_ctx* ctx, cs::CorrArgs<TC>& A, hipStream_t stream, bool allow_fast);
 
+// internal status of launch_corr<float>: a candidate sink was given without a map, and the kernel that would serve the
+// call writes maps (nothing was launched that matters: the caller allocates the map and calls again)
+constexpr int CS_NEED_MAP = 1000;
+
 // the streaming kernels write n_obs next to the coefficient (same index), so both maps must share
 // one geometry; plain cross-correlations run their unmasked instance
 template <typename TC>
@@ -481,13 +486,19 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
     A.n_cu = ctx->n_cu;
     A.reg_mode = 0;
     // per-bin masks on the matrix cores: the factorised mask tables + the persistent tile kernel
-    if (allow_fast && mfma_reg_wanted(A)) {
+    // (candidate mode without a sink -- the map fallback of find_candidates -- runs on the kernels that decide the screen
+    // at run time: the tile kernel's candidate instance has no map output)
+    if (allow_fast && mfma_reg_wanted(A) && !(A.ks.cand_cmin > 0.0f && !A.cand_keys)) {
         if (A.out.layout == CS_LAYOUT_BAND) {
             A.out_lo = A.out.band_lo;
             A.out_hi = A.out.band_lo + A.out.band_w - 1;
         } else {
             A.out_lo = -(1 << 30);
             A.out_hi = (1 << 30);
+        }
+        if (A.cand_keys) {                   // candidate sink: only the scanned diagonals (the map path trims in the compaction)
+            A.out_lo = std::max(A.out_lo, A.cand_dlo);
+            A.out_hi = std::min(A.out_hi, A.cand_dhi);
         }
         rc = prepare_regular_mask<float>(ctx, A, A.km, stream);
         if (rc != CS_OK) return rc;
@@ -516,10 +527,13 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
             int path = 0;
             rc = cs::launch_corr_mfma_f32(A, E, stream, &path);
             ctx->last_kernel = path == 2 ? CS_KERNEL_MFMA_REG : CS_KERNEL_MFMA;
+            if (rc == -5) return CS_NEED_MAP;
             if (rc != 0) return fail(ctx, CS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (path == 2 && A.cand_keys) ctx->cand_fused = true;
             return CS_OK;
         }
     }
+    if (!A.out.ptr) return CS_NEED_MAP;      // every other kernel writes a map
     if (allow_fast && mfma_wanted(A)) {
         if (A.sig_is_f64 && A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.nobs.ptr) {
             // float64 container, float32 arithmetic: narrow the rows the windows reach into context scratch
@@ -801,10 +815,8 @@ int build_args(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const c
     A.ks.den2_min = (TC)(p->denom_eps * p->denom_eps * st.n * st.n);
     A.ks.zk_possible = tc.zk_possible;
     A.ks.snap_possible = tc.snap_possible;
-    // candidate mode of the float32 kernels (find_candidates below; cs_device.h cand_screen_*): windows conditioned at
-    // least 8 n 2^-24 / margin have a float32 error below margin / 4 (2 gamma / conditioning, gamma = n 2^-24)
-    A.ks.cand_cmin = (sizeof(TC) == 4 && ctx->cand_margin > 0) ? (TC)std::min(0.5, 8.0 * st.n * 0x1p-24 / ctx->cand_margin) : (TC)0;
-    A.ks.cand_thr = (TC)ctx->cand_thr;
+    A.ks.cand_cmin = (TC)0;              // candidate mode: corr_candidates_f32 below
+    A.ks.cand_thr = (TC)0;
     A.xcorr_only = 0;
     A.w_sym = sym ? 1 : 0;
     A.w_rank1 = tc.rank1 ? 1 : 0;
@@ -856,6 +868,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
@@ -1403,6 +1416,51 @@ int cs_csr_median(cs_ctx* ctx, void* stream_, const cs_csr* mat, double* h_media
     return CS_OK;
 }
 
+int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_stage_block* blocks, int32_t n_blocks, double max_val)
+{
+    CS_ENTER(ctx);
+    cs::CsrView v;
+    int rc = csr_view(ctx, genome, &v);
+    if (rc) return rc;
+    if (n_blocks < 0 || (n_blocks > 0 && !blocks)) return fail(ctx, CS_ERR_INVALID, "bad block table");
+    if (n_blocks == 0) return CS_OK;
+    if (genome->d_row_end || genome->col0 != 0 || !v.row_w || v.row_w != v.col_w || v.n_rows != v.n_cols)
+        return fail(ctx, CS_ERR_INVALID, "cs_stage_blocks takes the whole-genome pixel table (square, one weight vector, plain row pointers)");
+    const int kRowsPerGroup = std::getenv("CHROMOSIGHT_HIP_STAGE_ROWS") ? std::max(8, atoi(std::getenv("CHROMOSIGHT_HIP_STAGE_ROWS"))) : 128;
+    std::vector<cs::StageBlock> tab((size_t)n_blocks);
+    int n_groups = 0, pitch = 1;
+    for (int b = 0; b < n_blocks; ++b) {
+        const cs_stage_block& s = blocks[b];
+        cs::StageBlock& B = tab[b];
+        if (s.n <= 0 || s.row0 < 0 || s.row0 + s.n > v.n_rows || s.keep < 0) return fail(ctx, CS_ERR_INVALID, "block %d outside the genome", b);
+        if (s.layout != CS_LAYOUT_BAND && s.layout != CS_LAYOUT_DENSE) return fail(ctx, CS_ERR_INVALID, "block %d: bad layout", b);
+        B.row0 = s.row0;
+        B.n = s.n;
+        B.keep = s.keep;
+        B.n_diags = (int)std::min<int64_t>(s.n, (int64_t)s.keep + 1);
+        B.dense = s.layout == CS_LAYOUT_DENSE;
+        B.width = B.dense ? s.n : B.n_diags;
+        if (!B.dense && s.band_w != B.n_diags) return fail(ctx, CS_ERR_INVALID, "block %d: band_w must be min(keep, n - 1) + 1", b);
+        if (s.ld < B.width) return fail(ctx, CS_ERR_INVALID, "block %d: ld < stored slots", b);
+        if (!s.d_law || (!s.d_band64 && !s.d_band32)) return fail(ctx, CS_ERR_INVALID, "block %d: null outputs", b);
+        B.ld = s.ld;
+        B.band64 = (double*)s.d_band64;
+        B.band32 = (float*)s.d_band32;
+        B.law = s.d_law;
+        B.group0 = B.n_groups = 0;
+        n_groups += (s.n + kRowsPerGroup - 1) / kRowsPerGroup;
+        pitch = std::max(pitch, B.n_diags);
+    }
+    if (pitch > 4096) return fail(ctx, CS_ERR_UNSUPPORTED, "distance laws of more than 4096 diagonals: stage block by block");
+    pitch = (pitch + 63) / 64 * 64;
+    rc = ensure_scratch(ctx, &ctx->d_stage, &ctx->d_stage_bytes, cs::stage_scratch_bytes(n_blocks, n_groups, pitch, v.n_rows));
+    if (rc) return rc;
+    rc = cs::enqueue_stage_blocks(v.indptr, v.indices, v.data, v.is_f64, v.row_w, v.n_rows, tab.data(), n_blocks, max_val,
+                                  kRowsPerGroup, ctx->n_cu, ctx->d_stage, (hipStream_t)stream_);
+    if (rc) return fail(ctx, CS_ERR_HIP, "staging kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
 int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr)
 {
     if (!h_ptr) return CS_ERR_INVALID;
@@ -1429,6 +1487,44 @@ static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel
 }
 
 namespace {
+// Where the masked matrix-core tile kernel appends its candidates (keys tag + row * ns + col); see CorrArgs::cand_keys.
+struct CandSink {
+    unsigned long long* keys;
+    unsigned long long* count;       // zeroed by the caller
+    long long cap;
+    unsigned long long tag;
+    int lo_diag, hi_diag;            // scanned diagonals
+};
+
+// float32 correlation in candidate mode (cs_device.h cand_screen_*: margin + conditioning screen, sentinel 2.0).  With a
+// sink and the masked tile kernel the candidates are appended to the sink and no map is written (ctx->cand_fused);
+// otherwise the map goes to `out` -- CS_NEED_MAP when that has no storage, before anything that matters was launched.
+int corr_candidates_f32(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal, const cs_kernel* kernel,
+                        const cs_normxcorr2_params* p, const cs_matrix* out, double margin, double thr, const CandSink* sink)
+{
+    cs::CorrArgs<float> A;
+    int rc = build_args<float>(ctx, stream, signal, kernel, p, &A);
+    if (rc) return rc;
+    // windows conditioned at least 8 n 2^-24 / margin have a float32 error below margin / 4 (2 gamma / conditioning)
+    A.ks.cand_cmin = (float)std::min(0.5, 8.0 * (double)A.ks.n * 0x1p-24 / margin);
+    A.ks.cand_thr = (float)thr;
+    A.out = view_of(out);
+    A.out_is_f64 = 0;
+    A.nobs = cs::MatView{nullptr, 0, 0, 0, 0, 0};
+    if (sink) {
+        A.cand_keys = sink->keys;
+        A.cand_count = sink->count;
+        A.cand_cap = sink->cap;
+        A.cand_tag = sink->tag;
+        A.cand_dlo = sink->lo_diag;
+        A.cand_dhi = sink->hi_diag;
+    } else if (!out || !out->d_ptr) {
+        return fail(ctx, CS_ERR_INVALID, "candidate mode needs a sink or a map");
+    }
+    ctx->cand_fused = false;
+    return launch_corr<float>(ctx, A, stream, getenv("CHROMOSIGHT_HIP_FORCE_GENERIC") == nullptr);
+}
+
 // 1-D patterns (cs_foci_params.diag_only): the reference forces bin1 = bin2 AFTER shifting the coordinates by (kh, kw)
 // into a map padded by (kw, kh) (detection.py:287-315, preprocessing.py:636-676), so with a non-square template in full
 // mode the row ends up kw - kh away from the column.  The kernels take an odd code whose upper bits hold that offset.
@@ -1505,21 +1601,49 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
         return CS_OK;
     }
     const size_t map_bytes = (size_t)(re - rb) * (size_t)map.ld * (f64 ? 8 : 4);
-    rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
-    if (rc) return rc;
-    map.d_ptr = ctx->d_map;
     // float32 maps are computed in candidate mode (cs_device.h cand_screen_*): a pixel keeps its value only if that is
     // below pearson - margin on a window conditioned well enough for the float32 error to stay under margin / 4; every
     // other pixel holds 2.0 and is re-evaluated.  float64 maps hold the coefficient.
     const double margin = std::max(fp->rescore_margin, 1e-4);
-    ctx->cand_margin = f64 ? 0.0 : margin;
-    ctx->cand_thr = fp->pearson - margin;
-    rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
-    ctx->cand_margin = 0.0;
-    if (rc) return rc;
-    // ---- candidates: thresholded compaction
     const double thr = f64 ? fp->pearson : fp->pearson - margin;
     size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
+    // ---- float32, masked tile kernel: the kernel appends the candidates itself (no map, no compaction pass)
+    bool fused_ok = !f64 && !std::getenv("CHROMOSIGHT_HIP_NO_FUSED_CANDIDATES");
+    while (fused_ok) {
+        if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
+        rc = layout(c_cap);
+        if (rc) return rc;
+        char* pool = (char*)ctx->d_pool;
+        long long* d_cnt = (long long*)(pool + P->off_cnt);
+        CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        CandSink sink{(unsigned long long*)(pool + P->off_vals), (unsigned long long*)d_cnt, (long long)c_cap, 0ull,
+                      fp->lo_diag, fp->hi_diag};
+        rc = corr_candidates_f32(ctx, stream, signal, kernel, p, &map, margin, thr, &sink);
+        if (rc == CS_NEED_MAP) {
+            fused_ok = false;
+            break;
+        }
+        if (rc) return rc;
+        CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        P->n_cand = ctx->h_counts[0];
+        if ((size_t)P->n_cand <= c_cap) {
+            if (P->n_cand > 0) {
+                rc = cs::launch_decode_keys((const long long*)(pool + P->off_vals), P->n_cand, p->ns, (int*)pool,
+                                            (int*)(pool + P->off_cols), stream);
+                if (rc) return fail(ctx, CS_ERR_HIP, "key decoding failed: %s", hipGetErrorString((hipError_t)rc));
+            }
+            return CS_OK;
+        }
+        c_cap = (size_t)P->n_cand + (size_t)P->n_cand / 8;      // the list overflowed: once more with room for all
+    }
+    // ---- coefficient map in context scratch, then thresholded compaction
+    rc = ensure_scratch(ctx, &ctx->d_map, &ctx->d_map_bytes, map_bytes);
+    if (rc) return rc;
+    map.d_ptr = ctx->d_map;
+    if (f64) rc = cs_normxcorr2(ctx, stream_, signal, kernel, p, &map, nullptr);
+    else rc = corr_candidates_f32(ctx, stream, signal, kernel, p, &map, margin, thr, nullptr);
+    if (rc) return rc;
     while (true) {
         if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
         rc = layout(c_cap);
@@ -1683,6 +1807,123 @@ int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_
     for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
     if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
     (void)kk;
+    return CS_OK;
+}
+
+// 2-D patterns (loops, stripes: a band of scanned diagonals) of MANY sub-matrices with one launch chain: the masked
+// matrix-core tile kernel of every block appends its candidates to one list (composite keys block | row | col), then
+// ONE sort, ONE float64 re-scoring, one labelling workgroup per block, one statistics pass -- instead of ~20 small
+// launches and three synchronisations per block (23 blocks of a human genome: the loops pass was bound by them).
+int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_matrix* signals, const cs_matrix* signals_f32,
+                          const cs_kernel* kernel, const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci,
+                          int64_t cap, int64_t* h_n_foci, double* h_windows)
+{
+    CS_ENTER(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_blocks <= 0 || !signals || !kernel || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
+        return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
+    constexpr int kKeyShift = 40;                 // row * ns + col < 2^40: sub-matrices of up to 2^20 bins
+    bool all_narrow = true;
+    long long pixels = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        const cs_normxcorr2_params* p = params + b;
+        const cs_foci_params* fp = foci + b;
+        int rc = check_foci_args(ctx, signals + b, kernel, p, fp);
+        if (rc) return rc;
+        if (fp->pearson != foci[0].pearson || fp->min_size != foci[0].min_size || fp->diag_only != foci[0].diag_only ||
+            fp->inter != foci[0].inter || fp->want_windows != foci[0].want_windows || fp->rescore_margin != foci[0].rescore_margin)
+            return fail(ctx, CS_ERR_INVALID, "the blocks of a batch share the detection parameters");
+        if (p->row_end > p->row_begin) return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry takes whole blocks");
+        if (fp->hi_diag < fp->lo_diag) return fail(ctx, CS_ERR_INVALID, "empty diagonal range");
+        const int w = fp->hi_diag - fp->lo_diag + 1;
+        all_narrow = all_narrow && signals[b].layout == CS_LAYOUT_BAND && w <= 4 && fp->lo_diag >= 0;
+        if ((long long)p->ms * p->ns >= (1ll << kKeyShift)) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is too large for the batch keys", b);
+        pixels += (long long)p->ms * std::min<long long>(w, p->ns);
+    }
+    if (all_narrow && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW"))
+        return cs_detect_foci_batch(ctx, stream_, n_blocks, signals, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
+    if (params[0].compute_dtype != CS_F32) return fail(ctx, CS_ERR_UNSUPPORTED, "the 2-D batch runs the float32 tile kernel");
+    // results straight into page-locked caller buffers (cs_host_alloc)
+    auto device_view = [&](const void* h) -> void* {
+        if (!h) return nullptr;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, h) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
+    };
+    cs::FocusRec* rec = cap > 0 ? reinterpret_cast<cs::FocusRec*>(device_view(h_foci)) : nullptr;
+    double* win = (foci[0].want_windows && h_windows) ? reinterpret_cast<double*>(device_view(h_windows)) : nullptr;
+    if ((cap > 0 && !rec) || (foci[0].want_windows && h_windows && !win))
+        return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry writes into page-locked buffers (cs_host_alloc)");
+    const size_t cnt_bytes = 8 * ((size_t)n_blocks + 2);
+    if (cnt_bytes > ctx->h_blk_bytes) {
+        if (ctx->h_blk_counts) CS_HIP(ctx, hipHostFree(ctx->h_blk_counts));
+        ctx->h_blk_counts = nullptr;
+        ctx->h_blk_bytes = 0;
+        CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_blk_counts, 2 * cnt_bytes, hipHostMallocDefault));
+        ctx->h_blk_bytes = 2 * cnt_bytes;
+    }
+    // ---- candidates of every block into one list
+    const double margin = std::max(foci[0].rescore_margin, 1e-4);
+    const double thr = foci[0].pearson - margin;
+    size_t c_cap = std::max<size_t>(1 << 16, (size_t)(pixels / 256));
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    long long n_total = 0;
+    while (true) {
+        if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
+        const size_t off_cnt = al(8 * c_cap), off_tail = off_cnt + 256;
+        int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_tail + cs::keyed_batch_scratch_bytes(n_blocks, (long long)c_cap));
+        if (rc) return rc;
+        char* pool = (char*)ctx->d_pool;
+        unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);
+        CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        for (int b = 0; b < n_blocks; ++b) {
+            const cs_matrix* sig = (signals_f32 && signals_f32[b].d_ptr) ? signals_f32 + b : signals + b;
+            cs_matrix map;                        // geometry of the (virtual) coefficient map: the scanned diagonals
+            map.d_ptr = nullptr;
+            map.dtype = CS_F32;
+            map.layout = signals[b].layout;
+            map.row0 = 0;
+            if (map.layout == CS_LAYOUT_BAND) {
+                map.band_lo = foci[b].lo_diag;
+                map.band_w = foci[b].hi_diag - foci[b].lo_diag + 1;
+                map.ld = ((int64_t)map.band_w + 63) / 64 * 64;
+            } else {
+                map.band_lo = map.band_w = 0;
+                map.ld = ((int64_t)params[b].ns + 15) / 16 * 16;
+            }
+            CandSink sink{(unsigned long long*)pool, d_cnt, (long long)c_cap, (unsigned long long)b << kKeyShift, foci[b].lo_diag,
+                          foci[b].hi_diag};
+            rc = corr_candidates_f32(ctx, stream, sig, kernel, params + b, &map, margin, thr, &sink);
+            if (rc == CS_NEED_MAP) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is not served by the masked tile kernel", b);
+            if (rc) return rc;
+        }
+        CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        n_total = ctx->h_counts[0];
+        if ((size_t)n_total <= c_cap) break;
+        c_cap = (size_t)n_total + (size_t)n_total / 8;
+    }
+    // ---- exact scores, foci, statistics: one chain for all blocks
+    std::vector<cs::CorrArgs<double>> tab((size_t)n_blocks);
+    for (int b = 0; b < n_blocks; ++b) {
+        int rc = build_args<double>(ctx, stream, signals + b, kernel, params + b, &tab[b]);
+        if (rc) return rc;
+    }
+    char* pool = (char*)ctx->d_pool;
+    const size_t off_tail = al(8 * c_cap) + 256;
+    ctx->h_blk_counts[0] = -1;
+    int rc = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, n_total, kKeyShift, foci[0].pearson,
+                                          foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail, rec,
+                                          (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host table above was consumed
+    const long long total = ctx->h_blk_counts[0];
+    if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
+    for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
+    if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
     return CS_OK;
 }
 

@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                 // windows whose sums fall under the 1e-4 thresholds (rare): ONE inlined copy of the exact function
                 // per half instead of one per pixel (16 copies: 100 KB of code; a call pins the epilogue to the stack)
 #pragma unroll 1
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < (CAND ? 0 : 8); ++k) {      // (candidate mode: such pixels carry the sentinel)
                     if (!__builtin_amdgcn_ballot_w64((rare_bits >> k) != 0)) break;
                     if ((rare_bits >> k) & 1u) {
                         float cs = 0.0f, s1 = 0.0f, s2 = 0.0f, nm = 0.0f, ka = 0.0f, kb = 0.0f;
@@ -850,6 +850,37 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDense
                         for (int e = 0; e < 8; ++e)
                             if (e == k) rv[e >> 2][e & 3] = val;
                     }
+                }
+                if constexpr (CAND) {
+                    // candidate mode: no map leaves the kernel, only the coordinates of the pixels that carry the
+                    // sentinel (1e-4 of them), appended to the caller's list -- one atomic per wave and column that
+                    // has any.  A.out = the list (keys tag + row * ns + col), A.nobs = its counter, A.ld_out = its
+                    // capacity, A.row0_out = the tag (cs_api.cpp find_candidates / cs_detect_foci_blocks).
+                    unsigned long long* keys = reinterpret_cast<unsigned long long*>(A.out);
+                    unsigned long long* counter = reinterpret_cast<unsigned long long*>(A.nobs);
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int j = J0 + 16 * (2 * half + cc) + 4 * g + v;
+                            const int d = j - i;
+                            const bool hit = (rv[cc][v] >= KS.cand_thr) & (i < A.row_end) & (j >= 0) & (j < A.ns) &
+                                             (d >= A.out_lo) & (d <= A.out_hi);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                            if (m) {                                          // wave-uniform, rare
+                                const int first = __builtin_ctzll(m);
+                                unsigned long long base = 0;
+                                if (lane == first) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
+                                const unsigned lo = __builtin_amdgcn_readlane((unsigned)base, first);
+                                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(base >> 32), first);
+                                const unsigned long long pos = (((unsigned long long)hi << 32) | lo) +
+                                                               (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                                if (hit && pos < (unsigned long long)A.ld_out)
+                                    keys[pos] = (unsigned long long)A.row0_out + (unsigned long long)i * (unsigned long long)A.ns + (unsigned long long)j;
+                            }
+                        }
+                    }
+                    continue;
                 }
                 // 16 rows x 32 columns through the wave's scratch, out as 2 rows x 32 consecutive floats per
                 // instruction (band rows are shifted against each other: no wider aligned store exists)
@@ -1396,7 +1427,15 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             }
             *dense_path = 2;
             const bool rsym = A.w_sym && A.km == 17 && A.kn == 17 && !getenv("CHROMOSIGHT_HIP_MFMA_NORSYM");
+            // candidate mode: the CAND instances append candidate coordinates to the caller's list and write no map
             const bool cand = A.ks.cand_cmin > 0.0f;
+            if (cand) {
+                if (!A.cand_keys || !A.cand_count) return -5;
+                D.out = A.cand_keys;
+                D.nobs = reinterpret_cast<float*>(A.cand_count);
+                D.ld_out = A.cand_cap;
+                D.row0_out = (long long)A.cand_tag;
+            }
             typedef void (*reg_kernel_t)(const MfmaDenseArgs);
             const reg_kernel_t kr = rsym ? (cand ? corr_mfma_dense_kernel<true, true, true, true> : corr_mfma_dense_kernel<true, true, true, false>)
                                          : (cand ? corr_mfma_dense_kernel<true, true, false, true> : corr_mfma_dense_kernel<true, true, false, false>);
@@ -1407,6 +1446,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
             return (int)hipGetLastError();
         }
+        if (!A.out.ptr) return -5;
         // 16-byte pieces: the tile's first staged column (64 bx - kw) and the row length must be multiples
         // of 4 so that no piece straddles the matrix edge; the transfers themselves need only 4-byte alignment
         // (checked bit for bit against 4-byte transfers at every misalignment), the 16-byte stores aligned rows
@@ -1421,6 +1461,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
         return (int)hipGetLastError();
     }
+    if (!A.out.ptr) return -5;                   // (a candidate sink without a map: only the masked tile kernel serves that)
     const void* kern = masked ? (const void*)corr_mfma_kernel<true> : (const void*)corr_mfma_kernel<false>;
     hipError_t e = allow_big_lds(kern);
     if (e != hipSuccess) return (int)e;

@@ -88,6 +88,13 @@ struct CorrArgs {
     // factorised per-bin mask sums of the streaming kernel (cs_mask_prep.hip); reg_mode = 1:
     // strips whose windows stay inside the matrix use the tables, the others the general path
     int reg_mode;
+    // candidate mode (ks.cand_cmin > 0) with a sink: the masked matrix-core tile kernel appends the coordinates of its
+    // candidate pixels (keys cand_tag + row * ns + col) to this list instead of writing a map; `out.ptr` may then be null
+    unsigned long long* cand_keys;
+    unsigned long long* cand_count;
+    long long cand_cap;
+    unsigned long long cand_tag;
+    int cand_dlo, cand_dhi;  // only pixels on these diagonals are candidates (diag_trim of the coefficient map)
     int fix_on, fix_hi_w, fix_hi_d0;
     const TC* rowtab;
     const TC* coltab;

@@ -639,6 +639,13 @@ __global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const Corr
 // ================================================================================================
 // host side
 // ================================================================================================
+int launch_decode_keys(const long long* keys, long long n, int ns, int* rows, int* cols, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(decode_keys_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, keys, n, ns, rows, cols);
+    return (int)hipGetLastError();
+}
+
 size_t foci_scratch_bytes(long long n_cand)
 {
     size_t sort_tmp = 0, scan_tmp = 0;
@@ -1051,6 +1058,123 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
         }
     }
     hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, keys, vals, pearson, min_size,
+                       diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
+    hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
+                       f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
+    if (n_total > 0) {
+        const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
+        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(256), 0, stream, tab, f_blk, f_rows, f_cols,
+                           max_foci, d_total, f_score, f_nobs);
+        hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk,
+                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- 2-D patterns of MANY sub-matrices: the candidates arrive as one unsorted list of composite keys
+//      (block << kKeyShift) + row * ns + col, appended by the tile kernels of all blocks ------------------------------
+namespace {
+__global__ __launch_bounds__(kThreads) void keyed_segments_kernel(const long long* __restrict__ keys, long long n, int n_blocks,
+                                                                  int shift, long long* __restrict__ seg)
+{
+    const int b = blockIdx.x * kThreads + threadIdx.x;
+    if (b > n_blocks) return;
+    const long long want = (long long)b << shift;            // first key of block b
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    seg[b] = lo;
+}
+
+__global__ __launch_bounds__(kThreads) void keyed_split_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ keys,
+                                                               long long n, int shift, int* __restrict__ rows, int* __restrict__ cols,
+                                                               int* __restrict__ blk, long long* __restrict__ local)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n) return;
+    const long long key = keys[t];
+    const int b = (int)(key >> shift);
+    const long long rem = key - ((long long)b << shift);
+    const int ns = tab[b].ns;
+    rows[t] = (int)(rem / ns);
+    cols[t] = (int)(rem - (rem / ns) * ns);
+    blk[t] = b;
+    local[t] = rem;                                          // the block's own row-major key
+}
+}  // namespace
+
+size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
+{
+    size_t sort_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)std::max<long long>(n_total, 1));
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
+    return al(sort_tmp) + al(sizeof(CorrArgs<double>) * nb) + 9 * al(8 * n) + 15 * al(4 * n) + 6 * al(8 * nb) + 4096;
+}
+
+// d_keys: n_total composite keys in any order (device).  h_tab: the float64 argument blocks of the sub-matrices.
+// Records (and windows) block after block into rec / windows (device-visible page-locked memory), h_counts[0] = total,
+// h_counts[1 + b] = foci of block b.  Same chain as enqueue_foci_narrow_batch after its enumeration.
+int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
+                             double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
+    Bump b{(char*)scratch};
+    size_t sort_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)n);
+    void* tmp = b.take<char>(al(sort_tmp));
+    CorrArgs<double>* tab = b.take<CorrArgs<double>>(nb);
+    long long* keys_s = b.take<long long>(n);
+    long long* local = b.take<long long>(n);
+    long long* keys_k = b.take<long long>(n);
+    double* vals = b.take<double>(n);
+    double* vals_k = b.take<double>(n);
+    unsigned long long* best_val = b.take<unsigned long long>(n);
+    double* f_score = b.take<double>(n);
+    double* f_nobs = b.take<double>(n);
+    long long* spare = b.take<long long>(n);
+    (void)spare;
+    int* rows = b.take<int>(n);
+    int* cols = b.take<int>(n);
+    int* blk = b.take<int>(n);
+    int* flag = b.take<int>(n);
+    int* pos = b.take<int>(n);
+    int* parent = b.take<int>(n);
+    int* size = b.take<int>(n);
+    int* best_idx = b.take<int>(n);
+    int* s_rows = b.take<int>(n);
+    int* s_cols = b.take<int>(n);
+    int* s_size = b.take<int>(n);
+    int* f_rows = b.take<int>(n);
+    int* f_cols = b.take<int>(n);
+    int* f_size = b.take<int>(n);
+    int* f_blk = b.take<int>(n);
+    long long* seg = b.take<long long>(nb);
+    int* n_kept = reinterpret_cast<int*>(b.take<long long>(nb));
+    long long* n_foci_blk = b.take<long long>(nb);
+    long long* f_off = b.take<long long>(nb);
+    long long* d_total = b.take<long long>(8);
+    hipError_t e = hipMemcpyAsync(tab, h_tab, sizeof(CorrArgs<double>) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    int blk_bits = 1;
+    while ((1 << blk_bits) < n_blocks) ++blk_bits;
+    if (n_total > 0) {
+        e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
+    if (n_total > 0) {
+        const unsigned g = blocks_for(n_total);
+        hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, shift, rows, cols, blk, local);
+        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
+                           (const long long*)nullptr, vals, (double*)nullptr);
+    }
+    hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, local, vals, pearson, min_size,
                        diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
     hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
                        f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);

@@ -202,6 +202,37 @@ int launch_detrend_csr(const CsrView& M, const double* law, int n_law, double ma
                        int n_cu, hipStream_t stream);
 int launch_csr_to_band(const CsrView& M, const double* law, int n_law, double max_val,
                        const MatView& band, int band_dtype, int n_cu, hipStream_t stream);
+// ---- cs_stage.hip: all intra blocks of a genome staged by three launches ------------------------------------
+struct StageBlock {
+    long long row0;          // first genome bin of the block (its rows and its columns start there)
+    int n;                   // bins
+    int keep;                // last kept diagonal (diag_trim)
+    int n_diags;             // entries of the distance law: min(n, keep + 1)
+    int dense;               // 1: dense rows (slot = column), 0: diagonal band from diagonal 0 (slot = diagonal)
+    int width;               // slots that can hold a pixel: n (dense) or n_diags (band)
+    int group0, n_groups;    // filled by enqueue_stage_blocks
+    long long ld;            // row pitch in elements (slots width .. ld - 1 are zero padding)
+    double* band64;          // outputs, either may be null
+    float* band32;
+    double* law;             // n_diags values
+};
+struct StageGroup {
+    int block, row_begin, row_end;
+};
+size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_rows);
+int enqueue_stage_blocks(const long long* indptr, const int* indices, const void* data, int data_is_f64, const double* weight,
+                         long long n_rows, StageBlock* h_blocks, int n_blocks, double max_val, int rows_per_group, int n_cu,
+                         void* scratch, hipStream_t stream);
+
+// 2-D patterns of many sub-matrices: candidates as composite keys (block << shift) + row * ns + col
+size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total);
+int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
+                             double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream);
+
+// row-major keys (row * ns + col) -> coordinates
+int launch_decode_keys(const long long* keys, long long n, int ns, int* rows, int* cols, hipStream_t stream);
+
 int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, double threshold,
                       int lo_diag, int hi_diag, int* rows, int* cols, double* vals, long long cap,
                       long long* count, int n_cu, hipStream_t stream);

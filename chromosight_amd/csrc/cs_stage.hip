@@ -1,0 +1,319 @@
+// cs_stage.hip -- ContactMap.create_mat of ALL intra-chromosomal blocks of a genome in three launches
+// (reference contacts_map.py:527-548, 603-638; preprocessing.py:129-197, 256-310):
+//
+//   stage_law_kernel     balance (count * w[bin1] * w[bin2]), slice the block, trim to the diagonals 0 .. keep, and
+//                        reduce the strictly positive pixels of every diagonal -- one pass over the pixel table
+//   stage_finish_kernel  law[d] = sum / count per block (0 for an empty diagonal)
+//   stage_tile_kernel    detrend by the law, >= max_val -> 1, NaN -> 0, and write the diagonal band (or the dense
+//                        map of a short chromosome) ONCE, in float64 (exact re-scoring, windows) and / or float32
+//                        (what the matrix-core tile kernel stages by LDS-DMA)
+//
+// The pixel table of a .cool (upper triangle of the whole genome, sorted by bin1, bin2) is one CSR matrix whose row
+// r holds the pixels (r, c >= r); the intra block of chromosome b is the prefix of every row up to its last bin, so a
+// "view" needs no copy and no binary search: a wave walks the row until the column leaves the band.
+//
+// Why these and not one launch chain per block (cs_aux.hip, still used for inter blocks, row windows, smoothing):
+// a genome is 23 blocks of 3 000 - 16 000 rows; per block the old chain is 4 launches that each under-fill the chip,
+// and its kernels were bound by latency, not by HBM (distance_law_kernel 1.25 TB/s: one dependent load chain per
+// wave and 16 waves per CU).  Here work is cut into groups of 128 rows of one block, workgroups take groups in
+// order, every wave keeps 4 x 64 pixels in flight, partial sums live in LDS and leave the workgroup as plain stores
+// (one slot per group, summed by stage_finish_kernel in a fixed order: no global atomics).
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "cs_device.h"
+#include "cs_launch_aux.h"
+
+namespace cs {
+
+namespace {
+
+constexpr int kStageThreads = 512;
+constexpr int kStageWaves = kStageThreads / 64;
+
+__device__ __forceinline__ double stage_detrend(double v, double y, double max_val)
+{
+    double out = v / y;                                    // law 0 (empty diagonal) -> inf / NaN, as preprocessing.py:298
+    if (max_val > 0.0 && out >= max_val) out = 1.0;        // :301-302
+    return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
+}
+
+template <typename TV, int kStageUnroll>
+__global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                                  const TV* __restrict__ data, const double* __restrict__ weight,
+                                                                  const StageBlock* __restrict__ blocks,
+                                                                  const StageGroup* __restrict__ groups, int n_groups, int pitch,
+                                                                  double* __restrict__ part_sum, unsigned* __restrict__ part_cnt,
+                                                                  long long* __restrict__ row_stop)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* l_sum = reinterpret_cast<double*>(smem_raw);
+    unsigned* l_cnt = reinterpret_cast<unsigned*>(smem_raw + sizeof(double) * (size_t)pitch);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const StageGroup G = groups[g];
+        const StageBlock B = blocks[G.block];
+        for (int d = tid; d < B.n_diags; d += kStageThreads) {
+            l_sum[d] = 0.0;
+            l_cnt[d] = 0u;
+        }
+        __syncthreads();
+        const long long last_col = B.row0 + B.n - 1;
+        for (int rl = G.row_begin + wv; rl < G.row_end; rl += kStageWaves) {
+            const long long r = B.row0 + rl;
+            const double wr = weight[r];
+            const long long b = indptr[r];
+            const long long e = min(indptr[r + 1], b + (long long)B.keep + 1);       // columns are distinct and >= r
+            const long long c_hi = min(r + (long long)B.keep, last_col);
+            int n_in = 0;
+            for (long long k0 = b + lane; k0 - lane < e; k0 += 64 * kStageUnroll) {
+                long long c[kStageUnroll];
+                double x[kStageUnroll], wc[kStageUnroll];
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; ++u) {
+                    const long long k = k0 + 64 * u;
+                    const bool ok = k < e;
+                    c[u] = ok ? (long long)indices[k] : (long long)(1ll << 40);
+                    x[u] = ok ? (double)data[k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; ++u) wc[u] = c[u] <= c_hi ? weight[c[u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; ++u) {
+                    const bool in = c[u] <= c_hi;
+                    n_in += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                    const double v = (x[u] * wr) * wc[u];             // csr_value: cooler's matrix(balance=True)
+                    if (in && v > 0.0) {                              // also drops NaN (preprocessing.py:188)
+                        const int d = (int)(c[u] - r);
+                        atomicAdd(&l_sum[d], v);
+                        atomicAdd(&l_cnt[d], 1u);
+                    }
+                }
+            }
+            if (lane == 0) row_stop[r] = b + n_in;
+        }
+        __syncthreads();
+        for (int d = tid; d < B.n_diags; d += kStageThreads) {
+            part_sum[(size_t)g * pitch + d] = l_sum[d];
+            part_cnt[(size_t)g * pitch + d] = l_cnt[d];
+        }
+        __syncthreads();
+    }
+}
+
+// 64 diagonals x 4 group phases per workgroup: the partial sums of a block's groups are added in a fixed order
+// (phase by phase, then the four phases), so a law does not depend on how the groups were scheduled
+__global__ __launch_bounds__(256) void stage_finish_kernel(const StageBlock* __restrict__ blocks, int pitch,
+                                                           const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt)
+{
+    __shared__ double s_sum[4][64];
+    __shared__ unsigned long long s_cnt[4][64];
+    const StageBlock B = blocks[blockIdx.x];
+    const int dx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int d = blockIdx.y * 64 + dx;
+    double s = 0.0;
+    unsigned long long c = 0;
+    if (d < B.n_diags) {
+        for (int g = B.group0 + ph; g < B.group0 + B.n_groups; g += 4) {
+            s += part_sum[(size_t)g * pitch + d];
+            c += part_cnt[(size_t)g * pitch + d];
+        }
+    }
+    s_sum[ph][dx] = s;
+    s_cnt[ph][dx] = c;
+    __syncthreads();
+    if (ph == 0 && d < B.n_diags) {
+        s = ((s_sum[0][dx] + s_sum[1][dx]) + s_sum[2][dx]) + s_sum[3][dx];
+        c = s_cnt[0][dx] + s_cnt[1][dx] + s_cnt[2][dx] + s_cnt[3][dx];
+        B.law[d] = c > 0 ? s / (double)c : 0.0;             // cs_distance_law_finish
+    }
+}
+
+// A block's rows are written exactly once.  A wave builds its row in LDS -- zero it, scatter the detrended stored pixels
+// into their slots (slot = diagonal of a band, column of a dense block) -- and streams it out with 16-byte-per-lane
+// stores (1 KB per instruction, float64 and float32 copies from the same LDS row).  Writing gaps from the lane that holds
+// the previous stored pixel (the first version, and cs_aux.hip's block-by-block tiler) turns a sparse row -- Hi-C rows
+// ARE sparse away from the diagonal: 60 % of the slots of the bench genome are gaps -- into thousands of divergent
+// single-element stores: 3.1 ms for the 23-block genome (1.0 TB/s), against 0.3 ms for the same reads in the law kernel.
+// Rows are built in pieces of kStageRowMax slots (columns are sorted: a piece continues where the last one stopped), which
+// keeps three workgroups per CU resident.
+constexpr int kStageRowMax = 576;                // slots per LDS row piece: 4.5 KB per wave, 36 KB per workgroup of 8 waves
+
+__device__ __forceinline__ void stage_wave_sync()
+{
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename TV, int kStageUnroll>
+__global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                                   const TV* __restrict__ data, const double* __restrict__ weight,
+                                                                   const StageBlock* __restrict__ blocks,
+                                                                   const StageGroup* __restrict__ groups, int n_groups, int pitch,
+                                                                   const long long* __restrict__ row_stop, double max_val)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* l_law = reinterpret_cast<double*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* l_row = reinterpret_cast<double*>(smem_raw + sizeof(double) * (size_t)pitch) + (size_t)wv * kStageRowMax;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const StageGroup G = groups[g];
+        const StageBlock B = blocks[G.block];
+        __syncthreads();
+        for (int d = tid; d < B.n_diags; d += kStageThreads) l_law[d] = B.law[d];
+        __syncthreads();
+        const int ld = (int)B.ld;
+        for (int rl = G.row_begin + wv; rl < G.row_end; rl += kStageWaves) {
+            const long long r = B.row0 + rl;
+            const double wr = weight[r];
+            const long long b = indptr[r], e = row_stop[r];
+            double* out64 = B.band64 ? B.band64 + (size_t)rl * B.ld : nullptr;
+            float* out32 = B.band32 ? B.band32 + (size_t)rl * B.ld : nullptr;
+            const long long x0 = B.dense ? B.row0 : r;                  // slot of column c: c - x0
+            long long k_next = b;                                       // first stored pixel not yet placed
+            for (int s0 = 0; s0 < ld; s0 += kStageRowMax) {             // pieces of the row
+                const int s1 = min(ld, s0 + kStageRowMax);
+                for (int x = 2 * lane; x < s1 - s0; x += 128) *reinterpret_cast<d2*>(l_row + x) = d2{0.0, 0.0};
+                stage_wave_sync();
+                // stored pixels whose slot falls in [s0, s1): columns are sorted, so they are a run starting at k_next
+                const long long c_end = x0 + s1;                        // first column beyond the piece
+                int placed = 0;
+                for (long long k0 = k_next + lane; k0 - lane < e; k0 += 64 * kStageUnroll) {
+                    long long c[kStageUnroll];
+                    double x[kStageUnroll], wc[kStageUnroll];
+#pragma unroll
+                    for (int u = 0; u < kStageUnroll; ++u) {
+                        const long long k = k0 + 64 * u;
+                        const bool ok = k < e;
+                        c[u] = ok ? (long long)indices[k] : (long long)(1ll << 40);
+                        x[u] = ok ? (double)data[k] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kStageUnroll; ++u) wc[u] = c[u] < c_end ? weight[c[u]] : 0.0;
+                    bool more = true;
+#pragma unroll
+                    for (int u = 0; u < kStageUnroll; ++u) {
+                        const bool in = c[u] < c_end;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                        placed += __builtin_popcountll(m);
+                        if (in) {
+                            const int d = (int)(c[u] - r);
+                            l_row[(int)(c[u] - x0) - s0] = stage_detrend((x[u] * wr) * wc[u], d < B.n_diags ? l_law[d] : 0.0, max_val);
+                        }
+                        more = more && (m == ~0ull);                    // a lane beyond the piece (or the row): this piece is complete
+                    }
+                    if (!more) break;
+                }
+                k_next += placed;
+                stage_wave_sync();
+                // out: 4 slots per lane and instruction (ld is a multiple of 16, rows start 128-byte aligned)
+                for (int x = 4 * lane; x < s1 - s0; x += 256) {
+                    const d2 a = *reinterpret_cast<const d2*>(l_row + x), c2 = *reinterpret_cast<const d2*>(l_row + x + 2);
+                    if (out64) {
+                        *reinterpret_cast<d2*>(out64 + s0 + x) = a;
+                        *reinterpret_cast<d2*>(out64 + s0 + x + 2) = c2;
+                    }
+                    if (out32) *reinterpret_cast<f4*>(out32 + s0 + x) = f4{(float)a[0], (float)a[1], (float)c2[0], (float)c2[1]};
+                }
+                stage_wave_sync();
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_rows)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(sizeof(StageBlock) * (size_t)n_blocks) + al(sizeof(StageGroup) * (size_t)n_groups) +
+           al(sizeof(double) * (size_t)n_groups * pitch) + al(sizeof(unsigned) * (size_t)n_groups * pitch) +
+           al(sizeof(long long) * (size_t)n_rows) + 1024;
+}
+
+// h_blocks: group0 / n_groups are filled here.  Everything is enqueued on `stream`; `scratch` holds
+// stage_scratch_bytes(...) bytes and must stay untouched until the stream has drained.
+int enqueue_stage_blocks(const long long* indptr, const int* indices, const void* data, int data_is_f64, const double* weight,
+                         long long n_rows, StageBlock* h_blocks, int n_blocks, double max_val, int rows_per_group, int n_cu,
+                         void* scratch, hipStream_t stream)
+{
+    std::vector<StageGroup> groups;
+    int pitch = 1;
+    for (int b = 0; b < n_blocks; ++b) {
+        StageBlock& B = h_blocks[b];
+        B.group0 = (int)groups.size();
+        for (int r0 = 0; r0 < B.n; r0 += rows_per_group) groups.push_back(StageGroup{b, r0, std::min(B.n, r0 + rows_per_group)});
+        B.n_groups = (int)groups.size() - B.group0;
+        pitch = std::max(pitch, B.n_diags);
+    }
+    const int n_groups = (int)groups.size();
+    if (n_groups == 0) return 0;
+    pitch = (pitch + 63) / 64 * 64;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char* p = (char*)scratch;
+    StageBlock* d_blocks = (StageBlock*)p;
+    p += al(sizeof(StageBlock) * (size_t)n_blocks);
+    StageGroup* d_groups = (StageGroup*)p;
+    p += al(sizeof(StageGroup) * (size_t)n_groups);
+    double* part_sum = (double*)p;
+    p += al(sizeof(double) * (size_t)n_groups * pitch);
+    unsigned* part_cnt = (unsigned*)p;
+    p += al(sizeof(unsigned) * (size_t)n_groups * pitch);
+    long long* row_stop = (long long*)p;
+    hipError_t e = hipMemcpyAsync(d_blocks, h_blocks, sizeof(StageBlock) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(d_groups, groups.data(), sizeof(StageGroup) * (size_t)n_groups, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    // the group table lives in pageable host memory that dies with this call: the copy above must have read it
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return (int)e;
+    const int per_cu = getenv("CHROMOSIGHT_HIP_STAGE_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_GRID")) : 4;
+    const int unroll = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL")) : 4;
+    const int grid = std::min(n_groups, per_cu * n_cu);
+    const size_t smem_law = (sizeof(double) + sizeof(unsigned)) * (size_t)pitch;
+    const size_t smem_tile = sizeof(double) * ((size_t)pitch + (size_t)kStageWaves * kStageRowMax);
+    int max_b = 0;
+    for (int b = 0; b < n_blocks; ++b) max_b = std::max(max_b, h_blocks[b].n_diags);
+#define CS_STAGE_LAW(TV, U)                                                                                                       \
+    hipLaunchKernelGGL((stage_law_kernel<TV, U>), dim3(grid), dim3(kStageThreads), smem_law, stream, indptr, indices, (const TV*)data, \
+                       weight, d_blocks, d_groups, n_groups, pitch, part_sum, part_cnt, row_stop)
+#define CS_STAGE_TILE(TV, U)                                                                                                       \
+    do {                                                                                                                           \
+        if (smem_tile > 48 * 1024)                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)stage_tile_kernel<TV, U>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                                      160 * 1024);                                                                                 \
+        hipLaunchKernelGGL((stage_tile_kernel<TV, U>), dim3(grid), dim3(kStageThreads), smem_tile, stream, indptr, indices,          \
+                           (const TV*)data, weight, d_blocks, d_groups, n_groups, pitch, row_stop, max_val);                        \
+    } while (0)
+#define CS_STAGE_BOTH(WHAT)                      \
+    if (data_is_f64) {                           \
+        if (unroll >= 8) WHAT(double, 8);        \
+        else if (unroll >= 4) WHAT(double, 4);   \
+        else WHAT(double, 2);                    \
+    } else {                                     \
+        if (unroll >= 8) WHAT(float, 8);         \
+        else if (unroll >= 4) WHAT(float, 4);    \
+        else WHAT(float, 2);                     \
+    }
+    const char* skip = getenv("CHROMOSIGHT_HIP_STAGE_SKIP");      // diagnostics: "law" / "tile" leave that kernel out
+    if (!(skip && skip[0] == 'l')) {
+        CS_STAGE_BOTH(CS_STAGE_LAW)
+    }
+    hipLaunchKernelGGL(stage_finish_kernel, dim3(n_blocks, (max_b + 63) / 64), dim3(256), 0, stream, d_blocks, pitch, part_sum,
+                       part_cnt);
+    if (!(skip && skip[0] == 't')) {
+        CS_STAGE_BOTH(CS_STAGE_TILE)
+    }
+#undef CS_STAGE_BOTH
+#undef CS_STAGE_LAW
+#undef CS_STAGE_TILE
+    (void)n_rows;
+    return (int)hipGetLastError();
+}
+
+}  // namespace cs

@@ -242,6 +242,46 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
     return out
 
 
+def run_detect_foci_blocks(dev, sigs, sigs32, shapes, kspec, *, pearson, lo_diags, hi_diags, inter, diag_only, max_dists, miss_rows,
+                           miss_cols, missing_tol=0.75, want_windows=True, min_size=2, stream=None, precision=None):
+    """detect mode of one template on MANY sub-matrices with one native call (cs_detect_foci_blocks): 2-D scans on the masked
+    matrix-core tile kernel in candidate mode, one candidate list, one foci chain; 1-D scans are passed on to the narrow batch.
+    sigs32: the float32 twins of the float64 maps (entries may be None).  Returns (records, windows, counts) -- the records of
+    all blocks one block after the other -- or None when the library says a block does not qualify (caller: block by block)."""
+    if (precision or _precision) == "f64" or float(pearson) <= LOW_PEARSON_F64:
+        return None
+    n_blocks = len(sigs)
+    sig_arr = (_lib.CsMatrix * n_blocks)(*sigs)
+    s32_arr = None
+    if sigs32 is not None and any(s is not None for s in sigs32):
+        s32_arr = (_lib.CsMatrix * n_blocks)(*[s if s is not None else _lib.CsMatrix(None, CS_F32, 0, 0, 0, 0, 0) for s in sigs32])
+    par_arr = (CsNormxcorr2Params * n_blocks)(*[
+        _corr_params(shapes[b], kspec, True, not inter, max_dists[b], MASK_BINS, miss_rows[b], miss_cols[b], None, missing_tol, CS_F32)
+        for b in range(n_blocks)])
+    fp_arr = (CsFociParams * n_blocks)(*[
+        CsFociParams(float(pearson), rescore_margin(pearson), int(min_size), int(bool(diag_only)), int(lo_diags[b]), int(hi_diags[b]),
+                     int(bool(inter)), int(bool(want_windows))) for b in range(n_blocks)])
+    counts = (C.c_int64 * n_blocks)()
+    kk = kspec.km * kspec.kn
+    cap = 4096
+    while True:
+        rec, win = _host_buffers(dev, cap, kk, want_windows)
+        cap = rec.shape[0]
+        rc = dev.lib.cs_detect_foci_blocks(dev.ctx, stream, n_blocks, sig_arr, s32_arr, C.byref(kspec.struct), par_arr, fp_arr,
+                                           rec.ctypes.data, cap, counts, win.ctypes.data if want_windows else None)
+        if rc == -3:
+            return None
+        if rc == -4 and sum(counts) > cap:
+            cap = int(sum(counts)) + int(sum(counts)) // 4
+            continue
+        dev._check(rc)
+        break
+    cnt = np.frombuffer(counts, dtype=np.int64).copy()
+    total = int(cnt.sum())
+    windows = win.reshape(-1)[:total * kk].reshape(total, kspec.km, kspec.kn).copy() if want_windows else None
+    return rec[:total].copy(), windows, cnt
+
+
 def run_candidates(dev, sig, shape, kspec, row_window, *, pearson, lo_diag, hi_diag, inter, full, sym_upper, max_dist,
                    mask_mode=MASK_NONE, miss_row=None, miss_col=None, missing_tol=0.75, precision=None, stream=None,
                    **_unused):

@@ -210,8 +210,22 @@ def _gather(records, n_fields):
     return merged[np.argsort(merged[:, 0], kind="stable")]
 
 
+def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np.float64):
+    """Stage this rank's blocks ONCE for several pattern configurations (detect_genome(..., staged=...)): at the longest
+    keep distance any of them needs; the others scan band views of the same blocks (DeviceCool.view_for).  Returns
+    {chromosome: StagedBlock}."""
+    dist, rank, world = _world()
+    max_dist = max(max(cfg["max_dist"] // genome.binsize, 1) for cfg in kernel_configs)
+    largest = max(max(np.shape(k)[0] for k in cfg["kernels"]) for cfg in kernel_configs)
+    if owned is None:
+        costs = [block_cost((genome.chrom_size(ci),) * 2, max_dist, False) for ci in range(genome.n_chrom)]
+        owned = assign_blocks(costs, world)[rank]
+    owned = list(owned)
+    return dict(zip(owned, genome.stage_blocks(owned, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
+
+
 def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, stage=None, detect=None,
-                  owned=None):
+                  owned=None, staged=None):
     """`chromosight detect` over all intra-chromosomal blocks of a DeviceCool, sharded over the ranks
     like the reference's Pool.imap over sub-matrices (cli/chromosight.py:738-755): every rank stages
     and scans its own blocks (LPT assignment by band pixels), the per-block tables are all-gathered
@@ -223,6 +237,8 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     `detect(genome, block, cfg, kernel, tsvd)` default to the device pipeline (injected in CPU tests).
     `owned`: this rank's block indices when the caller fixed the assignment (e.g. a rank that only
     holds the pixels of its own chromosomes); default: LPT by scanned pixels.
+    `staged`: blocks of stage_genome (staged once for several patterns); a block that cannot serve this configuration
+    through a band view is staged here as usual.
     Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
     bins, identical on all ranks, in the single-process order."""
     batch = None
@@ -241,11 +257,23 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     sizes = [genome.chrom_size(ci) for ci in range(genome.n_chrom)]
     costs = [block_cost((n, n), max_dist, False) for n in sizes]
     mine = list(owned) if owned is not None else assign_blocks(costs, world)[rank]
+    have = {}
+    if staged is not None and not smooth:
+        for ci in mine:
+            blk = staged.get(ci)
+            if blk is None:
+                continue
+            view = blk if (blk.max_dist == max_dist and blk.keep == min(max_dist, genome.chrom_size(ci)) + largest) \
+                else genome.view_for(blk, max_dist, largest)
+            if view is not None:
+                have[ci] = view
+    todo = [ci for ci in mine if ci not in have]
     if batch is not None and stage_default:
-        # the device pipeline stages its blocks a few at a time (pipeline.DeviceCool.stage_blocks)
-        staged = dict(zip(mine, genome.stage_blocks(mine, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
+        # the device pipeline stages its blocks with one native call (pipeline.DeviceCool.stage_blocks)
+        fresh = dict(zip(todo, genome.stage_blocks(todo, max_dist, largest, smooth=smooth, band_dtype=band_dtype))) if todo else {}
     else:
-        staged = {ci: stage(genome, ci, max_dist, largest) for ci in mine}
+        fresh = {ci: stage(genome, ci, max_dist, largest) for ci in todo}
+    staged = {**have, **fresh}
     out = []
     one_exchange = kernel_config["max_iterations"] == 1 and world > 1      # no template depends on another's records
     pending = []

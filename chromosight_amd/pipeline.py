@@ -20,7 +20,7 @@ import pandas as pd
 import scipy.sparse as sp
 
 from . import engine
-from ._lib import CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, CsCsr, CsMatrix, get_device, np_dtype_code
+from ._lib import CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, CsCsr, CsMatrix, CsStageBlock, get_device, np_dtype_code
 from .utils import detection as cid
 from .utils import preprocessing as preproc
 from .utils.stats import fdr_correction
@@ -170,6 +170,17 @@ class _Scratch:
         return self.buf.ptr
 
 
+def _pitch(width, quantum):
+    """Row pitch (elements) of a staged map: `width` rounded up to `quantum`, and never a multiple of 4 KiB in float64 --
+    with a power-of-two pitch the same slot of every row lies on the same memory channels, and the waves of the staging and
+    tile kernels, which sweep their rows at the same pace, all hit those few channels at once (measured: the tiler of the
+    23-block genome 2.9 -> see DESIGN.md)."""
+    ld = (int(width) + quantum - 1) // quantum * quantum
+    if (ld * 8) % 4096 == 0:
+        ld += quantum
+    return ld
+
+
 class _FreeList:
     """Device buffers of released blocks, best fit first; every access under one lock (blocks are released by the
     garbage collector on whatever thread drops the last reference, taken by the staging threads)."""
@@ -201,6 +212,7 @@ class StagedBlock:
         self.max_dist, self.inter, self.keep = max_dist, inter, keep
         self.buffer, self.pool = None, None
         self.row_window = None          # (a, b): the block holds only these rows (+ halo) of the sub-matrix
+        self.sig32 = None               # the same map in float32 (same layout), written by the same staging pass
 
     def __del__(self):
         # a resident block hands its HBM back to the genome's free list (hipFree synchronises and costs
@@ -211,6 +223,8 @@ class StagedBlock:
         try:
             if self.buffer is not None and self.pool is not None:
                 self.pool.release(self.buffer)
+                if getattr(self, "buffer32", None) is not None:
+                    self.pool.release(self.buffer32)
         except Exception:
             pass
 
@@ -293,8 +307,11 @@ class DeviceCool:
         self.host = {"binsize": self.binsize, "chrom_offset": off, "chrom_names": np.asarray(self.names), "bin1_id": b1,
                      "bin2_id": b2, "count": cnt, "weight": weight, "bin_start": self.bin_start, "bin_end": self.bin_end}
         self.upload_bytes = self.indptr.nbytes + self.indices.nbytes + self.data.nbytes + self.weight.nbytes
+        # what cs_stage_blocks needs: every stored pixel on or above the diagonal (a .cool's symmetric-upper storage)
+        self.upper = bool(b1.size == 0 or np.all(b2 >= b1))
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
+        self._laws = _Scratch(dev)
         self._free = _FreeList()        # HBM of released resident blocks, reused by the next staging
         self._workers = None
 
@@ -308,6 +325,9 @@ class DeviceCool:
         measured slower than ONE stream on the 23-block genome (the hand-over costs two synchronisations per block).
         Every block's staging is complete on return."""
         chroms = list(chroms)
+        fast = self._stage_fast(chroms, max_dist, largest_kernel, **options)
+        if fast is not None:
+            return fast
         if workers <= 1 or len(chroms) <= 1:
             # one host thread, the blocks dealt to a few streams of this context (each with its own extent scratch):
             # a block's chain is 7 short launches that leave most of the chip idle, the chains of different blocks
@@ -339,6 +359,77 @@ class DeviceCool:
             return block
 
         return pool.map(one, chroms)
+
+    def _stage_fast(self, chroms, max_dist, largest_kernel, smooth=False, band_dtype=np.float64, reduce=None, rows=None,
+                    stream=None, **unused):
+        """All the given chromosomes with ONE native call (cs_stage_blocks: three launches for the whole genome -- a
+        pass over the pixel table for the distance laws, the laws' finish, and the detrend / tiler that writes every
+        block once in float64 (exact re-scoring, windows) and float32 (what the matrix-core kernel stages)); None when
+        an option needs the block-by-block path (isotonic smoothing, a block split over ranks, float32-only bands)."""
+        if (smooth or reduce is not None or rows is not None or unused or not self.upper or not chroms
+                or np.dtype(band_dtype) != np.float64 or os.environ.get("CHROMOSIGHT_HIP_NO_STAGE_BATCH")):
+            return None
+        dev, lib = self.dev, self.dev.lib
+        geo = []
+        for ci in chroms:
+            s, e = int(self.offsets[ci]), int(self.offsets[ci + 1])
+            n = e - s
+            keep = min(max_dist, n) + largest_kernel
+            n_diags = min(n, keep + 1)
+            if n_diags > 4096:
+                return None
+            in_w = min(keep, n - 1) + 1
+            out_w = min(max_dist, n - 1) + 1
+            band = 2 * max(in_w, out_w) < n
+            ld = _pitch(in_w, 64) if band else _pitch(n, 16)
+            geo.append((ci, s, n, keep, n_diags, in_w, band, ld))
+        laws = self._laws.get(8 * sum(g[4] for g in geo) + 256)
+        table = (CsStageBlock * len(geo))()
+        blocks, off = [], 0
+        for k, (ci, s, n, keep, n_diags, in_w, band, ld) in enumerate(geo):
+            b64 = self._resident(n * ld * 8)
+            b32 = self._resident(n * ld * 4)
+            table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND if band else LAYOUT_DENSE, in_w if band else 0, ld, b64.ptr, b32.ptr,
+                                    laws + off)
+            off += 8 * n_diags
+            layout = LAYOUT_BAND if band else LAYOUT_DENSE
+            flags = _Ptr(self.miss.ptr + s)
+            blk = StagedBlock(self.names[ci], CsMatrix(b64.ptr, CS_F64, layout, ld, 0, in_w if band else 0, 0), (n, n), flags, flags,
+                              max_dist, False, keep)
+            blk.sig32 = CsMatrix(b32.ptr, CS_F32, layout, ld, 0, in_w if band else 0, 0)
+            blk.buffer, blk.pool = b64, self._free
+            blk.buffer32 = b32
+            blocks.append(blk)
+        genome = CsCsr(self.n_bins, self.n_bins, max(self.nnz, 1), self.indptr.ptr, self.indices.ptr, self.data.ptr,
+                       np_dtype_code(self.val_dtype), 0, None, self.weight.ptr, self.weight.ptr)
+        dev._check(lib.cs_stage_blocks(dev.ctx, stream, C.byref(genome), table, len(geo), 10.0))
+        dev.sync(stream)
+        return blocks
+
+    def view_for(self, block, max_dist, largest_kernel):
+        """The staged block of the same chromosome for a pattern with a shorter scanning distance, WITHOUT staging it again:
+        ContactMap.create_mat with keep' = min(max_dist, n) + largest_kernel <= keep is the band of the first keep' + 1
+        diagonals of the block staged with `keep` -- the distance law of a diagonal does not depend on how many others are
+        kept (preprocessing.py:173-188, without --smooth-trend), so the detrended values are the same numbers, and a band
+        view with fewer stored diagonals reads every pixel beyond them as 0 (diag_trim).  None when a view cannot stand in
+        (dense-staged short chromosomes, row windows, a longer distance than the block holds)."""
+        n = block.shape[0]
+        keep = min(max_dist, n) + largest_kernel
+        if (block.inter or block.sig.layout != LAYOUT_BAND or getattr(block, "row_window", None) is not None
+                or block.keep is None or keep > block.keep or getattr(block, "smooth", False)):
+            return None
+        in_w = min(keep, n - 1) + 1
+        out_w = min(max_dist, n - 1) + 1
+        if not 2 * max(in_w, out_w) < n:
+            return None                              # this pattern would have been staged dense: keep the layouts identical
+        s = block.sig
+        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, LAYOUT_BAND, s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
+                           block.miss_col, max_dist, False, keep)
+        if block.sig32 is not None:
+            t = block.sig32
+            view.sig32 = CsMatrix(t.d_ptr, t.dtype, LAYOUT_BAND, t.ld, 0, in_w, t.row0)
+        view.parent = block                          # keeps the buffers alive; the view owns none
+        return view
 
     def workers(self, n=4):
         # process-wide: the workers' contexts, streams and scratch outlive this DeviceCool (creating them costs
@@ -424,7 +515,7 @@ class DeviceCool:
             d_law = d_sum                                     # finished in place
             dev._check(lib.cs_distance_law_finish(dev.ctx, stream, d_sum, d_cnt, n_diags, d_law))
         esz = np.dtype(band_dtype).itemsize
-        ld = (in_w + 63) // 64 * 64 if band else (n + 15) // 16 * 16
+        ld = _pitch(in_w, 64) if band else _pitch(n, 16)
         # resident: the block owns its buffer (288 GB of HBM hold every block of a genome at once, so
         # blocks are staged once and reused by all templates / iterations); else a shared scratch
         buf = self._resident(m * ld * esz, dev) if resident else None
@@ -435,6 +526,7 @@ class DeviceCool:
         block = StagedBlock(name or self.names[ci], sig, (n, n), flags, flags, max_dist, False, keep)
         block.buffer, block.pool = buf, self._free
         block.row_window = (a, b) if split else None
+        block.smooth = bool(smooth)
         return block
 
     def stage_inter(self, ca, cb, name=None, stream=None, resident=False, dtype=np.float64):
@@ -565,6 +657,21 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
         banded = [k for k in live if b_is_band(blocks[k])]
         res = cid.detect_many_on_device(dcool.dev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
                                         raw=raw, want_windows=want_windows) if len(banded) > 1 else None
+        if res is not None:
+            out = [(None, None)] * len(blocks)
+            for k, r in zip(banded, res):
+                out[k] = r
+            for k in live:
+                if k not in banded:
+                    out[k] = detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
+            return out
+    if len(blocks) > 1 and raw and batch and kernel_config["max_dist"] != 0 and not os.environ.get("CHROMOSIGHT_HIP_NO_BLOCK_BATCH"):
+        # 2-D patterns: every banded sub-matrix in ONE native call (tile kernels in candidate mode, one candidate list, one
+        # foci chain); what the library cannot batch (dense-staged short chromosomes, small blocks) goes one by one
+        live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
+        banded = [k for k in live if b_is_band(blocks[k])]
+        res = cid.detect_blocks_on_device(dcool.dev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
+                                          want_windows=want_windows) if len(banded) > 1 and tsvd is None else None
         if res is not None:
             out = [(None, None)] * len(blocks)
             for k, r in zip(banded, res):

@@ -670,6 +670,29 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     return out
 
 
+def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, stream=None):
+    """detect_on_device (raw tables) for a 2-D pattern on many banded intra sub-matrices with ONE native call
+    (cs_detect_foci_blocks: tile kernels in candidate mode -> one candidate list -> one foci chain): `blocks` = objects with
+    sig, sig32, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).  Returns the list of raw (table, windows) per
+    block, or None when the batch entry does not apply (caller: one call per block)."""
+    if not blocks or kspec.km != kspec.kn or kernel_config["max_dist"] == 0:
+        return None
+    if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None or b.sig.layout != LAYOUT_BAND for b in blocks):
+        return None
+    res = engine.run_detect_foci_blocks(
+        dev, [b.sig for b in blocks], [getattr(b, "sig32", None) for b in blocks], [b.shape for b in blocks], kspec,
+        pearson=kernel_config["pearson"], lo_diags=[0] * len(blocks), hi_diags=[b.max_dist for b in blocks], inter=False,
+        diag_only=False, max_dists=[b.max_dist for b in blocks], miss_rows=[b.miss_row for b in blocks],
+        miss_cols=[b.miss_col for b in blocks], missing_tol=kernel_config["max_perc_undetected"] / 100,
+        want_windows=want_windows, stream=stream)
+    if res is None:
+        return None
+    rec, windows, counts = res
+    if int(np.sum(counts)) == 0:
+        return [(None, None)] * len(blocks)
+    return accept_many(blocks, rec, windows, counts, kspec, kernel_config)
+
+
 def accept_many(blocks, rec, windows, counts, kspec, kernel_config):
     """The acceptance rules (detect mode, full maps) on the records of SEVERAL intra sub-matrices at once -- `rec` /
     `windows`: the records of `blocks` one block after the other, `counts` per block -- then cut at the block

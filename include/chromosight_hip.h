@@ -237,6 +237,29 @@ int cs_csr_band_extent(cs_ctx* ctx, void* stream, const cs_csr* mat, int32_t lo_
 int cs_distance_law_finish(cs_ctx* ctx, void* stream, const double* d_sum, const int64_t* d_cnt,
                            int32_t n_diags, double* d_law);
 
+/* ContactMap.create_mat of MANY intra-chromosomal blocks of one genome with three launches (contacts_map.py:527-548,
+ * 603-638; preprocessing.py:129-197, 256-310): balance, slice, trim to the diagonals 0 .. keep, per-block distance law,
+ * detrend, >= max_val -> 1, NaN -> 0, and the band (or dense map) written once in float64 and / or float32.
+ * `genome`: the pixel table of the whole genome as ONE CSR (what a .cool stores: upper triangle sorted by bin1, bin2;
+ * n_rows = n_cols = bins, col0 = 0, d_row_end NULL, d_row_weight = d_col_weight = the ICE weights, NaN = undetectable;
+ * every stored column must be >= its row).  blocks[b]: rows and columns row0 .. row0 + n - 1; layout CS_LAYOUT_BAND
+ * (band_lo 0, band_w = min(keep, n - 1) + 1 diagonals) or CS_LAYOUT_DENSE (n columns); ld >= width, the padding is
+ * zeroed; d_band64 / d_band32 (either may be NULL) n * ld elements; d_law min(n, keep + 1) float64 (the law, 0 for an
+ * empty diagonal).  Laws longer than 4096 diagonals: CS_ERR_UNSUPPORTED (use the per-block entry points). */
+typedef struct {
+    int64_t row0;
+    int32_t n;
+    int32_t keep;
+    int32_t layout;
+    int32_t band_w;
+    int64_t ld;
+    void* d_band64;
+    void* d_band32;
+    double* d_law;
+} cs_stage_block;
+int cs_stage_blocks(cs_ctx* ctx, void* stream, const cs_csr* genome, const cs_stage_block* blocks, int32_t n_blocks,
+                    double max_val);
+
 /* Median of the stored values of a CSR view, NaN counted as 0 (np.nanmedian after the NaN -> 0 of
  * contacts_map.py:598-601 preprocess_inter_matrix, which divides an inter-chromosomal block by it).
  * Balanced on the fly like every view.  *h_median = NaN for an empty view.  Synchronous. */
@@ -291,6 +314,18 @@ int cs_detect_foci(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_
 int cs_detect_foci_batch(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
                          const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci, int64_t cap,
                          int64_t* h_n_foci, double* h_windows);
+
+/* The same for ANY pattern: blocks whose scan is a band of diagonals (loops, stripes) run the masked matrix-core tile
+ * kernel in candidate mode -- every block's kernel appends its candidate pixels to one list -- followed by one sort, one
+ * float64 re-scoring, one labelling workgroup per block and one statistics pass for all blocks; batches of 1-D patterns
+ * are passed on to cs_detect_foci_batch.  signals: the float64 maps (exact scores, windows); signals_f32 (may be NULL,
+ * entries may have a NULL d_ptr): the same maps in float32 with the same layout, what the tile kernel stages (a float64
+ * map is rounded into context scratch first when it has no float32 twin).  Per-bin masks, float32 arithmetic, whole
+ * blocks; CS_ERR_UNSUPPORTED when a block is not served by the tile kernel (template size, layout): the caller then
+ * uses cs_detect_foci block by block.  Outputs as cs_detect_foci_batch. */
+int cs_detect_foci_blocks(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_matrix* signals_f32,
+                          const cs_kernel* kernel, const cs_normxcorr2_params* params, const cs_foci_params* foci,
+                          cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows);
 
 /* `quantify` mode (detection.py:277, 297-298): score, n_obs and window statistics at n given pixels
  * (host int32 arrays).  h_out: n records in input order; h_windows: n * km * kn float64 or NULL. */

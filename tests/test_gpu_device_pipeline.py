@@ -65,6 +65,39 @@ def test_fused_tiler_matches_reference_prepared_blocks(golden):
             assert np.array_equal(dcool.block_bins(ci), g[f"chr{ci}_det"])
 
 
+def test_batched_staging_matches_reference_and_the_block_by_block_path(golden):
+    """cs_stage_blocks (all chromosomes by three launches: law pass, finish, detrend / tiler with float64 + float32
+    outputs) == the reference's prepared blocks (<= 1e-11), == the block-by-block kernels bit for bit up to the
+    summation order of the law (<= 1e-13 relative), float32 copy == the float64 band rounded."""
+    for name, max_dists in (("example_cool", (2000, 1, 60)), ("yeast_cool", (1000, 1, 100))):
+        dcool = pipeline.DeviceCool(golden(name))
+        chroms = list(range(dcool.n_chrom))
+        for max_dist in max_dists:
+            fast = dcool.stage_blocks(chroms, max_dist, 17)
+            assert all(b.sig32 is not None for b in fast), "the batched entry did not serve the call"
+            for ci, blk in zip(chroms, fast):
+                slow = dcool.stage_intra(ci, max_dist, 17)
+                a, b = download_block(dcool, blk), download_block(dcool, slow)
+                assert blk.sig.layout == slow.sig.layout and blk.sig.ld == slow.sig.ld and blk.keep == slow.keep
+                scale = max(np.abs(b).max(), 1e-300)
+                assert np.abs(a - b).max() <= 1e-13 * scale, (name, max_dist, ci)
+                assert np.array_equal(a == 0, b == 0)
+                n = blk.shape[0]
+                ld = int(blk.sig.ld)
+                host32 = blk.buffer32.download().view(np.float32).reshape(-1)[:n * ld].reshape(n, ld)
+                host64 = blk.buffer.download().view(np.float64).reshape(-1)[:n * ld].reshape(n, ld)
+                assert np.array_equal(host32, host64.astype(np.float32)), (name, max_dist, ci)
+                assert not host64[:, (blk.sig.band_w if blk.sig.layout == 1 else n):].any()          # zeroed padding
+    dcool = pipeline.DeviceCool(golden("example_cool"))
+    g = golden("example_blocks")
+    for pname in ("loops", "borders", "hairpins"):
+        max_dist = int(g[f"chr0_{pname}_max_dist"])
+        largest = int(g[f"chr0_{pname}_keep"]) - min(max_dist, dcool.chrom_size(0))
+        for ci, blk in enumerate(dcool.stage_blocks([0, 1, 2], max_dist, largest)):
+            ref = coo(g, f"chr{ci}_{pname}_prepared").toarray()
+            assert np.abs(download_block(dcool, blk) - ref).max() < 1e-11, (ci, pname)
+
+
 def test_device_blocks_reproduce_reference_tables(golden, templates):
     """detect_block on the staged example chromosomes: tables bit-identical to the reference's
     pattern_detector captures (coordinates and order), scores <= 1e-9, windows <= 1e-12."""
@@ -134,8 +167,14 @@ def compare_genome(total_bins, max_dist_bins):
     loops["max_dist"] = max_dist_bins * binsize
     borders = copy.deepcopy(ck.borders)
     n_found = {}
+    # what the bench does: every block staged once at the loops' keep distance, the borders templates on band views
+    shared = parallel.stage_genome(dcool, [loops, borders])
     for name, cfg in (("loops", loops), ("borders", borders)):
         rec = parallel.detect_genome(dcool, cfg)
+        rec_shared = parallel.detect_genome(dcool, cfg, staged=shared)
+        # same foci in the same order; scores to the last bits (a law is a float64 sum whose order varies from run to run)
+        assert rec_shared.shape == rec.shape and np.array_equal(rec_shared[:, [0, 1, 2, 5, 6]], rec[:, [0, 1, 2, 5, 6]]), name
+        assert np.abs(rec_shared[:, 3] - rec[:, 3]).max() < 1e-12, name
         md = max(cfg["max_dist"] // binsize, 1)
         kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
         total = 0

@@ -35,6 +35,12 @@ struct cs_ctx {
     size_t d_map_bytes = 0;
     void* d_stage = nullptr;         // cs_stage_blocks: tables, per-group partial sums, row extents
     size_t d_stage_bytes = 0;
+    // cs_detect_foci_blocks: the tile kernels of consecutive blocks alternate over the caller's stream and two side
+    // streams (each with its own mask-table scratch), so that one block's tail overlaps the next block's ramp
+    hipStream_t s_blk[2] = {nullptr, nullptr};
+    hipEvent_t ev_blk[3] = {nullptr, nullptr, nullptr};
+    void* ws_alt[2] = {nullptr, nullptr};
+    size_t ws_alt_bytes[2] = {0, 0};
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
@@ -869,6 +875,12 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->ws_alt[k]) (void)hipFree(ctx->ws_alt[k]);
+        if (ctx->s_blk[k]) (void)hipStreamDestroy(ctx->s_blk[k]);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (ctx->ev_blk[k]) (void)hipEventDestroy(ctx->ev_blk[k]);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
@@ -1879,7 +1891,43 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         char* pool = (char*)ctx->d_pool;
         unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);
         CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        // side streams only when no block needs the (single) narrowing scratch
+        bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");
+        for (int b = 0; b < n_blocks && twins; ++b) twins = signals_f32[b].d_ptr != nullptr;
+        const int n_lanes = (twins && n_blocks > 1) ? 3 : 1;
+        if (n_lanes > 1) {
+            if (!ctx->s_blk[0]) {
+                for (int k = 0; k < 2; ++k) CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_blk[k], hipStreamNonBlocking));
+                for (int k = 0; k < 3; ++k) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_blk[k], hipEventDisableTiming));
+            }
+            // template weights / matrix-core fragments are uploaded on the caller's stream (once per template): before the
+            // side streams are released
+            {
+                cs::CorrArgs<float> A0;
+                int rc0 = build_args<float>(ctx, stream, signals_f32, kernel, params, &A0);
+                if (rc0) return rc0;
+                cs::MfmaWeights E0;
+                rc0 = ensure_wfrag(ctx, stream, A0.km, A0.kn, &E0);
+                if (rc0) return rc0;
+            }
+            CS_HIP(ctx, hipEventRecord(ctx->ev_blk[2], stream));              // the counter is zero, earlier work is done
+            for (int k = 0; k < 2; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[2], 0));
+        }
         for (int b = 0; b < n_blocks; ++b) {
+            const int lane = b % n_lanes;
+            hipStream_t stream = lane == 0 ? (hipStream_t)stream_ : ctx->s_blk[lane - 1];
+            struct WsSwap {                   // the side lanes build their mask tables in their own scratch
+                cs_ctx* c;
+                int k;
+                WsSwap(cs_ctx* c_, int k_) : c(c_), k(k_) { swap(); }
+                ~WsSwap() { swap(); }
+                void swap()
+                {
+                    if (k < 0) return;
+                    std::swap(c->d_ws, c->ws_alt[k]);
+                    std::swap(c->d_ws_bytes, c->ws_alt_bytes[k]);
+                }
+            } ws_swap(ctx, lane - 1);
             const cs_matrix* sig = (signals_f32 && signals_f32[b].d_ptr) ? signals_f32 + b : signals + b;
             cs_matrix map;                        // geometry of the (virtual) coefficient map: the scanned diagonals
             map.d_ptr = nullptr;
@@ -1897,8 +1945,17 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             CandSink sink{(unsigned long long*)pool, d_cnt, (long long)c_cap, (unsigned long long)b << kKeyShift, foci[b].lo_diag,
                           foci[b].hi_diag};
             rc = corr_candidates_f32(ctx, stream, sig, kernel, params + b, &map, margin, thr, &sink);
-            if (rc == CS_NEED_MAP) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is not served by the masked tile kernel", b);
-            if (rc) return rc;
+            if (rc) {
+                if (n_lanes > 1) (void)hipDeviceSynchronize();      // nothing of this call may still be running on a side stream
+                if (rc == CS_NEED_MAP) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is not served by the masked tile kernel", b);
+                return rc;
+            }
+        }
+        if (n_lanes > 1) {
+            for (int k = 0; k < 2; ++k) {
+                CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
+                CS_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_blk[k], 0));
+            }
         }
         CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
         CS_HIP(ctx, hipStreamSynchronize(stream));

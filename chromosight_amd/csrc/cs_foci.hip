@@ -272,12 +272,32 @@ __device__ __forceinline__ void foci_small_body(
         const long long key = keys_k[t];
         const int col = (int)(key % ns);
         if (t + 1 < n && col + 1 < ns && keys_k[t + 1] == key + 1) uf_union(parent, t, t + 1);
-        long long lo = t + 1, hi = n;
+        // lower neighbour (key + ns): the list is sorted, and in both regimes it sits -- or is seen to be absent -- within a
+        // few entries: a narrow scan (2 diagonals) keeps it 1-2 entries ahead, a sparse list jumps past it at once.  The
+        // binary search (15 dependent loads) is only the fallback.
         const long long want = key + ns;
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if (keys_k[mid] < want) lo = mid + 1;
-            else hi = mid;
+        long long lo = t + 1, hi = n;
+        bool decided = false;
+#pragma unroll
+        for (int s = 1; s <= 4 && !decided; ++s) {
+            if (t + s >= n) {
+                decided = true;
+                lo = n;
+            } else {
+                const long long k = keys_k[t + s];
+                if (k >= want) {
+                    decided = true;
+                    lo = t + s;
+                }
+            }
+        }
+        if (!decided) {
+            lo = t + 5;
+            while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                if (keys_k[mid] < want) lo = mid + 1;
+                else hi = mid;
+            }
         }
         if (lo < n && keys_k[lo] == want) uf_union(parent, t, (int)lo);
     }
@@ -409,15 +429,16 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
     unsigned char* const rfl = reinterpret_cast<unsigned char*>(wl + kRunWeights);       // 512 row flags, 1024 column flags
     unsigned char* const cfl = rfl + 512;
     __shared__ int red[8];
+    __shared__ int part[4][6];
     const int tid = threadIdx.x, lane = tid & 63;
     const long long t = (long long)blockIdx.x * blockDim.x + tid;
     const bool valid = t < n_px;
     const int b = valid ? blk[t] : -1;
     const int oi = valid ? rows[t] : 0, oj = valid ? cols[t] : 0;
-    // extent of the workgroup's entries (rows, diagonals, sub-matrices): wave reductions, then 4 partial results each
-    {
-        int v_lo[3] = {valid ? oi : 0x7fffffff, valid ? oj - oi : 0x7fffffff, valid ? b : 0x7fffffff};
-        int v_hi[3] = {valid ? oi : -0x7fffffff, valid ? oj - oi : -0x7fffffff, valid ? b : -0x7fffffff};
+    // extent (rows, diagonals, sub-matrices) of the entries selected by `sel`: wave reductions, then 4 partial results each
+    auto extent = [&](bool sel) {
+        int v_lo[3] = {sel ? oi : 0x7fffffff, sel ? oj - oi : 0x7fffffff, sel ? b : 0x7fffffff};
+        int v_hi[3] = {sel ? oi : -0x7fffffff, sel ? oj - oi : -0x7fffffff, sel ? b : -0x7fffffff};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                 v_hi[k] = max(v_hi[k], __shfl_xor(v_hi[k], o));
             }
         }
-        __shared__ int part[4][6];
+        __syncthreads();                                      // (the previous round's readers of red / part are done)
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -441,18 +462,24 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
             red[tid] = v;
         }
         __syncthreads();
-    }
-    const int i_lo = red[0], i_hi = red[1], d_lo = red[2], d_hi = red[3], b_lo = red[4], b_hi = red[5];
+    };
+    extent(valid);
+    const int b_lo = red[4], b_hi = red[5];
     double r = 0.0, nobs = 0.0;
-    bool staged = false;
-    if (b_lo == b_hi && b_lo >= 0 && tile_cap > 0) {
-        const CorrArgs<double>& A = tab[b_lo];
+    // A workgroup's 256 entries normally belong to one sub-matrix; the few that straddle two (or more, tiny ones) take them
+    // one after the other, each with its own tile -- left to the direct route, one such workgroup (289 dependent global
+    // loads per pixel) lasted as long as the rest of the launch together.
+    for (int bb = b_lo; bb <= b_hi && b_lo >= 0; ++bb) {
+        const bool mine = valid && b == bb;
+        if (b_lo != b_hi) extent(mine);
+        const int i_lo = red[0], i_hi = red[1], d_lo = red[2], d_hi = red[3];
+        if (i_hi < i_lo) continue;                            // no entry of this sub-matrix here (uniform)
+        const CorrArgs<double>& A = tab[bb];
         const int km = A.km, kn = A.kn, kh = (km - 1) / 2, kw = (kn - 1) / 2;
         const int P0 = i_lo - kh, RN = (i_hi - i_lo) + km;
         const int D0 = d_lo - kw - (km - 1 - kh), DN = (d_hi - d_lo) + (kn - 1) + (km - 1) + 1;
         const int C0 = P0 + D0, CN = RN + DN;                  // columns the tile can reach
-        if ((long long)RN * DN <= tile_cap && RN <= 512 && CN <= 1024 && 3 * km * kn <= kRunWeights) {
-            staged = true;
+        if (tile_cap > 0 && (long long)RN * DN <= tile_cap && RN <= 512 && CN <= 1024 && 3 * km * kn <= kRunWeights) {
             for (int idx = tid; idx < 3 * km * kn; idx += 256) wl[idx] = A.w[idx];
             const bool bins = A.mask_mode == 1;
             for (int idx = tid; idx < RN; idx += 256) {
@@ -469,17 +496,19 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                 tile[idx] = load_signal(A, p, p + D0 + dd);
             }
             __syncthreads();
-            if (valid) rescore_pixel_lane_lds(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
-        }
-    }
-    if (!staged) {
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-        while (todo) {
-            const int first = __builtin_ctzll(todo);
-            const int b0 = __builtin_amdgcn_readlane(b, first);
-            const bool mine = valid && b == b0;
-            if (mine) rescore_pixel_lane(tab[b0], oi, oj, r, nobs);
-            todo &= ~__builtin_amdgcn_ballot_w64(mine);
+            // every window of the run inside the matrix, detection configuration, square template: the branch-free form
+            const bool interior = P0 >= 0 && P0 + RN <= A.ms && C0 >= 0 && C0 + CN <= A.ns && bins && A.sym_upper && A.full &&
+                                  A.max_dist >= 0 && km == kn;
+            if (mine && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            else if (mine && interior && kn == 15) rescore_pixel_lane_lds_interior<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            else if (mine) {
+                if (kn == 17) rescore_pixel_lane_lds<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+                else if (kn == 15) rescore_pixel_lane_lds<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+                else rescore_pixel_lane_lds<0>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            }
+            __syncthreads();                                  // the tile is reused by the next sub-matrix
+        } else if (mine) {
+            rescore_pixel_lane(A, oi, oj, r, nobs);
         }
     }
     if (valid) out_corr[t] = r;

@@ -140,6 +140,51 @@ __device__ __forceinline__ void rescore_pixel_lane(const CorrArgs<double>& A, in
 // alone cost 34 such round trips per pixel).  Same operations in the same order as rescore_pixel_lane: identical
 // results.  The predicate is missing_from_flags written without branches for the detection configuration
 // (per-bin masks, sym_upper, full, max_dist given); other configurations call the general function.
+// The same for the configuration nearly every call has -- per-bin masks, sym_upper, full, max_dist given, a SQUARE
+// template of compile-time size K, and every window of the workgroup inside the matrix -- without a branch: the
+// predicate collapses to  d < 0 ? d >= -K : (row flag | column flag) & d <= max_dist  and the mask sums take 0.0 where
+// it is false (x + 0.0 == x: the sums are bit-identical to the branching form's).  The general function compiles to
+// ~215 instructions per window pixel (135 of them scalar branch bookkeeping around `if (missing)`): 363 us for the 400 000
+// pixels of a borders template on the 23-block genome; this one to ~25.
+template <int K>
+__device__ __forceinline__ void rescore_pixel_lane_lds_interior(const CorrArgs<double>& A, const double* tile, const double* wl,
+                                                                const unsigned char* rfl, const unsigned char* cfl, int P0, int C0,
+                                                                int D0, int DN, int oi, int oj, double& r, double& nobs)
+{
+    r = 0.0;
+    nobs = A.ks.n;
+    if (pixel_forced_zero(A, oi, oj)) return;
+    constexpr int kh = (K - 1) / 2, kk = K * K;
+    const int md = A.max_dist;
+    double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
+    const int q0 = oj - kh;
+    const unsigned char* cf = cfl + (q0 - C0);
+    for (int ki = 0; ki < K; ++ki) {
+        const int p = oi - kh + ki;
+        const int d0 = q0 - p;                                       // diagonal of the window row's first pixel
+        const double* row = tile + (p - P0) * DN + (d0 - D0);
+        const double* w = wl + ki * K;
+        const bool rf = rfl[p - P0] != 0;
+#pragma unroll
+        for (int kj = 0; kj < K; ++kj) {
+            const double v = row[kj];
+            cs_ = fma(v, w[kj], cs_);
+            s1 += v;
+            s2 = fma(v, v, s2);
+            const int d = d0 + kj;
+            const bool m = d < 0 ? d >= -K : ((rf | (cf[kj] != 0)) & (d <= md));
+            nm += m ? 1.0 : 0.0;
+            ka += m ? w[kk + kj] : 0.0;
+            kb += m ? w[2 * kk + kj] : 0.0;
+        }
+    }
+    r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, true, &nobs);
+}
+
+// KN > 0: template width known at compile time (17: every built-in 2-D / 1-D template but the 15 x 15 hairpin) -- the
+// row loop is unrolled, so its 17 LDS reads are issued together instead of one dependent read per multiply-add (the
+// runtime-size loop ran at a third of the instruction-issue floor).
+template <int KN = 0>
 __device__ __forceinline__ void rescore_pixel_lane_lds(const CorrArgs<double>& A, const double* tile, const double* wl,
                                                        const unsigned char* rfl, const unsigned char* cfl, int P0, int C0, int D0,
                                                        int DN, int oi, int oj, double& r, double& nobs)
@@ -148,7 +193,7 @@ __device__ __forceinline__ void rescore_pixel_lane_lds(const CorrArgs<double>& A
     nobs = A.ks.n;
     const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
     if (inside && !pixel_forced_zero(A, oi, oj)) {
-        const int km = A.km, kn = A.kn, kk = km * kn;
+        const int km = A.km, kn = KN ? KN : A.kn, kk = km * kn;
         const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
         const bool masked = A.mask_mode != 0;
         const bool bins = A.mask_mode == 1;
@@ -161,7 +206,7 @@ __device__ __forceinline__ void rescore_pixel_lane_lds(const CorrArgs<double>& A
             const double* row = tile + (p - P0) * DN + ((oj - kw) - p - D0);
             const bool rf = bins && rfl[p - P0] != 0;
             const bool in_r = (p >= 0) & (p < ms);
-            for (int kj = 0; kj < kn; ++kj, ++e) {
+            auto step = [&](int kj) {
                 const int q = oj - kw + kj;
                 const double v = row[kj];
                 cs_ = fma(v, wl[e], cs_);
@@ -189,6 +234,13 @@ __device__ __forceinline__ void rescore_pixel_lane_lds(const CorrArgs<double>& A
                         kb += wl[2 * kk + e];
                     }
                 }
+                ++e;
+            };
+            if constexpr (KN > 0) {
+#pragma unroll
+                for (int kj = 0; kj < KN; ++kj) step(kj);
+            } else {
+                for (int kj = 0; kj < kn; ++kj) step(kj);
             }
         }
         r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, masked, &nobs);

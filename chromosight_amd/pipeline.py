@@ -644,15 +644,42 @@ def b_is_band(block):
     return block.sig.layout == LAYOUT_BAND and not block.inter and getattr(block, "row_window", None) is None
 
 
-def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True):
-    """detect_block for every staged block of `blocks`, several at a time (see _Workers); results in
-    the order of `blocks`.  The staging of the blocks (default stream) is complete before they start."""
+def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True, defer=False):
+    """detect_block for every staged block of `blocks`; results in the order of `blocks`.  Banded intra blocks go to the
+    device in ONE native call per template (1-D patterns: cs_detect_foci_batch; 2-D patterns: cs_detect_foci_blocks);
+    what the library cannot batch (dense-staged short chromosomes, inter blocks, odd templates) goes block by block,
+    several at a time (see _Workers).  defer=True: returns a callable that yields the results -- the native calls are
+    done when detect_blocks returns, the acceptance rules (numpy on the returned records) run in the callable, so a
+    caller can overlap them with the next template's device work (parallel.detect_genome)."""
     kernel = np.asarray(kernel, dtype=np.float64)
+    done = (lambda res: (lambda: res)) if defer else (lambda res: res)
     if any(min(b.shape) > max(kernel.shape) for b in blocks):
         _check_template(kernel)
-    if len(blocks) > 1 and kernel_config["max_dist"] == 0 and batch and kernel.shape[0] == kernel.shape[1]:
-        # 1-D patterns: all banded sub-matrices in one native call; blocks too small for the template drop out
-        # as they do in detect_block, the few that are staged dense (very short chromosomes) go one by one
+    square = kernel.shape[0] == kernel.shape[1]
+    if len(blocks) > 1 and raw and batch and square and tsvd is None and not os.environ.get("CHROMOSIGHT_HIP_NO_BLOCK_BATCH"):
+        live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
+        banded = [k for k in live if b_is_band(blocks[k])]
+        kspec = engine.KernelSpec(kernel, tsvd)
+        fin = None
+        if len(banded) > 1:
+            many = cid.detect_many_on_device if kernel_config["max_dist"] == 0 else cid.detect_blocks_on_device
+            extra = dict(raw=True) if kernel_config["max_dist"] == 0 else {}
+            fin = many(dcool.dev, [blocks[k] for k in banded], kspec, kernel_config, want_windows=want_windows, defer=True, **extra)
+        if fin is not None:
+            rest = {k: detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
+                    for k in live if k not in banded}
+
+            def finish():
+                out = [(None, None)] * len(blocks)
+                for k, r in zip(banded, fin()):
+                    out[k] = r
+                for k, r in rest.items():
+                    out[k] = r
+                return out
+
+            return finish if defer else finish()
+    elif len(blocks) > 1 and kernel_config["max_dist"] == 0 and batch and square:
+        # 1-D patterns, tables as DataFrames: the same batch, accepted block by block
         live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
         banded = [k for k in live if b_is_band(blocks[k])]
         res = cid.detect_many_on_device(dcool.dev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
@@ -664,30 +691,15 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
             for k in live:
                 if k not in banded:
                     out[k] = detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
-            return out
-    if len(blocks) > 1 and raw and batch and kernel_config["max_dist"] != 0 and not os.environ.get("CHROMOSIGHT_HIP_NO_BLOCK_BATCH"):
-        # 2-D patterns: every banded sub-matrix in ONE native call (tile kernels in candidate mode, one candidate list, one
-        # foci chain); what the library cannot batch (dense-staged short chromosomes, small blocks) goes one by one
-        live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
-        banded = [k for k in live if b_is_band(blocks[k])]
-        res = cid.detect_blocks_on_device(dcool.dev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
-                                          want_windows=want_windows) if len(banded) > 1 and tsvd is None else None
-        if res is not None:
-            out = [(None, None)] * len(blocks)
-            for k, r in zip(banded, res):
-                out[k] = r
-            for k in live:
-                if k not in banded:
-                    out[k] = detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
-            return out
+            return done(out)
     if workers <= 1 or len(blocks) <= 1:
-        return [detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows) for b in blocks]
+        return done([detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows) for b in blocks])
     dcool.dev.sync()
     pool = dcool.workers(workers)
 
     # raw tables of banded intra blocks: the workers only run the native call; the acceptance rules are applied to all
     # their records in one go (numpy under the interpreter lock was a good part of a worker's time on a small block)
-    deferred = raw and kernel.shape[0] == kernel.shape[1] and all(b_is_band(b) and min(b.shape) > max(kernel.shape) for b in blocks)
+    deferred = raw and square and all(b_is_band(b) and min(b.shape) > max(kernel.shape) for b in blocks)
 
     def one(block):
         dev, stream = pool.device()
@@ -696,13 +708,13 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
 
     results = pool.map(one, blocks)
     if not deferred:
-        return results
+        return done(results)
     counts = [len(r[0]) for r in results]
     if sum(counts) == 0:
-        return [(None, None)] * len(blocks)
+        return done([(None, None)] * len(blocks))
     rec = np.concatenate([r[0] for r in results])
     windows = np.concatenate([r[1] for r in results]) if want_windows else None
-    return cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config)
+    return done(cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config))
 
 
 def sub_matrices(dcool, inter):

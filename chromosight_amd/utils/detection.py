@@ -638,7 +638,7 @@ def _offset_scores(dev, sig, shape, kspec, rr, cc, common):
     return sr, sc, vals
 
 
-def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None):
+def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None, defer=False):
     """detect_on_device for a 1-D pattern (kernel_config["max_dist"] == 0: borders, hairpins) on many intra
     sub-matrices at once: `blocks` = objects with sig, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).
     One native call (cs_detect_foci_batch) instead of one launch chain and synchronisation per sub-matrix.
@@ -658,6 +658,8 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
         return None
     if raw:
         rec, windows, counts = res
+        if defer:           # the native call is done; the acceptance rules (numpy) when the caller asks for them
+            return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config)
         return accept_many(blocks, rec, windows, counts, kspec, kernel_config)
     out = []
     for b, (rec, windows) in zip(blocks, res):
@@ -670,7 +672,7 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     return out
 
 
-def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, stream=None):
+def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, stream=None, defer=False):
     """detect_on_device (raw tables) for a 2-D pattern on many banded intra sub-matrices with ONE native call
     (cs_detect_foci_blocks: tile kernels in candidate mode -> one candidate list -> one foci chain): `blocks` = objects with
     sig, sig32, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).  Returns the list of raw (table, windows) per
@@ -689,7 +691,9 @@ def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=T
         return None
     rec, windows, counts = res
     if int(np.sum(counts)) == 0:
-        return [(None, None)] * len(blocks)
+        return (lambda: [(None, None)] * len(blocks)) if defer else [(None, None)] * len(blocks)
+    if defer:
+        return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config)
     return accept_many(blocks, rec, windows, counts, kspec, kernel_config)
 
 

@@ -164,6 +164,14 @@ _PROTOTYPES = {
     "cs_distance_law_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "cs_detect_foci_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(CsKernel),
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cs_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cs_comm_destroy": (None, [C.c_void_p]),
+    "cs_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "cs_comm_rank": (C.c_int, [C.c_void_p]),
+    "cs_comm_world": (C.c_int, [C.c_void_p]),
+    "cs_comm_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cs_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "cs_stage_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(CsStageBlock), C.c_int32, C.c_double]),
     "cs_csr_median": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(C.c_double)]),
     "cs_detect_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),

@@ -1,0 +1,254 @@
+// cs_comm.cpp -- the exchange step of the sharded path on RCCL (xGMI inside a node), behind the C ABI.
+//
+// The path shards over independent sub-matrices (reference cli/chromosight.py:748-752: Pool.imap over sub-matrices), so
+// there is no data-path collective; what ranks exchange is
+//   * the pattern records at the end of a detect call: variable-length lists of fixed-size float64 records ->
+//     ncclAllGather of the per-rank counts, then ONE padded ncclAllGather of the records;
+//   * the pileup of an iterated template (cli/chromosight.py:791) and the per-diagonal (sum, count) of a sub-matrix
+//     split over ranks -> ncclAllReduce(sum) of a small float64 vector.
+// Records live on the host on both sides (the acceptance rules are numpy), so the entry points take host arrays and do
+// the device staging themselves: no torch tensors, no Python between the two collectives.
+//
+// librccl is loaded on first use (dlopen): a single-GPU process never touches it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/chromosight_hip.h"
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    std::string err_create;      // why the last cs_comm_create failed (cs_comm_last_error(NULL))
+};
+
+Rccl* rccl()
+{
+    static Rccl R;
+    if (R.lib || !R.err.empty()) return &R;
+    // The librccl that belongs to the HIP runtime THIS library is bound to: a process may hold two (PyTorch wheels bundle
+    // their own libamdhip64 / librccl next to /opt/rocm's, same sonames), and a communicator only works with streams of
+    // its own runtime.  So: the directory of the libamdhip64 that hipGetDeviceCount resolves to, then the loader's defaults.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t cut = dir.rfind('/');
+        if (cut != std::string::npos) {
+            dir.resize(cut + 1);
+            names.push_back(dir + "librccl.so.1");
+            names.push_back(dir + "librccl.so");
+        }
+    }
+    for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) names.push_back(name);
+    for (const std::string& name : names) {
+        R.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (R.lib) break;
+    }
+    if (!R.lib) {
+        R.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+        return &R;
+    }
+#define CS_SYM(field, name)                                                   \
+    R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.lib, name));        \
+    if (!R.field) R.err = std::string("librccl lacks ") + name;
+    CS_SYM(GetUniqueId, "ncclGetUniqueId")
+    CS_SYM(CommInitRank, "ncclCommInitRank")
+    CS_SYM(CommDestroy, "ncclCommDestroy")
+    CS_SYM(AllGather, "ncclAllGather")
+    CS_SYM(AllReduce, "ncclAllReduce")
+    CS_SYM(GetErrorString, "ncclGetErrorString")
+#undef CS_SYM
+    return &R;
+}
+
+}  // namespace
+
+struct cs_comm {
+    int device = 0, rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    void* d_buf = nullptr;        // staging: send block | receive blocks
+    size_t d_bytes = 0;
+    void* h_pin = nullptr;        // page-locked mirror of the staging buffer
+    size_t h_bytes = 0;
+    std::string err;
+};
+
+namespace {
+
+int cfail(cs_comm* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+int ensure(cs_comm* c, size_t bytes)
+{
+    if (bytes <= c->d_bytes) return CS_OK;
+    bytes = std::max(bytes + bytes / 2, (size_t)1 << 16);
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    c->d_buf = c->h_pin = nullptr;
+    c->d_bytes = c->h_bytes = 0;
+    if (hipMalloc(&c->d_buf, bytes) != hipSuccess) return cfail(c, CS_ERR_HIP, "hipMalloc of %zu staging bytes failed", bytes);
+    if (hipHostMalloc(&c->h_pin, bytes, hipHostMallocDefault) != hipSuccess) return cfail(c, CS_ERR_HIP, "hipHostMalloc failed");
+    c->d_bytes = c->h_bytes = bytes;
+    return CS_OK;
+}
+
+#define CS_NCCL(c, call)                                                                                      \
+    do {                                                                                                      \
+        ncclResult_t r_ = (call);                                                                             \
+        if (r_ != ncclSuccess) return cfail(c, CS_ERR_HIP, "%s: %s", #call, rccl()->GetErrorString(r_));     \
+    } while (0)
+#define CS_HIPC(c, call)                                                                             \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return cfail(c, CS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int cs_comm_unique_id(void* out128)
+{
+    if (!out128) return CS_ERR_INVALID;
+    Rccl* R = rccl();
+    if (!R->err.empty()) return CS_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return CS_ERR_HIP;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, &id, sizeof(id));
+    return CS_OK;
+}
+
+int cs_comm_create(int device, int rank, int world, const void* unique_id128, cs_comm** out)
+{
+    if (!out || !unique_id128 || world < 1 || rank < 0 || rank >= world) return CS_ERR_INVALID;
+    *out = nullptr;
+    Rccl* R = rccl();
+    if (!R->err.empty()) return CS_ERR_UNSUPPORTED;
+    cs_comm* c = new cs_comm;
+    c->device = device;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id128, sizeof(id));
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    ncclResult_t ne = ncclSuccess;
+    if (he == hipSuccess) ne = R->CommInitRank(&c->comm, world, id, rank);
+    if (he != hipSuccess || ne != ncclSuccess) {
+        R->err_create = he != hipSuccess ? std::string("HIP: ") + hipGetErrorString(he)
+                                         : std::string("ncclCommInitRank: ") + R->GetErrorString(ne);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return CS_ERR_HIP;
+    }
+    *out = c;
+    return CS_OK;
+}
+
+void cs_comm_destroy(cs_comm* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)rccl()->CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    delete c;
+}
+
+const char* cs_comm_last_error(const cs_comm* c)
+{
+    if (c) return c->err.c_str();
+    Rccl* R = rccl();
+    return !R->err.empty() ? R->err.c_str() : R->err_create.c_str();      // NULL: why loading / the last create failed
+}
+
+int cs_comm_rank(const cs_comm* c) { return c ? c->rank : -1; }
+int cs_comm_world(const cs_comm* c) { return c ? c->world : 0; }
+
+int cs_comm_allreduce_f64(cs_comm* c, double* h_values, int64_t n)
+{
+    if (!c || n < 0 || (n > 0 && !h_values)) return CS_ERR_INVALID;
+    if (n == 0) return CS_OK;
+    CS_HIPC(c, hipSetDevice(c->device));
+    int rc = ensure(c, 8 * (size_t)n);
+    if (rc) return rc;
+    std::memcpy(c->h_pin, h_values, 8 * (size_t)n);
+    CS_HIPC(c, hipMemcpyAsync(c->d_buf, c->h_pin, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    CS_NCCL(c, rccl()->AllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+    CS_HIPC(c, hipMemcpyAsync(c->h_pin, c->d_buf, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    CS_HIPC(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_values, c->h_pin, 8 * (size_t)n);
+    return CS_OK;
+}
+
+int cs_comm_allgather_rows(cs_comm* c, const double* h_rows, int64_t n_rows, int32_t width, double* h_out, int64_t cap_rows,
+                           int64_t* h_counts)
+{
+    if (!c || n_rows < 0 || width <= 0 || !h_counts || (n_rows > 0 && !h_rows) || cap_rows < 0 || (cap_rows > 0 && !h_out))
+        return CS_ERR_INVALID;
+    CS_HIPC(c, hipSetDevice(c->device));
+    const int W = c->world;
+    // 1. counts (one int64 per rank)
+    int rc = ensure(c, 8 * (size_t)(W + 1));
+    if (rc) return rc;
+    long long* hp = reinterpret_cast<long long*>(c->h_pin);
+    hp[0] = n_rows;
+    CS_HIPC(c, hipMemcpyAsync(c->d_buf, hp, 8, hipMemcpyHostToDevice, c->stream));
+    CS_NCCL(c, rccl()->AllGather(c->d_buf, (char*)c->d_buf + 8, 1, ncclInt64, c->comm, c->stream));
+    CS_HIPC(c, hipMemcpyAsync(hp + 1, (char*)c->d_buf + 8, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+    CS_HIPC(c, hipStreamSynchronize(c->stream));
+    long long total = 0, widest = 0;
+    for (int r = 0; r < W; ++r) {
+        h_counts[r] = hp[1 + r];
+        total += hp[1 + r];
+        widest = std::max(widest, hp[1 + r]);
+    }
+    if (total > cap_rows) return cfail(c, CS_ERR_OVERFLOW, "%lld rows, room for %lld", total, (long long)cap_rows);
+    if (total == 0) return CS_OK;
+    // 2. the records, padded to the longest list
+    const size_t block = 8 * (size_t)widest * (size_t)width;
+    rc = ensure(c, block * (size_t)(W + 1));
+    if (rc) return rc;
+    std::memset(c->h_pin, 0, block);
+    if (n_rows) std::memcpy(c->h_pin, h_rows, 8 * (size_t)n_rows * (size_t)width);
+    CS_HIPC(c, hipMemcpyAsync(c->d_buf, c->h_pin, block, hipMemcpyHostToDevice, c->stream));
+    CS_NCCL(c, rccl()->AllGather(c->d_buf, (char*)c->d_buf + block, (size_t)widest * (size_t)width, ncclDouble, c->comm, c->stream));
+    CS_HIPC(c, hipMemcpyAsync((char*)c->h_pin + block, (char*)c->d_buf + block, block * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+    CS_HIPC(c, hipStreamSynchronize(c->stream));
+    double* dst = h_out;
+    for (int r = 0; r < W; ++r) {
+        const size_t bytes = 8 * (size_t)h_counts[r] * (size_t)width;
+        std::memcpy(dst, (char*)c->h_pin + block * (size_t)(1 + r), bytes);
+        dst += (size_t)h_counts[r] * (size_t)width;
+    }
+    return CS_OK;
+}
+
+}  // extern "C"

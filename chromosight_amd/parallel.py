@@ -14,6 +14,8 @@ exchange is the final gather of the per-block pattern tables (a few MB at most).
 `detectable_bins`, `max_dist`, `inter`); every rank passes the same list (or builds the same
 list lazily through `loader`), processes its own share and receives the gathered result.
 """
+import os
+
 import numpy as np
 
 RECORD_FIELDS = ("block", "bin1", "bin2", "score", "pvalue")
@@ -41,6 +43,79 @@ def assign_blocks(costs, world_size):
 
 
 _HELPER = None
+_COMMS = {}
+
+
+class NativeComm:
+    """The library's RCCL communicator (csrc/cs_comm.cpp: ncclAllGather / ncclAllReduce behind the C ABI, host arrays in
+    and out, no torch tensors in the exchange)."""
+
+    def __init__(self, device, rank, world, unique_id):
+        import ctypes as C
+        from ._lib import load_library
+        self.C, self.lib = C, load_library()
+        self.rank, self.world = rank, world
+        self.handle = C.c_void_p()
+        rc = self.lib.cs_comm_create(int(device), int(rank), int(world), unique_id, C.byref(self.handle))
+        if rc != 0:
+            raise RuntimeError(f"cs_comm_create failed ({rc}): {self.lib.cs_comm_last_error(None).decode()}")
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from ._lib import load_library
+        buf = (C.c_char * 128)()
+        rc = load_library().cs_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"cs_comm_unique_id failed ({rc})")
+        return bytes(buf)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"RCCL exchange failed ({rc}): {self.lib.cs_comm_last_error(self.handle).decode()}")
+
+    def allgather_rows(self, rows):
+        """Rank-order concatenation of every rank's (n_i, w) float64 array, and the per-rank counts."""
+        C = self.C
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        width = int(rows.shape[1])
+        counts = np.zeros(self.world, dtype=np.int64)
+        cap = max(4 * rows.shape[0] * self.world, 4096)
+        while True:
+            out = np.empty((cap, width))
+            rc = self.lib.cs_comm_allgather_rows(self.handle, rows.ctypes.data, rows.shape[0], width, out.ctypes.data, cap,
+                                                 counts.ctypes.data)
+            if rc == -4:                      # CS_ERR_OVERFLOW: the counts say how much room is needed
+                cap = int(counts.sum())
+                continue
+            self._check(rc)
+            return out[:int(counts.sum())], counts
+
+    def allreduce_sum(self, array):
+        out = np.ascontiguousarray(array, dtype=np.float64).copy()
+        self._check(self.lib.cs_comm_allreduce_f64(self.handle, out.ctypes.data, out.size))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.cs_comm_destroy(self.handle)
+            self.handle = None
+
+
+def native_comm():
+    """The RCCL communicator of this process group when the ranks are GPU ranks (torch backend "nccl"), else None (CPU
+    tests over gloo keep the torch path).  The 128-byte id is created on rank 0 and broadcast through torch.distributed
+    once; every exchange after that goes through the library."""
+    dist, rank, world = _world()
+    if dist is None or world == 1 or dist.get_backend() != "nccl" or os.environ.get("CHROMOSIGHT_HIP_TORCH_EXCHANGE"):
+        return None
+    key = (rank, world)
+    if key not in _COMMS:
+        import torch
+        box = [NativeComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        _COMMS[key] = NativeComm(torch.cuda.current_device(), rank, world, box[0])
+    return _COMMS[key]
 
 
 def _helper():
@@ -69,6 +144,10 @@ def gather_records(records, device=None):
     records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, len(RECORD_FIELDS))
     if dist is None or world == 1:
         return records
+    comm = native_comm()
+    if comm is not None:
+        merged, _ = comm.allgather_rows(records)
+        return merged[np.argsort(merged[:, 0], kind="stable")]
     import torch
     dev = device if device is not None else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
@@ -136,6 +215,9 @@ def _allreduce_sum(array):
     dist, rank, world = _world()
     if dist is None or world == 1:
         return array
+    comm = native_comm()
+    if comm is not None:
+        return comm.allreduce_sum(array).reshape(np.shape(array))
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to(dev)
@@ -152,6 +234,9 @@ def all_gather_rows(array):
         raise ValueError("all_gather_rows needs a 2-D array")
     if dist is None or world == 1:
         return array
+    comm = native_comm()
+    if comm is not None:
+        return comm.allgather_rows(array)[0]
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     count = torch.tensor([array.shape[0]], dtype=torch.int64, device=dev)
@@ -205,6 +290,10 @@ def _gather(records, n_fields):
     records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, n_fields)
     if dist is None or world == 1:
         return records
+    comm = native_comm()
+    if comm is not None:
+        merged, _ = comm.allgather_rows(records)
+        return merged[np.argsort(merged[:, 0], kind="stable")]
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     count = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
@@ -288,7 +377,6 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
         fresh = {ci: stage(genome, ci, max_dist, largest) for ci in todo}
     staged = {**have, **fresh}
     out = []
-    one_exchange = kernel_config["max_iterations"] == 1 and world > 1      # no template depends on another's records
     pending = []
     # Templates that do not depend on each other (a single iteration each): the device work of template k + 1 is issued
     # by a helper thread while this one applies the acceptance rules to the records of template k (numpy, a third of a
@@ -328,32 +416,35 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                 if windows is not None:
                     wins.append(windows)
             local = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(GENOME_FIELDS)))
-            if one_exchange:
-                pending.append(local)                        # a single iteration per template: gathered once, below
+            pending.append(local)                            # gathered once, at the end of the call
+            if kernel_config["max_iterations"] == 1:
                 continue
-            merged = _gather(local, len(GENOME_FIELDS))
-            if merged.shape[0] == 0:
-                break                                        # no pattern with this template: next one
-            out.append(merged)
-            if it + 1 < kernel_config["max_iterations"]:
-                # pileup = nanmean over ALL windows of this iteration (detection.py:158-174)
-                if world == 1:
-                    import warnings
-                    with warnings.catch_warnings():
-                        warnings.simplefilter("ignore")
-                        kernel = np.nanmean(np.concatenate(wins, axis=0), axis=0)
-                else:
-                    stack = np.concatenate(wins, axis=0) if wins else np.zeros((0,) + kernel.shape)
-                    both = np.stack([np.nansum(stack, axis=0), np.sum(~np.isnan(stack), axis=0).astype(np.float64)])
-                    both = _allreduce_sum(both)
-                    with np.errstate(all="ignore"):
-                        kernel = both[0] / both[1]
-    if one_exchange:
-        # one count + one padded all_gather for all templates (each exchange is two collectives and two host round
-        # trips: with 3 blocks per GPU they were a good part of a pass); per template the rows then come in the
-        # order the per-template gathers gave -- ranks concatenated, stable by block
-        local = np.concatenate(pending, axis=0) if pending else np.zeros((0, len(GENOME_FIELDS)))
-        merged = _gather(local, len(GENOME_FIELDS))
-        out = [merged[merged[:, 5] == kernel_id] for kernel_id in range(len(kernel_config["kernels"]))]
-        out = [m for m in out if m.shape[0]]
+            # iterated template: ONE all-reduce per iteration carries the pileup sums, their counts and the number of
+            # patterns (no pattern on any rank: next template, cli/chromosight.py:786-789); the records wait for the end
+            if it + 1 == kernel_config["max_iterations"]:
+                continue                                     # nothing depends on the last iteration's patterns
+            stack = np.concatenate(wins, axis=0) if wins else np.zeros((0,) + kernel.shape)
+            if world == 1:
+                if local.shape[0] == 0:
+                    break
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    kernel = np.nanmean(stack, axis=0)           # detection.py:158-174
+                continue
+            both = np.concatenate([np.nansum(stack, axis=0).ravel(), np.sum(~np.isnan(stack), axis=0).astype(np.float64).ravel(),
+                                   [float(local.shape[0])]])
+            both = _allreduce_sum(both)
+            if both[-1] == 0:
+                break
+            kk = kernel.size
+            with np.errstate(all="ignore"):
+                kernel = (both[:kk] / both[kk:2 * kk]).reshape(kernel.shape)
+    # one count + one padded all-gather for the whole call (RCCL: csrc/cs_comm.cpp); per (template, iteration) the rows then
+    # come in the order separate gathers gave -- ranks concatenated, stable by block
+    local = np.concatenate(pending, axis=0) if pending else np.zeros((0, len(GENOME_FIELDS)))
+    merged = _gather(local, len(GENOME_FIELDS))
+    out = [merged[(merged[:, 5] == kernel_id) & (merged[:, 6] == it)] for kernel_id in range(len(kernels))
+           for it in range(kernel_config["max_iterations"])]
+    out = [m for m in out if m.shape[0]]
     return np.concatenate(out, axis=0) if out else np.zeros((0, len(GENOME_FIELDS)))

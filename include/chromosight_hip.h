@@ -353,6 +353,29 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
                   const int32_t* h_cols, const double* h_vals, int64_t n, int32_t min_size, int32_t diag_only,
                   int32_t* h_foci_rows, int32_t* h_foci_cols, int32_t* h_foci_size, int64_t cap, int64_t* n_foci);
 
+/* ---- the exchange step of the sharded path on RCCL (one process per GPU) --------------------------------
+ * The path shards over independent sub-matrices like the reference's Pool.imap (cli/chromosight.py:748-752); ranks only
+ * exchange pattern records (variable-length lists of fixed-size float64 records) and small float64 vectors (the pileup of
+ * an iterated template, :791; the per-diagonal sums of a sub-matrix split over ranks).  Host arrays in and out -- the
+ * records are host data on both sides -- device staging and the collectives (ncclAllGather / ncclAllReduce over xGMI)
+ * inside.  librccl is loaded on first use; CS_ERR_UNSUPPORTED when it is absent.
+ *
+ * cs_comm_unique_id: 128 bytes to be created on ONE rank and handed to the others by whatever launched them (the Python
+ * side broadcasts them over the torch.distributed store).  cs_comm_create: collective over all ranks.
+ * cs_comm_allgather_rows: every rank passes n_rows rows of `width` float64; h_out receives the rows of rank 0, 1, ...
+ * in rank order (h_counts[r] rows of rank r), identical on every rank; CS_ERR_OVERFLOW (counts set) when cap_rows is
+ * too small.  cs_comm_allreduce_f64: element-wise sum over the ranks, in place. */
+typedef struct cs_comm cs_comm;
+int cs_comm_unique_id(void* out128);
+int cs_comm_create(int device, int rank, int world, const void* unique_id128, cs_comm** out);
+void cs_comm_destroy(cs_comm* comm);
+const char* cs_comm_last_error(const cs_comm* comm);
+int cs_comm_rank(const cs_comm* comm);
+int cs_comm_world(const cs_comm* comm);
+int cs_comm_allgather_rows(cs_comm* comm, const double* h_rows, int64_t n_rows, int32_t width, double* h_out,
+                           int64_t cap_rows, int64_t* h_counts);
+int cs_comm_allreduce_f64(cs_comm* comm, double* h_values, int64_t n);
+
 /* Greedy neighbour suppression of detection.py:348 remove_neighbours, on the host, in O(n) with a
  * grid of win x win cells instead of the reference's O(n^2) scan: patterns are visited in `h_order`
  * (indices by decreasing score, as the caller sorted them); a pattern is kept iff no pattern kept

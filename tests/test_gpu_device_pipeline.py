@@ -362,3 +362,24 @@ def test_run_scoring_of_1d_patterns_equals_wave_per_pixel(monkeypatch):
                 assert np.allclose(a[0][:, 2:], b[0][:, 2:], rtol=0, atol=1e-12, equal_nan=True)
             total += 0 if a[0] is None else len(a[0])
         assert total > 50, (name, total)
+
+
+def test_native_rccl_exchange_single_rank():
+    """csrc/cs_comm.cpp on the GPU: librccl loads, a communicator comes up, and the two exchanges of the sharded path
+    (count + padded all-gather of records, all-reduce of a float64 vector) round-trip.  One rank is all a one-GPU box
+    can run -- RCCL refuses two ranks on one device -- so this pins loading, staging and the call sequence; the gloo
+    tests (tests/test_parallel.py) pin what detect_genome does with several ranks."""
+    from chromosight_amd.parallel import NativeComm
+    comm = NativeComm(0, 0, 1, NativeComm.unique_id())
+    rng = np.random.default_rng(4)
+    rows = rng.random((1234, 7))
+    got, counts = comm.allgather_rows(rows)
+    assert counts.tolist() == [1234] and np.array_equal(got, rows)
+    got, counts = comm.allgather_rows(np.zeros((0, 7)))
+    assert counts.tolist() == [0] and got.shape == (0, 7)
+    big = rng.random((50_000, 7))                      # more than the first capacity guess: the overflow path
+    got, counts = comm.allgather_rows(big)
+    assert np.array_equal(got, big)
+    vec = rng.random(2 * 289 + 1)
+    assert np.array_equal(comm.allreduce_sum(vec), vec)
+    comm.close()

@@ -136,7 +136,7 @@ class Workload:
 
     def step(self):
         if self.name == "c3":
-            block = self.dcool.stage_intra(0, self.max_dist, 17, band_dtype=np.float32)
+            block = self.dcool.stage_blocks([0], self.max_dist, 17, band_dtype=np.float32)[0]
             self.engine.run_normxcorr2(self.dev, block.sig, self.shape, self.kspec, self.out, precision=self.precision,
                                        miss_row=block.miss_row, miss_col=block.miss_col, **self.kwargs)
             return

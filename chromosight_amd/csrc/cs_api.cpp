@@ -35,6 +35,10 @@ struct cs_ctx {
     size_t d_map_bytes = 0;
     void* d_stage = nullptr;         // cs_stage_blocks: tables, per-group partial sums, row extents
     size_t d_stage_bytes = 0;
+    void* h_stage[2] = {nullptr, nullptr};       // page-locked staging of its tables, two slots
+    size_t h_stage_bytes[2] = {0, 0};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    int stage_slot = 0;
     // cs_detect_foci_blocks: the tile kernels of consecutive blocks alternate over the caller's stream and two side
     // streams (each with its own mask-table scratch), so that one block's tail overlaps the next block's ramp
     hipStream_t s_blk[2] = {nullptr, nullptr};
@@ -876,6 +880,10 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     for (int k = 0; k < 2; ++k) {
+        if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
+        if (ctx->ev_stage[k]) (void)hipEventDestroy(ctx->ev_stage[k]);
+    }
+    for (int k = 0; k < 2; ++k) {
         if (ctx->ws_alt[k]) (void)hipFree(ctx->ws_alt[k]);
         if (ctx->s_blk[k]) (void)hipStreamDestroy(ctx->s_blk[k]);
     }
@@ -1467,9 +1475,23 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_s
     pitch = (pitch + 63) / 64 * 64;
     rc = ensure_scratch(ctx, &ctx->d_stage, &ctx->d_stage_bytes, cs::stage_scratch_bytes(n_blocks, n_groups, pitch, v.n_rows));
     if (rc) return rc;
+    // the block / group tables go through one of two page-locked slots; a slot is reused two calls later, after the
+    // event recorded behind its copy has fired (normally long ago): no synchronisation on the way in
+    const int slot = ctx->stage_slot ^= 1;
+    const size_t tbytes = cs::stage_table_bytes(n_blocks, n_groups);
+    if (!ctx->ev_stage[slot]) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stage[slot], hipEventDisableTiming));
+    else CS_HIP(ctx, hipEventSynchronize(ctx->ev_stage[slot]));
+    if (tbytes > ctx->h_stage_bytes[slot]) {
+        if (ctx->h_stage[slot]) CS_HIP(ctx, hipHostFree(ctx->h_stage[slot]));
+        ctx->h_stage[slot] = nullptr;
+        ctx->h_stage_bytes[slot] = 0;
+        CS_HIP(ctx, hipHostMalloc(&ctx->h_stage[slot], 2 * tbytes, hipHostMallocDefault));
+        ctx->h_stage_bytes[slot] = 2 * tbytes;
+    }
     rc = cs::enqueue_stage_blocks(v.indptr, v.indices, v.data, v.is_f64, v.row_w, v.n_rows, tab.data(), n_blocks, max_val,
-                                  kRowsPerGroup, ctx->n_cu, ctx->d_stage, (hipStream_t)stream_);
+                                  kRowsPerGroup, ctx->n_cu, ctx->d_stage, ctx->h_stage[slot], (hipStream_t)stream_);
     if (rc) return fail(ctx, CS_ERR_HIP, "staging kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipEventRecord(ctx->ev_stage[slot], (hipStream_t)stream_));
     return CS_OK;
 }
 

@@ -272,9 +272,10 @@ struct StageGroup {
     int block, row_begin, row_end;
 };
 size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_rows);
+size_t stage_table_bytes(int n_blocks, int n_groups);        // page-locked host bytes for h_tables
 int enqueue_stage_blocks(const long long* indptr, const int* indices, const void* data, int data_is_f64, const double* weight,
                          long long n_rows, StageBlock* h_blocks, int n_blocks, double max_val, int rows_per_group, int n_cu,
-                         void* scratch, hipStream_t stream);
+                         void* scratch, void* h_tables, hipStream_t stream);
 
 // 2-D patterns of many sub-matrices: candidates as composite keys (block << shift) + row * ns + col
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total);

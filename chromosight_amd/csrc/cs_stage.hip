@@ -20,6 +20,7 @@
 // (one slot per group, summed by stage_finish_kernel in a fixed order: no global atomics).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "cs_device.h"
@@ -228,6 +229,12 @@ __global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long lo
 
 }  // namespace
 
+size_t stage_table_bytes(int n_blocks, int n_groups)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(sizeof(StageBlock) * (size_t)n_blocks) + al(sizeof(StageGroup) * (size_t)n_groups);
+}
+
 size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_rows)
 {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -240,7 +247,7 @@ size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_ro
 // stage_scratch_bytes(...) bytes and must stay untouched until the stream has drained.
 int enqueue_stage_blocks(const long long* indptr, const int* indices, const void* data, int data_is_f64, const double* weight,
                          long long n_rows, StageBlock* h_blocks, int n_blocks, double max_val, int rows_per_group, int n_cu,
-                         void* scratch, hipStream_t stream)
+                         void* scratch, void* h_tables, hipStream_t stream)
 {
     std::vector<StageGroup> groups;
     int pitch = 1;
@@ -265,12 +272,11 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     unsigned* part_cnt = (unsigned*)p;
     p += al(sizeof(unsigned) * (size_t)n_groups * pitch);
     long long* row_stop = (long long*)p;
-    hipError_t e = hipMemcpyAsync(d_blocks, h_blocks, sizeof(StageBlock) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(d_groups, groups.data(), sizeof(StageGroup) * (size_t)n_groups, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return (int)e;
-    // the group table lives in pageable host memory that dies with this call: the copy above must have read it
-    e = hipStreamSynchronize(stream);
+    // the two tables travel from page-locked memory the caller keeps alive (stage_table_bytes; one copy, no synchronisation)
+    const size_t blocks_bytes = al(sizeof(StageBlock) * (size_t)n_blocks);
+    std::memcpy(h_tables, h_blocks, sizeof(StageBlock) * (size_t)n_blocks);
+    std::memcpy((char*)h_tables + blocks_bytes, groups.data(), sizeof(StageGroup) * (size_t)n_groups);
+    hipError_t e = hipMemcpyAsync(d_blocks, h_tables, blocks_bytes + sizeof(StageGroup) * (size_t)n_groups, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return (int)e;
     const int per_cu = getenv("CHROMOSIGHT_HIP_STAGE_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_GRID")) : 4;
     const int unroll = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL")) : 4;

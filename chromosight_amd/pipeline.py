@@ -367,8 +367,10 @@ class DeviceCool:
         block once in float64 (exact re-scoring, windows) and float32 (what the matrix-core kernel stages)); None when
         an option needs the block-by-block path (isotonic smoothing, a block split over ranks, float32-only bands)."""
         if (smooth or reduce is not None or rows is not None or unused or not self.upper or not chroms
-                or np.dtype(band_dtype) != np.float64 or os.environ.get("CHROMOSIGHT_HIP_NO_STAGE_BATCH")):
+                or np.dtype(band_dtype) not in (np.dtype(np.float64), np.dtype(np.float32))
+                or os.environ.get("CHROMOSIGHT_HIP_NO_STAGE_BATCH")):
             return None
+        only32 = np.dtype(band_dtype) == np.float32       # float32 maps only (map-level callers: no exact re-scoring)
         dev, lib = self.dev, self.dev.lib
         geo = []
         for ci in chroms:
@@ -387,23 +389,27 @@ class DeviceCool:
         table = (CsStageBlock * len(geo))()
         blocks, off = [], 0
         for k, (ci, s, n, keep, n_diags, in_w, band, ld) in enumerate(geo):
-            b64 = self._resident(n * ld * 8)
+            b64 = None if only32 else self._resident(n * ld * 8)
             b32 = self._resident(n * ld * 4)
-            table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND if band else LAYOUT_DENSE, in_w if band else 0, ld, b64.ptr, b32.ptr,
-                                    laws + off)
+            table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND if band else LAYOUT_DENSE, in_w if band else 0, ld,
+                                    b64.ptr if b64 is not None else None, b32.ptr, laws + off)
             off += 8 * n_diags
             layout = LAYOUT_BAND if band else LAYOUT_DENSE
             flags = _Ptr(self.miss.ptr + s)
-            blk = StagedBlock(self.names[ci], CsMatrix(b64.ptr, CS_F64, layout, ld, 0, in_w if band else 0, 0), (n, n), flags, flags,
-                              max_dist, False, keep)
-            blk.sig32 = CsMatrix(b32.ptr, CS_F32, layout, ld, 0, in_w if band else 0, 0)
-            blk.buffer, blk.pool = b64, self._free
-            blk.buffer32 = b32
+            sig32 = CsMatrix(b32.ptr, CS_F32, layout, ld, 0, in_w if band else 0, 0)
+            sig64 = sig32 if only32 else CsMatrix(b64.ptr, CS_F64, layout, ld, 0, in_w if band else 0, 0)
+            blk = StagedBlock(self.names[ci], sig64, (n, n), flags, flags, max_dist, False, keep)
+            blk.sig32 = sig32
+            blk.buffer, blk.pool = (b32 if only32 else b64), self._free
+            blk.buffer32 = None if only32 else b32
             blocks.append(blk)
         genome = CsCsr(self.n_bins, self.n_bins, max(self.nnz, 1), self.indptr.ptr, self.indices.ptr, self.data.ptr,
                        np_dtype_code(self.val_dtype), 0, None, self.weight.ptr, self.weight.ptr)
+        # asynchronous on `stream`: whoever reads the blocks on another stream or context synchronises first (the callers
+        # that hand blocks to worker threads do; the law scratch is rewritten in stream order)
         dev._check(lib.cs_stage_blocks(dev.ctx, stream, C.byref(genome), table, len(geo), 10.0))
-        dev.sync(stream)
+        if os.environ.get("CHROMOSIGHT_HIP_STAGE_SYNC"):
+            dev.sync(stream)
         return blocks
 
     def view_for(self, block, max_dist, largest_kernel):

@@ -88,6 +88,11 @@ def test_batched_staging_matches_reference_and_the_block_by_block_path(golden):
                 host64 = blk.buffer.download().view(np.float64).reshape(-1)[:n * ld].reshape(n, ld)
                 assert np.array_equal(host32, host64.astype(np.float32)), (name, max_dist, ci)
                 assert not host64[:, (blk.sig.band_w if blk.sig.layout == 1 else n):].any()          # zeroed padding
+    # float32-only staging (map-level callers): the same values rounded once
+    dcool = pipeline.DeviceCool(golden("yeast_cool"))
+    for b64, b32 in zip(dcool.stage_blocks([0, 3, 11], 100, 17), dcool.stage_blocks([0, 3, 11], 100, 17, band_dtype=np.float32)):
+        assert b32.sig.dtype == 0 and b32.sig.ld == b64.sig.ld
+        assert np.array_equal(download_block(dcool, b32), download_block(dcool, b64).astype(np.float32).astype(np.float64))
     dcool = pipeline.DeviceCool(golden("example_cool"))
     g = golden("example_blocks")
     for pname in ("loops", "borders", "hairpins"):

@@ -388,9 +388,10 @@ class GenomeC4:
     def step(self):
         # every owned block is staged ONCE per step, at the loops' keep distance; the borders templates scan band views of
         # the same blocks (the law of a diagonal does not depend on how many diagonals are kept: identical values)
+        # and the two patterns are scanned side by side (parallel.detect_patterns: the 1-D templates' latency-bound chains
+        # run under the loops template's tile kernels)
         staged = self.parallel.stage_genome(self.dcool, [self.loops, self.borders], owned=self.mine)
-        rec_l = self.parallel.detect_genome(self.dcool, self.loops, owned=self.mine, staged=staged)
-        rec_b = self.parallel.detect_genome(self.dcool, self.borders, owned=self.mine, staged=staged)
+        rec_l, rec_b = self.parallel.detect_patterns(self.dcool, [self.loops, self.borders], owned=self.mine, staged=staged)
         return rec_l, rec_b
 
 

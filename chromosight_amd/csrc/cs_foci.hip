@@ -496,11 +496,14 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                 tile[idx] = load_signal(A, p, p + D0 + dd);
             }
             __syncthreads();
-            // every window of the run inside the matrix, detection configuration, square template: the branch-free form
-            const bool interior = P0 >= 0 && P0 + RN <= A.ms && C0 >= 0 && C0 + CN <= A.ns && bins && A.sym_upper && A.full &&
-                                  A.max_dist >= 0 && km == kn;
-            if (mine && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
-            else if (mine && interior && kn == 15) rescore_pixel_lane_lds_interior<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            // detection configuration, square template: the branch-free forms (every window of the run inside the matrix,
+            // or not)
+            const bool lean = bins && A.sym_upper && A.full && A.max_dist >= 0 && km == kn;
+            const bool interior = P0 >= 0 && P0 + RN <= A.ms && C0 >= 0 && C0 + CN <= A.ns;
+            if (mine && lean && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            else if (mine && lean && interior && kn == 15) rescore_pixel_lane_lds_interior<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            else if (mine && lean && kn == 17) rescore_pixel_lane_lds_interior<17, true>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            else if (mine && lean && kn == 15) rescore_pixel_lane_lds_interior<15, true>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine) {
                 if (kn == 17) rescore_pixel_lane_lds<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
                 else if (kn == 15) rescore_pixel_lane_lds<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);

@@ -146,16 +146,19 @@ __device__ __forceinline__ void rescore_pixel_lane(const CorrArgs<double>& A, in
 // it is false (x + 0.0 == x: the sums are bit-identical to the branching form's).  The general function compiles to
 // ~215 instructions per window pixel (135 of them scalar branch bookkeeping around `if (missing)`): 363 us for the 400 000
 // pixels of a borders template on the 23-block genome; this one to ~25.
-template <int K>
+// EDGE: windows that leave the matrix (the first and last runs of every sub-matrix) -- the frame rules of
+// missing_from_flags as selects; still no branch.
+template <int K, bool EDGE = false>
 __device__ __forceinline__ void rescore_pixel_lane_lds_interior(const CorrArgs<double>& A, const double* tile, const double* wl,
                                                                 const unsigned char* rfl, const unsigned char* cfl, int P0, int C0,
                                                                 int D0, int DN, int oi, int oj, double& r, double& nobs)
 {
     r = 0.0;
     nobs = A.ks.n;
+    if (EDGE && !((oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns))) return;
     if (pixel_forced_zero(A, oi, oj)) return;
     constexpr int kh = (K - 1) / 2, kk = K * K;
-    const int md = A.max_dist;
+    const int md = A.max_dist, ms = A.ms, ns = A.ns;
     double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
     const int q0 = oj - kh;
     const unsigned char* cf = cfl + (q0 - C0);
@@ -172,7 +175,13 @@ __device__ __forceinline__ void rescore_pixel_lane_lds_interior(const CorrArgs<d
             s1 += v;
             s2 = fma(v, v, s2);
             const int d = d0 + kj;
-            const bool m = d < 0 ? d >= -K : ((rf | (cf[kj] != 0)) & (d <= md));
+            bool m = d < 0 ? d >= -K : ((rf | (cf[kj] != 0)) & (d <= md));
+            if constexpr (EDGE) {
+                const int q = q0 + kj;
+                const bool inside = ((unsigned)p < (unsigned)ms) & ((unsigned)q < (unsigned)ns);
+                const bool m_out = (q >= ns) ? (p >= ms - md - 2) : ((p < 0) & ((q < 0) | (q < md + K)));
+                m = (inside ? ((rf | (cf[kj] != 0)) & (d >= 0) & (d <= md)) : m_out) | ((d < 0) & (d >= -K));
+            }
             nm += m ? 1.0 : 0.0;
             ka += m ? w[kk + kj] : 0.0;
             kb += m ? w[2 * kk + kj] : 0.0;

@@ -42,7 +42,6 @@ def assign_blocks(costs, world_size):
     return [sorted(o) for o in owned]
 
 
-_HELPER = None
 _COMMS = {}
 
 
@@ -116,15 +115,6 @@ def native_comm():
         dist.broadcast_object_list(box, src=0)
         _COMMS[key] = NativeComm(torch.cuda.current_device(), rank, world, box[0])
     return _COMMS[key]
-
-
-def _helper():
-    """One helper thread per process (detect_genome: device work of the next template while this thread post-processes)."""
-    global _HELPER
-    if _HELPER is None:
-        import concurrent.futures
-        _HELPER = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="chromosight-next-template")
-    return _HELPER
 
 
 def _world():
@@ -325,8 +315,55 @@ def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np
     return dict(zip(owned, genome.stage_blocks(owned, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
 
 
+def _exchange_records(local, n_kernels, n_iterations):
+    """The ONE record exchange of a detect call: count + padded all-gather (RCCL: csrc/cs_comm.cpp); per (template,
+    iteration) the rows come in the order separate gathers would give -- ranks concatenated, stable by block."""
+    merged = _gather(local, len(GENOME_FIELDS))
+    out = [merged[(merged[:, 5] == kernel_id) & (merged[:, 6] == it)] for kernel_id in range(n_kernels) for it in range(n_iterations)]
+    out = [m for m in out if m.shape[0]]
+    return np.concatenate(out, axis=0) if out else np.zeros((0, len(GENOME_FIELDS)))
+
+
+_PATTERN_THREADS = None
+
+
+def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
+    """detect_genome for SEVERAL pattern configurations on blocks staged once (stage_genome), concurrently: a genome
+    scan is a few bandwidth / matrix-core-bound launches (a 2-D pattern's tile kernels) next to many latency-bound ones
+    (1-D patterns: a few thousand pixels per block and template; labelling, statistics, synchronisations) -- run one after
+    the other the latter leave the chip idle, run side by side they disappear under the former.  One host thread per
+    configuration whose templates are not iterated; the record exchanges then follow in configuration order on this
+    thread (collectives must be issued in the same order on every rank), and so do iterated configurations as a whole.
+    Returns the list of detect_genome results."""
+    global _PATTERN_THREADS
+    if staged is None:
+        staged = stage_genome(genome, kernel_configs, owned=owned)
+    dist, rank, world = _world()
+    if owned is None:
+        max_dist = max(max(cfg["max_dist"] // genome.binsize, 1) for cfg in kernel_configs)
+        costs = [block_cost((genome.chrom_size(ci),) * 2, max_dist, False) for ci in range(genome.n_chrom)]
+        owned = assign_blocks(costs, world)[rank]
+    owned = list(owned)
+    complete = all(ci in staged for ci in owned)
+    side = [i for i, cfg in enumerate(kernel_configs) if cfg["max_iterations"] == 1] if complete and len(kernel_configs) > 1 else []
+    if _PATTERN_THREADS is None and side:
+        import concurrent.futures
+        _PATTERN_THREADS = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="chromosight-pattern")
+    if side:
+        genome.dev.sync()                                    # staging is complete before several threads and streams read it
+    futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=staged,
+                                          exchange=False) for i in side}
+    results = [None] * len(kernel_configs)
+    for i, cfg in enumerate(kernel_configs):
+        if i not in futures:
+            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=staged)
+    for i in side:
+        results[i] = _exchange_records(futures[i].result(), len(kernel_configs[i]["kernels"]), 1)
+    return results
+
+
 def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, stage=None, detect=None,
-                  owned=None, staged=None):
+                  owned=None, staged=None, exchange=True):
     """`chromosight detect` over all intra-chromosomal blocks of a DeviceCool, sharded over the ranks
     like the reference's Pool.imap over sub-matrices (cli/chromosight.py:738-755): every rank stages
     and scans its own blocks (LPT assignment by band pixels), the per-block tables are all-gathered
@@ -339,15 +376,15 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     `owned`: this rank's block indices when the caller fixed the assignment (e.g. a rank that only
     holds the pixels of its own chromosomes); default: LPT by scanned pixels.
     `staged`: blocks of stage_genome (staged once for several patterns); a block that cannot serve this configuration
-    through a band view is staged here as usual.
+    through a band view is staged here as usual.  exchange=False: this rank's records only (detect_patterns).
     Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
     bins, identical on all ranks, in the single-process order."""
     batch = None
     stage_default = stage is None
     if stage is None and detect is None:
         from . import pipeline
-        batch = lambda g, blks, cfg, k, t, w=True, defer=False: pipeline.detect_blocks(g, blks, cfg, k, tsvd=t, raw=True,
-                                                                                       want_windows=w, defer=defer)
+        batch = lambda g, blks, cfg, k, t, w=True, defer=False, dev=None, stream=None: pipeline.detect_blocks(
+            g, blks, cfg, k, tsvd=t, raw=True, want_windows=w, defer=defer, dev=dev, stream=stream)
     if stage is None or detect is None:
         from . import pipeline
         stage = stage or (lambda g, ci, md, lk: g.stage_intra(ci, md, lk, smooth=smooth, band_dtype=band_dtype,
@@ -378,22 +415,32 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     staged = {**have, **fresh}
     out = []
     pending = []
-    # Templates that do not depend on each other (a single iteration each): the device work of template k + 1 is issued
-    # by a helper thread while this one applies the acceptance rules to the records of template k (numpy, a third of a
-    # template's wall time on the 23-block genome).  One native call in flight at a time: the context is not shared.
+    # Templates that do not depend on each other (a single iteration each) are scanned concurrently: one host thread per
+    # template, each with its own context and stream on this GPU (pipeline._Workers), so the latency-bound stages of one
+    # template's chain (labelling, statistics, the synchronisations) run under another's, and this thread applies the
+    # acceptance rules (numpy, a third of a template's wall time on the 23-block genome) while the others are on the device.
     kernels = [np.asarray(k, dtype=np.float64) for k in kernel_config["kernels"]]
-    overlap = batch is not None and kernel_config["max_iterations"] == 1 and len(kernels) > 1 and bool(mine)
-    submit = lambda k: _helper().submit(batch, genome, [staged[ci] for ci in mine], kernel_config, kernels[k], tsvd, False, True)
-    ahead = submit(0) if overlap else None
+    overlap = (batch is not None and stage_default and kernel_config["max_iterations"] == 1 and len(kernels) > 1 and bool(mine)
+               and hasattr(genome, "workers") and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_OVERLAP"))
+    futures = []
+    if overlap:
+        pool = genome.workers(min(len(kernels), 3))
+        if exchange:                                         # (detect_patterns has synchronised once for all its threads)
+            genome.dev.sync()                                # the staged blocks are complete before other streams read them
+        blocks_mine = [staged[ci] for ci in mine]
+
+        def scan(k):
+            dev, stream = pool.device()
+            return batch(genome, blocks_mine, kernel_config, kernels[k], tsvd, False, True, dev, stream)
+
+        futures = [pool.pool.submit(scan, k) for k in range(len(kernels))]
     for kernel_id, kernel in enumerate(kernels):
         for it in range(kernel_config["max_iterations"]):
             rows, wins = [], []
             # the windows only feed the pileup of the next iteration: the last one does not fetch them
             need_windows = it + 1 < kernel_config["max_iterations"]
             if overlap:
-                finish = ahead.result()
-                ahead = submit(kernel_id + 1) if kernel_id + 1 < len(kernels) else None
-                results = finish()
+                results = futures[kernel_id].result()()
             else:
                 results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd, need_windows) if batch else None
             for pos, ci in enumerate(mine):
@@ -440,11 +487,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
             kk = kernel.size
             with np.errstate(all="ignore"):
                 kernel = (both[:kk] / both[kk:2 * kk]).reshape(kernel.shape)
-    # one count + one padded all-gather for the whole call (RCCL: csrc/cs_comm.cpp); per (template, iteration) the rows then
-    # come in the order separate gathers gave -- ranks concatenated, stable by block
     local = np.concatenate(pending, axis=0) if pending else np.zeros((0, len(GENOME_FIELDS)))
-    merged = _gather(local, len(GENOME_FIELDS))
-    out = [merged[(merged[:, 5] == kernel_id) & (merged[:, 6] == it)] for kernel_id in range(len(kernels))
-           for it in range(kernel_config["max_iterations"])]
-    out = [m for m in out if m.shape[0]]
-    return np.concatenate(out, axis=0) if out else np.zeros((0, len(GENOME_FIELDS)))
+    if not exchange:
+        return local                                         # detect_patterns: the caller exchanges (in a fixed order)
+    return _exchange_records(local, len(kernels), kernel_config["max_iterations"])

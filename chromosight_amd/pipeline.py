@@ -650,14 +650,17 @@ def b_is_band(block):
     return block.sig.layout == LAYOUT_BAND and not block.inter and getattr(block, "row_window", None) is None
 
 
-def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True, defer=False):
+def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True, defer=False,
+                  dev=None, stream=None):
     """detect_block for every staged block of `blocks`; results in the order of `blocks`.  Banded intra blocks go to the
     device in ONE native call per template (1-D patterns: cs_detect_foci_batch; 2-D patterns: cs_detect_foci_blocks);
     what the library cannot batch (dense-staged short chromosomes, inter blocks, odd templates) goes block by block,
     several at a time (see _Workers).  defer=True: returns a callable that yields the results -- the native calls are
     done when detect_blocks returns, the acceptance rules (numpy on the returned records) run in the callable, so a
-    caller can overlap them with the next template's device work (parallel.detect_genome)."""
+    caller can overlap them with the next template's device work (parallel.detect_genome).  dev / stream: another
+    context and stream of the same GPU for the batched calls (templates scanned concurrently by several host threads)."""
     kernel = np.asarray(kernel, dtype=np.float64)
+    bdev = dev or dcool.dev
     done = (lambda res: (lambda: res)) if defer else (lambda res: res)
     if any(min(b.shape) > max(kernel.shape) for b in blocks):
         _check_template(kernel)
@@ -670,9 +673,11 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
         if len(banded) > 1:
             many = cid.detect_many_on_device if kernel_config["max_dist"] == 0 else cid.detect_blocks_on_device
             extra = dict(raw=True) if kernel_config["max_dist"] == 0 else {}
-            fin = many(dcool.dev, [blocks[k] for k in banded], kspec, kernel_config, want_windows=want_windows, defer=True, **extra)
+            fin = many(bdev, [blocks[k] for k in banded], kspec, kernel_config, want_windows=want_windows, defer=True, stream=stream,
+                       **extra)
         if fin is not None:
-            rest = {k: detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
+            rest = {k: detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows, dev=dev,
+                                    stream=stream)
                     for k in live if k not in banded}
 
             def finish():

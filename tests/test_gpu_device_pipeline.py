@@ -171,6 +171,12 @@ def compare_genome(total_bins, max_dist_bins):
     loops = copy.deepcopy(ck.loops)
     loops["max_dist"] = max_dist_bins * binsize
     borders = copy.deepcopy(ck.borders)
+    # ... and both patterns side by side (parallel.detect_patterns)
+    both = parallel.detect_patterns(dcool, [loops, borders])
+    for cfg, rec in zip((loops, borders), both):
+        ref = parallel.detect_genome(dcool, cfg)
+        assert rec.shape == ref.shape and np.array_equal(rec[:, [0, 1, 2, 5, 6]], ref[:, [0, 1, 2, 5, 6]])
+        assert np.abs(rec[:, 3] - ref[:, 3]).max() < 1e-12
     n_found = {}
     # what the bench does: every block staged once at the loops' keep distance, the borders templates on band views
     shared = parallel.stage_genome(dcool, [loops, borders])

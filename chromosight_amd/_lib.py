@@ -141,6 +141,7 @@ _PROTOTYPES = {
     "cs_event_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cs_event_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cs_event_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "cs_normxcorr2": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                 C.POINTER(CsNormxcorr2Params), C.POINTER(CsMatrix), C.POINTER(CsMatrix)]),
@@ -394,6 +395,10 @@ class Device:
 
     def record(self, event, stream=None):
         self._check(self.lib.cs_event_record(self.ctx, event, stream))
+
+    def wait_event(self, event, stream=None):
+        """Later work on `stream` waits for `event` (device-side, no host synchronisation)."""
+        self._check(self.lib.cs_stream_wait_event(self.ctx, stream, event))
 
     def elapsed_ms(self, start, stop):
         ms = C.c_float()

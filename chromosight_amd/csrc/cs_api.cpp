@@ -999,6 +999,14 @@ int cs_event_record(cs_ctx* ctx, void* event, void* stream)
     return CS_OK;
 }
 
+int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event)
+{
+    if (!event) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
+    CS_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return CS_OK;
+}
+
 int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms)
 {
     if (!start || !stop || !ms) return CS_ERR_INVALID;

@@ -312,7 +312,19 @@ def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np
         costs = [block_cost((genome.chrom_size(ci),) * 2, max_dist, False) for ci in range(genome.n_chrom)]
         owned = assign_blocks(costs, world)[rank]
     owned = list(owned)
-    return dict(zip(owned, genome.stage_blocks(owned, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
+    staged = StagedSet(zip(owned, genome.stage_blocks(owned, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
+    if hasattr(genome, "dev") and hasattr(genome.dev, "new_event"):
+        # staging is asynchronous on the genome's stream: streams of other contexts wait for this event, not the host
+        if getattr(genome, "_ready_event", None) is None:
+            genome._ready_event = genome.dev.new_event()
+        genome.dev.record(genome._ready_event)
+        staged.ready = genome._ready_event
+    return staged
+
+
+class StagedSet(dict):
+    """{chromosome: StagedBlock} of stage_genome + the event that fires when their staging is complete."""
+    ready = None
 
 
 def _exchange_records(local, n_kernels, n_iterations):
@@ -349,7 +361,8 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     if _PATTERN_THREADS is None and side:
         import concurrent.futures
         _PATTERN_THREADS = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="chromosight-pattern")
-    if side:
+    ready = getattr(staged, "ready", None)
+    if side and ready is None:
         genome.dev.sync()                                    # staging is complete before several threads and streams read it
     futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=staged,
                                           exchange=False) for i in side}
@@ -397,6 +410,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     costs = [block_cost((n, n), max_dist, False) for n in sizes]
     mine = list(owned) if owned is not None else assign_blocks(costs, world)[rank]
     have = {}
+    staged_in = staged
     if staged is not None and not smooth:
         for ci in mine:
             blk = staged.get(ci)
@@ -425,12 +439,15 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     futures = []
     if overlap:
         pool = genome.workers(min(len(kernels), 3))
-        if exchange:                                         # (detect_patterns has synchronised once for all its threads)
+        ready = getattr(staged_in, "ready", None) if not todo else None
+        if ready is None:
             genome.dev.sync()                                # the staged blocks are complete before other streams read them
         blocks_mine = [staged[ci] for ci in mine]
 
         def scan(k):
             dev, stream = pool.device()
+            if ready is not None:
+                dev.wait_event(ready, stream)                # device-side: the staging of these blocks has finished
             return batch(genome, blocks_mine, kernel_config, kernels[k], tsvd, False, True, dev, stream)
 
         futures = [pool.pool.submit(scan, k) for k in range(len(kernels))]
@@ -440,6 +457,8 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
             # the windows only feed the pileup of the next iteration: the last one does not fetch them
             need_windows = it + 1 < kernel_config["max_iterations"]
             if overlap:
+                # the acceptance rules (many small numpy calls) here, one template after the other: spread over the worker
+                # threads they fight for the interpreter lock and each takes four times as long
                 results = futures[kernel_id].result()()
             else:
                 results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd, need_windows) if batch else None

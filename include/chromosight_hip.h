@@ -82,6 +82,9 @@ int cs_stream_destroy(cs_ctx* ctx, void* stream);
 int cs_event_create(cs_ctx* ctx, void** event);
 int cs_event_destroy(cs_ctx* ctx, void* event);
 int cs_event_record(cs_ctx* ctx, void* event, void* stream);
+/* work enqueued on `stream` after this call starts only when `event` (recorded on any stream of the same GPU, by any
+ * context) has fired: ordering between streams without a host synchronisation */
+int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event);
 /* synchronises on `stop`, then returns the elapsed milliseconds between the two events */
 int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms);
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU run of the C4 genome does, timed on one GPU (no exchange): its LPT share of the 23 blocks.
+    python tools/time_rank_share.py [n_gpus] [rank]"""
+import copy, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import chromosight_amd.kernels as ck
+from chromosight_amd import parallel, pipeline
+from tools.synthetic_genome import genome_sizes, make_cool
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+rank = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+sizes = genome_sizes(200_000)
+costs = [parallel.block_cost((int(n), int(n)), 1000, False) for n in sizes]
+mine = parallel.assign_blocks(costs, world)[rank]
+template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+cool, _ = make_cool(200_000, 1000, 2000, seed=2, template=template, only=mine)
+dcool = pipeline.DeviceCool(cool)
+loops = copy.deepcopy(ck.loops); loops["max_dist"] = 2_000_000
+borders = copy.deepcopy(ck.borders)
+ts = []
+for it in range(14):
+    dcool.dev.sync(); t0 = time.perf_counter()
+    staged = parallel.stage_genome(dcool, [loops, borders], owned=mine)
+    rec = parallel.detect_patterns(dcool, [loops, borders], owned=mine, staged=staged)
+    dcool.dev.sync(); ts.append((time.perf_counter() - t0) * 1e3)
+px = sum(costs[i] for i in mine)
+print(f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (min {min(ts):.3f}); "
+      f"patterns {[len(r) for r in rec]}")
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for it in range(20):
+        staged = parallel.stage_genome(dcool, [loops, borders], owned=mine)
+        rec = parallel.detect_patterns(dcool, [loops, borders], owned=mine, staged=staged)
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative").print_stats(28)

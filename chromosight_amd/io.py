@@ -3,9 +3,10 @@ reads through cooler (contacts_map.py:129, 209, 529: pixel table, bin table with
 chromosome offsets) decoded into the dictionary `pipeline.DeviceCool` uploads.
 
 Neither cooler nor h5py exists in the target image, and the path needs nothing of them: a .cool is a
-handful of 1-D HDF5 datasets.  They are decoded with the HDF5 command line tool `h5dump -b` (binary
-dump of one dataset, any chunking / compression), located through $CHROMOSIGHT_H5DUMP, PATH or
-/opt/conda/bin.  Multi-resolution files: `path::/resolutions/2000`.
+handful of 1-D HDF5 datasets.  They are decoded by chromosight_amd.hdf5_lite (numpy + zlib: the classic
+HDF5 format h5py writes by default); files in a newer format fall back to the HDF5 command line tool
+`h5dump -b` (located through $CHROMOSIGHT_H5DUMP, PATH or /opt/conda/bin).  Multi-resolution files:
+`path::/resolutions/2000`.
 """
 import csv
 import json
@@ -17,6 +18,8 @@ import subprocess
 import tempfile
 
 import numpy as np
+
+from . import hdf5_lite
 
 _TYPES = {"H5T_STD_I8LE": "<i1", "H5T_STD_I16LE": "<i2", "H5T_STD_I32LE": "<i4", "H5T_STD_I64LE": "<i8",
           "H5T_STD_U8LE": "<u1", "H5T_STD_U16LE": "<u2", "H5T_STD_U32LE": "<u4", "H5T_STD_U64LE": "<u8",
@@ -66,10 +69,67 @@ def _attr_int(tool, path, group, name):
     return int(re.search(r"\(0\):\s*(-?\d+)", txt).group(1))
 
 
+def _weights(uri, balance, norm, n_bins, read):
+    """The balancing weights under the rules of load_cool; read() returns the column or None when it is absent."""
+    weight = read()
+    if weight is not None:
+        weight = np.asarray(weight, dtype=np.float64)
+        return np.where(np.isfinite(weight), 1.0, np.nan) if norm == "raw" else weight
+    if norm == "raw":
+        return np.ones(n_bins)
+    raise ValueError(f"{uri}: no balancing weights (bins/{balance}).  Balance the file first (cooler balance; the "
+                     "reference does it with cooler.balance_cooler) or pass norm='raw' to scan raw counts with every "
+                     "bin detectable")
+
+
+def _load_cool_native(path, group, balance, norm):
+    """load_cool through chromosight_amd.hdf5_lite (no external tool)."""
+    f = hdf5_lite.File(path)
+    ds = lambda name: f"{group}/{name}"
+    names = f.dataset(ds("chroms/name"))
+    attrs = f.attrs(group or "/")
+    if "bin-size" not in attrs:
+        raise hdf5_lite.Hdf5Unsupported("no numeric bin-size attribute (variable-size bins?)")
+    cool = {
+        "bin1_id": f.dataset(ds("pixels/bin1_id")),
+        "bin2_id": f.dataset(ds("pixels/bin2_id")),
+        "count": f.dataset(ds("pixels/count")),
+        "bin_start": f.dataset(ds("bins/start")).astype(np.int64),
+        "bin_end": f.dataset(ds("bins/end")).astype(np.int64),
+        "chrom_offset": f.dataset(ds("indexes/chrom_offset")).astype(np.int64),
+        "chrom_names": np.array([n.split(b"\0")[0].decode() for n in names]),
+        "binsize": np.int64(attrs["bin-size"]),
+    }
+    cool["weight"] = _weights(path, balance, norm, cool["bin_start"].size,
+                              lambda: f.dataset(ds(f"bins/{balance}")) if f.exists(ds(f"bins/{balance}")) else None)
+    return cool
+
+
 def _has_dataset(tool, path, dataset):
     """Is `dataset` an object of the file?  (`h5dump -n` lists every group and dataset.)"""
     listing = _run([tool, "-n", str(path)])
     return re.search(r"^\s*dataset\s+" + re.escape(dataset) + r"\s*$", listing, flags=re.M) is not None
+
+
+def _load_cool_h5dump(uri, path, group, balance, norm):
+    """load_cool through the HDF5 command line tool (`h5dump -b`: any chunking, compression, format version)."""
+    tool = find_h5dump()
+    ds = lambda name: f"{group}/{name}"
+    n_bins = None
+    cool = {
+        "bin1_id": _numeric(tool, path, ds("pixels/bin1_id")),
+        "bin2_id": _numeric(tool, path, ds("pixels/bin2_id")),
+        "count": _numeric(tool, path, ds("pixels/count")),
+        "bin_start": _numeric(tool, path, ds("bins/start")).astype(np.int64),
+        "bin_end": _numeric(tool, path, ds("bins/end")).astype(np.int64),
+        "chrom_offset": _numeric(tool, path, ds("indexes/chrom_offset")).astype(np.int64),
+        "chrom_names": np.array(_strings(tool, path, ds("chroms/name"))),
+        "binsize": np.int64(_attr_int(tool, path, group or "/", "bin-size")),
+    }
+    n_bins = cool["bin_start"].size
+    cool["weight"] = _weights(uri, balance, norm, n_bins,
+                              lambda: _numeric(tool, path, ds(f"bins/{balance}")) if _has_dataset(tool, path, ds(f"bins/{balance}")) else None)
+    return cool
 
 
 def load_cool(uri, balance="weight", norm="auto"):
@@ -89,29 +149,14 @@ def load_cool(uri, balance="weight", norm="auto"):
         raise ValueError("norm must be one of: auto, raw ('force' re-balances the file: not part of this package)")
     path, _, group = str(uri).partition("::")
     group = "/" + group.strip("/") if group else ""
-    tool = find_h5dump()
-    ds = lambda name: f"{group}/{name}"
-    n_bins = None
-    cool = {
-        "bin1_id": _numeric(tool, path, ds("pixels/bin1_id")),
-        "bin2_id": _numeric(tool, path, ds("pixels/bin2_id")),
-        "count": _numeric(tool, path, ds("pixels/count")),
-        "bin_start": _numeric(tool, path, ds("bins/start")).astype(np.int64),
-        "bin_end": _numeric(tool, path, ds("bins/end")).astype(np.int64),
-        "chrom_offset": _numeric(tool, path, ds("indexes/chrom_offset")).astype(np.int64),
-        "chrom_names": np.array(_strings(tool, path, ds("chroms/name"))),
-        "binsize": np.int64(_attr_int(tool, path, group or "/", "bin-size")),
-    }
-    n_bins = cool["bin_start"].size
-    if _has_dataset(tool, path, ds(f"bins/{balance}")):
-        weight = _numeric(tool, path, ds(f"bins/{balance}")).astype(np.float64)
-        cool["weight"] = np.where(np.isfinite(weight), 1.0, np.nan) if norm == "raw" else weight
-    elif norm == "raw":
-        cool["weight"] = np.ones(n_bins)
-    else:
-        raise ValueError(f"{uri}: no balancing weights (bins/{balance}).  Balance the file first (cooler balance; the "
-                         "reference does it with cooler.balance_cooler) or pass norm='raw' to scan raw counts with every "
-                         "bin detectable")
+    cool = None
+    if not os.environ.get("CHROMOSIGHT_H5DUMP_ONLY"):
+        try:
+            cool = _load_cool_native(path, group, balance, norm)
+        except hdf5_lite.Hdf5Unsupported:
+            cool = None                  # a file written with a newer HDF5 format: the command line tool below
+    if cool is None:
+        cool = _load_cool_h5dump(uri, path, group, balance, norm)
     for key in ("bin1_id", "bin2_id"):
         if cool[key].size and cool[key].max() < 2 ** 31:
             cool[key] = cool[key].astype(np.int32)

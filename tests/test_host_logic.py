@@ -325,22 +325,56 @@ def test_sub_matrix_order_and_bins():
     assert pipeline.sub_matrices(G, True) == [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]   # contacts_map.py:274-279
 
 
-def test_load_cool_decodes_the_reference_fixture(golden):
-    """chromosight_amd.io.load_cool on data_test/example.cool (the reference's own test file, kept as
-    a data fixture) == the decoded arrays every pipeline test uses."""
+def test_load_cool_decodes_the_reference_fixture(golden, monkeypatch):
+    """chromosight_amd.io.load_cool on data_test/example.cool (the reference's own test file, kept as a data fixture)
+    == the decoded arrays every pipeline test uses: through the package's own HDF5 reader (hdf5_lite: no external tool,
+    never skipped) and, where the HDF5 command line tool exists, through the h5dump route as well."""
     from chromosight_amd import io as cio
+    from conftest import GOLDEN
+    ref = golden("example_cool")
+    routes = [None]
     try:
         cio.find_h5dump()
+        routes.append("1")
     except RuntimeError:
-        pytest.skip("no h5dump in this environment")
+        pass
+    for only in routes:
+        if only:
+            monkeypatch.setenv("CHROMOSIGHT_H5DUMP_ONLY", only)
+        cool = cio.load_cool(GOLDEN / "example.cool")
+        for key in ("bin1_id", "bin2_id", "count", "bin_start", "bin_end", "chrom_offset", "binsize"):
+            assert np.array_equal(np.asarray(cool[key]).astype(np.int64), np.asarray(ref[key]).astype(np.int64)), (only, key)
+        assert np.array_equal(np.isnan(cool["weight"]), np.isnan(ref["weight"]))
+        assert np.allclose(cool["weight"], ref["weight"], equal_nan=True, rtol=0, atol=0)
+        assert [str(n) for n in cool["chrom_names"]] == [str(n) for n in ref["chrom_names"]]
+
+
+def test_hdf5_lite_reads_what_a_cool_holds(golden):
+    """The reader on the fixture: group listing, chunked + shuffled + deflated columns, the enumerated chromosome column,
+    fixed-length strings, numeric attributes; load_cool's rules for the weight column (refused when absent unless
+    norm='raw'; read errors are not swallowed)."""
+    from chromosight_amd import hdf5_lite
+    from chromosight_amd import io as cio
     from conftest import GOLDEN
-    cool = cio.load_cool(GOLDEN / "example.cool")
-    ref = golden("example_cool")
-    for key in ("bin1_id", "bin2_id", "count", "bin_start", "bin_end", "chrom_offset", "binsize"):
-        assert np.array_equal(np.asarray(cool[key]).astype(np.int64), np.asarray(ref[key]).astype(np.int64)), key
-    assert np.array_equal(np.isnan(cool["weight"]), np.isnan(ref["weight"]))
-    assert np.allclose(cool["weight"], ref["weight"], equal_nan=True, rtol=0, atol=0)
-    assert [str(n) for n in cool["chrom_names"]] == [str(n) for n in ref["chrom_names"]]
+    f = hdf5_lite.File(GOLDEN / "example.cool")
+    assert sorted(f.links(f.root)) == ["bins", "chroms", "indexes", "pixels"]
+    assert f.exists("bins/weight") and not f.exists("bins/KR")
+    attrs = f.attrs("/")
+    assert int(attrs["bin-size"]) == 1000 and int(attrs["nbins"]) == 720 and int(attrs["nnz"]) == 109975
+    chrom = f.dataset("bins/chrom")
+    assert f.enum_names("bins/chrom") == {0: "chr1", 1: "chr2", 2: "chr3"}
+    off = golden("example_cool")["chrom_offset"]
+    assert np.array_equal(chrom, np.repeat(np.arange(3), np.diff(off)))
+    assert [n.decode() for n in f.dataset("chroms/name")] == ["chr1", "chr2", "chr3"]
+    assert int(f.dataset("pixels/count").sum()) == int(attrs["sum"])
+    with pytest.raises(ValueError, match="no balancing weights"):
+        cio.load_cool(GOLDEN / "example.cool", balance="KR")
+    raw = cio.load_cool(GOLDEN / "example.cool", balance="KR", norm="raw")
+    assert np.all(raw["weight"] == 1.0)
+    keep = cio.load_cool(GOLDEN / "example.cool", norm="raw")            # detectable bins of the stored weights, raw counts
+    assert np.array_equal(np.isnan(keep["weight"]), np.isnan(golden("example_cool")["weight"]))
+    with pytest.raises(hdf5_lite.Hdf5Unsupported):
+        hdf5_lite.File(GOLDEN / "example_loops.tsv")
 
 
 def test_distance_law_other_reducers_on_host():

@@ -5,14 +5,14 @@
 # summaries into profiles/ (tracked).  Counter passes are separate from the trace passes and from
 # each other (FETCH_SIZE and WRITE_SIZE do not fit one pass), as the MI355X guide prescribes.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$root"
 
-bench() { python bench.py "$@" 2>/dev/null | tail -1; }
+bench() { timeout 600 python bench.py "$@" 2>/dev/null | tail -1; }
 
 # 1. bench lines (the default command first: it is what the driver runs)
 bench > "$out/bench_c2.json"
@@ -33,33 +33,33 @@ CHROMOSIGHT_HIP_MFMA_REG=0 python bench.py --workload c4p --no-cpu-baseline 2>/d
 # 2. kernel traces of the same commands (c3 and c4 show the helper kernels: band extents, distance law,
 #    tiler, mask tables, compaction, sort, foci, re-scoring)
 for w in c2 c3 c3k c4p; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$w" -o $w -- \
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$w" -o $w -- \
       python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > "$out/trace_$w.log" 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c4" -o c4 -- \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c4" -o c4 -- \
     python bench.py --workload c4 --steps 3 --warmup 1 > "$out/trace_c4.log" 2>&1
 
 # 3. HBM counters of the dominant kernel of the dense and the two banded workloads, one pass each
 for w in c2 c3k c4p; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_${w}_$c" -o $w -- \
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_${w}_$c" -o $w -- \
         python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_${w}_$c.log" 2>&1
   done
   # VALU / wave counters (own pass)
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY \
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY \
       --kernel-trace --output-format csv -d "$out/pmc_${w}_sq" -o $w -- \
       python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_${w}_sq.log" 2>&1
 done
 # matrix-core occupancy of the dense kernel (own pass)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-trace --output-format csv -d "$out/pmc_c2_mfma" -o c2 -- \
     python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c2_mfma.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-trace --output-format csv -d "$out/pmc_c4p_mfma" -o c4p -- \
     python bench.py --workload c4p --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c4p_mfma.log" 2>&1
 # helper kernels of the CSR path: bytes moved by the distance law / tiler (c3)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c3_$c" -o c3 -- \
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c3_$c" -o c3 -- \
       python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c3_$c.log" 2>&1
 done
 
@@ -69,7 +69,7 @@ mkdir -p tools/ubench/build
 for u in fetch_calib coexec fma_rate; do
   [ -x tools/ubench/build/$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/build/$u 2>/dev/null
 done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o calib -- \
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o calib -- \
     tools/ubench/build/fetch_calib > "$out/calib.log" 2>&1
 python tools/time_templates.py c3 > "$out/template_kernels.txt" 2>/dev/null
 python tools/time_templates.py c4p >> "$out/template_kernels.txt" 2>/dev/null

@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
@@ -92,7 +92,8 @@ avg_ns = {}
 if stats:
     for r in csv.DictReader(open(stats)):
         avg_ns[r["Name"]] = float(r["AverageNs"])
-for kname in ("distance_law_kernel", "csr_to_band_rows_kernel", "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel"):
+for kname in ("stage_law_kernel", "stage_tile_kernel", "stage_finish_kernel", "distance_law_kernel", "csr_to_band_rows_kernel",
+              "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel"):
     rec = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         rec.update(per_dispatch(find(f"pmc_c3_{c}/**/*counter_collection.csv"), kname))

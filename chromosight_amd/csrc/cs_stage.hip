@@ -103,20 +103,21 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
     }
 }
 
-// 64 diagonals x 4 group phases per workgroup: the partial sums of a block's groups are added in a fixed order
-// (phase by phase, then the four phases), so a law does not depend on how the groups were scheduled
-__global__ __launch_bounds__(256) void stage_finish_kernel(const StageBlock* __restrict__ blocks, int pitch,
+// 64 diagonals x 16 group phases per workgroup: the partial sums of a block's groups are added in a fixed order
+// (phase by phase, then the phases), so a law does not depend on how the groups were scheduled
+constexpr int kFinishPhases = 16;
+__global__ __launch_bounds__(64 * kFinishPhases) void stage_finish_kernel(const StageBlock* __restrict__ blocks, int pitch,
                                                            const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt)
 {
-    __shared__ double s_sum[4][64];
-    __shared__ unsigned long long s_cnt[4][64];
+    __shared__ double s_sum[kFinishPhases][64];
+    __shared__ unsigned long long s_cnt[kFinishPhases][64];
     const StageBlock B = blocks[blockIdx.x];
     const int dx = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int d = blockIdx.y * 64 + dx;
     double s = 0.0;
     unsigned long long c = 0;
     if (d < B.n_diags) {
-        for (int g = B.group0 + ph; g < B.group0 + B.n_groups; g += 4) {
+        for (int g = B.group0 + ph; g < B.group0 + B.n_groups; g += kFinishPhases) {
             s += part_sum[(size_t)g * pitch + d];
             c += part_cnt[(size_t)g * pitch + d];
         }
@@ -125,8 +126,12 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(const StageBlock* __r
     s_cnt[ph][dx] = c;
     __syncthreads();
     if (ph == 0 && d < B.n_diags) {
-        s = ((s_sum[0][dx] + s_sum[1][dx]) + s_sum[2][dx]) + s_sum[3][dx];
-        c = s_cnt[0][dx] + s_cnt[1][dx] + s_cnt[2][dx] + s_cnt[3][dx];
+        s = 0.0;
+        c = 0;
+        for (int k = 0; k < kFinishPhases; ++k) {
+            s += s_sum[k][dx];
+            c += s_cnt[k][dx];
+        }
         B.law[d] = c > 0 ? s / (double)c : 0.0;             // cs_distance_law_finish
     }
 }
@@ -310,7 +315,7 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     if (!(skip && skip[0] == 'l')) {
         CS_STAGE_BOTH(CS_STAGE_LAW)
     }
-    hipLaunchKernelGGL(stage_finish_kernel, dim3(n_blocks, (max_b + 63) / 64), dim3(256), 0, stream, d_blocks, pitch, part_sum,
+    hipLaunchKernelGGL(stage_finish_kernel, dim3(n_blocks, (max_b + 63) / 64), dim3(64 * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
                        part_cnt);
     if (!(skip && skip[0] == 't')) {
         CS_STAGE_BOTH(CS_STAGE_TILE)

@@ -101,6 +101,8 @@ class CsFociParams(C.Structure):
         ("hi_diag", C.c_int32),
         ("inter", C.c_int32),
         ("want_windows", C.c_int32),
+        ("exclusive", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -192,6 +194,8 @@ _PROTOTYPES = {
     "cs_normxcorr2_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.c_void_p, C.c_int32, C.c_int64]),
     "cs_remove_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "cs_accept_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
 }

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -18,6 +19,8 @@
 #include "cs_device.h"
 #include "cs_launch.h"
 #include "cs_launch_aux.h"
+
+constexpr int kBlkLanes = 6;        // streams a multi-block tile pass may use (the caller's + side streams)
 
 struct cs_ctx {
     int device = 0;
@@ -41,10 +44,17 @@ struct cs_ctx {
     int stage_slot = 0;
     // cs_detect_foci_blocks: the tile kernels of consecutive blocks alternate over the caller's stream and two side
     // streams (each with its own mask-table scratch), so that one block's tail overlaps the next block's ramp
-    hipStream_t s_blk[2] = {nullptr, nullptr};
-    hipEvent_t ev_blk[3] = {nullptr, nullptr, nullptr};
-    void* ws_alt[2] = {nullptr, nullptr};
-    size_t ws_alt_bytes[2] = {0, 0};
+    hipStream_t s_blk[kBlkLanes - 1] = {};
+    hipEvent_t ev_blk[kBlkLanes] = {};
+    void* ws_alt[kBlkLanes - 1] = {};
+    size_t ws_alt_bytes[kBlkLanes - 1] = {};
+    int grid_cap = 0;                  // CorrArgs::grid_cap of the launches built next (cs_detect_foci_blocks)
+    // one launch for the tiles of all blocks (cs::launch_corr_mfma_blocks): mask tables per block, argument table
+    std::vector<void*> ws_tab;
+    std::vector<size_t> ws_tab_bytes;
+    void* h_tab = nullptr;
+    void* d_tab = nullptr;
+    size_t tab_bytes = 0;
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
@@ -494,6 +504,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
+    A.grid_cap = ctx->grid_cap;
     A.reg_mode = 0;
     // per-bin masks on the matrix cores: the factorised mask tables + the persistent tile kernel
     // (candidate mode without a sink -- the map fallback of find_candidates -- runs on the kernels that decide the screen
@@ -610,6 +621,7 @@ int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream
 {
     int K = 0, tw, th, rc;
     A.n_cu = ctx->n_cu;
+    A.grid_cap = ctx->grid_cap;
     ctx->last_kernel = CS_KERNEL_GENERIC;
     if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
         ctx->last_kernel = CS_KERNEL_STREAM;
@@ -883,12 +895,16 @@ void cs_ctx_destroy(cs_ctx* ctx)
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->ev_stage[k]) (void)hipEventDestroy(ctx->ev_stage[k]);
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kBlkLanes - 1; ++k) {
         if (ctx->ws_alt[k]) (void)hipFree(ctx->ws_alt[k]);
         if (ctx->s_blk[k]) (void)hipStreamDestroy(ctx->s_blk[k]);
     }
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < kBlkLanes; ++k)
         if (ctx->ev_blk[k]) (void)hipEventDestroy(ctx->ev_blk[k]);
+    for (void* w : ctx->ws_tab)
+        if (w) (void)hipFree(w);
+    if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
@@ -1412,6 +1428,102 @@ int cs_remove_neighbours(const int64_t* h_bin1, const int64_t* h_bin2, const int
     return CS_OK;
 }
 
+// 2 * Phi(-a), a >= 0 or NaN: the two-sided tail of stats.py:43-81 with the case split of the normal distribution
+// function the reference calls (scipy.special.ndtr)
+static double two_sided_tail(double a)
+{
+    const double x = -a * M_SQRT1_2, z = std::fabs(x);
+    double y;
+    if (z < M_SQRT1_2) y = 0.5 + 0.5 * std::erf(x);
+    else {
+        y = 0.5 * std::erfc(z);
+        if (x > 0) y = 1.0 - y;
+    }
+    return 2.0 * y;
+}
+
+int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_counts, const int32_t* h_rows,
+                      const int32_t* h_cols, const int32_t* h_max_dist, int32_t inter, int32_t km, int32_t kn,
+                      double missing_tol, double zero_tol, int32_t full, int32_t compact, double* h_table, uint8_t* h_ok,
+                      int64_t* h_kept)
+{
+    if (n_blocks < 0 || km < 1 || kn < 1 || (n_blocks > 0 && (!h_counts || !h_rows || !h_cols || !h_kept))) return CS_ERR_INVALID;
+    const double tot = (double)km * (double)kn;
+    int64_t n = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        if (h_counts[b] < 0) return CS_ERR_INVALID;
+        n += h_counts[b];
+    }
+    if (n > 0 && (!h_rec || !h_table || !h_ok)) return CS_ERR_INVALID;
+    // pass 1, record by record (a few transcendental functions each: threads beyond a couple of thousand records):
+    // the row of every record at its own slot
+    auto rows_of = [&](int64_t b0, int64_t b1, int64_t at) {
+        for (int64_t b = b0; b < b1; ++b) {
+            const int64_t ms = h_rows[b], ns = h_cols[b];
+            const bool limited = !inter && h_max_dist && h_max_dist[b] >= 0;
+            for (int64_t t = at; t < at + h_counts[b]; ++t) {
+                const cs_focus& f = h_rec[t];
+                const int64_t r = f.bin1, c = f.bin2;
+                // coefficient on the trimmed map (detection.py:269-270) ...
+                bool in_band = r >= 0 && r < ms && c >= 0 && c < ns;
+                if (!inter) in_band = in_band && c - r >= 0 && (!limited || c - r <= (int64_t)h_max_dist[b]);
+                // acceptance rules of validate_patterns (:121-141) on the window statistics
+                const double undetected = (double)f.n_missing / tot;
+                const double zero = (double)f.n_zero / (tot - (double)f.n_missing);   // 0 / 0 -> NaN -> rejected
+                const bool ok = f.inside != 0 && undetected < missing_tol && zero < zero_tol;
+                h_ok[t] = ok ? 1 : 0;
+                if (!ok && compact) continue;
+                // ... p-value on the untrimmed one (:332-336), Fisher z (stats.py:43-81)
+                double n_obs = full ? f.n_obs : tot;
+                if (n_obs == 0) n_obs = tot;
+                double pval = 1.0;                                // 10 ** 0 where the coefficient is exactly 0
+                if (f.score != 0) {
+                    const double zz = std::atanh(f.score) * std::sqrt(n_obs - 3.0);
+                    pval = std::pow(10.0, std::log10(two_sided_tail(std::fabs(zz))));
+                }
+                double* row = h_table + 4 * t;
+                row[0] = (double)r;
+                row[1] = (double)c;
+                row[2] = ok ? (in_band ? f.score : 0.0) : std::numeric_limits<double>::quiet_NaN();
+                row[3] = pval;
+            }
+            at += h_counts[b];
+        }
+    };
+    const int n_threads = (int)std::min<int64_t>(8, std::min<int64_t>(n / 1024, n_blocks));
+    if (n_threads > 1) {
+        std::vector<std::thread> pool;
+        int64_t b0 = 0, at = 0;
+        for (int t = 0; t < n_threads; ++t) {
+            // consecutive blocks holding about n / n_threads records
+            int64_t b1 = b0, sum = 0;
+            while (b1 < n_blocks && (t + 1 == n_threads || sum < (n + n_threads - 1) / n_threads)) sum += h_counts[b1++];
+            pool.emplace_back(rows_of, b0, b1, at);
+            b0 = b1;
+            at += sum;
+        }
+        for (auto& th : pool) th.join();
+    } else {
+        rows_of(0, n_blocks, 0);
+    }
+    // pass 2: counts, and in compact mode the accepted rows packed to the front (in place: a row never moves backwards)
+    int64_t at = 0, out = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        int64_t kept = 0;
+        for (int64_t t = at; t < at + h_counts[b]; ++t) {
+            if (!h_ok[t]) continue;
+            ++kept;
+            if (compact) {
+                if (out != t) std::memcpy(h_table + 4 * out, h_table + 4 * t, 4 * sizeof(double));
+                ++out;
+            }
+        }
+        h_kept[b] = kept;
+        at += h_counts[b];
+    }
+    return CS_OK;
+}
+
 // grow-only device scratch; growing waits for the device, since queued work may still use the old block
 static int ensure_scratch(cs_ctx* ctx, void** buf, size_t* have, size_t need)
 {
@@ -1543,6 +1655,8 @@ struct CandSink {
     long long cap;
     unsigned long long tag;
     int lo_diag, hi_diag;            // scanned diagonals
+    void* defer_args = nullptr;      // see CorrArgs::defer_args: prepare the tile kernel's launch, do not launch
+    int* defer_rsym = nullptr;
 };
 
 // float32 correlation in candidate mode (cs_device.h cand_screen_*: margin + conditioning screen, sentinel 2.0).  With a
@@ -1567,6 +1681,8 @@ int corr_candidates_f32(cs_ctx* ctx, hipStream_t stream, const cs_matrix* signal
         A.cand_tag = sink->tag;
         A.cand_dlo = sink->lo_diag;
         A.cand_dhi = sink->hi_diag;
+        A.defer_args = sink->defer_args;
+        A.defer_rsym = sink->defer_rsym;
     } else if (!out || !out->d_ptr) {
         return fail(ctx, CS_ERR_INVALID, "candidate mode needs a sink or a map");
     }
@@ -1931,12 +2047,59 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // side streams only when no block needs the (single) narrowing scratch
         bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");
         for (int b = 0; b < n_blocks && twins; ++b) twins = signals_f32[b].d_ptr != nullptr;
-        const int n_lanes = (twins && n_blocks > 1) ? 3 : 1;
-        if (n_lanes > 1) {
-            if (!ctx->s_blk[0]) {
-                for (int k = 0; k < 2; ++k) CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_blk[k], hipStreamNonBlocking));
-                for (int k = 0; k < 3; ++k) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_blk[k], hipEventDisableTiming));
+        // Lanes: the blocks' persistent launches run side by side on n_lanes streams, each with 1 / n_lanes of the chip's
+        // workgroup slots -- a launch then walks n_lanes times as many tiles per workgroup (pipeline fill / drain and the
+        // rounding to whole tiles per workgroup are paid per launch), and no launch waits for slots another one holds.
+        static const int lanes_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_LANES") ? atoi(std::getenv("CHROMOSIGHT_HIP_BLOCK_LANES")) : 3;
+        static const int share_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_SHARE") ? atoi(std::getenv("CHROMOSIGHT_HIP_BLOCK_SHARE")) : 0;
+        const int n_lanes = (twins && n_blocks > 1) ? std::min(std::min(std::max(lanes_env, 1), kBlkLanes), n_blocks) : 1;
+        // one persistent launch for the tiles of all blocks (the lanes then only carry the blocks' mask tables)
+        static const char* table_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_TABLE");      // "0" / "1": force
+        const bool table = n_lanes > 1 && (table_env ? table_env[0] == '1' : foci[0].exclusive != 0);
+        int table_rsym = -1;
+        if (table) {
+            const size_t need = cs::mfma_blocks_table_bytes(n_blocks);
+            if (need > ctx->tab_bytes) {
+                CS_HIP(ctx, hipDeviceSynchronize());
+                if (ctx->h_tab) CS_HIP(ctx, hipHostFree(ctx->h_tab));
+                if (ctx->d_tab) CS_HIP(ctx, hipFree(ctx->d_tab));
+                ctx->h_tab = ctx->d_tab = nullptr;
+                ctx->tab_bytes = 0;
+                CS_HIP(ctx, hipHostMalloc(&ctx->h_tab, 2 * need, hipHostMallocDefault));
+                CS_HIP(ctx, hipMalloc(&ctx->d_tab, 2 * need));
+                ctx->tab_bytes = 2 * need;
             }
+            if (ctx->ws_tab.size() < (size_t)n_blocks) {
+                ctx->ws_tab.resize((size_t)n_blocks, nullptr);
+                ctx->ws_tab_bytes.resize((size_t)n_blocks, 0);
+            }
+        }
+        struct GridCap {                      // the cap applies to the launches of this call only
+            cs_ctx* c;
+            GridCap(cs_ctx* c_, int cap) : c(c_) { c->grid_cap = cap; }
+            ~GridCap() { c->grid_cap = 0; }
+        } grid_cap(ctx, (n_lanes > 1 && share_env) ? 2 * ctx->n_cu / n_lanes : 0);
+        // blocks to lanes: largest first onto the least loaded lane
+        std::vector<int> lane_of((size_t)n_blocks, 0);
+        if (n_lanes > 1) {
+            std::vector<int> order((size_t)n_blocks);
+            for (int b = 0; b < n_blocks; ++b) order[b] = b;
+            auto cost = [&](int b) { return (long long)params[b].ms * (foci[b].hi_diag - foci[b].lo_diag + 1); };
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
+            long long load[kBlkLanes] = {};
+            for (int b : order) {
+                int best = 0;
+                for (int k = 1; k < n_lanes; ++k)
+                    if (load[k] < load[best]) best = k;
+                lane_of[b] = best;
+                load[best] += cost(b);
+            }
+        }
+        if (n_lanes > 1) {
+            for (int k = 0; k < n_lanes - 1; ++k)
+                if (!ctx->s_blk[k]) CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_blk[k], hipStreamNonBlocking));
+            for (int k = 0; k < kBlkLanes; ++k)
+                if (!ctx->ev_blk[k]) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_blk[k], hipEventDisableTiming));
             // template weights / matrix-core fragments are uploaded on the caller's stream (once per template): before the
             // side streams are released
             {
@@ -1947,11 +2110,18 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 rc0 = ensure_wfrag(ctx, stream, A0.km, A0.kn, &E0);
                 if (rc0) return rc0;
             }
-            CS_HIP(ctx, hipEventRecord(ctx->ev_blk[2], stream));              // the counter is zero, earlier work is done
-            for (int k = 0; k < 2; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[2], 0));
+            CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
+            for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
         }
-        for (int b = 0; b < n_blocks; ++b) {
-            const int lane = b % n_lanes;
+        // (largest blocks first on every lane: the short ones fill the end)
+        std::vector<int> launch_order((size_t)n_blocks);
+        for (int b = 0; b < n_blocks; ++b) launch_order[b] = b;
+        if (n_lanes > 1)
+            std::stable_sort(launch_order.begin(), launch_order.end(), [&](int x, int y) {
+                return (long long)params[x].ms * (foci[x].hi_diag - foci[x].lo_diag + 1) > (long long)params[y].ms * (foci[y].hi_diag - foci[y].lo_diag + 1);
+            });
+        for (int b : launch_order) {
+            const int lane = lane_of[b];
             hipStream_t stream = lane == 0 ? (hipStream_t)stream_ : ctx->s_blk[lane - 1];
             struct WsSwap {                   // the side lanes build their mask tables in their own scratch
                 cs_ctx* c;
@@ -1964,7 +2134,19 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                     std::swap(c->d_ws, c->ws_alt[k]);
                     std::swap(c->d_ws_bytes, c->ws_alt_bytes[k]);
                 }
-            } ws_swap(ctx, lane - 1);
+            } ws_swap(ctx, table ? -1 : lane - 1);
+            struct TabSwap {                  // table mode: every block keeps its own mask tables until the one launch is done
+                cs_ctx* c;
+                int b;
+                TabSwap(cs_ctx* c_, int b_) : c(c_), b(b_) { swap(); }
+                ~TabSwap() { swap(); }
+                void swap()
+                {
+                    if (b < 0) return;
+                    std::swap(c->d_ws, c->ws_tab[(size_t)b]);
+                    std::swap(c->d_ws_bytes, c->ws_tab_bytes[(size_t)b]);
+                }
+            } tab_swap(ctx, table ? b : -1);
             const cs_matrix* sig = (signals_f32 && signals_f32[b].d_ptr) ? signals_f32 + b : signals + b;
             cs_matrix map;                        // geometry of the (virtual) coefficient map: the scanned diagonals
             map.d_ptr = nullptr;
@@ -1981,7 +2163,17 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
             CandSink sink{(unsigned long long*)pool, d_cnt, (long long)c_cap, (unsigned long long)b << kKeyShift, foci[b].lo_diag,
                           foci[b].hi_diag};
+            int rsym = 0;
+            if (table) {
+                sink.defer_args = (char*)ctx->h_tab + cs::mfma_blocks_arg_offset(n_blocks) + (size_t)b * cs::mfma_blocks_arg_bytes();
+                sink.defer_rsym = &rsym;
+            }
             rc = corr_candidates_f32(ctx, stream, sig, kernel, params + b, &map, margin, thr, &sink);
+            if (!rc && table) {
+                if (!ctx->cand_fused) rc = CS_NEED_MAP;             // another kernel than the masked tile kernel took the block
+                else if (table_rsym >= 0 && table_rsym != rsym) rc = fail(ctx, CS_ERR_UNSUPPORTED, "blocks need different tile kernels");
+                table_rsym = rsym;
+            }
             if (rc) {
                 if (n_lanes > 1) (void)hipDeviceSynchronize();      // nothing of this call may still be running on a side stream
                 if (rc == CS_NEED_MAP) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is not served by the masked tile kernel", b);
@@ -1989,10 +2181,14 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
         }
         if (n_lanes > 1) {
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < n_lanes - 1; ++k) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
                 CS_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_blk[k], 0));
             }
+        }
+        if (table) {
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream);
+            if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
         CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
         CS_HIP(ctx, hipStreamSynchronize(stream));

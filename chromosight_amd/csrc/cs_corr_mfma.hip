@@ -29,6 +29,7 @@
 #include "cs_device.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -516,7 +517,21 @@ __device__ __forceinline__ StatsPtr stats_args()
     return (StatsPtr)(kv + offsetof(MfmaDenseArgs, ks));
 }
 
-__device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, FixArgsPtr F, int i, int j)
+// the same two blocks of an entry of a device table (corr_mfma_blocks_kernel)
+__device__ __forceinline__ FixArgsPtr fix_args_at(unsigned long long entry)
+{
+    asm volatile("" : "+s"(entry));
+    return (FixArgsPtr)(entry + offsetof(MfmaDenseArgs, fx));
+}
+
+__device__ __forceinline__ StatsPtr stats_args_at(unsigned long long entry)
+{
+    asm volatile("" : "+s"(entry));
+    return (StatsPtr)(entry + offsetof(MfmaDenseArgs, ks));
+}
+
+template <typename AT>
+__device__ __forceinline__ const float* mask_fix_record(AT& A, FixArgsPtr F, int i, int j)
 {
     const int K = A.km, KH = (A.km - 1) / 2;
     const int d = j - i;
@@ -547,773 +562,58 @@ __device__ __forceinline__ const float* mask_fix_record(const MfmaDenseArgs& A, 
 template <bool VEC4, bool REG, bool RSYM = false, bool CAND = false>
 __global__ __launch_bounds__(256, 2) void corr_mfma_dense_kernel(const MfmaDenseArgs A)
 {
+    constexpr bool TABLE = false;
+    constexpr unsigned long long table_entry = 0;
+    constexpr int table_tile = 0, table_tile_end = 0, table_tile_step = 0;
+    (void)table_entry; (void)table_tile; (void)table_tile_end; (void)table_tile_step;
+#define MFD_NOMASK_KS A.ks
+#include "cs_corr_mfma_body.inc"
+#undef MFD_NOMASK_KS
+}
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const pl_xh = smem;
-    char* const pl_xl = smem + MF_PLANE;
-    char* const pl_qh = smem + 2 * MF_PLANE;
-    char* const pl_ql = smem + 3 * MF_PLANE;
-    float* const raw = reinterpret_cast<float*>(smem + 2 * MF_PLANE);      // next tile's pixels: aliases the squares
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    char* const scr = smem + MFD_SCR + wv * (2 * MF_SCR_PLANE);
-    unsigned* const red = reinterpret_cast<unsigned*>(smem + MFD_RED);
-    const int km = A.km, kn = A.kn;
-    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+// Several matrices (the banded blocks of a genome) in ONE persistent launch of the masked candidate instance: the tiles of
+// all blocks form one list (first[b] .. first[b + 1] are block b's), XCD x takes the x-th eighth of it and its workgroups
+// walk that range side by side; a workgroup drains its pipeline only where its range crosses into the next block (a few
+// times per launch instead of once per block and launch).  The argument blocks live in a device table.
+struct MfmaBlocksArgs {
+    const MfmaDenseArgs* args;
+    const int* first;
+    int n_blocks, n_tiles;
+};
 
-    h8 ones_b, ones_a;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int t = 8 * g + e - n;
-        ones_b[e] = (t >= 0 && t < kn) ? (_Float16)1.0f : (_Float16)0.0f;
-        ones_a[e] = (t >= 0 && t < km) ? (_Float16)1.0f : (_Float16)0.0f;
-    }
-    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int wr0 = 16 * wv;
-    const int c2 = tid % 40, rg = tid / 40;         // staging: column pair, row group (threads >= 240 idle)
-    const int c2_ = c2, rg_ = rg;
-    const bool stager = tid < 240;
-    // input rows that windows of [row_begin, row_end) reach and that exist
-    const int p_min = max(0, A.row_begin - kh), p_max = min(A.ms, A.row_end + (km - 1) - kh) - 1;
+typedef const __attribute__((address_space(4))) MfmaDenseArgs MfmaDenseArgsC;
 
-    auto tile_origin = [&](int tile, int& I0, int& J0) {
-        const int by = tile / A.tiles_x;
-        I0 = A.row_begin + by * MF_T;
-        J0 = (tile - by * A.tiles_x) * MF_T;
-        if (REG && A.band_out) J0 += I0 + A.out_lo;       // the strip of tiles follows the band
-    };
-    // LDS-DMA of one tile's 80 x 80 pixels (clamped addresses; the reader masks what lies outside).
-    // The image is row-major; a wave-wide transfer moves 64 consecutive 4-byte (VEC4: 16-byte) pieces of
-    // it, wave w issues the transfers w, w + 4, ...  A lane's piece advances by 256 pieces per step.
-    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
-    constexpr int kPiecesPerRow = VEC4 ? MF_R / 4 : MF_R;
-    constexpr int kTransfers = VEC4 ? 25 : 100;
-    auto fetch = [&](int tile, int slot) {
-        int I0, J0;
-        tile_origin(tile, I0, J0);
-        const int P0 = I0 - kh, Q0 = J0 - kw;
-        // The per-lane constants of the transfers are recomputed from an opaque copy of the lane index: hoisted out
-        // of the tile loop they are spilled, and a reload here waits (vmcnt) for the previous tile's stores.
-        int lane_f = lane;
-        if constexpr (REG) asm volatile("" : "+v"(lane_f));         // (the dense instances have registers to spare)
-        const int e0 = 64 * wv_u + lane_f;
-        int r = e0 / kPiecesPerRow, c = e0 - r * kPiecesPerRow;
-        if (REG && !(A.dbg & 16384)) {
-            // column terms of the tile's 64 columns (waves 0..2) and the flags of its 80 staged columns (wave 3)
-            if (wv_u < 3) {
-                const float* src = A.coltab + (size_t)wv_u * A.ns + min(max(J0 + lane_f, 0), A.ns - 1);
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(
-                    (__attribute__((address_space(3))) char*)(smem) + MFD_COL + (slot * 3 + wv_u) * 256), 4, 0, 0);
-            } else {
-                // the 80 flag bytes of columns Q0 .. Q0 + 79 as the <= 22 aligned dwords that hold them (lanes
-                // beyond are harmless repeats; addresses clamped to the dwords that overlap the array)
-                const long long base = (long long)(uintptr_t)A.miss_col;
-                const long long first = ((base + Q0) >> 2) << 2;
-                long long addr = first + 4 * min(lane_f, 23);
-                addr = min(max(addr, (base >> 2) << 2), ((base + A.ns - 1) >> 2) << 2);
-                if (lane_f < 24)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>((uintptr_t)addr),
-                                                     (__attribute__((address_space(3))) void*)(
-                                                         (__attribute__((address_space(3))) char*)(smem) + MFD_CFB + slot * 128), 4, 0, 0);
-            }
-        }
-        const __attribute__((address_space(3))) char* dst =
-            (const __attribute__((address_space(3))) char*)(raw) + (VEC4 ? 1024 : 256) * wv_u;
-#pragma unroll 1
-        for (int i = wv_u; i < kTransfers; i += 4) {
-            const int p = min(max(P0 + r, p_min), p_max);
-            const float* row = A.sig + ((long long)p - A.row0_in) * A.ld_in;
-            if constexpr (VEC4) {
-                // REG: the piece's first stored index (band: diagonal index q - p - lo), clamped into the row's
-                // stored range -- the reader undoes the shift (16-byte transfers need no 16-byte alignment)
-                int q = Q0 + 4 * c;
-                if (REG && A.band_in) q = min(max(q - p - A.lo_in, 0), A.bw_in - 4);
-                else q = min(max(q, 0), A.ns - 4);
-                __builtin_amdgcn_global_load_lds(row + q, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                dst += 4096;
-                c += 256 % kPiecesPerRow;
-                r += 256 / kPiecesPerRow;
-            } else {
-                int q = min(max(Q0 + c, 0), A.ns - 1);
-                if (REG && A.band_in) q = min(max(q - p - A.lo_in, 0), A.bw_in - 1);      // stored diagonal index
-                __builtin_amdgcn_global_load_lds(row + q, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
-                dst += 1024;
-                c += 256 % kPiecesPerRow;
-                r += 256 / kPiecesPerRow;
-            }
-            if (c >= kPiecesPerRow) {
-                c -= kPiecesPerRow;
-                r += 1;
-            }
-        }
-    };
+template <bool VEC4, bool REG, bool RSYM, bool CAND, bool TABLE_ = true>
+__device__ __forceinline__ void mfma_dense_tiles_table(MfmaDenseArgsC& A, const unsigned long long table_entry, const int table_tile,
+                                                       const int table_tile_end, const int table_tile_step)
+{
+    constexpr bool TABLE = TABLE_;
+    const KernelStats<float> no_ks{};       // (the unmasked epilogue is never part of a table instance: REG)
+#define MFD_NOMASK_KS no_ks
+#include "cs_corr_mfma_body.inc"
+#undef MFD_NOMASK_KS
+}
 
-    // epilogue of one tile (lane = row n of the wave's 16, columns 16 c + 4 g + v), run one iteration late:
-    // its stores then have the whole next tile to retire before the `vmcnt(0)` that awaits the DMA
-    auto emit = [&](int I0, int J0, float unscale, const f4 (&acc)[4], const f4 (&S1)[4], const f4 (&S2)[4],
-                    const f4& hdr, int slot) {
-        const float u_cs = unscale * A.w_unscale;
-        const float u_s2 = 32.0f * unscale;
-        if constexpr (REG) {
-            // ---- per-bin masks: the factorised mask sums of cs_mask_prep.hip (see cs_corr_stream.h MODE 2)
-            //   n_missing = K nr[i] + (K - nr[i]) ncol[j],  sum_missing Wa = RA[i] + CA[j] - sum_kj c[j+kj] U_i[kj]
-            // plus the precomputed corrections of the pixels whose window leaves the matrix / 0..max_dist
-            const int K = km;
-            const int i = I0 + wr0 + n;
-            KernelStats<float> KS;                                // loaded here, not held across the tile loop
-            {
-                const StatsPtr sp = stats_args();
-                KS.n = sp->n; KS.inv_n = sp->inv_n; KS.kmean = sp->kmean; KS.kstd = sp->kstd; KS.kvar = sp->kvar;
-                KS.ksum = sp->ksum; KS.k2sum = sp->k2sum; KS.thr = sp->thr; KS.eps = sp->eps; KS.cut = sp->cut;
-                KS.thr_n = sp->thr_n; KS.nkvar = sp->nkvar; KS.eps2 = sp->eps2; KS.den2_min = sp->den2_min;
-                KS.zk_possible = sp->zk_possible; KS.snap_possible = sp->snap_possible;
-                KS.cand_cmin = CAND ? sp->cand_cmin : 0.0f;
-                KS.cand_thr = CAND ? sp->cand_thr : 0.0f;
-            }
-            const float* colb = reinterpret_cast<const float*>(smem + MFD_COL) + slot * 3 * 64;
-            const float nr = hdr[0], ra = hdr[1], rb = hdr[2];
-            // The cross term sum_kj c[j + kj] U_i[kj], U_i[kj] = sum over the flagged rows ki of row i's window of
-            // W[ki][kj], exists only where a flagged row AND a flagged column reach the window.  On the matrix
-            // cores: A = Hankel matrix of the column flags (exact in float16), B = U (head + tail), per column tile.
-            const unsigned* cfm = reinterpret_cast<const unsigned*>(smem + MFD_CFL) + slot * 4;
-            const unsigned m0 = __builtin_amdgcn_readfirstlane(cfm[0]), m1 = __builtin_amdgcn_readfirstlane(cfm[1]),
-                           m2 = __builtin_amdgcn_readfirstlane(cfm[2]);
-            const bool tile_flags = (m0 | m1 | m2) != 0;
-            const unsigned row_bits = (tile_flags && !(A.dbg & 128)) ? (unsigned)hdr[3] : 0u;
-            const bool cross_on = __builtin_amdgcn_ballot_w64(row_bits != 0) != 0;
-            h8 ua_h, ua_t, ub_h, ub_t;
-            if (cross_on) {
-                float ua[8], ub[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ua[e] = ub[e] = 0.0f;
-                unsigned bits = row_bits;
-                while (__builtin_amdgcn_ballot_w64(bits != 0)) {
-                    if (bits) {
-                        const int ki = __builtin_ctz(bits);
-                        bits &= bits - 1;
-                        const float* wa = A.w + K * K + ki * K;
-                        const float* wb = A.w + 2 * K * K + ki * K;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int kj = 8 * g + e;
-                            const float in = kj < K ? 1.0f : 0.0f;
-                            ua[e] = fmaf(wa[min(kj, K - 1)], in, ua[e]);
-                            ub[e] = fmaf(wb[min(kj, K - 1)], in, ub[e]);
-                        }
-                    }
-                }
-                const float sa = __builtin_amdgcn_rcpf(A.wa_unscale), sb = __builtin_amdgcn_rcpf(A.wb_unscale);   // powers of two
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float a = ua[e] * sa, b = ub[e] * sb;
-                    ua_h[e] = (_Float16)a;
-                    ua_t[e] = (_Float16)(a - (float)ua_h[e]);
-                    ub_h[e] = (_Float16)b;
-                    ub_t[e] = (_Float16)(b - (float)ub_h[e]);
-                }
-            }
-            const unsigned kmask8 = (((1u << K) - 1u) >> (8 * g)) & 0xffu;      // template columns 8 g .. 8 g + 7 that exist
-            const int dmin = J0 - (I0 + MF_T - 1), dmax = J0 + MF_T - 1 - I0;
-            const bool needs_fix = !(A.dbg & 256) && ((I0 < A.fix_top) | (I0 + MF_T - 1 >= A.fix_bot0) | (A.fix_any_side != 0) |
-                                   (A.fix_on && ((dmin < K - 1 && dmax >= 0) |
-                                                 (dmax >= A.fix_hi_d0 && dmin < A.fix_hi_d0 + A.fix_hi_w))));
-            // every pixel of the tile is produced: rows below row_end, columns inside the matrix, diagonals inside the band
-            const bool plain_out = I0 + MF_T <= A.row_end && J0 >= 0 && J0 + MF_T <= A.ns && dmin >= A.out_lo && dmax <= A.out_hi;
-            float* tb = reinterpret_cast<float*>(scr);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f4 rv[2], nmv[2], kav[2], kbv[2];
-                unsigned rare_bits = 0u;
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const int c = 2 * half + cc;
-                    __builtin_amdgcn_sched_barrier(0);       // one column tile at a time: keeps the live set small
-                    // cross term of this column tile
-                    f4 xa = zero4, xb = zero4;
-#ifndef CS_X_NOCROSS
-                    if (cross_on) {
-                        // lane (m = n, k group g) of the Hankel operand: flags of staged columns 16 c + n + 8 g + e
-                        const int sh = 16 * c + n + 8 * g;                       // 0 .. 87
-                        const unsigned lo = sh < 32 ? m0 : sh < 64 ? m1 : m2;
-                        const unsigned hi = sh < 32 ? m1 : sh < 64 ? m2 : 0u;
-                        const unsigned w8 = (unsigned)((((unsigned long long)hi << 32) | lo) >> (sh & 31)) & kmask8;
-                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                        u4 fw;
-#pragma unroll
-                        for (int pr = 0; pr < 4; ++pr)
-                            fw[pr] = ((w8 >> (2 * pr)) & 1u) * 0x3C00u + ((w8 >> (2 * pr + 1)) & 1u) * 0x3C000000u;   // 1.0 in float16
-                        const h8 ff = __builtin_bit_cast(h8, fw);
-                        xa = mfma16(ff, ua_h, xa);
-                        xa = mfma16(ff, ua_t, xa);
-                        xb = mfma16(ff, ub_h, xb);
-                        xb = mfma16(ff, ub_t, xb);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            xa[v] *= A.wa_unscale;
-                            xb[v] *= A.wb_unscale;
-                        }
-                    }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    const f4 ncol = *reinterpret_cast<const f4*>(colb + 16 * c + 4 * g);
-                    const f4 ca = *reinterpret_cast<const f4*>(colb + 64 + 16 * c + 4 * g);
-                    const f4 cb = *reinterpret_cast<const f4*>(colb + 128 + 16 * c + 4 * g);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        nmv[cc][v] = (float)K * nr + ((float)K - nr) * ncol[v];
-                        kav[cc][v] = ra + ca[v] - xa[v];
-                        kbv[cc][v] = rb + cb[v] - xb[v];
-                    }
-                }
-#ifndef CS_X_NOFIX
-                if (needs_fix) {
-                    // pixels whose window leaves the matrix or the diagonals 0 .. max_dist (tiles on the rim of the band)
-                    const FixArgsPtr F = fix_args();
-                    const int iw0 = I0 + wr0;                 // the wave's 16 rows
-                    const bool rows_hit = (iw0 < A.fix_top) | (iw0 + 15 >= A.fix_bot0) | (A.fix_any_side != 0);
-                    // rolled over the half's 8 pixels two at a time: two record loads in flight (one at a time, each awaited
-                    // before the next lookup, made a rim tile 45 % slower than an inner one; four at a time spill)
-#pragma unroll 1
-                    for (int k = 0; k < 4; ++k) {
-                        // the wave's pixels of this step: columns j0 + 4 g + {0, 1}, diagonals [j0 - iw0 - 15, j0 + 13 - iw0]
-                        const int cc = k >> 1, v0 = 2 * (k & 1);
-                        const int j0 = J0 + 16 * (2 * half + cc) + v0;
-                        const int dlo = j0 - iw0 - 15, dhi = j0 + 13 - iw0;
-                        const bool diag_hit = A.fix_on && ((dlo < K - 1 && dhi >= 0) | (dhi >= A.fix_hi_d0 && dlo < A.fix_hi_d0 + A.fix_hi_w));
-                        if (!(rows_hit | diag_hit)) continue;
-                        const float* fa = mask_fix_record(A, F, i, j0 + 4 * g);
-                        const float* fb = mask_fix_record(A, F, i, j0 + 4 * g + 1);
-                        if (!__builtin_amdgcn_ballot_w64((fa != nullptr) | (fb != nullptr))) continue;
-                        f4 ra = zero4, rb = zero4;
-                        if (fa) ra = *reinterpret_cast<const f4*>(fa);        // 16-byte records, 16-byte aligned tables
-                        if (fb) rb = *reinterpret_cast<const f4*>(fb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (e == k) {
-                                nmv[e >> 1][2 * (e & 1)] += ra[0];
-                                kav[e >> 1][2 * (e & 1)] += ra[1];
-                                kbv[e >> 1][2 * (e & 1)] += ra[2];
-                                nmv[e >> 1][2 * (e & 1) + 1] += rb[0];
-                                kav[e >> 1][2 * (e & 1) + 1] += rb[1];
-                                kbv[e >> 1][2 * (e & 1) + 1] += rb[2];
-                            }
-                        }
-                    }
-                }
-#endif
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const int c = 2 * half + cc;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int j = J0 + 16 * c + 4 * g + v;
-                        const int d = j - i;
-                        const float nm = nmv[cc][v], ka = kav[cc][v], kb = kbv[cc][v];
-                        const float cs = acc[c][v] * u_cs;
-                        const float s1 = S1[c][v] * unscale;
-                        const float s2 = (S2[c][v] * u_s2) * unscale;
-                        bool rare;
-                        float val = pearson_masked_core<CAND ? 1 : 0>(cs, s1, s2, nm, ka, kb, KS, rare);
-                        if constexpr (CAND) val = cand_range_guard(val, s2, unscale, KS);
-                        if (A.dbg & 4096) {
-                            val = cs + s1 + s2 + nm + ka + kb;
-                            rare = false;
-                        }
-                        const bool forced = A.sym_upper && d + (kn - km) < 0;          // full mode: triu in framed coordinates
-                        if (forced) val = 0.0f;
-                        if (rare && !forced) rare_bits |= 1u << (4 * cc + v);
-                        rv[cc][v] = val;
-                    }
-                }
-                // windows whose sums fall under the 1e-4 thresholds (rare): ONE inlined copy of the exact function
-                // per half instead of one per pixel (16 copies: 100 KB of code; a call pins the epilogue to the stack)
-#pragma unroll 1
-                for (int k = 0; k < (CAND ? 0 : 8); ++k) {      // (candidate mode: such pixels carry the sentinel)
-                    if (!__builtin_amdgcn_ballot_w64((rare_bits >> k) != 0)) break;
-                    if ((rare_bits >> k) & 1u) {
-                        float cs = 0.0f, s1 = 0.0f, s2 = 0.0f, nm = 0.0f, ka = 0.0f, kb = 0.0f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int c = 2 * half + (e >> 2), v = e & 3;
-                            if (e == k) {
-                                cs = acc[c][v] * u_cs;
-                                s1 = S1[c][v] * unscale;
-                                s2 = (S2[c][v] * u_s2) * unscale;
-                                nm = nmv[e >> 2][v];
-                                ka = kav[e >> 2][v];
-                                kb = kbv[e >> 2][v];
-                            }
-                        }
-                        const float val = pearson_masked_f32(cs, s1, s2, nm, ka, kb, KS);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (e == k) rv[e >> 2][e & 3] = val;
-                    }
-                }
-                if constexpr (CAND) {
-                    // candidate mode: no map leaves the kernel, only the coordinates of the pixels that carry the
-                    // sentinel (1e-4 of them), appended to the caller's list -- one atomic per wave and column that
-                    // has any.  A.out = the list (keys tag + row * ns + col), A.nobs = its counter, A.ld_out = its
-                    // capacity, A.row0_out = the tag (cs_api.cpp find_candidates / cs_detect_foci_blocks).
-                    unsigned long long* keys = reinterpret_cast<unsigned long long*>(A.out);
-                    unsigned long long* counter = reinterpret_cast<unsigned long long*>(A.nobs);
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int j = J0 + 16 * (2 * half + cc) + 4 * g + v;
-                            const int d = j - i;
-                            const bool hit = (rv[cc][v] >= KS.cand_thr) & (i < A.row_end) & (j >= 0) & (j < A.ns) &
-                                             (d >= A.out_lo) & (d <= A.out_hi);
-                            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                            if (m) {                                          // wave-uniform, rare
-                                const int first = __builtin_ctzll(m);
-                                unsigned long long base = 0;
-                                if (lane == first) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
-                                const unsigned lo = __builtin_amdgcn_readlane((unsigned)base, first);
-                                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(base >> 32), first);
-                                const unsigned long long pos = (((unsigned long long)hi << 32) | lo) +
-                                                               (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                                if (hit && pos < (unsigned long long)A.ld_out)
-                                    keys[pos] = (unsigned long long)A.row0_out + (unsigned long long)i * (unsigned long long)A.ns + (unsigned long long)j;
-                            }
-                        }
-                    }
-                    continue;
-                }
-                // 16 rows x 32 columns through the wave's scratch, out as 2 rows x 32 consecutive floats per
-                // instruction (band rows are shifted against each other: no wider aligned store exists)
-                const int pass_n = (A.dbg & 8192) ? (int)(rv[0][0] == 123.456f) : (A.nobs ? 2 : 1);
-                for (int pass = 0; pass < pass_n; ++pass) {
-                    wave_lds_sync();
-                    f4 t0 = rv[0], t1 = rv[1];
-                    if (pass) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            t0[v] = KS.n - nmv[0][v];
-                            t1[v] = KS.n - nmv[1][v];
-                        }
-                    }
-                    *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = t0;
-                    *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = t1;
-                    wave_lds_sync();
-                    const int xx = lane & 31;
-                    int oi = I0 + wr0 + (lane >> 5);
-                    const int oj = J0 + 32 * half + xx;
-                    // two rows further down: 2 ld, and on a banded output two diagonals to the left
-                    long long idx = ((long long)oi - A.row0_out) * A.ld_out + (A.band_out ? oj - oi - A.lo_out : oj);
-                    const long long step = 2 * (long long)A.ld_out - (A.band_out ? 2 : 0);
-                    const bool col_ok = oj >= 0 && oj < A.ns;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const float val = tb[(2 * it + (lane >> 5)) * 36 + xx];
-                        bool ok = !(A.dbg & 1);
-                        if (!plain_out) {
-                            const int d = oj - oi;
-                            ok = ok && oi < A.row_end && col_ok && d >= A.out_lo && d <= A.out_hi;
-                        }
-                        if (ok) {
-                            if (pass == 1) A.nobs[idx] = val;
-                            else if (A.out_is_f64) reinterpret_cast<double*>(A.out)[idx] = (double)val;
-                            else reinterpret_cast<float*>(A.out)[idx] = val;
-                        }
-                        oi += 2;
-                        idx += step;
-                    }
-                }
-            }
-            return;
-        }
-        const bool plain = I0 + MF_T <= A.row_end && J0 + MF_T <= A.ns &&
-                           (A.full || (I0 >= kh && I0 + MF_T - 1 <= A.ms - km + kh && J0 >= kw && J0 + MF_T - 1 <= A.ns - kn + kw)) &&
-                           (!A.sym_upper || J0 - (I0 + MF_T - 1) + (A.full ? kn - km : 0) >= 0);
-        const int i = I0 + wr0 + n;
-        const long long o_idx = ((long long)i - A.row0_out) * A.ld_out + (J0 + 4 * g);
-        f4 rv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float cs = acc[c][v] * u_cs;
-                const float s1 = S1[c][v] * unscale;
-                const float s2 = (S2[c][v] * u_s2) * unscale;
-                rv[c][v] = A.xcorr_only ? (fabsf(cs) < A.ks.thr ? 0.0f : cs)            // detection.py:716-722
-                                        : (A.dbg & 32) ? cs + s1 + s2
-                                                       : cand_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
-            }
-        }
-        if (A.dbg & 1) {
-            if (rv[0][0] == 123.456f) reinterpret_cast<float*>(A.out)[o_idx] = rv[1][1] + rv[2][2] + rv[3][3];
-        } else if (plain && VEC4) {
-            // A lane holds 4 consecutive columns of ONE row per column tile: stored directly, every
-            // instruction would touch 16 rows with 64 bytes each (measured: 4x the cost of the same bytes
-            // at consecutive addresses).  Two column tiles at a time go through the wave's scratch
-            // (16 rows x 32 columns, pitch 36 floats) and leave as 8 rows x 128 contiguous bytes.
-            float* tb = reinterpret_cast<float*>(scr);
-            const long long r_idx = ((long long)(I0 + wr0 + (lane >> 3)) - A.row0_out) * A.ld_out + J0 + 4 * (lane & 7);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                wave_lds_sync();
-                *reinterpret_cast<f4*>(tb + n * 36 + 4 * g) = rv[2 * half];
-                *reinterpret_cast<f4*>(tb + n * 36 + 16 + 4 * g) = rv[2 * half + 1];
-                wave_lds_sync();
-                const f4 lo = *reinterpret_cast<const f4*>(tb + (lane >> 3) * 36 + 4 * (lane & 7));
-                const f4 hi = *reinterpret_cast<const f4*>(tb + ((lane >> 3) + 8) * 36 + 4 * (lane & 7));
-                if (A.out_is_f64) {
-                    typedef double d2 __attribute__((ext_vector_type(2)));
-                    double* od = reinterpret_cast<double*>(A.out) + r_idx + 32 * half;
-                    d2 a, b;
-                    a[0] = lo[0]; a[1] = lo[1]; b[0] = lo[2]; b[1] = lo[3];
-                    *reinterpret_cast<d2*>(od) = a;
-                    *reinterpret_cast<d2*>(od + 2) = b;
-                    a[0] = hi[0]; a[1] = hi[1]; b[0] = hi[2]; b[1] = hi[3];
-                    *reinterpret_cast<d2*>(od + 8 * A.ld_out) = a;
-                    *reinterpret_cast<d2*>(od + 8 * A.ld_out + 2) = b;
-                } else {
-                    float* of = reinterpret_cast<float*>(A.out) + r_idx + 32 * half;
-                    *reinterpret_cast<f4*>(of) = lo;
-                    *reinterpret_cast<f4*>(of + 8 * A.ld_out) = hi;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int j = J0 + 16 * c + 4 * g + v;
-                    bool z = false;
-                    if (!A.full) z = (i < kh) | (i > A.ms - km + kh) | (j < kw) | (j > A.ns - kn + kw);
-                    if (A.sym_upper) z = z | ((j - i) + (A.full ? (kn - km) : 0) < 0);
-                    if (i < A.row_end && j < A.ns) {
-                        const float val = z ? 0.0f : rv[c][v];
-                        if (A.out_is_f64) reinterpret_cast<double*>(A.out)[o_idx + 16 * c + v] = (double)val;
-                        else reinterpret_cast<float*>(A.out)[o_idx + 16 * c + v] = val;
-                    }
-                }
-            }
-        }
-    };
-
-    f4 p_acc[4], p_S1[4], p_S2[4], p_hdr = zero4;
-    int p_I0 = 0, p_J0 = 0, p_slot = 0, slot = 0;
-    float p_unscale = 0.0f;
-    bool pending = false;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) p_acc[c] = p_S1[c] = p_S2[c] = zero4;
-
-    // Tile sequence of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs (own L2 each): XCD x
-    // takes the tiles [x n / 8, (x + 1) n / 8) and its workgroups walk that range side by side, so the 16
-    // halo rows / columns neighbouring tiles share are re-read from the XCD's own L2.
-    int tile, tile_end, tile_step;
-    if (A.xcd_order && gridDim.x % 8 == 0) {
-        const int x = blockIdx.x & 7, per = (A.n_tiles + 7) / 8;
-        tile = x * per + (blockIdx.x >> 3);
-        tile_end = min(A.n_tiles, (x + 1) * per);
-        tile_step = gridDim.x >> 3;
-    } else {
-        tile = blockIdx.x;
-        tile_end = A.n_tiles;
-        tile_step = gridDim.x;
-    }
-    if (A.dbg & 2048) return;                  // diagnostics: launch + dispatch only
-    if (tile < tile_end) fetch(tile, 0);       // the first tile is on its way while the weights are loaded
-
-    // ---- weights: heads of all 17 template rows in registers (rows >= km are zero), tails in LDS
-    constexpr int kHeads = RSYM ? 9 : 17;
-    h8 wh[kHeads];
-    {
-        const h8* frag = reinterpret_cast<const h8*>(A.frag);
-        h8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
-#pragma unroll
-        for (int s = 0; s < kHeads; ++s) {
-            const int sc = min(s, km - 1);
-            const h8 a = frag[(2 * sc + 0) * 64 + lane];
-            wh[s] = s < km ? a : z;
-        }
-        h8 tails[5];                                   // 17 x 64 fragments = 4.25 per thread: loads first
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int idx = min(tid + 256 * k, 17 * 64 - 1);
-            tails[k] = frag[(2 * min(idx >> 6, km - 1) + 1) * 64 + (idx & 63)];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int idx = tid + 256 * k;
-            if (idx < 17 * 64) reinterpret_cast<h8*>(smem + MFD_WL)[idx] = (idx >> 6) < km ? tails[k] : z;
-        }
-    }
-    // REG: one emit site (its epilogue is 4 K instructions) -- the loop runs one pass beyond the last tile, in which
-    // only the pending tile is emitted.  The dense instances emit the last tile after the loop.
-    for (;; tile += tile_step) {
-        const bool have = REG ? tile < tile_end : true;              // uniform over the workgroup
-        if constexpr (REG) {
-            if (!have && !pending) break;
-        } else {
-            if (tile >= tile_end) break;
-        }
-        int I0 = 0, J0 = 0;
-        if (have) tile_origin(tile, I0, J0);
-        const int P0 = I0 - kh, Q0 = J0 - kw;
-        // every staged pixel exists (rows, columns and, for a banded input, stored diagonals): the transfers were not
-        // clamped and the reader needs no masks
-        bool inside = P0 >= p_min && P0 + MF_R - 1 <= p_max && Q0 >= 0 && Q0 + MF_R <= A.ns;
-        if (REG && A.band_in) inside = inside && Q0 - (P0 + MF_R - 1) - A.lo_in >= 0 && Q0 + MF_R - 1 - P0 - A.lo_in <= A.bw_in - 1;
-        if (REG && (A.dbg & 512)) inside = true;
-        if (A.dbg & 1024) {                    // diagnostics: prologue only
-            if (!have) break;
-            continue;
-        }
-        float unscale = 0.0f;
-#ifdef CS_MF_PROFILE
-        unsigned long long tprev_ = __builtin_readcyclecounter();
-        if (tid == 0 && have) atomicAdd(&cs_mf_prof[15], 1ull);
-#endif
-        if (have) {
-
-            // ---- the tile's pixels have landed in `raw`: read this thread's 14 x 2, find the scale
-            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's DMA transfers (and long-retired stores)
-            lds_barrier();                           // everyone's transfers; the previous tile's plane readers are done
-            float xa[MFD_ROWS_PER_THREAD], xb[MFD_ROWS_PER_THREAD];
-            float amax = 0.0f;
-            if (inside) {
-#pragma unroll
-                for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
-                    const int r = rg + 6 * k;
-                    float2 v = make_float2(0.0f, 0.0f);
-                    if (stager && r < MF_R) v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
-                    xa[k] = v.x;
-                    xb[k] = v.y;
-                    amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
-                }
-            } else {
-                int c2 = c2_, rg = rg_;               // (opaque copies: see fetch)
-                if constexpr (REG) asm volatile("" : "+v"(c2), "+v"(rg));
-#pragma unroll
-                for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
-                    const int r = rg + 6 * k;
-                    float a = 0.0f, b = 0.0f;
-                    if (REG && VEC4) {
-                        if (stager && r < MF_R) {
-                            // pieces of 4 whose start was clamped into the stored range of their row: element o of the
-                            // piece holds stored index idx_c + o
-                            const int p = P0 + r, q = Q0 + 2 * c2, cs = (2 * c2) & ~3;
-                            const int w = A.band_in ? A.bw_in : A.ns;
-                            const int off = A.band_in ? p + A.lo_in : 0;
-                            const int idx_s = Q0 + cs - off;
-                            const int idx_c = min(max(idx_s, 0), w - 4);
-                            const int oa = (2 * c2 - cs) + (idx_s - idx_c), ob = oa + 1;
-                            const int idx_a = q - off;
-                            const bool rok = (p >= p_min) & (p <= p_max);
-                            const bool oka = rok & (q >= 0) & (q < A.ns) & (idx_a >= 0) & (idx_a < w) & (oa >= 0) & (oa < 4);
-                            const bool okb = rok & (q + 1 >= 0) & (q + 1 < A.ns) & (idx_a + 1 >= 0) & (idx_a + 1 < w) & (ob >= 0) & (ob < 4);
-                            const float* piece = raw + r * MF_R + cs;
-                            a = oka ? piece[min(max(oa, 0), 3)] : 0.0f;
-                            b = okb ? piece[min(max(ob, 0), 3)] : 0.0f;
-                        }
-                    } else if (stager && r < MF_R) {
-                        const float2 v = *reinterpret_cast<const float2*>(raw + r * MF_R + 2 * c2);
-                        const int p = P0 + r, q = Q0 + 2 * c2;
-                        const bool rok = (p >= p_min) & (p <= p_max);
-                        bool oka = rok & (q >= 0) & (q < A.ns), okb = rok & (q + 1 >= 0) & (q + 1 < A.ns);
-                        if (REG && A.band_in) {               // outside the stored diagonals: zero
-                            const int dd = q - p - A.lo_in;
-                            oka &= (dd >= 0) & (dd < A.bw_in);
-                            okb &= (dd + 1 >= 0) & (dd + 1 < A.bw_in);
-                        }
-                        a = oka ? v.x : 0.0f;
-                        b = okb ? v.y : 0.0f;
-                    }
-                    xa[k] = a;
-                    xb[k] = b;
-                    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
-                }
-            }
-            amax = wave_max_nonneg(amax);
-            if (lane == 63) red[wv] = __float_as_uint(amax);
-            if constexpr (REG) {
-                // the tile's column flags as bit masks (bit t = staged column Q0 + t), zero outside the matrix (the
-                // transfer clamped its addresses)
-                if (wv < 2) {
-                    const int q = Q0 + tid;
-                    const long long start = (long long)(uintptr_t)A.miss_col + Q0;
-                    const int skew = (int)(start - ((start >> 2) << 2));           // bytes before column Q0 in the first dword
-                    const uint8_t fb = reinterpret_cast<const uint8_t*>(smem + MFD_CFB)[slot * 128 + skew + min(tid, 79)];
-                    const bool flagged = tid < 80 && q >= 0 && q < A.ns && fb;
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(flagged);
-                    unsigned* cfm = reinterpret_cast<unsigned*>(smem + MFD_CFL) + slot * 4;
-                    if (lane == 0) {
-                        cfm[2 * wv] = (unsigned)m;
-                        if (wv == 0) cfm[1] = (unsigned)(m >> 32);
-                    }
-                }
-            }
-            MF_STAMP(0);
-            lds_barrier();                           // everyone has read `raw`: the squares may overwrite it
-            int ex = 0;
-            {
-                const uint4 m4 = *reinterpret_cast<const uint4*>(red);
-                const unsigned mx = max(max(m4.x, m4.y), max(m4.z, m4.w));     // non-negative floats order as integers
-                const int e = (int)((mx >> 23) & 0xffu);
-                if (e != 0 && e != 255) ex = 6 - (e - 127);
-                ex = max(-100, min(100, ex));
-            }
-            const float scale = __uint_as_float((unsigned)(ex + 127) << 23);
-            const float qscale = __uint_as_float((unsigned)(ex + 127 - 5) << 23);   // 2^-5: 17-sums of squares < 65504
-            unscale = __uint_as_float((unsigned)(127 - ex) << 23);
-            typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int k = 0; k < MFD_ROWS_PER_THREAD; ++k) {
-                const int r = rg + 6 * k;
-                if (stager && r < MF_R && !(A.dbg & 16)) {
-                    // heads by truncation, tails exact differences: head + tail carries 21-22 bits either way
-                    const float a = xa[k] * scale, b = xb[k] * scale;
-                    const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
-                    const hv2 tt = __builtin_amdgcn_cvt_pkrtz(a - (float)hh[0], b - (float)hh[1]);
-                    const float qa = (xa[k] * qscale) * a, qb = (xb[k] * qscale) * b;
-                    const hv2 qh = __builtin_amdgcn_cvt_pkrtz(qa, qb);
-                    const hv2 qt = __builtin_amdgcn_cvt_pkrtz(qa - (float)qh[0], qb - (float)qh[1]);
-                    const int o = (r * MF_R + 2 * c2) * 2;
-                    *reinterpret_cast<hv2*>(pl_xh + o) = hh;
-                    *reinterpret_cast<hv2*>(pl_xl + o) = tt;
-                    *reinterpret_cast<hv2*>(pl_qh + o) = qh;
-                    *reinterpret_cast<hv2*>(pl_ql + o) = qt;
-                }
-            }
-            MF_STAMP(1);
-        } else if (REG) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            lds_barrier();
-        }
-        // ---- the previous tile's coefficients and stores
-        if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
-        if (!have) break;
-        MF_STAMP(6);
-        lds_barrier();
-
-        // ---- box sums: horizontal pass over the wave's 32 input rows (all-ones Toeplitz as B), the
-        //      partial sums split again and transposed through the wave's scratch, vertical pass
-        //      (all-ones Toeplitz as B again: transposed tile).  8 steps (4 column tiles x {x, x^2}); the
-        //      fragments of step t + 1 are loaded before the scratch round trip of step t.
-        f4 S1[4], S2[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) S1[c] = S2[c] = zero4;
-        if (!(A.dbg & 4) && !A.xcorr_only) {
-            auto hfrag = [&](int t, h8 (&f)[4]) {
-                const int c = t >> 1;
-                const char* ph = (t & 1) ? pl_qh : pl_xh;
-                const char* pt = (t & 1) ? pl_ql : pl_xl;
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const int off = ((wr0 + 16 * rb + n) * MF_R + 16 * c + 8 * g) * 2;
-                    f[2 * rb] = *reinterpret_cast<const h8*>(ph + off);
-                    f[2 * rb + 1] = *reinterpret_cast<const h8*>(pt + off);
-                }
-            };
-            h8 cur[4];
-            hfrag(0, cur);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                h8 nxt[4];
-                if (t + 1 < 8) hfrag(t + 1, nxt);
-                h4 th[2], tl[2];
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    f4 h = mfma16(cur[2 * rb], ones_b, zero4);
-                    h = mfma16(cur[2 * rb + 1], ones_b, h);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        th[rb][v] = (_Float16)h[v];
-                        tl[rb][v] = (_Float16)(h[v] - (float)th[rb][v]);
-                    }
-                }
-                wave_lds_sync();                 // the previous step's scratch reads are issued
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const int so = (n * MF_SCR_PITCH + 16 * rb + 4 * g) * 2;
-                    *reinterpret_cast<h4*>(scr + so) = th[rb];
-                    *reinterpret_cast<h4*>(scr + MF_SCR_PLANE + so) = tl[rb];
-                }
-                wave_lds_sync();
-                const int ro = (n * MF_SCR_PITCH + 8 * g) * 2;
-                const h8 bh = *reinterpret_cast<const h8*>(scr + ro);
-                const h8 bl = *reinterpret_cast<const h8*>(scr + MF_SCR_PLANE + ro);
-                f4 sacc = mfma16(bh, ones_a, zero4);
-                sacc = mfma16(bl, ones_a, sacc);
-                if (t & 1) S2[t >> 1] = sacc;
-                else S1[t >> 1] = sacc;
-                if (t + 1 < 8) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
-                }
-            }
-        }
-        MF_STAMP(2);
-        lds_barrier();                           // all waves are done with the squares
-        // ---- next tile's pixels -> `raw` while this tile's correlation runs
-        if (tile + tile_step < tile_end && !(A.dbg & 2)) fetch(tile + tile_step, slot ^ 1);
-
-        MF_STAMP(3);
-        // ---- cross term: 17 template rows x 4 column tiles, fragments of row s + 1 in flight during row s
-        f4 acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = zero4;
-        h8 ah[4], al[4], bl;
-        const int fo = ((wr0 + n) * MF_R + 8 * g) * 2;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            ah[c] = *reinterpret_cast<const h8*>(pl_xh + fo + 32 * c);
-            al[c] = *reinterpret_cast<const h8*>(pl_xl + fo + 32 * c);
-        }
-        bl = reinterpret_cast<const h8*>(smem + MFD_WL)[lane];
-        if (!(A.dbg & 8))
-#pragma unroll
-        for (int s = 0; s < 17; ++s) {
-            h8 nh[4], nl[4], nb;
-            if (s + 1 < 17) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    nh[c] = *reinterpret_cast<const h8*>(pl_xh + fo + (s + 1) * MF_R * 2 + 32 * c);
-                    nl[c] = *reinterpret_cast<const h8*>(pl_xl + fo + (s + 1) * MF_R * 2 + 32 * c);
-                }
-                nb = reinterpret_cast<const h8*>(smem + MFD_WL)[(s + 1) * 64 + lane];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[RSYM && s > 8 ? 16 - s : s], ah[c], acc[c]);     // weights as A: transposed tile
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(bl, ah[c], acc[c]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(wh[RSYM && s > 8 ? 16 - s : s], al[c], acc[c]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < 17) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    ah[c] = nh[c];
-                    al[c] = nl[c];
-                }
-                bl = nb;
-            }
-        }
-        MF_STAMP(4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            p_acc[c] = acc[c];
-            p_S1[c] = S1[c];
-            p_S2[c] = S2[c];
-        }
-        p_I0 = I0;
-        p_J0 = J0;
-        p_unscale = unscale;
-        p_slot = slot;
-        if constexpr (REG) p_hdr = *reinterpret_cast<const f4*>(A.rowtab + 4 * (size_t)min(I0 + wr0 + n, A.ms - 1));
-        slot ^= 1;
-        pending = true;
-    }
-    if constexpr (!REG) {
-        if (pending) emit(p_I0, p_J0, p_unscale, p_acc, p_S1, p_S2, p_hdr, p_slot);
+template <bool RSYM>
+__global__ __launch_bounds__(256, 2) void corr_mfma_blocks_kernel(const MfmaBlocksArgs T)
+{
+    typedef const __attribute__((address_space(4))) int IntC;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, step = gridDim.x >> 3;
+    const int per = (T.n_tiles + 7) / 8;
+    const int lo_x = x * per, hi_x = min(T.n_tiles, (x + 1) * per);
+    IntC* first = (IntC*)(unsigned long long)T.first;
+    bool ran = false;
+    for (int b = 0; b < T.n_blocks; ++b) {
+        const int s0 = first[b], s1 = first[b + 1];
+        const int lo = max(lo_x, s0), hi = min(hi_x, s1);
+        if (lo >= hi) continue;
+        int g = lo_x + j;                              // this workgroup's sequence: lo_x + j + k step
+        if (g < lo) g += (lo - g + step - 1) / step * step;
+        if (g >= hi) continue;
+        if (ran) lds_barrier();                        // the previous block's last epilogue has read its LDS tables
+        ran = true;
+        const unsigned long long entry = (unsigned long long)(T.args + b);
+        mfma_dense_tiles_table<true, true, RSYM, true>(*(MfmaDenseArgsC*)entry, entry, g - s0, hi - s0, step);
     }
 }
 
@@ -1436,13 +736,20 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
                 D.ld_out = A.cand_cap;
                 D.row0_out = (long long)A.cand_tag;
             }
+            if (A.defer_args) {
+                if (!cand) return -5;
+                std::memcpy(A.defer_args, &D, sizeof(D));
+                if (A.defer_rsym) *A.defer_rsym = rsym ? 1 : 0;
+                return 0;
+            }
             typedef void (*reg_kernel_t)(const MfmaDenseArgs);
             const reg_kernel_t kr = rsym ? (cand ? corr_mfma_dense_kernel<true, true, true, true> : corr_mfma_dense_kernel<true, true, true, false>)
                                          : (cand ? corr_mfma_dense_kernel<true, true, false, true> : corr_mfma_dense_kernel<true, true, false, false>);
             hipError_t e3 = allow_big_lds((const void*)kr);
             if (e3 != hipSuccess) return (int)e3;
             const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
-            const int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
+            int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
+            if (A.grid_cap > 0 && grid_r > A.grid_cap) grid_r = std::max(8, A.grid_cap & ~7);     // (multiples of 8: XCD-contiguous ranges)
             hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
             return (int)hipGetLastError();
         }
@@ -1467,6 +774,40 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
     if (e != hipSuccess) return (int)e;
     if (masked) hipLaunchKernelGGL(corr_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), MF_SMEM, stream, A, E);
     else hipLaunchKernelGGL(corr_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), MF_SMEM, stream, A, E);
+    return (int)hipGetLastError();
+}
+
+size_t mfma_blocks_arg_bytes() { return sizeof(MfmaDenseArgs); }
+size_t mfma_blocks_arg_offset(int n_blocks) { return ((size_t)(n_blocks + 1) * sizeof(int) + 255) & ~(size_t)255; }
+size_t mfma_blocks_table_bytes(int n_blocks) { return mfma_blocks_arg_offset(n_blocks) + (size_t)n_blocks * sizeof(MfmaDenseArgs); }
+
+int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t stream)
+{
+    if (n_blocks <= 0) return 0;
+    int* first = reinterpret_cast<int*>(h_table);
+    const MfmaDenseArgs* args = reinterpret_cast<const MfmaDenseArgs*>((char*)h_table + mfma_blocks_arg_offset(n_blocks));
+    long long total = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        first[b] = (int)total;
+        total += args[b].n_tiles;
+        if (total > 0x7fffffffLL) return -3;
+    }
+    first[n_blocks] = (int)total;
+    if (total == 0) return 0;
+    hipError_t e = hipMemcpyAsync(d_table, h_table, mfma_blocks_table_bytes(n_blocks), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    MfmaBlocksArgs T;
+    T.first = reinterpret_cast<const int*>(d_table);
+    T.args = reinterpret_cast<const MfmaDenseArgs*>((char*)d_table + mfma_blocks_arg_offset(n_blocks));
+    T.n_blocks = n_blocks;
+    T.n_tiles = (int)total;
+    const void* kr = rsym ? (const void*)corr_mfma_blocks_kernel<true> : (const void*)corr_mfma_blocks_kernel<false>;
+    e = allow_big_lds(kr);
+    if (e != hipSuccess) return (int)e;
+    const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+    const int grid = std::max(8, (int)std::min<long long>((total + 7) / 8 * 8, (long long)per_cu * n_cu) & ~7);
+    if (rsym) hipLaunchKernelGGL(corr_mfma_blocks_kernel<true>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG, stream, T);
+    else hipLaunchKernelGGL(corr_mfma_blocks_kernel<false>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG, stream, T);
     return (int)hipGetLastError();
 }
 

@@ -83,6 +83,7 @@ struct CorrArgs {
                              // map: API calls pipelined over PCIe, one block split over several GPUs);
                              // the signal buffer must hold the rows row_begin - kh .. row_end + kh - 1
     int n_cu;                // compute units of the device (launch shaping)
+    int grid_cap;            // > 0: at most this many persistent workgroups (tile kernel launches that run side by side)
     int w_sym;               // all three weight sets are symmetric under a vertical flip (row s == row km-1-s)
     int w_rank1;             // the template is exactly u v^T: u (km values) and v (kn) follow the three weight sets in `w`
     // factorised per-bin mask sums of the streaming kernel (cs_mask_prep.hip); reg_mode = 1:
@@ -94,6 +95,10 @@ struct CorrArgs {
     unsigned long long* cand_count;
     long long cand_cap;
     unsigned long long cand_tag;
+    // non-null (candidate mode, masked tile kernel only): do not launch -- write the kernel's argument block here
+    // (mfma_blocks_arg_bytes() bytes, host memory) for launch_corr_mfma_blocks; defer_rsym: which instance it needs
+    void* defer_args;
+    int* defer_rsym;
     int cand_dlo, cand_dhi;  // only pixels on these diagonals are candidates (diag_trim of the coefficient map)
     int fix_on, fix_hi_w, fix_hi_d0;
     const TC* rowtab;

@@ -34,5 +34,13 @@ struct MfmaWeights {
     float unscale[3];
 };
 int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s, int* dense_path);
+// Several matrices in one persistent launch of the masked candidate instance (corr_mfma_blocks_kernel).  h_table: page-locked,
+// mfma_blocks_table_bytes(n) bytes, argument block b (CorrArgs::defer_args of launch_corr_mfma_f32) at
+// h_table + mfma_blocks_arg_offset(n) + b * mfma_blocks_arg_bytes(); d_table: as many device bytes.  The table is
+// completed (tile ranges), uploaded and the kernel launched on `s`; both buffers stay untouched until `s` has drained.
+size_t mfma_blocks_arg_bytes();
+size_t mfma_blocks_arg_offset(int n_blocks);
+size_t mfma_blocks_table_bytes(int n_blocks);
+int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t s);
 
 }  // namespace cs

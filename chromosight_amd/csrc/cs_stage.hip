@@ -218,14 +218,14 @@ __global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long lo
                 k_next += placed;
                 stage_wave_sync();
                 // out: 4 slots per lane and instruction (ld is a multiple of 16, rows start 128-byte aligned)
-                for (int x = 4 * lane; x < s1 - s0; x += 256) {
-                    const d2 a = *reinterpret_cast<const d2*>(l_row + x), c2 = *reinterpret_cast<const d2*>(l_row + x + 2);
-                    if (out64) {
-                        *reinterpret_cast<d2*>(out64 + s0 + x) = a;
-                        *reinterpret_cast<d2*>(out64 + s0 + x + 2) = c2;
+                // (every store instruction covers one dense kilobyte: lanes 16 bytes apart in either precision)
+                if (out64)
+                    for (int x = 2 * lane; x < s1 - s0; x += 128) *reinterpret_cast<d2*>(out64 + s0 + x) = *reinterpret_cast<const d2*>(l_row + x);
+                if (out32)
+                    for (int x = 4 * lane; x < s1 - s0; x += 256) {
+                        const d2 a = *reinterpret_cast<const d2*>(l_row + x), c2 = *reinterpret_cast<const d2*>(l_row + x + 2);
+                        *reinterpret_cast<f4*>(out32 + s0 + x) = f4{(float)a[0], (float)a[1], (float)c2[0], (float)c2[1]};
                     }
-                    if (out32) *reinterpret_cast<f4*>(out32 + s0 + x) = f4{(float)a[0], (float)a[1], (float)c2[0], (float)c2[1]};
-                }
                 stage_wave_sync();
             }
         }

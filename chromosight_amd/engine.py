@@ -264,7 +264,7 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
 
 
 def run_detect_foci_blocks(dev, sigs, sigs32, shapes, kspec, *, pearson, lo_diags, hi_diags, inter, diag_only, max_dists, miss_rows,
-                           miss_cols, missing_tol=0.75, want_windows=True, min_size=2, stream=None, precision=None):
+                           miss_cols, missing_tol=0.75, want_windows=True, min_size=2, stream=None, precision=None, exclusive=False):
     """detect mode of one template on MANY sub-matrices with one native call (cs_detect_foci_blocks): 2-D scans on the masked
     matrix-core tile kernel in candidate mode, one candidate list, one foci chain; 1-D scans are passed on to the narrow batch.
     sigs32: the float32 twins of the float64 maps (entries may be None).  Returns (records, windows, counts) -- the records of
@@ -276,7 +276,7 @@ def run_detect_foci_blocks(dev, sigs, sigs32, shapes, kspec, *, pearson, lo_diag
                                               not inter)
     fp_arr = (CsFociParams * n_blocks)(*[
         CsFociParams(float(pearson), rescore_margin(pearson), int(min_size), int(bool(diag_only)), int(lo_diags[b]), int(hi_diags[b]),
-                     int(bool(inter)), int(bool(want_windows))) for b in range(n_blocks)])
+                     int(bool(inter)), int(bool(want_windows)), int(bool(exclusive)), 0) for b in range(n_blocks)])
     counts = (C.c_int64 * n_blocks)()
     kk = kspec.km * kspec.kn
     cap = 4096

@@ -302,38 +302,58 @@ def _gather(records, n_fields):
 
 
 def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np.float64):
-    """Stage this rank's blocks ONCE for several pattern configurations (detect_genome(..., staged=...)): at the longest
-    keep distance any of them needs; the others scan band views of the same blocks (DeviceCool.view_for).  Returns
-    {chromosome: StagedBlock}."""
+    """Stage this rank's blocks for several pattern configurations (detect_genome(..., staged=...)): ONCE at the longest
+    keep distance any of them needs, the others scan band views of the same blocks (DeviceCool.view_for).
+    CHROMOSIGHT_HIP_NARROW_STAGING=1 (experiment, measured slower on the 23-block genome: 5.75 against 5.5 ms): configurations
+    that need a band at least 8 times narrower (1-D patterns next to loops: 18 diagonals against 1017) get their own narrow
+    staging FIRST so that their launch chains run under the wide staging instead of beside the matrix-core kernels.
+    Returns a StagedSet {chromosome: StagedBlock} (for_config(i): the set configuration i scans)."""
     dist, rank, world = _world()
-    max_dist = max(max(cfg["max_dist"] // genome.binsize, 1) for cfg in kernel_configs)
-    largest = max(max(np.shape(k)[0] for k in cfg["kernels"]) for cfg in kernel_configs)
+    dists = [max(cfg["max_dist"] // genome.binsize, 1) for cfg in kernel_configs]
+    tallest = [max(np.shape(k)[0] for k in cfg["kernels"]) for cfg in kernel_configs]
+    max_dist = max(dists)
     if owned is None:
         costs = [block_cost((genome.chrom_size(ci),) * 2, max_dist, False) for ci in range(genome.n_chrom)]
         owned = assign_blocks(costs, world)[rank]
     owned = list(owned)
-    staged = StagedSet(zip(owned, genome.stage_blocks(owned, max_dist, largest, smooth=smooth, band_dtype=band_dtype)))
-    if hasattr(genome, "dev") and hasattr(genome.dev, "new_event"):
-        # staging is asynchronous on the genome's stream: streams of other contexts wait for this event, not the host
-        if getattr(genome, "_ready_event", None) is None:
-            genome._ready_event = genome.dev.new_event()
-        genome.dev.record(genome._ready_event)
-        staged.ready = genome._ready_event
+    events = hasattr(genome, "dev") and hasattr(genome.dev, "new_event")
+
+    def stage(which, slot):
+        md = max(dists[i] for i in which)
+        out = StagedSet(zip(owned, genome.stage_blocks(owned, md, max(tallest[i] for i in which), smooth=smooth, band_dtype=band_dtype)))
+        if events:
+            # staging is asynchronous on the genome's stream: streams of other contexts wait for this event, not the host
+            name = f"_ready_event{slot}"
+            if getattr(genome, name, None) is None:
+                setattr(genome, name, genome.dev.new_event())
+            genome.dev.record(getattr(genome, name))
+            out.ready = getattr(genome, name)
+        return out
+
+    narrow = [i for i in range(len(kernel_configs)) if (dists[i] + tallest[i]) * 8 <= max_dist] \
+        if events and os.environ.get("CHROMOSIGHT_HIP_NARROW_STAGING") else []
+    first = stage(narrow, 1) if narrow else None
+    staged = stage([i for i in range(len(kernel_configs)) if i not in narrow], 0)
+    staged.by_config = {i: first for i in narrow}
     return staged
 
 
 class StagedSet(dict):
     """{chromosome: StagedBlock} of stage_genome + the event that fires when their staging is complete."""
     ready = None
+    by_config = None
+
+    def for_config(self, i):
+        return (self.by_config or {}).get(i) or self
 
 
 def _exchange_records(local, n_kernels, n_iterations):
     """The ONE record exchange of a detect call: count + padded all-gather (RCCL: csrc/cs_comm.cpp); per (template,
     iteration) the rows come in the order separate gathers would give -- ranks concatenated, stable by block."""
-    merged = _gather(local, len(GENOME_FIELDS))
-    out = [merged[(merged[:, 5] == kernel_id) & (merged[:, 6] == it)] for kernel_id in range(n_kernels) for it in range(n_iterations)]
-    out = [m for m in out if m.shape[0]]
-    return np.concatenate(out, axis=0) if out else np.zeros((0, len(GENOME_FIELDS)))
+    if _world()[2] == 1:
+        return local                                         # already (template, iteration, block)-ordered
+    merged = _gather(local, len(GENOME_FIELDS))              # ranks concatenated, stably sorted by block
+    return merged[np.argsort(merged[:, 5] * n_iterations + merged[:, 6], kind="stable")]
 
 
 _PATTERN_THREADS = None
@@ -364,19 +384,20 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     ready = getattr(staged, "ready", None)
     if side and ready is None:
         genome.dev.sync()                                    # staging is complete before several threads and streams read it
-    futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=staged,
-                                          exchange=False) for i in side}
+    pick = lambda i: staged.for_config(i) if isinstance(staged, StagedSet) else staged
+    futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=pick(i),
+                                          exchange=False, exclusive=len(side) < 2) for i in side}
     results = [None] * len(kernel_configs)
     for i, cfg in enumerate(kernel_configs):
         if i not in futures:
-            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=staged)
+            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=pick(i), exclusive=not futures)
     for i in side:
         results[i] = _exchange_records(futures[i].result(), len(kernel_configs[i]["kernels"]), 1)
     return results
 
 
 def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, stage=None, detect=None,
-                  owned=None, staged=None, exchange=True):
+                  owned=None, staged=None, exchange=True, exclusive=True):
     """`chromosight detect` over all intra-chromosomal blocks of a DeviceCool, sharded over the ranks
     like the reference's Pool.imap over sub-matrices (cli/chromosight.py:738-755): every rank stages
     and scans its own blocks (LPT assignment by band pixels), the per-block tables are all-gathered
@@ -390,6 +411,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     holds the pixels of its own chromosomes); default: LPT by scanned pixels.
     `staged`: blocks of stage_genome (staged once for several patterns); a block that cannot serve this configuration
     through a band view is staged here as usual.  exchange=False: this rank's records only (detect_patterns).
+    exclusive=False: other configurations are being scanned on this GPU at the same time (detect_patterns).
     Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
     bins, identical on all ranks, in the single-process order."""
     batch = None
@@ -397,7 +419,8 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     if stage is None and detect is None:
         from . import pipeline
         batch = lambda g, blks, cfg, k, t, w=True, defer=False, dev=None, stream=None: pipeline.detect_blocks(
-            g, blks, cfg, k, tsvd=t, raw=True, want_windows=w, defer=defer, dev=dev, stream=stream)
+            g, blks, cfg, k, tsvd=t, raw=True, want_windows=w, defer=defer, dev=dev, stream=stream, merged=True,
+            exclusive=exclusive and len(kernel_config["kernels"]) == 1)
     if stage is None or detect is None:
         from . import pipeline
         stage = stage or (lambda g, ci, md, lk: g.stage_intra(ci, md, lk, smooth=smooth, band_dtype=band_dtype,
@@ -462,7 +485,18 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                 results = futures[kernel_id].result()()
             else:
                 results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd, need_windows) if batch else None
-            for pos, ci in enumerate(mine):
+            if isinstance(results, tuple):
+                # one native call covered every block: its table is already the concatenation of the blocks' tables
+                table, kept, windows = results
+                rec = np.empty((len(table), len(GENOME_FIELDS)))
+                rec[:, 0] = np.repeat(np.asarray(mine, dtype=np.float64), kept)
+                rec[:, 1:5] = table
+                rec[:, 5] = kernel_id
+                rec[:, 6] = it
+                rows.append(rec)
+                if windows is not None:
+                    wins.append(windows)
+            for pos, ci in enumerate(mine if not isinstance(results, tuple) else ()):
                 table, windows = results[pos] if results is not None else detect(genome, staged[ci], kernel_config,
                                                                                 kernel, tsvd)
                 if table is None or len(table) == 0:

@@ -651,14 +651,17 @@ def b_is_band(block):
 
 
 def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True, defer=False,
-                  dev=None, stream=None):
+                  dev=None, stream=None, merged=False, exclusive=True):
     """detect_block for every staged block of `blocks`; results in the order of `blocks`.  Banded intra blocks go to the
     device in ONE native call per template (1-D patterns: cs_detect_foci_batch; 2-D patterns: cs_detect_foci_blocks);
     what the library cannot batch (dense-staged short chromosomes, inter blocks, odd templates) goes block by block,
     several at a time (see _Workers).  defer=True: returns a callable that yields the results -- the native calls are
     done when detect_blocks returns, the acceptance rules (numpy on the returned records) run in the callable, so a
     caller can overlap them with the next template's device work (parallel.detect_genome).  dev / stream: another
-    context and stream of the same GPU for the batched calls (templates scanned concurrently by several host threads)."""
+    context and stream of the same GPU for the batched calls (templates scanned concurrently by several host threads).
+    merged=True: when ONE native call covered every block, the result is the tuple (table of all blocks (k, 4), accepted
+    records per block, windows or None) instead of the per-block list (the genome drivers concatenate the tables anyway).
+    exclusive=False: other templates / patterns are being scanned on this GPU at the same time (parallel.detect_patterns)."""
     kernel = np.asarray(kernel, dtype=np.float64)
     bdev = dev or dcool.dev
     done = (lambda res: (lambda: res)) if defer else (lambda res: res)
@@ -672,9 +675,12 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
         fin = None
         if len(banded) > 1:
             many = cid.detect_many_on_device if kernel_config["max_dist"] == 0 else cid.detect_blocks_on_device
-            extra = dict(raw=True) if kernel_config["max_dist"] == 0 else {}
+            extra = dict(raw=True) if kernel_config["max_dist"] == 0 else dict(exclusive=exclusive)
+            whole = merged and len(banded) == len(blocks)
             fin = many(bdev, [blocks[k] for k in banded], kspec, kernel_config, want_windows=want_windows, defer=True, stream=stream,
-                       **extra)
+                       merged=whole, **extra)
+            if fin is not None and whole:
+                return fin if defer else fin()
         if fin is not None:
             rest = {k: detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows, dev=dev,
                                     stream=stream)

@@ -638,7 +638,7 @@ def _offset_scores(dev, sig, shape, kspec, rr, cc, common):
     return sr, sc, vals
 
 
-def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None, defer=False):
+def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None, defer=False, merged=False):
     """detect_on_device for a 1-D pattern (kernel_config["max_dist"] == 0: borders, hairpins) on many intra
     sub-matrices at once: `blocks` = objects with sig, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).
     One native call (cs_detect_foci_batch) instead of one launch chain and synchronisation per sub-matrix.
@@ -659,8 +659,8 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     if raw:
         rec, windows, counts = res
         if defer:           # the native call is done; the acceptance rules (numpy) when the caller asks for them
-            return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config)
-        return accept_many(blocks, rec, windows, counts, kspec, kernel_config)
+            return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
+        return accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
     out = []
     for b, (rec, windows) in zip(blocks, res):
         if rec.shape[0] == 0:
@@ -672,11 +672,13 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     return out
 
 
-def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, stream=None, defer=False):
+def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, stream=None, defer=False, merged=False,
+                            exclusive=False):
     """detect_on_device (raw tables) for a 2-D pattern on many banded intra sub-matrices with ONE native call
     (cs_detect_foci_blocks: tile kernels in candidate mode -> one candidate list -> one foci chain): `blocks` = objects with
     sig, sig32, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).  Returns the list of raw (table, windows) per
-    block, or None when the batch entry does not apply (caller: one call per block)."""
+    block, or None when the batch entry does not apply (caller: one call per block).  exclusive: no other launch chain runs
+    beside this call (cs_foci_params.exclusive: one persistent launch for the tiles of all blocks)."""
     if not blocks or kspec.km != kspec.kn or kernel_config["max_dist"] == 0:
         return None
     if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None or b.sig.layout != LAYOUT_BAND for b in blocks):
@@ -686,34 +688,58 @@ def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=T
         pearson=kernel_config["pearson"], lo_diags=[0] * len(blocks), hi_diags=[b.max_dist for b in blocks], inter=False,
         diag_only=False, max_dists=[b.max_dist for b in blocks], miss_rows=[b.miss_row for b in blocks],
         miss_cols=[b.miss_col for b in blocks], missing_tol=kernel_config["max_perc_undetected"] / 100,
-        want_windows=want_windows, stream=stream)
+        want_windows=want_windows, stream=stream, exclusive=exclusive)
     if res is None:
         return None
     rec, windows, counts = res
-    if int(np.sum(counts)) == 0:
+    if int(np.sum(counts)) == 0 and not merged:
         return (lambda: [(None, None)] * len(blocks)) if defer else [(None, None)] * len(blocks)
     if defer:
-        return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config)
-    return accept_many(blocks, rec, windows, counts, kspec, kernel_config)
+        return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
+    return accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
 
 
-def accept_many(blocks, rec, windows, counts, kspec, kernel_config):
+def accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=False):
     """The acceptance rules (detect mode, full maps) on the records of SEVERAL intra sub-matrices at once -- `rec` /
     `windows`: the records of `blocks` one block after the other, `counts` per block -- then cut at the block
     boundaries: the list of raw (table, windows) per block.  (23 numpy passes over a few hundred records each cost
-    more than the native calls that produced them.)"""
-    counts = np.asarray(counts, dtype=np.int64)
-    per = lambda values: np.repeat(np.asarray(values, dtype=np.int64), counts)
-    rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
-    shape = (per([b.shape[0] for b in blocks]), per([b.shape[1] for b in blocks]))
-    rec4, windows, ok = _accept_records(rec, windows, rr, cc, "detect", shape, kspec, kernel_config, inter=False,
-                                        max_dist=per([b.max_dist for b in blocks]), full=True, raw=True, return_ok=True)
-    ends = np.cumsum(counts)
-    kept = np.concatenate([[0], np.cumsum(ok)])[ends]              # accepted records up to the end of each block
-    cuts = kept[:-1]
+    more than the native calls that produced them; the rules themselves run in the library: cs_accept_records.)
+    merged=True: no cutting -- (table of all blocks, accepted records per block, windows)."""
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    rec4, ok, kept = accept_native(rec, counts, [b.shape for b in blocks], [b.max_dist for b in blocks], kspec, kernel_config,
+                                   inter=False, full=True, compact=True)
+    if windows is not None:
+        windows = windows[ok]
+    if merged:
+        return rec4, kept, windows
+    cuts = np.cumsum(kept)[:-1]
     parts = np.split(rec4, cuts)
     wparts = np.split(windows, cuts) if windows is not None else [None] * len(blocks)
     return [(None, None) if n == 0 else (t, w) for n, t, w in zip(counts, parts, wparts)]
+
+
+def accept_native(rec, counts, shapes, max_dists, kspec, kernel_config, *, inter, full, compact):
+    """cs_accept_records on the records of len(counts) sub-matrices: (table (k, 4), accepted mask over the records,
+    accepted per sub-matrix); what _accept_records computes with numpy (and is tested against)."""
+    from .._lib import load_library
+    rec = np.ascontiguousarray(rec)
+    n = int(rec.shape[0])
+    nb = len(counts)
+    geo = np.empty((3, max(nb, 1)), dtype=np.int32)
+    geo[0, :nb] = [s[0] for s in shapes]
+    geo[1, :nb] = [s[1] for s in shapes]
+    geo[2, :nb] = [-1 if m is None else m for m in max_dists]
+    table = np.empty((n, 4), dtype=np.float64)
+    ok = np.empty(n, dtype=np.uint8)
+    kept = np.empty(max(nb, 1), dtype=np.int64)
+    rc = load_library().cs_accept_records(
+        rec.ctypes.data, nb, counts.ctypes.data, geo[0].ctypes.data, geo[1].ctypes.data, geo[2].ctypes.data, int(bool(inter)),
+        int(kspec.km), int(kspec.kn), kernel_config["max_perc_undetected"] / 100, kernel_config["max_perc_zero"] / 100,
+        int(bool(full)), int(bool(compact)), table.ctypes.data, ok.ctypes.data, kept.ctypes.data)
+    if rc:
+        raise ValueError(f"cs_accept_records: bad arguments ({rc})")
+    kept = kept[:nb]
+    return (table[:int(kept.sum())] if compact else table), ok.view(np.bool_), kept
 
 
 def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config, *, inter, max_dist, full, raw, return_ok=False,

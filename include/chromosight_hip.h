@@ -282,6 +282,11 @@ typedef struct {
     int32_t lo_diag, hi_diag; /* scanned diagonals (diag_trim of the coefficient map, :269-270)          */
     int32_t inter;          /* 1: inter-chromosomal block (no NaN sub-diagonals in the windows, :301)    */
     int32_t want_windows;   /* 1: also return the km x kn window of every record                         */
+    int32_t exclusive;      /* cs_detect_foci_blocks, entry 0: 1 = nothing else is queued on the device beside
+                               this call -- the tiles of all blocks go out as ONE persistent launch (a table of
+                               per-block arguments); 0 = one launch per block over several streams, which leaves
+                               gaps for the launch chains of other templates running side by side               */
+    int32_t reserved;
 } cs_foci_params;
 
 typedef struct {
@@ -385,6 +390,20 @@ int cs_comm_allreduce_f64(cs_comm* comm, double* h_values, int64_t n);
  * before it lies closer than `win` bins on both axes.  h_keep: n bytes, 1 = kept. */
 int cs_remove_neighbours(const int64_t* h_bin1, const int64_t* h_bin2, const int64_t* h_order, int64_t n,
                          int64_t win, uint8_t* h_keep);
+
+/* The acceptance rules and p-values that follow a detection call, on its HOST records (reference
+ * detection.py:121-141 validate_patterns' window rules; :269-270 coefficient read on the trimmed map; :332-336 +
+ * stats.py:43-81 corr_to_pval on the untrimmed one): plain C++ over a few thousand records, here because the numpy
+ * version cost more than the device work that produced them.  h_rec: the records of n_blocks sub-matrices one after
+ * the other (h_counts[b] each; sub-matrix b has h_rows[b] x h_cols[b] bins and was scanned up to diagonal
+ * h_max_dist[b], < 0 or NULL: no limit).  inter: no diagonal rules.  full = 0: every window has km * kn
+ * observations.  h_table: 4 doubles (bin1, bin2, score, p-value) per record -- compact = 1 (detect mode): accepted
+ * records only, packed; compact = 0 (quantify mode): every record, rejected ones with a NaN score.  h_ok: one byte per
+ * input record; h_kept[b]: accepted records of sub-matrix b. */
+int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_counts, const int32_t* h_rows,
+                      const int32_t* h_cols, const int32_t* h_max_dist, int32_t inter, int32_t km, int32_t kn,
+                      double missing_tol, double zero_tol, int32_t full, int32_t compact, double* h_table, uint8_t* h_ok,
+                      int64_t* h_kept);
 
 /* ---- pinned host memory (PCIe side of the boundary: page-locked buffers copy at link speed) ---- */
 int cs_host_alloc(cs_ctx* ctx, size_t bytes, void** h_ptr);

@@ -43,5 +43,5 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.CsKernel) == 32
     assert ctypes.sizeof(_lib.CsNormxcorr2Params) == 80
     assert ctypes.sizeof(_lib.CsCsr) == 72
-    assert ctypes.sizeof(_lib.CsFociParams) == 40
+    assert ctypes.sizeof(_lib.CsFociParams) == 48
     assert ctypes.sizeof(_lib.CsFocus) == 40 == _lib.FOCUS_DTYPE.itemsize

@@ -425,3 +425,43 @@ def test_writers_and_bed2d(tmp_path):
     with pytest.raises(OSError):
         cio.check_prefix_dir(str(tmp_path / "missing_dir" / "prefix"))
     cio.check_prefix_dir(str(tmp_path / "prefix"))
+
+
+def test_native_acceptance_rules_equal_the_numpy_ones():
+    """cs_accept_records (host C++, what the genome drivers call) against _accept_records (numpy restatement of reference
+    detection.py:121-141, 269-270, 332-336 + stats.py:43-81) on random records with every edge the rules have."""
+    import types
+    from chromosight_amd._lib import FOCUS_DTYPE
+    from chromosight_amd.utils import detection as cid
+    rng = np.random.default_rng(5)
+    kspec = types.SimpleNamespace(km=17, kn=17)
+    cfg = {"max_perc_undetected": 50.0, "max_perc_zero": 10.0}
+    shapes, max_dists, counts = [(900, 900), (400, 400), (50, 50), (700, 700)], [300, 80, None, 5], np.array([2000, 700, 0, 300])
+    n = int(counts.sum())
+    rec = np.zeros(n, FOCUS_DTYPE)
+    rec["bin1"] = rng.integers(-3, 905, n)
+    rec["bin2"] = rec["bin1"] + rng.integers(-2, 320, n)
+    rec["inside"] = rng.random(n) < 0.95
+    rec["n_missing"] = rng.integers(0, 290, n)
+    rec["n_missing"][rng.random(n) < 0.02] = 289
+    rec["n_zero"] = rng.integers(0, 60, n)
+    rec["score"] = rng.uniform(-1, 1, n)
+    rec["score"][:8] = [0.0, 1.0, -1.0, np.nan, 1e-300, 0.999999999, -0.0, 1.5]
+    rec["n_obs"] = 289 - rec["n_missing"]
+    rec["n_obs"][8:12] = [0, 2, 3, 4]
+    per = lambda v: np.repeat(np.asarray(v, dtype=np.int64), counts)
+    for full in (True, False):
+        for compact in (True, False):
+            got, ok, kept = cid.accept_native(rec, counts, shapes, max_dists, kspec, cfg, inter=False, full=full, compact=compact)
+            rr, cc = rec["bin1"].astype(np.int64), rec["bin2"].astype(np.int64)
+            md = per([10 ** 9 if m is None else m for m in max_dists])
+            want, _, want_ok = cid._accept_records(rec, None, rr, cc, "detect" if compact else "quantify",
+                                                   (per([s[0] for s in shapes]), per([s[1] for s in shapes])), kspec, cfg, inter=False,
+                                                   max_dist=md, full=full, raw=True, return_ok=True)
+            assert np.array_equal(ok, want_ok)
+            assert np.array_equal(kept, [want_ok[a:b].sum() for a, b in zip(np.cumsum(counts) - counts, np.cumsum(counts))])
+            assert got.shape == want.shape
+            assert np.array_equal(got[:, :3], want[:, :3], equal_nan=True)          # coordinates and scores: the same bits
+            assert np.allclose(got[:, 3], want[:, 3], rtol=1e-12, atol=1e-300, equal_nan=True)   # libm vs scipy's erfc
+    got, ok, kept = cid.accept_native(rec[:0], np.zeros(0, np.int64), [], [], kspec, cfg, inter=False, full=True, compact=True)
+    assert got.shape == (0, 4) and ok.size == 0 and kept.size == 0

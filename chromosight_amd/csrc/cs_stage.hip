@@ -40,6 +40,13 @@ __device__ __forceinline__ double stage_detrend(double v, double y, double max_v
     return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
 }
 
+// Latency, not bandwidth, bounded the first version (2.1 TB/s): per row a wave waited for the row pointers, then for the
+// pixels they delimit, then for the gathered column weights -- three dependent round trips for ~270 stored pixels.  Now
+// the row pointers and row weights of all the wave's rows of a group arrive together (one lane per row), the column
+// weights the group can touch sit in LDS (rows r0 .. r0 + rows, columns up to keep further: one coalesced load per
+// group), and the first kStageUnroll x 64 pixels of the NEXT row are requested before the current row is reduced.
+constexpr int kStageGroupRows = 128;             // upper bound of rows per group (cs_api.cpp picks 64 .. 128)
+
 template <typename TV, int kStageUnroll>
 __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                                   const TV* __restrict__ data, const double* __restrict__ weight,
@@ -51,54 +58,93 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* l_sum = reinterpret_cast<double*>(smem_raw);
     unsigned* l_cnt = reinterpret_cast<unsigned*>(smem_raw + sizeof(double) * (size_t)pitch);
+    double* l_w = reinterpret_cast<double*>(smem_raw + (sizeof(double) + sizeof(unsigned)) * (size_t)pitch);   // pitch + kStageGroupRows
+    // (a store per row would sit between a row's pixel request and its use: memory operations retire in order, so every
+    // row would wait a full write round trip -- the group's row ends leave together instead)
+    long long* l_stop = reinterpret_cast<long long*>(l_w + pitch + kStageGroupRows);                             // kStageGroupRows
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const StageGroup G = groups[g];
         const StageBlock B = blocks[G.block];
+        const long long last_col = B.row0 + B.n - 1;
+        const long long r0 = B.row0 + G.row_begin;                         // first row of the group = first column it can touch
+        const int n_w = (int)min((long long)(G.row_end - G.row_begin) + B.keep, last_col - r0 + 1);
         for (int d = tid; d < B.n_diags; d += kStageThreads) {
             l_sum[d] = 0.0;
             l_cnt[d] = 0u;
         }
+        for (int t = tid; t < n_w; t += kStageThreads) l_w[t] = weight[r0 + t];
+        // this wave's rows: G.row_begin + wv + 8 i, i < n_mine (<= 16) -- lane i holds row i's pointers
+        const int n_mine = (G.row_end - G.row_begin - wv + kStageWaves - 1) / kStageWaves;
+        long long my_b = 0, my_e = 0;
+        if (lane < n_mine) {
+            const long long r = r0 + wv + (long long)kStageWaves * lane;
+            my_b = indptr[r];
+            my_e = min(indptr[r + 1], my_b + (long long)B.keep + 1);       // columns are distinct and >= r
+        }
         __syncthreads();
-        const long long last_col = B.row0 + B.n - 1;
-        for (int rl = G.row_begin + wv; rl < G.row_end; rl += kStageWaves) {
+        auto row_b = [&](int i) { return __shfl(my_b, i); };
+        auto row_e = [&](int i) { return __shfl(my_e, i); };
+        int cn[kStageUnroll];                                              // the next row's first pixels, in flight
+        TV xn[kStageUnroll];
+        auto request = [&](int i) {
+            const long long b = row_b(i), e = row_e(i);
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; ++u) {
+                const long long k = b + lane + 64 * u;
+                const bool ok = k < e;
+                cn[u] = ok ? indices[k] : 0x7fffffff;
+                xn[u] = ok ? data[k] : (TV)0;
+            }
+        };
+        if (n_mine > 0) request(0);
+        for (int i = 0; i < n_mine; ++i) {
+            const int rl = G.row_begin + wv + kStageWaves * i;
             const long long r = B.row0 + rl;
-            const double wr = weight[r];
-            const long long b = indptr[r];
-            const long long e = min(indptr[r + 1], b + (long long)B.keep + 1);       // columns are distinct and >= r
+            const double wr = l_w[rl - G.row_begin];
+            const long long b = row_b(i), e = row_e(i);
             const long long c_hi = min(r + (long long)B.keep, last_col);
+            int c[kStageUnroll];
+            TV x[kStageUnroll];
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; ++u) {
+                c[u] = cn[u];
+                x[u] = xn[u];
+            }
+            if (i + 1 < n_mine) request(i + 1);
             int n_in = 0;
-            for (long long k0 = b + lane; k0 - lane < e; k0 += 64 * kStageUnroll) {
-                long long c[kStageUnroll];
-                double x[kStageUnroll], wc[kStageUnroll];
+            for (long long k0 = b;;) {
 #pragma unroll
                 for (int u = 0; u < kStageUnroll; ++u) {
-                    const long long k = k0 + 64 * u;
-                    const bool ok = k < e;
-                    c[u] = ok ? (long long)indices[k] : (long long)(1ll << 40);
-                    x[u] = ok ? (double)data[k] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < kStageUnroll; ++u) wc[u] = c[u] <= c_hi ? weight[c[u]] : 0.0;
-#pragma unroll
-                for (int u = 0; u < kStageUnroll; ++u) {
-                    const bool in = c[u] <= c_hi;
+                    const bool in = (long long)c[u] <= c_hi;
                     n_in += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
-                    const double v = (x[u] * wr) * wc[u];             // csr_value: cooler's matrix(balance=True)
+                    const double wc = in ? l_w[(int)((long long)c[u] - r0)] : 0.0;
+                    const double v = ((double)x[u] * wr) * wc;        // csr_value: cooler's matrix(balance=True)
                     if (in && v > 0.0) {                              // also drops NaN (preprocessing.py:188)
-                        const int d = (int)(c[u] - r);
+                        const int d = (int)((long long)c[u] - r);
                         atomicAdd(&l_sum[d], v);
                         atomicAdd(&l_cnt[d], 1u);
                     }
                 }
+                k0 += 64 * kStageUnroll;
+                if (k0 >= e) break;
+                // a row with more stored pixels inside the band than one request holds: the rest, request by request
+#pragma unroll
+                for (int u = 0; u < kStageUnroll; ++u) {
+                    const long long k = k0 + lane + 64 * u;
+                    const bool ok = k < e;
+                    c[u] = ok ? indices[k] : 0x7fffffff;
+                    x[u] = ok ? data[k] : (TV)0;
+                }
             }
-            if (lane == 0) row_stop[r] = b + n_in;
+            if (lane == 0) l_stop[rl - G.row_begin] = b + n_in;
         }
         __syncthreads();
         for (int d = tid; d < B.n_diags; d += kStageThreads) {
             part_sum[(size_t)g * pitch + d] = l_sum[d];
             part_cnt[(size_t)g * pitch + d] = l_cnt[d];
         }
+        for (int t = tid; t < G.row_end - G.row_begin; t += kStageThreads) row_stop[r0 + t] = l_stop[t];
         __syncthreads();
     }
 }
@@ -144,7 +190,7 @@ __global__ __launch_bounds__(64 * kFinishPhases) void stage_finish_kernel(const 
 // single-element stores: 3.1 ms for the 23-block genome (1.0 TB/s), against 0.3 ms for the same reads in the law kernel.
 // Rows are built in pieces of kStageRowMax slots (columns are sorted: a piece continues where the last one stopped), which
 // keeps three workgroups per CU resident.
-constexpr int kStageRowMax = 576;                // slots per LDS row piece: 4.5 KB per wave, 36 KB per workgroup of 8 waves
+constexpr int kStageRowMax = 544;                // slots per LDS row piece: 4.25 KB per wave, 34 KB per workgroup (+ law and weights: 52 KB, three per CU)
 
 __device__ __forceinline__ void stage_wave_sync()
 {
@@ -154,71 +200,120 @@ __device__ __forceinline__ void stage_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Per group: the law and the column weights the group can touch go to LDS, lane i of a wave holds the first and last stored
+// pixel of the wave's i-th row, and the first 64 x kStageUnroll stored pixels of the NEXT row are requested before the current
+// row is assembled -- a row whose stored pixels fit one request (kStageUnroll is picked by the width of the band) is built
+// without waiting for a load.  What still serialises: memory operations of a wave retire in order, so the use of a request
+// also waits for the previous row's stores.  (Tried: builder waves that only load and assemble + writer waves that only
+// store, a workgroup barrier per piece -- 1.27 ms against 0.95 for the 23-block genome; the stores alone take 0.39 ms,
+// tools/ubench/write_rate.hip.)
 template <typename TV, int kStageUnroll>
 __global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
-                                                                   const TV* __restrict__ data, const double* __restrict__ weight,
-                                                                   const StageBlock* __restrict__ blocks,
-                                                                   const StageGroup* __restrict__ groups, int n_groups, int pitch,
-                                                                   const long long* __restrict__ row_stop, double max_val)
+                                                                          const TV* __restrict__ data, const double* __restrict__ weight,
+                                                                          const StageBlock* __restrict__ blocks,
+                                                                          const StageGroup* __restrict__ groups, int n_groups, int pitch,
+                                                                          const long long* __restrict__ row_stop, double max_val, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* l_law = reinterpret_cast<double*>(smem_raw);
+    double* l_w = l_law + pitch;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double* l_row = reinterpret_cast<double*>(smem_raw + sizeof(double) * (size_t)pitch) + (size_t)wv * kStageRowMax;
+    double* l_row = l_w + pitch + kStageGroupRows + (size_t)wv * kStageRowMax;
     typedef double d2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const StageGroup G = groups[g];
         const StageBlock B = blocks[G.block];
+        const long long last_col = B.row0 + B.n - 1;
+        const long long r0 = B.row0 + G.row_begin;
+        const int n_w = (int)min((long long)(G.row_end - G.row_begin) + B.keep, last_col - r0 + 1);
         __syncthreads();
         for (int d = tid; d < B.n_diags; d += kStageThreads) l_law[d] = B.law[d];
+        for (int t = tid; t < n_w; t += kStageThreads) l_w[t] = weight[r0 + t];
+        const int n_mine = (G.row_end - G.row_begin - wv + kStageWaves - 1) / kStageWaves;
+        long long my_b = 0, my_e = 0;
+        if (lane < n_mine) {
+            const long long r = r0 + wv + (long long)kStageWaves * lane;
+            my_b = indptr[r];
+            my_e = row_stop[r];
+        }
         __syncthreads();
+        int cn[kStageUnroll];
+        TV xn[kStageUnroll];
+        auto request = [&](int i) {
+            const long long b = __shfl(my_b, i), e = __shfl(my_e, i);
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; ++u) {
+                const long long k = b + lane + 64 * u;
+                const bool ok = k < e;
+                cn[u] = ok ? indices[k] : 0x7fffffff;
+                xn[u] = ok ? data[k] : (TV)0;
+            }
+        };
+        if (n_mine > 0) request(0);
         const int ld = (int)B.ld;
-        for (int rl = G.row_begin + wv; rl < G.row_end; rl += kStageWaves) {
+        const int n_pieces = (ld + kStageRowMax - 1) / kStageRowMax;
+        const int piece_len = ((ld + n_pieces - 1) / n_pieces + 15) & ~15;
+        for (int i = 0; i < n_mine; ++i) {
+            const int rl = G.row_begin + wv + kStageWaves * i;
             const long long r = B.row0 + rl;
-            const double wr = weight[r];
-            const long long b = indptr[r], e = row_stop[r];
-            double* out64 = B.band64 ? B.band64 + (size_t)rl * B.ld : nullptr;
-            float* out32 = B.band32 ? B.band32 + (size_t)rl * B.ld : nullptr;
-            const long long x0 = B.dense ? B.row0 : r;                  // slot of column c: c - x0
-            long long k_next = b;                                       // first stored pixel not yet placed
-            for (int s0 = 0; s0 < ld; s0 += kStageRowMax) {             // pieces of the row
-                const int s1 = min(ld, s0 + kStageRowMax);
+            const double wr = l_w[rl - G.row_begin];
+            const long long b = __shfl(my_b, i), e = __shfl(my_e, i);
+            double* out64 = (B.band64 && !(dbg & 1)) ? B.band64 + (size_t)rl * B.ld : nullptr;
+            float* out32 = (B.band32 && !(dbg & 2)) ? B.band32 + (size_t)rl * B.ld : nullptr;
+            const long long x0 = B.dense ? B.row0 : r;
+            double v[kStageUnroll];
+            int slot[kStageUnroll];
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; ++u) {
+                const bool ok = cn[u] != 0x7fffffff;
+                const int d = ok ? (int)((long long)cn[u] - r) : 0;
+                const double wc = ok ? l_w[(int)((long long)cn[u] - r0)] : 0.0;
+                v[u] = stage_detrend(((double)xn[u] * wr) * wc, d < B.n_diags ? l_law[d] : 0.0, max_val);
+                slot[u] = ok ? (int)((long long)cn[u] - x0) : -1;
+            }
+            const bool fits = e - b <= 64 * kStageUnroll;
+            if (i + 1 < n_mine) request(i + 1);
+            long long k_next = b;
+            for (int p = 0; p < n_pieces; ++p) {
+                const int s0 = p * piece_len, s1 = min(ld, s0 + piece_len);
                 for (int x = 2 * lane; x < s1 - s0; x += 128) *reinterpret_cast<d2*>(l_row + x) = d2{0.0, 0.0};
                 stage_wave_sync();
-                // stored pixels whose slot falls in [s0, s1): columns are sorted, so they are a run starting at k_next
-                const long long c_end = x0 + s1;                        // first column beyond the piece
-                int placed = 0;
-                for (long long k0 = k_next + lane; k0 - lane < e; k0 += 64 * kStageUnroll) {
-                    long long c[kStageUnroll];
-                    double x[kStageUnroll], wc[kStageUnroll];
+                if (fits) {
 #pragma unroll
-                    for (int u = 0; u < kStageUnroll; ++u) {
-                        const long long k = k0 + 64 * u;
-                        const bool ok = k < e;
-                        c[u] = ok ? (long long)indices[k] : (long long)(1ll << 40);
-                        x[u] = ok ? (double)data[k] : 0.0;
-                    }
+                    for (int u = 0; u < kStageUnroll; ++u)
+                        if (slot[u] >= s0 && slot[u] < s1) l_row[slot[u] - s0] = v[u];
+                } else {
+                    const long long c_end = x0 + s1;
+                    int placed = 0;
+                    for (long long k0 = k_next + lane; k0 - lane < e; k0 += 64 * kStageUnroll) {
+                        long long c[kStageUnroll];
+                        double x[kStageUnroll];
 #pragma unroll
-                    for (int u = 0; u < kStageUnroll; ++u) wc[u] = c[u] < c_end ? weight[c[u]] : 0.0;
-                    bool more = true;
-#pragma unroll
-                    for (int u = 0; u < kStageUnroll; ++u) {
-                        const bool in = c[u] < c_end;
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
-                        placed += __builtin_popcountll(m);
-                        if (in) {
-                            const int d = (int)(c[u] - r);
-                            l_row[(int)(c[u] - x0) - s0] = stage_detrend((x[u] * wr) * wc[u], d < B.n_diags ? l_law[d] : 0.0, max_val);
+                        for (int u = 0; u < kStageUnroll; ++u) {
+                            const long long k = k0 + 64 * u;
+                            const bool ok = k < e;
+                            c[u] = ok ? (long long)indices[k] : (long long)(1ll << 40);
+                            x[u] = ok ? (double)data[k] : 0.0;
                         }
-                        more = more && (m == ~0ull);                    // a lane beyond the piece (or the row): this piece is complete
+                        bool more = true;
+#pragma unroll
+                        for (int u = 0; u < kStageUnroll; ++u) {
+                            const bool in = c[u] < c_end;
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                            placed += __builtin_popcountll(m);
+                            if (in) {
+                                const int d = (int)(c[u] - r);
+                                l_row[(int)(c[u] - x0) - s0] =
+                                    stage_detrend((x[u] * wr) * l_w[(int)(c[u] - r0)], d < B.n_diags ? l_law[d] : 0.0, max_val);
+                            }
+                            more = more && (m == ~0ull);
+                        }
+                        if (!more) break;
                     }
-                    if (!more) break;
+                    k_next += placed;
                 }
-                k_next += placed;
                 stage_wave_sync();
-                // out: 4 slots per lane and instruction (ld is a multiple of 16, rows start 128-byte aligned)
-                // (every store instruction covers one dense kilobyte: lanes 16 bytes apart in either precision)
                 if (out64)
                     for (int x = 2 * lane; x < s1 - s0; x += 128) *reinterpret_cast<d2*>(out64 + s0 + x) = *reinterpret_cast<const d2*>(l_row + x);
                 if (out32)
@@ -286,8 +381,9 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     const int per_cu = getenv("CHROMOSIGHT_HIP_STAGE_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_GRID")) : 4;
     const int unroll = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL")) : 4;
     const int grid = std::min(n_groups, per_cu * n_cu);
-    const size_t smem_law = (sizeof(double) + sizeof(unsigned)) * (size_t)pitch;
-    const size_t smem_tile = sizeof(double) * ((size_t)pitch + (size_t)kStageWaves * kStageRowMax);
+    if (rows_per_group > kStageGroupRows) return (int)hipErrorInvalidValue;
+    const size_t smem_law = (sizeof(double) + sizeof(unsigned)) * (size_t)pitch + sizeof(double) * ((size_t)pitch + 2 * kStageGroupRows);
+    const size_t smem_tile = sizeof(double) * (2 * (size_t)pitch + kStageGroupRows + (size_t)kStageWaves * kStageRowMax);
     int max_b = 0;
     for (int b = 0; b < n_blocks; ++b) max_b = std::max(max_b, h_blocks[b].n_diags);
 #define CS_STAGE_LAW(TV, U)                                                                                                       \
@@ -299,26 +395,29 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
             (void)hipFuncSetAttribute((const void*)stage_tile_kernel<TV, U>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
                                       160 * 1024);                                                                                 \
         hipLaunchKernelGGL((stage_tile_kernel<TV, U>), dim3(grid), dim3(kStageThreads), smem_tile, stream, indptr, indices,          \
-                           (const TV*)data, weight, d_blocks, d_groups, n_groups, pitch, row_stop, max_val);                        \
+                           (const TV*)data, weight, d_blocks, d_groups, n_groups, pitch, row_stop, max_val, stage_dbg);             \
     } while (0)
-#define CS_STAGE_BOTH(WHAT)                      \
+#define CS_STAGE_BOTH(WHAT, UNROLL)               \
     if (data_is_f64) {                           \
-        if (unroll >= 8) WHAT(double, 8);        \
-        else if (unroll >= 4) WHAT(double, 4);   \
+        if (UNROLL >= 8) WHAT(double, 8);        \
+        else if (UNROLL >= 4) WHAT(double, 4);   \
         else WHAT(double, 2);                    \
     } else {                                     \
-        if (unroll >= 8) WHAT(float, 8);         \
-        else if (unroll >= 4) WHAT(float, 4);    \
+        if (UNROLL >= 8) WHAT(float, 8);         \
+        else if (UNROLL >= 4) WHAT(float, 4);    \
         else WHAT(float, 2);                     \
     }
+    // the tiler keeps a whole row's stored pixels in registers when they fit its request (64 x unroll): by the widest band
+    const int unroll_tile = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL_TILE") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL_TILE")) : (max_b > 256 ? 8 : 4);
+    const int stage_dbg = getenv("CHROMOSIGHT_HIP_STAGE_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_DBG")) : 0;   // timing experiments only
     const char* skip = getenv("CHROMOSIGHT_HIP_STAGE_SKIP");      // diagnostics: "law" / "tile" leave that kernel out
     if (!(skip && skip[0] == 'l')) {
-        CS_STAGE_BOTH(CS_STAGE_LAW)
+        CS_STAGE_BOTH(CS_STAGE_LAW, unroll)
     }
     hipLaunchKernelGGL(stage_finish_kernel, dim3(n_blocks, (max_b + 63) / 64), dim3(64 * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
                        part_cnt);
     if (!(skip && skip[0] == 't')) {
-        CS_STAGE_BOTH(CS_STAGE_TILE)
+        CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile)
     }
 #undef CS_STAGE_BOTH
 #undef CS_STAGE_LAW

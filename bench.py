@@ -81,15 +81,20 @@ class Workload:
             rng = np.random.default_rng(0 + rank)
             self.host_sig = rng.gamma(4.0, 0.25, size=(n, n)).astype(np.float32)
             self.shape = (n, n)
-            self.sig_buf = dev.to_device(self.host_sig)
-            self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0)
-            self.out_buf = dev.empty((n, n), out_dtype)
-            self.out = CsMatrix(self.out_buf.ptr, np_dtype_code(out_dtype), LAYOUT_DENSE, n, 0, 0)
+            # device-resident maps with the engine's row pitch (never a power of two: HBM channel spread, engine.map_pitch)
+            if os.environ.get("CHROMOSIGHT_BENCH_TIGHT_PITCH"):        # comparison only: rows packed tight (pitch n)
+                self.sig_buf, ld_in, ld_out = dev.to_device(self.host_sig), n, n
+            else:
+                self.sig_buf, ld_in = engine.to_device_map(dev, self.host_sig)
+                ld_out = engine.map_pitch(n, np.dtype(out_dtype).itemsize)
+            self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, ld_in, 0, 0)
+            self.out_buf = dev.empty((n, ld_out), out_dtype)
+            self.out = CsMatrix(self.out_buf.ptr, np_dtype_code(out_dtype), LAYOUT_DENSE, ld_out, 0, 0)
             self.kwargs = dict(full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE)
             self.pixels = n * n
             self.bytes_per_pixel = 4 + np.dtype(out_dtype).itemsize
             self.desc = (f"C2: dense {n}x{n} float32 gamma(4,0.25) seed 0, 17x17 loops template, "
-                         "normxcorr2(full=False, no mask)")
+                         f"normxcorr2(full=False, no mask); device-resident, row pitch {ld_in} / {ld_out} elements")
         elif name == "c3":
             # CSR in, detrend included (two passes over nnz * 8 B + 4 B per pixel written)
             from chromosight_amd import pipeline

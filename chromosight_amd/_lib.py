@@ -139,6 +139,7 @@ _PROTOTYPES = {
     "cs_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "cs_stream_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cs_stream_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cs_stream_create_priority": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "cs_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cs_event_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cs_event_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -182,6 +183,8 @@ _PROTOTYPES = {
                                  C.POINTER(C.c_int64), C.c_void_p]),
     "cs_detect_foci_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(CsKernel), C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_detect_foci_batch_templates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cs_quantify_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),
@@ -387,9 +390,12 @@ class Device:
         raw._lease = lease
         return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
-    def new_stream(self):
+    def new_stream(self, high_priority=False):
         s = C.c_void_p()
-        self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))
+        if high_priority:
+            self._check(self.lib.cs_stream_create_priority(self.ctx, 1, C.byref(s)))
+        else:
+            self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))
         return s.value
 
     def new_event(self):

@@ -33,6 +33,16 @@ struct cs_ctx {
     size_t d_w_bytes[2] = {0, 0};
     // host copies of what d_w currently holds, to skip re-uploads of an unchanged template
     std::vector<unsigned char> w_cached[2];
+    // the weight sets of the templates used before the current one (calls that alternate between a few templates, or
+    // hand several to one launch chain: cs_detect_foci_batch_templates) -- swapped back in instead of uploaded again
+    struct ParkedWeights {
+        void* d = nullptr;
+        size_t bytes = 0;
+        std::vector<unsigned char> host;
+        unsigned long long stamp = 0;
+    };
+    ParkedWeights w_parked[2][3];
+    unsigned long long w_clock = 0;
     // cs_detect_foci: coefficient map and candidate / foci scratch (grow-only), pinned counters
     void* d_map = nullptr;
     size_t d_map_bytes = 0;
@@ -169,6 +179,26 @@ int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w
     std::vector<TC> w(w64.size());
     for (size_t t = 0; t < w64.size(); ++t) w[t] = (TC)w64[t];
     const size_t bytes = w.size() * sizeof(TC);
+    if (ctx->w_cached[slot].size() == bytes && std::memcmp(ctx->w_cached[slot].data(), w.data(), bytes) == 0) return CS_OK;
+    // a set used before?  swap it back in; otherwise the current set is parked in the slot used longest ago and that
+    // slot's buffer takes the upload (work queued by earlier calls has drained: every entry point ends synchronised)
+    {
+        auto swap_in = [&](cs_ctx::ParkedWeights& pk) {
+            std::swap(ctx->d_w[slot], pk.d);
+            std::swap(ctx->d_w_bytes[slot], pk.bytes);
+            ctx->w_cached[slot].swap(pk.host);
+            pk.stamp = ++ctx->w_clock;
+        };
+        cs_ctx::ParkedWeights* oldest = &ctx->w_parked[slot][0];
+        for (auto& pk : ctx->w_parked[slot]) {
+            if (pk.d && pk.host.size() == bytes && std::memcmp(pk.host.data(), w.data(), bytes) == 0) {
+                swap_in(pk);
+                return CS_OK;
+            }
+            if (pk.stamp < oldest->stamp) oldest = &pk;
+        }
+        if (ctx->d_w[slot]) swap_in(*oldest);
+    }
     // + 64 bytes of slack: the fast kernels' scalar row loads over-read (cs_corr_stream.h WRow)
     if (bytes + 64 > ctx->d_w_bytes[slot]) {
         if (ctx->d_w[slot]) {
@@ -885,8 +915,11 @@ void cs_ctx_destroy(cs_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int slot = 0; slot < 2; ++slot)
+    for (int slot = 0; slot < 2; ++slot) {
         if (ctx->d_w[slot]) (void)hipFree(ctx->d_w[slot]);
+        for (auto& pk : ctx->w_parked[slot])
+            if (pk.d) (void)hipFree(pk.d);
+    }
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
@@ -979,6 +1012,18 @@ int cs_stream_create(cs_ctx* ctx, void** stream)
     CS_ENTER(ctx);
     hipStream_t s;
     CS_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return CS_OK;
+}
+
+int cs_stream_create_priority(cs_ctx* ctx, int32_t high, void** stream)
+{
+    if (!stream) return CS_ERR_INVALID;
+    CS_ENTER(ctx);
+    int least = 0, greatest = 0;                     // numerically lower = served first
+    CS_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s;
+    CS_HIP(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
     *stream = (void*)s;
     return CS_OK;
 }
@@ -1903,38 +1948,46 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
     return CS_OK;
 }
 
-int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
-                         const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci, int64_t cap,
-                         int64_t* h_n_foci, double* h_windows)
+int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_matrix* signals, int32_t n_kernels,
+                                   const cs_kernel* kernels, const cs_normxcorr2_params* params, const cs_foci_params* foci,
+                                   cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows)
 {
     CS_ENTER(ctx);
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_blocks <= 0 || !signals || !kernel || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
+    if (n_blocks <= 0 || !signals || !kernels || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
         return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
-    const int kk = kernel->km * kernel->kn;
-    std::vector<cs::CorrArgs<double>> tab((size_t)n_blocks);
-    std::vector<long long> seg((size_t)n_blocks + 1, 0);
-    std::vector<int> lo_w(2 * (size_t)n_blocks);
-    for (int b = 0; b < n_blocks; ++b) {
-        const cs_normxcorr2_params* p = params + b;
-        const cs_foci_params* fp = foci + b;
-        int rc = check_foci_args(ctx, signals + b, kernel, p, fp);
-        if (rc) return rc;
-        const int w = fp->hi_diag - fp->lo_diag + 1;
-        if (signals[b].layout != CS_LAYOUT_BAND || w < 1 || w > 4 || fp->lo_diag < 0 || (p->row_end > p->row_begin))
-            return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry takes 1-D patterns (<= 4 scanned diagonals from 0 up) of whole banded blocks");
-        if (fp->pearson != foci[0].pearson || fp->min_size != foci[0].min_size || fp->diag_only != foci[0].diag_only ||
-            fp->inter != foci[0].inter || fp->want_windows != foci[0].want_windows)
-            return fail(ctx, CS_ERR_INVALID, "the blocks of a batch share the detection parameters");
-        const long long n_b = cs::narrow_band_pixels(0, p->ms, p->ns, fp->lo_diag, w);
-        if (n_b > cs::kFociSmallMax) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d has %lld candidate pixels", b, n_b);
-        seg[b + 1] = seg[b] + n_b;
-        lo_w[2 * b] = fp->lo_diag;
-        lo_w[2 * b + 1] = w;
-        rc = build_args<double>(ctx, stream, signals + b, kernel, p, &tab[b]);
-        if (rc) return rc;
-    }
-    const long long n_total = seg[n_blocks];
+    // (the weight sets of all templates stay resident side by side: the current one + the parked ones of upload_weights)
+    if (n_kernels < 1 || n_kernels > 4) return fail(ctx, CS_ERR_UNSUPPORTED, "1 to 4 templates per batch");
+    for (int t = 1; t < n_kernels; ++t)
+        if (kernels[t].km != kernels[0].km || kernels[t].kn != kernels[0].kn)
+            return fail(ctx, CS_ERR_INVALID, "the templates of a batch share their size");
+    // virtual block v = t * n_blocks + b: sub-matrix b under template t
+    const int n_virtual = n_blocks * n_kernels;
+    std::vector<cs::CorrArgs<double>> tab((size_t)n_virtual);
+    std::vector<long long> seg((size_t)n_virtual + 1, 0);
+    std::vector<int> lo_w(2 * (size_t)n_virtual);
+    for (int t = 0; t < n_kernels; ++t)
+        for (int b = 0; b < n_blocks; ++b) {
+            const int v = t * n_blocks + b;
+            const cs_normxcorr2_params* p = params + b;
+            const cs_foci_params* fp = foci + b;
+            int rc = check_foci_args(ctx, signals + b, kernels + t, p, fp);
+            if (rc) return rc;
+            const int w = fp->hi_diag - fp->lo_diag + 1;
+            if (signals[b].layout != CS_LAYOUT_BAND || w < 1 || w > 4 || fp->lo_diag < 0 || (p->row_end > p->row_begin))
+                return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry takes 1-D patterns (<= 4 scanned diagonals from 0 up) of whole banded blocks");
+            if (fp->pearson != foci[0].pearson || fp->min_size != foci[0].min_size || fp->diag_only != foci[0].diag_only ||
+                fp->inter != foci[0].inter || fp->want_windows != foci[0].want_windows)
+                return fail(ctx, CS_ERR_INVALID, "the blocks of a batch share the detection parameters");
+            const long long n_b = cs::narrow_band_pixels(0, p->ms, p->ns, fp->lo_diag, w);
+            if (n_b > cs::kFociSmallMax) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d has %lld candidate pixels", b, n_b);
+            seg[v + 1] = seg[v] + n_b;
+            lo_w[2 * v] = fp->lo_diag;
+            lo_w[2 * v + 1] = w;
+            rc = build_args<double>(ctx, stream, signals + b, kernels + t, p, &tab[v]);      // (uploads template t once: b == 0)
+            if (rc) return rc;
+        }
+    const long long n_total = seg[n_virtual];
     if (n_total > INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%lld)", n_total);
     // results straight into page-locked caller buffers (cs_host_alloc); anything else goes through cs_detect_foci
     auto device_view = [&](const void* h) -> void* {
@@ -1951,7 +2004,7 @@ int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_
     if ((cap > 0 && !rec) || (foci[0].want_windows && h_windows && !win))
         return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry writes into page-locked buffers (cs_host_alloc)");
     // per-block counts through a page-locked array owned by the context
-    const size_t cnt_bytes = 8 * ((size_t)n_blocks + 2);
+    const size_t cnt_bytes = 8 * ((size_t)n_virtual + 2);
     if (cnt_bytes > ctx->h_blk_bytes) {
         if (ctx->h_blk_counts) CS_HIP(ctx, hipHostFree(ctx->h_blk_counts));
         ctx->h_blk_counts = nullptr;
@@ -1960,19 +2013,25 @@ int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_
         ctx->h_blk_bytes = 2 * cnt_bytes;
     }
     ctx->h_blk_counts[0] = -1;
-    int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, cs::narrow_batch_scratch_bytes(n_blocks, n_total));
+    int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, cs::narrow_batch_scratch_bytes(n_virtual, n_total));
     if (rc) return rc;
-    rc = cs::enqueue_foci_narrow_batch(tab.data(), seg.data(), lo_w.data(), n_blocks, foci[0].pearson, foci[0].min_size,
-                                       diag_code(foci, kernel, params), foci[0].inter, ctx->d_pool, rec, (long long)cap, win,
+    rc = cs::enqueue_foci_narrow_batch(tab.data(), seg.data(), lo_w.data(), n_virtual, foci[0].pearson, foci[0].min_size,
+                                       diag_code(foci, kernels, params), foci[0].inter, ctx->d_pool, rec, (long long)cap, win,
                                        win ? (long long)cap : 0, ctx->h_blk_counts, stream);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host tables above were consumed
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
-    for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
+    for (int v = 0; v < n_virtual; ++v) h_n_foci[v] = ctx->h_blk_counts[1 + v];
     if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
-    (void)kk;
     return CS_OK;
+}
+
+int cs_detect_foci_batch(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
+                         const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci, int64_t cap,
+                         int64_t* h_n_foci, double* h_windows)
+{
+    return cs_detect_foci_batch_templates(ctx, stream_, n_blocks, signals, 1, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
 }
 
 // 2-D patterns (loops, stripes: a band of scanned diagonals) of MANY sub-matrices with one launch chain: the masked

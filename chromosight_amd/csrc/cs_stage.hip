@@ -163,7 +163,24 @@ __global__ __launch_bounds__(64 * kFinishPhases) void stage_finish_kernel(const 
     double s = 0.0;
     unsigned long long c = 0;
     if (d < B.n_diags) {
-        for (int g = B.group0 + ph; g < B.group0 + B.n_groups; g += kFinishPhases) {
+        // eight groups' partials requested together (the order of the additions stays the one of the plain loop)
+        const int g_end = B.group0 + B.n_groups;
+        int g = B.group0 + ph;
+        for (; g + 7 * kFinishPhases < g_end; g += 8 * kFinishPhases) {
+            double ps[8];
+            unsigned pc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ps[u] = part_sum[(size_t)(g + u * kFinishPhases) * pitch + d];
+                pc[u] = part_cnt[(size_t)(g + u * kFinishPhases) * pitch + d];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s += ps[u];
+                c += pc[u];
+            }
+        }
+        for (; g < g_end; g += kFinishPhases) {
             s += part_sum[(size_t)g * pitch + d];
             c += part_cnt[(size_t)g * pitch + d];
         }

@@ -131,6 +131,28 @@ def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist
 # the reference's zeroing thresholds; the exact values are then thresholded.  The candidate set is a superset of the pixels
 # whose exact coefficient passes whatever the data look like (tests/test_gpu_margin.py).
 RESCORE_MARGIN = 0.05
+
+
+def map_pitch(width, itemsize=4, quantum=16):
+    """Row pitch (elements) for a device-resident dense map of `width` columns: rounded up to `quantum`, and never a multiple
+    of 2 KiB -- with a power-of-two pitch the same column of every row lies on the same HBM channels, and a tile's 64 rows x
+    256 bytes of stores (or the 80 rows a tile stages) all land on those few channels: the dense matrix-core kernel's stores
+    cost 15 us of a 105 us call at pitch 4096 floats and 5 us at 4160.  CsMatrix.ld carries the pitch."""
+    ld = (int(width) + quantum - 1) // quantum * quantum
+    if (ld * itemsize) % 2048 == 0:
+        ld += 64
+    return ld
+
+
+def to_device_map(dev, array, stream=None):
+    """Upload a dense 2-D host array with the pitch of map_pitch: (DeviceBuffer, ld)."""
+    array = np.asarray(array)
+    ld = map_pitch(array.shape[1], array.dtype.itemsize)
+    if ld == array.shape[1]:
+        return dev.to_device(array, stream=stream), ld
+    padded = np.zeros((array.shape[0], ld), dtype=array.dtype)
+    padded[:, :array.shape[1]] = array
+    return dev.to_device(padded, stream=stream), ld
 # below this threshold most pixels of a float32 map would be candidates: such maps are computed in float64
 LOW_PEARSON_F64 = 0.1
 
@@ -226,20 +248,32 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
                           missing_tol=0.75, want_windows=True, min_size=2, stream=None, flat=False):
     """detect mode of a 1-D pattern (<= 4 scanned diagonals) on MANY banded sub-matrices with one native call
     (cs_detect_foci_batch).  Returns a list of (records, windows) per sub-matrix, or None when the library
-    says a block does not qualify (the caller then goes block by block)."""
+    says a block does not qualify (the caller then goes block by block).  kspec may be a list of up to 4 templates of one
+    size (cs_detect_foci_batch_templates; flat=True only): the records then come template by template, counts[t * n + b]."""
+    kspecs = list(kspec) if isinstance(kspec, (list, tuple)) else None
+    if kspecs is not None:
+        if not flat or not 1 <= len(kspecs) <= 4 or any((k.km, k.kn) != (kspecs[0].km, kspecs[0].kn) for k in kspecs):
+            return None
+        kspec = kspecs[0]
+    n_templates = len(kspecs) if kspecs is not None else 1
     n_blocks = len(sigs)
     sig_arr, _, par_arr = _block_arrays(dev, sigs, None, shapes, kspec, max_dists, miss_rows, miss_cols, missing_tol, CS_F64, True)
     fp_arr = (CsFociParams * n_blocks)(*[
         CsFociParams(float(pearson), rescore_margin(pearson), int(min_size), int(bool(diag_only)), 0, int(hi_diags[b]), int(bool(inter)),
                      int(bool(want_windows))) for b in range(n_blocks)])
-    counts = (C.c_int64 * n_blocks)()
+    counts = (C.c_int64 * (n_blocks * n_templates))()
     kk = kspec.km * kspec.kn
-    cap = 4096
+    cap = 4096 * n_templates
+    k_arr = (_lib.CsKernel * n_templates)(*[k.struct for k in kspecs]) if kspecs is not None else None
     while True:
         rec, win = _host_buffers(dev, cap, kk, want_windows)
         cap = rec.shape[0]
-        rc = dev.lib.cs_detect_foci_batch(dev.ctx, stream, n_blocks, sig_arr, C.byref(kspec.struct), par_arr, fp_arr,
-                                          rec.ctypes.data, cap, counts, win.ctypes.data if want_windows else None)
+        if kspecs is not None:
+            rc = dev.lib.cs_detect_foci_batch_templates(dev.ctx, stream, n_blocks, sig_arr, n_templates, k_arr, par_arr, fp_arr,
+                                                        rec.ctypes.data, cap, counts, win.ctypes.data if want_windows else None)
+        else:
+            rc = dev.lib.cs_detect_foci_batch(dev.ctx, stream, n_blocks, sig_arr, C.byref(kspec.struct), par_arr, fp_arr,
+                                              rec.ctypes.data, cap, counts, win.ctypes.data if want_windows else None)
         if rc == -3:
             return None
         if rc == -4 and sum(counts) > cap:

@@ -460,6 +460,21 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     overlap = (batch is not None and stage_default and kernel_config["max_iterations"] == 1 and len(kernels) > 1 and bool(mine)
                and hasattr(genome, "workers") and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_OVERLAP"))
     futures = []
+    joint = None
+    if overlap and kernel_config["max_dist"] == 0 and tsvd is None and not todo and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_BATCH"):
+        # a 1-D pattern's templates share one launch chain (cs_detect_foci_batch_templates): on a worker context, so that the
+        # chain runs beside whatever this genome's own stream is doing (another pattern's tile kernels)
+        pool = genome.workers(1)
+        ready = getattr(staged_in, "ready", None)
+        if ready is None:
+            genome.dev.sync()
+        dev, stream = pool.device()
+        if ready is not None:
+            dev.wait_event(ready, stream)
+        joint = pipeline.detect_blocks_templates(genome, [staged[ci] for ci in mine], kernel_config, kernels, dev=dev, stream=stream)
+        if joint is not None:
+            joint = joint()                                  # the acceptance rules, here
+            overlap = False
     if overlap:
         pool = genome.workers(min(len(kernels), 3))
         ready = getattr(staged_in, "ready", None) if not todo else None
@@ -479,7 +494,9 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
             rows, wins = [], []
             # the windows only feed the pileup of the next iteration: the last one does not fetch them
             need_windows = it + 1 < kernel_config["max_iterations"]
-            if overlap:
+            if joint is not None:
+                results = joint[kernel_id]
+            elif overlap:
                 # the acceptance rules (many small numpy calls) here, one template after the other: spread over the worker
                 # threads they fight for the interpreter lock and each takes four times as long
                 results = futures[kernel_id].result()()

@@ -248,7 +248,8 @@ class _Workers:
         dev = getattr(self.local, "dev", None)
         if dev is None:
             dev = self.local.dev = self.device_cls(self.index)
-            self.local.stream = dev.new_stream()
+            # worker streams carry the short launch chains that run beside another pattern's tile kernels: served first
+            self.local.stream = dev.new_stream(high_priority=not os.environ.get("CHROMOSIGHT_HIP_NO_PRIORITY"))
             self.local.scratch = _Scratch(dev)
         return dev, self.local.stream
 
@@ -732,6 +733,24 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
     rec = np.concatenate([r[0] for r in results])
     windows = np.concatenate([r[1] for r in results]) if want_windows else None
     return done(cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config))
+
+
+def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=False, dev=None, stream=None):
+    """A 1-D pattern's templates (one size, e.g. the three borders templates) on banded intra blocks with ONE native call
+    (cs_detect_foci_batch_templates) instead of one launch chain per template.  Returns a callable that yields, per template,
+    the merged result of detect_blocks (table of all blocks, accepted records per block, windows) -- the native call is done
+    when this returns, the acceptance rules run in the callable -- or None when the entry does not apply."""
+    kernels = [np.asarray(k, dtype=np.float64) for k in kernels]
+    if kernel_config["max_dist"] != 0 or len(kernels) < 2 or len(kernels) > 4 or len(blocks) < 1:
+        return None
+    if any(k.shape != kernels[0].shape or k.shape[0] != k.shape[1] for k in kernels):
+        return None
+    if not all(b_is_band(b) and min(b.shape) > max(kernels[0].shape) for b in blocks):
+        return None
+    for k in kernels:
+        _check_template(k)
+    return cid.detect_many_on_device(dev or dcool.dev, blocks, [engine.KernelSpec(k) for k in kernels], kernel_config,
+                                     want_windows=want_windows, raw=True, stream=stream, defer=True, merged=True)
 
 
 def sub_matrices(dcool, inter):

@@ -643,12 +643,39 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     sub-matrices at once: `blocks` = objects with sig, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).
     One native call (cs_detect_foci_batch) instead of one launch chain and synchronisation per sub-matrix.
     Returns the list of (table, windows) detect_on_device would return, or None if the batch entry does not
-    apply (caller falls back to one call per block)."""
+    apply (caller falls back to one call per block).  kspec = a list of templates of one size (raw=True): all of them in
+    the same launch chain (cs_detect_foci_batch_templates); the result is then a list over the templates."""
+    templates = list(kspec) if isinstance(kspec, (list, tuple)) else None      # several templates of one size: ONE launch chain
+    if templates is not None:
+        if not raw or not templates:
+            return None
+        kspec = templates[0]
     if kernel_config["max_dist"] != 0 or not blocks or kspec.km != kspec.kn:
         return None
     if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None for b in blocks):
         return None
     missing_tol = kernel_config["max_perc_undetected"] / 100
+    if templates is not None:
+        res = engine.run_detect_foci_batch(
+            dev, [b.sig for b in blocks], [b.shape for b in blocks], templates, pearson=kernel_config["pearson"],
+            hi_diags=[b.max_dist for b in blocks], inter=False, diag_only=True, max_dists=[b.max_dist for b in blocks],
+            miss_rows=[b.miss_row for b in blocks], miss_cols=[b.miss_col for b in blocks], missing_tol=missing_tol,
+            want_windows=want_windows, stream=stream, flat=True)
+        if res is None:
+            return None
+        rec, windows, counts = res
+        n = len(blocks)
+        ends = np.concatenate([[0], np.cumsum(counts)])
+
+        def per_template():
+            out = []
+            for t in range(len(templates)):
+                a, z = int(ends[t * n]), int(ends[(t + 1) * n])
+                out.append(accept_many(blocks, rec[a:z], windows[a:z] if windows is not None else None, counts[t * n:(t + 1) * n],
+                                       templates[t], kernel_config, merged=merged))
+            return out
+
+        return per_template if defer else per_template()
     res = engine.run_detect_foci_batch(
         dev, [b.sig for b in blocks], [b.shape for b in blocks], kspec, pearson=kernel_config["pearson"],
         hi_diags=[b.max_dist for b in blocks], inter=False, diag_only=True, max_dists=[b.max_dist for b in blocks],

@@ -78,6 +78,9 @@ int cs_memset(cs_ctx* ctx, void* d_dst, int value, size_t bytes, void* stream);
 int cs_stream_sync(cs_ctx* ctx, void* stream);
 /* streams and events (hipStream_t / hipEvent_t as void*), for callers without a HIP binding */
 int cs_stream_create(cs_ctx* ctx, void** stream);
+/* high = 1: a stream whose kernels are dispatched ahead of those of ordinary streams (short latency-bound launch chains --
+ * labelling, statistics of a 1-D pattern -- beside persistent tile kernels that would otherwise hold every slot) */
+int cs_stream_create_priority(cs_ctx* ctx, int32_t high, void** stream);
 int cs_stream_destroy(cs_ctx* ctx, void* stream);
 int cs_event_create(cs_ctx* ctx, void** event);
 int cs_event_destroy(cs_ctx* ctx, void* event);
@@ -322,6 +325,14 @@ int cs_detect_foci(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_
 int cs_detect_foci_batch(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
                          const cs_normxcorr2_params* params, const cs_foci_params* foci, cs_focus* h_foci, int64_t cap,
                          int64_t* h_n_foci, double* h_windows);
+
+/* cs_detect_foci_batch for SEVERAL templates of one size (n_kernels <= 4: the three borders templates of the reference's
+ * borders.json) in the same launch chain: sub-matrix b under template t is handled like block t * n_blocks + b of a
+ * batch -- records and windows template by template, h_n_foci[t * n_blocks + b].  What it replaces: one launch chain and
+ * one synchronisation per template (reference: the loop over kernels in cli/chromosight.py:731). */
+int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, int32_t n_kernels,
+                                   const cs_kernel* kernels, const cs_normxcorr2_params* params, const cs_foci_params* foci,
+                                   cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows);
 
 /* The same for ANY pattern: blocks whose scan is a band of diagonals (loops, stripes) run the masked matrix-core tile
  * kernel in candidate mode -- every block's kernel appends its candidate pixels to one list -- followed by one sort, one

@@ -32,17 +32,25 @@ def check(got, want, cond, what):
     return assert_parity(got, want, cond, "f32", what, max_ill_frac=1e-4)
 
 
-def test_c2_dense_4096_full_map():
-    """C2 as benched: dense 4096^2 float32 gamma(4, 0.25) seed 0, loops 17x17, full=False, no mask."""
+@pytest.mark.parametrize("pitch", ["engine", "tight"])
+def test_c2_dense_4096_full_map(pitch):
+    """C2 as benched: dense 4096^2 float32 gamma(4, 0.25) seed 0, loops 17x17, full=False, no mask -- device maps with the
+    engine's row pitch (4160 elements: what bench.py times) and with rows packed tight (4096)."""
     dev = get_device()
     n = 4096
     sig = np.random.default_rng(0).gamma(4.0, 0.25, size=(n, n)).astype(np.float32)
-    d_sig, d_out = dev.to_device(sig), dev.empty((n, n), np.float32)
-    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0), (n, n),
+    if pitch == "engine":
+        d_sig, ld_in = engine.to_device_map(dev, sig)
+        ld_out = engine.map_pitch(n, 4)
+        assert ld_in == ld_out == 4160
+    else:
+        d_sig, ld_in, ld_out = dev.to_device(sig), n, n
+    d_out = dev.empty((n, ld_out), np.float32)
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, ld_in, 0, 0), (n, n),
                           engine.KernelSpec(loops()),
-                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, n, 0, 0),
+                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, ld_out, 0, 0),
                           full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE, precision="f32")
-    got = d_out.download()
+    got = d_out.download()[:, :n]
     assert last_kernel() == KERNEL_MFMA_DENSE            # the kernel bench.py times on this workload
     want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), loops(), 0, n, full=False)
     check(got, want, cond, "C2 4096x4096")

@@ -2114,9 +2114,13 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         const int n_lanes = (twins && n_blocks > 1) ? std::min(std::min(std::max(lanes_env, 1), kBlkLanes), n_blocks) : 1;
         // one persistent launch for the tiles of all blocks (the lanes then only carry the blocks' mask tables)
         static const char* table_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_TABLE");      // "0" / "1": force
-        const bool table = n_lanes > 1 && (table_env ? table_env[0] == '1' : foci[0].exclusive != 0);
+        const bool table = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE") && (table_env ? table_env[0] == '1' : foci[0].exclusive != 0);
+        // either way the blocks' launches are PREPARED first (mask tables of every block on the lanes, argument blocks in a host
+        // table) and the tile kernels go out afterwards: a mask-table launch queued behind persistent tile kernels would wait
+        // for their workgroups to drain, and its lane's next tile kernel with it
+        const bool prepared = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE");
         int table_rsym = -1;
-        if (table) {
+        if (prepared) {
             const size_t need = cs::mfma_blocks_table_bytes(n_blocks);
             if (need > ctx->tab_bytes) {
                 CS_HIP(ctx, hipDeviceSynchronize());
@@ -2193,7 +2197,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                     std::swap(c->d_ws, c->ws_alt[k]);
                     std::swap(c->d_ws_bytes, c->ws_alt_bytes[k]);
                 }
-            } ws_swap(ctx, table ? -1 : lane - 1);
+            } ws_swap(ctx, prepared ? -1 : lane - 1);
             struct TabSwap {                  // table mode: every block keeps its own mask tables until the one launch is done
                 cs_ctx* c;
                 int b;
@@ -2205,7 +2209,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                     std::swap(c->d_ws, c->ws_tab[(size_t)b]);
                     std::swap(c->d_ws_bytes, c->ws_tab_bytes[(size_t)b]);
                 }
-            } tab_swap(ctx, table ? b : -1);
+            } tab_swap(ctx, prepared ? b : -1);
             const cs_matrix* sig = (signals_f32 && signals_f32[b].d_ptr) ? signals_f32 + b : signals + b;
             cs_matrix map;                        // geometry of the (virtual) coefficient map: the scanned diagonals
             map.d_ptr = nullptr;
@@ -2223,12 +2227,12 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             CandSink sink{(unsigned long long*)pool, d_cnt, (long long)c_cap, (unsigned long long)b << kKeyShift, foci[b].lo_diag,
                           foci[b].hi_diag};
             int rsym = 0;
-            if (table) {
+            if (prepared) {
                 sink.defer_args = (char*)ctx->h_tab + cs::mfma_blocks_arg_offset(n_blocks) + (size_t)b * cs::mfma_blocks_arg_bytes();
                 sink.defer_rsym = &rsym;
             }
             rc = corr_candidates_f32(ctx, stream, sig, kernel, params + b, &map, margin, thr, &sink);
-            if (!rc && table) {
+            if (!rc && prepared) {
                 if (!ctx->cand_fused) rc = CS_NEED_MAP;             // another kernel than the masked tile kernel took the block
                 else if (table_rsym >= 0 && table_rsym != rsym) rc = fail(ctx, CS_ERR_UNSUPPORTED, "blocks need different tile kernels");
                 table_rsym = rsym;
@@ -2237,6 +2241,18 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 if (n_lanes > 1) (void)hipDeviceSynchronize();      // nothing of this call may still be running on a side stream
                 if (rc == CS_NEED_MAP) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is not served by the masked tile kernel", b);
                 return rc;
+            }
+        }
+        if (prepared && !table) {
+            // one persistent launch per block, each on the lane that built its mask tables
+            for (int b : launch_order) {
+                hipStream_t s_lane = lane_of[b] == 0 ? stream : ctx->s_blk[lane_of[b] - 1];
+                const void* arg = (const char*)ctx->h_tab + cs::mfma_blocks_arg_offset(n_blocks) + (size_t)b * cs::mfma_blocks_arg_bytes();
+                rc = cs::launch_corr_mfma_prepared(arg, table_rsym, ctx->n_cu, ctx->grid_cap, s_lane);
+                if (rc) {
+                    (void)hipDeviceSynchronize();
+                    return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+                }
             }
         }
         if (n_lanes > 1) {

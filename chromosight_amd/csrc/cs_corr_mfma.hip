@@ -781,6 +781,22 @@ size_t mfma_blocks_arg_bytes() { return sizeof(MfmaDenseArgs); }
 size_t mfma_blocks_arg_offset(int n_blocks) { return ((size_t)(n_blocks + 1) * sizeof(int) + 255) & ~(size_t)255; }
 size_t mfma_blocks_table_bytes(int n_blocks) { return mfma_blocks_arg_offset(n_blocks) + (size_t)n_blocks * sizeof(MfmaDenseArgs); }
 
+int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_cap, hipStream_t stream)
+{
+    MfmaDenseArgs D;
+    std::memcpy(&D, h_arg, sizeof(D));
+    if (D.n_tiles <= 0) return 0;
+    typedef void (*reg_kernel_t)(const MfmaDenseArgs);
+    const reg_kernel_t kr = rsym ? corr_mfma_dense_kernel<true, true, true, true> : corr_mfma_dense_kernel<true, true, false, true>;
+    hipError_t e = allow_big_lds((const void*)kr);
+    if (e != hipSuccess) return (int)e;
+    const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+    int grid = (int)std::min<long long>(D.n_tiles, (long long)per_cu * n_cu);
+    if (grid_cap > 0 && grid > grid_cap) grid = std::max(8, grid_cap & ~7);
+    hipLaunchKernelGGL(kr, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG, stream, D);
+    return (int)hipGetLastError();
+}
+
 int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t stream)
 {
     if (n_blocks <= 0) return 0;

@@ -342,6 +342,37 @@ def test_batched_1d_patterns_equal_per_block_calls():
             assert total > 50, (name, total)
 
 
+def test_templates_of_a_1d_pattern_in_one_chain_equal_one_chain_each():
+    """cs_detect_foci_batch_templates (the three borders templates as virtual blocks of one launch chain, with and without
+    windows) == cs_detect_foci_batch template by template: same records in the same order, same windows."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(30_000, 300, 2000, seed=13, template=template, chrom_sizes=[9000, 700, 6000, 14300])
+    dcool = pipeline.DeviceCool(cool)
+    cfg = copy.deepcopy(ck.borders)
+    kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+    blocks = [dcool.stage_intra(ci, 1, 17, resident=True) for ci in range(dcool.n_chrom)]
+    for want in (True, False):
+        joint = pipeline.detect_blocks_templates(dcool, blocks, cfg, kernels, want_windows=want)
+        assert joint is not None
+        joint = joint()
+        assert len(joint) == len(kernels)
+        total = 0
+        for kernel, (table, kept, windows) in zip(kernels, joint):
+            one = pipeline.detect_blocks(dcool, blocks, cfg, kernel, raw=True, want_windows=want, merged=True)
+            assert isinstance(one, tuple)
+            assert np.array_equal(kept, one[1]) and np.array_equal(table[:, :2], one[0][:, :2])
+            assert np.allclose(table[:, 2:], one[0][:, 2:], rtol=0, atol=1e-12, equal_nan=True)
+            if want:
+                assert np.allclose(windows, one[2], rtol=0, atol=0, equal_nan=True)
+            else:
+                assert windows is None and one[2] is None
+            total += len(table)
+        assert total > 100
+    # templates of different sizes, or a 2-D pattern: the entry does not apply
+    assert pipeline.detect_blocks_templates(dcool, blocks, cfg, [kernels[0], kernels[1][:15, :15]]) is None
+    assert pipeline.detect_blocks_templates(dcool, blocks, ck.loops, kernels) is None
+
+
 def test_run_scoring_of_1d_patterns_equals_wave_per_pixel(monkeypatch):
     """The float64 scoring of the enumerated diagonals one lane per pixel from an LDS tile
     (rescore_run_batch_kernel; the direct route for workgroups that straddle two sub-matrices) against the

@@ -66,7 +66,7 @@ done
 # 4. FETCH_SIZE calibration on a known byte count with the kernel's own load pattern, and the
 #    micro-benchmarks behind two design decisions (FMA forms; MFMA beside packed FMAs)
 mkdir -p tools/ubench/build
-for u in fetch_calib coexec fma_rate; do
+for u in fetch_calib coexec fma_rate write_rate; do
   [ -x tools/ubench/build/$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/build/$u 2>/dev/null
 done
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/calib" -o calib -- \
@@ -75,4 +75,5 @@ python tools/time_templates.py c3 > "$out/template_kernels.txt" 2>/dev/null
 python tools/time_templates.py c4p >> "$out/template_kernels.txt" 2>/dev/null
 tools/ubench/build/coexec > "$out/ubench_coexec.txt" 2>&1
 tools/ubench/build/fma_rate > "$out/ubench_fma_rate.txt" 2>&1
+tools/ubench/build/write_rate > "$out/ubench_write_rate.txt" 2>&1
 ls "$out" | head -80

@@ -37,7 +37,7 @@ for w in ("c2", "c3", "c3k", "c4p", "c4"):
 f = os.path.join(src, "template_kernels.txt")
 if os.path.exists(f) and os.path.getsize(f):
     shutil.copy(f, os.path.join(dst, f"{tag}_template_kernels.txt"))
-for u in ("coexec", "fma_rate"):
+for u in ("coexec", "fma_rate", "write_rate"):
     f = os.path.join(src, f"ubench_{u}.txt")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_ubench_{u}.txt"))

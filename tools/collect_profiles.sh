@@ -19,7 +19,7 @@ bench > "$out/bench_c2.json"
 bench --workload c3 --no-cpu-baseline > "$out/bench_c3.json"
 bench --workload c3k --no-cpu-baseline > "$out/bench_c3k.json"
 bench --workload c4p --no-cpu-baseline > "$out/bench_c4p.json"
-bench --workload c4 --steps 5 --warmup 1 > "$out/bench_c4.json"
+bench --workload c4 --steps 40 --warmup 8 > "$out/bench_c4.json"
 bench --workload c5 --steps 10 --warmup 2 > "$out/bench_c5.json"
 bench --size 16384 --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_dense16384.json"
 bench --precision f64 --no-cpu-baseline > "$out/bench_c2_f64.json"

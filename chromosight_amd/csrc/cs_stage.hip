@@ -224,8 +224,11 @@ __device__ __forceinline__ void stage_wave_sync()
 // also waits for the previous row's stores.  (Tried: builder waves that only load and assemble + writer waves that only
 // store, a workgroup barrier per piece -- 1.27 ms against 0.95 for the 23-block genome; the stores alone take 0.39 ms,
 // tools/ubench/write_rate.hip.)
+#ifndef CS_STAGE_TILE_WAVES
+#define CS_STAGE_TILE_WAVES 4
+#endif
 template <typename TV, int kStageUnroll>
-__global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+__global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                                           const TV* __restrict__ data, const double* __restrict__ weight,
                                                                           const StageBlock* __restrict__ blocks,
                                                                           const StageGroup* __restrict__ groups, int n_groups, int pitch,
@@ -258,13 +261,17 @@ __global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long lo
         int cn[kStageUnroll];
         TV xn[kStageUnroll];
         auto request = [&](int i) {
-            const long long b = __shfl(my_b, i), e = __shfl(my_e, i);
+            // (a uniform base pointer + a 32-bit lane offset per load: no 64-bit address per load in registers)
+            const long long b = __shfl(my_b, i);
+            const int n = (int)(__shfl(my_e, i) - b);
+            const int* ip = indices + b;
+            const TV* dp = data + b;
 #pragma unroll
             for (int u = 0; u < kStageUnroll; ++u) {
-                const long long k = b + lane + 64 * u;
-                const bool ok = k < e;
-                cn[u] = ok ? indices[k] : 0x7fffffff;
-                xn[u] = ok ? data[k] : (TV)0;
+                const int off = lane + 64 * u;
+                const bool ok = off < n;
+                cn[u] = ok ? ip[off] : 0x7fffffff;
+                xn[u] = ok ? dp[off] : (TV)0;
             }
         };
         if (n_mine > 0) request(0);
@@ -281,14 +288,19 @@ __global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long lo
             const long long x0 = B.dense ? B.row0 : r;
             double v[kStageUnroll];
             int slot[kStageUnroll];
+            const int c_r = (int)(r - r0), c_x0 = (int)(x0 - r0);        // columns relative to the group's first row: 32-bit
+            const int c_base = (int)r0;                                  // (pixel tables of fewer than 2^31 bins: the indices are int32)
 #pragma unroll
             for (int u = 0; u < kStageUnroll; ++u) {
+                __builtin_amdgcn_sched_barrier(0);                       // one division at a time: they would all be in flight
                 const bool ok = cn[u] != 0x7fffffff;
-                const int d = ok ? (int)((long long)cn[u] - r) : 0;
-                const double wc = ok ? l_w[(int)((long long)cn[u] - r0)] : 0.0;
-                v[u] = stage_detrend(((double)xn[u] * wr) * wc, d < B.n_diags ? l_law[d] : 0.0, max_val);
-                slot[u] = ok ? (int)((long long)cn[u] - x0) : -1;
+                const int rel = ok ? cn[u] - c_base : 0;                 // column - r0
+                const int d = rel - c_r;
+                const double wc = ok ? l_w[rel] : 0.0;
+                v[u] = stage_detrend(((double)xn[u] * wr) * wc, (ok && d < B.n_diags) ? l_law[d] : 0.0, max_val);
+                slot[u] = ok ? rel - c_x0 : -1;
             }
+            __builtin_amdgcn_sched_barrier(0);
             const bool fits = e - b <= 64 * kStageUnroll;
             if (i + 1 < n_mine) request(i + 1);
             long long k_next = b;
@@ -303,34 +315,37 @@ __global__ __launch_bounds__(kStageThreads) void stage_tile_kernel(const long lo
                 } else {
                     const long long c_end = x0 + s1;
                     int placed = 0;
-                    for (long long k0 = k_next + lane; k0 - lane < e; k0 += 64 * kStageUnroll) {
-                        long long c[kStageUnroll];
-                        double x[kStageUnroll];
+                    constexpr int kSlow = 2;                            // (this path keeps few registers: it bounds the kernel's)
+                    for (long long k0 = k_next + lane; k0 - lane < e; k0 += 64 * kSlow) {
+                        int c[kSlow];
+                        TV x[kSlow];
 #pragma unroll
-                        for (int u = 0; u < kStageUnroll; ++u) {
+                        for (int u = 0; u < kSlow; ++u) {
                             const long long k = k0 + 64 * u;
                             const bool ok = k < e;
-                            c[u] = ok ? (long long)indices[k] : (long long)(1ll << 40);
-                            x[u] = ok ? (double)data[k] : 0.0;
+                            c[u] = ok ? indices[k] : 0x7fffffff;
+                            x[u] = ok ? data[k] : (TV)0;
                         }
                         bool more = true;
 #pragma unroll
-                        for (int u = 0; u < kStageUnroll; ++u) {
-                            const bool in = c[u] < c_end;
+                        for (int u = 0; u < kSlow; ++u) {
+                            const bool in = (long long)c[u] < c_end;
                             const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
                             placed += __builtin_popcountll(m);
                             if (in) {
-                                const int d = (int)(c[u] - r);
-                                l_row[(int)(c[u] - x0) - s0] =
-                                    stage_detrend((x[u] * wr) * l_w[(int)(c[u] - r0)], d < B.n_diags ? l_law[d] : 0.0, max_val);
+                                const int rel = c[u] - c_base;
+                                const int d = rel - c_r;
+                                l_row[rel - c_x0 - s0] = stage_detrend(((double)x[u] * wr) * l_w[rel], d < B.n_diags ? l_law[d] : 0.0, max_val);
                             }
-                            more = more && (m == ~0ull);
+                            more = more && (m == ~0ull);                // a lane beyond the piece (or the row): this piece is complete
                         }
                         if (!more) break;
                     }
                     k_next += placed;
                 }
                 stage_wave_sync();
+                // (one read of the piece serving both copies -- 4 slots per lane, float64 stores 32 bytes apart -- was slower:
+                // 1.12 against 0.95 ms for the genome; a store instruction should cover one dense kilobyte)
                 if (out64)
                     for (int x = 2 * lane; x < s1 - s0; x += 128) *reinterpret_cast<d2*>(out64 + s0 + x) = *reinterpret_cast<const d2*>(l_row + x);
                 if (out32)

@@ -15,6 +15,7 @@ exchange is the final gather of the per-block pattern tables (a few MB at most).
 list lazily through `loader`), processes its own share and receives the gathered result.
 """
 import os
+import sys
 
 import numpy as np
 
@@ -111,9 +112,39 @@ def native_comm():
     key = (rank, world)
     if key not in _COMMS:
         import torch
-        box = [NativeComm.unique_id() if rank == 0 else None]
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def all_ok(ok):
+            # every rank takes the same branch: a rank that could not load or create its communicator must not leave the
+            # others inside a collective of the library
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        # 1. local: the library and the RCCL of its HIP runtime load on this rank (every rank makes an id; rank 0's is used)
+        try:
+            my_id, err = NativeComm.unique_id(), None
+        except Exception as exc:                              # noqa: BLE001 -- whatever it is, the torch path remains
+            my_id, err = None, exc
+        if not all_ok(err is None):
+            _COMMS[key] = None
+            if err is not None:
+                sys.stderr.write(f"[chromosight_amd] rank {rank}: native RCCL exchange unavailable ({err}); torch.distributed instead\n")
+            return None
+        box = [my_id if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        _COMMS[key] = NativeComm(torch.cuda.current_device(), rank, world, box[0])
+        # 2. collective: ncclCommInitRank on every rank
+        try:
+            comm, err = NativeComm(torch.cuda.current_device(), rank, world, box[0]), None
+        except Exception as exc:                              # noqa: BLE001
+            comm, err = None, exc
+        if not all_ok(err is None):
+            if comm is not None:
+                comm.close()
+            comm = None
+            if err is not None:
+                sys.stderr.write(f"[chromosight_amd] rank {rank}: RCCL communicator not created ({err}); torch.distributed instead\n")
+        _COMMS[key] = comm
     return _COMMS[key]
 
 

@@ -700,18 +700,23 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
         # 1-D patterns, tables as DataFrames: the same batch, accepted block by block
         live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
         banded = [k for k in live if b_is_band(blocks[k])]
-        res = cid.detect_many_on_device(dcool.dev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
-                                        raw=raw, want_windows=want_windows) if len(banded) > 1 else None
+        # (on the caller's context and stream: several host threads may be scanning templates side by side)
+        res = cid.detect_many_on_device(bdev, [blocks[k] for k in banded], engine.KernelSpec(kernel, tsvd), kernel_config,
+                                        raw=raw, want_windows=want_windows, stream=stream) if len(banded) > 1 else None
         if res is not None:
             out = [(None, None)] * len(blocks)
             for k, r in zip(banded, res):
                 out[k] = r
             for k in live:
                 if k not in banded:
-                    out[k] = detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows)
+                    out[k] = detect_block(dcool, blocks[k], kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows,
+                                          dev=dev, stream=stream)
             return done(out)
-    if workers <= 1 or len(blocks) <= 1:
-        return done([detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows) for b in blocks])
+    if workers <= 1 or len(blocks) <= 1 or dev is not None:
+        # (a caller that brought its own context and stream -- a template scanned beside others -- keeps every call on them:
+        # that stream is the one that waited for the staging of the blocks)
+        return done([detect_block(dcool, b, kernel_config, kernel, tsvd=tsvd, raw=raw, want_windows=want_windows, dev=dev, stream=stream)
+                     for b in blocks])
     dcool.dev.sync()
     pool = dcool.workers(workers)
 

@@ -373,6 +373,23 @@ def test_templates_of_a_1d_pattern_in_one_chain_equal_one_chain_each():
     assert pipeline.detect_blocks_templates(dcool, blocks, ck.loops, kernels) is None
 
 
+def test_templates_scanned_side_by_side_keep_to_their_own_context(monkeypatch):
+    """Truncated-SVD templates do not take the batched entries: the three borders templates are then scanned by three host
+    threads, each on its own context and stream (they once shared the genome's context on that path: wrong tables).  Same
+    records as one template after the other."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(30_000, 300, 2000, seed=17, template=template, chrom_sizes=[9000, 700, 6000, 14300])
+    dcool = pipeline.DeviceCool(cool)
+    cfg = copy.deepcopy(ck.borders)
+    for _ in range(3):
+        side_by_side = parallel.detect_genome(dcool, cfg, tsvd=0.999)
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_TEMPLATE_OVERLAP", "1")
+    in_turn = parallel.detect_genome(dcool, cfg, tsvd=0.999)
+    assert side_by_side.shape == in_turn.shape and side_by_side.shape[0] > 100
+    assert np.array_equal(side_by_side[:, [0, 1, 2, 5, 6]], in_turn[:, [0, 1, 2, 5, 6]])
+    assert np.abs(side_by_side[:, 3] - in_turn[:, 3]).max() < 1e-12
+
+
 def test_run_scoring_of_1d_patterns_equals_wave_per_pixel(monkeypatch):
     """The float64 scoring of the enumerated diagonals one lane per pixel from an LDS tile
     (rescore_run_batch_kernel; the direct route for workgroups that straddle two sub-matrices) against the

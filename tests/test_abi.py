@@ -44,4 +44,26 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.CsNormxcorr2Params) == 80
     assert ctypes.sizeof(_lib.CsCsr) == 72
     assert ctypes.sizeof(_lib.CsFociParams) == 48
+    assert ctypes.sizeof(_lib.CsStageBlock) == 56
     assert ctypes.sizeof(_lib.CsFocus) == 40 == _lib.FOCUS_DTYPE.itemsize
+
+
+def test_struct_sizes_against_the_header_compiled_as_c(tmp_path):
+    """include/chromosight_hip.h compiles as plain C, and every struct the ctypes binding mirrors has the size the C
+    compiler gives it (a field added on one side only would shift everything behind it)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = [("cs_matrix", _lib.CsMatrix), ("cs_kernel", _lib.CsKernel), ("cs_normxcorr2_params", _lib.CsNormxcorr2Params),
+             ("cs_csr", _lib.CsCsr), ("cs_foci_params", _lib.CsFociParams), ("cs_focus", _lib.CsFocus),
+             ("cs_stage_block", _lib.CsStageBlock)]
+    header = ROOT / "include" / "chromosight_hip.h"
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void) {\n%s    return 0;\n}\n' % (
+        header, "".join(f'    printf("%zu\\n", sizeof({name}));\n' for name, _ in pairs)))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    for (name, struct), size in zip(pairs, sizes):
+        assert ctypes.sizeof(struct) == size, name

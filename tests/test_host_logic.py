@@ -465,3 +465,30 @@ def test_native_acceptance_rules_equal_the_numpy_ones():
             assert np.allclose(got[:, 3], want[:, 3], rtol=1e-12, atol=1e-300, equal_nan=True)   # libm vs scipy's erfc
     got, ok, kept = cid.accept_native(rec[:0], np.zeros(0, np.int64), [], [], kspec, cfg, inter=False, full=True, compact=True)
     assert got.shape == (0, 4) and ok.size == 0 and kept.size == 0
+
+
+def test_map_pitch_never_lands_on_a_power_of_two_stride():
+    """engine.map_pitch: the row pitch the engine gives device-resident dense maps (bench.py C2)."""
+    from chromosight_amd import engine
+    assert engine.map_pitch(4096, 4) == 4160 and engine.map_pitch(4096, 8) == 4160
+    assert engine.map_pitch(4000, 4) == 4000 and engine.map_pitch(4001, 4) == 4016
+    assert engine.map_pitch(512, 4) == 576 and engine.map_pitch(500, 4) == 576 and engine.map_pitch(500, 8) == 576
+    for width in (1, 17, 255, 256, 1000, 1024, 8192, 16384, 50_000):
+        for itemsize in (4, 8):
+            ld = engine.map_pitch(width, itemsize)
+            assert ld >= width and ld % 16 == 0 and (ld * itemsize) % 2048 != 0 and ld - width < 16 + 64
+
+
+def test_accept_records_rejects_bad_arguments():
+    import types
+    from chromosight_amd._lib import FOCUS_DTYPE, load_library
+    lib = load_library()
+    rec = np.zeros(4, FOCUS_DTYPE)
+    counts = np.array([5], dtype=np.int64)            # more records than the buffer holds is the caller's business; negative is not
+    geo = np.array([10, 10, 3], dtype=np.int32)
+    table, ok, kept = np.zeros((4, 4)), np.zeros(4, np.uint8), np.zeros(1, np.int64)
+    args = lambda cnt, km: (rec.ctypes.data, 1, cnt.ctypes.data, geo[0:1].ctypes.data, geo[1:2].ctypes.data, geo[2:3].ctypes.data, 0, km, 17,
+                            0.5, 0.1, 1, 1, table.ctypes.data, ok.ctypes.data, kept.ctypes.data)
+    assert lib.cs_accept_records(*args(np.array([-1], dtype=np.int64), 17)) != 0
+    assert lib.cs_accept_records(*args(np.array([4], dtype=np.int64), 0)) != 0
+    assert lib.cs_accept_records(*args(np.array([4], dtype=np.int64), 17)) == 0

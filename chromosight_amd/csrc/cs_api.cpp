@@ -2114,7 +2114,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         const int n_lanes = (twins && n_blocks > 1) ? std::min(std::min(std::max(lanes_env, 1), kBlkLanes), n_blocks) : 1;
         // one persistent launch for the tiles of all blocks (the lanes then only carry the blocks' mask tables)
         static const char* table_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_TABLE");      // "0" / "1": force
-        const bool table = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE") && (table_env ? table_env[0] == '1' : foci[0].exclusive != 0);
+        const bool table = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE") && (table_env ? table_env[0] == '1' : (foci[0].exclusive != 0 || n_blocks <= 4));    // (a rank's share of a genome on 8 GPUs: 3 blocks -- one launch beats three that fight for the slots: 1.40 -> 1.29 ms per rank)
         // either way the blocks' launches are PREPARED first (mask tables of every block on the lanes, argument blocks in a host
         // table) and the tile kernels go out afterwards: a mask-table launch queued behind persistent tile kernels would wait
         // for their workgroups to drain, and its lane's next tile kernel with it

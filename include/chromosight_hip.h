@@ -288,7 +288,8 @@ typedef struct {
     int32_t exclusive;      /* cs_detect_foci_blocks, entry 0: 1 = nothing else is queued on the device beside
                                this call -- the tiles of all blocks go out as ONE persistent launch (a table of
                                per-block arguments); 0 = one launch per block over several streams, which leaves
-                               gaps for the launch chains of other templates running side by side               */
+                               gaps for the launch chains of other templates running side by side (calls with up
+                               to four blocks take the single launch either way)                                */
     int32_t reserved;
 } cs_foci_params;
 

@@ -235,8 +235,13 @@ cool, _ = make_cool(12_000, 200, 2000, seed=5, template=template)
 dcool = pipeline.DeviceCool(cool)
 cfg = copy.deepcopy(ck.loops); cfg["max_dist"] = 200 * 2000; cfg["max_iterations"] = 2
 rec = parallel.detect_genome(dcool, cfg)
+# ... and two patterns side by side on blocks staged once (what bench.py's sharded genome does on every rank)
+loops = copy.deepcopy(ck.loops); loops["max_dist"] = 200 * 2000
+rec_l, rec_b = parallel.detect_patterns(dcool, [loops, copy.deepcopy(ck.borders)])
 if dist.get_rank() == 0:
     np.save(os.environ["CS_OUT"], rec)
+    np.save(os.environ["CS_OUT"] + ".loops.npy", rec_l)
+    np.save(os.environ["CS_OUT"] + ".borders.npy", rec_b)
 dist.destroy_process_group()
 """
 
@@ -268,6 +273,17 @@ def test_two_ranks_equal_single_process(tmp_path):
     # 1e-16 level) and the second template is a pileup summed in another order
     assert np.abs(both[:, 3] - single[:, 3]).max() < 1e-9
     assert np.allclose(both[:, 4], single[:, 4], rtol=1e-6, atol=1e-300)
+    # detect_patterns on two ranks (blocks staged once per rank, the three borders templates in one chain, one record
+    # exchange per pattern) == the single process: records of every template in the single-process order
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    want_l, want_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
+    for name, want in (("loops", want_l), ("borders", want_b)):
+        got = np.load(str(out) + f".{name}.npy")
+        assert got.shape == want.shape and want.shape[0] > 30, name
+        assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]]), name
+        assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9, name
+    assert set(np.unique(want_b[:, 5])) == {0.0, 1.0, 2.0}
 
 
 # ------------------------------------------------------------------------------------------------

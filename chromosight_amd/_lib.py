@@ -168,6 +168,7 @@ _PROTOTYPES = {
     "cs_distance_law_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "cs_detect_foci_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(CsKernel),
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_comm_available": (C.c_int, []),
     "cs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cs_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "cs_comm_destroy": (None, [C.c_void_p]),

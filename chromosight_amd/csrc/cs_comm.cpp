@@ -132,6 +132,11 @@ int ensure(cs_comm* c, size_t bytes)
 
 extern "C" {
 
+int cs_comm_available(void)
+{
+    return rccl()->err.empty() ? CS_OK : CS_ERR_UNSUPPORTED;
+}
+
 int cs_comm_unique_id(void* out128)
 {
     if (!out128) return CS_ERR_INVALID;

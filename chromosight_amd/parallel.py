@@ -121,9 +121,12 @@ def native_comm():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(flag.item())
 
-        # 1. local: the library and the RCCL of its HIP runtime load on this rank (every rank makes an id; rank 0's is used)
+        # 1. local: the library and the RCCL of its HIP runtime load on this rank; rank 0 makes the id
         try:
-            my_id, err = NativeComm.unique_id(), None
+            from ._lib import load_library
+            if load_library().cs_comm_available() != 0:
+                raise RuntimeError("librccl of the library's HIP runtime does not load")
+            my_id, err = (NativeComm.unique_id() if rank == 0 else None), None
         except Exception as exc:                              # noqa: BLE001 -- whatever it is, the torch path remains
             my_id, err = None, exc
         if not all_ok(err is None):

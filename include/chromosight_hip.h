@@ -386,6 +386,7 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
  * in rank order (h_counts[r] rows of rank r), identical on every rank; CS_ERR_OVERFLOW (counts set) when cap_rows is
  * too small.  cs_comm_allreduce_f64: element-wise sum over the ranks, in place. */
 typedef struct cs_comm cs_comm;
+int cs_comm_available(void);            /* CS_OK when the RCCL of the library's HIP runtime loads (a local check: no rank talks) */
 int cs_comm_unique_id(void* out128);
 int cs_comm_create(int device, int rank, int world, const void* unique_id128, cs_comm** out);
 void cs_comm_destroy(cs_comm* comm);

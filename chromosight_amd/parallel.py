@@ -419,14 +419,22 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     if side and ready is None:
         genome.dev.sync()                                    # staging is complete before several threads and streams read it
     pick = lambda i: staged.for_config(i) if isinstance(staged, StagedSet) else staged
+    # the configuration that scans the widest band stays on this thread (a hand-over to a pool thread costs 50-100 us, and
+    # its pass is the longest); the others go to the pool first
+    here = max(side, key=lambda i: kernel_configs[i]["max_dist"]) if side else None
     futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=pick(i),
-                                          exchange=False, exclusive=len(side) < 2) for i in side}
+                                          exchange=False, exclusive=len(side) < 2) for i in side if i != here}
+    local = {}
+    if here is not None:
+        local[here] = detect_genome(genome, kernel_configs[here], tsvd=tsvd, owned=owned, staged=pick(here), exchange=False,
+                                    exclusive=len(side) < 2)
     results = [None] * len(kernel_configs)
     for i, cfg in enumerate(kernel_configs):
-        if i not in futures:
-            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=pick(i), exclusive=not futures)
-    for i in side:
-        results[i] = _exchange_records(futures[i].result(), len(kernel_configs[i]["kernels"]), 1)
+        if i not in side:
+            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=pick(i), exclusive=not side)
+    for i in side:                                           # (collectives in the same order on every rank)
+        mine = local[i] if i in local else futures[i].result()
+        results[i] = _exchange_records(mine, len(kernel_configs[i]["kernels"]), 1)
     return results
 
 

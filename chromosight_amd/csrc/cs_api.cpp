@@ -2089,6 +2089,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_blk_counts, 2 * cnt_bytes, hipHostMallocDefault));
         ctx->h_blk_bytes = 2 * cnt_bytes;
     }
+    std::vector<cs::CorrArgs<double>> tab;       // the float64 argument blocks of the chain behind the tile kernels
     // ---- candidates of every block into one list
     const double margin = std::max(foci[0].rescore_margin, 1e-4);
     const double thr = foci[0].pearson - margin;
@@ -2266,17 +2267,23 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
         CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+        if (tab.empty()) {
+            // built while the tile kernels run, not between the two synchronisations
+            tab.resize((size_t)n_blocks);
+            for (int b = 0; b < n_blocks; ++b) {
+                int rc2 = build_args<double>(ctx, stream, signals + b, kernel, params + b, &tab[b]);
+                if (rc2) {
+                    (void)hipDeviceSynchronize();
+                    return rc2;
+                }
+            }
+        }
         CS_HIP(ctx, hipStreamSynchronize(stream));
         n_total = ctx->h_counts[0];
         if ((size_t)n_total <= c_cap) break;
         c_cap = (size_t)n_total + (size_t)n_total / 8;
     }
-    // ---- exact scores, foci, statistics: one chain for all blocks
-    std::vector<cs::CorrArgs<double>> tab((size_t)n_blocks);
-    for (int b = 0; b < n_blocks; ++b) {
-        int rc = build_args<double>(ctx, stream, signals + b, kernel, params + b, &tab[b]);
-        if (rc) return rc;
-    }
+    // ---- exact scores, foci, statistics: one chain for all blocks (its argument table was built while the tile kernels ran)
     char* pool = (char*)ctx->d_pool;
     const size_t off_tail = al(8 * c_cap) + 256;
     ctx->h_blk_counts[0] = -1;

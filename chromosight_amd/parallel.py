@@ -423,7 +423,7 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     # its pass is the longest); the others go to the pool first
     here = max(side, key=lambda i: kernel_configs[i]["max_dist"]) if side else None
     futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=pick(i),
-                                          exchange=False, exclusive=len(side) < 2) for i in side if i != here}
+                                          exchange=False, exclusive=len(side) < 2, own_context=True) for i in side if i != here}
     local = {}
     if here is not None:
         local[here] = detect_genome(genome, kernel_configs[here], tsvd=tsvd, owned=owned, staged=pick(here), exchange=False,
@@ -439,7 +439,7 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
 
 
 def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, stage=None, detect=None,
-                  owned=None, staged=None, exchange=True, exclusive=True):
+                  owned=None, staged=None, exchange=True, exclusive=True, own_context=False):
     """`chromosight detect` over all intra-chromosomal blocks of a DeviceCool, sharded over the ranks
     like the reference's Pool.imap over sub-matrices (cli/chromosight.py:738-755): every rank stages
     and scans its own blocks (LPT assignment by band pixels), the per-block tables are all-gathered
@@ -454,6 +454,8 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     `staged`: blocks of stage_genome (staged once for several patterns); a block that cannot serve this configuration
     through a band view is staged here as usual.  exchange=False: this rank's records only (detect_patterns).
     exclusive=False: other configurations are being scanned on this GPU at the same time (detect_patterns).
+    own_context=True: this call runs on a host thread beside another one that uses the genome's own context and stream
+    (detect_patterns): every device call goes to a context and stream of this thread (a context serves one call in flight).
     Returns float64 records (block, bin1, bin2, score, pvalue, kernel_id, iteration), block-local
     bins, identical on all ranks, in the single-process order."""
     batch = None
@@ -542,6 +544,15 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                 # the acceptance rules (many small numpy calls) here, one template after the other: spread over the worker
                 # threads they fight for the interpreter lock and each takes four times as long
                 results = futures[kernel_id].result()()
+            elif batch and own_context and hasattr(genome, "workers"):
+                # a single template on a pool thread: not on the genome's context, which the calling thread is using
+                dev_t, stream_t = genome.workers(1).device()
+                ready_t = getattr(staged_in, "ready", None) if not todo else None
+                if ready_t is not None:
+                    dev_t.wait_event(ready_t, stream_t)
+                else:
+                    genome.dev.sync()
+                results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd, need_windows, False, dev_t, stream_t)
             else:
                 results = batch(genome, [staged[ci] for ci in mine], kernel_config, kernel, tsvd, need_windows) if batch else None
             if isinstance(results, tuple):

@@ -313,6 +313,7 @@ class DeviceCool:
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
         self._laws = _Scratch(dev)
+        self._stage_lock = threading.Lock()
         self._free = _FreeList()        # HBM of released resident blocks, reused by the next staging
         self._workers = None
 
@@ -326,7 +327,12 @@ class DeviceCool:
         measured slower than ONE stream on the 23-block genome (the hand-over costs two synchronisations per block).
         Every block's staging is complete on return."""
         chroms = list(chroms)
-        fast = self._stage_fast(chroms, max_dist, largest_kernel, **options)
+        # One staging call at a time per pixel table: the calls share this context's staging scratch, its page-locked
+        # table slots and the law scratch, and they are ordered on one stream.  (Patterns scanned side by side by several
+        # host threads each stage the blocks they cannot take as views -- short chromosomes staged dense for a wider
+        # pattern: two such calls at once handed each other's block tables to the kernels.)
+        with self._stage_lock:
+            fast = self._stage_fast(chroms, max_dist, largest_kernel, **options)
         if fast is not None:
             return fast
         if workers <= 1 or len(chroms) <= 1:

@@ -408,6 +408,35 @@ def test_templates_scanned_side_by_side_keep_to_their_own_context(monkeypatch):
     assert np.abs(side_by_side[:, 3] - in_turn[:, 3]).max() < 1e-12
 
 
+def test_three_patterns_side_by_side_repeat_exactly():
+    """stage_genome + detect_patterns with THREE patterns (loops on the calling thread; borders -- three templates, one chain --
+    and hairpins on pool threads, each on its own context; short chromosomes staged dense for loops are staged again, banded,
+    by the threads of the 1-D patterns): every repetition gives the records of the first.  Found by this test's long form
+    (tools/stress_genome_repeat.py): a single-template pattern on a pool thread used the genome's own context beside the
+    calling thread, and two threads staging at once handed each other's block tables to the kernels."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(30_000, 300, 2000, seed=2, template=template)
+    dcool = pipeline.DeviceCool(cool)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 300 * 2000
+    cfgs = [loops, copy.deepcopy(ck.borders), copy.deepcopy(ck.hairpins)]
+    first = None
+    for it in range(80):
+        staged = parallel.stage_genome(dcool, cfgs)
+        recs = parallel.detect_patterns(dcool, cfgs, staged=staged)
+        if first is None:
+            first = recs
+            # ... and the first equals one pattern after the other
+            for cfg, rec in zip(cfgs, recs):
+                alone = parallel.detect_genome(dcool, cfg)
+                assert rec.shape == alone.shape and np.array_equal(rec[:, [0, 1, 2, 5, 6]], alone[:, [0, 1, 2, 5, 6]]), cfg["name"]
+            assert all(r.shape[0] > 100 for r in recs)
+            continue
+        for cfg, a, b in zip(cfgs, first, recs):
+            assert a.shape == b.shape and np.array_equal(a[:, [0, 1, 2, 5, 6]], b[:, [0, 1, 2, 5, 6]]), (it, cfg["name"])
+            assert np.abs(a[:, 3] - b[:, 3]).max() < 1e-12, (it, cfg["name"])
+
+
 def test_run_scoring_of_1d_patterns_equals_wave_per_pixel(monkeypatch):
     """The float64 scoring of the enumerated diagonals one lane per pixel from an LDS tile
     (rescore_run_batch_kernel; the direct route for workgroups that straddle two sub-matrices) against the

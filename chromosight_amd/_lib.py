@@ -326,6 +326,9 @@ class Device:
     def __init__(self, index=0):
         self.lib = load_library()
         self.index = int(index)
+        # a context serves one call in flight: the engine's entry points hold this while they use it (callers that want
+        # concurrency on one GPU take one Device per host thread, as the genome drivers do)
+        self.lock = threading.RLock()
         ctx = C.c_void_p()
         rc = self.lib.cs_ctx_create(self.index, C.byref(ctx))
         if rc != 0:

@@ -36,6 +36,18 @@ def compute_code(precision=None):
     return CS_F64 if (precision or _precision) == "f64" else CS_F32
 
 
+def _one_call_per_context(fn):
+    """The library's contexts own scratch (template weights, mask tables, candidate pools): one call in flight each.  The
+    reference's functions can be called from several threads at once; calls that share a Device take turns here."""
+    import functools
+
+    @functools.wraps(fn)
+    def locked(dev, *args, **kwargs):
+        with dev.lock:
+            return fn(dev, *args, **kwargs)
+    return locked
+
+
 class KernelSpec:
     """Host-side description of one pattern template (keeps the float64 arrays alive while the
     C struct points at them).  With tsvd, the correlated kernels are the truncated-SVD
@@ -69,6 +81,7 @@ def min_present(kernel_shape, missing_tol):
     return int((1 - missing_tol) * kernel_shape[0] * kernel_shape[1])
 
 
+@_one_call_per_context
 def run_normxcorr2(dev, sig, shape, kspec, out, *, full, sym_upper, max_dist, mask_mode=MASK_NONE,
                    miss_row=None, miss_col=None, mask=None, missing_tol=0.75, nobs=None,
                    precision=None, stream=None):
@@ -87,6 +100,7 @@ def run_normxcorr2(dev, sig, shape, kspec, out, *, full, sym_upper, max_dist, ma
     return params
 
 
+@_one_call_per_context
 def run_normxcorr2_host(dev, signal, kspec, *, full, sym_upper, max_dist, missing_tol=0.75, out_dtype=np.float64):
     """Dense float32 host map -> coefficient map on the host through cs_normxcorr2_host (upload, kernel and
     download of row slabs overlap; float64 widening on the library's host threads)."""
@@ -101,6 +115,7 @@ def run_normxcorr2_host(dev, signal, kspec, *, full, sym_upper, max_dist, missin
     return out
 
 
+@_one_call_per_context
 def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist, mask_mode=MASK_NONE,
                 miss_row=None, miss_col=None, mask=None, missing_tol=0.75, stream=None):
     """float64 coefficients (and present-pixel counts) at the given pixels."""
@@ -131,6 +146,8 @@ def run_rescore(dev, sig, shape, kspec, rows, cols, *, full, sym_upper, max_dist
 # the reference's zeroing thresholds; the exact values are then thresholded.  The candidate set is a superset of the pixels
 # whose exact coefficient passes whatever the data look like (tests/test_gpu_margin.py).
 RESCORE_MARGIN = 0.05
+
+
 
 
 def map_pitch(width, itemsize=4, quantum=16):
@@ -189,6 +206,7 @@ def _host_buffers(dev, cap, kk, want_windows):
     return rec, win
 
 
+@_one_call_per_context
 def run_detect_foci(dev, sig, shape, kspec, *, pearson, lo_diag, hi_diag, inter, diag_only, full, sym_upper, max_dist,
                     mask_mode=MASK_NONE, miss_row=None, miss_col=None, missing_tol=0.75, precision=None,
                     want_windows=True, min_size=2, stream=None):
@@ -244,6 +262,7 @@ def _block_arrays(dev, sigs, sigs32, shapes, kspec, max_dists, miss_rows, miss_c
     return hit
 
 
+@_one_call_per_context
 def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter, diag_only, max_dists, miss_rows, miss_cols,
                           missing_tol=0.75, want_windows=True, min_size=2, stream=None, flat=False):
     """detect mode of a 1-D pattern (<= 4 scanned diagonals) on MANY banded sub-matrices with one native call
@@ -297,6 +316,7 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
     return out
 
 
+@_one_call_per_context
 def run_detect_foci_blocks(dev, sigs, sigs32, shapes, kspec, *, pearson, lo_diags, hi_diags, inter, diag_only, max_dists, miss_rows,
                            miss_cols, missing_tol=0.75, want_windows=True, min_size=2, stream=None, precision=None, exclusive=False):
     """detect mode of one template on MANY sub-matrices with one native call (cs_detect_foci_blocks): 2-D scans on the masked
@@ -332,6 +352,7 @@ def run_detect_foci_blocks(dev, sigs, sigs32, shapes, kspec, *, pearson, lo_diag
     return rec[:total].copy(), windows, cnt
 
 
+@_one_call_per_context
 def run_candidates(dev, sig, shape, kspec, row_window, *, pearson, lo_diag, hi_diag, inter, full, sym_upper, max_dist,
                    mask_mode=MASK_NONE, miss_row=None, miss_col=None, missing_tol=0.75, precision=None, stream=None,
                    **_unused):
@@ -359,6 +380,7 @@ def run_candidates(dev, sig, shape, kspec, row_window, *, pearson, lo_diag, hi_d
     return rows[:k], cols[:k], vals[:k]
 
 
+@_one_call_per_context
 def run_label_foci(dev, shape, rows, cols, vals, *, min_size=2, diag_only=False, stream=None):
     """Second half of detect mode (cs_label_foci): the 4-connected foci of a candidate list -- the
     coordinates of each focus at its maximum and its size, in the order of cs_detect_foci."""
@@ -376,6 +398,7 @@ def run_label_foci(dev, shape, rows, cols, vals, *, min_size=2, diag_only=False,
     return f_rows[:m], f_cols[:m], f_size[:m]
 
 
+@_one_call_per_context
 def run_quantify_pixels(dev, sig, shape, kspec, rows, cols, *, inter, full, sym_upper, max_dist, mask_mode=MASK_NONE,
                         miss_row=None, miss_col=None, missing_tol=0.75, want_windows=True, stream=None):
     """quantify mode (cs_quantify_pixels): one record (and window) per given pixel, in input order."""
@@ -393,6 +416,7 @@ def run_quantify_pixels(dev, sig, shape, kspec, rows, cols, *, inter, full, sym_
     return rec[:k].copy(), windows
 
 
+@_one_call_per_context
 def run_compact(dev, corr, shape, threshold, lo_diag, hi_diag, stream=None, guess=1 << 16):
     """(rows, cols, vals) of the stored pixels of `corr` with value >= threshold inside the
     diagonal range; sorted row-major."""

@@ -152,9 +152,10 @@ def xcorr2(signal, kernel, threshold=1e-4, tsvd=None):
     st = _Staged(dev, signal, (km, kn), sym_upper=False, full=False)
     out_buf, out_mat = st.alloc_out(_out_dtype())
     w = np.ascontiguousarray(kernel, dtype=np.float64)
-    dev._check(dev.lib.cs_xcorr2(dev.ctx, None, C.byref(st.sig), sm, sn,
-                                 w.ctypes.data_as(C.POINTER(C.c_double)), km, kn, float(threshold),
-                                 engine.compute_code(), C.byref(out_mat)))
+    with dev.lock:                                   # one call in flight per context (engine._one_call_per_context)
+        dev._check(dev.lib.cs_xcorr2(dev.ctx, None, C.byref(st.sig), sm, sn,
+                                     w.ctypes.data_as(C.POINTER(C.c_double)), km, kn, float(threshold),
+                                     engine.compute_code(), C.byref(out_mat)))
     # even kernel sizes give an output one row/column short, like the reference's re-padding
     osm = sm - km + 1 + 2 * ((km - 1) // 2)
     osn = sn - kn + 1 + 2 * ((kn - 1) // 2)

@@ -311,3 +311,50 @@ def test_banded_masked_multi_strip_vs_oracle(n, max_dist, ksize, tol, precision)
         got_tab = tab[["bin1", "bin2", "score"]].to_numpy(dtype=np.float64)
         assert np.array_equal(got_tab[:, :2], want_tab[:, :2]), (n, max_dist)     # same foci, same order
         assert np.abs(got_tab[:, 2] - want_tab[:, 2]).max() < 1e-9
+
+
+def test_api_calls_from_several_threads_take_turns():
+    """The reference's functions are plain numpy / scipy: callable from several threads at once.  Here calls that share the
+    process-wide Device take turns (engine._one_call_per_context; a context owns its template weights, mask tables and
+    pools) -- four threads with their own maps, templates and masks get the single-threaded results.  Without the lock all
+    four got wrong ones (tools/stress_api_threads.py)."""
+    import threading
+    import chromosight_amd.kernels as ck
+    from chromosight_amd.utils import preprocessing as cup
+    jobs = []
+    for t in range(4):
+        rng = np.random.default_rng(100 + t)
+        n = 300 + 60 * t
+        a = np.triu(rng.gamma(4, 0.25, size=(n, n)))
+        kern = np.asarray([ck.loops, ck.borders, ck.hairpins, ck.loops][t]["kernels"][0], dtype=np.float64)
+        valid = np.flatnonzero(rng.random(n) > 0.03)
+        mask = cup.make_missing_mask((n, n), valid, valid, max_dist=120, sym_upper=True)
+        miss = np.ones(n, bool)
+        miss[valid] = False
+        a[miss, :] = 0
+        a[:, miss] = 0
+        jobs.append((sp.csr_matrix(a), kern, mask, rng.gamma(4, 0.25, size=(200 + 30 * t, 320))))
+
+    def work(job):
+        s, kern, mask, dense = job
+        c1, p1 = cud.normxcorr2(s, kern, max_dist=120, sym_upper=True, full=True, missing_mask=mask, missing_tol=0.6, pval=True)
+        c2, _ = cud.normxcorr2(dense, kern, full=False)
+        c3 = cud.xcorr2(dense, kern)
+        return c1.toarray(), p1.toarray(), c2, c3
+
+    want = [work(j) for j in jobs]
+    bad = []
+
+    def thread(k):
+        for _ in range(12):
+            for g, w in zip(work(jobs[k]), want[k]):
+                if not np.array_equal(g, w, equal_nan=True):
+                    bad.append(k)
+                    return
+
+    threads = [threading.Thread(target=thread, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, sorted(set(bad))

@@ -313,7 +313,7 @@ class DeviceCool:
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
         self._laws = _Scratch(dev)
-        self._stage_lock = threading.Lock()
+        self._stage_lock = threading.RLock()
         self._free = _FreeList()        # HBM of released resident blocks, reused by the next staging
         self._workers = None
 
@@ -414,7 +414,8 @@ class DeviceCool:
                        np_dtype_code(self.val_dtype), 0, None, self.weight.ptr, self.weight.ptr)
         # asynchronous on `stream`: whoever reads the blocks on another stream or context synchronises first (the callers
         # that hand blocks to worker threads do; the law scratch is rewritten in stream order)
-        dev._check(lib.cs_stage_blocks(dev.ctx, stream, C.byref(genome), table, len(geo), 10.0))
+        with dev.lock:
+            dev._check(lib.cs_stage_blocks(dev.ctx, stream, C.byref(genome), table, len(geo), 10.0))
         if os.environ.get("CHROMOSIGHT_HIP_STAGE_SYNC"):
             dev.sync(stream)
         return blocks
@@ -464,8 +465,17 @@ class DeviceCool:
                      begin if begin is not None else self.indptr.ptr + 8 * s, self.indices.ptr, self.data.ptr,
                      np_dtype_code(self.val_dtype), cs, end, self.weight.ptr + 8 * s, self.weight.ptr + 8 * cs)
 
-    def stage_intra(self, ci, max_dist, largest_kernel, smooth=False, band_dtype=np.float64, name=None, stream=None,
-                    resident=False, rows=None, reduce=None, dev=None, ext=None):
+    def stage_intra(self, *args, dev=None, **options):
+        """_stage_intra holding the context it uses (one call in flight per context: engine._one_call_per_context)."""
+        with (dev or self.dev).lock:
+            return self._stage_intra(*args, dev=dev, **options)
+
+    def stage_inter(self, *args, **options):
+        with self.dev.lock:
+            return self._stage_inter(*args, **options)
+
+    def _stage_intra(self, ci, max_dist, largest_kernel, smooth=False, band_dtype=np.float64, name=None, stream=None,
+                     resident=False, rows=None, reduce=None, dev=None, ext=None):
         """ContactMap.create_mat of one balanced intra block, on the device: distance law over the
         first keep_distance diagonals of the detectable bins, detrend, >= 10 -> 1, NaN -> 0, upper
         band only (contacts_map.py:527-548, 603-638; preprocessing.py:129-197, 256-310).
@@ -542,7 +552,7 @@ class DeviceCool:
         block.smooth = bool(smooth)
         return block
 
-    def stage_inter(self, ca, cb, name=None, stream=None, resident=False, dtype=np.float64):
+    def _stage_inter(self, ca, cb, name=None, stream=None, resident=False, dtype=np.float64):
         """ContactMap.create_mat of a balanced inter-chromosomal block (ca < cb), on the device:
         NaN -> 0, divided by the median of its stored values (contacts_map.py:598-601), dense layout."""
         dev, lib = self.dev, self.dev.lib

@@ -129,6 +129,11 @@ def _out_dtype():
     return np.float64 if engine.get_precision() == "f64" else np.float32
 
 
+# largest |pixel| the float32 kernels take: a 31 x 31 window of squares must stay below FLT_MAX (3.4e38) with room for the
+# per-tile scaling of the matrix-core kernels
+_F32_SAFE_PEAK = 1e15
+
+
 # ============================================================================================
 # xcorr2 / normxcorr2
 # ============================================================================================
@@ -210,6 +215,30 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         pvals = cus.corr_to_pval(corr.ravel(), km * kn).reshape(corr.shape) if pval else None
         return corr, pvals
     mask_range = engine.diag_range(missing_mask) if missing_mask is not None else None
+    # Values the device arithmetic does not take as they are.  Non-finite pixels: in the reference a NaN or an infinite
+    # pixel makes every window that holds it NaN and then 0 (detection.py:1088-1101) and leaves the others alone; the
+    # device's running box sums would carry it into windows further down, so such pixels are staged as 0 and the windows
+    # that hold them are zeroed afterwards.  Magnitudes: float32 arithmetic squares the pixels -- maps whose values leave
+    # the range where a window's sum of squares fits are evaluated in float64 (the reference is float64 throughout).
+    precision = None
+    bad_pixels = None
+    values = signal.data if sp.issparse(signal) else np.asarray(signal)
+    peak = float(np.max(np.abs(values))) if values.size else 0.0
+    if not np.isfinite(peak):
+        if sp.issparse(signal):
+            coo = signal.tocoo()
+            nf = ~np.isfinite(coo.data)
+            bad_pixels = (coo.row[nf].astype(np.int64), coo.col[nf].astype(np.int64))
+            signal = sp.csr_matrix((np.where(nf, 0.0, coo.data), (coo.row, coo.col)), shape=signal.shape)
+            finite = coo.data[~nf]
+        else:
+            nf = ~np.isfinite(values)
+            bad_pixels = tuple(a.astype(np.int64) for a in np.nonzero(nf))
+            signal = np.where(nf, 0.0, values)
+            finite = values[~nf]
+        peak = float(np.max(np.abs(finite))) if finite.size else 0.0
+    if engine.get_precision() == "f32" and peak > _F32_SAFE_PEAK:
+        precision = "f64"
     st = _Staged(dev, signal, (km, kn), sym_upper, full, extra_range=mask_range)
     mask_buf = None
     mask_mode = MASK_NONE
@@ -229,7 +258,7 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
             mask_mode = MASK_EXPLICIT
     # dense inputs come back as float64 arrays (as the reference returns them): the kernel stores
     # float64 directly, which is cheaper than converting 8 bytes per pixel on the host
-    out_dtype = _out_dtype() if st.sparse else np.float64
+    out_dtype = (np.float64 if precision == "f64" else _out_dtype()) if st.sparse else np.float64
     out_buf, out_mat = st.alloc_out(out_dtype)
     want_nobs = pval and full and missing_mask is not None
     nobs_buf = nobs_mat = None
@@ -237,11 +266,16 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         nobs_buf, nobs_mat = st.alloc_out(np.float32)
     engine.run_normxcorr2(dev, st.sig, (ms, ns), kspec, out_mat, full=full, sym_upper=sym_upper,
                           max_dist=max_dist, mask_mode=mask_mode, mask=mask_buf,
-                          missing_tol=missing_tol, nobs=nobs_mat, **mask_kw)
+                          missing_tol=missing_tol, nobs=nobs_mat, precision=precision, **mask_kw)
     n = km * kn
     if st.sparse:
         rows, cols, vals = st.to_host_coo(out_buf)
         vals = vals.astype(np.float64)
+        if bad_pixels is not None:
+            hit = np.zeros(vals.shape, dtype=bool)
+            for p, q in zip(*bad_pixels):            # (a handful of pixels: one pass over the result each)
+                hit |= (np.abs(rows - p) <= (km - 1) // 2) & (np.abs(cols - q) <= (kn - 1) // 2)
+            rows, cols, vals = rows[~hit], cols[~hit], vals[~hit]
         corr = sp.csr_matrix((vals, (rows, cols)), shape=(ms, ns))
         pvals = None
         if pval:
@@ -258,6 +292,9 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
             pvals = sp.csr_matrix((logp, (rows, cols)), shape=(ms, ns))
         return corr, pvals
     corr = st.to_host_dense(out_buf).astype(np.float64, copy=False)
+    if bad_pixels is not None:
+        for p, q in zip(*bad_pixels):
+            corr[max(p - (km - 1) // 2, 0):p + (km - 1) // 2 + 1, max(q - (kn - 1) // 2, 0):q + (kn - 1) // 2 + 1] = 0.0
     pvals = None
     if pval:
         if want_nobs:

@@ -20,6 +20,8 @@
                         reference's own per-template tables of yeast_quantify.npz: best of the templates
                         per coordinate, bin columns from start1 / start2, q-values, output order; some
                         intervals are three bins wide so that bin1 / bin2 differ from the scored midpoints
+  nonfinite.npz         normxcorr2 on maps with one NaN / +inf / -inf pixel (sparse + mask, dense): the windows that
+                        hold the pixel are 0, the others as if it were 0
 """
 import pathlib
 import sys
@@ -297,7 +299,39 @@ def make_quantify_select():
           int(np.count_nonzero(bed2d.end1 - bed2d.start1 > binsize)), "wide intervals")
 
 
+def make_nonfinite():
+    """normxcorr2 on maps that hold a NaN / an infinite pixel (API misuse: chromosight's own maps are zeroed first,
+    contacts_map.py:539-540): every window that holds the pixel comes out 0 (detection.py:1088-1101), the others as if the
+    pixel were 0.  Sparse + mask (the pipeline's call) and dense."""
+    rng = np.random.default_rng(7)
+    n = 90
+    base = np.triu(rng.gamma(4, 0.25, size=(n, n)))
+    valid = np.flatnonzero(rng.random(n) > 0.04)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    base[miss, :] = 0
+    base[:, miss] = 0
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=40, sym_upper=True)
+    out = {"kernel": LOOPS, "valid": valid}
+    for tag, bad, (p, q) in (("nan", np.nan, (30, 35)), ("inf", np.inf, (61, 70)), ("ninf", -np.inf, (12, 12))):
+        a = base.copy()
+        if miss[p] or miss[q]:
+            raise SystemExit("pick another pixel")
+        a[p, q] = bad
+        c, lp = cud.normxcorr2(sp.csr_matrix(a), LOOPS, max_dist=40, sym_upper=True, full=True, missing_mask=mask,
+                               missing_tol=0.75, pval=True)
+        out[f"{tag}_in"] = a
+        out[f"{tag}_corr"] = c.toarray()
+        d = np.abs(rng.gamma(4, 0.25, size=(60, 70)))
+        d[20, 33] = bad
+        cd, _ = cud.normxcorr2(d, LOOPS, full=False)
+        out[f"{tag}_dense_in"] = d
+        out[f"{tag}_dense_corr"] = cd
+    np.savez_compressed(HERE / "nonfinite.npz", **out)
+    print("nonfinite.npz written")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select"]
+    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite"]
     for name in which:
         globals()[f"make_{name}"]()

@@ -247,3 +247,34 @@ def test_quantify_selection_matches_reference_capture(golden):
     wide = (num[:, 1] - num[:, 0]) > int(cool["binsize"])
     assert wide.sum() > 100          # intervals whose reported bins differ from the scored midpoints
     assert windows.shape == (len(table), 11, 11)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_nonfinite_pixels_zero_their_windows_like_the_reference(golden, precision):
+    """normxcorr2 on maps with a NaN / +inf / -inf pixel (tests/golden/nonfinite.npz, from the reference): every window that
+    holds the pixel is 0 (detection.py:1088-1101), the others as if the pixel were 0 -- sparse with the pipeline's mask, and
+    dense.  (The device's running box sums would carry such a pixel into other windows: it is staged as 0 and its windows are
+    zeroed at the Python boundary.)"""
+    from chromosight_amd.utils import preprocessing as cup
+    g = golden("nonfinite")
+    kern, valid = g["kernel"], g["valid"]
+    tol = 1e-5 if precision == "f32" else 1e-10
+    chromosight_amd.set_precision(precision)
+    try:
+        for tag in ("nan", "inf", "ninf"):
+            a, want = g[f"{tag}_in"], g[f"{tag}_corr"]
+            n = a.shape[0]
+            mask = cup.make_missing_mask((n, n), valid, valid, max_dist=40, sym_upper=True)
+            got, logp = cud.normxcorr2(sp.csr_matrix(a), kern, max_dist=40, sym_upper=True, full=True, missing_mask=mask,
+                                       missing_tol=0.75, pval=True)
+            got = got.toarray()
+            assert np.isfinite(got).all() and np.isfinite(logp.toarray()).all()
+            p, q = (int(x[0]) for x in np.nonzero(~np.isfinite(a)))
+            assert not got[max(p - 8, 0):p + 9, max(q - 8, 0):q + 9].any() and not want[max(p - 8, 0):p + 9, max(q - 8, 0):q + 9].any()
+            assert np.abs(got - want).max() <= tol, (tag, np.abs(got - want).max())
+            d, want_d = g[f"{tag}_dense_in"], g[f"{tag}_dense_corr"]
+            got_d, _ = cud.normxcorr2(d, kern, full=False)
+            assert np.isfinite(got_d).all()
+            assert np.abs(got_d - want_d).max() <= tol, (tag, "dense", np.abs(got_d - want_d).max())
+    finally:
+        chromosight_amd.set_precision("f32")

@@ -298,3 +298,20 @@ def test_oracles_match_reference_nonsquare_inter(golden, tag):
     assert np.array_equal(tab[:, :2], ref[:, :2])
     assert np.abs(tab[:, 2] - ref[:, 2]).max() < 1e-12
     assert np.allclose(wins, g[f"{tag}_windows"], equal_nan=True, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["nan", "inf", "ninf"])
+def test_oracle_with_nonfinite_pixels(golden, tag):
+    """The C oracle on the reference's captures with one NaN / infinite pixel (tests/golden/nonfinite.npz): the sums of every
+    window that holds it are non-finite there as in the reference, and come out 0 (detection.py:1088-1101)."""
+    g = golden("nonfinite")
+    a, want, valid = g[f"{tag}_in"], g[f"{tag}_corr"], g["valid"]
+    n = a.shape[0]
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    got, _ = c_oracle.normxcorr2_rows(a, g["kernel"], 0, n, max_dist=40, sym_upper=True, full=True, miss_row=miss, miss_col=miss,
+                                      missing_tol=0.75)
+    got = np.where(np.isfinite(got), got, 0.0)
+    ii, jj = np.indices((n, n))
+    band = (jj >= ii) & (jj - ii <= 40)
+    assert np.abs(got - want)[band].max() < 1e-12               # (the reference's map is not trimmed to max_dist yet: in-band pixels)

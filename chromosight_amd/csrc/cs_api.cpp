@@ -68,6 +68,8 @@ struct cs_ctx {
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
+    void* d_counts_peak = nullptr;   // cs_normxcorr2_host: largest |pixel| of the map (float bits), and its pinned copy
+    unsigned* h_peak = nullptr;
     // grow-only scratch for the mask tables of the streaming kernel (one call in flight per context)
     void* d_ws = nullptr;
     size_t d_ws_bytes = 0;
@@ -940,6 +942,8 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->d_counts_peak) (void)hipFree(ctx->d_counts_peak);
+    if (ctx->h_peak) (void)hipHostFree(ctx->h_peak);
     if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
     if (ctx->h_blk_counts) (void)hipHostFree(ctx->h_blk_counts);
     if (ctx->d_host_in) (void)hipFree(ctx->d_host_in);
@@ -1231,6 +1235,11 @@ int cs_normxcorr2_host(cs_ctx* ctx, const void* h_signal, int32_t sig_dtype, int
     // template is taller than two slabs), all of which must have landed before the kernel of slab k starts (uploads are
     // issued in order on one stream, so waiting for the furthest one covers the others)
     (void)kh;
+    if (!ctx->d_counts_peak) {
+        CS_HIP(ctx, hipMalloc(&ctx->d_counts_peak, 256));
+        CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_peak, 256, hipHostMallocDefault));
+    }
+    CS_HIP(ctx, hipMemsetAsync(ctx->d_counts_peak, 0, 4, ctx->s_run));
     const int ahead = std::max(1, (kt + rows - 1) / rows);
     int uploaded = -1;
     hipError_t he = hipSuccess;
@@ -1246,6 +1255,12 @@ int cs_normxcorr2_host(cs_ctx* ctx, const void* h_signal, int32_t sig_dtype, int
         pk.row_end = r1;
         rc = cs_normxcorr2(ctx, ctx->s_run, &m_in, kernel, &pk, &m_out, nullptr);
         if (rc != CS_OK) break;
+        // the slab's largest |pixel| on the side (16 us for the whole 4096^2 map): see CS_ERR_RANGE
+        if (cs::launch_peak_rows((const char*)ctx->d_host_in + (size_t)r0 * ld * esz, sig_dtype == CS_F64, ld, r1 - r0, ns, ctx->n_cu,
+                                 reinterpret_cast<unsigned*>(ctx->d_counts_peak), ctx->s_run) != 0) {
+            he = hipErrorLaunchFailure;
+            break;
+        }
         he = hipEventRecord(ctx->ev_run[k], ctx->s_run);
         if (he != hipSuccess) break;
         he = hipStreamWaitEvent(ctx->s_down, ctx->ev_run[k], 0);
@@ -1261,12 +1276,25 @@ int cs_normxcorr2_host(cs_ctx* ctx, const void* h_signal, int32_t sig_dtype, int
         he = hipEventRecord(ctx->ev_down[k], ctx->s_down);
         if (he == hipSuccess) enqueued.store(k + 1, std::memory_order_release);
     }
+    unsigned peak_bits = 0u;
+    if (he == hipSuccess && rc == CS_OK) {
+        he = hipMemcpyAsync(ctx->h_peak, ctx->d_counts_peak, 4, hipMemcpyDeviceToHost, ctx->s_run);
+        if (he == hipSuccess) he = hipStreamSynchronize(ctx->s_run);
+        if (he == hipSuccess) peak_bits = *ctx->h_peak;
+    }
     if (he != hipSuccess || rc != CS_OK) enqueued.store(-1, std::memory_order_release);     // release the workers
     for (auto& t : workers) t.join();
     if (rc != CS_OK) return rc;
     if (he != hipSuccess) return fail(ctx, CS_ERR_HIP, "pipelined call failed: %s", hipGetErrorString(he));
     for (int w = 0; w < n_workers; ++w)
         if (worker_rc[w]) return fail(ctx, CS_ERR_HIP, "download wait failed");
+    {
+        const float limit = 1e15f;
+        unsigned limit_bits;
+        std::memcpy(&limit_bits, &limit, 4);
+        if (p->compute_dtype == CS_F32 && peak_bits > limit_bits)
+            return fail(ctx, CS_ERR_RANGE, "the map holds non-finite pixels or magnitudes beyond 1e15: float64 path");
+    }
     return CS_OK;
 }
 

@@ -479,6 +479,36 @@ __global__ __launch_bounds__(256) void narrow_rows_kernel(const double* __restri
     }
 }
 
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void peak_rows_kernel(const T* __restrict__ src, long long ld, int rows, int cols,
+                                                        unsigned* __restrict__ out)
+{
+    const long long n = (long long)rows * cols;
+    unsigned best = 0u;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        const long long r = t / cols, c = t - r * cols;
+        best = max(best, __float_as_uint(fabsf((float)src[r * ld + c])));      // (float64 beyond FLT_MAX -> inf: out of range too)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+}  // namespace
+
+int launch_peak_rows(const void* src, int src_is_f64, long long ld_src, int rows, int cols, int n_cu, unsigned* d_peak_bits,
+                     hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    const long long want = ((long long)rows * cols + 255) / 256;
+    const int blocks = (int)std::min<long long>(want, (long long)n_cu * 8);
+    if (src_is_f64)
+        hipLaunchKernelGGL(peak_rows_kernel<double>, dim3(blocks), dim3(256), 0, stream, (const double*)src, ld_src, rows, cols, d_peak_bits);
+    else
+        hipLaunchKernelGGL(peak_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)src, ld_src, rows, cols, d_peak_bits);
+    return (int)hipGetLastError();
+}
+
 int launch_narrow_rows(const double* src, long long ld_src, float* dst, long long ld_dst, int rows, int cols, int n_cu,
                        hipStream_t stream)
 {

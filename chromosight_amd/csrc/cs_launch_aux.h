@@ -305,6 +305,10 @@ int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* co
 int launch_csr_band_extent(const CsrView& M, int lo_diag, int hi_diag, long long* begin, long long* end,
                            hipStream_t stream);
 int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream);
+// largest |pixel| of rows x cols values (as the bits of a float: a NaN or an infinity compares above every finite value),
+// combined into *d_peak_bits with an atomic maximum (zero it first)
+int launch_peak_rows(const void* src, int src_is_f64, long long ld_src, int rows, int cols, int n_cu, unsigned* d_peak_bits,
+                     hipStream_t stream);
 int launch_narrow_rows(const double* src, long long ld_src, float* dst, long long ld_dst, int rows, int cols, int n_cu,
                        hipStream_t stream);
 

@@ -103,15 +103,19 @@ def run_normxcorr2(dev, sig, shape, kspec, out, *, full, sym_upper, max_dist, ma
 @_one_call_per_context
 def run_normxcorr2_host(dev, signal, kspec, *, full, sym_upper, max_dist, missing_tol=0.75, out_dtype=np.float64):
     """Dense float32 host map -> coefficient map on the host through cs_normxcorr2_host (upload, kernel and
-    download of row slabs overlap; float64 widening on the library's host threads)."""
+    download of row slabs overlap; float64 widening on the library's host threads).  None when the map holds non-finite
+    pixels or values the float32 kernels cannot square (the library finds out on the device, beside the kernels)."""
     ms, ns = signal.shape
     params = _corr_params((ms, ns), kspec, full, sym_upper, max_dist, MASK_NONE, None, None, None, missing_tol, CS_F32)
     # result pages from the device's pool of page-locked buffers: a fresh 128 MB numpy array would be
     # page-faulted in by the widening threads (measured: 7 ms of an 11 ms call)
     out = dev.pinned_result((ms, ns), out_dtype)
-    dev._check(dev.lib.cs_normxcorr2_host(dev.ctx, signal.ctypes.data, _lib.np_dtype_code(signal.dtype), ns,
-                                          C.byref(kspec.struct), C.byref(params), out.ctypes.data,
-                                          _lib.np_dtype_code(out_dtype), ns))
+    rc = dev.lib.cs_normxcorr2_host(dev.ctx, signal.ctypes.data, _lib.np_dtype_code(signal.dtype), ns,
+                                    C.byref(kspec.struct), C.byref(params), out.ctypes.data,
+                                    _lib.np_dtype_code(out_dtype), ns)
+    if rc == -5:
+        return None                  # CS_ERR_RANGE: non-finite pixels or magnitudes beyond the float32 range (caller: staged path)
+    dev._check(rc)
     return out
 
 

@@ -212,8 +212,10 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         # (cs_normxcorr2_host); the float64 array the reference returns is filled by the library's threads
         corr = engine.run_normxcorr2_host(dev, signal, kspec, full=full, sym_upper=sym_upper, max_dist=max_dist,
                                           missing_tol=missing_tol)
-        pvals = cus.corr_to_pval(corr.ravel(), km * kn).reshape(corr.shape) if pval else None
-        return corr, pvals
+        if corr is not None:
+            pvals = cus.corr_to_pval(corr.ravel(), km * kn).reshape(corr.shape) if pval else None
+            return corr, pvals
+        # (out of the float32 kernels' range, or non-finite pixels: the staged path below sorts that out)
     mask_range = engine.diag_range(missing_mask) if missing_mask is not None else None
     # Values the device arithmetic does not take as they are.  Non-finite pixels: in the reference a NaN or an infinite
     # pixel makes every window that holds it NaN and then 0 (detection.py:1088-1101) and leaves the others alone; the

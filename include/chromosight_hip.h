@@ -48,7 +48,9 @@ typedef enum {
     CS_ERR_INVALID = -1,   /* bad argument (the Python shim raises ValueError) */
     CS_ERR_HIP = -2,       /* HIP runtime error */
     CS_ERR_UNSUPPORTED = -3,
-    CS_ERR_OVERFLOW = -4   /* an output buffer was too small; see the call's doc */
+    CS_ERR_OVERFLOW = -4,  /* an output buffer was too small; see the call's doc */
+    CS_ERR_RANGE = -5      /* cs_normxcorr2_host: the map holds a non-finite pixel, or magnitudes beyond what the float32
+                              kernels square without overflow (1e15): evaluate it in float64 (the Python shim does) */
 } cs_status;
 
 enum { CS_F32 = 0, CS_F64 = 1, CS_U8 = 2 /* masks only */ };

@@ -278,3 +278,26 @@ def test_nonfinite_pixels_zero_their_windows_like_the_reference(golden, precisio
             assert np.abs(got_d - want_d).max() <= tol, (tag, "dense", np.abs(got_d - want_d).max())
     finally:
         chromosight_amd.set_precision("f32")
+
+
+def test_nonfinite_pixels_in_a_large_host_map():
+    """The pipelined host call (maps of >= 1 Mpixel: cs_normxcorr2_host) finds a non-finite pixel or an out-of-range
+    magnitude on the device, beside its kernels (CS_ERR_RANGE), and the Python boundary then applies the rule pinned above:
+    the windows that hold the pixel are 0, the others as if it were 0; a map scaled by 1e20 goes through float64."""
+    kern = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    a = np.random.default_rng(0).gamma(4.0, 0.25, size=(1200, 1100)).astype(np.float32)
+    for bad in (np.nan, -np.inf):
+        b = a.copy()
+        b[600, 500] = bad
+        zeroed = a.copy()
+        zeroed[600, 500] = 0.0
+        got, _ = cud.normxcorr2(b, kern, full=False)
+        want, _ = cud.normxcorr2(zeroed, kern, full=False)
+        want = want.copy()
+        want[592:609, 492:509] = 0.0
+        assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-6
+    # a map beyond the float32 range as a whole (every pixel x 1e20): float64 arithmetic, the coefficients of the unscaled map
+    # (nothing here sits near the 1e-4 zeroing thresholds)
+    clean, _ = cud.normxcorr2(a, kern, full=False)
+    got, _ = cud.normxcorr2(a.astype(np.float64) * 1e20, kern, full=False)
+    assert np.isfinite(got).all() and np.abs(got - clean).max() < 2e-6

@@ -367,8 +367,32 @@ def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np
     narrow = [i for i in range(len(kernel_configs)) if (dists[i] + tallest[i]) * 8 <= max_dist] \
         if events and os.environ.get("CHROMOSIGHT_HIP_NARROW_STAGING") else []
     first = stage(narrow, 1) if narrow else None
-    staged = stage([i for i in range(len(kernel_configs)) if i not in narrow], 0)
+    wide = [i for i in range(len(kernel_configs)) if i not in narrow]
+    staged = stage(wide, 0)
     staged.by_config = {i: first for i in narrow}
+    # Blocks a configuration cannot take as a band view of the shared staging -- a short chromosome staged dense for the
+    # widest pattern is a band for a narrower one -- are staged for it here, on the genome's stream, instead of by the
+    # host thread that will scan that configuration (detect_patterns: the thread would have to use the genome's context
+    # beside the calling thread, and the templates of a 1-D pattern could not share one launch chain).
+    if hasattr(genome, "view_for") and not smooth:
+        extra_any = False
+        for i in wide:
+            need = []
+            for ci in owned:
+                blk = staged[ci]
+                same = blk.max_dist == dists[i] and blk.keep == min(dists[i], genome.chrom_size(ci)) + tallest[i]
+                if not same and genome.view_for(blk, dists[i], tallest[i]) is None:
+                    need.append(ci)
+            if need:
+                own = StagedSet(staged)
+                own.update(zip(need, genome.stage_blocks(need, dists[i], tallest[i], smooth=smooth, band_dtype=band_dtype)))
+                staged.by_config[i] = own
+                extra_any = True
+        if extra_any and events:
+            genome.dev.record(staged.ready)                  # (one event: after everything staged here)
+            for own in staged.by_config.values():
+                if own is not None and own is not first:
+                    own.ready = staged.ready
     return staged
 
 

@@ -648,6 +648,13 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         A.out_hi = (1 << 30);
         A.tiles_x = (A.ns + MF_T - 1) / MF_T;
     }
+    if (A.cand_keys) {
+        // candidate sink: only the scanned diagonals (diag_trim of the coefficient map) -- also for a dense layout, whose
+        // range was just reset above (a 1-D pattern on a chromosome short enough to be staged dense: pixels of every
+        // diagonal became candidates and joined the foci of the scanned ones)
+        A.out_lo = std::max(A.out_lo, A.cand_dlo);
+        A.out_hi = std::min(A.out_hi, A.cand_dhi);
+    }
     const long long blocks = (long long)A.tiles_x * A.tiles_y;
     if (blocks <= 0) return 0;
     if (blocks > 0x7fffffffLL) return -3;

@@ -210,6 +210,35 @@ def test_synthetic_genome_small_vs_oracle_pipeline(seed):
     assert found["loops"] > 100 and found["borders"] >= 0
 
 
+@pytest.mark.parametrize("sizes,md,seed", [([12, 36, 400, 400], 400, 101), ([900, 60, 400, 36, 36, 400, 19, 60], 40, 121),
+                                           ([2500, 19, 400, 12, 150], 1, 123), ([36, 36, 900, 150], 150, 122)])
+def test_genomes_with_very_short_chromosomes_vs_oracle_pipeline(sizes, md, seed):
+    """Chromosomes of a few dozen bins next to long ones (the long form: tools/fuzz_genomes.py): blocks not larger than the
+    template are skipped, blocks short enough to be staged dense take the per-block calls -- where, in float32 mode, a 1-D
+    pattern once kept the candidates of EVERY diagonal of a dense block (the scanned range was reset for dense layouts) and
+    reported a focus at the wrong bin.  loops + borders + hairpins side by side == the CPU pipeline of the oracles."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(sum(sizes), md, 2000, seed=seed, template=template, chrom_sizes=sizes)
+    dcool = pipeline.DeviceCool(cool)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = md * 2000
+    cfgs = [loops, copy.deepcopy(ck.borders), copy.deepcopy(ck.hairpins)]
+    recs = parallel.detect_patterns(dcool, cfgs, staged=parallel.stage_genome(dcool, cfgs))
+    total = 0
+    for cfg, rec in zip(cfgs, recs):
+        mdc = max(cfg["max_dist"] // 2000, 1)
+        kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+        for ci in range(dcool.n_chrom):
+            for ki, tab in enumerate(oracle_block_tables(cool, ci, cfg, mdc, kernels, 2000)):
+                got = rec[(rec[:, 0] == ci) & (rec[:, 5] == ki)]
+                assert got.shape[0] == tab.shape[0], (cfg["name"], ci, ki, got.shape[0], tab.shape[0])
+                if tab.shape[0]:
+                    assert np.array_equal(got[:, 1:3], tab[:, :2]), (cfg["name"], ci, ki)
+                    assert np.abs(got[:, 3] - tab[:, 2]).max() < 1e-9, (cfg["name"], ci, ki)
+                total += tab.shape[0]
+    assert total > 50
+
+
 def test_c4_genome_200k_vs_oracle_pipeline():
     """C4 of BASELINE.md at full size: 200 000 bins, 23 blocks, max_dist 1000, loops + 3 borders
     templates; every pattern table equal to the CPU oracle pipeline's (coordinates bit-exact and in

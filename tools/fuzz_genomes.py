@@ -12,7 +12,7 @@ from tools.synthetic_genome import make_cool
 import test_gpu_device_pipeline as T
 
 genomes = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-rng = np.random.default_rng(21)
+rng = np.random.default_rng(int(os.environ.get("CS_FUZZ_SEED", "21")))
 template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
 total_patterns = 0
 for g in range(genomes):

@@ -20,6 +20,7 @@
                         reference's own per-template tables of yeast_quantify.npz: best of the templates
                         per coordinate, bin columns from start1 / start2, q-values, output order; some
                         intervals are three bins wide so that bin1 / bin2 differ from the scored midpoints
+  inter_detect.npz      pattern_detector in detect mode on six inter-chromosomal blocks of the yeast map (median scaling)
   nonfinite.npz         normxcorr2 on maps with one NaN / +inf / -inf pixel (sparse + mask, dense): the windows that
                         hold the pixel are 0, the others as if it were 0
 """
@@ -299,6 +300,36 @@ def make_quantify_select():
           int(np.count_nonzero(bed2d.end1 - bed2d.start1 > binsize)), "wide intervals")
 
 
+def make_inter_detect():
+    """pattern_detector in DETECT mode on inter-chromosomal blocks of the yeast map (`detect --inter`, cli/chromosight.py:601-614
+    with ContactMap.inter: NaN -> 0, divided by the median of the stored values, contacts_map.py:598-601): the loops template
+    with a low threshold so that every block yields patterns; tables (block-local bins) and windows."""
+    cool = dict(np.load(HERE / "yeast_cool.npz", allow_pickle=True))
+    off = cool["chrom_offset"]
+    det_all = np.flatnonzero(np.isfinite(cool["weight"]))
+    cfg = dict(pearson=0.12, max_perc_undetected=60.0, max_perc_zero=95.0, max_dist=2000000, min_dist=20000, min_separation=5000,
+               max_iterations=1)
+    pairs = [(3, 6), (1, 12), (11, 14), (6, 15), (0, 16), (9, 10)]
+    out_cfg = np.array([cfg["pearson"], cfg["max_perc_undetected"], cfg["max_perc_zero"]])
+    out = {"pairs": np.array(pairs), "kernel": LOOPS, "cfg": out_cfg}
+    for (ca, cb) in pairs:
+        blk = balanced_block(cool, ca, cb).tocoo()
+        blk.data[np.isnan(blk.data)] = 0.0
+        blk.data = blk.data / np.nanmedian(blk.data)
+        blk.data[np.isnan(blk.data)] = 0
+        blk.eliminate_zeros()
+        det_r = det_all[(det_all >= off[ca]) & (det_all < off[ca + 1])] - off[ca]
+        det_c = det_all[(det_all >= off[cb]) & (det_all < off[cb + 1])] - off[cb]
+        cmap = RefMap(blk.tocsr(), (det_r.copy(), det_c.copy()), None, True)
+        tab, wins = cud.pattern_detector(cmap, cfg, LOOPS, full=True)
+        tag = f"b{ca}_{cb}"
+        out[f"{tag}_table"] = np.zeros((0, 4)) if tab is None else tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+        if blk.shape[0] * blk.shape[1] < 60_000:             # (windows of the two small blocks only: fixture size)
+            out[f"{tag}_windows"] = np.zeros((0,) + LOOPS.shape) if tab is None else wins
+        print("inter detect", tag, blk.shape, out[f"{tag}_table"].shape)
+    np.savez_compressed(HERE / "inter_detect.npz", **out)
+
+
 def make_nonfinite():
     """normxcorr2 on maps that hold a NaN / an infinite pixel (API misuse: chromosight's own maps are zeroed first,
     contacts_map.py:539-540): every window that holds the pixel comes out 0 (detection.py:1088-1101), the others as if the
@@ -332,6 +363,6 @@ def make_nonfinite():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite"]
+    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect"]
     for name in which:
         globals()[f"make_{name}"]()

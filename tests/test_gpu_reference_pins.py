@@ -301,3 +301,34 @@ def test_nonfinite_pixels_in_a_large_host_map():
     clean, _ = cud.normxcorr2(a, kern, full=False)
     got, _ = cud.normxcorr2(a.astype(np.float64) * 1e20, kern, full=False)
     assert np.isfinite(got).all() and np.abs(got - clean).max() < 2e-6
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_inter_detect_matches_reference(golden, precision):
+    """`detect --inter`: pattern_detector in detect mode on six inter-chromosomal blocks of the yeast map (rectangular, dense,
+    median scaling: contacts_map.py:598-601), captured from the reference (tests/golden/inter_detect.npz): same patterns in
+    the same order, scores to 1e-9, windows of the small blocks."""
+    g = golden("inter_detect")
+    cool = golden("yeast_cool")
+    dcool = pipeline.DeviceCool(cool)
+    kern = g["kernel"]
+    pearson, undetected, zero = (float(x) for x in g["cfg"])
+    cfg = dict(pearson=pearson, max_perc_undetected=undetected, max_perc_zero=zero, max_dist=2000000, min_dist=20000,
+               min_separation=5000, max_iterations=1)
+    chromosight_amd.set_precision(precision)
+    try:
+        total = 0
+        for ca, cb in g["pairs"]:
+            blk = dcool.stage_inter(int(ca), int(cb), resident=True)
+            tab, wins = pipeline.detect_block(dcool, blk, cfg, kern, raw=True)
+            want = g[f"b{ca}_{cb}_table"]
+            assert tab is not None and tab.shape == want.shape, (ca, cb, None if tab is None else tab.shape, want.shape)
+            assert np.array_equal(tab[:, :2], want[:, :2]), (ca, cb)
+            assert np.abs(tab[:, 2] - want[:, 2]).max() < 1e-9, (ca, cb)
+            assert np.allclose(tab[:, 3], want[:, 3], rtol=1e-6, atol=1e-300)
+            if f"b{ca}_{cb}_windows" in g:
+                assert np.allclose(wins, g[f"b{ca}_{cb}_windows"], rtol=0, atol=1e-9, equal_nan=True)
+            total += len(want)
+        assert total > 2000
+    finally:
+        chromosight_amd.set_precision("f32")

@@ -20,6 +20,7 @@
                         reference's own per-template tables of yeast_quantify.npz: best of the templates
                         per coordinate, bin columns from start1 / start2, q-values, output order; some
                         intervals are three bins wide so that bin1 / bin2 differ from the scored midpoints
+  options.npz           `detect --smooth-trend` and `--tsvd 0.999` (loops, borders) on the example blocks: per-block raw tables
   inter_detect.npz      pattern_detector in detect mode on six inter-chromosomal blocks of the yeast map (median scaling)
   nonfinite.npz         normxcorr2 on maps with one NaN / +inf / -inf pixel (sparse + mask, dense): the windows that
                         hold the pixel are 0, the others as if it were 0
@@ -330,6 +331,45 @@ def make_inter_detect():
     np.savez_compressed(HERE / "inter_detect.npz", **out)
 
 
+def make_options():
+    """`detect --smooth-trend` and `detect --tsvd` on the three blocks of data_test/example.cool, loops and borders, per-block
+    raw tables: smooth = the isotonic fit of the distance law (preprocessing.py:192-195) inside detrend (contacts_map.py:603-621);
+    tsvd = 0.999, the CLI's value (cli/chromosight.py:308, 644), through pattern_detector."""
+    cool = dict(np.load(HERE / "example_cool.npz", allow_pickle=True))
+    binsize = int(cool["binsize"])
+    off = cool["chrom_offset"]
+    det_all = np.flatnonzero(np.isfinite(cool["weight"]))
+    configs = {
+        "loops": (dict(pearson=0.3, max_perc_undetected=50.0, max_perc_zero=10.0, max_dist=2000000, min_dist=20000,
+                       min_separation=5000, max_iterations=1), [LOOPS]),
+        "borders": (dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+                         min_separation=5000, max_iterations=1), BORDERS),
+    }
+    out = {}
+    for name, (cfg, kernels) in configs.items():
+        max_dist = max(cfg["max_dist"] // binsize, 1)
+        largest = max(k.shape[0] for k in kernels)
+        for ci in range(len(off) - 1):
+            s, e = off[ci], off[ci + 1]
+            det = det_all[(det_all >= s) & (det_all < e)] - s
+            block = balanced_block(cool, ci, ci)
+            n = block.shape[0]
+            keep = min(max_dist, n) + largest
+            plain, _, _ = prepare_intra(block, det, max_dist, largest)
+            smooth = cup.detrend(block, max_dist=keep, smooth=True, detectable_bins=det, max_val=10)
+            smooth = cup.diag_trim(smooth.tocsr(), keep)
+            smooth.data[np.isnan(smooth.data)] = 0
+            smooth.eliminate_zeros()
+            for ki, kern in enumerate(kernels):
+                for tag, m, tsvd in (("smooth", smooth, None), ("tsvd", plain, 0.999)):
+                    cmap = RefMap(m.copy(), (det.copy(), det.copy()), max_dist, False)
+                    tab, _ = cud.pattern_detector(cmap, cfg, kern, full=True, tsvd=tsvd)
+                    key = f"{name}_{tag}_c{ci}_k{ki}"
+                    out[key] = np.zeros((0, 4)) if tab is None else tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+                    print("options", key, out[key].shape)
+    np.savez_compressed(HERE / "options.npz", **out)
+
+
 def make_nonfinite():
     """normxcorr2 on maps that hold a NaN / an infinite pixel (API misuse: chromosight's own maps are zeroed first,
     contacts_map.py:539-540): every window that holds the pixel comes out 0 (detection.py:1088-1101), the others as if the
@@ -363,6 +403,6 @@ def make_nonfinite():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect"]
+    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect", "options"]
     for name in which:
         globals()[f"make_{name}"]()

@@ -332,3 +332,36 @@ def test_inter_detect_matches_reference(golden, precision):
         assert total > 2000
     finally:
         chromosight_amd.set_precision("f32")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_smooth_trend_and_tsvd_match_reference(golden, precision):
+    """`detect --smooth-trend` (isotonic fit of the distance law inside the detrend) and `detect --tsvd` (0.999, the CLI's value)
+    on the three example blocks, loops and the three borders templates: per-block raw tables captured from the reference
+    (tests/golden/options.npz) -- same patterns in the same order, scores to 1e-9."""
+    g = golden("options")
+    dcool = pipeline.DeviceCool(golden("example_cool"))
+    chromosight_amd.set_precision(precision)
+    try:
+        total = 0
+        for name in ("loops", "borders"):
+            cfg = copy.deepcopy(getattr(ck, name))
+            max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
+            kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+            largest = max(k.shape[0] for k in kernels)
+            for ci in range(dcool.n_chrom):
+                plain = dcool.stage_intra(ci, max_dist, largest, resident=True)
+                smooth = dcool.stage_intra(ci, max_dist, largest, smooth=True, resident=True)
+                for ki, kern in enumerate(kernels):
+                    for tag, blk, tsvd in (("smooth", smooth, None), ("tsvd", plain, 0.999)):
+                        want = g[f"{name}_{tag}_c{ci}_k{ki}"]
+                        tab, _ = pipeline.detect_block(dcool, blk, cfg, kern, tsvd=tsvd, raw=True)
+                        got = np.zeros((0, 4)) if tab is None else tab
+                        assert got.shape == want.shape, (name, tag, ci, ki, got.shape, want.shape)
+                        if len(want):
+                            assert np.array_equal(got[:, :2], want[:, :2]), (name, tag, ci, ki)
+                            assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9, (name, tag, ci, ki)
+                        total += len(want)
+        assert total > 400
+    finally:
+        chromosight_amd.set_precision("f32")

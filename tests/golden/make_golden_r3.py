@@ -20,6 +20,7 @@
                         reference's own per-template tables of yeast_quantify.npz: best of the templates
                         per coordinate, bin columns from start1 / start2, q-values, output order; some
                         intervals are three bins wide so that bin1 / bin2 differ from the scored midpoints
+  resize.npz            resize_kernel / crop_kernel of the built-in templates (factors, resolutions, target sizes)
   options.npz           `detect --smooth-trend` and `--tsvd 0.999` (loops, borders) on the example blocks: per-block raw tables
   inter_detect.npz      pattern_detector in detect mode on six inter-chromosomal blocks of the yeast map (median scaling)
   nonfinite.npz         normxcorr2 on maps with one NaN / +inf / -inf pixel (sparse + mask, dense): the windows that
@@ -370,6 +371,25 @@ def make_options():
     np.savez_compressed(HERE / "options.npz", **out)
 
 
+def make_resize():
+    """resize_kernel / crop_kernel (preprocessing.py:679-807: what --win-size and a resolution other than the template's do to
+    the templates before the hot path sees them): the reference's outputs for the built-in templates."""
+    out = {}
+    kernels = {"loops": LOOPS, "borders0": BORDERS[0], "borders2": BORDERS[2], "hairpin": HAIRPIN}
+    for name, kern in kernels.items():
+        for fi, factor in enumerate((0.3, 0.5, 0.65, 0.8, 1.0, 1.2, 1.7, 2.5)):
+            out[f"{name}_factor{fi}"] = cup.resize_kernel(kern, factor=factor, quiet=True)
+            out[f"{name}_factor{fi}_value"] = np.float64(factor)
+        for ri, (kres, sres) in enumerate(((2000, 1000), (2000, 5000), (10000, 3200), (5000, 640))):
+            out[f"{name}_res{ri}"] = cup.resize_kernel(kern, kernel_res=kres, signal_res=sres, quiet=True)
+            out[f"{name}_res{ri}_value"] = np.array([kres, sres])
+        for ti, target in enumerate(((11, 11), (7, 7), (13, 9), (3, 3), (17, 17))):
+            out[f"{name}_crop{ti}"] = cup.crop_kernel(kern, target)
+            out[f"{name}_crop{ti}_value"] = np.array(target)
+    np.savez_compressed(HERE / "resize.npz", **out)
+    print("resize.npz written", len(out))
+
+
 def make_nonfinite():
     """normxcorr2 on maps that hold a NaN / an infinite pixel (API misuse: chromosight's own maps are zeroed first,
     contacts_map.py:539-540): every window that holds the pixel comes out 0 (detection.py:1088-1101), the others as if the
@@ -403,6 +423,6 @@ def make_nonfinite():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect", "options"]
+    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect", "options", "resize"]
     for name in which:
         globals()[f"make_{name}"]()

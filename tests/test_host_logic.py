@@ -492,3 +492,28 @@ def test_accept_records_rejects_bad_arguments():
     assert lib.cs_accept_records(*args(np.array([-1], dtype=np.int64), 17)) != 0
     assert lib.cs_accept_records(*args(np.array([4], dtype=np.int64), 0)) != 0
     assert lib.cs_accept_records(*args(np.array([4], dtype=np.int64), 17)) == 0
+
+
+def test_resize_and_crop_kernel_match_the_reference(golden):
+    """resize_kernel / crop_kernel against the reference's outputs for the built-in templates (tests/golden/resize.npz:
+    8 factors, 4 resolution pairs, 5 crop targets each): what --win-size and another resolution feed the hot path."""
+    from chromosight_amd.utils import preprocessing as cup
+    import chromosight_amd.kernels as ck
+    g = golden("resize")
+    kernels = {"loops": ck.loops["kernels"][0], "borders0": ck.borders["kernels"][0], "borders2": ck.borders["kernels"][2],
+               "hairpin": ck.hairpins["kernels"][0]}
+    checked = 0
+    for name, kern in kernels.items():
+        kern = np.asarray(kern, dtype=np.float64)
+        for key in [k for k in g if k.startswith(name + "_") and not k.endswith("_value")]:
+            value = g[key + "_value"]
+            if "_factor" in key:
+                got = cup.resize_kernel(kern, factor=float(value), quiet=True)
+            elif "_res" in key:
+                got = cup.resize_kernel(kern, kernel_res=int(value[0]), signal_res=int(value[1]), quiet=True)
+            else:
+                got = cup.crop_kernel(kern, (int(value[0]), int(value[1])))
+            assert got.shape == g[key].shape, (key, got.shape, g[key].shape)
+            assert np.abs(got - g[key]).max() < 1e-12, key
+            checked += 1
+    assert checked == 4 * 17

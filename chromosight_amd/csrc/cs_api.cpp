@@ -280,6 +280,7 @@ int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeight
     const int kk = km * kn;
     const size_t n_floats = key.size() / 4;
     if (kk <= 0 || n_floats < (size_t)kk) return fail(ctx, CS_ERR_INVALID, "weights missing for the matrix-core kernel");
+    if (km > 17 || kn > 17) return fail(ctx, CS_ERR_INVALID, "the matrix-core weight image holds templates of up to 17 x 17");
     const int nsets = (int)std::min<size_t>(3, n_floats / kk);
     constexpr size_t kImage = 3 * 17 * 2 * 1024;
     if (!ctx->d_wfrag) CS_HIP(ctx, hipMalloc(&ctx->d_wfrag, kImage));
@@ -2095,6 +2096,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     if (all_narrow && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW"))
         return cs_detect_foci_batch(ctx, stream_, n_blocks, signals, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
     if (params[0].compute_dtype != CS_F32) return fail(ctx, CS_ERR_UNSUPPORTED, "the 2-D batch runs the float32 tile kernel");
+    if (kernel->km != kernel->kn || kernel->km > 17 || kernel->km < 3 || !(kernel->km & 1))
+        return fail(ctx, CS_ERR_UNSUPPORTED, "the masked tile kernel takes odd square templates of 3 .. 17 (caller: block by block)");
     // results straight into page-locked caller buffers (cs_host_alloc)
     auto device_view = [&](const void* h) -> void* {
         if (!h) return nullptr;

@@ -774,19 +774,34 @@ def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=
                                      want_windows=want_windows, raw=True, stream=stream, defer=True, merged=True)
 
 
+def with_win_size(kernel_config, win_size):
+    """--win-size of the reference's CLI (cli/chromosight.py:365-370, 689-695): every template of the
+    config resized to win_size x win_size (odd), "auto" / None keeps the config's own sizes."""
+    if win_size is None or win_size == "auto":
+        return kernel_config
+    win_size = int(win_size)
+    if not win_size % 2:
+        raise ValueError("--win-size must be odd")
+    cfg = dict(kernel_config)
+    cfg["kernels"] = [preproc.resize_kernel(np.asarray(k, dtype=np.float64), factor=win_size / np.shape(k)[0], quiet=True)
+                      for k in kernel_config["kernels"]]
+    return cfg
+
+
 def sub_matrices(dcool, inter):
     """(chrom a, chrom b) of every sub-matrix in the reference's order (contacts_map.py:274-312)."""
     return [(a, b) for a in range(dcool.n_chrom) for b in range(dcool.n_chrom) if a == b or (a < b and inter)]
 
 
 def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, inter=False, subsample=None, seed=0,
-           return_windows=False):
+           return_windows=False, win_size=None):
     """`chromosight detect` (balanced matrix) on a decoded cool (dict) or a DeviceCool; options
     --inter, --smooth-trend, --tsvd, --subsample (seeded), --iterations through the config.  Every
     block is staged once in HBM (distance law, detrend, band / median scaling) and stays resident
     across templates and iterations; each (block, template) is one native call.
     Returns the output table (same columns and row order as the reference's <prefix>.tsv); with
     return_windows also the windows of its rows (what the reference saves as <prefix>.json / .npy)."""
+    kernel_config = with_win_size(kernel_config, win_size)
     dcool = cool if isinstance(cool, DeviceCool) else DeviceCool(cool)
     if subsample is not None:
         dcool = dcool.subsampled(subsample, seed=seed, inter=inter)
@@ -878,7 +893,7 @@ def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end, 
 
 
 def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=None, seed=0, smooth=False,
-             max_dist_bp=None):
+             max_dist_bp=None, win_size=None):
     """`chromosight quantify` (cli/chromosight.py:264-470): score the given 2-D positions with every
     template of the config and keep, per position, the row the reference keeps (sorted by score,
     last of each (chrom1, start1, chrom2, start2) group).  `positions`: DataFrame with chrom1, start1,
@@ -886,7 +901,7 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     dcool = cool if isinstance(cool, DeviceCool) else DeviceCool(cool)
     if subsample is not None:
         dcool = dcool.subsampled(subsample, seed=seed, inter=inter)
-    cfg = dict(kernel_config)
+    cfg = dict(with_win_size(kernel_config, win_size))
     bed2d = positions.loc[:, ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]].reset_index(drop=True).copy()
     furthest = np.max(bed2d.start2 - bed2d.start1)
     cfg["max_dist"] = min(furthest, dcool.n_bins * dcool.binsize)       # scan up to the furthest pattern

@@ -239,6 +239,37 @@ def test_genomes_with_very_short_chromosomes_vs_oracle_pipeline(sizes, md, seed)
     assert total > 50
 
 
+@pytest.mark.parametrize("win", [9, 13, 23, 33])
+def test_win_size_templates_vs_oracle_pipeline(win):
+    """--win-size (cli/chromosight.py:689-695): every template resized (order-1 spline, pipeline.with_win_size) before the
+    scan; templates smaller and larger than the built-in ones through the same chains == the CPU pipeline of the oracles.
+    (Templates above 17 x 17 leave the masked tile kernel: the many-blocks entry once built the matrix-core weight image for
+    them anyway and wrote past its host buffer -- a crash at --win-size >= 19 with a 2-D pattern; now it answers
+    "unsupported" and the blocks take the per-block calls.)"""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    sizes = [3000, 1200, 500, 30]
+    cool, _ = make_cool(sum(sizes), 200, 2000, seed=310 + win, template=template, chrom_sizes=sizes)
+    dcool = pipeline.DeviceCool(cool)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    cfgs = [pipeline.with_win_size(c, win) for c in (loops, copy.deepcopy(ck.borders), copy.deepcopy(ck.hairpins))]
+    assert all(np.shape(k) == (win, win) for c in cfgs for k in c["kernels"])
+    recs = parallel.detect_patterns(dcool, cfgs, staged=parallel.stage_genome(dcool, cfgs))
+    total = 0
+    for cfg, rec in zip(cfgs, recs):
+        mdc = max(cfg["max_dist"] // 2000, 1)
+        kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+        for ci in range(dcool.n_chrom):
+            for ki, tab in enumerate(oracle_block_tables(cool, ci, cfg, mdc, kernels, 2000)):
+                got = rec[(rec[:, 0] == ci) & (rec[:, 5] == ki)]
+                assert got.shape[0] == tab.shape[0], (cfg["name"], ci, ki, got.shape[0], tab.shape[0])
+                if tab.shape[0]:
+                    assert np.array_equal(got[:, 1:3], tab[:, :2]), (cfg["name"], ci, ki)
+                    assert np.abs(got[:, 3] - tab[:, 2]).max() < 1e-9, (cfg["name"], ci, ki)
+                total += tab.shape[0]
+    assert total > 20
+
+
 def test_c4_genome_200k_vs_oracle_pipeline():
     """C4 of BASELINE.md at full size: 200 000 bins, 23 blocks, max_dist 1000, loops + 3 borders
     templates; every pattern table equal to the CPU oracle pipeline's (coordinates bit-exact and in

@@ -517,3 +517,21 @@ def test_resize_and_crop_kernel_match_the_reference(golden):
             assert np.abs(got - g[key]).max() < 1e-12, key
             checked += 1
     assert checked == 4 * 17
+
+
+def test_win_size_option_resizes_every_template():
+    """--win-size (cli/chromosight.py:365-370, 689-695): every template resized to win_size / its own size, even sizes
+    rejected, "auto" / None leaves the config alone; the caller's config is not modified."""
+    import chromosight_amd.kernels as ck
+    from chromosight_amd import pipeline
+    cfg = dict(ck.borders)
+    before = [np.array(k) for k in cfg["kernels"]]
+    assert pipeline.with_win_size(cfg, None) is cfg and pipeline.with_win_size(cfg, "auto") is cfg
+    for win in (9, "11", 21):
+        out = pipeline.with_win_size(cfg, win)
+        assert [np.shape(k) for k in out["kernels"]] == [(int(win), int(win))] * len(before)
+        for k, src in zip(out["kernels"], before):
+            assert np.array_equal(k, cup.resize_kernel(src.astype(np.float64), factor=int(win) / src.shape[0], quiet=True))
+    assert all(np.array_equal(a, b) for a, b in zip(before, cfg["kernels"]))
+    with pytest.raises(ValueError):
+        pipeline.with_win_size(cfg, 10)

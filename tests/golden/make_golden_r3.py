@@ -20,6 +20,7 @@
                         reference's own per-template tables of yeast_quantify.npz: best of the templates
                         per coordinate, bin columns from start1 / start2, q-values, output order; some
                         intervals are three bins wide so that bin1 / bin2 differ from the scored midpoints
+  winsize.npz           detect --win-size 9 / 21 (loops) and 23 (borders) on the example blocks, per-block raw tables
   resize.npz            resize_kernel / crop_kernel of the built-in templates (factors, resolutions, target sizes)
   options.npz           `detect --smooth-trend` and `--tsvd 0.999` (loops, borders) on the example blocks: per-block raw tables
   inter_detect.npz      pattern_detector in detect mode on six inter-chromosomal blocks of the yeast map (median scaling)
@@ -371,6 +372,42 @@ def make_options():
     np.savez_compressed(HERE / "options.npz", **out)
 
 
+def make_winsize():
+    """`detect --win-size W` (cli/chromosight.py:689-695: every template through resize_kernel(factor=W / size) before the
+    genome is split, so the kept distance grows with the template) on the three blocks of data_test/example.cool: loops at
+    9 / 21 and borders at 23, per-block raw tables through pattern_detector."""
+    cool = dict(np.load(HERE / "example_cool.npz", allow_pickle=True))
+    binsize = int(cool["binsize"])
+    off = cool["chrom_offset"]
+    det_all = np.flatnonzero(np.isfinite(cool["weight"]))
+    configs = {
+        "loops9": (dict(pearson=0.3, max_perc_undetected=50.0, max_perc_zero=10.0, max_dist=2000000, min_dist=20000,
+                        min_separation=5000, max_iterations=1), [LOOPS], 9),
+        "loops21": (dict(pearson=0.3, max_perc_undetected=50.0, max_perc_zero=10.0, max_dist=2000000, min_dist=20000,
+                         min_separation=5000, max_iterations=1), [LOOPS], 21),
+        "borders23": (dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+                           min_separation=5000, max_iterations=1), BORDERS, 23),
+    }
+    out = {}
+    for name, (cfg, kernels, win) in configs.items():
+        kernels = [cup.resize_kernel(np.asarray(k, dtype=np.float64), factor=win / k.shape[0], quiet=True) for k in kernels]
+        assert all(k.shape == (win, win) for k in kernels)
+        max_dist = max(cfg["max_dist"] // binsize, 1)
+        largest = max(k.shape[0] for k in kernels)
+        for ci in range(len(off) - 1):
+            s, e = off[ci], off[ci + 1]
+            det = det_all[(det_all >= s) & (det_all < e)] - s
+            block = balanced_block(cool, ci, ci)
+            plain, _, _ = prepare_intra(block, det, max_dist, largest)
+            for ki, kern in enumerate(kernels):
+                cmap = RefMap(plain.copy(), (det.copy(), det.copy()), max_dist, False)
+                tab, _ = cud.pattern_detector(cmap, cfg, kern, full=True)
+                key = f"{name}_c{ci}_k{ki}"
+                out[key] = np.zeros((0, 4)) if tab is None else tab[["bin1", "bin2", "score", "pvalue"]].to_numpy(dtype=np.float64)
+                print("winsize", key, out[key].shape)
+    np.savez_compressed(HERE / "winsize.npz", **out)
+
+
 def make_resize():
     """resize_kernel / crop_kernel (preprocessing.py:679-807: what --win-size and a resolution other than the template's do to
     the templates before the hot path sees them): the reference's outputs for the built-in templates."""
@@ -423,6 +460,6 @@ def make_nonfinite():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect", "options", "resize"]
+    which = sys.argv[1:] or ["iterations", "nonsquare", "yeast_detect", "quantify_select", "nonfinite", "inter_detect", "options", "resize", "winsize"]
     for name in which:
         globals()[f"make_{name}"]()

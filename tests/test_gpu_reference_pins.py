@@ -365,3 +365,34 @@ def test_smooth_trend_and_tsvd_match_reference(golden, precision):
         assert total > 400
     finally:
         chromosight_amd.set_precision("f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_win_size_matches_reference(golden, precision):
+    """`detect --win-size` (cli/chromosight.py:689-695) on the three example blocks: loops resized to 9 and 21, the borders
+    templates to 23 (pipeline.with_win_size), blocks staged with the resized template's keep distance: per-block raw tables
+    captured from the reference (tests/golden/winsize.npz) -- same patterns in the same order, scores to 1e-9."""
+    g = golden("winsize")
+    dcool = pipeline.DeviceCool(golden("example_cool"))
+    chromosight_amd.set_precision(precision)
+    try:
+        total = 0
+        for name, pattern, win in (("loops9", "loops", 9), ("loops21", "loops", 21), ("borders23", "borders", 23)):
+            cfg = pipeline.with_win_size(copy.deepcopy(getattr(ck, pattern)), win)
+            max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
+            kernels = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
+            for ci in range(dcool.n_chrom):
+                blk = dcool.stage_intra(ci, max_dist, win, resident=True)
+                for ki, kern in enumerate(kernels):
+                    want = g[f"{name}_c{ci}_k{ki}"]
+                    tab, _ = pipeline.detect_block(dcool, blk, cfg, kern, raw=True)
+                    got = np.zeros((0, 4)) if tab is None else tab
+                    assert got.shape == want.shape, (name, ci, ki, got.shape, want.shape)
+                    if len(want):
+                        assert np.array_equal(got[:, :2], want[:, :2]), (name, ci, ki)
+                        assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9, (name, ci, ki)
+                    total += len(want)
+        assert total > 500
+    finally:
+        chromosight_amd.set_precision("f32")

@@ -211,7 +211,9 @@ def test_synthetic_genome_small_vs_oracle_pipeline(seed):
 
 
 @pytest.mark.parametrize("sizes,md,seed", [([12, 36, 400, 400], 400, 101), ([900, 60, 400, 36, 36, 400, 19, 60], 40, 121),
-                                           ([2500, 19, 400, 12, 150], 1, 123), ([36, 36, 900, 150], 150, 122)])
+                                           ([2500, 19, 400, 12, 150], 1, 123), ([36, 36, 900, 150], 150, 122),
+                                           # a draft assembly: 240 contigs of 20 .. 160 bins (240 blocks in every batch entry)
+                                           ([20 + (37 * i * i + 11 * i) % 141 for i in range(240)], 60, 131)])
 def test_genomes_with_very_short_chromosomes_vs_oracle_pipeline(sizes, md, seed):
     """Chromosomes of a few dozen bins next to long ones (the long form: tools/fuzz_genomes.py): blocks not larger than the
     template are skipped, blocks short enough to be staged dense take the per-block calls -- where, in float32 mode, a 1-D

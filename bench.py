@@ -604,21 +604,26 @@ def main():
         }
     extras = {}
 
-    def bail_out():
+    def bail_out(why=None):
         if rank == 0:
             line = dict(head)
             line.update(extras)
-            line["extras_note"] = f"a reported extra did not finish within {EXTRAS_TIMEOUT_S} s; the line was printed without it"
+            line["extras_note"] = why or f"a reported extra did not finish within {EXTRAS_TIMEOUT_S} s; the line was printed without it"
             sys.stdout.write(json.dumps(line) + "\n")
             sys.stdout.flush()
         os._exit(0)
 
     watchdog = None
     if world > 1 and not args.no_cpu_baseline:
+        import signal
         import threading
         watchdog = threading.Timer(EXTRAS_TIMEOUT_S, bail_out)
         watchdog.daemon = True
         watchdog.start()
+        # the launcher ends the other ranks with SIGTERM when one of them dies inside an extra: the measured headline
+        # line still leaves rank 0
+        signal.signal(signal.SIGTERM, lambda *_: bail_out("a rank ended inside a reported extra (SIGTERM from the launcher); "
+                                                          "the line was printed without it"))
 
     # the north-star configuration next to the headline one, kernel only, at every N (each rank its own 200 000-bin
     # block: weak scaling like `value`): C4' = one 200 000-bin block, band to 1000 bins, masks, full mode
@@ -652,6 +657,7 @@ def main():
             genome = {"error": repr(exc)}
     if watchdog is not None:
         watchdog.cancel()
+        signal.signal(signal.SIGTERM, signal.SIG_DFL)
 
     if rank == 0:
         out = dict(head)

@@ -4,11 +4,14 @@ float32 screen reports the patterns of the float64 mode (same coordinates, score
 usage: python tools/fuzz_detect_options.py [n_combinations] [seed]"""
 import copy
 import itertools
+import os
 import random
 import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import chromosight_amd
 import chromosight_amd.kernels as ck

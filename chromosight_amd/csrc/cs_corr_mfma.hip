@@ -43,6 +43,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float cand_range_guard(float r, float s2, float unscale, const KernelStats<float>& K);
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte global access at 4-byte alignment (band rows)
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 constexpr int MF_T = 64;                      // output tile edge
 constexpr int MF_R = 80;                      // staged rows / columns (tile + 16)
@@ -55,14 +57,26 @@ constexpr int MF_PER_THREAD = (MF_R * MF_R) / 256;   // 25 staged pixels per thr
 
 static_assert(5 * MF_SCR_PLANE * 4 <= MF_WSET, "scratch aliases the weight region");
 
+// Ablation switches of the persistent kernels (CHROMOSIGHT_HIP_MFMA_DBG: skip a phase, results garbage) exist only in
+// builds with -DCS_MF_DEBUG: in the product build the word would be one more live scalar and a branch per phase.
+#ifdef CS_MF_DEBUG
+#define MFD_DBG(bit) (A.dbg & (bit))
+#else
+#define MFD_DBG(bit) (false)
+#endif
+
 #ifdef CS_MF_PROFILE
+// Per-phase cycle stamps of thread 0 of every workgroup.  The persistent kernels accumulate in LDS (prof_lds, 16 words
+// behind the kernel's own LDS) and add their totals to the device counters once, when the workgroup ends: one global
+// atomic per stamp and tile from 512 workgroups on the same six words cost more than the phases they measured.
 __device__ unsigned long long cs_mf_prof[16];
 #define MF_STAMP(k)                                                        \
     do {                                                                   \
         const unsigned long long now_ = __builtin_readcyclecounter();      \
-        if (tid == 0) atomicAdd(&cs_mf_prof[k], now_ - tprev_);            \
+        if (tid == 0) MF_PROF_ADD(k, now_ - tprev_);                       \
         tprev_ = now_;                                                     \
     } while (0)
+#define MF_PROF_ADD(k, v) atomicAdd(&cs_mf_prof[k], (unsigned long long)(v))
 #else
 #define MF_STAMP(k)
 #endif
@@ -426,6 +440,12 @@ constexpr int MFD_CFL = MFD_COL + 2 * 3 * 64 * 4;
 constexpr int MFD_CFB = MFD_CFL + 2 * 16;              // (CFL: the 80 column flags as 3 mask words per slot) raw flag bytes as they arrive
 constexpr int MFD_SMEM_REG = MFD_CFB + 2 * 128;
 static_assert(MFD_SMEM_REG <= 80 * 1024, "two workgroups per CU");
+#ifdef CS_MF_PROFILE
+constexpr int MFD_PROF = MFD_SMEM_REG;             // 16 x 8 bytes of per-workgroup phase counters
+constexpr int MFD_LAUNCH_EXTRA = 128;
+#else
+constexpr int MFD_LAUNCH_EXTRA = 0;
+#endif
 
 __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b)
 {
@@ -757,7 +777,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
             int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
             if (A.grid_cap > 0 && grid_r > A.grid_cap) grid_r = std::max(8, A.grid_cap & ~7);     // (multiples of 8: XCD-contiguous ranges)
-            hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG, stream, D);
+            hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, D);
             return (int)hipGetLastError();
         }
         if (!A.out.ptr) return -5;
@@ -771,8 +791,8 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         if (e2 != hipSuccess) return (int)e2;
         const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
         const int grid = (int)std::min<long long>(blocks, (long long)per_cu * A.n_cu);
-        if (vec4) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, false>), dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
-        else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), MFD_SMEM, stream, D);
+        if (vec4) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
+        else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
         return (int)hipGetLastError();
     }
     if (!A.out.ptr) return -5;                   // (a candidate sink without a map: only the masked tile kernel serves that)
@@ -800,7 +820,7 @@ int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_ca
     const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
     int grid = (int)std::min<long long>(D.n_tiles, (long long)per_cu * n_cu);
     if (grid_cap > 0 && grid > grid_cap) grid = std::max(8, grid_cap & ~7);
-    hipLaunchKernelGGL(kr, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG, stream, D);
+    hipLaunchKernelGGL(kr, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, D);
     return (int)hipGetLastError();
 }
 
@@ -829,8 +849,8 @@ int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym
     if (e != hipSuccess) return (int)e;
     const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
     const int grid = std::max(8, (int)std::min<long long>((total + 7) / 8 * 8, (long long)per_cu * n_cu) & ~7);
-    if (rsym) hipLaunchKernelGGL(corr_mfma_blocks_kernel<true>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG, stream, T);
-    else hipLaunchKernelGGL(corr_mfma_blocks_kernel<false>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG, stream, T);
+    if (rsym) hipLaunchKernelGGL(corr_mfma_blocks_kernel<true>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, T);
+    else hipLaunchKernelGGL(corr_mfma_blocks_kernel<false>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, T);
     return (int)hipGetLastError();
 }
 

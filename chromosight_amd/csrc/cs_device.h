@@ -388,7 +388,7 @@ __device__ __forceinline__ float cand_screen_masked(float r, float cs, float s1,
     if (K.zk_possible) {
         const float km_ = fmaf(K.kmean, nm, ka);
         const float k2m = kb + 2.0f * K.kmean * ka + K.kmean * K.kmean * nm;
-        keep &= (nm < 0.5f) || ((fabsf(km_) >= K.thr * kCandGuard) && (fabsf(k2m) >= K.thr * kCandGuard));
+        keep &= (bool)((int)(nm < 0.5f) | ((int)(fabsf(km_) >= K.thr * kCandGuard) & (int)(fabsf(k2m) >= K.thr * kCandGuard)));
     }
     const float out = keep ? r : 2.0f;
     return ((int)(s2 > 0.0f) & (int)(np >= K.cut)) ? out : 0.0f;
@@ -431,7 +431,7 @@ __device__ __forceinline__ float pearson_masked_core(float cs, float s1, float s
     if (K.zk_possible) {
         const float km_ = fmaf(K.kmean, nm, ka);
         const float k2m = kb + 2.0f * K.kmean * ka + K.kmean * K.kmean * nm;
-        normal &= (nm < 0.5f) || ((fabsf(km_) >= K.thr) && (fabsf(k2m) >= K.thr));
+        normal &= (bool)((int)(nm < 0.5f) | ((int)(fabsf(km_) >= K.thr) & (int)(fabsf(k2m) >= K.thr)));     // (no short circuits: no branches)
     }
     rare = !normal;
     if (CAND > 0 || (CAND < 0 && K.cand_cmin > 0.0f)) {  // wave-uniform

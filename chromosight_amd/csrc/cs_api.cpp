@@ -75,6 +75,7 @@ struct cs_ctx {
     size_t d_ws_bytes = 0;
     // matrix-core kernel: the float32 weight sets as float16 head / tail Toeplitz fragments
     void* d_wfrag = nullptr;
+    void* d_rim = nullptr;          // rim tables of the mask weight sets (cs_launch.h MfmaWeights::rim), same key as d_wfrag
     std::vector<unsigned char> wfrag_key;     // the float32 weights the image was built from
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
@@ -312,12 +313,49 @@ int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeight
                     }
         }
         CS_HIP(ctx, hipMemcpyAsync(ctx->d_wfrag, img.data(), kImage, hipMemcpyHostToDevice, stream));
-        CS_HIP(ctx, hipStreamSynchronize(stream));    // pageable source dies here
+        // rim tables of the two mask weight sets (cs_launch.h MfmaWeights::rim), square templates only
+        std::vector<float> rim(cs::kRimFloats, 0.0f);
+        if (nsets == 3 && km == kn) {
+            const int K = km;
+            for (int set = 0; set < 2; ++set) {
+                const float* ws = w + (1 + set) * kk;
+                for (int r = 0; r < K; ++r) {
+                    double sp = 0.0, sq = 0.0;
+                    for (int m = 0; m <= K; ++m) {
+                        rim[cs::kRimPW + (set * 17 + r) * 18 + m] = (float)sp;
+                        rim[cs::kRimQW + (set * 17 + r) * 18 + m] = (float)sq;
+                        if (m < K) {
+                            sp += ws[r * K + m];
+                            sq += ws[m * K + r];
+                        }
+                    }
+                    for (int c = 0; c < K; ++c) rim[cs::kRimW + set * 289 + r * 17 + c] = ws[r * K + c];
+                }
+            }
+            for (int D = 0; D < K - 1; ++D) {          // the whole lower triangle of diagonal D: row ki has its first ki - D pixels in it
+                double n = 0.0, a = 0.0, b = 0.0;
+                for (int ki = 0; ki < K; ++ki) {
+                    const int L = std::min(K, std::max(0, ki - D));
+                    n += L;
+                    for (int kj = 0; kj < L; ++kj) {
+                        a += w[kk + ki * K + kj];
+                        b += w[2 * kk + ki * K + kj];
+                    }
+                }
+                rim[cs::kRimBase + 0 * 17 + D] = (float)n;
+                rim[cs::kRimBase + 1 * 17 + D] = (float)a;
+                rim[cs::kRimBase + 2 * 17 + D] = (float)b;
+            }
+        }
+        if (!ctx->d_rim) CS_HIP(ctx, hipMalloc(&ctx->d_rim, sizeof(float) * cs::kRimFloats));
+        CS_HIP(ctx, hipMemcpyAsync(ctx->d_rim, rim.data(), sizeof(float) * cs::kRimFloats, hipMemcpyHostToDevice, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));    // pageable sources die here
         ctx->wfrag_key = key;
         ctx->wfrag_km = km;
         ctx->wfrag_kn = kn;
     }
     E->frag = reinterpret_cast<const uint4*>(ctx->d_wfrag);
+    E->rim = reinterpret_cast<const float*>(ctx->d_rim);
     for (int set = 0; set < 3; ++set) E->unscale[set] = ctx->wfrag_unscale[set];
     return CS_OK;
 }
@@ -409,10 +447,11 @@ void fill_grid(cs::CorrArgs<TC>& A, int tw, int th, bool aligned_x = true)
 // Decide whether the factorised per-bin mask path applies and, if so, build its tables in the
 // context's scratch buffer (cs_mask_prep.hip).  K = template size served by a streaming kernel.
 template <typename TC>
-int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t stream)
+int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t stream, bool rim_in_kernel = false)
 {
     A.reg_mode = 0;
     A.fix_on = 0;
+    A.rim_in_kernel = 0;
     if (std::getenv("CHROMOSIGHT_HIP_DEBUG"))
         fprintf(stderr, "[chromosight_hip] mask_mode=%d full=%d sym_upper=%d ms=%d ns=%d out_layout=%d out_lo=%d out_hi=%d max_dist=%d\n",
                 A.mask_mode, A.full, A.sym_upper, A.ms, A.ns, A.out.layout, A.out_lo, A.out_hi, A.max_dist);
@@ -449,8 +488,12 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     const int top = KH;
     auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };   // elements
     const size_t n_row = align((size_t)A.ms * 4 + 64), n_col = align(3 * (size_t)A.ns);
-    const size_t n_lo = edge_tables ? align((size_t)A.ms * (K - 1) * 4) : 0;
-    const size_t n_hi = edge_tables ? align((size_t)A.ms * hi_w * 4 + 4) : 0;
+    // (rim_in_kernel: the masked matrix-core tile kernel forms the corrections of the edge diagonals itself)
+    // ... when the two edge ranges hold at most 16 diagonals each and lie more than the 79 diagonals of a wave's
+    // 16 rows x 64 columns apart (its epilogue handles one range per wave); narrow bands keep the records
+    const bool edge_records = edge_tables && !(rim_in_kernel && K - 1 <= 16 && hi_w <= 16 && hi_d0 >= 96);
+    const size_t n_lo = edge_records ? align((size_t)A.ms * (K - 1) * 4) : 0;
+    const size_t n_hi = edge_records ? align((size_t)A.ms * hi_w * 4 + 4) : 0;
     const size_t n_frows = align((size_t)(top + A.ms - bot0) * width * 4);
     const size_t n_fcols = side ? align((size_t)A.ms * 2 * side * 4) : 0;
     const size_t bytes = (n_row + n_col + n_lo + n_hi + n_frows + n_fcols) * sizeof(TC);
@@ -480,6 +523,7 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     P.rowtab = rowtab;
     P.coltab = coltab;
     P.edge = edge_tables ? 1 : 0;
+    P.skip_edge = edge_records ? 0 : 1;
     P.hi_d0 = hi_d0;
     P.hi_w = hi_w;
     P.fix_lo = fix_lo;
@@ -495,6 +539,7 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     int rc = cs::launch_mask_prep<TC>(P, stream);
     if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
     if (edge_tables) A.fix_on = 1;
+    A.rim_in_kernel = (edge_tables && !edge_records) ? 1 : 0;
     A.reg_mode = 1;
     A.rowtab = rowtab;
     A.coltab = coltab;
@@ -554,7 +599,10 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
             A.out_lo = std::max(A.out_lo, A.cand_dlo);
             A.out_hi = std::min(A.out_hi, A.cand_dhi);
         }
-        rc = prepare_regular_mask<float>(ctx, A, A.km, stream);
+        // (the mirrored-row instance of the tile kernel forms the corrections of the edge diagonals itself: no records)
+        const bool rim_in_kernel = A.w_sym && A.km == 17 && A.kn == 17 && !std::getenv("CHROMOSIGHT_HIP_MFMA_NORSYM") &&
+                                   !std::getenv("CHROMOSIGHT_HIP_RIM_RECORDS");
+        rc = prepare_regular_mask<float>(ctx, A, A.km, stream, rim_in_kernel);
         if (rc != CS_OK) return rc;
         if (A.reg_mode == 1 && A.sig_is_f64) {
             // float64 container (the pipeline keeps the detrended band in float64 for the exact re-scoring of the
@@ -925,6 +973,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     }
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
+    if (ctx->d_rim) (void)hipFree(ctx->d_rim);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     for (int k = 0; k < 2; ++k) {

@@ -220,22 +220,26 @@ int cs_comm_allgather_rows(cs_comm* c, const double* h_rows, int64_t n_rows, int
         return CS_ERR_INVALID;
     CS_HIPC(c, hipSetDevice(c->device));
     const int W = c->world;
-    // 1. counts (one int64 per rank)
-    int rc = ensure(c, 8 * (size_t)(W + 1));
+    // 1. counts AND capacities (two int64 per rank): whether the records fit must come out the same on every rank --
+    // a rank that returned "overflow" on its own while the others went on to the record exchange would leave the
+    // communicator with mismatched collectives.  Every rank sees min(capacity) and takes the same branch.
+    int rc = ensure(c, 16 * (size_t)(W + 1));
     if (rc) return rc;
     long long* hp = reinterpret_cast<long long*>(c->h_pin);
     hp[0] = n_rows;
-    CS_HIPC(c, hipMemcpyAsync(c->d_buf, hp, 8, hipMemcpyHostToDevice, c->stream));
-    CS_NCCL(c, rccl()->AllGather(c->d_buf, (char*)c->d_buf + 8, 1, ncclInt64, c->comm, c->stream));
-    CS_HIPC(c, hipMemcpyAsync(hp + 1, (char*)c->d_buf + 8, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+    hp[1] = cap_rows;
+    CS_HIPC(c, hipMemcpyAsync(c->d_buf, hp, 16, hipMemcpyHostToDevice, c->stream));
+    CS_NCCL(c, rccl()->AllGather(c->d_buf, (char*)c->d_buf + 16, 2, ncclInt64, c->comm, c->stream));
+    CS_HIPC(c, hipMemcpyAsync(hp + 2, (char*)c->d_buf + 16, 16 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
     CS_HIPC(c, hipStreamSynchronize(c->stream));
-    long long total = 0, widest = 0;
+    long long total = 0, widest = 0, room = cap_rows;
     for (int r = 0; r < W; ++r) {
-        h_counts[r] = hp[1 + r];
-        total += hp[1 + r];
-        widest = std::max(widest, hp[1 + r]);
+        h_counts[r] = hp[2 + 2 * r];
+        total += hp[2 + 2 * r];
+        widest = std::max(widest, hp[2 + 2 * r]);
+        room = std::min(room, hp[3 + 2 * r]);
     }
-    if (total > cap_rows) return cfail(c, CS_ERR_OVERFLOW, "%lld rows, room for %lld", total, (long long)cap_rows);
+    if (total > room) return cfail(c, CS_ERR_OVERFLOW, "%lld rows, room for %lld on the tightest rank", total, room);
     if (total == 0) return CS_OK;
     // 2. the records, padded to the longest list
     const size_t block = 8 * (size_t)widest * (size_t)width;

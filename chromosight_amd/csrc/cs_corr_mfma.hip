@@ -396,6 +396,8 @@ struct MfmaFixArgs {
     const float* fix_rows;
     const float* fix_cols;
     int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
+    const float* rim;        // rim tables of the weights (cs_launch.h MfmaWeights::rim)
+    int max_dist;
 };
 
 struct MfmaDenseArgs {
@@ -425,12 +427,13 @@ struct MfmaDenseArgs {
     const float* rowtab;             // [row][4]: nr, RA, RB, flags of the window rows
     const float* coltab;             // [3][ns]: ncol, CA, CB
     int fix_on, fix_hi_w, fix_hi_d0, fix_top, fix_bot0, fix_any_side;     // what decides whether a tile has records
+    int rim_in_kernel;       // the corrections of the edge diagonals are formed in the epilogue (no fix_lo / fix_hi records)
     MfmaFixArgs fx;          // read through fix_args() only
 };
 
 constexpr int MFD_ROWS_PER_THREAD = 14;       // staging: 240 threads = 40 column pairs x 6 row groups
 constexpr int MFD_WL = 4 * MF_PLANE;          // weight tails
-constexpr int MFD_SCR = MFD_WL + 17 * 1024;   // per wave: head / tail plane of the transposed sums
+constexpr int MFD_SCR = MFD_WL + 18 * 1024;   // (17 tail rows; RSYM: 9 tail rows + 9 head rows) then, per wave: scratch of the stores
 constexpr int MFD_RED = MFD_SCR + 4 * 2 * MF_SCR_PLANE;
 constexpr int MFD_SMEM = MFD_RED + 64;
 // REG: column terms (ncol, CA, CB of the tile's 64 columns) and the column flags of its 80 staged columns,
@@ -563,8 +566,9 @@ __device__ __forceinline__ const float* mask_fix_record(AT& A, FixArgsPtr F, int
     const bool top = i < fix_top;
     const bool bot = (i >= fix_bot0) & (!fix_on | (i + KH >= A.ms) | (j + KH >= A.ns));
     const bool side = (fix_cols != nullptr) & ((j < fix_side) | (j >= A.ns - fix_side));
-    const bool lo = (fix_on != 0) & (d >= 0) & (d < K - 1);
-    const bool hi = (fix_on != 0) & (d >= fix_hi_d0) & (d - fix_hi_d0 < fix_hi_w);
+    const bool edge_rec = (fix_on != 0) & (A.rim_in_kernel == 0);
+    const bool lo = edge_rec & (d >= 0) & (d < K - 1);
+    const bool hi = edge_rec & (d >= fix_hi_d0) & (d - fix_hi_d0 < fix_hi_w);
     const long long o_rows = (long long)(top ? i : fix_top + i - fix_bot0) * F->fix_width + x;
     const long long o_side = (long long)i * 2 * fix_side + (j < fix_side ? j : j - (A.ns - 2 * fix_side));
     const long long o_lo = (long long)i * (K - 1) + d;
@@ -572,6 +576,54 @@ __device__ __forceinline__ const float* mask_fix_record(AT& A, FixArgsPtr F, int
     const float* base = (top | bot) ? F->fix_rows : side ? fix_cols : lo ? F->fix_lo : F->fix_hi;
     const long long off = (top | bot) ? o_rows : side ? o_side : lo ? o_lo : o_hi;
     return (in_range & (top | bot | side | lo | hi)) ? base + 4 * off : nullptr;
+}
+
+// The correction {d n_missing, d ka, d kb} of a pixel on an edge diagonal, formed from the rim tables (cs_launch.h
+// MfmaWeights::rim) instead of read from a record of cs_mask_prep.hip mask_edge_fix -- the same arithmetic.  The window
+// of pixel (i, i + D) reaches below the main diagonal (D < K - 1: those pixels are flagged stripes in the reference,
+// row | column flags in the regular model) or beyond max_dist (never missing in the reference): row ki of the window has
+// its first L = clamp(ki - D) pixels below the diagonal and its pixels from H = clamp(md - D + ki + 1) on beyond max_dist.
+// rbits / cbits: flags of the window's rows / columns.  Half of the windows have none and cost three loads.
+__device__ __forceinline__ void rim_correction(const float* __restrict__ T, int K, int D, int md, unsigned rbits, unsigned cbits,
+                                               float& fn, float& fa, float& fb)
+{
+    fn = fa = fb = 0.0f;
+    if (D < K - 1) {
+        fn = T[kRimBase + D];
+        fa = T[kRimBase + 17 + D];
+        fb = T[kRimBase + 34 + D];
+    }
+    for (unsigned rb = rbits; rb; rb &= rb - 1) {
+        const int ki = __builtin_ctz(rb);
+        const int L = min(K, max(0, ki - D));
+        const int H = min(K, max(0, md - D + ki + 1));
+        const float* pa = T + kRimPW + ki * 18;
+        const float* pb = pa + 17 * 18;
+        fn -= (float)(L + (K - H));
+        fa -= pa[L] + (pa[K] - pa[H]);
+        fb -= pb[L] + (pb[K] - pb[H]);
+    }
+    for (unsigned cb = cbits; cb; cb &= cb - 1) {
+        const int kj = __builtin_ctz(cb);
+        const int lo_k = min(K, max(0, kj + D + 1));
+        const int hi_k = min(K, max(0, kj - (md - D)));
+        const float* qa = T + kRimQW + kj * 18;
+        const float* qb = qa + 17 * 18;
+        float nn = (float)((K - lo_k) + hi_k);
+        float a = (qa[K] - qa[lo_k]) + qa[hi_k];
+        float b = (qb[K] - qb[lo_k]) + qb[hi_k];
+        for (unsigned rb = rbits; rb; rb &= rb - 1) {
+            const int ki = __builtin_ctz(rb);
+            if (ki >= lo_k || ki < hi_k) {
+                nn -= 1.0f;
+                a -= T[kRimW + ki * 17 + kj];
+                b -= T[kRimW + 289 + ki * 17 + kj];
+            }
+        }
+        fn -= nn;
+        fa -= a;
+        fb -= b;
+    }
 }
 
 // RSYM (REG only): 17 x 17 template whose rows mirror (row s == row 16 - s): 9 head fragments in registers
@@ -744,6 +796,9 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.fx.fix_xband = A.fix_xband;
         D.fx.fix_xlo = A.fix_xlo;
         D.fx.fix_side = A.fix_side;
+        D.fx.rim = E.rim;
+        D.fx.max_dist = A.max_dist;
+        D.rim_in_kernel = A.rim_in_kernel;
         if (reg_f32) {
             *dense_path = 2;
             // 16-byte transfers need rows that store at least 4 values (no alignment needed); narrower maps take the

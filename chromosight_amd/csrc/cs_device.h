@@ -110,6 +110,7 @@ struct CorrArgs {
     const TC* fix_rows;
     const TC* fix_cols;
     int fix_top, fix_bot0, fix_width, fix_xband, fix_xlo, fix_side;
+    int rim_in_kernel;       // edge mode without fix_lo / fix_hi records: the masked tile kernel forms them (MfmaWeights::rim)
 };
 
 // ---------------------------------------------------------------------------------------

@@ -32,7 +32,18 @@ void corr_sep_tile(int* tw, int* th);
 struct MfmaWeights {
     const uint4* frag;
     float unscale[3];
+    // Rim tables of the mask weight sets Wa (set 0) and Wb (set 1), float32, fixed strides whatever K is: what the masked
+    // tile kernel needs to form, per pixel, the correction of a window that reaches below the main diagonal or beyond
+    // max_dist (reference preprocessing.py:404-498 frame_missing_mask: the sub-diagonals are flagged, pixels beyond
+    // max_dist never are) -- the arithmetic of cs_mask_prep.hip mask_edge_fix without its 16-byte record per rim pixel:
+    //   PW[set][ki][m] = sum_{kj < m} W[ki][kj]   at kRimPW + (set * 17 + ki) * 18 + m
+    //   QW[set][kj][m] = sum_{ki < m} W[ki][kj]   at kRimQW + (set * 17 + kj) * 18 + m
+    //   W[set][ki][kj]                            at kRimW  + set * 289 + ki * 17 + kj
+    //   base[x][D], x = {count, Wa, Wb}: the whole lower triangle of diagonal D < K - 1   at kRimBase + x * 17 + D
+    const float* rim;
 };
+constexpr int kRimPW = 0, kRimQW = 2 * 17 * 18, kRimW = 4 * 17 * 18, kRimBase = 4 * 17 * 18 + 2 * 289;
+constexpr int kRimFloats = kRimBase + 3 * 17;
 int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s, int* dense_path);
 // Several matrices in one persistent launch of the masked candidate instance (corr_mfma_blocks_kernel).  h_table: page-locked,
 // mfma_blocks_table_bytes(n) bytes, argument block b (CorrArgs::defer_args of launch_corr_mfma_f32) at

@@ -355,6 +355,8 @@ struct MaskPrepArgs {
     TC* rowtab;
     TC* coltab;
     int edge, hi_d0, hi_w;          // edge corrections (band outputs ending near max_dist)
+    int skip_edge;                  // edge mode, but the records of the edge diagonals are not built (the masked tile kernel
+                                    // forms those corrections itself from the rim tables of the weights, cs_launch.h)
     TC* fix_lo;
     TC* fix_hi;
     int top, bot0, width, x_band, x_lo, side;   // frame corrections

@@ -381,7 +381,7 @@ int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream)
     P.b_rows = (P.ms + 255) / 256;
     P.b_tab = P.b_rows + (P.ns + 255) / 256;
     P.b_edge = 0;
-    if (P.edge) {
+    if (P.edge && !P.skip_edge) {
         const long long n = (long long)P.ms * ((P.K - 1) + P.hi_w);
         P.b_edge = (int)std::min<long long>((n + 255) / 256, 4096);
     }

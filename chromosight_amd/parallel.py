@@ -80,7 +80,10 @@ class NativeComm:
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         width = int(rows.shape[1])
         counts = np.zeros(self.world, dtype=np.int64)
-        cap = max(4 * rows.shape[0] * self.world, 4096)
+        # first guess; CHROMOSIGHT_HIP_GATHER_CAP forces a small one (tests of the retry).  The library exchanges the
+        # capacities with the counts and answers "overflow" on EVERY rank when any rank lacks room, so all ranks retry
+        # together with the exact total (the collectives stay matched whatever the per-rank guesses were).
+        cap = int(os.environ.get("CHROMOSIGHT_HIP_GATHER_CAP", 0)) or max(4 * rows.shape[0] * self.world, 4096)
         while True:
             out = np.empty((cap, width))
             rc = self.lib.cs_comm_allgather_rows(self.handle, rows.ctypes.data, rows.shape[0], width, out.ctypes.data, cap,

@@ -385,8 +385,10 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
  * cs_comm_unique_id: 128 bytes to be created on ONE rank and handed to the others by whatever launched them (the Python
  * side broadcasts them over the torch.distributed store).  cs_comm_create: collective over all ranks.
  * cs_comm_allgather_rows: every rank passes n_rows rows of `width` float64; h_out receives the rows of rank 0, 1, ...
- * in rank order (h_counts[r] rows of rank r), identical on every rank; CS_ERR_OVERFLOW (counts set) when cap_rows is
- * too small.  cs_comm_allreduce_f64: element-wise sum over the ranks, in place. */
+ * in rank order (h_counts[r] rows of rank r), identical on every rank; CS_ERR_OVERFLOW (counts set) when the rows do not
+ * fit the SMALLEST cap_rows any rank passed -- the capacities travel with the counts, so every rank gets the same
+ * answer and all of them call again (with room for the sum of the counts): the collectives of a communicator stay
+ * matched however unevenly the rows are spread.  cs_comm_allreduce_f64: element-wise sum over the ranks, in place. */
 typedef struct cs_comm cs_comm;
 int cs_comm_available(void);            /* CS_OK when the RCCL of the library's HIP runtime loads (a local check: no rank talks) */
 int cs_comm_unique_id(void* out128);

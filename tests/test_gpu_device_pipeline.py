@@ -545,9 +545,19 @@ def test_native_rccl_exchange_single_rank():
     assert counts.tolist() == [1234] and np.array_equal(got, rows)
     got, counts = comm.allgather_rows(np.zeros((0, 7)))
     assert counts.tolist() == [0] and got.shape == (0, 7)
-    big = rng.random((50_000, 7))                      # more than the first capacity guess: the overflow path
+    big = rng.random((50_000, 7))
     got, counts = comm.allgather_rows(big)
     assert np.array_equal(got, big)
+    # the retry: a first capacity that is too small comes back as CS_ERR_OVERFLOW (on every rank: the capacities travel
+    # with the counts), the second call has room for the sum of the counts
+    import os
+    os.environ["CHROMOSIGHT_HIP_GATHER_CAP"] = "100"
+    try:
+        got, counts = comm.allgather_rows(big[:5000])
+    finally:
+        del os.environ["CHROMOSIGHT_HIP_GATHER_CAP"]
+    assert counts.tolist() == [5000] and np.array_equal(got, big[:5000])
+    assert "room for 100" in comm.lib.cs_comm_last_error(comm.handle).decode()
     vec = rng.random(2 * 289 + 1)
     assert np.array_equal(comm.allreduce_sum(vec), vec)
     comm.close()

@@ -540,6 +540,22 @@ __device__ __forceinline__ StatsPtr stats_args()
     return (StatsPtr)(kv + offsetof(MfmaDenseArgs, ks));
 }
 
+// ... and the whole argument block for the epilogue of the masked instances
+typedef const __attribute__((address_space(4))) MfmaDenseArgs* ArgsPtr;
+
+__device__ __forceinline__ ArgsPtr args_here()
+{
+    unsigned long long kv = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kv));
+    return (ArgsPtr)kv;
+}
+
+__device__ __forceinline__ ArgsPtr args_at(unsigned long long entry)
+{
+    asm volatile("" : "+s"(entry));
+    return (ArgsPtr)entry;
+}
+
 // the same two blocks of an entry of a device table (corr_mfma_blocks_kernel)
 __device__ __forceinline__ FixArgsPtr fix_args_at(unsigned long long entry)
 {

@@ -647,6 +647,30 @@ def main():
             c4p = {"error": repr(exc)}
         extras["north_star_c4p"] = c4p
 
+    # C3 as BASELINE.md defines it (pixel table in, detrend included) next to it: the one single-GPU BASELINE configuration
+    # whose step is more than the correlation call -- staging kernels (law, finish, tiler), mask tables, tile kernel
+    c3 = None
+    if args.workload == "c2" and args.size == 4096 and not args.no_cpu_baseline and world == 1:
+        try:
+            w3 = Workload("c3", dev, rank, args.precision)
+            prewarm(w3.step, full_sync, 0.1)
+            steps3 = 20
+            el3, ms3 = time_steps(dev, w3.step, full_sync, steps3, 3, dist, local_rank)
+            id3 = int(dev.lib.cs_last_kernel(dev.ctx))
+            roof3 = roofline_of(w3, ms3, id3, args.precision, None,
+                                "per-kernel PMC bytes of the profiled run: profiles/r04_pmc_counters.json c3_helper_kernels")
+            roof3["note"] = ("whole step (HIP events around stage_law + stage_finish + stage_tile + mask tables + tile kernel): 714 "
+                             f"flop/pixel x {w3.pixels} pixels / {ms3:.4f} ms against the FP32 peak; bytes view: 2 passes over the "
+                             f"stored pixels (8 B each) + row pointers + 4 B per pixel written = {w3.bytes_per_pixel:.1f} B/pixel")
+            c3 = {"value": round(w3.pixels * steps3 / el3 / 1e6, 1), "unit": "Mpixel/s", "n_gpus": 1, "steps": steps3, "warmup": 3,
+                  "ms_per_step": round(el3 / steps3 * 1e3, 4), "kernel_ms": round(ms3, 4), "workload": w3.desc,
+                  "pixels_per_step": w3.pixels, "stored_pixels": int(w3.nnz), "roofline": roof3,
+                  "roofline_hbm": dict(roof3["hbm"], bound="hbm")}
+            del w3
+        except Exception as exc:
+            c3 = {"error": repr(exc)}
+        extras["c3_from_csr"] = c3
+
     genome = None
     if not args.no_cpu_baseline and args.workload == "c2":
         # the sharded end-to-end genome next to the kernel figure, at every N (strong scaling, records
@@ -663,6 +687,8 @@ def main():
         out = dict(head)
         if c4p is not None:
             out["north_star_c4p"] = c4p
+        if c3 is not None:
+            out["c3_from_csr"] = c3
         if genome is not None:
             out["sharded_genome"] = genome
         if not args.no_cpu_baseline and world == 1:     # reported extras: rank 0 at N = 1 only

@@ -128,6 +128,7 @@ FOCUS_DTYPE = np.dtype([("bin1", "<i4"), ("bin2", "<i4"), ("inside", "<i4"), ("n
 _PROTOTYPES = {
     "cs_version": (C.c_char_p, []),
     "cs_last_kernel": (C.c_int, [C.c_void_p]),
+    "cs_ctx_set_range_check": (C.c_int, [C.c_void_p, C.c_int32]),
     "cs_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "cs_ctx_destroy": (None, [C.c_void_p]),
     "cs_last_error": (C.c_char_p, [C.c_void_p]),

@@ -80,6 +80,7 @@ struct cs_ctx {
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
+    int range_check = 0;     // cs_ctx_set_range_check()
     bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
     // flags), per arithmetic type: a detect run calls with the same template thousands of times
@@ -945,6 +946,13 @@ const char* cs_version(void) { return "chromosight_hip 0.1 (gfx950)"; }
 
 int cs_last_kernel(const cs_ctx* ctx) { return ctx ? ctx->last_kernel : 0; }
 
+int cs_ctx_set_range_check(cs_ctx* ctx, int32_t on)
+{
+    if (!ctx) return CS_ERR_INVALID;
+    ctx->range_check = on ? 1 : 0;
+    return CS_OK;
+}
+
 int cs_ctx_create(int device, cs_ctx** out)
 {
     if (!out) return CS_ERR_INVALID;
@@ -1147,6 +1155,32 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         if (out_nobs->dtype != CS_F32) return fail(ctx, CS_ERR_INVALID, "out_nobs must be float32");
     }
     const bool allow_fast = getenv("CHROMOSIGHT_HIP_FORCE_GENERIC") == nullptr;
+    if (ctx->range_check && signal && signal->d_ptr && kernel) {
+        // the guard of cs_ctx_set_range_check: largest |pixel| of the rows this call reads (the reduction of
+        // cs_normxcorr2_host's slabs), then CS_ERR_RANGE for a non-finite pixel or, in float32, a magnitude beyond 1e15
+        const int kh = (kernel->km - 1) / 2;
+        const int rb = (p->row_begin == 0 && p->row_end == 0) ? 0 : p->row_begin, re = (p->row_begin == 0 && p->row_end == 0) ? p->ms : p->row_end;
+        const int p_lo = std::max(0, rb - kh), p_hi = std::min(p->ms, re + (kernel->km - 1) - kh);
+        const int width = signal->layout == CS_LAYOUT_BAND ? signal->band_w : p->ns;
+        if (!ctx->d_counts_peak) {
+            CS_HIP(ctx, hipMalloc(&ctx->d_counts_peak, 256));
+            CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_peak, 256, hipHostMallocDefault));
+        }
+        CS_HIP(ctx, hipMemsetAsync(ctx->d_counts_peak, 0, 4, stream));
+        const size_t esz = signal->dtype == CS_F64 ? 8 : 4;
+        const char* src = (const char*)signal->d_ptr + ((long long)p_lo - signal->row0) * signal->ld * (long long)esz;
+        if (p_hi > p_lo && cs::launch_peak_rows(src, signal->dtype == CS_F64, signal->ld, p_hi - p_lo, width, ctx->n_cu,
+                                                reinterpret_cast<unsigned*>(ctx->d_counts_peak), stream) != 0)
+            return fail(ctx, CS_ERR_HIP, "range reduction failed to launch");
+        CS_HIP(ctx, hipMemcpyAsync(ctx->h_peak, ctx->d_counts_peak, 4, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        const float limit = p->compute_dtype == CS_F32 ? 1e15f : 3.4e38f;
+        unsigned limit_bits;
+        std::memcpy(&limit_bits, &limit, 4);
+        if (*ctx->h_peak > limit_bits)
+            return fail(ctx, CS_ERR_RANGE, p->compute_dtype == CS_F32 ? "the map holds non-finite pixels or magnitudes beyond 1e15: float64 path"
+                                                                      : "the map holds non-finite pixels");
+    }
     if (p->compute_dtype == CS_F64) {
         cs::CorrArgs<double> A;
         rc = build_args<double>(ctx, stream, signal, kernel, p, &A);

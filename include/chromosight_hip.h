@@ -49,8 +49,9 @@ typedef enum {
     CS_ERR_HIP = -2,       /* HIP runtime error */
     CS_ERR_UNSUPPORTED = -3,
     CS_ERR_OVERFLOW = -4,  /* an output buffer was too small; see the call's doc */
-    CS_ERR_RANGE = -5      /* cs_normxcorr2_host: the map holds a non-finite pixel, or magnitudes beyond what the float32
-                              kernels square without overflow (1e15): evaluate it in float64 (the Python shim does) */
+    CS_ERR_RANGE = -5      /* cs_normxcorr2_host, cs_normxcorr2 with cs_ctx_set_range_check: the map holds a non-finite pixel,
+                              or magnitudes beyond what the float32 kernels square without overflow (1e15): evaluate it in
+                              float64 (the Python shim does) */
 } cs_status;
 
 enum { CS_F32 = 0, CS_F64 = 1, CS_U8 = 2 /* masks only */ };
@@ -70,6 +71,14 @@ const char* cs_version(void);
 enum { CS_KERNEL_NONE = 0, CS_KERNEL_GENERIC = 1, CS_KERNEL_STREAM = 2, CS_KERNEL_MFMA = 3, CS_KERNEL_MFMA_DENSE = 4,
        CS_KERNEL_MFMA_REG = 5, CS_KERNEL_SEPARABLE = 6 };
 int cs_last_kernel(const cs_ctx* ctx);
+/* Range guard of the device entries (off by default).  The reference sums every window on its own
+ * (detection.py:1002-1018) and zeroes exactly the windows that hold a non-finite pixel (:1088-1101); the device kernels
+ * keep running box sums and square in float32, so a DEVICE-RESIDENT map handed to cs_normxcorr2 must be finite and, for
+ * CS_F32 arithmetic, below 1e15 in magnitude -- PRECONDITION of cs_normxcorr2 (maps prepared by cs_stage_blocks are:
+ * detrended, capped, NaN -> 0; cs_normxcorr2_host and the Python surface check their host maps themselves).  With the
+ * guard on, cs_normxcorr2 first reduces the rows of `signal` that the call reads (one pass, one stream
+ * synchronisation) and refuses a violating map with CS_ERR_RANGE before anything is computed. */
+int cs_ctx_set_range_check(cs_ctx* ctx, int32_t on);
 
 /* ---- device memory helpers (so a ctypes caller needs nothing but this library) ------ */
 int cs_malloc(cs_ctx* ctx, size_t bytes, void** d_ptr);
@@ -151,7 +160,8 @@ typedef struct {
  * Pixels outside the stored band of `out_corr` are not written.
  * The call is asynchronous on `stream`.  The template weights and, for CS_MASK_BINS, the per-bin
  * mask tables live in buffers owned by `ctx`, so one context serves one call in flight: use one
- * context per stream / host thread (contexts are independent and cheap). */
+ * context per stream / host thread (contexts are independent and cheap).
+ * PRECONDITION on device-resident maps (finite; below 1e15 for CS_F32): see cs_ctx_set_range_check. */
 int cs_normxcorr2(cs_ctx* ctx, void* stream, const cs_matrix* signal, const cs_kernel* kernel,
                   const cs_normxcorr2_params* params, const cs_matrix* out_corr,
                   const cs_matrix* out_nobs);

@@ -303,6 +303,43 @@ def test_nonfinite_pixels_in_a_large_host_map():
     assert np.isfinite(got).all() and np.abs(got - clean).max() < 2e-6
 
 
+def test_range_guard_refuses_a_violating_device_map():
+    """The direct C-ABI path: a device-resident map handed to cs_normxcorr2 must be finite (and below 1e15 in float32) --
+    the kernels keep running box sums where the reference sums every window on its own (detection.py:1002-1018, 1088-1101).
+    With cs_ctx_set_range_check the entry reduces the map first and refuses a violating one with CS_ERR_RANGE instead of
+    returning silently different windows; a clean map passes and gives the unguarded call's result; off is the default."""
+    import ctypes as C
+    from chromosight_amd import engine
+    from chromosight_amd._lib import LAYOUT_DENSE, MASK_NONE, CsMatrix, HipLibraryError, get_device, np_dtype_code
+    dev = get_device()
+    kspec = engine.KernelSpec(np.asarray(ck.loops["kernels"][0], dtype=np.float64))
+    a = np.random.default_rng(3).gamma(4.0, 0.25, size=(300, 320)).astype(np.float32)
+
+    def call(host, precision):
+        sig = dev.to_device(host)
+        out = dev.zeros(host.shape, np.float32)
+        engine.run_normxcorr2(dev, CsMatrix(sig.ptr, np_dtype_code(host.dtype), LAYOUT_DENSE, host.shape[1], 0, 0), host.shape, kspec,
+                              CsMatrix(out.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, host.shape[1], 0, 0),
+                              full=False, sym_upper=False, max_dist=None, mask_mode=MASK_NONE, precision=precision)
+        return out.download()
+
+    plain = call(a, "f32")
+    assert dev.lib.cs_ctx_set_range_check(dev.ctx, 1) == 0
+    try:
+        assert np.array_equal(call(a, "f32"), plain)
+        for bad, precisions in ((np.nan, ("f32", "f64")), (np.inf, ("f32", "f64")), (3e16, ("f32",))):
+            b = a.copy()
+            b[150, 160] = bad
+            for precision in precisions:
+                with pytest.raises(HipLibraryError, match="non-finite"):
+                    call(b, precision)
+        b = a.astype(np.float64)
+        b[150, 160] = 3e16                    # float64 arithmetic squares it without overflow: accepted
+        assert np.isfinite(call(b, "f64")).all()
+    finally:
+        assert dev.lib.cs_ctx_set_range_check(dev.ctx, 0) == 0
+
+
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_inter_detect_matches_reference(golden, precision):
     """`detect --inter`: pattern_detector in detect mode on six inter-chromosomal blocks of the yeast map (rectangular, dense,

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Slowest-rank step time of the C4 genome at 1 / 2 / 4 / 8 shares, each share timed alone on ONE GPU (no exchange):
+#   bash tools/rank_share_sweep.sh <out.txt>
+out=${1:-gpurun_out/rank_share.txt}
+: > $out
+for w in 1 2 4 8; do
+  for r in $(seq 0 $((w-1))); do
+    python tools/time_rank_share.py $w $r 2>/dev/null | tail -1 >> $out
+  done
+done
+python - "$out" <<'PY'
+import re, sys
+worst = {}
+for line in open(sys.argv[1]):
+    m = re.match(r"(\d+) GPUs, rank (\d+): .* step ([\d.]+) ms", line)
+    if m:
+        w, t = int(m.group(1)), float(m.group(3))
+        worst[w] = max(worst.get(w, 0.0), t)
+with open(sys.argv[1], "a") as f:
+    for w in sorted(worst):
+        f.write(f"slowest share at {w}: {worst[w]:.3f} ms  ({worst[1] / worst[w]:.2f}x of the 1-share step)\n")
+PY
+tail -4 $out

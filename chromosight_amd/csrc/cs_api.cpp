@@ -75,6 +75,7 @@ struct cs_ctx {
     size_t d_ws_bytes = 0;
     // matrix-core kernel: the float32 weight sets as float16 head / tail Toeplitz fragments
     void* d_wfrag = nullptr;
+    std::vector<char> stage_uploaded;   // cs_stage_blocks: the tables the staging scratch holds (skip the upload of identical ones)
     void* d_rim = nullptr;          // rim tables of the mask weight sets (cs_launch.h MfmaWeights::rim), same key as d_wfrag
     std::vector<unsigned char> wfrag_key;     // the float32 weights the image was built from
     int wfrag_km = 0, wfrag_kn = 0;
@@ -1757,8 +1758,10 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_s
     }
     if (pitch > 4096) return fail(ctx, CS_ERR_UNSUPPORTED, "distance laws of more than 4096 diagonals: stage block by block");
     pitch = (pitch + 63) / 64 * 64;
+    const size_t stage_had = ctx->d_stage_bytes;
     rc = ensure_scratch(ctx, &ctx->d_stage, &ctx->d_stage_bytes, cs::stage_scratch_bytes(n_blocks, n_groups, pitch, v.n_rows));
     if (rc) return rc;
+    if (ctx->d_stage_bytes != stage_had) ctx->stage_uploaded.clear();       // a fresh allocation holds no tables
     // the block / group tables go through one of two page-locked slots; a slot is reused two calls later, after the
     // event recorded behind its copy has fired (normally long ago): no synchronisation on the way in
     const int slot = ctx->stage_slot ^= 1;
@@ -1773,7 +1776,7 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_s
         ctx->h_stage_bytes[slot] = 2 * tbytes;
     }
     rc = cs::enqueue_stage_blocks(v.indptr, v.indices, v.data, v.is_f64, v.row_w, v.n_rows, tab.data(), n_blocks, max_val,
-                                  kRowsPerGroup, ctx->n_cu, ctx->d_stage, ctx->h_stage[slot], (hipStream_t)stream_);
+                                  kRowsPerGroup, ctx->n_cu, ctx->d_stage, ctx->h_stage[slot], (hipStream_t)stream_, &ctx->stage_uploaded);
     if (rc) return fail(ctx, CS_ERR_HIP, "staging kernels failed: %s", hipGetErrorString((hipError_t)rc));
     CS_HIP(ctx, hipEventRecord(ctx->ev_stage[slot], (hipStream_t)stream_));
     return CS_OK;
@@ -2527,6 +2530,58 @@ int cs_quantify_pixels(cs_ctx* ctx, void* stream_, const cs_matrix* signal, cons
     CS_HIP(ctx, hipMemcpyAsync(h_out, pool + off_rec, sizeof(cs_focus) * un, hipMemcpyDeviceToHost, stream));
     if (d_win && h_windows) CS_HIP(ctx, hipMemcpyAsync(h_windows, d_win, 8 * un * kk, hipMemcpyDeviceToHost, stream));
     CS_HIP(ctx, hipStreamSynchronize(stream));
+    return CS_OK;
+}
+
+// quantify mode over the sub-matrices of a genome in ONE launch chain (one call per template instead of one per
+// sub-matrix and template: cli/chromosight.py:229-260 scores one sub-matrix per task)
+int cs_quantify_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
+                       const cs_normxcorr2_params* params, const cs_foci_params* foci, const int32_t* h_blk, const int32_t* h_rows,
+                       const int32_t* h_cols, int64_t n, cs_focus* h_out, double* h_windows)
+{
+    CS_ENTER(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_blocks <= 0 || !signals || !kernel || !params || !foci) return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
+    if (n < 0 || (n > 0 && (!h_blk || !h_rows || !h_cols || !h_out))) return fail(ctx, CS_ERR_INVALID, "bad pixel list");
+    for (int b = 0; b < n_blocks; ++b) {
+        int rc = check_foci_args(ctx, signals + b, kernel, params + b, foci + b);
+        if (rc) return rc;
+        if (params[b].compute_dtype != CS_F64) return fail(ctx, CS_ERR_UNSUPPORTED, "quantify scores in float64");
+    }
+    for (int64_t t = 0; t < n; ++t)
+        if (h_blk[t] < 0 || h_blk[t] >= n_blocks) return fail(ctx, CS_ERR_INVALID, "pixel %lld names sub-matrix %d of %d", (long long)t, h_blk[t], n_blocks);
+    if (n == 0) return CS_OK;
+    const bool want_windows = foci[0].want_windows && h_windows;
+    const int kk = kernel->km * kernel->kn;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t un = (size_t)n, nb = (size_t)n_blocks;
+    const size_t off_rows = al(4 * un), off_cols = off_rows + al(4 * un), off_inter = off_cols + al(4 * un),
+                 off_tab = off_inter + al(4 * nb), off_score = off_tab + al(sizeof(cs::CorrArgs<double>) * nb),
+                 off_nobs = off_score + al(8 * un), off_rec = off_nobs + al(8 * un), off_win = off_rec + al(sizeof(cs::FocusRec) * un),
+                 total = off_win + (want_windows ? al(8 * un * kk) : 0);
+    int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, total);
+    if (rc) return rc;
+    char* pool = (char*)ctx->d_pool;
+    std::vector<cs::CorrArgs<double>> tab(nb);
+    std::vector<int> inter(nb);
+    for (int b = 0; b < n_blocks; ++b) {
+        rc = build_args<double>(ctx, stream, signals + b, kernel, params + b, &tab[(size_t)b]);
+        if (rc) return rc;
+        inter[(size_t)b] = foci[b].inter;
+    }
+    CS_HIP(ctx, hipMemcpyAsync(pool, h_blk, 4 * un, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_rows, h_rows, 4 * un, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_cols, h_cols, 4 * un, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_inter, inter.data(), 4 * nb, hipMemcpyHostToDevice, stream));
+    CS_HIP(ctx, hipMemcpyAsync(pool + off_tab, tab.data(), sizeof(cs::CorrArgs<double>) * nb, hipMemcpyHostToDevice, stream));
+    double* d_win = want_windows ? (double*)(pool + off_win) : nullptr;
+    rc = cs::enqueue_quantify_batch((const cs::CorrArgs<double>*)(pool + off_tab), (const int*)(pool + off_inter), (const int*)pool,
+                                    (const int*)(pool + off_rows), (const int*)(pool + off_cols), n, (double*)(pool + off_score),
+                                    (double*)(pool + off_nobs), (cs::FocusRec*)(pool + off_rec), d_win, stream);
+    if (rc) return fail(ctx, CS_ERR_HIP, "quantify kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    CS_HIP(ctx, hipMemcpyAsync(h_out, pool + off_rec, sizeof(cs_focus) * un, hipMemcpyDeviceToHost, stream));
+    if (d_win) CS_HIP(ctx, hipMemcpyAsync(h_windows, d_win, 8 * un * kk, hipMemcpyDeviceToHost, stream));
+    CS_HIP(ctx, hipStreamSynchronize(stream));       // (the pageable tables above were consumed)
     return CS_OK;
 }
 

@@ -666,6 +666,23 @@ __global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const Corr
                          (windows && t < win_cap) ? windows + t * kk : nullptr, lane);
 }
 
+// quantify mode over several sub-matrices (cs_quantify_blocks): entry t is pixel (rows[t], cols[t]) of sub-matrix blk[t];
+// inter-chromosomal sub-matrices (no NaN sub-diagonals in the windows) are flagged per sub-matrix
+__global__ __launch_bounds__(kThreads) void quantify_stats_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk_inter,
+                                                                        const int* __restrict__ blk, const int* __restrict__ rows,
+                                                                        const int* __restrict__ cols, const double* __restrict__ score,
+                                                                        const double* __restrict__ nobs, long long n,
+                                                                        FocusRec* __restrict__ rec, double* __restrict__ windows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int b = blk[t];
+    const CorrArgs<double>& A = tab[b];
+    const int kk = A.km * A.kn;
+    window_stats_pattern(A, blk_inter[b], rows[t], cols[t], 0, score[t], nobs[t], rec + t, windows ? windows + t * kk : nullptr, lane);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -1306,6 +1323,19 @@ int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(voi
         return 0;
     }
     return 0;
+}
+
+// quantify mode, several sub-matrices in one chain: d_tab / d_inter (n_blocks entries, already on the device), the pixel list
+// (d_blk, d_rows, d_cols) -> float64 scores, records and windows (device arrays of n entries)
+int enqueue_quantify_batch(const CorrArgs<double>* d_tab, const int* d_inter, const int* d_blk, const int* d_rows, const int* d_cols,
+                           long long n, double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_tab, d_blk, d_rows, d_cols, n,
+                       (const long long*)nullptr, d_score, d_nobs);
+    hipLaunchKernelGGL(quantify_stats_batch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kThreads), 0, stream, d_tab, d_inter, d_blk, d_rows,
+                       d_cols, d_score, d_nobs, n, d_rec, d_windows);
+    return (int)hipGetLastError();
 }
 
 // quantify mode: records at n given pixels (device arrays)

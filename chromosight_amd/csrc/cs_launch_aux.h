@@ -1,5 +1,6 @@
 // cs_launch_aux.h -- launchers of the helper kernels in cs_aux.hip (internal).
 #pragma once
+#include <vector>
 #include "cs_device.h"
 
 namespace cs {
@@ -284,7 +285,7 @@ size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_ro
 size_t stage_table_bytes(int n_blocks, int n_groups);        // page-locked host bytes for h_tables
 int enqueue_stage_blocks(const long long* indptr, const int* indices, const void* data, int data_is_f64, const double* weight,
                          long long n_rows, StageBlock* h_blocks, int n_blocks, double max_val, int rows_per_group, int n_cu,
-                         void* scratch, void* h_tables, hipStream_t stream);
+                         void* scratch, void* h_tables, hipStream_t stream, std::vector<char>* uploaded = nullptr);
 
 // 2-D patterns of many sub-matrices: candidates as composite keys (block << shift) + row * ns + col
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total);
@@ -335,6 +336,8 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
                  int min_size, int diag_only, int inter, void* scratch, FocusRec** d_rec_out, double* d_windows,
                  long long win_cap, long long* d_n_foci, hipStream_t stream, int presorted, FocusRec* rec_target,
                  long long rec_cap, long long* n_out);
+int enqueue_quantify_batch(const CorrArgs<double>* d_tab, const int* d_inter, const int* d_blk, const int* d_rows, const int* d_cols,
+                           long long n, double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream);
 int enqueue_quantify(const CorrArgs<double>& A64, const int* d_rows, const int* d_cols, long long n, int inter,
                      double* d_score, double* d_nobs, FocusRec* d_rec, double* d_windows, hipStream_t stream);
 

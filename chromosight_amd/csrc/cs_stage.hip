@@ -396,7 +396,7 @@ size_t stage_scratch_bytes(int n_blocks, int n_groups, int pitch, long long n_ro
 // stage_scratch_bytes(...) bytes and must stay untouched until the stream has drained.
 int enqueue_stage_blocks(const long long* indptr, const int* indices, const void* data, int data_is_f64, const double* weight,
                          long long n_rows, StageBlock* h_blocks, int n_blocks, double max_val, int rows_per_group, int n_cu,
-                         void* scratch, void* h_tables, hipStream_t stream)
+                         void* scratch, void* h_tables, hipStream_t stream, std::vector<char>* uploaded)
 {
     std::vector<StageGroup> groups;
     int pitch = 1;
@@ -425,8 +425,26 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     const size_t blocks_bytes = al(sizeof(StageBlock) * (size_t)n_blocks);
     std::memcpy(h_tables, h_blocks, sizeof(StageBlock) * (size_t)n_blocks);
     std::memcpy((char*)h_tables + blocks_bytes, groups.data(), sizeof(StageGroup) * (size_t)n_groups);
-    hipError_t e = hipMemcpyAsync(d_blocks, h_tables, blocks_bytes + sizeof(StageGroup) * (size_t)n_groups, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return (int)e;
+    // (a genome staged again with the same layout and outputs -- every step of a run -- finds its tables on the device:
+    // `uploaded` holds what the scratch at this address received last, and the 5 us copy in front of the chain is skipped)
+    const size_t table_bytes = blocks_bytes + sizeof(StageGroup) * (size_t)n_groups;
+    const size_t key_bytes = table_bytes + sizeof(void*);
+    bool same = uploaded && uploaded->size() == key_bytes && std::memcmp(uploaded->data(), &scratch, sizeof(void*)) == 0;
+    if (same) {
+        // (the padding between the two tables is not initialised: compare them one by one)
+        same = std::memcmp(uploaded->data() + sizeof(void*), h_blocks, sizeof(StageBlock) * (size_t)n_blocks) == 0 &&
+               std::memcmp(uploaded->data() + sizeof(void*) + blocks_bytes, groups.data(), sizeof(StageGroup) * (size_t)n_groups) == 0;
+    }
+    if (!same) {
+        hipError_t e = hipMemcpyAsync(d_blocks, h_tables, table_bytes, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+        if (uploaded) {
+            uploaded->assign(key_bytes, 0);
+            std::memcpy(uploaded->data(), &scratch, sizeof(void*));
+            std::memcpy(uploaded->data() + sizeof(void*), h_blocks, sizeof(StageBlock) * (size_t)n_blocks);
+            std::memcpy(uploaded->data() + sizeof(void*) + blocks_bytes, groups.data(), sizeof(StageGroup) * (size_t)n_groups);
+        }
+    }
     const int per_cu = getenv("CHROMOSIGHT_HIP_STAGE_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_GRID")) : 4;
     const int unroll = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL")) : 4;
     const int grid = std::min(n_groups, per_cu * n_cu);

@@ -421,6 +421,29 @@ def run_quantify_pixels(dev, sig, shape, kspec, rows, cols, *, inter, full, sym_
 
 
 @_one_call_per_context
+def run_quantify_blocks(dev, blocks, kspec, blk, rows, cols, *, missing_tol=0.75, want_windows=True, stream=None):
+    """quantify mode over MANY staged sub-matrices with one native call (cs_quantify_blocks): position t is pixel
+    (rows[t], cols[t]) of blocks[blk[t]] (pipeline.StagedBlock: intra blocks banded or dense, inter blocks dense -- `inter`
+    and `max_dist` per block).  One record (and window) per position, in input order."""
+    blk = np.ascontiguousarray(blk, dtype=np.int32)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    k, n_blocks = rows.size, len(blocks)
+    sig_arr = (_lib.CsMatrix * n_blocks)(*[b.sig for b in blocks])
+    par_arr = (CsNormxcorr2Params * n_blocks)(*[
+        _corr_params(b.shape, kspec, True, not b.inter, b.max_dist, MASK_BINS, b.miss_row, b.miss_col, None, missing_tol, CS_F64)
+        for b in blocks])
+    fp_arr = (CsFociParams * n_blocks)(*[CsFociParams(0.0, 0.0, 1, 0, 0, 0, int(bool(b.inter)), int(bool(want_windows))) for b in blocks])
+    kk = kspec.km * kspec.kn
+    rec, win = _host_buffers(dev, max(k, 1), kk, want_windows)
+    dev._check(dev.lib.cs_quantify_blocks(dev.ctx, stream, n_blocks, sig_arr, C.byref(kspec.struct), par_arr, fp_arr, blk.ctypes.data,
+                                          rows.ctypes.data, cols.ctypes.data, k, rec.ctypes.data,
+                                          win.ctypes.data if want_windows else None))
+    windows = win.reshape(-1)[:k * kk].reshape(k, kspec.km, kspec.kn).copy() if want_windows else None
+    return rec[:k].copy(), windows
+
+
+@_one_call_per_context
 def run_compact(dev, corr, shape, threshold, lo_diag, hi_diag, stream=None, guess=1 << 16):
     """(rows, cols, vals) of the stored pixels of `corr` with value >= threshold inside the
     diagonal range; sorted row-major."""

@@ -641,3 +641,55 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
     if not exchange:
         return local                                         # detect_patterns: the caller exchanges (in a fixed order)
     return _exchange_records(local, len(kernels), kernel_config["max_iterations"])
+
+
+# ================================================================================================
+# `quantify`, sub-matrices sharded over the ranks
+# ================================================================================================
+class QuantifyShard:
+    """How pipeline.quantify shares its sub-matrices among the ranks: `select` keeps this rank's share of the (ca, cb,
+    positions, coordinates) work list -- longest-processing-time-first by the pixels a sub-matrix stages plus the windows its
+    positions read, the same list on every rank --, `merge` exchanges the scores once (one padded all-gather of
+    (position, template, score, p-value, window) rows: RCCL with the "nccl" backend, gloo in the CPU tests)."""
+
+    def __init__(self):
+        self.dist, self.rank, self.world = _world()
+
+    def select(self, todo, dcool, max_dist):
+        costs = []
+        for ca, cb, sel, _ in todo:
+            n_r, n_c = dcool.chrom_size(ca), dcool.chrom_size(cb)
+            staged = n_r * min(max_dist + 1, n_c) if ca == cb else n_r * n_c
+            costs.append(int(staged) + 512 * len(sel))
+        owned = assign_blocks(costs, self.world)[self.rank]
+        return [todo[i] for i in owned]
+
+    def merge(self, score_out, pval_out, win_out, sels):
+        n_k = len(score_out)
+        kk = int(np.prod(win_out[0].shape[1:]))
+        where = np.concatenate(sels) if sels else np.zeros(0, dtype=np.int64)
+        rows = np.empty((n_k * where.size, 4 + kk))
+        for k in range(n_k):
+            part = rows[k * where.size:(k + 1) * where.size]
+            part[:, 0] = where
+            part[:, 1] = k
+            part[:, 2] = score_out[k][where]
+            part[:, 3] = pval_out[k][where]
+            part[:, 4:] = win_out[k][where].reshape(where.size, kk)
+        merged = all_gather_rows(rows)
+        pos = merged[:, 0].astype(np.int64)
+        for k in range(n_k):
+            m = merged[:, 1] == k
+            score_out[k][pos[m]] = merged[m, 2]
+            pval_out[k][pos[m]] = merged[m, 3]
+            win_out[k][pos[m]] = merged[m, 4:].reshape((-1,) + win_out[k].shape[1:])
+        return score_out, pval_out, win_out
+
+
+def quantify_genome(cool, positions, kernel_config, **options):
+    """`chromosight quantify` with the sub-matrices sharded over the ranks like the reference's process pool
+    (cli/chromosight.py:396-410: one task per sub-matrix that holds a position): every rank stages and scores its own
+    sub-matrices (pipeline.quantify: one native call per template over all of them), ONE exchange carries the scores, and
+    every rank returns the same (table, windows) a single process returns."""
+    from . import pipeline
+    return pipeline.quantify(cool, positions, kernel_config, shard=QuantifyShard(), **options)

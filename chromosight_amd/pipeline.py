@@ -893,11 +893,12 @@ def postprocess(coords, kernel_config, binsize, off, names, bin_start, bin_end, 
 
 
 def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=None, seed=0, smooth=False,
-             max_dist_bp=None, win_size=None):
+             max_dist_bp=None, win_size=None, shard=None):
     """`chromosight quantify` (cli/chromosight.py:264-470): score the given 2-D positions with every
     template of the config and keep, per position, the row the reference keeps (sorted by score,
     last of each (chrom1, start1, chrom2, start2) group).  `positions`: DataFrame with chrom1, start1,
-    end1, chrom2, start2, end2.  Returns (table in the reference's output order and columns, windows)."""
+    end1, chrom2, start2, end2.  Returns (table in the reference's output order and columns, windows).
+    shard: parallel.QuantifyShard -- the sub-matrices are dealt to the ranks (parallel.quantify_genome)."""
     dcool = cool if isinstance(cool, DeviceCool) else DeviceCool(cool)
     if subsample is not None:
         dcool = dcool.subsampled(subsample, seed=seed, inter=inter)
@@ -937,18 +938,42 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
         if hi > lo:                                         # (no pattern on a sub-matrix: it is not scanned, :240)
             sel = order[lo:hi]
             todo.append((ca, cb, sel, np.column_stack([g1[sel] - dcool.offsets[ca], g2[sel] - dcool.offsets[cb]]).astype(int)))
+    # Sharded run (parallel.quantify_genome): this rank scores the positions of its own sub-matrices, the scores of all ranks
+    # are exchanged once below -- the reference's pool over sub-matrices (cli/chromosight.py:396-410)
+    mine = todo if shard is None else shard.select(todo, dcool, max_dist)
+    # every sub-matrix that holds a position is staged once: the intra blocks with ONE native call (cs_stage_blocks)
     staged = {}
+    intra = sorted({ca for ca, cb, _, _ in mine if ca == cb})
+    if intra:
+        for ca, blk in zip(intra, dcool.stage_blocks(intra, max_dist, largest, smooth=smooth)):
+            staged[(ca, ca)] = blk
+    for ca, cb, _, _ in mine:
+        if ca != cb:
+            staged[(ca, cb)] = dcool.stage_inter(ca, cb, resident=True)
+    blocks = [staged[(ca, cb)] for ca, cb, _, _ in mine]
     for kernel_id, kernel in enumerate(kernels):
-        for ca, cb, sel, coords in todo:
-            if (ca, cb) not in staged:
-                staged[(ca, cb)] = dcool.stage_intra(ca, max_dist, largest, smooth=smooth, resident=True) if ca == cb \
-                    else dcool.stage_inter(ca, cb, resident=True)
-            rec, wins = detect_block(dcool, staged[(ca, cb)], cfg, kernel, tsvd=tsvd, coords=coords.copy(), raw=True)
+        # one native call per template for the positions of all sub-matrices (cs_quantify_blocks) ...
+        res = None
+        if mine and tsvd is None and not os.environ.get("CHROMOSIGHT_HIP_NO_QUANTIFY_BATCH"):
+            _check_template(kernel)
+            res = cid.quantify_many_on_device(dcool.dev, blocks, engine.KernelSpec(kernel), cfg, [c for _, _, _, c in mine])
+        if res is not None:
+            table, wins = res
+            where = np.concatenate([sel for _, _, sel, _ in mine])
+            score_out[kernel_id][where] = table[:, 2]
+            pval_out[kernel_id][where] = table[:, 3]
+            win_out[kernel_id][where] = wins
+            continue
+        # ... or, where the batch does not apply (truncated SVD, non-square templates), one per sub-matrix and template
+        for (ca, cb, sel, coords), block in zip(mine, blocks):
+            rec, wins = detect_block(dcool, block, cfg, kernel, tsvd=tsvd, coords=coords.copy(), raw=True)
             if rec is None:
                 continue
             score_out[kernel_id][sel] = rec[:, 2]
             pval_out[kernel_id][sel] = rec[:, 3]
             win_out[kernel_id][sel] = wins
+    if shard is not None:
+        score_out, pval_out, win_out = shard.merge(score_out, pval_out, win_out, [sel for _, _, sel, _ in mine])
     bed_out = [bed2d.assign(score=score_out[k], pvalue=pval_out[k]) for k in range(len(kernels))]
     # best score of every coordinate among the templates, as the reference selects it (:432-441)
     bed = pd.concat(bed_out, axis=0).reset_index(drop=True)

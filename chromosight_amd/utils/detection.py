@@ -665,6 +665,54 @@ def detect_on_device(dev, sig, shape, kspec, kernel_config, miss_row, miss_col, 
                            full=full, raw=raw, conv=conv)
 
 
+def quantify_many_on_device(dev, blocks, kspec, kernel_config, coords_list, *, want_windows=True, stream=None):
+    """detect_on_device(coords=...) -- `quantify`, pattern_detector with given coordinates in full mode (reference
+    detection.py:277, 297-298) -- for MANY staged sub-matrices (pipeline.StagedBlock; intra and inter mixed) with ONE native
+    call per template (cs_quantify_blocks) instead of one per sub-matrix and template.  coords_list[b]: (n_b, 2) integer
+    array of block-local (row, col) bins.  Returns (table (n, 4): bin1, bin2, score, pvalue -- the rows of the blocks one after
+    the other, in input order --, windows or None), or None when the batch does not apply (non-square template: the
+    caller goes block by block)."""
+    km, kn = kspec.km, kspec.kn
+    if km != kn or not blocks:
+        return None
+    kh, kw = (km - 1) // 2, (kn - 1) // 2
+    live = [b for b in range(len(blocks)) if min(blocks[b].shape) > max(km, kn)]     # (:237-238: smaller blocks are skipped)
+    counts = [len(c) for c in coords_list]
+    total = int(sum(counts))
+    table = np.full((total, 4), np.nan)
+    windows = np.full((total, km, kn), np.nan) if want_windows else None
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    if total == 0 or not live:
+        return table, windows
+    diag_only = kernel_config["max_dist"] == 0
+    big = np.iinfo(np.int32).max // 2
+    blk, rr, cc, where = [], [], [], []
+    for slot, b in enumerate(live):
+        pts = np.array(coords_list[b], dtype=np.int64, copy=True).reshape(-1, 2)
+        if diag_only and not blocks[b].inter:
+            pts[:, 0] = pts[:, 1] + (kw - kh)                  # forced on the diagonal AFTER the (kh, kw) shift (:311-315)
+        blk.append(np.full(len(pts), slot, dtype=np.int32))
+        rr.append(pts[:, 0])
+        cc.append(pts[:, 1])
+        where.append(np.arange(starts[b], starts[b + 1]))
+    blk, rr, cc, where = (np.concatenate(x) for x in (blk, rr, cc, where))
+    used = [blocks[b] for b in live]
+    rec, win = engine.run_quantify_blocks(dev, used, kspec, blk, np.clip(rr, -big, big), np.clip(cc, -big, big),
+                                          missing_tol=kernel_config["max_perc_undetected"] / 100, want_windows=want_windows,
+                                          stream=stream)
+    # per-record geometry of the acceptance rules (_accept_records takes arrays)
+    ms = np.array([b.shape[0] for b in used], dtype=np.int64)[blk]
+    ns = np.array([b.shape[1] for b in used], dtype=np.int64)[blk]
+    inter = np.array([bool(b.inter) for b in used])[blk]
+    md = np.array([(-1 if b.max_dist is None else b.max_dist) for b in used], dtype=np.int64)[blk]
+    rec4, win = _accept_records(rec, win, rr, cc, "quantify", (ms, ns), kspec, kernel_config, inter=inter,
+                                max_dist=np.where(md < 0, np.iinfo(np.int64).max // 4, md), full=True, raw=True)
+    table[where] = rec4
+    if want_windows:
+        windows[where] = win
+    return table, windows
+
+
 def _offset_scores(dev, sig, shape, kspec, rr, cc, common):
     """Non-square templates in full mode: pattern_detector pads the coefficient map by (kw rows, kh columns)
     (zero_pad_sparse(mat_conv, kh, kw), preprocessing.py:636-676) yet shifts the coordinates by (kh, kw)
@@ -823,7 +871,10 @@ def _accept_records(rec, windows, rr, cc, run_mode, shape, kspec, kernel_config,
     # coefficient on the trimmed map (:269-270), p-value on the untrimmed one (:332-336)
     sr, sc, sv = (rr, cc, r64) if conv is None else conv
     in_band = (sr >= 0) & (sr < ms) & (sc >= 0) & (sc < ns)
-    if not inter:
+    if isinstance(inter, np.ndarray):                          # records of intra and inter sub-matrices in one call
+        d = sc - sr
+        in_band &= inter | ((d >= 0) & (d <= max_dist))
+    elif not inter:
         d = sc - sr
         in_band &= (d >= 0) & ((d <= max_dist) if max_dist is not None else True)
     conv_at = np.where(in_band, sv, 0.0)

@@ -366,6 +366,15 @@ int cs_quantify_pixels(cs_ctx* ctx, void* stream, const cs_matrix* signal, const
                        const int32_t* h_rows, const int32_t* h_cols, int64_t n, cs_focus* h_out,
                        double* h_windows);
 
+/* The same over the sub-matrices of a genome in ONE launch chain (`quantify` scores one sub-matrix per pool task,
+ * cli/chromosight.py:229-260, 396-410: hundreds of tasks of a few positions each): position t is pixel (h_rows[t], h_cols[t])
+ * of sub-matrix h_blk[t]; signals / params / foci hold n_blocks entries (float64 arithmetic; foci[b].inter says whether
+ * sub-matrix b is inter-chromosomal; want_windows from entry 0).  h_out: n records in input order, h_windows: n * km * kn
+ * float64 or NULL.  Synchronous. */
+int cs_quantify_blocks(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_kernel* kernel,
+                       const cs_normxcorr2_params* params, const cs_foci_params* foci, const int32_t* h_blk,
+                       const int32_t* h_rows, const int32_t* h_cols, int64_t n, cs_focus* h_out, double* h_windows);
+
 /* One sub-matrix split over several GPUs by row windows: pick_foci (detection.py:387-592)
  * needs the thresholded pixels of the whole map, so the two halves of cs_detect_foci are exposed.
  *

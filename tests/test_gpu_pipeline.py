@@ -7,6 +7,8 @@ import copy
 import io
 import time
 
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -184,6 +186,96 @@ def test_quantify_harness_inter_best_of_kernels(golden):
     assert windows.shape == (len(table), 11, 11)
     assert np.isnan(table["pvalue"].to_numpy(dtype=np.float64)[np.isnan(a)]).all()
     print(f"quantify: {len(table)} positions, {int(np.isnan(a).sum())} without a valid score")
+
+
+def _yeast_positions(cool, g):
+    names = [str(n) for n in cool["chrom_names"]]
+    binsize = int(cool["binsize"])
+    rows = []
+    for bi in range(int(g["n_blocks"])):
+        ca, cb = (int(x) for x in g[f"b{bi}_chroms"])
+        for r, c in g[f"b{bi}_coords"]:
+            rows.append((names[ca], int(r) * binsize, (int(r) + 1) * binsize, names[cb], int(c) * binsize, (int(c) + 1) * binsize))
+    return pd.DataFrame(rows, columns=["chrom1", "start1", "end1", "chrom2", "start2", "end2"])
+
+
+def _same_quantify_tables(table, windows, ref, ref_windows):
+    """Same positions in the same order; windows, scores, p- and q-values to rounding (the two scoring kernels sum a
+    window in different orders: a wave per pixel, or a lane per pixel on runs of neighbours)."""
+    assert len(table) == len(ref) and list(table.columns) == list(ref.columns)
+    for col in ref.columns:
+        a, b = table[col].to_numpy(), ref[col].to_numpy()
+        if a.dtype == object:
+            assert (a == b).all(), col
+        elif col in ("score", "pvalue", "qvalue"):
+            assert np.array_equal(np.isnan(a.astype(float)), np.isnan(b.astype(float))), col
+            assert np.allclose(a.astype(float), b.astype(float), rtol=1e-9, atol=1e-12, equal_nan=True), col
+        else:
+            assert np.array_equal(a, b, equal_nan=True), col
+    # (two stagings of a block differ at the 1e-16 level: the distance law is summed in LDS in arrival order)
+    assert np.array_equal(np.isnan(windows), np.isnan(ref_windows))
+    assert np.allclose(windows, ref_windows, rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_quantify_batched_equals_block_by_block(golden, monkeypatch):
+    """One native call per template over all sub-matrices (cs_quantify_blocks) == one call per sub-matrix and template
+    (cs_quantify_pixels): the same table (scores to rounding) and the same windows."""
+    cool = golden("yeast_cool")
+    g = golden("yeast_quantify")
+    positions = _yeast_positions(cool, g)
+    cfg = dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+               kernels=[g[f"kernel{ki}"] for ki in range(3)], max_iterations=1, min_separation=5000)
+    md = int(g["cfg_max_dist_bp"])
+    batched, win_b = pipeline.quantify(cool, positions, cfg, inter=True, max_dist_bp=md)
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_QUANTIFY_BATCH", "1")
+    single, win_s = pipeline.quantify(cool, positions, cfg, inter=True, max_dist_bp=md)
+    assert len(batched) == len(single) > 2000
+    _same_quantify_tables(batched, win_b, single, win_s)
+
+
+QUANTIFY_WORKER = r"""
+import os, sys, numpy as np, pandas as pd
+sys.path.insert(0, os.environ["CS_ROOT"])
+import torch.distributed as dist
+from chromosight_amd import parallel
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+cool = dict(np.load(os.path.join(os.environ["CS_ROOT"], "tests", "golden", "yeast_cool.npz"), allow_pickle=True))
+g = dict(np.load(os.path.join(os.environ["CS_ROOT"], "tests", "golden", "yeast_quantify.npz"), allow_pickle=True))
+positions = pd.read_pickle(os.environ["CS_POS"])
+cfg = dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+           kernels=[g[f"kernel{ki}"] for ki in range(3)], max_iterations=1, min_separation=5000)
+table, windows = parallel.quantify_genome(cool, positions, cfg, inter=True, max_dist_bp=int(g["cfg_max_dist_bp"]))
+table.to_pickle(os.environ["CS_OUT"] + f".{dist.get_rank()}.pkl")
+np.save(os.environ["CS_OUT"] + f".{dist.get_rank()}.npy", windows)
+dist.destroy_process_group()
+"""
+
+
+def test_quantify_two_ranks_equal_single_process(golden, tmp_path):
+    """parallel.quantify_genome on 2 ranks (gloo rendezvous, both ranks on this GPU): the sub-matrices that hold a position are
+    dealt to the ranks (cli/chromosight.py:396-410 pools over them), one exchange carries scores and windows, and BOTH ranks
+    return the single-process table (which test_quantify_harness_inter_best_of_kernels pins against the reference)."""
+    import subprocess
+    import sys
+    cool = golden("yeast_cool")
+    g = golden("yeast_quantify")
+    positions = _yeast_positions(cool, g)
+    cfg = dict(pearson=0.15, max_perc_undetected=75.0, max_perc_zero=10.0, max_dist=0, min_dist=0,
+               kernels=[g[f"kernel{ki}"] for ki in range(3)], max_iterations=1, min_separation=5000)
+    single, win_s = pipeline.quantify(cool, positions, cfg, inter=True, max_dist_bp=int(g["cfg_max_dist_bp"]))
+    pos_file = tmp_path / "positions.pkl"
+    positions.to_pickle(pos_file)
+    script = tmp_path / "worker.py"
+    script.write_text(QUANTIFY_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "q"
+    env = dict(os.environ, CS_ROOT=root, CS_OUT=str(out), CS_POS=str(pos_file), CHROMOSIGHT_HIP_DEVICE="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for r in range(2):
+        _same_quantify_tables(pd.read_pickle(str(out) + f".{r}.pkl"), np.load(str(out) + f".{r}.npy"), single, win_s)
 
 
 def test_detect_inter_and_subsample_run(golden):

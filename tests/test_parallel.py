@@ -168,3 +168,73 @@ def test_detect_genome_world2_equals_single(tmp_path):
     assert len(np.unique(single_one[:, 5])) == 3
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"genome_one{r}.npy"), single_one)      # same rows, same order
+
+
+# ------------------------------------------------------------------------------------------------
+# quantify: sub-matrices dealt to the ranks, one exchange of scores and windows (QuantifyShard)
+# ------------------------------------------------------------------------------------------------
+class _QGenome:
+    def chrom_size(self, ci):
+        return 60 + 11 * ci
+
+
+def _quantify_todo():
+    """The work list pipeline.quantify builds: (ca, cb, indices of the positions, block-local coordinates)."""
+    rng = np.random.default_rng(7)
+    pairs = [(0, 0), (0, 2), (1, 1), (1, 3), (2, 2), (3, 3), (2, 3)]
+    todo, start = [], 0
+    for ca, cb in pairs:
+        n = int(rng.integers(1, 9))
+        todo.append((ca, cb, np.arange(start, start + n), rng.integers(0, 50, size=(n, 2))))
+        start += n
+    return todo, start
+
+
+def _fake_scores(todo_part, n_pos, n_k=3, kk=(3, 3)):
+    """What a rank would compute for its sub-matrices: values keyed on (position, template) only."""
+    score = [np.full(n_pos, np.nan) for _ in range(n_k)]
+    pval = [np.full(n_pos, np.nan) for _ in range(n_k)]
+    win = [np.full((n_pos,) + kk, np.nan) for _ in range(n_k)]
+    for _, _, sel, _ in todo_part:
+        for k in range(n_k):
+            score[k][sel] = np.sin(sel * 1.5 + k)
+            pval[k][sel] = np.cos(sel * 0.5 + k) ** 2
+            win[k][sel] = (sel[:, None, None] + np.arange(9.0).reshape(kk)) * (k + 1)
+            win[k][sel[::3], 0, 0] = np.nan                    # windows carry NaN (missing bins): they must survive the exchange
+    return score, pval, win
+
+
+def _quantify_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        todo, n_pos = _quantify_todo()
+        shard = parallel.QuantifyShard()
+        mine = shard.select(todo, _QGenome(), 30)
+        score, pval, win = _fake_scores(mine, n_pos)
+        score, pval, win = shard.merge(score, pval, win, [sel for _, _, sel, _ in mine])
+        np.savez(os.path.join(out_dir, f"q{rank}.npz"), score=np.array(score), pval=np.array(pval), win=np.array(win),
+                 mine=np.array([list(t[:2]) for t in mine]).reshape(-1, 2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_quantify_shard_world2(tmp_path):
+    """Every rank ends with the scores, p-values and windows of ALL positions, whichever rank scored them; the shares are
+    disjoint, cover the work list and are balanced by staged pixels + positions."""
+    todo, n_pos = _quantify_todo()
+    want = _fake_scores(todo, n_pos)
+    world = 2
+    mp.spawn(_quantify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    shares = []
+    for r in range(world):
+        got = np.load(tmp_path / f"q{r}.npz")
+        for name, ref in zip(("score", "pval", "win"), want):
+            assert np.array_equal(got[name], np.array(ref), equal_nan=True), (r, name)
+        shares.append({tuple(x) for x in got["mine"].tolist()})
+    assert shares[0].isdisjoint(shares[1]) and shares[0] | shares[1] == {(ca, cb) for ca, cb, _, _ in todo}
+    assert all(len(s) >= 2 for s in shares)
+    # a single process keeps everything and exchanges nothing
+    alone = parallel.QuantifyShard()
+    assert alone.select(todo, _QGenome(), 30) == todo

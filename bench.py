@@ -301,7 +301,8 @@ def cpu_baseline(workload, budget_s=12.0):
 
 def api_call_ms(workload):
     """PCIe-inclusive cost of the reference-shaped Python call on the same map (host ndarray in, host
-    float64 ndarray out): never `value`, reported next to it."""
+    float64 ndarray out): never `value`, reported next to it.  The source is a plain (PAGEABLE) numpy array -- what a
+    caller of chromosight.utils.detection.normxcorr2 holds; the result lands in the library's page-locked pool."""
     if workload.host_sig is None:
         return None
     from chromosight_amd.utils import detection as cud
@@ -413,6 +414,9 @@ def time_genome(args, rank, local_rank, world, dist, torch, steps, warmup):
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(local_rank)
 
+    # which transport carries the exchanges, checked against torch.distributed before anything is timed (the first N > 1
+    # run of the library's own RCCL communicator happens on the driver's node: it must be diagnosable, not fragile)
+    transport = g.parallel.exchange_self_check() if dist is not None else "none"
     rec = None
     for _ in range(max(warmup, 1)):
         rec = g.step()
@@ -426,8 +430,30 @@ def time_genome(args, rank, local_rank, world, dist, torch, steps, warmup):
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # per-rank phases, outside the timed region (a device synchronisation between staging and detection would cost the
+    # timed steps their overlap): staging until its kernels are done, detection without the exchanges, the exchanges
+    phases = []
+    for _ in range(3):
+        g.dcool.dev.sync()
+        g.parallel.TIMERS.update(exchange_ms=0.0, exchanges=0)
+        ta = time.perf_counter()
+        staged = g.parallel.stage_genome(g.dcool, [g.loops, g.borders], owned=g.mine)
+        g.dcool.dev.sync()
+        tb = time.perf_counter()
+        g.parallel.detect_patterns(g.dcool, [g.loops, g.borders], owned=g.mine, staged=staged)
+        g.dcool.dev.sync()
+        tc = time.perf_counter()
+        ex = g.parallel.TIMERS["exchange_ms"]
+        phases.append(((tb - ta) * 1e3, (tc - tb) * 1e3 - ex, ex))
+    mine = {"rank": rank, "blocks": len(g.mine), "stage_ms": round(min(p[0] for p in phases), 3),
+            "detect_ms": round(min(p[1] for p in phases), 3), "exchange_ms": round(min(p[2] for p in phases), 3)}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     pixels = g.loop_pixels + g.border_pixels
     return {
+        "transport": transport, "per_rank": per_rank,
         "value": round(pixels * steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "ms_per_genome": round(elapsed / steps * 1e3, 2),
         "n_gpus": world, "steps": steps, "scaling": "strong",
         "workload": "C4: 200000 bins in 23 blocks (hg38 proportions), 2 kb bins, max_dist 1000 bins, 2 % unbalanced bins, "
@@ -720,6 +746,9 @@ def main():
                 out["detect_wallclock"] = {"error": repr(exc)}
             try:
                 out["api_call_ms"] = api_call_ms(wl)
+                out["api_call_note"] = ("host float32 ndarray in (pageable source, uploaded in 12 row slabs), float64 ndarray out "
+                                        "(page-locked pool); PCIe-inclusive, never `value`; box to box 3.5 - 6 ms with the host's "
+                                        "memory placement")
             except Exception as exc:
                 out["api_call_ms"] = {"error": repr(exc)}
             try:

@@ -408,13 +408,72 @@ class StagedSet(dict):
         return (self.by_config or {}).get(i) or self
 
 
+# wall time this process has spent inside record exchanges (bench.py --gpus N reports it per rank)
+TIMERS = {"exchange_ms": 0.0, "exchanges": 0}
+
+
 def _exchange_records(local, n_kernels, n_iterations):
     """The ONE record exchange of a detect call: count + padded all-gather (RCCL: csrc/cs_comm.cpp); per (template,
     iteration) the rows come in the order separate gathers would give -- ranks concatenated, stable by block."""
     if _world()[2] == 1:
         return local                                         # already (template, iteration, block)-ordered
+    import time
+    t0 = time.perf_counter()
     merged = _gather(local, len(GENOME_FIELDS))              # ranks concatenated, stably sorted by block
+    TIMERS["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+    TIMERS["exchanges"] += 1
     return merged[np.argsort(merged[:, 5] * n_iterations + merged[:, 6], kind="stable")]
+
+
+def transport():
+    """What carries this process group's exchanges: "native_rccl" (csrc/cs_comm.cpp), "torch_nccl", "torch_gloo" or "none"."""
+    dist, rank, world = _world()
+    if dist is None or world == 1:
+        return "none"
+    if native_comm() is not None:
+        return "native_rccl"
+    return "torch_" + str(dist.get_backend())
+
+
+def exchange_self_check():
+    """Before a timed multi-GPU region: one padded all-gather of rows with UNEVEN counts (rank r sends 3 r + 1 rows; rank 0
+    with a first capacity that is too small, so the retry runs) and one all-reduce through the library's communicator,
+    compared with torch.distributed's collectives on the same data.  On a mismatch or an error on ANY rank every rank
+    drops to the torch transport, loudly.  Returns the transport in use afterwards."""
+    dist, rank, world = _world()
+    if dist is None or world == 1:
+        return "none"
+    comm = native_comm()
+    if comm is None:
+        return transport()
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ok, why = True, ""
+    try:
+        mine = (np.arange((3 * rank + 1) * 5, dtype=np.float64).reshape(-1, 5) + 1000.0 * rank)
+        if rank == 0:
+            os.environ["CHROMOSIGHT_HIP_GATHER_CAP"] = "2"
+        try:
+            got, counts = comm.allgather_rows(mine)
+        finally:
+            os.environ.pop("CHROMOSIGHT_HIP_GATHER_CAP", None)
+        want = np.concatenate([np.arange((3 * r + 1) * 5, dtype=np.float64).reshape(-1, 5) + 1000.0 * r for r in range(world)])
+        if counts.tolist() != [3 * r + 1 for r in range(world)] or not np.array_equal(got, want):
+            ok, why = False, "all-gather of rows differs from the expected concatenation"
+        vec = np.linspace(0.0, 1.0, 97) * (rank + 1)
+        t = torch.from_numpy(vec.copy()).to(dev)
+        dist.all_reduce(t)
+        if ok and not np.allclose(comm.allreduce_sum(vec), t.cpu().numpy(), rtol=1e-13, atol=0):
+            ok, why = False, "all-reduce differs from torch.distributed's"
+    except Exception as exc:                                  # noqa: BLE001 -- whatever it is, the torch path remains
+        ok, why = False, repr(exc)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if not bool(flag.item()):
+        if not ok:
+            sys.stderr.write(f"[chromosight_amd] rank {rank}: native RCCL exchange failed its self-check ({why}); torch.distributed instead\n")
+        _COMMS[(rank, world)] = None
+    return transport()
 
 
 _PATTERN_THREADS = None

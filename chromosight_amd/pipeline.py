@@ -622,8 +622,7 @@ class DeviceCool:
     def bins_of(self, chroms, positions):
         """Whole-genome bin of (chromosome name, base pair) pairs; -1 outside the genome
         (HicGenome.coords_to_bins, contacts_map.py:404-450, for fixed-size bins)."""
-        index = {n: i for i, n in enumerate(self.names)}
-        ci = np.array([index.get(str(c), -1) for c in chroms], dtype=np.int64)
+        ci = pd.Categorical(pd.Series(np.asarray(chroms, dtype=object)).astype(str), categories=list(self.names)).codes.astype(np.int64)
         local = np.asarray(positions, dtype=np.int64) // self.binsize
         sizes = np.diff(self.offsets)
         ok = (ci >= 0) & (local >= 0) & (local < sizes[np.maximum(ci, 0)])
@@ -913,13 +912,20 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     km, kn = kernels[0].shape
     max_dist = max(cfg["max_dist"] // dcool.binsize, 1)
     largest = max(k.shape[0] for k in kernels)
-    pos1 = (bed2d.start1 + bed2d.end1) // 2
-    pos2 = (bed2d.start2 + bed2d.end2) // 2
-    g1 = dcool.bins_of(bed2d.chrom1, pos1)
-    g2 = dcool.bins_of(bed2d.chrom2, pos2)
-    index = {n: i for i, n in enumerate(dcool.names)}
-    c1 = np.array([index.get(str(c), -1) for c in bed2d.chrom1])
-    c2 = np.array([index.get(str(c), -1) for c in bed2d.chrom2])
+    # chromosome of every position, once (the four bin lookups below share it); HicGenome.coords_to_bins
+    # (contacts_map.py:404-450): -1 where the genome has no such bin
+    c1 = pd.Categorical(bed2d.chrom1.astype(str), categories=list(dcool.names)).codes.astype(np.int64)
+    c2 = pd.Categorical(bed2d.chrom2.astype(str), categories=list(dcool.names)).codes.astype(np.int64)
+    sizes = np.diff(dcool.offsets)
+
+    def bins(codes, bp):
+        local = np.asarray(bp, dtype=np.int64) // dcool.binsize
+        ok = (codes >= 0) & (local >= 0) & (local < sizes[np.maximum(codes, 0)])
+        return np.where(ok, dcool.offsets[np.maximum(codes, 0)] + local, -1)
+
+    s1, e1, s2, e2 = (bed2d[c].to_numpy() for c in ("start1", "end1", "start2", "end2"))
+    g1 = bins(c1, (s1 + e1) // 2)
+    g2 = bins(c2, (s2 + e2) // 2)
     n_pos = len(bed2d)
     # plain arrays while the blocks are scanned (one pandas assignment per block and template cost more than the
     # native calls); the tables are assembled once below
@@ -927,17 +933,20 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     pval_out = [np.full(n_pos, np.nan) for _ in kernels]
     win_out = [np.full((n_pos, km, kn), np.nan) for _ in kernels]
     located = (g1 >= 0) & (g2 >= 0)
-    # positions of every sub-matrix, in input order: one stable sort by (chrom1, chrom2)
-    pair_key = np.where(located, c1.astype(np.int64) * (dcool.n_chrom + 1) + c2, -1)
+    # positions of every sub-matrix, in input order: one stable sort by (chrom1, chrom2); only the sub-matrices that hold a
+    # position are visited (no pattern on a sub-matrix: it is not scanned, :240), in the order of sub_matrices()
+    pair_key = np.where(located, c1 * (dcool.n_chrom + 1) + c2, -1)
     order = np.argsort(pair_key, kind="stable")
     keys_sorted = pair_key[order]
+    present, first = np.unique(keys_sorted, return_index=True)
+    ends = np.append(first[1:], keys_sorted.size)
     todo = []
-    for ca, cb in sub_matrices(dcool, inter):
-        key = ca * (dcool.n_chrom + 1) + cb
-        lo, hi = np.searchsorted(keys_sorted, key, "left"), np.searchsorted(keys_sorted, key, "right")
-        if hi > lo:                                         # (no pattern on a sub-matrix: it is not scanned, :240)
-            sel = order[lo:hi]
-            todo.append((ca, cb, sel, np.column_stack([g1[sel] - dcool.offsets[ca], g2[sel] - dcool.offsets[cb]]).astype(int)))
+    for key, lo, hi in zip(present.tolist(), first.tolist(), ends.tolist()):
+        ca, cb = divmod(key, dcool.n_chrom + 1)
+        if key < 0 or ca > cb or (ca != cb and not inter):
+            continue                                        # (sub_matrices(): upper blocks, inter ones only with --inter)
+        sel = order[lo:hi]
+        todo.append((ca, cb, sel, np.column_stack([g1[sel] - dcool.offsets[ca], g2[sel] - dcool.offsets[cb]]).astype(int)))
     # Sharded run (parallel.quantify_genome): this rank scores the positions of its own sub-matrices, the scores of all ranks
     # are exchanged once below -- the reference's pool over sub-matrices (cli/chromosight.py:396-410)
     mine = todo if shard is None else shard.select(todo, dcool, max_dist)
@@ -974,25 +983,39 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
             win_out[kernel_id][sel] = wins
     if shard is not None:
         score_out, pval_out, win_out = shard.merge(score_out, pval_out, win_out, [sel for _, _, sel, _ in mine])
-    bed_out = [bed2d.assign(score=score_out[k], pvalue=pval_out[k]) for k in range(len(kernels))]
-    # best score of every coordinate among the templates, as the reference selects it (:432-441)
-    bed = pd.concat(bed_out, axis=0).reset_index(drop=True)
-    windows = np.concatenate(win_out, axis=0)
-    bed = bed.sort_values("score", ascending=True).groupby(["chrom1", "start1", "chrom2", "start2"], sort=False).tail(1)
-    windows = windows[bed.index, :, :]
-    bed = bed.reset_index(drop=True)
+    # best score of every coordinate among the templates, as the reference selects it (:432-441): the tables of the templates
+    # one below the other, sort_values("score"), last row of every (chrom1, start1, chrom2, start2) group.  In numpy -- the
+    # same argsort pandas runs (quicksort on the finite scores, NaN last), so ties fall as they do there -- because the
+    # pandas version (three assigns, a concat of 3 n rows, a sort and a groupby) cost more than scoring the positions.
+    n_k = len(kernels)
+    score_all, pval_all = np.concatenate(score_out), np.concatenate(pval_out)
+    idx = np.arange(score_all.size)
+    nan = np.isnan(score_all)
+    in_sorted = np.concatenate([idx[~nan][np.argsort(score_all[~nan], kind="quicksort")], idx[nan]])
+    # (group key: the four columns factorised into one integer -- a row-wise np.unique costs ten times as much)
+    gid = np.zeros(n_pos, dtype=np.int64)
+    for col in (bed2d.chrom1, s1, bed2d.chrom2, s2):
+        codes, uniques = pd.factorize(col)
+        gid = gid * (len(uniques) + 1) + (codes + 1)
+    groups_sorted = np.tile(gid, n_k)[in_sorted]
+    _, first_from_end = np.unique(groups_sorted[::-1], return_index=True)
+    pick = in_sorted[np.sort(groups_sorted.size - 1 - first_from_end)]          # groupby(sort=False).tail(1): in sorted-frame order
+    src = pick % n_pos
+    score, pvalue = score_all[pick], pval_all[pick]
+    windows = np.empty((pick.size, km, kn))
+    for k in range(n_k):
+        m = pick // n_pos == k
+        windows[m] = win_out[k][src[m]]
     # the bin columns come from the interval STARTS (coords_to_bins of start1 / start2, :446-455), the scores from
     # the interval midpoints: they differ for intervals wider than one bin
-    out1 = dcool.bins_of(bed.chrom1, bed.start1)
-    out2 = dcool.bins_of(bed.chrom2, bed.start2)
+    out1, out2 = bins(c1[src], s1[src]), bins(c2[src], s2[src])
     if (out1 < 0).any() or (out2 < 0).any():            # no such bin: NaN, as the reference's merge leaves it
         out1, out2 = np.where(out1 < 0, np.nan, out1), np.where(out2 < 0, np.nan, out2)
-    bed["bin1"] = out1
-    bed["bin2"] = out2
-    bed["qvalue"] = fdr_correction(bed["pvalue"])
-    bed = bed.loc[:, ["chrom1", "start1", "end1", "chrom2", "start2", "end2", "bin1", "bin2", "score", "pvalue", "qvalue"]]
-    bad = np.isnan(bed.score.to_numpy(dtype=np.float64))
-    bed.loc[bad, "pvalue"] = np.nan
-    bed.loc[bad, "qvalue"] = np.nan
-    order = bed.sort_values(["bin1", "bin2"], ascending=True).index.to_numpy()
-    return bed.loc[order].reset_index(drop=True), windows
+    qvalue = np.asarray(fdr_correction(pvalue), dtype=np.float64)
+    bad = np.isnan(score)
+    pvalue = np.where(bad, np.nan, pvalue)
+    qvalue = np.where(bad, np.nan, qvalue)
+    final = np.lexsort((out2, out1))                    # sort_values(["bin1", "bin2"]): stable, NaN last
+    cols = {c: bed2d[c].to_numpy()[src][final] for c in ("chrom1", "start1", "end1", "chrom2", "start2", "end2")}
+    cols.update(bin1=out1[final], bin2=out2[final], score=score[final], pvalue=pvalue[final], qvalue=qvalue[final])
+    return pd.DataFrame(cols), windows                   # (the windows keep the selection order, as before the final sort of the table: cli/chromosight.py:441-470)

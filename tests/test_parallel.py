@@ -74,6 +74,8 @@ def _worker(rank, world, port, out_dir):
         local = np.zeros((0, 5)) if rank == 0 else np.arange(15, dtype=float).reshape(3, 5)
         g = parallel.gather_records(local)
         np.save(os.path.join(out_dir, f"gather{rank}.npy"), g)
+        # CPU ranks exchange over torch / gloo; the start-up self-check of bench.py has nothing native to check there
+        assert parallel.transport() == "torch_gloo" and parallel.exchange_self_check() == "torch_gloo"
     finally:
         dist.destroy_process_group()
 

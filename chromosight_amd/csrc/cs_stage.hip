@@ -454,8 +454,13 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     int max_b = 0;
     for (int b = 0; b < n_blocks; ++b) max_b = std::max(max_b, h_blocks[b].n_diags);
 #define CS_STAGE_LAW(TV, U)                                                                                                       \
-    hipLaunchKernelGGL((stage_law_kernel<TV, U>), dim3(grid), dim3(kStageThreads), smem_law, stream, indptr, indices, (const TV*)data, \
-                       weight, d_blocks, d_groups, n_groups, pitch, part_sum, part_cnt, row_stop)
+    do {                                                                                                                           \
+        if (smem_law > 48 * 1024)       /* laws beyond ~ 2300 diagonals: more dynamic LDS than a launch gets by default */           \
+            (void)hipFuncSetAttribute((const void*)stage_law_kernel<TV, U>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                      160 * 1024);                                                                                 \
+        hipLaunchKernelGGL((stage_law_kernel<TV, U>), dim3(grid), dim3(kStageThreads), smem_law, stream, indptr, indices,           \
+                           (const TV*)data, weight, d_blocks, d_groups, n_groups, pitch, part_sum, part_cnt, row_stop);            \
+    } while (0)
 #define CS_STAGE_TILE(TV, U)                                                                                                       \
     do {                                                                                                                           \
         if (smem_tile > 48 * 1024)                                                                                                 \

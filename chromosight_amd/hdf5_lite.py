@@ -42,6 +42,21 @@ class File:
         # root group symbol table entry: link name offset, object header address, cache type, reserved, scratch
         _name, self.root = struct.unpack_from("<QQ", b, pos)
 
+    def close(self):
+        """Release the mapping and the file handle (datasets are returned as copies: nothing refers to the mapping)."""
+        if self.buf is not None:
+            self.buf.close()
+            self.buf = None
+        if self._fh is not None:
+            self._fh.close()
+            self._fh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     # ---- object headers ---------------------------------------------------------------------------------------------
     def messages(self, addr):
         """[(type, bytes)] of a version-1 object header, continuation blocks followed."""

@@ -84,7 +84,11 @@ def _weights(uri, balance, norm, n_bins, read):
 
 def _load_cool_native(path, group, balance, norm):
     """load_cool through chromosight_amd.hdf5_lite (no external tool)."""
-    f = hdf5_lite.File(path)
+    with hdf5_lite.File(path) as f:                       # (closes the mapping and the handle: ADVICE r3)
+        return _read_cool_datasets(f, path, group, balance, norm)
+
+
+def _read_cool_datasets(f, path, group, balance, norm):
     ds = lambda name: f"{group}/{name}"
     names = f.dataset(ds("chroms/name"))
     attrs = f.attrs(group or "/")

@@ -274,9 +274,17 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         rows, cols, vals = st.to_host_coo(out_buf)
         vals = vals.astype(np.float64)
         if bad_pixels is not None:
-            hit = np.zeros(vals.shape, dtype=bool)
-            for p, q in zip(*bad_pixels):            # (a handful of pixels: one pass over the result each)
-                hit |= (np.abs(rows - p) <= (km - 1) // 2) & (np.abs(cols - q) <= (kn - 1) // 2)
+            # the centres whose window holds a bad pixel p: p - km // 2 .. p + (km - 1) // 2 (the window of centre i spans
+            # i - (km - 1) // 2 .. i + km // 2: asymmetric for even sizes), as one set of dilated keys -- a map with a NaN row
+            # has thousands of bad pixels, a pass over the result per pixel took minutes
+            bp, bq = (np.asarray(x, dtype=np.int64) for x in bad_pixels)
+            di = np.arange(-(km // 2), (km - 1) // 2 + 1, dtype=np.int64)
+            dj = np.arange(-(kn // 2), (kn - 1) // 2 + 1, dtype=np.int64)
+            ci = (bp[:, None, None] + di[None, :, None])
+            cj = (bq[:, None, None] + dj[None, None, :])
+            ok = (ci >= 0) & (ci < ms) & (cj >= 0) & (cj < ns)
+            keys = np.unique((ci * ns + cj)[ok])
+            hit = np.isin(rows.astype(np.int64) * ns + cols.astype(np.int64), keys)
             rows, cols, vals = rows[~hit], cols[~hit], vals[~hit]
         corr = sp.csr_matrix((vals, (rows, cols)), shape=(ms, ns))
         pvals = None
@@ -295,8 +303,8 @@ def normxcorr2(signal, kernel, max_dist=None, sym_upper=False, full=False, missi
         return corr, pvals
     corr = st.to_host_dense(out_buf).astype(np.float64, copy=False)
     if bad_pixels is not None:
-        for p, q in zip(*bad_pixels):
-            corr[max(p - (km - 1) // 2, 0):p + (km - 1) // 2 + 1, max(q - (kn - 1) // 2, 0):q + (kn - 1) // 2 + 1] = 0.0
+        for p, q in zip(*bad_pixels):                # centres p - km // 2 .. p + (km - 1) // 2 (see the sparse branch)
+            corr[max(p - km // 2, 0):p + (km - 1) // 2 + 1, max(q - kn // 2, 0):q + (kn - 1) // 2 + 1] = 0.0
     pvals = None
     if pval:
         if want_nobs:
@@ -756,11 +764,26 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
         ends = np.concatenate([[0], np.cumsum(counts)])
 
         def per_template():
+            # the acceptance rules of ALL templates in one native call (cs_accept_records threads beyond 2000 records: three
+            # calls of ~ 60 us each on a rank's share of a genome were a sixth of its step), cut per template afterwards
+            n_t = len(templates)
+            cnt = np.ascontiguousarray(counts, dtype=np.int64)
+            rec4, ok, kept = accept_native(rec, cnt, [b.shape for b in blocks] * n_t, [b.max_dist for b in blocks] * n_t, templates[0],
+                                           kernel_config, inter=False, full=True, compact=True)
+            win_ok = windows[ok] if windows is not None else None
+            cut = np.concatenate([[0], np.cumsum(kept)])
             out = []
-            for t in range(len(templates)):
-                a, z = int(ends[t * n]), int(ends[(t + 1) * n])
-                out.append(accept_many(blocks, rec[a:z], windows[a:z] if windows is not None else None, counts[t * n:(t + 1) * n],
-                                       templates[t], kernel_config, merged=merged))
+            for t in range(n_t):
+                a, z = int(cut[t * n]), int(cut[(t + 1) * n])
+                kept_t = kept[t * n:(t + 1) * n]
+                win_t = win_ok[a:z] if win_ok is not None else None
+                if merged:
+                    out.append((rec4[a:z], kept_t, win_t))
+                    continue
+                cuts = np.cumsum(kept_t)[:-1]
+                parts = np.split(rec4[a:z], cuts)
+                wparts = np.split(win_t, cuts) if win_t is not None else [None] * n
+                out.append([(None, None) if c == 0 else (tb, w) for c, tb, w in zip(cnt[t * n:(t + 1) * n], parts, wparts)])
             return out
 
         return per_template if defer else per_template()

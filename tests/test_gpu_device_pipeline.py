@@ -103,6 +103,20 @@ def test_batched_staging_matches_reference_and_the_block_by_block_path(golden):
             assert np.abs(download_block(dcool, blk) - ref).max() < 1e-11, (ci, pname)
 
 
+def test_batched_staging_with_a_long_distance_law():
+    """Laws of 3000+ diagonals: the law pass then needs more than the default 64 KB of dynamic LDS (only the
+    tiler had asked for it) -- cs_stage_blocks == the block-by-block kernels up to the summation order of the law."""
+    cool, _ = make_cool(9_000, 3_400, 2000, seed=11, chrom_sizes=[5_000, 4_000], loops_per_10k=0)
+    dcool = pipeline.DeviceCool(cool)
+    fast = dcool.stage_blocks([0, 1], 3_400, 17)
+    assert all(b.sig32 is not None for b in fast), "the batched entry did not serve the call"
+    for ci, blk in enumerate(fast):
+        assert blk.sig.band_w > 3_100
+        a, b = download_block(dcool, blk), download_block(dcool, dcool.stage_intra(ci, 3_400, 17))
+        assert np.abs(a - b).max() <= 1e-13 * max(np.abs(b).max(), 1e-300), ci
+        assert np.array_equal(a == 0, b == 0)
+
+
 def test_device_blocks_reproduce_reference_tables(golden, templates):
     """detect_block on the staged example chromosomes: tables bit-identical to the reference's
     pattern_detector captures (coordinates and order), scores <= 1e-9, windows <= 1e-12."""

@@ -190,6 +190,7 @@ _PROTOTYPES = {
     "cs_quantify_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),
+    "cs_detect_foci_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_quantify_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),

@@ -75,6 +75,12 @@ struct cs_ctx {
     size_t d_ws_bytes = 0;
     // matrix-core kernel: the float32 weight sets as float16 head / tail Toeplitz fragments
     void* d_wfrag = nullptr;
+    // cs_detect_foci_batch_templates: host tables of the call in flight (asynchronous mode), its virtual blocks and capacity
+    std::vector<cs::CorrArgs<double>> nb_tab;
+    std::vector<long long> nb_seg;
+    std::vector<int> nb_lo_w;
+    int nb_pending = 0;
+    long long nb_cap = 0;
     std::vector<char> stage_uploaded;   // cs_stage_blocks: the tables the staging scratch holds (skip the upload of identical ones)
     void* d_rim = nullptr;          // rim tables of the mask weight sets (cs_launch.h MfmaWeights::rim), same key as d_wfrag
     std::vector<unsigned char> wfrag_key;     // the float32 weights the image was built from
@@ -2078,9 +2084,15 @@ int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream_, int32_t n_blocks,
             return fail(ctx, CS_ERR_INVALID, "the templates of a batch share their size");
     // virtual block v = t * n_blocks + b: sub-matrix b under template t
     const int n_virtual = n_blocks * n_kernels;
-    std::vector<cs::CorrArgs<double>> tab((size_t)n_virtual);
-    std::vector<long long> seg((size_t)n_virtual + 1, 0);
-    std::vector<int> lo_w(2 * (size_t)n_virtual);
+    // (the host tables live in the context: an asynchronous call -- foci[0].reserved & 1 -- returns while their copies may
+    // still be in flight; cs_detect_foci_batch_finish ends the call)
+    if (ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "an asynchronous batch is pending on this context: cs_detect_foci_batch_finish first");
+    std::vector<cs::CorrArgs<double>>& tab = ctx->nb_tab;
+    std::vector<long long>& seg = ctx->nb_seg;
+    std::vector<int>& lo_w = ctx->nb_lo_w;
+    tab.assign((size_t)n_virtual, cs::CorrArgs<double>{});
+    seg.assign((size_t)n_virtual + 1, 0);
+    lo_w.assign(2 * (size_t)n_virtual, 0);
     for (int t = 0; t < n_kernels; ++t)
         for (int b = 0; b < n_blocks; ++b) {
             const int v = t * n_blocks + b;
@@ -2134,11 +2146,24 @@ int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream_, int32_t n_blocks,
                                        diag_code(foci, kernels, params), foci[0].inter, ctx->d_pool, rec, (long long)cap, win,
                                        win ? (long long)cap : 0, ctx->h_blk_counts, stream);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
-    CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host tables above were consumed
+    ctx->nb_pending = n_virtual;
+    ctx->nb_cap = cap;
+    if (foci[0].reserved & 1) return CS_OK;          // asynchronous: everything is enqueued, cs_detect_foci_batch_finish waits
+    return cs_detect_foci_batch_finish(ctx, stream_, h_n_foci);
+}
+
+int cs_detect_foci_batch_finish(cs_ctx* ctx, void* stream_, int64_t* h_n_foci)
+{
+    CS_ENTER(ctx);
+    if (!h_n_foci) return fail(ctx, CS_ERR_INVALID, "null counts");
+    if (!ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "no batch is pending on this context");
+    const int n_virtual = ctx->nb_pending;
+    ctx->nb_pending = 0;
+    CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream_));       // also: the host tables were consumed
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
     for (int v = 0; v < n_virtual; ++v) h_n_foci[v] = ctx->h_blk_counts[1 + v];
-    if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
+    if (total > ctx->nb_cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)ctx->nb_cap);
     return CS_OK;
 }
 

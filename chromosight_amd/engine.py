@@ -268,11 +268,14 @@ def _block_arrays(dev, sigs, sigs32, shapes, kspec, max_dists, miss_rows, miss_c
 
 @_one_call_per_context
 def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter, diag_only, max_dists, miss_rows, miss_cols,
-                          missing_tol=0.75, want_windows=True, min_size=2, stream=None, flat=False):
+                          missing_tol=0.75, want_windows=True, min_size=2, stream=None, flat=False, begin_only=False):
     """detect mode of a 1-D pattern (<= 4 scanned diagonals) on MANY banded sub-matrices with one native call
     (cs_detect_foci_batch).  Returns a list of (records, windows) per sub-matrix, or None when the library
     says a block does not qualify (the caller then goes block by block).  kspec may be a list of up to 4 templates of one
-    size (cs_detect_foci_batch_templates; flat=True only): the records then come template by template, counts[t * n + b]."""
+    size (cs_detect_foci_batch_templates; flat=True only): the records then come template by template, counts[t * n + b].
+    begin_only=True (templates, flat): the chain is only ENQUEUED on `stream` (the library's asynchronous form) and a callable
+    is returned that waits for it and yields the flat result -- the caller puts other work on the device in between; nothing
+    else may use `dev` until the callable has run."""
     kspecs = list(kspec) if isinstance(kspec, (list, tuple)) else None
     if kspecs is not None:
         if not flat or not 1 <= len(kspecs) <= 4 or any((k.km, k.kn) != (kspecs[0].km, kspecs[0].kn) for k in kspecs):
@@ -288,6 +291,34 @@ def run_detect_foci_batch(dev, sigs, shapes, kspec, *, pearson, hi_diags, inter,
     kk = kspec.km * kspec.kn
     cap = 4096 * n_templates
     k_arr = (_lib.CsKernel * n_templates)(*[k.struct for k in kspecs]) if kspecs is not None else None
+    if begin_only:
+        if kspecs is None or not flat:
+            return None
+        rec, win = _host_buffers(dev, max(cap, getattr(dev, "_batch_cap_hint", 0)), kk, want_windows)
+        fp_arr[0].reserved = 1                                   # asynchronous: return once the chain is enqueued
+        rc = dev.lib.cs_detect_foci_batch_templates(dev.ctx, stream, n_blocks, sig_arr, n_templates, k_arr, par_arr, fp_arr,
+                                                    rec.ctypes.data, rec.shape[0], counts, win.ctypes.data if want_windows else None)
+        fp_arr[0].reserved = 0
+        if rc == -3:
+            return None
+        dev._check(rc)
+
+        def finish():
+            with dev.lock:
+                rc2 = dev.lib.cs_detect_foci_batch_finish(dev.ctx, stream, counts)
+            if rc2 == -4:                                        # more foci than the buffers hold: once more, waiting for it
+                dev._batch_cap_hint = int(sum(counts)) + int(sum(counts)) // 4
+                return run_detect_foci_batch(dev, sigs, shapes, kspecs, pearson=pearson, hi_diags=hi_diags, inter=inter,
+                                             diag_only=diag_only, max_dists=max_dists, miss_rows=miss_rows, miss_cols=miss_cols,
+                                             missing_tol=missing_tol, want_windows=want_windows, min_size=min_size, stream=stream,
+                                             flat=True)
+            dev._check(rc2)
+            cnt = np.frombuffer(counts, dtype=np.int64).copy()
+            total = int(cnt.sum())
+            windows = win.reshape(-1)[:total * kk].reshape(total, kspec.km, kspec.kn).copy() if want_windows else None
+            return rec[:total].copy(), windows, cnt
+
+        return finish
     while True:
         rec, win = _host_buffers(dev, cap, kk, want_windows)
         cap = rec.shape[0]

@@ -755,11 +755,12 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
     return done(cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config))
 
 
-def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=False, dev=None, stream=None):
+def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=False, dev=None, stream=None, begin_only=False):
     """A 1-D pattern's templates (one size, e.g. the three borders templates) on banded intra blocks with ONE native call
     (cs_detect_foci_batch_templates) instead of one launch chain per template.  Returns a callable that yields, per template,
     the merged result of detect_blocks (table of all blocks, accepted records per block, windows) -- the native call is done
-    when this returns, the acceptance rules run in the callable -- or None when the entry does not apply."""
+    when this returns, the acceptance rules run in the callable -- or None when the entry does not apply.
+    begin_only=True: the chain is only enqueued on (dev, stream) when this returns; the callable waits for it first."""
     kernels = [np.asarray(k, dtype=np.float64) for k in kernels]
     if kernel_config["max_dist"] != 0 or len(kernels) < 2 or len(kernels) > 4 or len(blocks) < 1:
         return None
@@ -770,7 +771,21 @@ def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=
     for k in kernels:
         _check_template(k)
     return cid.detect_many_on_device(dev or dcool.dev, blocks, [engine.KernelSpec(k) for k in kernels], kernel_config,
-                                     want_windows=want_windows, raw=True, stream=stream, defer=True, merged=True)
+                                     want_windows=want_windows, raw=True, stream=stream, defer=True, merged=True, begin_only=begin_only)
+
+
+_ASYNC_DEVICES = {}
+
+
+def async_device(dcool, slot):
+    """(context, high-priority stream) number `slot` for launch chains the calling thread enqueues beside its own work on the
+    genome's context (parallel.detect_patterns); process-wide like the worker pools."""
+    from ._lib import Device
+    key = (dcool.dev.index, slot)
+    if key not in _ASYNC_DEVICES:
+        dev = Device(dcool.dev.index)
+        _ASYNC_DEVICES[key] = (dev, dev.new_stream(high_priority=not os.environ.get("CHROMOSIGHT_HIP_NO_PRIORITY")))
+    return _ASYNC_DEVICES[key]
 
 
 def with_win_size(kernel_config, win_size):

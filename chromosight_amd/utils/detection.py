@@ -734,7 +734,8 @@ def _offset_scores(dev, sig, shape, kspec, rr, cc, common):
     return sr, sc, vals
 
 
-def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None, defer=False, merged=False):
+def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=True, raw=False, stream=None, defer=False, merged=False,
+                          begin_only=False):
     """detect_on_device for a 1-D pattern (kernel_config["max_dist"] == 0: borders, hairpins) on many intra
     sub-matrices at once: `blocks` = objects with sig, shape, miss_row, miss_col, max_dist (pipeline.StagedBlock).
     One native call (cs_detect_foci_batch) instead of one launch chain and synchronisation per sub-matrix.
@@ -756,14 +757,14 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
             dev, [b.sig for b in blocks], [b.shape for b in blocks], templates, pearson=kernel_config["pearson"],
             hi_diags=[b.max_dist for b in blocks], inter=False, diag_only=True, max_dists=[b.max_dist for b in blocks],
             miss_rows=[b.miss_row for b in blocks], miss_cols=[b.miss_col for b in blocks], missing_tol=missing_tol,
-            want_windows=want_windows, stream=stream, flat=True)
+            want_windows=want_windows, stream=stream, flat=True, begin_only=begin_only)
         if res is None:
             return None
-        rec, windows, counts = res
         n = len(blocks)
-        ends = np.concatenate([[0], np.cumsum(counts)])
 
         def per_template():
+            # (begin_only: the chain is enqueued; res() waits for it and ends the native call)
+            rec, windows, counts = res() if begin_only else res
             # the acceptance rules of ALL templates in one native call (cs_accept_records threads beyond 2000 records: three
             # calls of ~ 60 us each on a rank's share of a genome were a sixth of its step), cut per template afterwards
             n_t = len(templates)
@@ -786,7 +787,7 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
                 out.append([(None, None) if c == 0 else (tb, w) for c, tb, w in zip(cnt[t * n:(t + 1) * n], parts, wparts)])
             return out
 
-        return per_template if defer else per_template()
+        return per_template if (defer or begin_only) else per_template()
     res = engine.run_detect_foci_batch(
         dev, [b.sig for b in blocks], [b.shape for b in blocks], kspec, pearson=kernel_config["pearson"],
         hi_diags=[b.max_dist for b in blocks], inter=False, diag_only=True, max_dists=[b.max_dist for b in blocks],

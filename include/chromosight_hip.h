@@ -346,6 +346,14 @@ int cs_detect_foci_batch(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_m
 int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, int32_t n_kernels,
                                    const cs_kernel* kernels, const cs_normxcorr2_params* params, const cs_foci_params* foci,
                                    cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows);
+/* Asynchronous form: with foci[0].reserved & 1, cs_detect_foci_batch_templates (and cs_detect_foci_batch) return as soon as
+ * the whole chain is enqueued on `stream` -- records and windows go to the caller's page-locked buffers when it runs -- and
+ * cs_detect_foci_batch_finish(ctx, stream, h_n_foci) waits for it and fills the per-(template, block) counts
+ * (CS_ERR_OVERFLOW as in the synchronous call).  One call may be pending per context; the caller keeps `stream` and the
+ * buffers alive in between.  This is how a 1-D pattern's short, latency-bound kernels are put on the device BEFORE the
+ * persistent tile kernels of a 2-D pattern and finished after them (parallel.detect_patterns), instead of racing them from
+ * another host thread. */
+int cs_detect_foci_batch_finish(cs_ctx* ctx, void* stream, int64_t* h_n_foci);
 
 /* The same for ANY pattern: blocks whose scan is a band of diagonals (loops, stripes) run the masked matrix-core tile
  * kernel in candidate mode -- every block's kernel appends its candidate pixels to one list -- followed by one sort, one

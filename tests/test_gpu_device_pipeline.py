@@ -106,7 +106,7 @@ def test_batched_staging_matches_reference_and_the_block_by_block_path(golden):
 def test_batched_staging_with_a_long_distance_law():
     """Laws of 3000+ diagonals: the law pass then needs more than the default 64 KB of dynamic LDS (only the
     tiler had asked for it) -- cs_stage_blocks == the block-by-block kernels up to the summation order of the law."""
-    cool, _ = make_cool(9_000, 3_400, 2000, seed=11, chrom_sizes=[5_000, 4_000], loops_per_10k=0)
+    cool, _ = make_cool(15_500, 3_400, 2000, seed=11, chrom_sizes=[8_000, 7_500], loops_per_10k=0)
     dcool = pipeline.DeviceCool(cool)
     fast = dcool.stage_blocks([0, 1], 3_400, 17)
     assert all(b.sig32 is not None for b in fast), "the batched entry did not serve the call"
@@ -360,6 +360,23 @@ def test_two_ranks_equal_single_process(tmp_path):
         assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]]), name
         assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9, name
     assert set(np.unique(want_b[:, 5])) == {0.0, 1.0, 2.0}
+
+
+def test_asynchronous_batch_entry_equals_the_threaded_run(monkeypatch):
+    """cs_detect_foci_batch_templates' asynchronous form (chain enqueued, cs_detect_foci_batch_finish later;
+    CHROMOSIGHT_HIP_EARLY_CHAIN=1 makes detect_patterns use it for the 1-D pattern) == the default run of the same patterns."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(12_000, 200, 2000, seed=5, template=template)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    want_l, want_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
+    monkeypatch.setenv("CHROMOSIGHT_HIP_EARLY_CHAIN", "1")
+    for _ in range(3):
+        got_l, got_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
+        for got, want in ((got_l, want_l), (got_b, want_b)):
+            assert got.shape == want.shape and want.shape[0] > 30
+            assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]])
+            assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9
 
 
 # ------------------------------------------------------------------------------------------------

@@ -21,7 +21,9 @@ t0 = step[0][0]
 busy_end = t0
 print(f"{len(step)} kernels in the step, {(step[-1][1] - t0) / 1e3:.1f} us from the first start to the last end")
 for s, e, name, q in step:
-    short = name.split("(")[0].replace("void cs::", "").replace("(anonymous namespace)::", "")[:70]
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    short = short.split("(")[0] if not short.startswith("(") else short
+    short = short.replace("cs::", "").replace("rocprim::ROCPRIM_400200_NS::detail::", "rocprim::")[:70]
     gap = (s - busy_end) / 1e3
     print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  q{q:>3s}  gap {gap:7.1f}  {short}")
     busy_end = max(busy_end, e)

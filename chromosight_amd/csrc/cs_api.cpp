@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -117,6 +118,23 @@ struct cs_ctx {
 static int ensure_scratch(cs_ctx* ctx, void** buf, size_t* have, size_t need);
 
 namespace {
+
+// CHROMOSIGHT_HIP_TIMING=1: host-side lap times of the batched entries on stderr (where a call's microseconds go before its
+// kernels are on the device)
+struct Laps {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    const char* what;
+    explicit Laps(const char* w) : on(std::getenv("CHROMOSIGHT_HIP_TIMING") != nullptr), what(w) { t0 = last = std::chrono::steady_clock::now(); }
+    void lap(const char* name)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] %s: %-28s +%7.1f us (at %7.1f)\n", what, name,
+                std::chrono::duration<double, std::micro>(now - last).count(), std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
 
 int fail(cs_ctx* ctx, int code, const char* fmt, ...)
 {
@@ -2183,6 +2201,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                           int64_t cap, int64_t* h_n_foci, double* h_windows)
 {
     CS_ENTER(ctx);
+    Laps laps("detect_foci_blocks");
     hipStream_t stream = (hipStream_t)stream_;
     if (n_blocks <= 0 || !signals || !kernel || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
         return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
@@ -2231,6 +2250,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_blk_counts, 2 * cnt_bytes, hipHostMallocDefault));
         ctx->h_blk_bytes = 2 * cnt_bytes;
     }
+    laps.lap("checks, pinned views");
     std::vector<cs::CorrArgs<double>> tab;       // the float64 argument blocks of the chain behind the tile kernels
     // ---- candidates of every block into one list
     const double margin = std::max(foci[0].rescore_margin, 1e-4);
@@ -2246,6 +2266,16 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         char* pool = (char*)ctx->d_pool;
         unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);
         CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        // CHROMOSIGHT_HIP_ONE_SYNC=1 (experiment, measured SLOWER, off by default): one synchronisation per call -- the chain
+        // behind the tile kernels is enqueued WITHOUT waiting for the candidate count: the list is sorted at its full
+        // capacity, unused entries holding a sentinel that sorts last (0x7fffffff7fffffff: above every key, with the bit
+        // above the block bits set), and the kernels of the chain read the count on the device (the first sentinel's
+        // position); an overflowing list shows in the count at the end and the call repeats with room.  What it saves (the
+        // 45 us of enqueueing the chain and one wake-up) it loses to a sort and launches sized for the capacity -- 98 000
+        // entries for the 12 000 candidates of a rank's share of 8, 782 000 for the genome's 100 000: a rank's share
+        // 1.21 -> 1.27-1.32 ms per step, the 23-block genome 4.15 -> 4.34 ms.
+        static const bool single_sync = std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") != nullptr;
+        if (single_sync) CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)pool, 0x7fffffff, 2 * c_cap, stream));
         // side streams only when no block needs the (single) narrowing scratch
         bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");
         for (int b = 0; b < n_blocks && twins; ++b) twins = signals_f32[b].d_ptr != nullptr;
@@ -2319,6 +2349,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
             for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
         }
+        laps.lap("pool, weights, events");
         // (largest blocks first on every lane: the short ones fill the end)
         std::vector<int> launch_order((size_t)n_blocks);
         for (int b = 0; b < n_blocks; ++b) launch_order[b] = b;
@@ -2386,6 +2417,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 return rc;
             }
         }
+        laps.lap("mask tables + arguments");
         if (prepared && !table) {
             // one persistent launch per block, each on the lane that built its mask tables
             for (int b : launch_order) {
@@ -2408,6 +2440,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
+        laps.lap("tile kernels launched");
         CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
         if (tab.empty()) {
             // built while the tile kernels run, not between the two synchronisations
@@ -2420,7 +2453,30 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 }
             }
         }
+        laps.lap("float64 argument table");
+        if (single_sync) {
+            const size_t off_tail1 = al(8 * c_cap) + 256;
+            ctx->h_blk_counts[0] = -1;
+            int rc1 = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, (long long)c_cap, kKeyShift, foci[0].pearson,
+                                                   foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail1, rec,
+                                                   (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream, /*bounded=*/1);
+            if (rc1) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc1));
+            laps.lap("foci chain enqueued");
+            CS_HIP(ctx, hipStreamSynchronize(stream));   // (the copy of the candidate count above is behind the tile kernels)
+            laps.lap("wait: records");
+            n_total = ctx->h_counts[0];
+            if ((size_t)n_total <= c_cap) {
+                const long long total1 = ctx->h_blk_counts[0];
+                if (total1 < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
+                for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
+                if (total1 > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total1, (long long)cap);
+                return CS_OK;
+            }
+            c_cap = (size_t)n_total + (size_t)n_total / 8;   // the list overflowed: once more with room for all
+            continue;
+        }
         CS_HIP(ctx, hipStreamSynchronize(stream));
+        laps.lap("wait: candidates");
         n_total = ctx->h_counts[0];
         if ((size_t)n_total <= c_cap) break;
         c_cap = (size_t)n_total + (size_t)n_total / 8;
@@ -2433,7 +2489,9 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                                           foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail, rec,
                                           (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
+    laps.lap("foci chain enqueued");
     CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host table above was consumed
+    laps.lap("wait: records");
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
     for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];

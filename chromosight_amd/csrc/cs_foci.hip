@@ -532,6 +532,83 @@ __global__ __launch_bounds__(kSmallThreads) void foci_small_batch_kernel(
                     n_foci_blk + b, part);
 }
 
+// ---- foci of a 1-D pattern without the labelling workgroup --------------------------------------------------------------
+// A scan of the diagonals 0 and 1 lists (i, i), (i, i + 1), (i + 1, i + 1), ...: every 4-neighbour pair among the listed
+// pixels is a pair of CONSECUTIVE entries, so the 4-connected foci of the thresholded list (label_foci, detection.py:459-554)
+// are its maximal runs -- no union-find, and nothing that needs one workgroup per sub-matrix (foci_small_batch_kernel: 1024
+// threads walk 17 000 entries through a dozen barrier-separated phases, 160-180 us however many sub-matrices there are;
+// the gather after it copies block by block in ONE workgroup: 40 us).  Here: one thread per entry flags the start of a run
+// of at least min_size pixels and walks it (size, first maximum in row-major order = path order), a device-wide exclusive
+// scan gives every focus its place in the list of ALL sub-matrices, one more pass writes the foci and the per-block counts.
+__global__ __launch_bounds__(kThreads) void path_runs_kernel(const long long* __restrict__ seg, const int* __restrict__ blk,
+                                                             const double* __restrict__ vals, long long n_total, double pearson,
+                                                             int min_size, int* __restrict__ flag, int* __restrict__ size,
+                                                             int* __restrict__ best_idx)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n_total) return;
+    const int b = blk[t];
+    const long long s0 = seg[b], s1 = seg[b + 1];
+    auto above = [&](long long u) {
+        const double v = vals[u];
+        return v >= pearson && v != 0.0;                       // detection.py:417-421
+    };
+    int f = 0;
+    if (above(t) && (t == s0 || !above(t - 1))) {
+        int cnt = 0;
+        unsigned long long best = 0ull;
+        long long best_u = t;
+        for (long long u = t; u < s1 && above(u); ++u) {
+            ++cnt;
+            const unsigned long long k = order_key(vals[u]);
+            if (cnt == 1 || k > best) {                        // the first maximum in row-major order (pick_foci, :438-453)
+                best = k;
+                best_u = u;
+            }
+        }
+        if (cnt >= min_size) {
+            f = 1;
+            size[t] = cnt;
+            best_idx[t] = (int)best_u;
+        }
+    }
+    flag[t] = f;
+}
+
+__global__ __launch_bounds__(kThreads) void path_emit_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ seg,
+                                                             int n_blocks, long long n_total, const int* __restrict__ blk,
+                                                             const long long* __restrict__ keys, const int* __restrict__ flag,
+                                                             const int* __restrict__ pos, const int* __restrict__ size,
+                                                             const int* __restrict__ best_idx, int diag_only, int* __restrict__ f_rows,
+                                                             int* __restrict__ f_cols, int* __restrict__ f_size, int* __restrict__ f_blk,
+                                                             long long* __restrict__ f_off, long long* __restrict__ d_total,
+                                                             long long* __restrict__ h_counts)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    auto before = [&](long long x) { return x < n_total ? (long long)pos[x] : (long long)pos[n_total - 1] + flag[n_total - 1]; };
+    if (t <= n_blocks) {                                       // per-block counts and the total (also to page-locked host memory)
+        const long long here = before(seg[t]);
+        f_off[t] = here;
+        if (t < n_blocks) {
+            if (h_counts) h_counts[1 + t] = before(seg[t + 1]) - here;
+        } else {
+            *d_total = here;
+            if (h_counts) h_counts[0] = here;
+        }
+    }
+    if (t >= n_total || !flag[t]) return;
+    const int b = blk[t], p = pos[t];
+    const int ns = tab[b].ns;
+    const long long key = keys[best_idx[t]];
+    int row = (int)(key / ns);
+    const int col = (int)(key - (long long)row * ns);
+    if (diag_only) row = col + (diag_only >> 1);               // odd code: 1-D pattern, row offset in the upper bits
+    f_rows[p] = row;
+    f_cols[p] = col;
+    f_size[p] = size[t];
+    f_blk[p] = b;
+}
+
 // the foci of all sub-matrices, block after block: offsets from the per-block counts (one workgroup),
 // the per-block counts and the total also go to (page-locked) host memory
 __global__ __launch_bounds__(kSmallThreads) void gather_foci_batch_kernel(const long long* __restrict__ seg,
@@ -1106,10 +1183,28 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
                                cols, n_total, vals, tile_cap);
         }
     }
-    hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, keys, vals, pearson, min_size,
-                       diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
-    hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
-                       f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
+    // every sub-matrix scans the diagonals 0 and 1 (borders, hairpins: max_dist = 0 in the config): the foci are runs
+    bool path = n_total > 0 && min_size >= 1 && !getenv("CHROMOSIGHT_HIP_NO_PATH_FOCI");
+    for (int k = 0; k < n_blocks && path; ++k) path = h_lo_w[2 * k] == 0 && h_lo_w[2 * k + 1] == 2;
+    size_t scan_tmp = 0;
+    if (path) {
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int*)nullptr, (int*)nullptr, (int)n_total);
+        path = scan_tmp <= 8 * n;                              // (its scratch: the list of kept keys, unused on this route)
+    }
+    if (path) {
+        const unsigned g = blocks_for(std::max<long long>(n_total, n_blocks + 1));
+        hipLaunchKernelGGL(path_runs_kernel, dim3(blocks_for(n_total)), dim3(kThreads), 0, stream, seg, blk, vals, n_total, pearson, min_size,
+                           flag, size, best_idx);
+        hipError_t es = hipcub::DeviceScan::ExclusiveSum(keys_k, scan_tmp, flag, pos, (int)n_total, stream);
+        if (es != hipSuccess) return (int)es;
+        hipLaunchKernelGGL(path_emit_kernel, dim3(g), dim3(kThreads), 0, stream, tab, seg, n_blocks, n_total, blk, keys, flag, pos, size,
+                           best_idx, diag_only, f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
+    } else {
+        hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, keys, vals, pearson, min_size,
+                           diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
+        hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
+                           f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
+    }
     if (n_total > 0) {
         const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
         hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(256), 0, stream, tab, f_blk, f_rows, f_cols,
@@ -1139,11 +1234,12 @@ __global__ __launch_bounds__(kThreads) void keyed_segments_kernel(const long lon
 }
 
 __global__ __launch_bounds__(kThreads) void keyed_split_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ keys,
-                                                               long long n, int shift, int* __restrict__ rows, int* __restrict__ cols,
+                                                               long long n, const long long* __restrict__ n_ptr, int shift,
+                                                               int* __restrict__ rows, int* __restrict__ cols,
                                                                int* __restrict__ blk, long long* __restrict__ local)
 {
     const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (t >= n) return;
+    if (t >= n || (n_ptr && t >= *n_ptr)) return;            // (a bounded list: the entries behind the keys are sentinels)
     const long long key = keys[t];
     const int b = (int)(key >> shift);
     const long long rem = key - ((long long)b << shift);
@@ -1169,8 +1265,10 @@ size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
 // h_counts[1 + b] = foci of block b.  Same chain as enqueue_foci_narrow_batch after its enumeration.
 int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
                              double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
-                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream)
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded)
 {
+    // bounded: n_total is the CAPACITY of d_keys, whose unused entries hold a sentinel above every key with the bit above
+    // the block bits set (cs_api.cpp cs_detect_foci_blocks); the number of keys is seg[n_blocks], known on the device only
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
     Bump b{(char*)scratch};
@@ -1213,15 +1311,16 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
     int blk_bits = 1;
     while ((1 << blk_bits) < n_blocks) ++blk_bits;
     if (n_total > 0) {
-        e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits, stream);
+        e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits + (bounded ? 1 : 0), stream);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
     if (n_total > 0) {
         const unsigned g = blocks_for(n_total);
-        hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, shift, rows, cols, blk, local);
+        const long long* n_keys = bounded ? seg + n_blocks : nullptr;
+        hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
         hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
-                           (const long long*)nullptr, vals, (double*)nullptr);
+                           n_keys, vals, (double*)nullptr);
     }
     hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, local, vals, pearson, min_size,
                        diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);

@@ -2274,7 +2274,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // 45 us of enqueueing the chain and one wake-up) it loses to a sort and launches sized for the capacity -- 98 000
         // entries for the 12 000 candidates of a rank's share of 8, 782 000 for the genome's 100 000: a rank's share
         // 1.21 -> 1.27-1.32 ms per step, the 23-block genome 4.15 -> 4.34 ms.
-        static const bool single_sync = std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") != nullptr;
+        const bool single_sync = std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") != nullptr;       // (read per call: tests flip it)
         if (single_sync) CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)pool, 0x7fffffff, 2 * c_cap, stream));
         // side streams only when no block needs the (single) narrowing scratch
         bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");

@@ -362,7 +362,7 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert set(np.unique(want_b[:, 5])) == {0.0, 1.0, 2.0}
 
 
-def test_asynchronous_batch_entry_equals_the_threaded_run(monkeypatch):
+def test_switchable_chains_equal_the_default_run(monkeypatch):
     """cs_detect_foci_batch_templates' asynchronous form (chain enqueued, cs_detect_foci_batch_finish later;
     CHROMOSIGHT_HIP_EARLY_CHAIN=1 makes detect_patterns use it for the 1-D pattern) == the default run of the same patterns."""
     template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
@@ -370,13 +370,17 @@ def test_asynchronous_batch_entry_equals_the_threaded_run(monkeypatch):
     loops = copy.deepcopy(ck.loops)
     loops["max_dist"] = 200 * 2000
     want_l, want_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
-    monkeypatch.setenv("CHROMOSIGHT_HIP_EARLY_CHAIN", "1")
-    for _ in range(3):
-        got_l, got_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
-        for got, want in ((got_l, want_l), (got_b, want_b)):
-            assert got.shape == want.shape and want.shape[0] > 30
-            assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]])
-            assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9
+    # ... and the loops chain with ONE synchronisation (bounded, sentinel-padded candidate list; CHROMOSIGHT_HIP_ONE_SYNC=1),
+    # the 1-D foci through the labelling workgroup instead of the run kernels (CHROMOSIGHT_HIP_NO_PATH_FOCI=1)
+    for switch in ("CHROMOSIGHT_HIP_EARLY_CHAIN", "CHROMOSIGHT_HIP_ONE_SYNC", "CHROMOSIGHT_HIP_NO_PATH_FOCI"):
+        monkeypatch.setenv(switch, "1")
+        for _ in range(2):
+            got_l, got_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
+            for got, want in ((got_l, want_l), (got_b, want_b)):
+                assert got.shape == want.shape and want.shape[0] > 30, switch
+                assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]]), switch
+                assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9, switch
+        monkeypatch.delenv(switch)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -57,6 +57,30 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-trace --output-format csv -d "$out/pmc_c4p_mfma" -o c4p -- \
     python bench.py --workload c4p --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_c4p_mfma.log" 2>&1
+# the candidate (CAND) instances the pipeline runs -- corr_mfma_dense_kernel<.., CAND> per block, corr_mfma_blocks_kernel for
+# a rank's share -- on the C4 genome: matrix-core occupancy and HBM bytes (own passes)
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU \
+    --kernel-trace --output-format csv -d "$out/pmc_c4_mfma" -o c4 -- \
+    python bench.py --workload c4 --steps 3 --warmup 1 > "$out/pmc_c4_mfma.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c4_$c" -o c4 -- \
+      python bench.py --workload c4 --steps 3 --warmup 1 > "$out/pmc_c4_$c.log" 2>&1
+done
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU \
+    --kernel-trace --output-format csv -d "$out/pmc_share_mfma" -o share -- \
+    python tools/time_rank_share.py 8 1 > "$out/pmc_share_mfma.log" 2>&1
+# rank shares of the C4 genome, each alone on this GPU; host + device timeline of one share of 8; C4 / C5 phases; the
+# per-phase cycle shares of the tile kernels (profiling build)
+bash tools/rank_share_sweep.sh "$out/rank_share.txt" > /dev/null 2>&1
+python tools/trace_rank_share.py 8 1 > "$out/rank_share_host_trace.txt" 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$out/kt_8_1" -o rs -- python tools/time_rank_share.py 8 1 > "$out/kt_8_1.log" 2>&1
+python tools/kernel_timeline.py "$out/kt_8_1" > "$out/rank_share_timeline.txt" 2>&1
+CHROMOSIGHT_HIP_TIMING=1 python tools/time_rank_share.py 8 1 2>&1 | grep timing | tail -8 > "$out/rank_share_native_laps.txt"
+python tools/time_c4_phases.py 6 > "$out/c4_phases.txt" 2>&1
+python tools/time_c5_phases.py > "$out/c5_phases.txt" 2>&1
+[ -f chromosight_amd/csrc/build/libchromosight_hip_prof.so ] && python tools/prof_mfma_sections.py c2 c3k c4p > "$out/tile_kernel_sections.txt" 2>&1
+bash tools/c4_mode_sweep.sh "$out/c4_modes.txt" > /dev/null 2>&1
+
 # helper kernels of the CSR path: bytes moved by the distance law / tiler (c3)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c3_$c" -o c3 -- \

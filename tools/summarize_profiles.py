@@ -108,5 +108,23 @@ for kname in ("stage_law_kernel", "stage_tile_kernel", "stage_finish_kernel", "d
         helpers[kname] = rec
 if helpers:
     summary["c3_helper_kernels"] = helpers
+# the candidate instances of the pipeline (C4 genome; a rank's share of 8)
+for run, key, kernels in (("c4", "c4_genome_cand_instances", ("corr_mfma_dense_kernel",)),
+                          ("share", "rank_share_8_blocks_kernel", ("corr_mfma_blocks_kernel",))):
+    rec = per_dispatch(find(f"pmc_{run}_mfma/**/*counter_collection.csv"), kernels)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        rec.update(per_dispatch(find(f"pmc_{run}_{c}/**/*counter_collection.csv"), kernels))
+    if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") and rec.get("GRBM_GUI_ACTIVE"):
+        rec["mfma_pipe_busy_frac"] = (rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (rec["GRBM_GUI_ACTIVE"] / 8.0)
+    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+        rec["hbm_bytes_per_dispatch"] = (rec["FETCH_SIZE"] * f + rec["WRITE_SIZE"]) * 1024.0
+    if rec:
+        rec["kernel"] = " / ".join(kernels) + " (candidate instances: per-dispatch means over the launches of the run)"
+        summary[key] = rec
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
+for name in ("rank_share.txt", "rank_share_host_trace.txt", "rank_share_timeline.txt", "rank_share_native_laps.txt", "c4_phases.txt",
+             "c5_phases.txt", "tile_kernel_sections.txt", "c4_modes.txt"):
+    f2 = os.path.join(src, name)
+    if os.path.exists(f2) and os.path.getsize(f2):
+        shutil.copy(f2, os.path.join(dst, f"{tag}_{name}"))
 print(json.dumps(summary, indent=1)[:3000])

@@ -399,8 +399,9 @@ class GenomeC4:
         # the same blocks (the law of a diagonal does not depend on how many diagonals are kept: identical values)
         # and the two patterns are scanned side by side (parallel.detect_patterns: the 1-D templates' latency-bound chains
         # run under the loops template's tile kernels)
-        staged = self.parallel.stage_genome(self.dcool, [self.loops, self.borders], owned=self.mine)
-        rec_l, rec_b = self.parallel.detect_patterns(self.dcool, [self.loops, self.borders], owned=self.mine, staged=staged)
+        # (parallel.genome_step = stage_genome + detect_patterns; after the first step of a layout: one native call that
+        # replays the step's calls on the same buffers, chromosight_amd/plan.py)
+        rec_l, rec_b = self.parallel.genome_step(self.dcool, [self.loops, self.borders], owned=self.mine)
         return rec_l, rec_b
 
 

@@ -119,6 +119,28 @@ class CsFocus(C.Structure):
     ]
 
 
+class CsCall(C.Structure):
+    """One entry of a cs_run_calls list (include/chromosight_hip.h)."""
+    _fields_ = [
+        ("fn", C.c_int32),
+        ("lane", C.c_int32),
+        ("after", C.c_int32),
+        ("rc", C.c_int32),
+        ("p", C.c_void_p * 12),
+        ("i", C.c_int64 * 6),
+        ("d", C.c_double * 2),
+    ]
+
+
+CALL_STAGE_BLOCKS, CALL_EVENT_RECORD, CALL_STREAM_WAIT_EVENT, CALL_DETECT_FOCI_BLOCKS, CALL_DETECT_FOCI_BATCH_TEMPLATES, \
+    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH = 1, 2, 3, 4, 5, 6, 7
+
+# While a list is installed here, the entries named in _CAPTURED append (name, arguments) to it AFTER running as usual:
+# chromosight_amd/plan.py turns the calls of one genome step into a cs_run_calls list.
+CAPTURE = None
+_CAPTURED = ("cs_stage_blocks", "cs_event_record", "cs_stream_wait_event", "cs_detect_foci_blocks", "cs_detect_foci_batch_templates")
+
+
 # numpy view of an array of cs_focus records
 FOCUS_DTYPE = np.dtype([("bin1", "<i4"), ("bin2", "<i4"), ("inside", "<i4"), ("n_zero", "<i4"), ("n_missing", "<i4"),
                         ("focus_size", "<i4"), ("score", "<f8"), ("n_obs", "<f8")])
@@ -191,6 +213,7 @@ _PROTOTYPES = {
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),
     "cs_detect_foci_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_run_calls": (C.c_int, [C.POINTER(CsCall), C.c_int32]),
     "cs_quantify_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                      C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p]),
@@ -235,8 +258,36 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
+        for name in _CAPTURED:
+            setattr(lib, name, _capturing(name, getattr(lib, name)))
         _lib = lib
         return lib
+
+
+def _capturing(name, fn):
+    def call(*args):
+        rc = fn(*args)
+        cap = CAPTURE
+        if cap is not None:
+            cap.append((name, args, threading.get_ident()))
+        return rc
+    call.__name__ = name
+    return call
+
+
+def raw_arg(arg):
+    """The integer / float a ctypes call would pass for `arg` (None, int, float, byref(x), array, structure, c_void_p)."""
+    if arg is None:
+        return 0
+    if isinstance(arg, (int, float)):
+        return arg
+    if hasattr(arg, "_obj"):                      # byref(x)
+        return C.addressof(arg._obj)
+    if isinstance(arg, (C.Array, C.Structure)):
+        return C.addressof(arg)
+    if isinstance(arg, C.c_void_p):
+        return arg.value or 0
+    return C.cast(arg, C.c_void_p).value or 0
 
 
 def np_dtype_code(dtype):

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
+#include <memory>
+#include <condition_variable>
 #include <chrono>
 #include <atomic>
 #include <cmath>
@@ -2669,3 +2672,141 @@ int cs_quantify_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs_ma
 }
 
 }  // extern "C"
+
+// ---- cs_run_calls: a list of the library's own calls, natively (see the header) ---------------------------------------
+namespace {
+struct CallRun {
+    cs_call* calls = nullptr;
+    int n = 0;
+    std::atomic<int>* done = nullptr;      // per call: 1 once it has returned (or was skipped)
+};
+
+int dispatch_call(cs_call& c)
+{
+    void** p = c.p;
+    const int64_t* i = c.i;
+    switch (c.fn) {
+        case CS_CALL_STAGE_BLOCKS:
+            return cs_stage_blocks((cs_ctx*)p[0], p[1], (const cs_csr*)p[2], (const cs_stage_block*)p[3], (int32_t)i[0], c.d[0]);
+        case CS_CALL_EVENT_RECORD:
+            return cs_event_record((cs_ctx*)p[0], p[1], p[2]);
+        case CS_CALL_STREAM_WAIT_EVENT:
+            return cs_stream_wait_event((cs_ctx*)p[0], p[1], p[2]);
+        case CS_CALL_DETECT_FOCI_BLOCKS:
+            return cs_detect_foci_blocks((cs_ctx*)p[0], p[1], (int32_t)i[0], (const cs_matrix*)p[2], (const cs_matrix*)p[3],
+                                         (const cs_kernel*)p[4], (const cs_normxcorr2_params*)p[5], (const cs_foci_params*)p[6],
+                                         (cs_focus*)p[7], i[1], (int64_t*)p[8], (double*)p[9]);
+        case CS_CALL_DETECT_FOCI_BATCH_TEMPLATES:
+            return cs_detect_foci_batch_templates((cs_ctx*)p[0], p[1], (int32_t)i[0], (const cs_matrix*)p[2], (int32_t)i[1],
+                                                  (const cs_kernel*)p[3], (const cs_normxcorr2_params*)p[4],
+                                                  (const cs_foci_params*)p[5], (cs_focus*)p[6], i[2], (int64_t*)p[7], (double*)p[8]);
+        case CS_CALL_ACCEPT_RECORDS:
+            return cs_accept_records((const cs_focus*)p[0], i[0], (const int64_t*)p[1], (const int32_t*)p[2], (const int32_t*)p[3],
+                                     (const int32_t*)p[4], (int32_t)i[1], (int32_t)i[2], (int32_t)i[3], c.d[0], c.d[1], (int32_t)i[4],
+                                     (int32_t)i[5], (double*)p[5], (uint8_t*)p[6], (int64_t*)p[7]);
+        case CS_CALL_DETECT_FOCI_BATCH_FINISH:
+            return cs_detect_foci_batch_finish((cs_ctx*)p[0], p[1], (int64_t*)p[2]);
+        default:
+            return CS_ERR_INVALID;
+    }
+}
+
+void run_lane(const CallRun& R, int lane)
+{
+    bool failed = false;
+    for (int k = 0; k < R.n; ++k) {
+        cs_call& c = R.calls[k];
+        if (c.lane != lane) continue;
+        if (!failed && c.after >= 0 && c.after < R.n) {
+            int spins = 0;
+            while (R.done[c.after].load(std::memory_order_acquire) == 0)
+                if (++spins > 2000) std::this_thread::yield();
+            if (R.calls[c.after].rc != 0) failed = true;            // what it waited for did not happen
+        }
+        c.rc = failed ? CS_ERR_INVALID : dispatch_call(c);
+        if (c.rc != 0) failed = true;
+        R.done[k].store(1, std::memory_order_release);
+    }
+}
+
+// worker threads of the extra lanes: kept between calls (starting a thread costs more than a lane's host work), spinning
+// briefly after a job -- the next step of a loop is usually microseconds away -- before they sleep
+struct LaneWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> state{0};             // 0 idle, 1 job posted, 2 job done
+    const CallRun* job = nullptr;
+    int lane = 0;
+    bool quit = false;
+    void loop()
+    {
+        for (;;) {
+            int spins = 0;
+            while (state.load(std::memory_order_acquire) != 1) {
+                if (++spins < 20000) continue;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1 || quit; });
+                if (quit) return;
+            }
+            run_lane(*job, lane);
+            state.store(2, std::memory_order_release);
+        }
+    }
+};
+
+std::mutex g_run_mu;                       // one cs_run_calls at a time (the workers are shared)
+// (never destroyed: the detached workers may be waiting on their condition variables when the process exits)
+std::vector<LaneWorker*>& lane_workers()
+{
+    static std::vector<LaneWorker*>* v = new std::vector<LaneWorker*>();
+    return *v;
+}
+}  // namespace
+
+extern "C" int cs_run_calls(cs_call* calls, int32_t n_calls)
+{
+    if (n_calls < 0 || (n_calls > 0 && !calls)) return CS_ERR_INVALID;
+    if (n_calls == 0) return CS_OK;
+    int lanes = 1;
+    for (int k = 0; k < n_calls; ++k) {
+        if (calls[k].lane < 0 || calls[k].lane > 7 || calls[k].after >= k) return CS_ERR_INVALID;     // (waits only look back)
+        lanes = std::max(lanes, calls[k].lane + 1);
+        calls[k].rc = 0;
+    }
+    std::lock_guard<std::mutex> lock(g_run_mu);
+    std::vector<std::atomic<int>> done((size_t)n_calls);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    CallRun R;
+    R.calls = calls;
+    R.n = n_calls;
+    R.done = done.data();
+    std::vector<LaneWorker*>& g_workers = lane_workers();
+    while ((int)g_workers.size() < lanes - 1) {
+        LaneWorker* w = new LaneWorker;
+        g_workers.push_back(w);
+        w->th = std::thread([w] { w->loop(); });
+        w->th.detach();
+    }
+    for (int l = 1; l < lanes; ++l) {
+        LaneWorker* w = g_workers[(size_t)l - 1];
+        w->job = &R;
+        w->lane = l;
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->state.store(1, std::memory_order_release);
+        }
+        w->cv.notify_one();
+    }
+    run_lane(R, 0);
+    for (int l = 1; l < lanes; ++l) {
+        LaneWorker* w = g_workers[(size_t)l - 1];
+        int spins = 0;
+        while (w->state.load(std::memory_order_acquire) != 2)
+            if (++spins > 2000) std::this_thread::yield();
+        w->state.store(0, std::memory_order_release);
+    }
+    for (int k = 0; k < n_calls; ++k)
+        if (calls[k].rc != 0) return calls[k].rc;
+    return CS_OK;
+}

@@ -570,6 +570,43 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     return results
 
 
+def genome_step(genome, kernel_configs, owned=None, tsvd=None):
+    """One detect step of a sharded genome: stage_genome + detect_patterns, the results of detect_patterns.  For the usual
+    pair of configurations (a 2-D pattern and a 1-D pattern with several templates, single iterations) every step after the
+    first is ONE native call on the arguments the first step used (chromosight_amd/plan.py: cs_run_calls) plus one record
+    exchange per configuration; anything else -- and any step whose call list reports an error -- takes the two calls."""
+    from . import plan as _plan
+    dist, rank, world = _world()
+    if owned is None:
+        max_dist = max(max(cfg["max_dist"] // genome.binsize, 1) for cfg in kernel_configs)
+        costs = [block_cost((genome.chrom_size(ci),) * 2, max_dist, False) for ci in range(genome.n_chrom)]
+        owned = assign_blocks(costs, world)[rank]
+    owned = list(owned)
+    if not owned or not _plan.plannable(genome, kernel_configs, tsvd):
+        staged = stage_genome(genome, kernel_configs, owned=owned)
+        return detect_patterns(genome, kernel_configs, owned=owned, staged=staged, tsvd=tsvd)
+    key = (tuple(owned), tuple((cfg["max_dist"], cfg["pearson"], cfg["max_perc_undetected"], cfg["max_perc_zero"],
+                                tuple(np.asarray(k, dtype=np.float64).tobytes() for k in cfg["kernels"])) for cfg in kernel_configs))
+    plans = genome.__dict__.setdefault("_step_plans", {})
+    plan = plans.get(key)
+    if plan is not None and plan.ok:
+        local = plan.run()
+        if local is not None:
+            return [_exchange_records(rec, len(cfg["kernels"]), 1) for rec, cfg in zip(local, kernel_configs)]
+        plans.pop(key, None)                                  # (a result list outgrew its capacity: the usual path, a new plan)
+    from . import _lib
+    _lib.CAPTURE = captured = []
+    try:
+        staged = stage_genome(genome, kernel_configs, owned=owned)
+        results = detect_patterns(genome, kernel_configs, owned=owned, staged=staged, tsvd=tsvd)
+    finally:
+        _lib.CAPTURE = None
+    if len(plans) > 8:
+        plans.clear()
+    plans[key] = _plan.StepPlan(genome, kernel_configs, owned, captured, staged)
+    return results
+
+
 def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, stage=None, detect=None,
                   owned=None, staged=None, exchange=True, exclusive=True, own_context=False):
     """`chromosight detect` over all intra-chromosomal blocks of a DeviceCool, sharded over the ranks

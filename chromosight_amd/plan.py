@@ -1,0 +1,183 @@
+"""A genome step as ONE native call (reference: the per-sub-matrix tasks of cli/chromosight.py:738-755).
+
+`parallel.genome_step(genome, [cfg_2d, cfg_1d])` = stage_genome + detect_patterns.  On a rank's share of a genome the
+interpreter between the native calls of a step costs as much as their kernels (~ 350 us of a 1.1 ms step), and
+every step of a run on the same genome layout -- the steps of an iterated template, the patterns of a run, the steps of a
+benchmark -- makes the SAME calls on the same buffers.  So the first step runs the usual way with the library's entries
+recording their arguments (_lib.CAPTURE), a StepPlan turns them into a cs_run_calls list -- staging, the ready event, the
+2-D pattern's chain and its acceptance rules on the calling thread; the event wait, the 1-D pattern's chain and its
+acceptance rules on a worker thread of the library -- and every later step is that one call plus the slicing of its
+result tables.  Everything is recomputed on the device each time (nothing is cached but arguments); a step whose call list
+reports an error (a result list outgrew its capacity) falls back to the usual path and the plan is rebuilt.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_DETECT_FOCI_BATCH_TEMPLATES, CALL_DETECT_FOCI_BLOCKS,
+                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_WAIT_EVENT, FOCUS_DTYPE, CsCall, raw_arg)
+
+# argument slots of every entry: 'p' pointer, 'i' integer, 'd' double, in the order of the C prototype
+_SLOTS = {
+    "cs_stage_blocks": (CALL_STAGE_BLOCKS, "ppppid"),
+    "cs_event_record": (CALL_EVENT_RECORD, "ppp"),
+    "cs_stream_wait_event": (CALL_STREAM_WAIT_EVENT, "ppp"),
+    "cs_detect_foci_blocks": (CALL_DETECT_FOCI_BLOCKS, "ppippppppipp"),
+    "cs_detect_foci_batch_templates": (CALL_DETECT_FOCI_BATCH_TEMPLATES, "ppipippppipp"),
+}
+
+
+def _fill(call, fn, kinds, values, lane, after=-1):
+    call.fn, call.lane, call.after, call.rc = fn, lane, after, 0
+    np_, ni, nd = 0, 0, 0
+    for kind, v in zip(kinds, values):
+        v = raw_arg(v)
+        if kind == "p":
+            call.p[np_] = int(v) or None
+            np_ += 1
+        elif kind == "i":
+            call.i[ni] = int(v)
+            ni += 1
+        else:
+            call.d[nd] = float(v)
+            nd += 1
+
+
+class StepPlan:
+    """The native call list of stage_genome + detect_patterns for (genome, [2-D configuration, 1-D configuration], owned)."""
+
+    def __init__(self, genome, kernel_configs, owned, captured, staged):
+        self.ok = False
+        self.why = "not built"
+        cfg2, cfg1 = kernel_configs
+        by_name = {}
+        for name, args, _thread in captured:
+            by_name.setdefault(name, []).append(args)
+        stage, blocks, batch = (by_name.get(k, []) for k in ("cs_stage_blocks", "cs_detect_foci_blocks", "cs_detect_foci_batch_templates"))
+        if len(stage) != 1 or len(blocks) != 1 or len(batch) != 1:
+            # (extra stagings -- short chromosomes staged dense for the wider pattern --, retries, block-by-block fall-backs)
+            self.why = f"{len(stage)} staging calls, {len(blocks)} 2-D chains, {len(batch)} 1-D chains in the step (1 each wanted)"
+            return
+        ready = getattr(staged, "ready", None)
+        if ready is None:
+            self.why = "the staging has no ready event"
+            return
+        ctx_a, ctx_b, stream_b = raw_arg(stage[0][0]), raw_arg(batch[0][0]), raw_arg(batch[0][1])
+        rec_ev = [a for a in by_name.get("cs_event_record", []) if raw_arg(a[0]) == ctx_a and raw_arg(a[1]) == raw_arg(ready)]
+        waits = [a for a in by_name.get("cs_stream_wait_event", []) if raw_arg(a[0]) == ctx_b and raw_arg(a[1]) == stream_b
+                 and raw_arg(a[2]) == raw_arg(ready)]
+        if not rec_ev or not waits or raw_arg(blocks[0][0]) != ctx_a or blocks[0][11] is not None or batch[0][11] is not None:
+            self.why = (f"event records {len(rec_ev)}, event waits {len(waits)}, 2-D chain on the genome's context "
+                        f"{raw_arg(blocks[0][0]) == ctx_a}, windows asked for {blocks[0][11] is not None or batch[0][11] is not None}")
+            return
+        self.genome, self.owned, self.staged = genome, list(owned), staged
+        self.keep = (captured, kernel_configs)               # every argument array stays alive with the plan
+        self.n_blocks = int(blocks[0][2])
+        self.n_templates = int(batch[0][4])
+        if self.n_blocks != len(self.owned) or int(batch[0][2]) != len(self.owned):
+            self.why = "the chains did not cover every owned block"
+            return
+        dev = genome.dev
+        # result buffers of the plan's own (page-locked: the chains write into them from the device; the devices' shared
+        # result pools may be re-allocated by other calls)
+        n2 = int(np.frombuffer(blocks[0][10], dtype=np.int64).sum())
+        n1 = int(np.frombuffer(batch[0][10], dtype=np.int64).sum())
+        self.cap2, self.cap1 = max(4 * n2, 4096), max(2 * n1, 4096)
+        self.rec2, self.rec1 = dev.pinned_empty(self.cap2, FOCUS_DTYPE), dev.pinned_empty(self.cap1, FOCUS_DTYPE)
+        self.counts2, self.counts1 = blocks[0][10], batch[0][10]        # ctypes int64 arrays of the recorded calls
+        sizes = [genome.chrom_size(ci) for ci in self.owned]
+
+        def accept_io(cap, n_virtual, max_dist, kernel):
+            geo = np.empty((3, n_virtual), dtype=np.int32)
+            reps = n_virtual // len(sizes)
+            geo[0] = geo[1] = np.tile(np.asarray(sizes, dtype=np.int32), reps)
+            geo[2] = np.minimum(max_dist, 2 ** 31 - 1)
+            return dict(geo=geo, table=np.empty((cap, 4)), ok=np.empty(cap, dtype=np.uint8), kept=np.zeros(n_virtual, dtype=np.int64),
+                        k=np.shape(kernel))
+
+        md2 = max(cfg2["max_dist"] // genome.binsize, 1)
+        md1 = max(cfg1["max_dist"] // genome.binsize, 1)
+        self.acc2 = accept_io(self.cap2, self.n_blocks, md2, cfg2["kernels"][0])
+        self.acc1 = accept_io(self.cap1, self.n_blocks * self.n_templates, md1, cfg1["kernels"][0])
+        # Both chains are enqueued as soon as the staging is (lane 1 uses the entry's asynchronous form and waits for its chain
+        # afterwards), so they share the device the way the two pattern threads of detect_patterns make them -- minus the
+        # interpreter.  CHROMOSIGHT_HIP_PLAN_ORDERED=1 (measured: no gain on a rank's share of 8, 0.95 ms either way, and
+        # SLOWER on the whole genome, 4.2 against 3.95 ms) orders them ON THE DEVICE instead: lane 1 records an event behind
+        # the 1-D chain and the genome's stream waits for it before the 2-D chain -- no contention (a tile kernel in
+        # residence holds every register of every SIMD: the 1-D chain's kernels otherwise wait for its workgroups to drain),
+        # but the 1-D chain's 220 us then sit in front of the tile kernels instead of beside them.
+        contend = not os.environ.get("CHROMOSIGHT_HIP_PLAN_ORDERED")
+        self.done_b = dev.new_event()
+        stream_a = raw_arg(blocks[0][1])
+        calls = (CsCall * 10)()
+        _fill(calls[0], *_SLOTS["cs_stage_blocks"], stage[0], 0)
+        _fill(calls[1], *_SLOTS["cs_event_record"], rec_ev[-1], 0)
+        _fill(calls[2], *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=1)
+        b = list(batch[0])
+        b[8], b[9] = self.rec1.ctypes.data, self.cap1
+        b[7][0].reserved = 1                                  # asynchronous form: return once the chain is enqueued
+        _fill(calls[3], *_SLOTS["cs_detect_foci_batch_templates"], b, 1)
+        _fill(calls[4], *_SLOTS["cs_event_record"], (ctx_b, self.done_b, stream_b), 1)
+        _fill(calls[5], *_SLOTS["cs_stream_wait_event"], (ctx_a, stream_a, None if contend else self.done_b), 0, after=4)
+        if contend:
+            calls[5].fn, calls[5].after = CALL_EVENT_RECORD, -1          # (a harmless record instead of the wait)
+            _fill(calls[5], *_SLOTS["cs_event_record"], rec_ev[-1], 0)
+        a = list(blocks[0])
+        a[8], a[9] = self.rec2.ctypes.data, self.cap2
+        _fill(calls[6], *_SLOTS["cs_detect_foci_blocks"], a, 0)
+        self._accept(calls[7], self.rec2, self.counts2, self.acc2, cfg2, 0)
+        _fill(calls[8], CALL_DETECT_FOCI_BATCH_FINISH, "ppp", (ctx_b, stream_b, self.counts1), 1)
+        self._accept(calls[9], self.rec1, self.counts1, self.acc1, cfg1, 1)
+        self.calls = calls
+        self.lib = dev.lib
+        self.ok = True
+        self.why = ""
+
+    @staticmethod
+    def _accept(call, rec, counts, io, cfg, lane):
+        km, kn = io["k"]
+        values = (rec.ctypes.data, io["geo"].shape[1], counts, io["geo"][0].ctypes.data, io["geo"][1].ctypes.data,
+                  io["geo"][2].ctypes.data, 0, int(km), int(kn), cfg["max_perc_undetected"] / 100, cfg["max_perc_zero"] / 100, 1, 1,
+                  io["table"].ctypes.data, io["ok"].ctypes.data, io["kept"].ctypes.data)
+        assert len(values) == 16
+        _fill(call, CALL_ACCEPT_RECORDS, "pippppiiiddiippp", values, lane)
+
+    def run(self):
+        """One step: (records of the 2-D configuration, records of the 1-D configuration) of this rank, in detect_genome's
+        layout (block, bin1, bin2, score, pvalue, kernel_id, iteration) -- or None when a call reported an error."""
+        rc = self.lib.cs_run_calls(self.calls, len(self.calls))
+        if rc != 0:
+            if os.environ.get("CHROMOSIGHT_HIP_DEBUG"):
+                import sys
+                sys.stderr.write(f"[chromosight_amd] step plan failed: rc {[c.rc for c in self.calls]}\n")
+            return None
+        out = []
+        owned = np.asarray(self.owned, dtype=np.float64)
+        for io, n_t in ((self.acc2, 1), (self.acc1, self.n_templates)):
+            kept = io["kept"]
+            total = int(kept.sum())
+            rec = np.empty((total, 7))
+            rec[:, 0] = np.repeat(np.tile(owned, n_t), kept)
+            rec[:, 1:5] = io["table"][:total]
+            rec[:, 5] = np.repeat(np.repeat(np.arange(n_t, dtype=np.float64), len(self.owned)), kept)
+            rec[:, 6] = 0.0
+            out.append(rec)
+        return out
+
+
+def plannable(genome, kernel_configs, tsvd):
+    """The configuration a StepPlan covers: a 2-D pattern with one template next to a 1-D pattern with 2-4 templates of one size,
+    single iterations, the device pipeline."""
+    if tsvd is not None or len(kernel_configs) != 2 or os.environ.get("CHROMOSIGHT_HIP_NO_STEP_PLAN"):
+        return False
+    if not (hasattr(genome, "view_for") and hasattr(genome, "dev") and hasattr(genome.dev, "pinned_empty")):
+        return False
+    cfg2, cfg1 = kernel_configs
+    if cfg2["max_iterations"] != 1 or cfg1["max_iterations"] != 1 or cfg2["max_dist"] <= 0 or cfg1["max_dist"] != 0:
+        return False
+    k2, k1 = cfg2["kernels"], cfg1["kernels"]
+    if len(k2) != 1 or not 2 <= len(k1) <= 4 or len({np.shape(k) for k in k1}) != 1:
+        return False
+    return np.shape(k2[0])[0] == np.shape(k2[0])[1] and np.shape(k1[0])[0] == np.shape(k1[0])[1]

@@ -402,6 +402,30 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
                   const int32_t* h_cols, const double* h_vals, int64_t n, int32_t min_size, int32_t diag_only,
                   int32_t* h_foci_rows, int32_t* h_foci_cols, int32_t* h_foci_size, int64_t cap, int64_t* n_foci);
 
+/* ---- a genome step as ONE native call -------------------------------------------------------------------------------
+ * The entries above are what a detect step is made of -- cs_stage_blocks, an event, cs_detect_foci_blocks for the 2-D
+ * pattern, cs_detect_foci_batch_templates for a 1-D pattern's templates on another context, cs_accept_records on each
+ * result -- and on a rank's share of a genome the interpreter between them costs as much as their kernels (reference:
+ * cli/chromosight.py:738-755, the same calls per sub-matrix task).  cs_run_calls runs a list of such calls natively: the
+ * calls of lane 0 on the calling thread, in order, the calls of lane k > 0 in order on a worker thread of the library
+ * (kept between calls), `after` >= 0 making a call wait until call number `after` of the list has returned (how a lane
+ * waits for another lane's event record).  The argument slots are the entry's own arguments in order: pointers in p[],
+ * integers in i[], doubles in d[] (chromosight_amd/plan.py builds them from the arguments of a step that ran the usual way
+ * and replays them on the same buffers).  rc of every call is filled in; a lane stops at its first failing call; the
+ * return value is the first non-zero rc (0: every call succeeded). */
+enum { CS_CALL_STAGE_BLOCKS = 1, CS_CALL_EVENT_RECORD = 2, CS_CALL_STREAM_WAIT_EVENT = 3, CS_CALL_DETECT_FOCI_BLOCKS = 4,
+       CS_CALL_DETECT_FOCI_BATCH_TEMPLATES = 5, CS_CALL_ACCEPT_RECORDS = 6, CS_CALL_DETECT_FOCI_BATCH_FINISH = 7 };
+typedef struct {
+    int32_t fn;        /* CS_CALL_* */
+    int32_t lane;      /* 0: the calling thread */
+    int32_t after;     /* index of a call that must have returned first, or -1 */
+    int32_t rc;        /* out */
+    void* p[12];
+    int64_t i[6];
+    double d[2];
+} cs_call;
+int cs_run_calls(cs_call* calls, int32_t n_calls);
+
 /* ---- the exchange step of the sharded path on RCCL (one process per GPU) --------------------------------
  * The path shards over independent sub-matrices like the reference's Pool.imap (cli/chromosight.py:748-752); ranks only
  * exchange pattern records (variable-length lists of fixed-size float64 records) and small float64 vectors (the pileup of

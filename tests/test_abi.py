@@ -45,6 +45,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.CsCsr) == 72
     assert ctypes.sizeof(_lib.CsFociParams) == 48
     assert ctypes.sizeof(_lib.CsStageBlock) == 56
+    assert ctypes.sizeof(_lib.CsCall) == 176
     assert ctypes.sizeof(_lib.CsFocus) == 40 == _lib.FOCUS_DTYPE.itemsize
 
 
@@ -57,7 +58,7 @@ def test_struct_sizes_against_the_header_compiled_as_c(tmp_path):
         pytest.skip("no C compiler")
     pairs = [("cs_matrix", _lib.CsMatrix), ("cs_kernel", _lib.CsKernel), ("cs_normxcorr2_params", _lib.CsNormxcorr2Params),
              ("cs_csr", _lib.CsCsr), ("cs_foci_params", _lib.CsFociParams), ("cs_focus", _lib.CsFocus),
-             ("cs_stage_block", _lib.CsStageBlock)]
+             ("cs_stage_block", _lib.CsStageBlock), ("cs_call", _lib.CsCall)]
     header = ROOT / "include" / "chromosight_hip.h"
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "%s"\nint main(void) {\n%s    return 0;\n}\n' % (

@@ -362,6 +362,33 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert set(np.unique(want_b[:, 5])) == {0.0, 1.0, 2.0}
 
 
+def test_genome_step_as_one_native_call_equals_the_two_calls():
+    """parallel.genome_step: the first step of a layout runs stage_genome + detect_patterns and records the library calls it
+    made; every later step is ONE cs_run_calls on those arguments (chromosight_amd/plan.py) -- staging, both patterns' chains
+    and the acceptance rules recomputed natively -- and must give the records of the two calls, every time; a second
+    genome (other data, same code path) gets its own plan."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    borders = copy.deepcopy(ck.borders)
+    for seed in (5, 6):
+        # (chromosomes long enough to be staged as bands for both patterns: a short one staged dense for the loops needs a
+        # second staging call for the borders, and such a step is not planned)
+        cool, _ = make_cool(12_000, 200, 2000, seed=seed, template=template, chrom_sizes=[4000, 3500, 2500, 2000])
+        dcool = pipeline.DeviceCool(cool)
+        staged = parallel.stage_genome(dcool, [loops, borders])
+        want = parallel.detect_patterns(dcool, [loops, borders], staged=staged)
+        first = parallel.genome_step(dcool, [loops, borders])
+        plans = dcool.__dict__["_step_plans"]
+        assert len(plans) == 1 and all(p.ok for p in plans.values()), [p.why for p in plans.values()]
+        for step in [first] + [parallel.genome_step(dcool, [loops, borders]) for _ in range(4)]:
+            for got, ref in zip(step, want):
+                assert got.shape == ref.shape and ref.shape[0] > 30
+                assert np.array_equal(got[:, [0, 1, 2, 5, 6]], ref[:, [0, 1, 2, 5, 6]])
+                assert np.abs(got[:, 3] - ref[:, 3]).max() < 1e-9
+                assert np.allclose(got[:, 4], ref[:, 4], rtol=1e-9, atol=1e-300)
+
+
 def test_switchable_chains_equal_the_default_run(monkeypatch):
     """cs_detect_foci_batch_templates' asynchronous form (chain enqueued, cs_detect_foci_batch_finish later;
     CHROMOSIGHT_HIP_EARLY_CHAIN=1 makes detect_patterns use it for the 1-D pattern) == the default run of the same patterns."""

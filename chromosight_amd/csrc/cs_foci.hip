@@ -421,8 +421,10 @@ constexpr int kRunWeights = 3 * 17 * 17;               // the three weight sets 
 // dynamic LDS: tile (tile_cap doubles), then the weights, then the row / column flags
 __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
                                                                 const int* __restrict__ rows, const int* __restrict__ cols,
-                                                                long long n_px, double* __restrict__ out_corr, int tile_cap)
+                                                                long long n_px, double* __restrict__ out_corr, int tile_cap,
+                                                                int no_run17)
 {
+    const bool RUN_NO_FAST = no_run17 != 0;
     extern __shared__ __attribute__((aligned(16))) double run_smem[];
     double* const tile = run_smem;
     double* const wl = run_smem + tile_cap;
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
         __syncthreads();
     };
     extent(valid);
-    const int b_lo = red[4], b_hi = red[5];
+    const int b_lo = __builtin_amdgcn_readfirstlane(red[4]), b_hi = __builtin_amdgcn_readfirstlane(red[5]);   // (uniform: the
+                                                              // sub-matrix's table entry is read through the scalar unit)
     double r = 0.0, nobs = 0.0;
     // A workgroup's 256 entries normally belong to one sub-matrix; the few that straddle two (or more, tiny ones) take them
     // one after the other, each with its own tile -- left to the direct route, one such workgroup (289 dependent global
@@ -490,17 +493,36 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                 const int q = C0 + idx;
                 cfl[idx] = (bins && q >= 0 && q < A.ns) ? A.miss_col[q] : 0;
             }
-            for (int idx = tid; idx < RN * DN; idx += 256) {
-                const int rr = idx / DN, dd = idx - rr * DN;
-                const int p = P0 + rr;
-                tile[idx] = load_signal(A, p, p + D0 + dd);
-            }
-            __syncthreads();
             // detection configuration, square template: the branch-free forms (every window of the run inside the matrix,
             // or not)
             const bool lean = bins && A.sym_upper && A.full && A.max_dist >= 0 && km == kn;
             const bool interior = P0 >= 0 && P0 + RN <= A.ms && C0 >= 0 && C0 + CN <= A.ns;
-            if (mine && lean && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
+            // runs on one or two diagonals under a 17 x 17 template (1-D patterns): the transposed tile of rescore_run17
+            const bool run17 = lean && kn == 17 && d_hi - d_lo <= 1 && RN <= kRunRP && DN * kRunRP <= tile_cap && !RUN_NO_FAST;
+            if (run17) {
+                // 8 rows x 8 diagonals per wave and step: 64-byte pieces of band rows in, 8 consecutive doubles of 8 tile
+                // rows out
+                const int n_dc = (DN + 7) >> 3, n_ch = ((RN + 7) >> 3) * n_dc;
+                for (int ch = tid >> 6; ch < n_ch; ch += 4) {
+                    const int cr = ch / n_dc, cd = ch - cr * n_dc;
+                    const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
+                    const int p = P0 + rr;
+                    if (rr < RN && dd < DN) tile[dd * kRunRP + rr] = load_signal(A, p, p + D0 + dd);
+                }
+            } else {
+                for (int idx = tid; idx < RN * DN; idx += 256) {
+                    const int rr = idx / DN, dd = idx - rr * DN;
+                    const int p = P0 + rr;
+                    tile[idx] = load_signal(A, p, p + D0 + dd);
+                }
+            }
+            __syncthreads();
+            if (run17) {
+                if (mine) {
+                    if (interior) rescore_run17<false>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
+                    else rescore_run17<true>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
+                }
+            } else if (mine && lean && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && interior && kn == 15) rescore_pixel_lane_lds_interior<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && kn == 17) rescore_pixel_lane_lds_interior<17, true>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && kn == 15) rescore_pixel_lane_lds_interior<15, true>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
@@ -1180,7 +1202,7 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
             if ((size_t)tile_cap * 8 > 48 * 1024) tile_cap = 48 * 1024 / 8;        // wider scans: the direct route where needed
             const size_t smem = (size_t)tile_cap * 8 + kRunWeights * 8 + 512 + 1024;
             hipLaunchKernelGGL(rescore_run_batch_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), smem, stream, tab, blk, rows,
-                               cols, n_total, vals, tile_cap);
+                               cols, n_total, vals, tile_cap, getenv("CHROMOSIGHT_HIP_NO_RUN17") ? 1 : 0);
         }
     }
     // every sub-matrix scans the diagonals 0 and 1 (borders, hairpins: max_dist = 0 in the config): the foci are runs

@@ -191,6 +191,88 @@ __device__ __forceinline__ void rescore_pixel_lane_lds_interior(const CorrArgs<d
     r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, true, &nobs);
 }
 
+// The 17 x 17 walk of a run on at most two neighbouring diagonals (borders: every template, every sub-matrix), written
+// for the instruction-issue floor: the interior walk above is ~25 instructions per window pixel -- five LDS reads (pixel,
+// three weights, a column flag), the predicate from compares, six selects -- and the kernel around it was the second
+// largest of a genome step (0.8 ms of device time on the 23-block genome).  Here
+//   * the tile is staged TRANSPOSED (tileT[(d - D0) * kRunRP + (p - P0)]): the lanes of a wave are consecutive rows of
+//     one or two diagonals, so an LDS read takes consecutive doubles; kRunRP = 146 rows (256 entries on two diagonals
+//     span 129 rows when they start on the second one, + 16 of the template) = 18 (mod 32) doubles puts the second
+//     diagonal's lanes on the other 32 banks but for two doubles;
+//   * the weights come through the scalar unit (the same address for every lane: s_load from the template's table);
+//   * the predicate of a window row is ONE 17-bit word per lane, built from ranges once per row (the EDGE rules of
+//     missing_from_flags included), nm is its population count (exact: the sums of 1.0 it replaces are integers),
+//     and ka / kb take fma(w, m ? 1.0 : 0.0, .) -- w * 1.0 is exact and x + 0.0 == x, so the sums are bit for bit those
+//     of `ka += m ? w : 0.0`;
+// 7 vector instructions per window pixel (3 sums, 2 for the multiplier, 2 mask sums) and one LDS read.  Same operations
+// on the same values in the same order as rescore_pixel_lane: identical results.
+constexpr int kRunRP = 146;
+
+__device__ __forceinline__ unsigned run_range_bits(int a, int b)     // bits k with a <= k < b, clipped to 0 .. 17
+{
+    const int ac = min(max(a, 0), 17), bc = min(max(b, 0), 17);
+    return bc > ac ? ((1u << bc) - 1u) & ~((1u << ac) - 1u) : 0u;
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void rescore_run17(const CorrArgs<double>& A, const double* tileT, const unsigned char* rfl,
+                                              const unsigned char* cfl, int P0, int C0, int D0, int oi, int oj, double& r,
+                                              double& nobs)
+{
+    constexpr int K = 17, kh = 8, kk = K * K;
+    constexpr unsigned all = (1u << K) - 1u;
+    r = 0.0;
+    nobs = A.ks.n;
+    if (EDGE && !((oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns))) return;
+    if (pixel_forced_zero(A, oi, oj)) return;
+    typedef const __attribute__((address_space(4))) double DblC;
+    DblC* const w = (DblC*)(unsigned long long)A.w;
+    const int ms = A.ms, ns = A.ns, md = min(A.max_dist, 1 << 20);
+    const int q0 = oj - kh, p0 = oi - kh;
+    unsigned cbits = 0u, qin = all, qge = 0u, qlt = 0u;
+#pragma unroll
+    for (int kj = 0; kj < K; ++kj) {
+        cbits |= (cfl[q0 - C0 + kj] != 0 ? 1u : 0u) << kj;
+        if constexpr (EDGE) {
+            const int q = q0 + kj;
+            qin &= ~(((unsigned)q < (unsigned)ns ? 0u : 1u) << kj);
+            qge |= (q >= ns ? 1u : 0u) << kj;
+            qlt |= (((q < 0) | (q < md + K)) ? 1u : 0u) << kj;
+        }
+    }
+    double cs_ = 0, s1 = 0, s2 = 0, ka = 0, kb = 0;
+    int nm_i = 0;
+    const double* row = tileT + (q0 - p0 - D0) * kRunRP + (p0 - P0);         // window row 0, kj = 0; one row on: 1 - kRunRP
+#pragma unroll 1
+    for (int ki = 0; ki < K; ++ki, row -= kRunRP - 1) {
+        const int p = p0 + ki;
+        const int dl = q0 - p;                                               // diagonal of the row's first pixel
+        const unsigned rc = rfl[p - P0] != 0 ? all : cbits;
+        const unsigned below = run_range_bits(-K - dl, -dl);                 // -K <= d < 0
+        const unsigned band = run_range_bits(-dl, md - dl + 1);              // 0 <= d <= max_dist
+        unsigned M = below | (rc & band);
+        if constexpr (EDGE) {
+            const unsigned in_b = ((unsigned)p < (unsigned)ms) ? qin : 0u;
+            const unsigned out_b = (qge & (p >= ms - md - 2 ? all : 0u)) | (~qge & (p < 0 ? qlt : 0u));
+            M = (in_b & rc & band) | (~in_b & out_b & all) | below;
+        }
+        nm_i += __builtin_popcount(M);
+        DblC* const wr = w + ki * K;
+#pragma unroll
+        for (int kj = 0; kj < K; ++kj) {
+            const double v = row[kj * kRunRP];
+            cs_ = fma(v, wr[kj], cs_);
+            s1 += v;
+            s2 = fma(v, v, s2);
+            const int sel = ((int)(M << (31 - kj))) >> 31;                   // bit kj of M as 0 / -1
+            const double mf = __hiloint2double(sel & 0x3FF00000, 0);        // 0.0 / 1.0
+            ka = fma(wr[kk + kj], mf, ka);
+            kb = fma(wr[2 * kk + kj], mf, kb);
+        }
+    }
+    r = pearson_from_sums<double>(cs_, s1, s2, (double)nm_i, ka, kb, A.ks, true, &nobs);
+}
+
 // KN > 0: template width known at compile time (17: every built-in 2-D / 1-D template but the 15 x 15 hairpin) -- the
 // row loop is unrolled, so its 17 LDS reads are issued together instead of one dependent read per multiply-add (the
 // runtime-size loop ran at a third of the instruction-issue floor).

@@ -17,6 +17,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/chromosight_hip.h"
@@ -69,6 +70,10 @@ struct cs_ctx {
     void* h_tab = nullptr;
     void* d_tab = nullptr;
     size_t tab_bytes = 0;
+    // mask tables of all blocks in one launch: while set, prepare_regular_mask<float> appends a block's arguments and its
+    // number of workgroups here instead of launching (cs::launch_mask_prep_batch)
+    std::vector<cs::MaskPrepArgs<float>>* prep_defer = nullptr;
+    std::vector<int> prep_groups;
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
@@ -565,8 +570,20 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     P.side = side;
     P.fix_rows = fix_rows;
     P.fix_cols = fix_cols;
-    int rc = cs::launch_mask_prep<TC>(P, stream);
-    if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
+    bool deferred = false;
+    if constexpr (std::is_same<TC, float>::value) {
+        if (ctx->prep_defer) {
+            const int n_wg = cs::mask_prep_blocks<float>(P);
+            if (n_wg < 0) return fail(ctx, CS_ERR_HIP, "mask tables: template too large");
+            ctx->prep_defer->push_back(P);
+            ctx->prep_groups.push_back(n_wg);
+            deferred = true;
+        }
+    }
+    if (!deferred) {
+        int rc = cs::launch_mask_prep<TC>(P, stream);
+        if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
+    }
     if (edge_tables) A.fix_on = 1;
     A.rim_in_kernel = (edge_tables && !edge_records) ? 1 : 0;
     A.reg_mode = 1;
@@ -2296,8 +2313,25 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // for their workgroups to drain, and its lane's next tile kernel with it
         const bool prepared = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE");
         int table_rsym = -1;
+        // CHROMOSIGHT_HIP_PREP_BATCH=1 (experiment, measured neutral to slower, off by default): the mask tables of all blocks
+        // built by ONE launch on the caller's stream instead of one launch per block on the lanes.  The 23 launches of a
+        // genome take 220 us of device timeline, but they run WHILE the host prepares the next block's arguments (~ 9 us per
+        // block, and in a genome step all of it under the staging kernels): the one launch waits for the whole loop and the
+        // call is no shorter (loops pass of the 23-block genome 2.69 / 2.70 ms; a rank's share of 8: 0.93 -> 0.96 ms).
+        const bool prep_batch = prepared && std::getenv("CHROMOSIGHT_HIP_PREP_BATCH") != nullptr;
+        const size_t tile_tab_bytes = prepared ? al(cs::mfma_blocks_table_bytes(n_blocks)) : 0;
+        std::vector<cs::MaskPrepArgs<float>> prep_list;
+        struct PrepDefer {
+            cs_ctx* c;
+            PrepDefer(cs_ctx* c_, std::vector<cs::MaskPrepArgs<float>>* v) : c(c_)
+            {
+                c->prep_defer = v;
+                c->prep_groups.clear();
+            }
+            ~PrepDefer() { c->prep_defer = nullptr; }
+        } prep_defer(ctx, prep_batch ? &prep_list : nullptr);
         if (prepared) {
-            const size_t need = cs::mfma_blocks_table_bytes(n_blocks);
+            const size_t need = tile_tab_bytes + cs::mask_prep_table_bytes(n_blocks);
             if (need > ctx->tab_bytes) {
                 CS_HIP(ctx, hipDeviceSynchronize());
                 if (ctx->h_tab) CS_HIP(ctx, hipHostFree(ctx->h_tab));
@@ -2349,8 +2383,10 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 rc0 = ensure_wfrag(ctx, stream, A0.km, A0.kn, &E0);
                 if (rc0) return rc0;
             }
-            CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
-            for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
+            if (!prep_batch) {
+                CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
+                for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
+            }
         }
         laps.lap("pool, weights, events");
         // (largest blocks first on every lane: the short ones fill the end)
@@ -2361,7 +2397,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 return (long long)params[x].ms * (foci[x].hi_diag - foci[x].lo_diag + 1) > (long long)params[y].ms * (foci[y].hi_diag - foci[y].lo_diag + 1);
             });
         for (int b : launch_order) {
-            const int lane = lane_of[b];
+            const int lane = prep_batch ? 0 : lane_of[b];      // (batched mask tables: nothing is launched per block here)
             hipStream_t stream = lane == 0 ? (hipStream_t)stream_ : ctx->s_blk[lane - 1];
             struct WsSwap {                   // the side lanes build their mask tables in their own scratch
                 cs_ctx* c;
@@ -2420,6 +2456,16 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 return rc;
             }
         }
+        if (prep_batch) {
+            prep_defer.c->prep_defer = nullptr;
+            int rcp = cs::launch_mask_prep_batch(prep_list.data(), ctx->prep_groups.data(), (int)prep_list.size(), (char*)ctx->h_tab + tile_tab_bytes,
+                                                 (char*)ctx->d_tab + tile_tab_bytes, stream);
+            if (rcp) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rcp));
+            if (!table) {                             // the lanes' tile kernels follow the tables (and the zeroed counter)
+                CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));
+                for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
+            }
+        }
         laps.lap("mask tables + arguments");
         if (prepared && !table) {
             // one persistent launch per block, each on the lane that built its mask tables
@@ -2433,7 +2479,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 }
             }
         }
-        if (n_lanes > 1) {
+        if (n_lanes > 1 && !(prep_batch && table)) {          // (batched tables + one tile launch: the lanes carried nothing)
             for (int k = 0; k < n_lanes - 1; ++k) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
                 CS_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_blk[k], 0));

@@ -98,6 +98,7 @@ struct cs_ctx {
     int last_kernel = 0;     // cs_last_kernel()
     int range_check = 0;     // cs_ctx_set_range_check()
     bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
+    bool allow_lazy = false; // the entry in progress takes CS_LAYOUT_BAND_LAZY signals (check_matrix)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
     // flags), per arithmetic type: a detect run calls with the same template thousands of times
     struct TemplateCache {
@@ -172,6 +173,15 @@ int fail(cs_ctx* ctx, int code, const char* fmt, ...)
         CS_HIP(ctx, hipSetDevice((ctx)->device));                                            \
     } while (0)
 
+// entries whose float64 kernels all read their signal through load_signal take lazily evaluated bands (cs_stage_block)
+struct AllowLazy {
+    cs_ctx* c;
+    bool was;
+    explicit AllowLazy(cs_ctx* c_);
+    ~AllowLazy();
+};
+inline bool is_band(int layout) { return layout == CS_LAYOUT_BAND || layout == CS_LAYOUT_BAND_LAZY; }
+
 cs::MatView view_of(const cs_matrix* m)
 {
     cs::MatView v;
@@ -182,6 +192,15 @@ cs::MatView view_of(const cs_matrix* m)
     v.band_w = m ? m->band_w : 0;
     v.row0 = m ? m->row0 : 0;
     return v;
+}
+
+AllowLazy::AllowLazy(cs_ctx* c_) : c(c_), was(c_ ? c_->allow_lazy : false)
+{
+    if (c) c->allow_lazy = true;
+}
+AllowLazy::~AllowLazy()
+{
+    if (c) c->allow_lazy = was;
 }
 
 struct HostStats {
@@ -787,6 +806,9 @@ int check_matrix(cs_ctx* ctx, const cs_matrix* m, const char* what, int ns)
         if (m->ld < ns) return fail(ctx, CS_ERR_INVALID, "%s: ld < number of columns", what);
     } else if (m->layout == CS_LAYOUT_BAND) {
         if (m->band_w <= 0 || m->ld < m->band_w) return fail(ctx, CS_ERR_INVALID, "%s: bad band geometry", what);
+    } else if (m->layout == CS_LAYOUT_BAND_LAZY && ctx->allow_lazy) {
+        // a lazily evaluated float64 band (cs_stage_block): only the float64 kernels behind the batched foci entries read it
+        if (m->band_w <= 0 || m->band_lo != 0 || m->row0 != 0 || m->dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "%s: bad lazy band", what);
     } else {
         return fail(ctx, CS_ERR_INVALID, "%s: bad layout", what);
     }
@@ -1796,6 +1818,17 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_s
         B.band64 = (double*)s.d_band64;
         B.band32 = (float*)s.d_band32;
         B.law = s.d_law;
+        B.ld64 = s.ld;
+        B.w64 = 0;
+        B.pad_ = 0;
+        B.lazy = nullptr;
+        if (s.f64_diags > 0 || s.d_lazy) {
+            if (B.dense || !s.d_lazy || !s.d_band64 || s.f64_diags <= 0 || s.ld64 < s.f64_diags || (s.ld64 & 1))
+                return fail(ctx, CS_ERR_INVALID, "block %d: a lazy float64 band needs the band layout, d_lazy, d_band64 and an even ld64 >= f64_diags > 0", b);
+            B.ld64 = s.ld64;
+            B.w64 = std::min<int>(s.f64_diags, B.width);
+            B.lazy = reinterpret_cast<cs::LazyBand*>(s.d_lazy);
+        }
         B.group0 = B.n_groups = 0;
         n_groups += (s.n + kRowsPerGroup - 1) / kRowsPerGroup;
         pitch = std::max(pitch, B.n_diags);
@@ -2112,6 +2145,7 @@ int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream_, int32_t n_blocks,
                                    cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows)
 {
     CS_ENTER(ctx);
+    AllowLazy allow_lazy(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (n_blocks <= 0 || !signals || !kernels || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
         return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
@@ -2139,7 +2173,7 @@ int cs_detect_foci_batch_templates(cs_ctx* ctx, void* stream_, int32_t n_blocks,
             int rc = check_foci_args(ctx, signals + b, kernels + t, p, fp);
             if (rc) return rc;
             const int w = fp->hi_diag - fp->lo_diag + 1;
-            if (signals[b].layout != CS_LAYOUT_BAND || w < 1 || w > 4 || fp->lo_diag < 0 || (p->row_end > p->row_begin))
+            if (!is_band(signals[b].layout) || w < 1 || w > 4 || fp->lo_diag < 0 || (p->row_end > p->row_begin))
                 return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry takes 1-D patterns (<= 4 scanned diagonals from 0 up) of whole banded blocks");
             if (fp->pearson != foci[0].pearson || fp->min_size != foci[0].min_size || fp->diag_only != foci[0].diag_only ||
                 fp->inter != foci[0].inter || fp->want_windows != foci[0].want_windows)
@@ -2221,6 +2255,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                           int64_t cap, int64_t* h_n_foci, double* h_windows)
 {
     CS_ENTER(ctx);
+    AllowLazy allow_lazy(ctx);
     Laps laps("detect_foci_blocks");
     hipStream_t stream = (hipStream_t)stream_;
     if (n_blocks <= 0 || !signals || !kernel || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
@@ -2239,7 +2274,9 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         if (p->row_end > p->row_begin) return fail(ctx, CS_ERR_UNSUPPORTED, "the batch entry takes whole blocks");
         if (fp->hi_diag < fp->lo_diag) return fail(ctx, CS_ERR_INVALID, "empty diagonal range");
         const int w = fp->hi_diag - fp->lo_diag + 1;
-        all_narrow = all_narrow && signals[b].layout == CS_LAYOUT_BAND && w <= 4 && fp->lo_diag >= 0;
+        all_narrow = all_narrow && is_band(signals[b].layout) && w <= 4 && fp->lo_diag >= 0;
+        if (signals[b].layout == CS_LAYOUT_BAND_LAZY && !(signals_f32 && signals_f32[b].d_ptr) && !(is_band(signals[b].layout) && w <= 4 && fp->lo_diag >= 0))
+            return fail(ctx, CS_ERR_INVALID, "block %d: a lazily evaluated float64 band needs its float32 twin for the tile kernel", b);
         if ((long long)p->ms * p->ns >= (1ll << kKeyShift)) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is too large for the batch keys", b);
         pixels += (long long)p->ms * std::min<long long>(w, p->ns);
     }
@@ -2427,7 +2464,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             cs_matrix map;                        // geometry of the (virtual) coefficient map: the scanned diagonals
             map.d_ptr = nullptr;
             map.dtype = CS_F32;
-            map.layout = signals[b].layout;
+            map.layout = is_band(signals[b].layout) ? CS_LAYOUT_BAND : signals[b].layout;
             map.row0 = 0;
             if (map.layout == CS_LAYOUT_BAND) {
                 map.band_lo = foci[b].lo_diag;

@@ -13,7 +13,7 @@ constexpr int kWave = 64;
 struct MatView {
     void* ptr;
     long long ld;
-    int layout;   // 0 dense row-major, 1 diagonal band
+    int layout;   // 0 dense row-major, 1 diagonal band, 2 diagonal band recomputed on demand (ptr -> LazyBand, below)
     int band_lo;  // first stored diagonal offset (band)
     int band_w;   // number of stored diagonals (band)
     long long row0;  // matrix row stored at ptr: the buffer holds a window of rows (0 = the whole matrix)
@@ -26,6 +26,63 @@ __device__ __forceinline__ long long mat_offset(const MatView& m, int p, int q)
     int d = q - p - m.band_lo;
     if (d < 0 || d >= m.band_w) return -1;
     return ((long long)p - m.row0) * m.ld + d;
+}
+
+// layout 2 (CS_LAYOUT_BAND_LAZY): the float64 band of a staged intra block WITHOUT its storage.  A genome's float64 bands
+// are twice the bytes of the float32 bands the tile kernel reads, and the float64 consumers -- the exact evaluation of
+// the candidates, the windows of the records -- touch 1e-3 of them; writing them was a third of the staging pass.  The
+// pixel (p, q) of the band is a pure function of the genome's pixel table, the block's distance law and the ICE weights
+// (cs_stage.hip stage_tile_kernel: stage_value below), so MatView::ptr points to this descriptor (device memory,
+// written by cs_stage_blocks) and load_signal recomputes the value: from `near` for the first near_w diagonals (stored:
+// the runs of a 1-D pattern live there), else by a binary search of the pixel table's row.  band_lo / band_w of the
+// view still bound the diagonals that read as non-zero (a narrower view of the same block shares the descriptor).
+struct LazyBand {
+    const long long* indptr;       // the genome's pixel table (CSR over all bins, columns >= row)
+    const int* indices;
+    const void* data;              // float32 or float64 counts
+    const double* weight;          // ICE weights (NaN: undetectable bin)
+    const double* law;             // the block's distance law, n_diags values
+    const double* near_;           // float64 band of the diagonals 0 .. near_w - 1, row pitch near_ld (or null)
+    long long row0;                // first genome bin of the block
+    long long near_ld;
+    double max_val;
+    int n, n_diags, near_w, data_is_f64;
+};
+
+// the staged value of one stored pixel (contacts_map.py:531-540, preprocessing.py:296-302): balance, detrend by the law of
+// its diagonal (0: inf / NaN), >= max_val -> 1, NaN -> 0
+__device__ __forceinline__ double stage_detrend(double v, double y, double max_val)
+{
+    double out = v / y;                                    // law 0 (empty diagonal) -> inf / NaN, as preprocessing.py:298
+    if (max_val > 0.0 && out >= max_val) out = 1.0;        // :301-302
+    return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
+}
+
+__device__ __forceinline__ double lazy_stored_value(const LazyBand& L, long long k, int p, int q)
+{
+    const double x = L.data_is_f64 ? reinterpret_cast<const double*>(L.data)[k] : (double)reinterpret_cast<const float*>(L.data)[k];
+    const int d = q - p;
+    return stage_detrend((x * L.weight[L.row0 + p]) * L.weight[L.row0 + q], d < L.n_diags ? L.law[d] : 0.0, L.max_val);
+}
+
+// pixel (p, q) of the block, 0 <= p <= q < n, on a diagonal the view keeps
+__device__ __forceinline__ double lazy_load(const MatView& m, int p, int q)
+{
+    const LazyBand& L = *reinterpret_cast<const LazyBand*>(m.ptr);
+    const int d = q - p;
+    if (d - m.band_lo < 0 || d - m.band_lo >= m.band_w || d < 0 || d >= L.n_diags) return 0.0;
+    if (d < L.near_w) return L.near_[(long long)p * L.near_ld + d];
+    const long long r = L.row0 + p;
+    long long lo = L.indptr[r], hi = L.indptr[r + 1];
+    const long long end = hi;
+    const int c = (int)(L.row0 + q);
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (L.indices[mid] < c) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo >= end || L.indices[lo] != c) return 0.0;
+    return lazy_stored_value(L, lo, p, q);
 }
 
 template <typename T>
@@ -217,6 +274,7 @@ template <typename TC>
 __device__ __forceinline__ TC load_signal(const CorrArgs<TC>& A, int p, int q)
 {
     if ((p < 0) | (p >= A.ms) | (q < 0) | (q >= A.ns)) return TC(0);
+    if (A.sig.layout == 2) return (TC)lazy_load(A.sig, p, q);
     long long off = mat_offset(A.sig, p, q);
     if (off < 0) return TC(0);
     if (A.sig_is_f64) return (TC)(((const double*)A.sig.ptr)[off]);

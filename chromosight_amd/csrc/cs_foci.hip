@@ -399,11 +399,23 @@ __global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<doubl
                                                             long long n_px, const long long* __restrict__ n_ptr,
                                                             double* __restrict__ out_corr, double* __restrict__ out_nobs)
 {
+    __shared__ double lazy_win[4][kLazyWinMax];             // (lazily evaluated float64 bands: the wave's window)
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= n_px || (n_ptr && t >= *n_ptr)) return;
     double r, nobs;
-    rescore_pixel(tab[blk[t]], rows[t], cols[t], lane, r, nobs);
+    const CorrArgs<double>& A = tab[blk[t]];
+    const int oi = rows[t], oj = cols[t];
+    if (A.sig.layout == 2 && A.km * A.kn <= kLazyWinMax && oi >= 0 && oi < A.ms && oj >= 0 && oj < A.ns) {     // wave-uniform
+        double* win = lazy_win[threadIdx.x >> 6];
+        lazy_gather_window(A, oi - (A.km - 1) / 2, oj - (A.kn - 1) / 2, lane, win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        rescore_pixel(A, oi, oj, lane, r, nobs, win);
+    } else {
+        rescore_pixel(A, oi, oj, lane, r, nobs);
+    }
     if (lane == 0) {
         out_corr[t] = r;
         if (out_nobs) out_nobs[t] = nobs;
@@ -673,7 +685,8 @@ __global__ __launch_bounds__(kSmallThreads) void gather_foci_batch_kernel(const 
 // window statistics of one pattern by one wave (validate_patterns, detection.py:18-155); rec_out / win_out
 // may be nullptr (beyond the caller's capacity) or page-locked host memory
 __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, int inter, int row, int col, int fsize, double score,
-                                                     double nobs, FocusRec* rec_out, double* win_out, int lane)
+                                                     double nobs, FocusRec* rec_out, double* win_out, int lane,
+                                                     double* lazy_win = nullptr)
 {
     const int km = A.km, kn = A.kn, kk = km * kn;
     const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
@@ -688,13 +701,21 @@ __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, 
     const bool inside = (high >= 0) & (low < H) & (left >= 0) & (right < W);   // strict upper bounds (:99-104)
     int n_zero = 0, n_miss = 0;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    // a lazily evaluated band: the window's pixels gathered by the wave first (cs_launch_aux.h lazy_gather_window)
+    const bool gathered = lazy_win && inside && A.sig.layout == 2 && kk <= kLazyWinMax;          // wave-uniform
+    if (gathered) {
+        lazy_gather_window(A, high - pad_r, left - pad_c, lane, lazy_win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     for (int e = lane; e < kk; e += 64) {
         double v = nan;
         if (inside) {
             const int a = e / kn, b = e - a * kn;
             const int rr = high + a, cc = left + b;
             const int src_r = rr - pad_r, src_c = cc - pad_c;
-            v = load_signal(A, src_r, src_c);                     // 0 outside the matrix / stored band
+            v = gathered ? lazy_win[e] : load_signal(A, src_r, src_c);       // 0 outside the matrix / stored band
             const int d = cc - rr;
             bool miss = (d <= -1) & (d >= -big_k);
             // framed row rr is detectable iff rr - sh_r is a detectable bin
@@ -759,10 +780,11 @@ __global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const Corr
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * (kThreads >> 6) + (threadIdx.x >> 6);
     if (t >= n) return;
+    __shared__ double lazy_win[kThreads >> 6][kLazyWinMax];
     const CorrArgs<double>& A = tab[blk[t]];
     const int kk = A.km * A.kn;
     window_stats_pattern(A, inter, rows[t], cols[t], focus_size[t], score[t], nobs[t], t < rec_cap ? rec + t : nullptr,
-                         (windows && t < win_cap) ? windows + t * kk : nullptr, lane);
+                         (windows && t < win_cap) ? windows + t * kk : nullptr, lane, lazy_win[threadIdx.x >> 6]);
 }
 
 // quantify mode over several sub-matrices (cs_quantify_blocks): entry t is pixel (rows[t], cols[t]) of sub-matrix blk[t];

@@ -43,10 +43,74 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The km x kn window with the top left pixel (p0, q0) of a lazily evaluated band (cs_device.h LazyBand), gathered by ONE WAVE into `win`
+// (km * kn doubles of LDS): what load_signal returns for every pixel of the window, without a binary search per pixel.
+// The stored diagonals come from the near band; beyond them lane ki finds the first entry of row ki of the window in the
+// pixel table (one search per ROW, all rows at once), and the at most kn entries behind it are read side by side,
+// detrended and dropped into their window slots.
+constexpr int kLazyWinMax = 17 * 17;
+
+__device__ __forceinline__ void lazy_gather_window(const CorrArgs<double>& A, int p0, int q0, int lane, double* win)
+{
+    const LazyBand& L = *reinterpret_cast<const LazyBand*>(A.sig.ptr);
+    const int km = A.km, kn = A.kn, kk = km * kn;
+    const int d_lo = max(A.sig.band_lo, 0), d_end = min(A.sig.band_lo + A.sig.band_w, L.n_diags);      // kept diagonals
+    const int near_end = min(L.near_w, d_end);
+    for (int e = lane; e < kk; e += 64) {
+        const int ki = e / kn, kj = e - ki * kn;
+        const int p = p0 + ki, q = q0 + kj, d = q - p;
+        double v = 0.0;
+        if ((p >= 0) & (p < A.ms) & (q >= 0) & (q < A.ns) & (d >= d_lo) & (d < near_end)) v = L.near_[(long long)p * L.near_ld + d];
+        win[e] = v;
+    }
+    // (the LDS operations of a wave execute in order: the slots are zero before anything is dropped into them)
+    long long pos = 0, end = 0;
+    int c_hi = -1;
+    if (lane < km) {
+        const int p = p0 + lane;
+        if (p >= 0 && p < A.ms) {
+            const int c_lo = max(q0, p + max(near_end, d_lo));
+            const int hi = min(min(q0 + kn - 1, p + d_end - 1), A.ns - 1);
+            if (c_lo <= hi) {
+                const long long r = L.row0 + p;
+                long long lo = L.indptr[r];
+                end = L.indptr[r + 1];
+                long long up = end;
+                const int target = (int)(L.row0 + c_lo);
+                while (lo < up) {
+                    const long long mid = (lo + up) >> 1;
+                    if (L.indices[mid] < target) lo = mid + 1;
+                    else up = mid;
+                }
+                pos = lo;
+                c_hi = hi;
+            }
+        }
+    }
+    if (!__builtin_amdgcn_ballot_w64(c_hi >= 0)) return;
+    for (int t0 = 0; t0 < kk; t0 += 64) {
+        const int t = min(t0 + lane, kk - 1);
+        const int ki = t / kn, s = t - ki * kn;
+        const long long ps = __shfl(pos, ki), en = __shfl(end, ki);
+        const int ch = __shfl(c_hi, ki);
+        const long long idx = ps + s;
+        if (t0 + lane < kk && ch >= 0 && idx < en) {
+            const int c = L.indices[idx] - (int)L.row0;
+            if (c <= ch) {
+                const int p = p0 + ki;
+                win[ki * kn + (c - q0)] = lazy_stored_value(L, idx, p, c);
+            }
+        }
+    }
+}
+
 // float64 coefficient (and present-pixel count) of one pixel by one wave: _normxcorr2_sparse per pixel
 // (detection.py:917-1131).  `A` may live in registers (kernel argument) or in global memory (a table of
 // per-sub-matrix arguments: the wave's loads are uniform).
-__device__ __forceinline__ void rescore_pixel(const CorrArgs<double>& A, int oi, int oj, int lane, double& r, double& nobs)
+// `win` (optional): the window's km x kn pixels already gathered by the wave (lazy_gather_window) -- the same values
+// load_signal returns, in the same places of the same sums.
+__device__ __forceinline__ void rescore_pixel(const CorrArgs<double>& A, int oi, int oj, int lane, double& r, double& nobs,
+                                              const double* win = nullptr)
 {
     r = 0.0;
     nobs = A.ks.n;
@@ -59,7 +123,7 @@ __device__ __forceinline__ void rescore_pixel(const CorrArgs<double>& A, int oi,
         for (int e = lane; e < kk; e += 64) {
             const int ki = e / kn, kj = e - ki * kn;
             const int p = oi - kh + ki, q = oj - kw + kj;
-            const double v = load_signal(A, p, q);
+            const double v = win ? win[e] : load_signal(A, p, q);
             cs_ = fma(v, A.w[e], cs_);
             s1 += v;
             s2 = fma(v, v, s2);
@@ -359,6 +423,19 @@ struct StageBlock {
     double* band64;          // outputs, either may be null
     float* band32;
     double* law;             // n_diags values
+    long long ld64;          // row pitch of band64 (= ld unless only its first w64 diagonals are written)
+    int w64;                 // band layout: band64 receives the slots 0 .. w64 - 1 only (0: all of them)
+    int pad_;
+    LazyBand* lazy;          // descriptor of the block's lazily evaluated float64 band, written by stage_finish_kernel (or null)
+};
+// what a LazyBand points to besides its block (the genome's pixel table)
+struct LazySource {
+    const long long* indptr;
+    const int* indices;
+    const void* data;
+    const double* weight;
+    double max_val;
+    int data_is_f64;
 };
 struct StageGroup {
     int block, row_begin, row_end;

@@ -33,12 +33,7 @@ namespace {
 constexpr int kStageThreads = 512;
 constexpr int kStageWaves = kStageThreads / 64;
 
-__device__ __forceinline__ double stage_detrend(double v, double y, double max_val)
-{
-    double out = v / y;                                    // law 0 (empty diagonal) -> inf / NaN, as preprocessing.py:298
-    if (max_val > 0.0 && out >= max_val) out = 1.0;        // :301-302
-    return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
-}
+// (stage_detrend: cs_device.h -- the lazily evaluated float64 bands recompute the same value)
 
 // Latency, not bandwidth, bounded the first version (2.1 TB/s): per row a wave waited for the row pointers, then for the
 // pixels they delimit, then for the gathered column weights -- three dependent round trips for ~270 stored pixels.  Now
@@ -156,11 +151,31 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
 constexpr int kFinishDiags = 16;
 constexpr int kFinishPhases = 64;
 __global__ __launch_bounds__(kFinishDiags * kFinishPhases) void stage_finish_kernel(const StageBlock* __restrict__ blocks, int pitch,
-                                                           const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt)
+                                                           const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
+                                                           const LazySource src)
 {
     __shared__ double s_sum[kFinishPhases][kFinishDiags];
     __shared__ unsigned long long s_cnt[kFinishPhases][kFinishDiags];
     const StageBlock B = blocks[blockIdx.x];
+    if (B.lazy && blockIdx.y == 0 && threadIdx.x == 0) {
+        // the block's float64 band as a function of the pixel table (cs_device.h LazyBand): only its first w64 diagonals
+        // are stored
+        LazyBand L;
+        L.indptr = src.indptr;
+        L.indices = src.indices;
+        L.data = src.data;
+        L.weight = src.weight;
+        L.law = B.law;
+        L.near_ = B.band64;
+        L.row0 = B.row0;
+        L.near_ld = B.ld64;
+        L.max_val = src.max_val;
+        L.n = B.n;
+        L.n_diags = B.n_diags;
+        L.near_w = B.band64 ? (B.w64 > 0 ? min(B.w64, B.width) : B.width) : 0;
+        L.data_is_f64 = src.data_is_f64;
+        *B.lazy = L;
+    }
     const int dx = threadIdx.x % kFinishDiags, ph = threadIdx.x / kFinishDiags;
     const int d = blockIdx.y * kFinishDiags + dx;
     double s = 0.0;
@@ -300,7 +315,8 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
             const long long r = B.row0 + rl;
             const double wr = l_w[rl - G.row_begin];
             const long long b = __shfl(my_b, i), e = __shfl(my_e, i);
-            double* out64 = (B.band64 && !(dbg & 1)) ? B.band64 + (size_t)rl * B.ld : nullptr;
+            double* out64 = (B.band64 && !(dbg & 1)) ? B.band64 + (size_t)rl * B.ld64 : nullptr;
+            const int w64 = B.w64 > 0 ? ((B.w64 + 1) & ~1) : (int)B.ld;               // (stored in pairs; ld64 is even)
             float* out32 = (B.band32 && !(dbg & 2)) ? B.band32 + (size_t)rl * B.ld : nullptr;
             const long long x0 = B.dense ? B.row0 : r;
             double v[kStageUnroll];
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
                 // (one read of the piece serving both copies -- 4 slots per lane, float64 stores 32 bytes apart -- was slower:
                 // 1.12 against 0.95 ms for the genome; a store instruction should cover one dense kilobyte)
                 if (out64)
-                    for (int x = 2 * lane; x < s1 - s0; x += 128) *reinterpret_cast<d2*>(out64 + s0 + x) = *reinterpret_cast<const d2*>(l_row + x);
+                    for (int x = 2 * lane; x < min(s1, w64) - s0; x += 128) *reinterpret_cast<d2*>(out64 + s0 + x) = *reinterpret_cast<const d2*>(l_row + x);
                 if (out32)
                     for (int x = 4 * lane; x < s1 - s0; x += 256) {
                         const d2 a = *reinterpret_cast<const d2*>(l_row + x), c2 = *reinterpret_cast<const d2*>(l_row + x + 2);
@@ -486,8 +502,9 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     if (!(skip && skip[0] == 'l')) {
         CS_STAGE_BOTH(CS_STAGE_LAW, unroll)
     }
+    const LazySource lazy_src{indptr, indices, data, weight, max_val, data_is_f64};
     hipLaunchKernelGGL(stage_finish_kernel, dim3(n_blocks, (max_b + kFinishDiags - 1) / kFinishDiags), dim3(kFinishDiags * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
-                       part_cnt);
+                       part_cnt, lazy_src);
     if (!(skip && skip[0] == 't')) {
         CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile)
     }

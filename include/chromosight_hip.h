@@ -55,7 +55,7 @@ typedef enum {
 } cs_status;
 
 enum { CS_F32 = 0, CS_F64 = 1, CS_U8 = 2 /* masks only */ };
-enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1 };
+enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1, CS_LAYOUT_BAND_LAZY = 2 /* see cs_stage_block */ };
 enum { CS_MASK_NONE = 0, CS_MASK_BINS = 1, CS_MASK_EXPLICIT = 2 };
 
 /* ---- context ----------------------------------------------------------------------- */
@@ -274,7 +274,21 @@ typedef struct {
     void* d_band64;
     void* d_band32;
     double* d_law;
+    /* A lazily evaluated float64 band (layout CS_LAYOUT_BAND only; all zero: the plain float64 band above).  The float64
+     * consumers of a detect step -- the exact evaluation of the candidates, the windows of the records -- read 1e-3 of a
+     * band that costs twice the bytes of the float32 one; with f64_diags > 0 only the diagonals 0 .. f64_diags - 1 are
+     * written to d_band64 (n rows of pitch ld64 >= f64_diags, even), and d_lazy (CS_LAZY_BAND_BYTES of device memory)
+     * receives a descriptor through which the kernels behind cs_detect_foci_blocks / cs_detect_foci_batch(_templates)
+     * recompute any other pixel from the pixel table, the weights and d_law -- the same operations in the same order as the
+     * staging pass, bit for bit.  The block is then handed to those entries as a cs_matrix {d_ptr = d_lazy, CS_F64,
+     * CS_LAYOUT_BAND_LAZY, ld (unused), band_lo 0, band_w <= min(keep, n - 1) + 1, row0 0}; `genome`'s arrays, d_law and
+     * d_band64 must outlive it.  Every other entry refuses the layout (CS_ERR_INVALID). */
+    int64_t ld64;
+    int32_t f64_diags;
+    int32_t reserved;
+    void* d_lazy;
 } cs_stage_block;
+#define CS_LAZY_BAND_BYTES 128
 int cs_stage_blocks(cs_ctx* ctx, void* stream, const cs_csr* genome, const cs_stage_block* blocks, int32_t n_blocks,
                     double max_val);
 

@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 CS_F32, CS_F64 = 0, 1
-LAYOUT_DENSE, LAYOUT_BAND = 0, 1
+LAYOUT_DENSE, LAYOUT_BAND, LAYOUT_BAND_LAZY = 0, 1, 2
+LAZY_BAND_BYTES = 128          # CS_LAZY_BAND_BYTES: descriptor of a lazily evaluated float64 band (cs_stage_block)
 MASK_NONE, MASK_BINS, MASK_EXPLICIT = 0, 1, 2
 
 # CHROMOSIGHT_HIP_LIBRARY: another build of the same library (diagnostics, e.g. the section-timing build)
@@ -88,6 +89,10 @@ class CsStageBlock(C.Structure):
         ("d_band64", C.c_void_p),
         ("d_band32", C.c_void_p),
         ("d_law", C.c_void_p),
+        ("ld64", C.c_int64),
+        ("f64_diags", C.c_int32),
+        ("reserved", C.c_int32),
+        ("d_lazy", C.c_void_p),
     ]
 
 

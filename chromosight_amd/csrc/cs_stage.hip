@@ -30,6 +30,8 @@ namespace cs {
 
 namespace {
 
+static_assert(sizeof(LazyBand) <= 128, "CS_LAZY_BAND_BYTES of include/chromosight_hip.h");
+
 constexpr int kStageThreads = 512;
 constexpr int kStageWaves = kStageThreads / 64;
 

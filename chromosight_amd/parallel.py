@@ -338,14 +338,22 @@ def _gather(records, n_fields):
     return merged[np.argsort(merged[:, 0], kind="stable")]
 
 
-def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np.float64):
+def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np.float64, lazy64=None):
     """Stage this rank's blocks for several pattern configurations (detect_genome(..., staged=...)): ONCE at the longest
     keep distance any of them needs, the others scan band views of the same blocks (DeviceCool.view_for).
     CHROMOSIGHT_HIP_NARROW_STAGING=1 (experiment, measured slower on the 23-block genome: 5.75 against 5.5 ms): configurations
     that need a band at least 8 times narrower (1-D patterns next to loops: 18 diagonals against 1017) get their own narrow
     staging FIRST so that their launch chains run under the wide staging instead of beside the matrix-core kernels.
+    lazy64 (default: on for templates of up to 17 x 17 in float32 arithmetic, CHROMOSIGHT_HIP_F64_TWIN=1 turns it off): the
+    float64 bands are not stored beyond their first diagonals -- the exact evaluation of the candidates and the windows of
+    the records recompute the pixels they read from the pixel table (pipeline.DeviceCool._stage_fast).
     Returns a StagedSet {chromosome: StagedBlock} (for_config(i): the set configuration i scans)."""
     dist, rank, world = _world()
+    if lazy64 is None:
+        from .engine import get_precision
+        lazy64 = (not smooth and not os.environ.get("CHROMOSIGHT_HIP_F64_TWIN") and get_precision() == "f32"
+                  and np.dtype(band_dtype) == np.float64
+                  and all(max(np.shape(k)) <= 17 for cfg in kernel_configs for k in cfg["kernels"]))
     dists = [max(cfg["max_dist"] // genome.binsize, 1) for cfg in kernel_configs]
     tallest = [max(np.shape(k)[0] for k in cfg["kernels"]) for cfg in kernel_configs]
     max_dist = max(dists)
@@ -357,7 +365,9 @@ def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np
 
     def stage(which, slot):
         md = max(dists[i] for i in which)
-        out = StagedSet(zip(owned, genome.stage_blocks(owned, md, max(tallest[i] for i in which), smooth=smooth, band_dtype=band_dtype)))
+        extra = dict(lazy64=True) if lazy64 and hasattr(genome, "_stage_fast") else {}
+        out = StagedSet(zip(owned, genome.stage_blocks(owned, md, max(tallest[i] for i in which), smooth=smooth, band_dtype=band_dtype,
+                                                       **extra)))
         if events:
             # staging is asynchronous on the genome's stream: streams of other contexts wait for this event, not the host
             name = f"_ready_event{slot}"

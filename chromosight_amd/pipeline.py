@@ -20,7 +20,8 @@ import pandas as pd
 import scipy.sparse as sp
 
 from . import engine
-from ._lib import CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_DENSE, CsCsr, CsMatrix, CsStageBlock, get_device, np_dtype_code
+from ._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_DENSE, LAZY_BAND_BYTES, CsCsr, CsMatrix, CsStageBlock,
+                   get_device, np_dtype_code)
 from .utils import detection as cid
 from .utils import preprocessing as preproc
 from .utils.stats import fdr_correction
@@ -202,6 +203,20 @@ class _FreeList:
             return self._bufs.pop(best) if best is not None else None
 
 
+class _Shared:
+    """HBM shared by the blocks of one staging call (laws and descriptors of lazily evaluated bands): back to the genome's
+    free list when the last block that refers to it is gone."""
+
+    def __init__(self, pool, buffer):
+        self.pool, self.buffer = pool, buffer
+
+    def __del__(self):
+        try:
+            self.pool.release(self.buffer)
+        except Exception:
+            pass
+
+
 class StagedBlock:
     """One sub-matrix staged in HBM (detrended band or dense map + the flags of its undetectable
     bins): what pattern_detector works on after ContactMap.create_mat (contacts_map.py:453-526)."""
@@ -213,6 +228,18 @@ class StagedBlock:
         self.buffer, self.pool = None, None
         self.row_window = None          # (a, b): the block holds only these rows (+ halo) of the sub-matrix
         self.sig32 = None               # the same map in float32 (same layout), written by the same staging pass
+        self.restage = None             # lazily evaluated float64 band (sig.layout == LAYOUT_BAND_LAZY): stages the block
+        self._full = None               # again with the band stored, for the paths that read it themselves (full())
+
+    def full(self):
+        """This block with its float64 band in memory.  The batched native entries read a lazily evaluated band through
+        its descriptor (include/chromosight_hip.h cs_stage_block); every other path gets the block staged once more, the
+        plain way (same values: the staging pass and the descriptor compute the same expression)."""
+        if self.sig.layout != LAYOUT_BAND_LAZY:
+            return self
+        if self._full is None:
+            self._full = self.restage()
+        return self._full
 
     def __del__(self):
         # a resident block hands its HBM back to the genome's free list (hipFree synchronises and costs
@@ -327,12 +354,13 @@ class DeviceCool:
         measured slower than ONE stream on the 23-block genome (the hand-over costs two synchronisations per block).
         Every block's staging is complete on return."""
         chroms = list(chroms)
+        lazy64 = options.pop("lazy64", False)                # (only the one-call staging knows lazily evaluated bands)
         # One staging call at a time per pixel table: the calls share this context's staging scratch, its page-locked
         # table slots and the law scratch, and they are ordered on one stream.  (Patterns scanned side by side by several
         # host threads each stage the blocks they cannot take as views -- short chromosomes staged dense for a wider
         # pattern: two such calls at once handed each other's block tables to the kernels.)
         with self._stage_lock:
-            fast = self._stage_fast(chroms, max_dist, largest_kernel, **options)
+            fast = self._stage_fast(chroms, max_dist, largest_kernel, lazy64=lazy64, **options)
         if fast is not None:
             return fast
         if workers <= 1 or len(chroms) <= 1:
@@ -368,7 +396,7 @@ class DeviceCool:
         return pool.map(one, chroms)
 
     def _stage_fast(self, chroms, max_dist, largest_kernel, smooth=False, band_dtype=np.float64, reduce=None, rows=None,
-                    stream=None, **unused):
+                    stream=None, lazy64=False, **unused):
         """All the given chromosomes with ONE native call (cs_stage_blocks: three launches for the whole genome -- a
         pass over the pixel table for the distance laws, the laws' finish, and the detrend / tiler that writes every
         block once in float64 (exact re-scoring, windows) and float32 (what the matrix-core kernel stages)); None when
@@ -392,23 +420,48 @@ class DeviceCool:
             band = 2 * max(in_w, out_w) < n
             ld = _pitch(in_w, 64) if band else _pitch(n, 16)
             geo.append((ci, s, n, keep, n_diags, in_w, band, ld))
-        laws = self._laws.get(8 * sum(g[4] for g in geo) + 256)
+        # lazy64: the float64 band of a banded block is NOT stored beyond its first `near` diagonals (where the runs of a
+        # 1-D pattern live); the float64 kernels behind the batched entries recompute the few pixels they read from the
+        # pixel table (include/chromosight_hip.h cs_stage_block: a third of the staging pass was writing that band).  The
+        # laws and the descriptors then live as long as the blocks do: one shared buffer each, not the rewritten scratch.
+        # (lazy64 = "all": every diagonal stored AND a descriptor -- what tests/test_gpu_device_pipeline.py checks the recomputed
+        # pixels against)
+        near = int(os.environ.get("CHROMOSIGHT_HIP_NEAR_DIAGS", "64"))
+        lazy = [bool(lazy64 and not only32 and g[6] and (lazy64 == "all" or g[5] > 2 * near)) for g in geo]
+        shared = None
+        if any(lazy):
+            shared = _Shared(self._free, self._resident(8 * sum(g[4] for g in geo) + 256 + LAZY_BAND_BYTES * len(geo)))
+            laws = shared.buffer.ptr + LAZY_BAND_BYTES * len(geo)
+        else:
+            laws = self._laws.get(8 * sum(g[4] for g in geo) + 256)
         table = (CsStageBlock * len(geo))()
         blocks, off = [], 0
         for k, (ci, s, n, keep, n_diags, in_w, band, ld) in enumerate(geo):
-            b64 = None if only32 else self._resident(n * ld * 8)
+            near_k = in_w if lazy64 == "all" else near
+            ld64 = (ld if lazy64 == "all" else _pitch(near, 2)) if lazy[k] else ld
+            b64 = None if only32 else self._resident(n * ld64 * 8)
             b32 = self._resident(n * ld * 4)
+            desc = shared.buffer.ptr + LAZY_BAND_BYTES * k if lazy[k] else None
             table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND if band else LAYOUT_DENSE, in_w if band else 0, ld,
-                                    b64.ptr if b64 is not None else None, b32.ptr, laws + off)
+                                    b64.ptr if b64 is not None else None, b32.ptr, laws + off,
+                                    ld64 if lazy[k] else 0, near_k if lazy[k] else 0, 0, desc)
             off += 8 * n_diags
             layout = LAYOUT_BAND if band else LAYOUT_DENSE
             flags = _Ptr(self.miss.ptr + s)
             sig32 = CsMatrix(b32.ptr, CS_F32, layout, ld, 0, in_w if band else 0, 0)
-            sig64 = sig32 if only32 else CsMatrix(b64.ptr, CS_F64, layout, ld, 0, in_w if band else 0, 0)
+            if only32:
+                sig64 = sig32
+            elif lazy[k]:
+                sig64 = CsMatrix(desc, CS_F64, LAYOUT_BAND_LAZY, ld, 0, in_w, 0)
+            else:
+                sig64 = CsMatrix(b64.ptr, CS_F64, layout, ld, 0, in_w if band else 0, 0)
             blk = StagedBlock(self.names[ci], sig64, (n, n), flags, flags, max_dist, False, keep)
             blk.sig32 = sig32
             blk.buffer, blk.pool = (b32 if only32 else b64), self._free
             blk.buffer32 = None if only32 else b32
+            if lazy[k]:
+                blk.shared, blk.genome = shared, self           # (the descriptor points into both)
+                blk.restage = (lambda ci=ci: self.stage_blocks([ci], max_dist, largest_kernel, band_dtype=band_dtype)[0])
             blocks.append(blk)
         genome = CsCsr(self.n_bins, self.n_bins, max(self.nnz, 1), self.indptr.ptr, self.indices.ptr, self.data.ptr,
                        np_dtype_code(self.val_dtype), 0, None, self.weight.ptr, self.weight.ptr)
@@ -429,7 +482,7 @@ class DeviceCool:
         (dense-staged short chromosomes, row windows, a longer distance than the block holds)."""
         n = block.shape[0]
         keep = min(max_dist, n) + largest_kernel
-        if (block.inter or block.sig.layout != LAYOUT_BAND or getattr(block, "row_window", None) is not None
+        if (block.inter or block.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY) or getattr(block, "row_window", None) is not None
                 or block.keep is None or keep > block.keep or getattr(block, "smooth", False)):
             return None
         in_w = min(keep, n - 1) + 1
@@ -437,8 +490,11 @@ class DeviceCool:
         if not 2 * max(in_w, out_w) < n:
             return None                              # this pattern would have been staged dense: keep the layouts identical
         s = block.sig
-        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, LAYOUT_BAND, s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
+        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, s.layout, s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
                            block.miss_col, max_dist, False, keep)
+        if s.layout == LAYOUT_BAND_LAZY:                 # (a view shares the descriptor; read by itself it is staged for itself)
+            ci = self.names.index(block.name)
+            view.restage = lambda: self.stage_blocks([ci], max_dist, largest_kernel)[0]
         if block.sig32 is not None:
             t = block.sig32
             view.sig32 = CsMatrix(t.d_ptr, t.dtype, LAYOUT_BAND, t.ld, 0, in_w, t.row0)
@@ -643,6 +699,7 @@ def detect_block(dcool, block, kernel_config, kernel, tsvd=None, coords=None, wa
         return None, None
     _check_template(kernel)
     kspec = engine.KernelSpec(kernel, tsvd)
+    block = block.full() if hasattr(block, "full") else block     # (the per-block entries read the float64 band themselves)
     if getattr(block, "row_window", None) is not None:
         if coords is not None or all_gather is None:
             raise ValueError("a row window of a block needs detect mode and an all_gather")
@@ -663,7 +720,7 @@ def _check_template(kernel):
 
 
 def b_is_band(block):
-    return block.sig.layout == LAYOUT_BAND and not block.inter and getattr(block, "row_window", None) is None
+    return block.sig.layout in (LAYOUT_BAND, LAYOUT_BAND_LAZY) and not block.inter and getattr(block, "row_window", None) is None
 
 
 def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True, defer=False,

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.CsNormxcorr2Params) == 80
     assert ctypes.sizeof(_lib.CsCsr) == 72
     assert ctypes.sizeof(_lib.CsFociParams) == 48
-    assert ctypes.sizeof(_lib.CsStageBlock) == 56
+    assert ctypes.sizeof(_lib.CsStageBlock) == 80
     assert ctypes.sizeof(_lib.CsCall) == 176
     assert ctypes.sizeof(_lib.CsFocus) == 40 == _lib.FOCUS_DTYPE.itemsize
 

@@ -389,6 +389,101 @@ def test_genome_step_as_one_native_call_equals_the_two_calls():
                 assert np.allclose(got[:, 4], ref[:, 4], rtol=1e-9, atol=1e-300)
 
 
+def test_lazy_float64_bands_equal_the_stored_ones(monkeypatch):
+    """stage_genome's default: the float64 band of a block is stored for its first diagonals only and the float64 kernels
+    recompute every other pixel they read from the pixel table (cs_stage_block.d_lazy).
+    (1) On ONE staging that stores every diagonal and builds the descriptors (lazy64="all"), the same blocks read through
+    copies of their descriptors with near_w cut to 0 / 8 / 64 diagonals give the records, scores and windows of the stored
+    bands BIT FOR BIT, for the 2-D pattern and for the 1-D pattern's templates.
+    (2) The default staging == the stored-band staging (CHROMOSIGHT_HIP_F64_TWIN=1) up to the arrival order of the distance
+    law's additions (two stagings differ in the last bit), and a lazy block handed to a per-block path is staged again."""
+    from chromosight_amd._lib import CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, CsMatrix
+    from chromosight_amd.utils import detection as cud
+    from chromosight_amd import engine
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    borders = copy.deepcopy(ck.borders)
+    cool, _ = make_cool(12_000, 200, 2000, seed=7, template=template, chrom_sizes=[4000, 3500, 2500, 2000])
+    dcool = pipeline.DeviceCool(cool)
+    dev = dcool.dev
+
+    # ---- (1) same staging, stored against recomputed
+    blocks = dcool.stage_blocks([0, 1, 2, 3], 200, 17, lazy64="all")
+    dev.sync()
+    assert all(b.sig.layout == LAYOUT_BAND_LAZY for b in blocks)
+    border_blocks = [dcool.view_for(b, 1, 17) for b in blocks]
+    assert all(v is not None for v in border_blocks)
+
+    def with_sig(blks, make):
+        out = []
+        for b in blks:
+            c = copy.copy(b)
+            c.restage, c._full = None, None
+            c.buffer = c.pool = None                     # (the copies own nothing)
+            c.sig = make(b)
+            out.append(c)
+        return out
+
+    def scan(loop_blocks, bord_blocks):
+        res_l = pipeline.detect_blocks(dcool, loop_blocks, loops, template, want_windows=True)
+        kspecs = [engine.KernelSpec(np.asarray(k, dtype=np.float64), None) for k in borders["kernels"]]
+        res_b = cud.detect_many_on_device(dev, bord_blocks, kspecs, borders, want_windows=True, raw=True)
+        return res_l, res_b
+
+    stored = lambda parents: (lambda b: CsMatrix(parents[b.name].buffer.ptr, CS_F64, LAYOUT_BAND, b.sig.ld, 0, b.sig.band_w, 0))
+    by_name = {b.name: b for b in blocks}
+    want_l, want_b = scan(with_sig(blocks, stored(by_name)), with_sig(border_blocks, stored(by_name)))
+    keep = []
+    for near_w in (0, 8, 64):
+        def patched(b):
+            raw = np.empty(128, dtype=np.uint8)
+            dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, raw.ctypes.data, b.sig.d_ptr, 128, None))
+            raw[80:84] = np.frombuffer(np.int32(near_w).tobytes(), dtype=np.uint8)        # LazyBand::near_w
+            buf = dev.to_device(raw, np.uint8)
+            keep.append(buf)
+            return CsMatrix(buf.ptr, CS_F64, LAYOUT_BAND_LAZY, b.sig.ld, 0, b.sig.band_w, 0)
+        got_l, got_b = scan(with_sig(blocks, patched), with_sig(border_blocks, patched))
+        n_rec = 0
+        for (gt, gw), (wt, ww) in zip(got_l, want_l):
+            assert (gt is None) == (wt is None)
+            if gt is not None:
+                assert np.array_equal(gt, wt) and np.array_equal(gw, ww, equal_nan=True), near_w
+                n_rec += len(gt)
+        assert n_rec > 30
+        n_rec = 0
+        for got_t, want_t in zip(got_b, want_b):
+            for (gt, gw), (wt, ww) in zip(got_t, want_t):
+                assert (gt is None) == (wt is None)
+                if gt is not None:
+                    assert np.array_equal(gt, wt) and np.array_equal(gw, ww, equal_nan=True), near_w
+                    n_rec += len(gt)
+        assert n_rec > 100
+
+    # ---- (2) the default staging against the stored-band staging
+    def run():
+        staged = parallel.stage_genome(dcool, [loops, borders])
+        return staged, parallel.detect_patterns(dcool, [loops, borders], staged=staged)
+
+    monkeypatch.setenv("CHROMOSIGHT_HIP_F64_TWIN", "1")
+    staged_t, want = run()
+    assert all(b.sig.layout == LAYOUT_BAND for b in staged_t.values())
+    monkeypatch.delenv("CHROMOSIGHT_HIP_F64_TWIN")
+    staged_l, got = run()
+    assert all(b.sig.layout == LAYOUT_BAND_LAZY for b in staged_l.values())
+    for g, w in zip(got, want):
+        assert w.shape[0] > 30 and g.shape == w.shape
+        assert np.array_equal(g[:, [0, 1, 2, 5, 6]], w[:, [0, 1, 2, 5, 6]])
+        assert np.abs(g[:, 3] - w[:, 3]).max() < 1e-12 and np.allclose(g[:, 4], w[:, 4], rtol=1e-9, atol=1e-300)
+    # the per-block entry reads the band itself: the lazy block is staged once more, with its band
+    ci = sorted(staged_l)[1]
+    table_l, win_l = pipeline.detect_block(dcool, staged_l[ci], loops, template, raw=True)
+    table_t, win_t = pipeline.detect_block(dcool, staged_t[ci], loops, template, raw=True)
+    assert len(table_t) > 5 and np.array_equal(table_l[:, :2], table_t[:, :2]) and np.abs(table_l[:, 2] - table_t[:, 2]).max() < 1e-12
+    assert np.allclose(win_l, win_t, rtol=1e-12, atol=1e-300, equal_nan=True)
+    assert staged_l[ci]._full is not None and staged_l[ci]._full.sig.layout == LAYOUT_BAND
+
+
 def test_switchable_chains_equal_the_default_run(monkeypatch):
     """cs_detect_foci_batch_templates' asynchronous form (chain enqueued, cs_detect_foci_batch_finish later;
     CHROMOSIGHT_HIP_EARLY_CHAIN=1 makes detect_patterns use it for the 1-D pattern) == the default run of the same patterns."""

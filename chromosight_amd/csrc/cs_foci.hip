@@ -551,19 +551,169 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
     if (valid) out_corr[t] = r;
 }
 
+// The same phases with the working arrays in LDS, for lists of up to kSmallLds candidates of a sub-matrix whose keys fit
+// 32 bits -- the blocks of a genome scan: ~ 4 000 candidates each.  foci_small_body walks global arrays with a workgroup
+// barrier between its dozen phases and a 10-step scan (20 barriers) twice: ~ 95 us however short the list, all of it on the
+// critical path behind the tile kernels.  Here the keys, the union-find forest, the sizes and the arg-maxima live in LDS
+// (18 bytes per candidate), compaction and emission take their positions from a shuffle scan of per-thread counts (two
+// barriers), and global memory is read for the values and written for the foci only.  Same algorithm, same order: the
+// root of a focus is its first pixel in row-major order, ties of the maximum go to the first pixel.
+constexpr int kSmallLds = 8192;
+constexpr size_t kSmallLdsBytes = (size_t)kSmallLds * (4 + 4 + 4 + 4 + 2);
+
+// exclusive prefix of `cnt` over the workgroup's 1024 threads and the total; part: 32 ints
+__device__ __forceinline__ int block_scan_counts(int cnt, int* __restrict__ part, int& total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    __syncthreads();                                      // (readers of the previous scan's partials are done)
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        int v = lane < 16 ? part[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int up = __shfl_up(v, off);
+            if (lane >= off) v += up;
+        }
+        if (lane < 16) part[16 + lane] = v;
+    }
+    __syncthreads();
+    total = part[31];
+    return (wv ? part[16 + wv - 1] : 0) + incl - cnt;
+}
+
+__device__ __forceinline__ void foci_small_lds_body(
+    const long long* __restrict__ keys_s, const double* __restrict__ vals, int n_cand, double pearson, unsigned ns, int min_size,
+    int diag_only, unsigned long long* __restrict__ best_val, int* __restrict__ out_rows, int* __restrict__ out_cols,
+    int* __restrict__ out_size, int* __restrict__ n_kept_out, long long* __restrict__ n_foci, int* __restrict__ part, char* lds)
+{
+    unsigned* s_key = reinterpret_cast<unsigned*>(lds);
+    int* s_parent = reinterpret_cast<int*>(lds + 4 * (size_t)kSmallLds);
+    int* s_size = reinterpret_cast<int*>(lds + 8 * (size_t)kSmallLds);
+    int* s_best = reinterpret_cast<int*>(lds + 12 * (size_t)kSmallLds);
+    unsigned short* s_src = reinterpret_cast<unsigned short*>(lds + 16 * (size_t)kSmallLds);
+    const int tid = threadIdx.x;
+    // (1) exact threshold (detection.py:417-421), stable compaction: thread tid owns the candidates [b, e)
+    const int chunk = (n_cand + kSmallThreads - 1) / kSmallThreads;
+    const int b = min(n_cand, tid * chunk), e = min(n_cand, b + chunk);
+    unsigned keep_bits = 0u;                              // (chunk <= 8)
+    for (int t = b; t < e; ++t) {
+        const double v = vals[t];
+        keep_bits |= ((v >= pearson && v != 0.0) ? 1u : 0u) << (t - b);
+    }
+    int n = 0;
+    int run = block_scan_counts(__builtin_popcount(keep_bits), part, n);
+    for (int t = b; t < e; ++t)
+        if ((keep_bits >> (t - b)) & 1u) {
+            s_key[run] = (unsigned)keys_s[t];
+            s_src[run] = (unsigned short)t;
+            s_parent[run] = run;
+            s_size[run] = 0;
+            s_best[run] = INT_MAX;
+            best_val[run] = 0ull;
+            ++run;
+        }
+    if (tid == 0) *n_kept_out = n;
+    __syncthreads();
+    // (2) 4-connected foci of the kept pixels: union-find, root = first pixel in row-major order
+    for (int t = tid; t < n; t += kSmallThreads) {
+        const unsigned key = s_key[t];
+        const unsigned col = key % ns;
+        if (t + 1 < n && col + 1 < ns && s_key[t + 1] == key + 1u) uf_union(s_parent, t, t + 1);
+        const unsigned long long want = (unsigned long long)key + ns;       // lower neighbour: the list is sorted
+        int lo = t + 1, hi = n;
+        bool decided = false;
+#pragma unroll
+        for (int s = 1; s <= 4 && !decided; ++s) {
+            if (t + s >= n) {
+                decided = true;
+                lo = n;
+            } else if (s_key[t + s] >= want) {
+                decided = true;
+                lo = t + s;
+            }
+        }
+        if (!decided) {
+            lo = t + 5;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_key[mid] < want) lo = mid + 1;
+                else hi = mid;
+            }
+        }
+        if (lo < n && s_key[lo] == want) uf_union(s_parent, t, lo);
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) s_parent[t] = uf_find(s_parent, t);
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) {
+        const int r = s_parent[t];
+        atomicAdd(s_size + r, 1);
+        atomicMax(best_val + r, order_key(vals[s_src[t]]));
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kSmallThreads) {
+        const int r = s_parent[t];
+        if (order_key(vals[s_src[t]]) == best_val[r]) atomicMin(s_best + r, t);
+    }
+    __syncthreads();
+    // (3) foci of at least min_size pixels, in the order of their first pixels: thread tid owns the kept pixels [b2, e2)
+    const int chunk2 = (n + kSmallThreads - 1) / kSmallThreads;
+    const int b2 = min(n, tid * chunk2), e2 = min(n, b2 + chunk2);
+    int cnt = 0;
+    for (int t = b2; t < e2; ++t) cnt += (s_parent[t] == t && s_size[t] >= min_size) ? 1 : 0;
+    int n_out = 0;
+    int at = block_scan_counts(cnt, part, n_out);
+    for (int t = b2; t < e2; ++t)
+        if (s_parent[t] == t && s_size[t] >= min_size) {
+            const unsigned key = s_key[s_best[t]];
+            int row = (int)(key / ns);
+            const int col = (int)(key - (unsigned)row * ns);
+            if (diag_only) row = col + (diag_only >> 1);   // odd code: 1-D pattern, row offset in the upper bits
+            out_rows[at] = row;
+            out_cols[at] = col;
+            out_size[at] = s_size[t];
+            ++at;
+        }
+    if (tid == 0) *n_foci = n_out;
+}
+
 __global__ __launch_bounds__(kSmallThreads) void foci_small_batch_kernel(
     const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ seg, const long long* __restrict__ keys_s,
     const double* __restrict__ vals, double pearson, int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos,
     long long* __restrict__ keys_k, double* __restrict__ vals_k, int* __restrict__ parent, int* __restrict__ size,
     unsigned long long* __restrict__ best_val, int* __restrict__ best_idx, int* __restrict__ out_rows, int* __restrict__ out_cols,
-    int* __restrict__ out_size, int* __restrict__ n_kept, long long* __restrict__ n_foci_blk)
+    int* __restrict__ out_size, int* __restrict__ n_kept, long long* __restrict__ n_foci_blk, int lds_ok)
 {
     __shared__ int part[kSmallThreads];
+    extern __shared__ __attribute__((aligned(16))) char small_lds[];     // kSmallLdsBytes, or nothing (lds_ok = 0)
     const int b = blockIdx.x;
     const long long o = seg[b], n_cand = seg[b + 1] - o;
+    if (lds_ok && n_cand <= kSmallLds && (unsigned long long)tab[b].ms * (unsigned long long)tab[b].ns <= 0xffffffffull) {
+        foci_small_lds_body(keys_s + o, vals + o, (int)n_cand, pearson, (unsigned)tab[b].ns, min_size, diag_only, best_val + o,
+                            out_rows + o, out_cols + o, out_size + o, n_kept + b, n_foci_blk + b, part, small_lds);
+        return;
+    }
     foci_small_body(keys_s + o, vals + o, n_cand, pearson, tab[b].ns, min_size, diag_only, flag + o, pos + o, keys_k + o, vals_k + o,
                     parent + o, size + o, best_val + o, best_idx + o, out_rows + o, out_cols + o, out_size + o, n_kept + b,
                     n_foci_blk + b, part);
+}
+
+// dynamic LDS of foci_small_batch_kernel (0: CHROMOSIGHT_HIP_NO_LDS_FOCI, every list through the global arrays)
+static size_t foci_small_lds_bytes()
+{
+    static int state = 0;                                  // 1: the kernel may ask for that much, 2: it may not
+    if (state == 0) {
+        state = hipFuncSetAttribute((const void*)foci_small_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLdsBytes) == hipSuccess ? 1 : 2;
+        (void)hipGetLastError();
+    }
+    return (state == 1 && !getenv("CHROMOSIGHT_HIP_NO_LDS_FOCI")) ? kSmallLdsBytes : 0;
 }
 
 // ---- foci of a 1-D pattern without the labelling workgroup --------------------------------------------------------------
@@ -1244,8 +1394,10 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
         hipLaunchKernelGGL(path_emit_kernel, dim3(g), dim3(kThreads), 0, stream, tab, seg, n_blocks, n_total, blk, keys, flag, pos, size,
                            best_idx, diag_only, f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
     } else {
-        hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, keys, vals, pearson, min_size,
-                           diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
+        const size_t lds_small = foci_small_lds_bytes();
+        hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), lds_small, stream, tab, seg, keys, vals, pearson, min_size,
+                           diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk,
+                           lds_small ? 1 : 0);
         hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
                            f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
     }
@@ -1366,8 +1518,10 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
         hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
                            n_keys, vals, (double*)nullptr);
     }
-    hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), 0, stream, tab, seg, local, vals, pearson, min_size,
-                       diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk);
+    const size_t lds_small = foci_small_lds_bytes();
+    hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), lds_small, stream, tab, seg, local, vals, pearson, min_size,
+                       diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk,
+                       lds_small ? 1 : 0);
     hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
                        f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
     if (n_total > 0) {

@@ -496,8 +496,10 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     # the 1-D foci through the labelling workgroup instead of the run kernels (CHROMOSIGHT_HIP_NO_PATH_FOCI=1), the runs of a
     # 1-D pattern scored by the general lane walk instead of rescore_run17 (CHROMOSIGHT_HIP_NO_RUN17=1), the mask tables of
     # all blocks from one launch (CHROMOSIGHT_HIP_PREP_BATCH=1)
+    # all blocks from one launch (CHROMOSIGHT_HIP_PREP_BATCH=1), the labelling workgroups on global arrays instead of LDS
+    # (CHROMOSIGHT_HIP_NO_LDS_FOCI=1)
     for switch in ("CHROMOSIGHT_HIP_EARLY_CHAIN", "CHROMOSIGHT_HIP_ONE_SYNC", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
-                   "CHROMOSIGHT_HIP_PREP_BATCH"):
+                   "CHROMOSIGHT_HIP_PREP_BATCH", "CHROMOSIGHT_HIP_NO_LDS_FOCI"):
         monkeypatch.setenv(switch, "1")
         for _ in range(2):
             got_l, got_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])

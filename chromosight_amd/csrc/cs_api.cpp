@@ -99,6 +99,7 @@ struct cs_ctx {
     int range_check = 0;     // cs_ctx_set_range_check()
     bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
     bool allow_lazy = false; // the entry in progress takes CS_LAYOUT_BAND_LAZY signals (check_matrix)
+    long long uploads = 0;   // template weights / fragments / rim tables copied to the device so far (upload_weights, ensure_wfrag)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
     // flags), per arithmetic type: a detect run calls with the same template thousands of times
     struct TemplateCache {
@@ -271,6 +272,7 @@ int upload_weights(cs_ctx* ctx, hipStream_t stream, const std::vector<double>& w
     if (ctx->w_cached[slot].size() == bytes && std::memcmp(ctx->w_cached[slot].data(), w.data(), bytes) == 0)
         return CS_OK;
     CS_HIP(ctx, hipMemcpyAsync(ctx->d_w[slot], w.data(), bytes, hipMemcpyHostToDevice, stream));
+    ++ctx->uploads;
     // `w` is pageable and dies here: on a non-default stream the runtime may still be reading it after
     // the call returns, so wait (uploads only happen when the template changes)
     CS_HIP(ctx, hipStreamSynchronize(stream));
@@ -366,6 +368,7 @@ int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeight
                     }
         }
         CS_HIP(ctx, hipMemcpyAsync(ctx->d_wfrag, img.data(), kImage, hipMemcpyHostToDevice, stream));
+        ++ctx->uploads;
         // rim tables of the two mask weight sets (cs_launch.h MfmaWeights::rim), square templates only
         std::vector<float> rim(cs::kRimFloats, 0.0f);
         if (nsets == 3 && km == kn) {
@@ -402,6 +405,7 @@ int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeight
         }
         if (!ctx->d_rim) CS_HIP(ctx, hipMalloc(&ctx->d_rim, sizeof(float) * cs::kRimFloats));
         CS_HIP(ctx, hipMemcpyAsync(ctx->d_rim, rim.data(), sizeof(float) * cs::kRimFloats, hipMemcpyHostToDevice, stream));
+        ++ctx->uploads;
         CS_HIP(ctx, hipStreamSynchronize(stream));    // pageable sources die here
         ctx->wfrag_key = key;
         ctx->wfrag_km = km;
@@ -2389,6 +2393,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             GridCap(cs_ctx* c_, int cap) : c(c_) { c->grid_cap = cap; }
             ~GridCap() { c->grid_cap = 0; }
         } grid_cap(ctx, (n_lanes > 1 && share_env) ? 2 * ctx->n_cu / n_lanes : 0);
+        bool early_tables = false;
         // blocks to lanes: largest first onto the least loaded lane
         std::vector<int> lane_of((size_t)n_blocks, 0);
         if (n_lanes > 1) {
@@ -2412,6 +2417,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 if (!ctx->ev_blk[k]) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_blk[k], hipEventDisableTiming));
             // template weights / matrix-core fragments are uploaded on the caller's stream (once per template): before the
             // side streams are released
+            const long long uploads_before = ctx->uploads;
             {
                 cs::CorrArgs<float> A0;
                 int rc0 = build_args<float>(ctx, stream, signals_f32, kernel, params, &A0);
@@ -2420,7 +2426,13 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 rc0 = ensure_wfrag(ctx, stream, A0.km, A0.kn, &E0);
                 if (rc0) return rc0;
             }
-            if (!prep_batch) {
+            // The mask tables depend on the bins' flags and the template only -- not on the maps, which the caller's stream
+            // may still be staging (a genome step enqueues this call right behind cs_stage_blocks): with the launches
+            // prepared first, every block's tables are built on the SIDE lanes at once, beside whatever the caller's stream is
+            // doing, and the lanes wait for that stream only when this call uploaded the template.  (The tables' scratch is
+            // free: the previous call's tile kernels were synchronised before it returned.)
+            early_tables = prepared && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_TABLES");
+            if (!prep_batch && (!early_tables || ctx->uploads != uploads_before)) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
                 for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
             }
@@ -2434,7 +2446,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 return (long long)params[x].ms * (foci[x].hi_diag - foci[x].lo_diag + 1) > (long long)params[y].ms * (foci[y].hi_diag - foci[y].lo_diag + 1);
             });
         for (int b : launch_order) {
-            const int lane = prep_batch ? 0 : lane_of[b];      // (batched mask tables: nothing is launched per block here)
+            // (batched mask tables: nothing is launched per block here; early tables: on the side lanes only)
+            const int lane = prep_batch ? 0 : (early_tables && lane_of[b] == 0) ? 1 + b % (n_lanes - 1) : lane_of[b];
             hipStream_t stream = lane == 0 ? (hipStream_t)stream_ : ctx->s_blk[lane - 1];
             struct WsSwap {                   // the side lanes build their mask tables in their own scratch
                 cs_ctx* c;
@@ -2504,6 +2517,20 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
         }
         laps.lap("mask tables + arguments");
+        if (early_tables) {
+            // the tile kernels read the maps and the zeroed counter: behind the caller's stream.  A block whose tables were
+            // built on another lane than the one that launches its tiles: every lane waits for every lane's tables.
+            CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));
+            if (!table) {
+                for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
+                for (int k = 0; k < n_lanes - 1; ++k) {
+                    CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
+                    for (int j = 0; j < n_lanes - 1; ++j)
+                        if (j != k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[j], 0));
+                    CS_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_blk[k], 0));
+                }
+            }
+        }
         if (prepared && !table) {
             // one persistent launch per block, each on the lane that built its mask tables
             for (int b : launch_order) {

@@ -499,7 +499,7 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     # all blocks from one launch (CHROMOSIGHT_HIP_PREP_BATCH=1), the labelling workgroups on global arrays instead of LDS
     # (CHROMOSIGHT_HIP_NO_LDS_FOCI=1)
     for switch in ("CHROMOSIGHT_HIP_EARLY_CHAIN", "CHROMOSIGHT_HIP_ONE_SYNC", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
-                   "CHROMOSIGHT_HIP_PREP_BATCH", "CHROMOSIGHT_HIP_NO_LDS_FOCI"):
+                   "CHROMOSIGHT_HIP_PREP_BATCH", "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES"):
         monkeypatch.setenv(switch, "1")
         for _ in range(2):
             got_l, got_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])

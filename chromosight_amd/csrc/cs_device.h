@@ -303,75 +303,21 @@ __device__ __forceinline__ TC pearson_from_sums(TC cs, TC s1, TC s2, TC nm, TC k
                                                 const KernelStats<TC>& K, bool mask_branch,
                                                 TC* n_obs)
 {
-    const TC m1 = s1 * K.inv_n;
-    const TC m2 = s2 * K.inv_n;
-    const TC c = cs_fma(K.kmean, s1, cs) * K.inv_n;
-    const bool z1 = cs_abs(m1) < K.thr;
-    const bool z2 = cs_abs(m2) < K.thr;
-    const bool zc = cs_abs(c) < K.thr;
-    const TC m1z = z1 ? TC(0) : m1;
-    const TC m2z = z2 ? TC(0) : m2;
-    const TC cz = zc ? TC(0) : c;
-    TC num, den;
-    *n_obs = K.n;
-    if (!mask_branch || nm < TC(0.5)) {
-        num = (z1 | zc) ? (cz - m1z * K.kmean) : cs * K.inv_n;
-        const TC var = m2z - m1z * m1z;
-        den = mask_branch ? cs_sqrt(var * K.kvar) : cs_sqrt(var) * K.kstd;
-    } else {
-        const TC np = K.n - nm;
-        *n_obs = np;
-        const TC inv_np = TC(1) / np;
-        TC kmw, kvw, dk;  // dk = kmean - kmw, kept separately to avoid re-rounding
-        bool zk;
-        if constexpr (sizeof(TC) == 8) {
-            // float64: the reference's own order of operations, so that windows whose present
-            // template pixels are all equal (piecewise-constant templates such as borders) give
-            // an exactly zero variance, as they do in the reference.  ka = sum_missing K',
-            // kb = sum_missing K'^2 (un-centred mask weights).
-            zk = cs_abs(ka) < K.thr;
-            const bool zk2 = cs_abs(kb) < K.thr;
-            // true divisions: (np * v) / np == v exactly, (np * v) * (1 / np) need not be
-            kmw = (K.ksum - (zk ? TC(0) : ka)) / np;
-            const TC k2mw = (K.k2sum - (zk2 ? TC(0) : kb)) / np;
-            kvw = k2mw - kmw * kmw;
-            dk = K.kmean - kmw;
-        } else {
-            // float32: centred mask sums (ka = sum_missing (K' - kmean), kb chosen so that
-            // kb + 2 kmean ka + kmean^2 nm = sum_missing K'^2) avoid the cancellation of the
-            // literal form; a variance below 1e-5 of the template's is rounding noise of an
-            // exactly degenerate window and is snapped to the reference's exact zero.
-            const TC km_ = cs_fma(K.kmean, nm, ka);
-            const TC k2m = kb + TC(2) * K.kmean * ka + K.kmean * K.kmean * nm;
-            zk = cs_abs(km_) < K.thr;
-            const bool zk2 = cs_abs(k2m) < K.thr;
-            if (!zk && !zk2) {
-                const TC a = ka * inv_np;
-                kmw = K.kmean - a;
-                dk = a;
-                kvw = (K.n * K.kvar - kb) * inv_np - a * a;
-                if (kvw < TC(1e-5) * K.kvar) kvw = TC(0);
-            } else {
-                kmw = (K.ksum - (zk ? TC(0) : km_)) * inv_np;
-                const TC k2mw = (K.k2sum - (zk2 ? TC(0) : k2m)) * inv_np;
-                kvw = k2mw - kmw * kmw;
-                dk = K.kmean - kmw;
-            }
-        }
-        const TC m1w = m1z * K.n * inv_np;
-        const TC m2w = m2z * K.n * inv_np;
-        den = cs_sqrt((m2w - m1w * m1w) * kvw);
-        if (np < K.cut) den = TC(0);
-        if (!z1 && !zc && !zk)
-            num = cs_fma(s1, dk, cs) * inv_np;
-        else
-            num = (cz - m1z * kmw) * K.n * inv_np;
-    }
-    TC r = (cs_abs(den) < K.eps) ? TC(0) : num / den;
-    if (!(cs_abs(r) <= TC(3.0e38))) r = TC(0);   // NaN / inf -> 0 (detection.py:1101)
-    r = r < TC(-1) ? TC(-1) : r;
-    r = r > TC(1) ? TC(1) : r;
-    return r;
+#include "cs_pearson_body.inc"
+}
+
+// The float64 instance, without floating-point contraction: the compiler's choice of which a * b + c it fuses depends on the
+// code the function is inlined into (a compile-time-true mask_branch, a neighbouring common subexpression), and the same
+// window scored by two kernels -- a block by its own entry or in a batch, the general or the compile-time-size
+// wave-per-window function -- then differed by a few ulps.  Unfused, every kernel evaluates the reference's own operations
+// (numpy fuses nothing either), and a window has ONE float64 coefficient whichever kernel scores it.
+template <>
+__device__ __forceinline__ double pearson_from_sums<double>(double cs, double s1, double s2, double nm, double ka, double kb,
+                                                            const KernelStats<double>& K, bool mask_branch, double* n_obs)
+{
+#pragma clang fp contract(off)
+    using TC = double;
+#include "cs_pearson_body.inc"
 }
 
 // Unmasked branch only (reference detection.py:1000-1018, 1213-1220), used by the streaming

@@ -17,6 +17,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <climits>
+#include <cstdlib>
 
 #include "cs_device.h"
 #include "cs_launch_aux.h"
@@ -394,10 +395,18 @@ __global__ __launch_bounds__(kThreads) void narrow_enumerate_batch_kernel(const 
     blk[t] = b;
 }
 
+// CHROMOSIGHT_HIP_NO_FAST_WINDOWS=1: the wave-per-window kernels keep the general functions (rescore_pixel, lazy_gather_window)
+// where the compile-time-size ones of cs_launch_aux.h apply -- the two are the same sums in the same order
+static bool fast_windows_on()
+{
+    return std::getenv("CHROMOSIGHT_HIP_NO_FAST_WINDOWS") == nullptr;     // (read per launch: the switch test flips it in-process)
+}
+
 __global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
                                                             const int* __restrict__ rows, const int* __restrict__ cols,
                                                             long long n_px, const long long* __restrict__ n_ptr,
-                                                            double* __restrict__ out_corr, double* __restrict__ out_nobs)
+                                                            double* __restrict__ out_corr, double* __restrict__ out_nobs,
+                                                            bool fast_windows)
 {
     __shared__ double lazy_win[4][kLazyWinMax];             // (lazily evaluated float64 bands: the wave's window)
     const int lane = threadIdx.x & 63;
@@ -406,7 +415,20 @@ __global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<doubl
     double r, nobs;
     const CorrArgs<double>& A = tab[blk[t]];
     const int oi = rows[t], oj = cols[t];
-    if (A.sig.layout == 2 && A.km * A.kn <= kLazyWinMax && oi >= 0 && oi < A.ms && oj >= 0 && oj < A.ns) {     // wave-uniform
+    const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);
+    if (inside && fast_windows && window_fast_applies<17>(A)) {                  // wave-uniform
+        // the detection configuration with a 17 x 17 template (cs_launch_aux.h rescore_pixel_sq: same sums, ~ 1/2 of the
+        // instructions); CHROMOSIGHT_HIP_NO_FAST_WINDOWS=1 keeps the general functions (tested bit-equal)
+        double* win = nullptr;
+        if (A.sig.layout == 2) {
+            win = lazy_win[threadIdx.x >> 6];
+            lazy_gather_window_sq<17>(A, oi - 8, oj - 8, lane, win);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        rescore_pixel_sq<17>(A, oi, oj, lane, r, nobs, win);
+    } else if (A.sig.layout == 2 && A.km * A.kn <= kLazyWinMax && inside) {     // wave-uniform
         double* win = lazy_win[threadIdx.x >> 6];
         lazy_gather_window(A, oi - (A.km - 1) / 2, oj - (A.kn - 1) / 2, lane, win);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -422,6 +444,54 @@ __global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<doubl
     }
 }
 
+// rescore_batch_kernel when EVERY sub-matrix of the table is in the detection configuration with a 17 x 17 template on a lazily
+// evaluated band (checked on the host, launch_rescore_batch below) -- what the 2-D chain of a genome step runs.  Nothing but the
+// compile-time-size functions is compiled in: the general kernel's 92 vector registers (its runtime-size paths) hold five waves
+// per SIMD, and a window's evaluation is a chain of dependent round trips (row search, entries, values) that only other waves hide.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void rescore_batch_lazy17_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
+                                                                   const int* __restrict__ rows, const int* __restrict__ cols,
+                                                                   long long n_px, const long long* __restrict__ n_ptr,
+                                                                   double* __restrict__ out_corr, double* __restrict__ out_nobs)
+{
+    __shared__ double lazy_win[4][kLazyWinMax];
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_px || (n_ptr && t >= *n_ptr)) return;
+    const CorrArgs<double>& A = tab[blk[t]];
+    const int oi = rows[t], oj = cols[t];
+    double r = 0.0, nobs = A.ks.n;
+    if ((oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns)) {                      // wave-uniform
+        double* win = lazy_win[threadIdx.x >> 6];
+        lazy_gather_window_sq<17>(A, oi - 8, oj - 8, lane, win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        rescore_pixel_sq<17>(A, oi, oj, lane, r, nobs, win);
+    }
+    if (lane == 0) {
+        out_corr[t] = r;
+        if (out_nobs) out_nobs[t] = nobs;
+    }
+}
+
+// h_tab: the host copy of the argument table (or nullptr: unknown -> the general kernel)
+static void launch_rescore_batch(const CorrArgs<double>* h_tab, int n_blocks, long long n_waves, hipStream_t stream,
+                                 const CorrArgs<double>* tab, const int* blk, const int* rows, const int* cols, long long n_px,
+                                 const long long* n_ptr, double* out_corr, double* out_nobs)
+{
+    const bool fast = fast_windows_on();
+    bool lazy17 = fast && h_tab != nullptr && n_blocks > 0;
+    for (int b = 0; lazy17 && b < n_blocks; ++b) {
+        const CorrArgs<double>& A = h_tab[b];
+        lazy17 = A.km == 17 && A.kn == 17 && A.mask_mode == 1 && A.sym_upper && A.full && A.max_dist >= 0 && A.sig.layout == 2;
+    }
+    const dim3 grid((unsigned)((n_waves + 3) / 4));
+    if (lazy17)
+        hipLaunchKernelGGL(rescore_batch_lazy17_kernel, grid, dim3(256), 0, stream, tab, blk, rows, cols, n_px, n_ptr, out_corr, out_nobs);
+    else
+        hipLaunchKernelGGL(rescore_batch_kernel, grid, dim3(256), 0, stream, tab, blk, rows, cols, n_px, n_ptr, out_corr, out_nobs, fast);
+}
+
 // lane-per-pixel version for the enumerated diagonals (rescore_pixel_lane).  A workgroup's 256 list entries are
 // normally a run of 256 / w rows on w neighbouring diagonals of one sub-matrix: the rows and diagonals their
 // windows reach are staged in LDS once (coalesced) and every lane walks its window there -- straight from memory
@@ -434,7 +504,7 @@ constexpr int kRunWeights = 3 * 17 * 17;               // the three weight sets 
 __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
                                                                 const int* __restrict__ rows, const int* __restrict__ cols,
                                                                 long long n_px, double* __restrict__ out_corr, int tile_cap,
-                                                                int no_run17)
+                                                                int no_run17, bool fast_windows)
 {
     const bool RUN_NO_FAST = no_run17 != 0;
     extern __shared__ __attribute__((aligned(16))) double run_smem[];
@@ -511,15 +581,35 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
             const bool interior = P0 >= 0 && P0 + RN <= A.ms && C0 >= 0 && C0 + CN <= A.ns;
             // runs on one or two diagonals under a 17 x 17 template (1-D patterns): the transposed tile of rescore_run17
             const bool run17 = lean && kn == 17 && d_hi - d_lo <= 1 && RN <= kRunRP && DN * kRunRP <= tile_cap && !RUN_NO_FAST;
+            // (the signal through a SigReader: the argument block's and the lazily evaluated band's fields are read once, not
+            // behind every LDS store of the loops below; CHROMOSIGHT_HIP_NO_FAST_WINDOWS=1 keeps load_signal)
+            const SigReader S(A);
             if (run17) {
                 // 8 rows x 8 diagonals per wave and step: 64-byte pieces of band rows in, 8 consecutive doubles of 8 tile
                 // rows out
                 const int n_dc = (DN + 7) >> 3, n_ch = ((RN + 7) >> 3) * n_dc;
-                for (int ch = tid >> 6; ch < n_ch; ch += 4) {
-                    const int cr = ch / n_dc, cd = ch - cr * n_dc;
-                    const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
+                if (fast_windows) {
+#pragma unroll 4
+                    for (int ch = tid >> 6; ch < n_ch; ch += 4) {
+                        const int cr = ch / n_dc, cd = ch - cr * n_dc;
+                        const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
+                        const int p = P0 + rr;
+                        if (rr < RN && dd < DN) tile[dd * kRunRP + rr] = S.at(p, p + D0 + dd);
+                    }
+                } else {
+                    for (int ch = tid >> 6; ch < n_ch; ch += 4) {
+                        const int cr = ch / n_dc, cd = ch - cr * n_dc;
+                        const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
+                        const int p = P0 + rr;
+                        if (rr < RN && dd < DN) tile[dd * kRunRP + rr] = load_signal(A, p, p + D0 + dd);
+                    }
+                }
+            } else if (fast_windows) {
+#pragma unroll 4
+                for (int idx = tid; idx < RN * DN; idx += 256) {
+                    const int rr = idx / DN, dd = idx - rr * DN;
                     const int p = P0 + rr;
-                    if (rr < RN && dd < DN) tile[dd * kRunRP + rr] = load_signal(A, p, p + D0 + dd);
+                    tile[idx] = S.at(p, p + D0 + dd);
                 }
             } else {
                 for (int idx = tid; idx < RN * DN; idx += 256) {
@@ -836,7 +926,7 @@ __global__ __launch_bounds__(kSmallThreads) void gather_foci_batch_kernel(const 
 // may be nullptr (beyond the caller's capacity) or page-locked host memory
 __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, int inter, int row, int col, int fsize, double score,
                                                      double nobs, FocusRec* rec_out, double* win_out, int lane,
-                                                     double* lazy_win = nullptr)
+                                                     double* lazy_win = nullptr, bool fast_windows = false)
 {
     const int km = A.km, kn = A.kn, kk = km * kn;
     const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
@@ -854,7 +944,8 @@ __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, 
     // a lazily evaluated band: the window's pixels gathered by the wave first (cs_launch_aux.h lazy_gather_window)
     const bool gathered = lazy_win && inside && A.sig.layout == 2 && kk <= kLazyWinMax;          // wave-uniform
     if (gathered) {
-        lazy_gather_window(A, high - pad_r, left - pad_c, lane, lazy_win);
+        if (fast_windows && km == 17 && kn == 17) lazy_gather_window_sq<17>(A, high - pad_r, left - pad_c, lane, lazy_win);
+        else lazy_gather_window(A, high - pad_r, left - pad_c, lane, lazy_win);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -924,7 +1015,8 @@ __global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const Corr
                                                                       const int* __restrict__ cols, const int* __restrict__ focus_size,
                                                                       const double* __restrict__ score, const double* __restrict__ nobs,
                                                                       const long long* __restrict__ n_ptr, FocusRec* __restrict__ rec,
-                                                                      double* __restrict__ windows, long long win_cap, long long rec_cap)
+                                                                      double* __restrict__ windows, long long win_cap, long long rec_cap,
+                                                                      bool fast_windows)
 {
     const long long n = *n_ptr;
     const int lane = threadIdx.x & 63;
@@ -934,7 +1026,7 @@ __global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const Corr
     const CorrArgs<double>& A = tab[blk[t]];
     const int kk = A.km * A.kn;
     window_stats_pattern(A, inter, rows[t], cols[t], focus_size[t], score[t], nobs[t], t < rec_cap ? rec + t : nullptr,
-                         (windows && t < win_cap) ? windows + t * kk : nullptr, lane, lazy_win[threadIdx.x >> 6]);
+                         (windows && t < win_cap) ? windows + t * kk : nullptr, lane, lazy_win[threadIdx.x >> 6], fast_windows);
 }
 
 // quantify mode over several sub-matrices (cs_quantify_blocks): entry t is pixel (rows[t], cols[t]) of sub-matrix blk[t];
@@ -1361,8 +1453,8 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
         // thousands of window pixels straight from memory, so they keep one wave per pixel
         const bool big_template = 3LL * h_tab[0].km * h_tab[0].kn > kRunWeights;
         if (getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE") || big_template)
-            hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
-                               (const long long*)nullptr, vals, (double*)nullptr);
+            launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, (const long long*)nullptr, vals,
+                                 (double*)nullptr);
         else {
             // tile of a workgroup's 256 entries: 256 / w rows (+ halo) x (w + 32) diagonals, w = narrowest scanned band
             int w_min = 1 << 30, w_max = 1;
@@ -1374,7 +1466,7 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
             if ((size_t)tile_cap * 8 > 48 * 1024) tile_cap = 48 * 1024 / 8;        // wider scans: the direct route where needed
             const size_t smem = (size_t)tile_cap * 8 + kRunWeights * 8 + 512 + 1024;
             hipLaunchKernelGGL(rescore_run_batch_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), smem, stream, tab, blk, rows,
-                               cols, n_total, vals, tile_cap, getenv("CHROMOSIGHT_HIP_NO_RUN17") ? 1 : 0);
+                               cols, n_total, vals, tile_cap, getenv("CHROMOSIGHT_HIP_NO_RUN17") ? 1 : 0, fast_windows_on());
         }
     }
     // every sub-matrix scans the diagonals 0 and 1 (borders, hairpins: max_dist = 0 in the config): the foci are runs
@@ -1403,10 +1495,9 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
     }
     if (n_total > 0) {
         const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
-        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(256), 0, stream, tab, f_blk, f_rows, f_cols,
-                           max_foci, d_total, f_score, f_nobs);
+        launch_rescore_batch(h_tab, n_blocks, max_foci, stream, tab, f_blk, f_rows, f_cols, max_foci, d_total, f_score, f_nobs);
         hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk,
-                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap);
+                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap, fast_windows_on());
     }
     return (int)hipGetLastError();
 }
@@ -1515,8 +1606,7 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
         const unsigned g = blocks_for(n_total);
         const long long* n_keys = bounded ? seg + n_blocks : nullptr;
         hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
-        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, tab, blk, rows, cols, n_total,
-                           n_keys, vals, (double*)nullptr);
+        launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, n_keys, vals, (double*)nullptr);
     }
     const size_t lds_small = foci_small_lds_bytes();
     hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), lds_small, stream, tab, seg, local, vals, pearson, min_size,
@@ -1526,10 +1616,9 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
                        f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
     if (n_total > 0) {
         const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
-        hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(256), 0, stream, tab, f_blk, f_rows, f_cols,
-                           max_foci, d_total, f_score, f_nobs);
+        launch_rescore_batch(h_tab, n_blocks, max_foci, stream, tab, f_blk, f_rows, f_cols, max_foci, d_total, f_score, f_nobs);
         hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk,
-                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap);
+                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap, fast_windows_on());
     }
     return (int)hipGetLastError();
 }
@@ -1629,7 +1718,7 @@ int enqueue_quantify_batch(const CorrArgs<double>* d_tab, const int* d_inter, co
 {
     if (n == 0) return 0;
     hipLaunchKernelGGL(rescore_batch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_tab, d_blk, d_rows, d_cols, n,
-                       (const long long*)nullptr, d_score, d_nobs);
+                       (const long long*)nullptr, d_score, d_nobs, fast_windows_on());
     hipLaunchKernelGGL(quantify_stats_batch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kThreads), 0, stream, d_tab, d_inter, d_blk, d_rows,
                        d_cols, d_score, d_nobs, n, d_rec, d_windows);
     return (int)hipGetLastError();

@@ -145,6 +145,246 @@ __device__ __forceinline__ void rescore_pixel(const CorrArgs<double>& A, int oi,
     }
 }
 
+// ---- the wave-per-window evaluation for the configuration nearly every window of a detect run has --------------------
+// rescore_pixel / lazy_gather_window compile to ~1 800 instructions per window for a 17 x 17 template (runtime sizes: an integer
+// division per pixel; a branch, two flag loads and three weight loads inside it per pixel for the predicate; 64-bit lane
+// exchanges), and the float64 re-scoring of a genome's ~10^5 candidate windows is bound by exactly that -- instruction issue at
+// full occupancy, not latency, not bytes (313 us exposed at the end of a 23-block genome step, profiles/r04b_genome_timeline.txt).
+// The same operations on the same operands in the same order -- per-lane sums over e = lane, lane + 64, ..., then the
+// butterfly -- for per-bin masks, sym_upper, full, max_dist given and a SQUARE template of compile-time size K:
+//   * the flags of the window's K rows and K columns are loaded once (lane k: row k, lane K + k: column k) and become two
+//     bit words by a ballot; the predicate is missing_from_flags written as selects (x + 0.0 == x: the mask sums are
+//     bit-identical to the branching form's);
+//   * the three mask sums are reduced only when some lane saw a missing pixel (else they are exactly 0);
+//   * the lazily evaluated band's gather keeps its positions relative to the window's first row (32-bit exchanges).
+template <int K>
+__device__ __forceinline__ bool window_fast_applies(const CorrArgs<double>& A)
+{
+    return (A.km == K) & (A.kn == K) & (A.mask_mode == 1) & (A.sym_upper != 0) & (A.full != 0) & (A.max_dist >= 0);
+}
+
+// a wave-uniform pointer as a scalar pointer to GLOBAL memory: pointers read from a descriptor in memory are generic
+// (flat_load: every wait also waits for the LDS) and, kept in vector registers, cost two lanes-wide additions per address
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* uniform_global(const T* p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const __attribute__((address_space(1))) T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// load_signal for a wave-uniform argument block with every field read ONCE into scalars: `A` lives in a device table, a lazily
+// evaluated band behind one more pointer, and a loop  tile[i] = load_signal(A, p, q)  re-reads those fields behind every LDS
+// store (the compiler must assume they changed) -- three dependent round trips per element, which is what the tile staging
+// of rescore_run_batch_kernel spent its time on (~ 100 of its 144 us on a rank's share of a genome).  Same values as
+// load_signal; the pixels of a lazily evaluated band beyond its stored diagonals still go through lazy_load.
+struct SigReader {
+    const __attribute__((address_space(1))) double* p64;
+    const __attribute__((address_space(1))) float* p32;
+    const MatView* view;
+    long long ld, row0;
+    int ms, ns, layout, band_lo, band_w, is_f64, near_w, n_diags;
+
+    __device__ __forceinline__ explicit SigReader(const CorrArgs<double>& A)
+    {
+        view = &A.sig;
+        ms = __builtin_amdgcn_readfirstlane(A.ms);
+        ns = __builtin_amdgcn_readfirstlane(A.ns);
+        layout = __builtin_amdgcn_readfirstlane(A.sig.layout);
+        band_lo = __builtin_amdgcn_readfirstlane(A.sig.band_lo);
+        band_w = __builtin_amdgcn_readfirstlane(A.sig.band_w);
+        is_f64 = __builtin_amdgcn_readfirstlane(A.sig_is_f64);
+        near_w = n_diags = 0;
+        const void* ptr = A.sig.ptr;
+        ld = A.sig.ld;
+        row0 = A.sig.row0;
+        if (layout == 2) {
+            const LazyBand* L = reinterpret_cast<const LazyBand*>(ptr);
+            ptr = L->near_;
+            ld = L->near_ld;
+            row0 = 0;
+            near_w = __builtin_amdgcn_readfirstlane(L->near_w);
+            n_diags = __builtin_amdgcn_readfirstlane(L->n_diags);
+            is_f64 = 1;
+        }
+        ld = ((long long)__builtin_amdgcn_readfirstlane((int)(ld >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ld);
+        row0 = ((long long)__builtin_amdgcn_readfirstlane((int)(row0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)row0);
+        p64 = uniform_global(reinterpret_cast<const double*>(ptr));
+        p32 = uniform_global(reinterpret_cast<const float*>(ptr));
+    }
+
+    __device__ __forceinline__ double at(int p, int q) const
+    {
+        if ((p < 0) | (p >= ms) | (q < 0) | (q >= ns)) return 0.0;
+        const int d = q - p;
+        if (layout == 2) {
+            if ((d - band_lo < 0) | (d - band_lo >= band_w) | (d < 0) | (d >= n_diags)) return 0.0;
+            if (d < near_w) return p64[(long long)p * ld + d];
+            return lazy_load(*view, p, q);
+        }
+        long long off;
+        if (layout == 0) off = ((long long)p - row0) * ld + q;
+        else {
+            const int dd = d - band_lo;
+            if ((dd < 0) | (dd >= band_w)) return 0.0;
+            off = ((long long)p - row0) * ld + dd;
+        }
+        return is_f64 ? p64[off] : (double)p32[off];
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void lazy_gather_window_sq(const CorrArgs<double>& A, int p0, int q0, int lane, double* win)
+{
+    // every field of the descriptor and of the arguments is read ONCE, before the first LDS store: behind a store to `win` the
+    // compiler must assume the descriptor changed and re-read it (the general function pays six dependent round trips per
+    // 64 window slots for that)
+    const LazyBand* Lp = reinterpret_cast<const LazyBand*>(A.sig.ptr);
+    const auto* indptr = uniform_global(Lp->indptr);
+    const auto* indices = uniform_global(Lp->indices);
+    const auto* data32 = uniform_global(reinterpret_cast<const float*>(Lp->data));
+    const auto* data64 = uniform_global(reinterpret_cast<const double*>(Lp->data));
+    const auto* weight = uniform_global(Lp->weight);
+    const auto* law = uniform_global(Lp->law);
+    const auto* near_ = uniform_global(Lp->near_);
+    const long long row0 = __builtin_amdgcn_readfirstlane((int)Lp->row0);         // (genome bins: < 2^31)
+    const long long near_ld = __builtin_amdgcn_readfirstlane((int)Lp->near_ld);
+    const double max_val = Lp->max_val;
+    const int n_diags = __builtin_amdgcn_readfirstlane(Lp->n_diags), near_w = __builtin_amdgcn_readfirstlane(Lp->near_w);
+    const bool is_f64 = __builtin_amdgcn_readfirstlane(Lp->data_is_f64) != 0;
+    const int ms = __builtin_amdgcn_readfirstlane(A.ms), ns = __builtin_amdgcn_readfirstlane(A.ns);
+    const int band_lo = __builtin_amdgcn_readfirstlane(A.sig.band_lo), band_w = __builtin_amdgcn_readfirstlane(A.sig.band_w);
+    constexpr int kk = K * K;
+    const int d_lo = max(band_lo, 0), d_end = min(band_lo + band_w, n_diags);      // kept diagonals
+    const int near_end = min(near_w, d_end);
+    // (wave-uniform: does the window reach the stored diagonals at all?  its smallest diagonal is q0 - p0 - (K - 1))
+    const bool near_hit = q0 - p0 - (K - 1) < near_end;
+    // the rows' first entries at or behind their first wanted column: one search per ROW, all rows at once, positions
+    // relative to the window's first row (32-bit lane exchanges below)
+    const long long base = indptr[row0 + min(max(p0, 0), ms - 1)];                // uniform; every position below is >= base
+    int pos = 0, end = 0, c_hi = -1;
+    if (lane < K) {
+        const int p = p0 + lane;
+        if (p >= 0 && p < ms) {
+            const int c_lo = max(q0, p + max(near_end, d_lo));
+            const int hi = min(min(q0 + K - 1, p + d_end - 1), ns - 1);
+            if (c_lo <= hi) {
+                const long long r = row0 + p;
+                int lo = (int)(indptr[r] - base);
+                end = (int)(indptr[r + 1] - base);
+                int up = end;
+                const int target = (int)row0 + c_lo;
+                const auto* ind = indices + base;
+                while (lo < up) {
+                    const int mid = (lo + up) >> 1;
+                    if (ind[mid] < target) lo = mid + 1;
+                    else up = mid;
+                }
+                pos = lo;
+                c_hi = hi;
+            }
+        }
+    }
+    const bool any_row = __builtin_amdgcn_ballot_w64(c_hi >= 0) != 0;
+    constexpr int kRounds = (kk + 63) / 64;
+#pragma unroll
+    for (int e = lane, i = 0; i < kRounds; e += 64, ++i) {
+        if (e < kk) {
+            double v = 0.0;
+            if (near_hit) {
+                const int ki = e / K, kj = e - ki * K;
+                const int p = p0 + ki, q = q0 + kj, d = q - p;
+                if ((p >= 0) & (p < ms) & (q >= 0) & (q < ns) & (d >= d_lo) & (d < near_end)) v = near_[(long long)p * near_ld + d];
+            }
+            win[e] = v;
+        }
+    }
+    if (!any_row) return;
+    // (the LDS operations of a wave execute in order: the slots are zero before anything is dropped into them; the global
+    // loads below are through address-space-1 pointers held in scalars, so nothing is re-read behind the LDS stores)
+#pragma unroll
+    for (int i = 0; i < kRounds; ++i) {
+        const int t = min(64 * i + lane, kk - 1);
+        const int ki = t / K, s = t - ki * K;
+        const int ps = __shfl(pos, ki), en = __shfl(end, ki), ch = __shfl(c_hi, ki);
+        const int rel = ps + s;
+        if (64 * i + lane < kk && ch >= 0 && rel < en) {
+            const long long idx = base + rel;
+            const int c = indices[idx] - (int)row0;
+            if (c <= ch) {
+                // lazy_stored_value / stage_detrend (cs_device.h), on the hoisted fields
+                const int p = p0 + ki, d = c - p;
+                const double x = is_f64 ? data64[idx] : (double)data32[idx];
+                const double y = d < n_diags ? law[d] : 0.0;
+                double out = ((x * weight[row0 + p]) * weight[row0 + c]) / y;
+                if (max_val > 0.0 && out >= max_val) out = 1.0;
+                win[ki * K + (c - q0)] = out != out ? 0.0 : out;
+            }
+        }
+    }
+}
+
+// rescore_pixel for window_fast_applies<K>(A) and (oi, oj) inside the matrix; `win`: the gathered window (lazily evaluated band) or
+// nullptr (stored band / dense map: load_signal)
+template <int K>
+__device__ __forceinline__ void rescore_pixel_sq(const CorrArgs<double>& A, int oi, int oj, int lane, double& r, double& nobs,
+                                                 const double* win)
+{
+    r = 0.0;
+    nobs = A.ks.n;
+    if (oj - oi < 0) return;                                   // pixel_forced_zero: sym_upper, km == kn
+    constexpr int kh = (K - 1) / 2, kk = K * K;
+    const int p0 = oi - kh, q0 = oj - kh;
+    const int ms = __builtin_amdgcn_readfirstlane(A.ms), ns = __builtin_amdgcn_readfirstlane(A.ns);
+    const int md = __builtin_amdgcn_readfirstlane(A.max_dist);
+    // flags of the window's rows and columns, one load per lane
+    unsigned rbits, cbits;
+    {
+        const auto* miss_row = uniform_global(A.miss_row);
+        const auto* miss_col = uniform_global(A.miss_col);
+        const bool is_row = lane < K;
+        const int idx = is_row ? p0 + lane : q0 + (lane - K);
+        const bool in = is_row ? (idx >= 0) & (idx < ms) : (lane < 2 * K) & (idx >= 0) & (idx < ns);
+        const unsigned char fr = miss_row[(in & is_row) ? idx : 0], fc = miss_col[(in & !is_row) ? idx : 0];
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(in & ((is_row ? fr : fc) != 0));
+        rbits = (unsigned)bal & ((1u << K) - 1u);
+        cbits = (unsigned)(bal >> K) & ((1u << K) - 1u);
+    }
+    const auto* w = uniform_global(A.w);
+    double cs_ = 0, s1 = 0, s2 = 0, nm = 0, ka = 0, kb = 0;
+    bool any_missing = false;
+#pragma unroll
+    for (int e = lane; e < kk; e += 64) {
+        const int ki = e / K, kj = e - ki * K;
+        const int p = p0 + ki, q = q0 + kj, d = q - p;
+        const double v = win ? win[e] : load_signal(A, p, q);
+        cs_ = fma(v, w[e], cs_);
+        s1 += v;
+        s2 = fma(v, v, s2);
+        // missing_from_flags for per-bin masks, sym_upper, full, max_dist >= 0, km == kn
+        const bool in = (p >= 0) & (p < ms) & (q >= 0) & (q < ns);
+        const bool flagged = (((rbits >> ki) | (cbits >> kj)) & 1u) != 0;
+        const bool m_in = flagged & (d >= 0) & (d <= md);
+        const bool m_out = (q >= ns) ? (p >= ms - md - 2) : ((p < 0) & ((q < 0) | (q < md + K)));
+        const bool m = (in ? m_in : m_out) | ((d <= -1) & (d >= -K));
+        if (__builtin_amdgcn_ballot_w64(m)) {                  // (uniform; half of a genome's windows have no missing pixel at all)
+            any_missing = true;
+            nm += m ? 1.0 : 0.0;
+            ka += m ? w[kk + e] : 0.0;
+            kb += m ? w[2 * kk + e] : 0.0;
+        }
+    }
+    cs_ = wave_sum(cs_);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (any_missing) {
+        nm = wave_sum(nm);
+        ka = wave_sum(ka);
+        kb = wave_sum(kb);
+    }
+    r = pearson_from_sums<double>(cs_, s1, s2, nm, ka, kb, A.ks, true, &nobs);
+}
+
 // per-bin flags of the rows p0 .. p0 + km - 1 and the columns q0 .. q0 + kn - 1 of a window as bit masks (bins outside
 // the matrix: 0); for templates of up to 32 x 32 -- larger ones evaluate missing_pred per pixel
 __device__ __forceinline__ void window_flag_bits(const CorrArgs<double>& A, int p0, int q0, unsigned& rbits, unsigned& cbits)

@@ -152,7 +152,13 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
 // 10 us; now 13 loads per thread in 16 workgroups.)
 constexpr int kFinishDiags = 16;
 constexpr int kFinishPhases = 64;
-__global__ __launch_bounds__(kFinishDiags * kFinishPhases) void stage_finish_kernel(const StageBlock* __restrict__ blocks, int pitch,
+// PPT phases per thread: the same additions in the same order whatever the launch shape -- 64 phase sums per diagonal, then
+// eight sums of eight, then the eight.  PPT = 1 (1024 threads) for blocks of hundreds of groups (C3: 781 groups, 13 loads
+// per thread); PPT = 4 (256 threads, a thread walks four phases) when every block has at most 256 groups -- the 23 blocks of
+// a genome are 1472 workgroups whose threads hold one or two partials each, and as 1024-thread workgroups they took three
+// rounds of residence for 42 us between the law pass and the tiler (profiles/r04b_genome_timeline.txt).
+template <int PPT>
+__global__ __launch_bounds__(kFinishDiags * kFinishPhases / PPT) void stage_finish_kernel(const StageBlock* __restrict__ blocks, int pitch,
                                                            const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
                                                            const LazySource src)
 {
@@ -178,51 +184,55 @@ __global__ __launch_bounds__(kFinishDiags * kFinishPhases) void stage_finish_ker
         L.data_is_f64 = src.data_is_f64;
         *B.lazy = L;
     }
-    const int dx = threadIdx.x % kFinishDiags, ph = threadIdx.x / kFinishDiags;
+    const int dx = threadIdx.x % kFinishDiags, t_ph = threadIdx.x / kFinishDiags;
     const int d = blockIdx.y * kFinishDiags + dx;
+    const int g_end = B.group0 + B.n_groups;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int ph = t_ph * PPT + j;
+        double s = 0.0;
+        unsigned long long c = 0;
+        if (d < B.n_diags) {
+            // eight groups' partials requested together (the order of the additions stays the one of the plain loop)
+            int g = B.group0 + ph;
+            for (; g + 7 * kFinishPhases < g_end; g += 8 * kFinishPhases) {
+                double ps[8];
+                unsigned pc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ps[u] = part_sum[(size_t)(g + u * kFinishPhases) * pitch + d];
+                    pc[u] = part_cnt[(size_t)(g + u * kFinishPhases) * pitch + d];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s += ps[u];
+                    c += pc[u];
+                }
+            }
+            for (; g < g_end; g += kFinishPhases) {
+                s += part_sum[(size_t)g * pitch + d];
+                c += part_cnt[(size_t)g * pitch + d];
+            }
+        }
+        s_sum[ph][dx] = s;
+        s_cnt[ph][dx] = c;
+    }
+    __syncthreads();
     double s = 0.0;
     unsigned long long c = 0;
-    if (d < B.n_diags) {
-        // eight groups' partials requested together (the order of the additions stays the one of the plain loop)
-        const int g_end = B.group0 + B.n_groups;
-        int g = B.group0 + ph;
-        for (; g + 7 * kFinishPhases < g_end; g += 8 * kFinishPhases) {
-            double ps[8];
-            unsigned pc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ps[u] = part_sum[(size_t)(g + u * kFinishPhases) * pitch + d];
-                pc[u] = part_cnt[(size_t)(g + u * kFinishPhases) * pitch + d];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                s += ps[u];
-                c += pc[u];
-            }
-        }
-        for (; g < g_end; g += kFinishPhases) {
-            s += part_sum[(size_t)g * pitch + d];
-            c += part_cnt[(size_t)g * pitch + d];
-        }
-    }
-    s_sum[ph][dx] = s;
-    s_cnt[ph][dx] = c;
-    __syncthreads();
-    if (ph < 8) {
-        s = 0.0;
-        c = 0;
-        for (int k = 8 * ph; k < 8 * ph + 8; ++k) {
+    if (t_ph < 8) {
+        for (int k = 8 * t_ph; k < 8 * t_ph + 8; ++k) {
             s += s_sum[k][dx];
             c += s_cnt[k][dx];
         }
     }
     __syncthreads();
-    if (ph < 8) {
-        s_sum[ph][dx] = s;
-        s_cnt[ph][dx] = c;
+    if (t_ph < 8) {
+        s_sum[t_ph][dx] = s;
+        s_cnt[t_ph][dx] = c;
     }
     __syncthreads();
-    if (ph == 0 && d < B.n_diags) {
+    if (t_ph == 0 && d < B.n_diags) {
         s = 0.0;
         c = 0;
         for (int k = 0; k < 8; ++k) {
@@ -505,8 +515,16 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
         CS_STAGE_BOTH(CS_STAGE_LAW, unroll)
     }
     const LazySource lazy_src{indptr, indices, data, weight, max_val, data_is_f64};
-    hipLaunchKernelGGL(stage_finish_kernel, dim3(n_blocks, (max_b + kFinishDiags - 1) / kFinishDiags), dim3(kFinishDiags * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
-                       part_cnt, lazy_src);
+    int max_groups = 0;
+    for (int b = 0; b < n_blocks; ++b) max_groups = std::max(max_groups, h_blocks[b].n_groups);
+    const dim3 finish_grid(n_blocks, (max_b + kFinishDiags - 1) / kFinishDiags);
+    // (few workgroups: they are all resident at once either way, and the 1024-thread shape has the shorter per-thread chain)
+    if (max_groups <= 256 && (long long)finish_grid.x * finish_grid.y > 512 && !getenv("CHROMOSIGHT_HIP_FINISH_WIDE"))
+        hipLaunchKernelGGL(stage_finish_kernel<4>, finish_grid, dim3(kFinishDiags * kFinishPhases / 4), 0, stream, d_blocks, pitch, part_sum,
+                           part_cnt, lazy_src);
+    else
+        hipLaunchKernelGGL(stage_finish_kernel<1>, finish_grid, dim3(kFinishDiags * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
+                           part_cnt, lazy_src);
     if (!(skip && skip[0] == 't')) {
         CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile)
     }

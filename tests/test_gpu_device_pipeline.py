@@ -508,6 +508,23 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
                 assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]]), switch
                 assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9, switch
         monkeypatch.delenv(switch)
+    # the wave-per-window kernels with the general functions instead of the compile-time-size ones (cs_launch_aux.h
+    # rescore_pixel_sq / lazy_gather_window_sq / SigReader: the same sums in the same order): records bit for bit on ONE staging
+    # (the distance law of a staging is summed with LDS atomics: two stagings differ in the last bits), on lazily evaluated
+    # and on stored float64 bands
+    for twin in (False, True):
+        if twin:
+            monkeypatch.setenv("CHROMOSIGHT_HIP_F64_TWIN", "1")
+        dcool = pipeline.DeviceCool(cool)
+        cfgs = [loops, copy.deepcopy(ck.borders)]
+        staged = parallel.stage_genome(dcool, cfgs)
+        fast_l, fast_b = parallel.detect_patterns(dcool, cfgs, staged=staged)
+        monkeypatch.setenv("CHROMOSIGHT_HIP_NO_FAST_WINDOWS", "1")
+        slow_l, slow_b = parallel.detect_patterns(dcool, cfgs, staged=staged)
+        monkeypatch.delenv("CHROMOSIGHT_HIP_NO_FAST_WINDOWS")
+        for fast, slow, want in ((fast_l, slow_l, want_l), (fast_b, slow_b, want_b)):
+            assert fast.shape == want.shape and np.array_equal(fast, slow), twin
+            assert np.array_equal(fast[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]]) and np.abs(fast[:, 3] - want[:, 3]).max() < 1e-12
 
 
 # ------------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ dcool = pipeline.DeviceCool(cool)
 loops = copy.deepcopy(ck.loops); loops["max_dist"] = 2_000_000
 borders = copy.deepcopy(ck.borders)
 ts = []
-for it in range(14):
+for it in range(24):
     dcool.dev.sync(); t0 = time.perf_counter()
     rec = parallel.genome_step(dcool, [loops, borders], owned=mine)
     dcool.dev.sync(); ts.append((time.perf_counter() - t0) * 1e3)
@@ -28,7 +28,7 @@ px = sum(costs[i] for i in mine)
 plans = dcool.__dict__.get("_step_plans", {})
 if not all(p.ok for p in plans.values()) or not plans:
     print("no step plan:", [p.why for p in plans.values()])
-print(f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (min {min(ts):.3f}); "
+print(f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (median {np.median(ts[4:]):.3f}, min {min(ts):.3f}); "
       f"patterns {[len(r) for r in rec]}")
 if os.environ.get("PROFILE"):
     import cProfile, pstats

@@ -2789,6 +2789,8 @@ struct CallRun {
     cs_call* calls = nullptr;
     int n = 0;
     std::atomic<int>* done = nullptr;      // per call: 1 once it has returned (or was skipped)
+    bool timing = false;
+    std::chrono::steady_clock::time_point t0;
 };
 
 int dispatch_call(cs_call& c)
@@ -2833,7 +2835,12 @@ void run_lane(const CallRun& R, int lane)
                 if (++spins > 2000) std::this_thread::yield();
             if (R.calls[c.after].rc != 0) failed = true;            // what it waited for did not happen
         }
+        const auto t_begin = std::chrono::steady_clock::now();
         c.rc = failed ? CS_ERR_INVALID : dispatch_call(c);
+        if (R.timing)       // CHROMOSIGHT_HIP_TIMING: the host timeline of the list (lane, entry, begin and end since the list began)
+            fprintf(stderr, "[timing] run_calls: lane %d call %2d fn %d  %7.1f -> %7.1f us\n", lane, k, c.fn,
+                    std::chrono::duration<double, std::micro>(t_begin - R.t0).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - R.t0).count());
         if (c.rc != 0) failed = true;
         R.done[k].store(1, std::memory_order_release);
     }
@@ -2891,6 +2898,8 @@ extern "C" int cs_run_calls(cs_call* calls, int32_t n_calls)
     R.calls = calls;
     R.n = n_calls;
     R.done = done.data();
+    R.timing = std::getenv("CHROMOSIGHT_HIP_TIMING") != nullptr;
+    R.t0 = std::chrono::steady_clock::now();
     std::vector<LaneWorker*>& g_workers = lane_workers();
     while ((int)g_workers.size() < lanes - 1) {
         LaneWorker* w = new LaneWorker;

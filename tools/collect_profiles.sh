@@ -75,7 +75,14 @@ bash tools/rank_share_sweep.sh "$out/rank_share.txt" > /dev/null 2>&1
 python tools/trace_rank_share.py 8 1 > "$out/rank_share_host_trace.txt" 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$out/kt_8_1" -o rs -- python tools/time_rank_share.py 8 1 > "$out/kt_8_1.log" 2>&1
 python tools/kernel_timeline.py "$out/kt_8_1" > "$out/rank_share_timeline.txt" 2>&1
-CHROMOSIGHT_HIP_TIMING=1 python tools/time_rank_share.py 8 1 2>&1 | grep timing | tail -8 > "$out/rank_share_native_laps.txt"
+CHROMOSIGHT_HIP_TIMING=1 python tools/time_rank_share.py 8 1 2>&1 | grep timing | tail -19 > "$out/rank_share_native_laps.txt"
+# the whole genome on one GPU: device timeline of one step, host timeline of its call list
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$out/kt_1_0" -o rs -- python tools/time_rank_share.py 1 0 > "$out/kt_1_0.log" 2>&1
+python tools/kernel_timeline.py "$out/kt_1_0" > "$out/genome_timeline.txt" 2>&1
+CHROMOSIGHT_HIP_TIMING=1 python tools/time_rank_share.py 1 0 2>&1 | grep timing | tail -19 > "$out/genome_native_laps.txt"
+# one pattern's chain alone on a rank's share (no second chain beside it)
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$out/kt_b" -o rs -- python tools/time_pattern_alone.py 8 1 1 > "$out/kt_b.log" 2>&1
+python tools/kernel_timeline.py "$out/kt_b" narrow_enumerate > "$out/borders_alone_timeline.txt" 2>&1
 python tools/time_c4_phases.py 6 > "$out/c4_phases.txt" 2>&1
 python tools/time_c5_phases.py > "$out/c5_phases.txt" 2>&1
 [ -f chromosight_amd/csrc/build/libchromosight_hip_prof.so ] && python tools/prof_mfma_sections.py c2 c3k c4p > "$out/tile_kernel_sections.txt" 2>&1

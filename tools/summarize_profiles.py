@@ -123,7 +123,8 @@ for run, key, kernels in (("c4", "c4_genome_cand_instances", ("corr_mfma_dense_k
         summary[key] = rec
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
 for name in ("rank_share.txt", "rank_share_host_trace.txt", "rank_share_timeline.txt", "rank_share_native_laps.txt", "c4_phases.txt",
-             "c5_phases.txt", "tile_kernel_sections.txt", "c4_modes.txt"):
+             "c5_phases.txt", "tile_kernel_sections.txt", "c4_modes.txt", "genome_timeline.txt", "genome_native_laps.txt",
+             "borders_alone_timeline.txt"):
     f2 = os.path.join(src, name)
     if os.path.exists(f2) and os.path.getsize(f2):
         shutil.copy(f2, os.path.join(dst, f"{tag}_{name}"))

@@ -138,7 +138,7 @@ class CsCall(C.Structure):
 
 
 CALL_STAGE_BLOCKS, CALL_EVENT_RECORD, CALL_STREAM_WAIT_EVENT, CALL_DETECT_FOCI_BLOCKS, CALL_DETECT_FOCI_BATCH_TEMPLATES, \
-    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH = 1, 2, 3, 4, 5, 6, 7
+    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_WAIT_TILE_LAUNCH = 1, 2, 3, 4, 5, 6, 7, 8
 
 # While a list is installed here, the entries named in _CAPTURED append (name, arguments) to it AFTER running as usual:
 # chromosight_amd/plan.py turns the calls of one genome step into a cs_run_calls list.
@@ -207,6 +207,7 @@ _PROTOTYPES = {
     "cs_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "cs_stage_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(CsStageBlock), C.c_int32, C.c_double]),
     "cs_csr_median": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(C.c_double)]),
+    "cs_csr_median_many": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.c_int32, C.POINTER(C.c_double)]),
     "cs_detect_foci": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                  C.POINTER(CsNormxcorr2Params), C.POINTER(CsFociParams), C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64), C.c_void_p]),

@@ -131,6 +131,100 @@ namespace {
 
 // CHROMOSIGHT_HIP_TIMING=1: host-side lap times of the batched entries on stderr (where a call's microseconds go before its
 // kernels are on the device)
+// Worker threads of the host-side passes (cs_accept_records), kept between calls: starting seven threads for the 7 000 records
+// of a rank's share cost more than their work (128 us for 30 us of arithmetic), and on a genome the 1-D pattern's 56 000
+// records are the last thing a step waits for once its launch chain runs behind the tile kernels.  Tasks are taken from a
+// shared counter by the workers AND the caller; a second caller at the same time runs its tasks itself.
+class HostPool {
+public:
+    static HostPool& get()
+    {
+        static HostPool* p = new HostPool();           // (never destroyed: the detached workers may be waiting at exit)
+        return *p;
+    }
+    template <typename F>
+    void run(int n_tasks, int max_threads, const F& fn)
+    {
+        if (n_tasks <= 0) return;
+        std::unique_lock<std::mutex> busy(busy_mu_, std::try_to_lock);
+        if (n_tasks == 1 || max_threads <= 1 || !busy.owns_lock()) {
+            for (int t = 0; t < n_tasks; ++t) fn(t);
+            return;
+        }
+        const int want = std::min(std::min(max_threads, n_tasks) - 1, kMaxWorkers);
+        grow(want);
+        Job job;
+        job.fn = [](const void* f, int t) { (*static_cast<const F*>(f))(t); };
+        job.ctx = &fn;
+        job.n_tasks = n_tasks;
+        job.next.store(0, std::memory_order_relaxed);
+        job.active.store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &job;
+            wanted_ = want;
+            ++generation_;
+        }
+        cv_.notify_all();
+        for (int t; (t = job.next.fetch_add(1, std::memory_order_relaxed)) < n_tasks;) fn(t);
+        {
+            // no worker joins from here on (they register under the same lock); the ones that did are waited for -- a worker
+            // that wakes up late finds no job instead of holding the caller up
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = nullptr;
+        }
+        int spins = 0;
+        while (job.active.load(std::memory_order_acquire) != 0)
+            if (++spins > 2000) std::this_thread::yield();
+    }
+
+private:
+    static constexpr int kMaxWorkers = 31;
+    struct Job {
+        void (*fn)(const void*, int) = nullptr;
+        const void* ctx = nullptr;
+        int n_tasks = 0;
+        std::atomic<int> next{0};
+        std::atomic<int> active{0};        // workers that took the job and have not finished with it
+    };
+    void grow(int n)
+    {
+        while ((int)threads_ < n) {
+            const int id = (int)threads_++;
+            std::thread([this, id] { loop(id); }).detach();
+        }
+    }
+    void loop(int id)
+    {
+        long long seen = 0;
+        for (;;) {
+            Job* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (id < wanted_ && job_) {
+                    job = job_;
+                    job->active.fetch_add(1, std::memory_order_relaxed);
+                }
+            }
+            if (!job) continue;
+            for (int t; (t = job->next.fetch_add(1, std::memory_order_relaxed)) < job->n_tasks;) job->fn(job->ctx, t);
+            job->active.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::mutex busy_mu_, mu_;
+    std::condition_variable cv_;
+    Job* job_ = nullptr;
+    int wanted_ = 0;
+    long long generation_ = 0;
+    size_t threads_ = 0;
+};
+
+// bumped by cs_detect_foci_blocks once its tile kernels are launched: a lane of cs_run_calls can hold its own launch chain back
+// until then (CS_CALL_WAIT_TILE_LAUNCH), so that the persistent tile workgroups take their slots on an empty device
+std::atomic<long long> g_tile_launch_seq{0};
+
 struct Laps {
     bool on;
     std::chrono::steady_clock::time_point t0, last;
@@ -1685,11 +1779,11 @@ int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_
     if (n > 0 && (!h_rec || !h_table || !h_ok)) return CS_ERR_INVALID;
     // pass 1, record by record (a few transcendental functions each: threads beyond a couple of thousand records):
     // the row of every record at its own slot
-    auto rows_of = [&](int64_t b0, int64_t b1, int64_t at) {
-        for (int64_t b = b0; b < b1; ++b) {
+    auto rows_piece = [&](int64_t b, int64_t at, int64_t cnt) {
+        {
             const int64_t ms = h_rows[b], ns = h_cols[b];
             const bool limited = !inter && h_max_dist && h_max_dist[b] >= 0;
-            for (int64_t t = at; t < at + h_counts[b]; ++t) {
+            for (int64_t t = at; t < at + cnt; ++t) {
                 const cs_focus& f = h_rec[t];
                 const int64_t r = f.bin1, c = f.bin2;
                 // coefficient on the trimmed map (detection.py:269-270) ...
@@ -1715,25 +1809,24 @@ int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_
                 row[2] = ok ? (in_band ? f.score : 0.0) : std::numeric_limits<double>::quiet_NaN();
                 row[3] = pval;
             }
-            at += h_counts[b];
         }
     };
-    const int n_threads = (int)std::min<int64_t>(8, std::min<int64_t>(n / 1024, n_blocks));
-    if (n_threads > 1) {
-        std::vector<std::thread> pool;
-        int64_t b0 = 0, at = 0;
-        for (int t = 0; t < n_threads; ++t) {
-            // consecutive blocks holding about n / n_threads records
-            int64_t b1 = b0, sum = 0;
-            while (b1 < n_blocks && (t + 1 == n_threads || sum < (n + n_threads - 1) / n_threads)) sum += h_counts[b1++];
-            pool.emplace_back(rows_of, b0, b1, at);
-            b0 = b1;
-            at += sum;
+    // tasks: a block's records, long blocks in pieces of 1024; the pool's workers and this thread take them from a counter
+    struct Piece { int64_t b, at, n; };
+    std::vector<Piece> pieces;
+    {
+        int64_t at = 0;
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            for (int64_t o = 0; o < h_counts[b]; o += 1024) pieces.push_back({b, at + o, std::min<int64_t>(1024, h_counts[b] - o)});
+            at += h_counts[b];
         }
-        for (auto& th : pool) th.join();
-    } else {
-        rows_of(0, n_blocks, 0);
     }
+    static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int max_threads = (int)std::min<int64_t>(std::min(32, std::max(1, cores / 2)), n / 256);
+    HostPool::get().run((int)pieces.size(), max_threads, [&](int t) {
+        const Piece& pc = pieces[(size_t)t];
+        rows_piece(pc.b, pc.at, pc.n);
+    });
     // pass 2: counts, and in compact mode the accepted rows packed to the front (in place: a row never moves backwards)
     int64_t at = 0, out = 0;
     for (int64_t b = 0; b < n_blocks; ++b) {
@@ -1781,6 +1874,24 @@ int cs_csr_median(cs_ctx* ctx, void* stream_, const cs_csr* mat, double* h_media
     };
     rc = cs::csr_median(v, ctx->n_cu, (hipStream_t)stream_, grow, ctx, h_median);
     if (rc) return fail(ctx, CS_ERR_HIP, "median failed: %s", hipGetErrorString((hipError_t)rc));
+    return CS_OK;
+}
+
+int cs_csr_median_many(cs_ctx* ctx, void* stream_, const cs_csr* mats, int32_t n, double* h_medians)
+{
+    CS_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!mats || !h_medians))) return fail(ctx, CS_ERR_INVALID, "bad view list");
+    std::vector<cs::CsrView> views((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        int rc = csr_view(ctx, mats + i, &views[(size_t)i]);
+        if (rc) return rc;
+    }
+    auto grow = [](void* user, size_t bytes) -> void* {
+        cs_ctx* c = (cs_ctx*)user;
+        return ensure_scratch(c, &c->d_pool, &c->d_pool_bytes, bytes) == CS_OK ? c->d_pool : nullptr;
+    };
+    int rc = cs::csr_median_many(views.data(), n, ctx->n_cu, (hipStream_t)stream_, grow, ctx, h_medians);
+    if (rc) return fail(ctx, CS_ERR_HIP, "medians failed: %s", hipGetErrorString((hipError_t)rc));
     return CS_OK;
 }
 
@@ -2554,6 +2665,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
         laps.lap("tile kernels launched");
+        g_tile_launch_seq.fetch_add(1, std::memory_order_release);      // (CS_CALL_WAIT_TILE_LAUNCH of cs_run_calls)
         CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
         if (tab.empty()) {
             // built while the tile kernels run, not between the two synchronisations
@@ -2791,6 +2903,7 @@ struct CallRun {
     std::atomic<int>* done = nullptr;      // per call: 1 once it has returned (or was skipped)
     bool timing = false;
     std::chrono::steady_clock::time_point t0;
+    long long tile_seq0 = 0;               // g_tile_launch_seq when the list began
 };
 
 int dispatch_call(cs_call& c)
@@ -2818,6 +2931,8 @@ int dispatch_call(cs_call& c)
                                      (int32_t)i[5], (double*)p[5], (uint8_t*)p[6], (int64_t*)p[7]);
         case CS_CALL_DETECT_FOCI_BATCH_FINISH:
             return cs_detect_foci_batch_finish((cs_ctx*)p[0], p[1], (int64_t*)p[2]);
+        case CS_CALL_WAIT_TILE_LAUNCH:
+            return CS_OK;                      // (the wait itself is in run_lane: it needs the list's state)
         default:
             return CS_ERR_INVALID;
     }
@@ -2836,6 +2951,14 @@ void run_lane(const CallRun& R, int lane)
             if (R.calls[c.after].rc != 0) failed = true;            // what it waited for did not happen
         }
         const auto t_begin = std::chrono::steady_clock::now();
+        if (!failed && c.fn == CS_CALL_WAIT_TILE_LAUNCH) {
+            // until call number i[0] of the list (a cs_detect_foci_blocks) has launched its tile kernels -- or has returned
+            const int64_t k2 = c.i[0];
+            int spins = 0;
+            while (g_tile_launch_seq.load(std::memory_order_acquire) == R.tile_seq0 &&
+                   !(k2 >= 0 && k2 < R.n && R.done[k2].load(std::memory_order_acquire)))
+                if (++spins > 2000) std::this_thread::yield();
+        }
         c.rc = failed ? CS_ERR_INVALID : dispatch_call(c);
         if (R.timing)       // CHROMOSIGHT_HIP_TIMING: the host timeline of the list (lane, entry, begin and end since the list began)
             fprintf(stderr, "[timing] run_calls: lane %d call %2d fn %d  %7.1f -> %7.1f us\n", lane, k, c.fn,
@@ -2898,6 +3021,7 @@ extern "C" int cs_run_calls(cs_call* calls, int32_t n_calls)
     R.calls = calls;
     R.n = n_calls;
     R.done = done.data();
+    R.tile_seq0 = g_tile_launch_seq.load(std::memory_order_acquire);
     R.timing = std::getenv("CHROMOSIGHT_HIP_TIMING") != nullptr;
     R.t0 = std::chrono::steady_clock::now();
     std::vector<LaneWorker*>& g_workers = lane_workers();

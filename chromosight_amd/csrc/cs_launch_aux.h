@@ -714,6 +714,7 @@ int launch_narrow_rows(const double* src, long long ld_src, float* dst, long lon
 
 // median of the stored values of a view (cs_foci.hip)
 int csr_median(const CsrView& M, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_median);
+int csr_median_many(const CsrView* views, int n, int n_cu, hipStream_t stream, void* (*grow)(void*, size_t), void* user, double* h_medians);
 
 // split blocks: candidates of a row window / foci of a merged candidate list (cs_foci.hip)
 size_t keep_scratch_bytes(long long n_cand);

@@ -636,6 +636,54 @@ class DeviceCool:
         block.buffer, block.pool = own, self._free
         return block
 
+    def stage_inter_many(self, pairs, dtype=np.float64, stream=None):
+        """stage_inter(resident=True) for SEVERAL inter-chromosomal blocks: the extents of all of them, then their medians with
+        one native call (cs_csr_median_many: two synchronisations in all instead of two per block), then the dense maps."""
+        pairs = list(pairs)
+        if not pairs:
+            return []
+        with self.dev.lock:
+            dev, lib = self.dev, self.dev.lib
+            geo, total = [], 0
+            for ca, cb in pairs:
+                s1, e1 = int(self.offsets[ca]), int(self.offsets[ca + 1])
+                s2, e2 = int(self.offsets[cb]), int(self.offsets[cb + 1])
+                n_r, n_c = e1 - s1, e2 - s2
+                geo.append((ca, cb, s1, e1, s2, e2, n_r, n_c, total))
+                total += (16 * n_r + 511) // 256 * 256
+            # (the blocks' "laws" -- their median on every diagonal -- side by side behind the row extents: ONE upload)
+            law_off, laws = [], 0
+            for _, _, _, _, _, _, n_r, n_c, _ in geo:
+                law_off.append(laws)
+                laws += (max(n_r, n_c) + 31) // 32 * 32
+            ext = self._ext.get(total + 8 * laws + 512)
+            views = (type(self._view(0, 1, 0, 1)) * len(pairs))()
+            for i, (ca, cb, s1, e1, s2, e2, n_r, n_c, off) in enumerate(geo):
+                d_begin, d_end = ext + off, ext + off + 8 * n_r
+                raw = self._view(s1, e1, s2, e2)
+                dev._check(lib.cs_csr_band_extent(dev.ctx, stream, C.byref(raw), -n_r, n_c, d_begin, d_end))
+                views[i] = self._view(s1, e1, s2, e2, d_begin, d_end)
+            med = (C.c_double * len(pairs))()
+            dev._check(lib.cs_csr_median_many(dev.ctx, stream, views, len(pairs), med))
+            out = []
+            esz = np.dtype(dtype).itemsize
+            scale = np.empty(laws)
+            for i, (_, _, _, _, _, _, n_r, n_c, _) in enumerate(geo):
+                scale[law_off[i]:law_off[i] + max(n_r, n_c)] = med[i]
+            dev._check(lib.cs_memcpy_h2d(dev.ctx, ext + total, scale.ctypes.data, scale.nbytes, stream))
+            for i, (ca, cb, s1, e1, s2, e2, n_r, n_c, off) in enumerate(geo):
+                d_law = ext + total + 8 * law_off[i]
+                ld = (n_c + 15) // 16 * 16
+                own = self._resident(n_r * ld * esz)
+                sig = CsMatrix(own.ptr, np_dtype_code(dtype), LAYOUT_DENSE, ld, 0, 0)
+                # "law" = the median on every diagonal, no cap: value / median, NaN -> 0
+                dev._check(lib.cs_csr_to_band(dev.ctx, stream, C.byref(views[i]), d_law, max(n_r, n_c), 0.0, C.byref(sig)))
+                block = StagedBlock(f"{self.names[ca]}-{self.names[cb]}", sig, (n_r, n_c), _Ptr(self.miss.ptr + s1),
+                                    _Ptr(self.miss.ptr + s2), None, True, None)
+                block.buffer, block.pool = own, self._free
+                out.append(block)
+            return out
+
     def subsampled(self, sample, seed=0, inter=False):
         """A DeviceCool whose counts are a random subsample of this one's, drawn per sub-matrix without
         replacement like the reference's --subsample (contacts_map.py:552-596, preprocessing.py:359-401):
@@ -1003,7 +1051,15 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     # native calls); the tables are assembled once below
     score_out = [np.full(n_pos, np.nan) for _ in kernels]
     pval_out = [np.full(n_pos, np.nan) for _ in kernels]
-    win_out = [np.full((n_pos, km, kn), np.nan) for _ in kernels]
+    # windows: in position order where a path needs them there (block-by-block fall-back, sharded runs); the batched path hands
+    # its windows on in block order with the positions they belong to (three 2.4 MB scatters and as many NaN fills less)
+    win_out = [None for _ in kernels]
+    win_src = [None for _ in kernels]
+
+    def win_array(k):
+        if win_out[k] is None:
+            win_out[k] = np.full((n_pos, km, kn), np.nan)
+        return win_out[k]
     located = (g1 >= 0) & (g2 >= 0)
     # positions of every sub-matrix, in input order: one stable sort by (chrom1, chrom2); only the sub-matrices that hold a
     # position are visited (no pattern on a sub-matrix: it is not scanned, :240), in the order of sub_matrices()
@@ -1028,22 +1084,32 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     if intra:
         for ca, blk in zip(intra, dcool.stage_blocks(intra, max_dist, largest, smooth=smooth)):
             staged[(ca, ca)] = blk
-    for ca, cb, _, _ in mine:
-        if ca != cb:
+    inter_pairs = [(ca, cb) for ca, cb, _, _ in mine if ca != cb]
+    if len(inter_pairs) > 1 and not os.environ.get("CHROMOSIGHT_HIP_NO_MEDIAN_BATCH"):
+        for pair, blk in zip(inter_pairs, dcool.stage_inter_many(inter_pairs)):
+            staged[pair] = blk
+    else:
+        for ca, cb in inter_pairs:
             staged[(ca, cb)] = dcool.stage_inter(ca, cb, resident=True)
     blocks = [staged[(ca, cb)] for ca, cb, _, _ in mine]
-    for kernel_id, kernel in enumerate(kernels):
-        # one native call per template for the positions of all sub-matrices (cs_quantify_blocks) ...
-        res = None
-        if mine and tsvd is None and not os.environ.get("CHROMOSIGHT_HIP_NO_QUANTIFY_BATCH"):
+    # one native call per template for the positions of all sub-matrices (cs_quantify_blocks), the coordinate lists prepared
+    # once for all templates ...
+    res_all = None
+    if mine and tsvd is None and not os.environ.get("CHROMOSIGHT_HIP_NO_QUANTIFY_BATCH"):
+        for kernel in kernels:
             _check_template(kernel)
-            res = cid.quantify_many_on_device(dcool.dev, blocks, engine.KernelSpec(kernel), cfg, [c for _, _, _, c in mine])
-        if res is not None:
-            table, wins = res
-            where = np.concatenate([sel for _, _, sel, _ in mine])
+        res_all = cid.quantify_many_on_device(dcool.dev, blocks, [engine.KernelSpec(k) for k in kernels], cfg, [c for _, _, _, c in mine])
+    if res_all is not None:
+        where = np.concatenate([sel for _, _, sel, _ in mine])
+        for kernel_id, (table, wins) in enumerate(res_all):
             score_out[kernel_id][where] = table[:, 2]
             pval_out[kernel_id][where] = table[:, 3]
-            win_out[kernel_id][where] = wins
+            if shard is None:
+                win_src[kernel_id] = (wins, where)
+            else:
+                win_array(kernel_id)[where] = wins
+    for kernel_id, kernel in enumerate(kernels):
+        if res_all is not None:
             continue
         # ... or, where the batch does not apply (truncated SVD, non-square templates), one per sub-matrix and template
         for (ca, cb, sel, coords), block in zip(mine, blocks):
@@ -1052,8 +1118,9 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
                 continue
             score_out[kernel_id][sel] = rec[:, 2]
             pval_out[kernel_id][sel] = rec[:, 3]
-            win_out[kernel_id][sel] = wins
+            win_array(kernel_id)[sel] = wins
     if shard is not None:
+        win_out = [win_array(k) for k in range(len(kernels))]
         score_out, pval_out, win_out = shard.merge(score_out, pval_out, win_out, [sel for _, _, sel, _ in mine])
     # best score of every coordinate among the templates, as the reference selects it (:432-441): the tables of the templates
     # one below the other, sort_values("score"), last row of every (chrom1, start1, chrom2, start2) group.  In numpy -- the
@@ -1077,7 +1144,19 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
     windows = np.empty((pick.size, km, kn))
     for k in range(n_k):
         m = pick // n_pos == k
-        windows[m] = win_out[k][src[m]]
+        if win_src[k] is not None:
+            wins, where = win_src[k]
+            inv = np.full(n_pos, -1, dtype=np.int64)
+            inv[where] = np.arange(where.size)
+            at = inv[src[m]]
+            if (at >= 0).all():
+                windows[m] = wins[at]
+            else:                                       # (positions no sub-matrix holds: NaN windows, as the position-order arrays had)
+                w = np.full((at.size, km, kn), np.nan)
+                w[at >= 0] = wins[at[at >= 0]]
+                windows[m] = w
+        else:
+            windows[m] = win_array(k)[src[m]]
     # the bin columns come from the interval STARTS (coords_to_bins of start1 / start2, :446-455), the scores from
     # the interval midpoints: they differ for intervals wider than one bin
     out1, out2 = bins(c1[src], s1[src]), bins(c2[src], s2[src])

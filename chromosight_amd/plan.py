@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_DETECT_FOCI_BATCH_TEMPLATES, CALL_DETECT_FOCI_BLOCKS,
-                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_WAIT_EVENT, FOCUS_DTYPE, CsCall, raw_arg)
+                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_WAIT_EVENT, CALL_WAIT_TILE_LAUNCH, FOCUS_DTYPE, CsCall, raw_arg)
 
 # argument slots of every entry: 'p' pointer, 'i' integer, 'd' double, in the order of the C prototype
 _SLOTS = {
@@ -109,27 +109,48 @@ class StepPlan:
         # residence holds every register of every SIMD: the 1-D chain's kernels otherwise wait for its workgroups to drain),
         # but the 1-D chain's 220 us then sit in front of the tile kernels instead of beside them.
         contend = not os.environ.get("CHROMOSIGHT_HIP_PLAN_ORDERED")
+        # CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1: lane 1 holds its chain back until the 2-D chain's tile kernels are launched
+        # (CS_CALL_WAIT_TILE_LAUNCH): the persistent tile workgroups then take their slots on an empty device -- their tile
+        # ranges are static, one that starts late finishes late -- and the 1-D chain runs in what they leave
+        # (measured, profiles/r04b_tiles_first.txt: the device span of a genome step shrinks from 3.06 to 2.82 ms -- one
+        # persistent tile launch of 1.71 ms instead of 2.11 ms of per-block launches, the 1-D chain behind it -- but the step
+        # does not: 3.28-3.34 ms either way, a share of 8 0.63 against 0.60-0.63 ms; off by default)
+        tiles_first = bool(os.environ.get("CHROMOSIGHT_HIP_PLAN_TILES_FIRST"))
         self.done_b = dev.new_event()
         stream_a = raw_arg(blocks[0][1])
-        calls = (CsCall * 10)()
-        _fill(calls[0], *_SLOTS["cs_stage_blocks"], stage[0], 0)
-        _fill(calls[1], *_SLOTS["cs_event_record"], rec_ev[-1], 0)
-        _fill(calls[2], *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=1)
+        n_calls = 11 if tiles_first else 10
+        calls = (CsCall * n_calls)()
+        k = 0
+
+        def nxt():
+            nonlocal k
+            k += 1
+            return calls[k - 1]
+        _fill(nxt(), *_SLOTS["cs_stage_blocks"], stage[0], 0)
+        _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)
+        _fill(nxt(), *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=1)
+        if tiles_first:
+            _fill(nxt(), CALL_WAIT_TILE_LAUNCH, "i", (7,), 1)            # (call 7 below: cs_detect_foci_blocks)
         b = list(batch[0])
         b[8], b[9] = self.rec1.ctypes.data, self.cap1
         b[7][0].reserved = 1                                  # asynchronous form: return once the chain is enqueued
-        _fill(calls[3], *_SLOTS["cs_detect_foci_batch_templates"], b, 1)
-        _fill(calls[4], *_SLOTS["cs_event_record"], (ctx_b, self.done_b, stream_b), 1)
-        _fill(calls[5], *_SLOTS["cs_stream_wait_event"], (ctx_a, stream_a, None if contend else self.done_b), 0, after=4)
+        _fill(nxt(), *_SLOTS["cs_detect_foci_batch_templates"], b, 1)
+        i_done_b = k
+        _fill(nxt(), *_SLOTS["cs_event_record"], (ctx_b, self.done_b, stream_b), 1)
         if contend:
-            calls[5].fn, calls[5].after = CALL_EVENT_RECORD, -1          # (a harmless record instead of the wait)
-            _fill(calls[5], *_SLOTS["cs_event_record"], rec_ev[-1], 0)
+            _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)          # (a harmless record instead of the wait)
+        else:
+            _fill(nxt(), *_SLOTS["cs_stream_wait_event"], (ctx_a, stream_a, self.done_b), 0, after=i_done_b)
         a = list(blocks[0])
         a[8], a[9] = self.rec2.ctypes.data, self.cap2
-        _fill(calls[6], *_SLOTS["cs_detect_foci_blocks"], a, 0)
-        self._accept(calls[7], self.rec2, self.counts2, self.acc2, cfg2, 0)
-        _fill(calls[8], CALL_DETECT_FOCI_BATCH_FINISH, "ppp", (ctx_b, stream_b, self.counts1), 1)
-        self._accept(calls[9], self.rec1, self.counts1, self.acc1, cfg1, 1)
+        assert not tiles_first or k == 7
+        if tiles_first:
+            a[6][0].exclusive = 1                             # ONE persistent launch for the tiles of all blocks
+        _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], a, 0)
+        self._accept(nxt(), self.rec2, self.counts2, self.acc2, cfg2, 0)
+        _fill(nxt(), CALL_DETECT_FOCI_BATCH_FINISH, "ppp", (ctx_b, stream_b, self.counts1), 1)
+        self._accept(nxt(), self.rec1, self.counts1, self.acc1, cfg1, 1)
+        assert k == n_calls
         self.calls = calls
         self.lib = dev.lib
         self.ok = True

@@ -296,6 +296,10 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream, const cs_csr* genome, const cs_st
  * contacts_map.py:598-601 preprocess_inter_matrix, which divides an inter-chromosomal block by it).
  * Balanced on the fly like every view.  *h_median = NaN for an empty view.  Synchronous. */
 int cs_csr_median(cs_ctx* ctx, void* stream, const cs_csr* mat, double* h_median);
+/* The same for n views with two synchronisations in all (sizes, results) instead of two per view: every inter-chromosomal
+ * sub-matrix that holds a position of a `quantify --inter` run is scaled by its own median (cli/chromosight.py:229-260 one
+ * task per sub-matrix).  h_medians[i] = NaN for an empty view.  Synchronous. */
+int cs_csr_median_many(cs_ctx* ctx, void* stream, const cs_csr* mats, int32_t n, double* h_medians);
 
 /* ---- device-side foci: detection.py:387 pick_foci + the statistics of :18 validate_patterns ---- */
 typedef struct {
@@ -428,7 +432,11 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
  * and replays them on the same buffers).  rc of every call is filled in; a lane stops at its first failing call; the
  * return value is the first non-zero rc (0: every call succeeded). */
 enum { CS_CALL_STAGE_BLOCKS = 1, CS_CALL_EVENT_RECORD = 2, CS_CALL_STREAM_WAIT_EVENT = 3, CS_CALL_DETECT_FOCI_BLOCKS = 4,
-       CS_CALL_DETECT_FOCI_BATCH_TEMPLATES = 5, CS_CALL_ACCEPT_RECORDS = 6, CS_CALL_DETECT_FOCI_BATCH_FINISH = 7 };
+       CS_CALL_DETECT_FOCI_BATCH_TEMPLATES = 5, CS_CALL_ACCEPT_RECORDS = 6, CS_CALL_DETECT_FOCI_BATCH_FINISH = 7,
+       /* no entry of its own: the lane waits until call number i[0] of the list (a CS_CALL_DETECT_FOCI_BLOCKS) has LAUNCHED its
+        * tile kernels, or has returned -- a launch chain enqueued only then finds the persistent tile workgroups in their
+        * slots and runs in what they leave, instead of taking slots first and making some of them start late */
+       CS_CALL_WAIT_TILE_LAUNCH = 8 };
 typedef struct {
     int32_t fn;        /* CS_CALL_* */
     int32_t lane;      /* 0: the calling thread */

@@ -362,11 +362,15 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert set(np.unique(want_b[:, 5])) == {0.0, 1.0, 2.0}
 
 
-def test_genome_step_as_one_native_call_equals_the_two_calls():
+@pytest.mark.parametrize("tiles_first", [False, True])
+def test_genome_step_as_one_native_call_equals_the_two_calls(monkeypatch, tiles_first):
     """parallel.genome_step: the first step of a layout runs stage_genome + detect_patterns and records the library calls it
     made; every later step is ONE cs_run_calls on those arguments (chromosight_amd/plan.py) -- staging, both patterns' chains
     and the acceptance rules recomputed natively -- and must give the records of the two calls, every time; a second
-    genome (other data, same code path) gets its own plan."""
+    genome (other data, same code path) gets its own plan.  tiles_first: the list with CS_CALL_WAIT_TILE_LAUNCH (the 1-D chain
+    held back until the tile kernels are launched, ONE persistent tile launch; CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1)."""
+    if tiles_first:
+        monkeypatch.setenv("CHROMOSIGHT_HIP_PLAN_TILES_FIRST", "1")
     template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
     loops = copy.deepcopy(ck.loops)
     loops["max_dist"] = 200 * 2000

@@ -467,6 +467,61 @@ def test_native_acceptance_rules_equal_the_numpy_ones():
     assert got.shape == (0, 4) and ok.size == 0 and kept.size == 0
 
 
+def test_native_acceptance_rules_pool_and_concurrent_callers():
+    """cs_accept_records on lists long enough for the library's worker pool (pieces of 1024 records taken from a counter by
+    the workers and the caller), from several threads at once (a caller that finds the pool busy runs its pieces itself):
+    every call gives the table of the single-piece calls, many times over."""
+    import threading
+    import types
+    from chromosight_amd._lib import FOCUS_DTYPE
+    from chromosight_amd.utils import detection as cid
+    rng = np.random.default_rng(11)
+    kspec = types.SimpleNamespace(km=17, kn=17)
+    cfg = {"max_perc_undetected": 50.0, "max_perc_zero": 10.0}
+    counts = np.array([9000, 0, 30000, 1500, 700, 12000])
+    shapes, max_dists = [(5000, 5000)] * 6, [1000] * 6
+    n = int(counts.sum())
+    rec = np.zeros(n, FOCUS_DTYPE)
+    rec["bin1"] = rng.integers(0, 5000, n)
+    rec["bin2"] = rec["bin1"] + rng.integers(0, 1100, n)
+    rec["inside"] = rng.random(n) < 0.95
+    rec["n_missing"] = rng.integers(0, 200, n)
+    rec["n_zero"] = rng.integers(0, 40, n)
+    rec["score"] = rng.uniform(-1, 1, n)
+    rec["n_obs"] = 289 - rec["n_missing"]
+    # reference: block by block, each below the pool's threshold in pieces of 200 records
+    want_rows, want_kept = [], []
+    at = 0
+    for c in counts:
+        kept_b = 0
+        for o in range(0, int(c), 200):
+            m = min(200, int(c) - o)
+            g, _, k = cid.accept_native(rec[at + o:at + o + m], np.array([m]), shapes[:1], max_dists[:1], kspec, cfg, inter=False,
+                                        full=True, compact=True)
+            want_rows.append(g)
+            kept_b += int(k[0])
+        want_kept.append(kept_b)
+        at += int(c)
+    want = np.concatenate(want_rows)
+    results, errors = {}, []
+
+    def worker(i):
+        try:
+            for rep in range(6):
+                g, _, k = cid.accept_native(rec, counts, shapes, max_dists, kspec, cfg, inter=False, full=True, compact=True)
+                if not (np.array_equal(g, want, equal_nan=True) and np.array_equal(k, want_kept)):
+                    errors.append((i, rep))
+            results[i] = True
+        except Exception as exc:                                 # noqa: BLE001
+            errors.append((i, repr(exc)))
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(results) == 3, errors
+
+
 def test_map_pitch_never_lands_on_a_power_of_two_stride():
     """engine.map_pitch: the row pitch the engine gives device-resident dense maps (bench.py C2)."""
     from chromosight_amd import engine

@@ -1,20 +1,15 @@
-o=gpurun_out/s11; mkdir -p $o
+o=gpurun_out/s12; mkdir -p $o
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python tools/time_rank_share.py 8 1 > $o/rs81_default.txt 2>&1
-CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1 python tools/time_rank_share.py 8 1 > $o/rs81_tf.txt 2>&1
-python tools/time_rank_share.py 1 0 > $o/rs10_default.txt 2>&1
-CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1 python tools/time_rank_share.py 1 0 > $o/rs10_tf.txt 2>&1
-CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1 CHROMOSIGHT_HIP_BLOCK_TABLE=1 python tools/time_rank_share.py 1 0 > $o/rs10_tf_table.txt 2>&1
-CHROMOSIGHT_HIP_BLOCK_TABLE=1 python tools/time_rank_share.py 1 0 > $o/rs10_table.txt 2>&1
-python tools/time_rank_share.py 8 1 > $o/rs81_default2.txt 2>&1
-CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1 python tools/time_rank_share.py 8 1 > $o/rs81_tf2.txt 2>&1
-export CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $o/kt_8_1 -o rs -- python tools/time_rank_share.py 8 1 > $o/kt_8_1.log 2>&1
-python tools/kernel_timeline.py $o/kt_8_1 > $o/rank_share_timeline_tf.txt 2>&1
-export CHROMOSIGHT_HIP_BLOCK_TABLE=1
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $o/kt_1_0 -o rs -- python tools/time_rank_share.py 1 0 > $o/kt_1_0.log 2>&1
-python tools/kernel_timeline.py $o/kt_1_0 > $o/genome_timeline_tf_table.txt 2>&1
-rm -rf $o/kt_8_1 $o/kt_1_0
-unset CHROMOSIGHT_HIP_PLAN_TILES_FIRST CHROMOSIGHT_HIP_BLOCK_TABLE
-python tools/prof_c5.py > $o/prof_c5.txt 2>&1
-tail -n 2 $o/rs*.txt; cat $o/rank_share_timeline_tf.txt
+for i in 1 2; do
+python tools/time_rank_share.py 8 1 > $o/rs81_tf$i.txt 2>&1
+CHROMOSIGHT_HIP_PLAN_CONTEND=1 python tools/time_rank_share.py 8 1 > $o/rs81_contend$i.txt 2>&1
+python tools/time_rank_share.py 1 0 > $o/rs10_tf$i.txt 2>&1
+CHROMOSIGHT_HIP_PLAN_CONTEND=1 python tools/time_rank_share.py 1 0 > $o/rs10_contend$i.txt 2>&1
+done
+python tools/time_rank_share.py 2 0 > $o/rs20_tf.txt 2>&1
+CHROMOSIGHT_HIP_PLAN_CONTEND=1 python tools/time_rank_share.py 2 0 > $o/rs20_contend.txt 2>&1
+python tools/time_rank_share.py 4 0 > $o/rs40_tf.txt 2>&1
+CHROMOSIGHT_HIP_PLAN_CONTEND=1 python tools/time_rank_share.py 4 0 > $o/rs40_contend.txt 2>&1
+CHROMOSIGHT_HIP_TIMING=1 python tools/time_rank_share.py 1 0 2>&1 | grep -E "timing" | tail -20 > $o/genome_host.txt
+CHROMOSIGHT_HIP_TIMING=1 python tools/time_rank_share.py 8 1 2>&1 | grep -E "timing" | tail -20 > $o/share_host.txt
+tail -n 2 $o/rs*.txt; cat $o/genome_host.txt $o/share_host.txt

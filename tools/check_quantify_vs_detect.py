@@ -3,9 +3,12 @@ coefficient detect reported there (the reference's pattern_detector takes both f
 detection.py:849-916), for the built-in templates and for templates resized with --win-size (pipeline.with_win_size),
 both precisions.  usage: python tools/check_quantify_vs_detect.py [seed]"""
 import copy
+import os
 import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import chromosight_amd
 import chromosight_amd.kernels as ck

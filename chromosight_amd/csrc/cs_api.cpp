@@ -260,6 +260,26 @@ int fail(cs_ctx* ctx, int code, const char* fmt, ...)
             return fail(ctx, CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
     } while (0)
 
+// Wait for a stream on the paths where the wake-up is part of a step's critical path (the candidate count and the records of the
+// batched foci entries): hipStreamSynchronize blocks on an interrupt and the thread comes back tens of microseconds after the
+// work is done; polling the stream costs a core for the few hundred microseconds of a chain and returns within a microsecond
+// or two.  After ~ 5 ms of polling (a long scan) the blocking wait takes over.  MEASURED NEUTRAL on a rank's share of 8 and on the
+// genome (medians 0.71-0.76 / 3.30-3.35 ms either way on one box: the runtime's own wait already polls before it blocks), so
+// it is opt-in: CHROMOSIGHT_HIP_SPIN_WAIT=1.
+static hipError_t wait_stream_hot(hipStream_t stream)
+{
+    static const bool spin = std::getenv("CHROMOSIGHT_HIP_SPIN_WAIT") != nullptr;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e != hipErrorNotReady) return e;
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
+
 // every entry point that launches, copies or allocates first makes the context's GPU current: a
 // process may hold contexts on several devices
 #define CS_ENTER(ctx)                                                                        \
@@ -2346,7 +2366,7 @@ int cs_detect_foci_batch_finish(cs_ctx* ctx, void* stream_, int64_t* h_n_foci)
     if (!ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "no batch is pending on this context");
     const int n_virtual = ctx->nb_pending;
     ctx->nb_pending = 0;
-    CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream_));       // also: the host tables were consumed
+    CS_HIP(ctx, wait_stream_hot((hipStream_t)stream_));            // also: the host tables were consumed
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
     for (int v = 0; v < n_virtual; ++v) h_n_foci[v] = ctx->h_blk_counts[1 + v];
@@ -2700,7 +2720,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             c_cap = (size_t)n_total + (size_t)n_total / 8;   // the list overflowed: once more with room for all
             continue;
         }
-        CS_HIP(ctx, hipStreamSynchronize(stream));
+        CS_HIP(ctx, wait_stream_hot(stream));
         laps.lap("wait: candidates");
         n_total = ctx->h_counts[0];
         if ((size_t)n_total <= c_cap) break;
@@ -2715,7 +2735,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                                           (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     laps.lap("foci chain enqueued");
-    CS_HIP(ctx, hipStreamSynchronize(stream));       // also: the host table above was consumed
+    CS_HIP(ctx, wait_stream_hot(stream));            // also: the host table above was consumed
     laps.lap("wait: records");
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");

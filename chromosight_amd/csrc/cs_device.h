@@ -50,10 +50,17 @@ struct LazyBand {
 };
 
 // the staged value of one stored pixel (contacts_map.py:531-540, preprocessing.py:296-302): balance, detrend by the law of
-// its diagonal (0: inf / NaN), >= max_val -> 1, NaN -> 0
-__device__ __forceinline__ double stage_detrend(double v, double y, double max_val)
+// its diagonal (0: inf / NaN), >= max_val -> 1, NaN -> 0.
+// The staging pass of a genome (cs_stage.hip stage_tile_kernel) multiplies by the RECIPROCAL of the law, taken once per
+// diagonal and workgroup, instead of dividing every stored pixel by it: the float64 division sequence (11 instructions, one of
+// them the quarter-rate reciprocal) was a quarter of what that kernel issues per stored pixel, and the kernel is bound by
+// issue, not by bytes.  v * (1 / y) differs from the reference's v / y (preprocessing.py:298) by at most one unit in the last
+// place of a float64 -- 1e-16 relative against tolerances of 1e-11 and wider everywhere downstream -- and keeps its special
+// cases: law 0 -> 1 / 0 = inf -> v * inf = inf (>= max_val -> 1) or NaN for v = 0 (-> 0), as inf and NaN of the division.
+// Whatever recomputes a staged pixel (the lazily evaluated bands) uses THIS function, so that the two stay bit-identical.
+__device__ __forceinline__ double stage_detrend_rcp(double v, double inv_y, double max_val)
 {
-    double out = v / y;                                    // law 0 (empty diagonal) -> inf / NaN, as preprocessing.py:298
+    double out = v * inv_y;
     if (max_val > 0.0 && out >= max_val) out = 1.0;        // :301-302
     return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
 }
@@ -62,7 +69,7 @@ __device__ __forceinline__ double lazy_stored_value(const LazyBand& L, long long
 {
     const double x = L.data_is_f64 ? reinterpret_cast<const double*>(L.data)[k] : (double)reinterpret_cast<const float*>(L.data)[k];
     const int d = q - p;
-    return stage_detrend((x * L.weight[L.row0 + p]) * L.weight[L.row0 + q], d < L.n_diags ? L.law[d] : 0.0, L.max_val);
+    return stage_detrend_rcp((x * L.weight[L.row0 + p]) * L.weight[L.row0 + q], 1.0 / (d < L.n_diags ? L.law[d] : 0.0), L.max_val);
 }
 
 // pixel (p, q) of the block, 0 <= p <= q < n, on a diagonal the view keeps

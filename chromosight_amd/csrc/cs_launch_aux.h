@@ -312,11 +312,11 @@ __device__ __forceinline__ void lazy_gather_window_sq(const CorrArgs<double>& A,
             const long long idx = base + rel;
             const int c = indices[idx] - (int)row0;
             if (c <= ch) {
-                // lazy_stored_value / stage_detrend (cs_device.h), on the hoisted fields
+                // lazy_stored_value / stage_detrend_rcp (cs_device.h), on the hoisted fields
                 const int p = p0 + ki, d = c - p;
                 const double x = is_f64 ? data64[idx] : (double)data32[idx];
                 const double y = d < n_diags ? law[d] : 0.0;
-                double out = ((x * weight[row0 + p]) * weight[row0 + c]) / y;
+                double out = ((x * weight[row0 + p]) * weight[row0 + c]) * (1.0 / y);        // stage_detrend_rcp (cs_device.h)
                 if (max_val > 0.0 && out >= max_val) out = 1.0;
                 win[ki * K + (c - q0)] = out != out ? 0.0 : out;
             }

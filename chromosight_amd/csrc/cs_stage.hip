@@ -35,7 +35,7 @@ static_assert(sizeof(LazyBand) <= 128, "CS_LAZY_BAND_BYTES of include/chromosigh
 constexpr int kStageThreads = 512;
 constexpr int kStageWaves = kStageThreads / 64;
 
-// (stage_detrend: cs_device.h -- the lazily evaluated float64 bands recompute the same value)
+// (stage_detrend_rcp: cs_device.h -- the lazily evaluated float64 bands recompute the same value)
 
 // Latency, not bandwidth, bounded the first version (2.1 TB/s): per row a wave waited for the row pointers, then for the
 // pixels they delimit, then for the gathered column weights -- three dependent round trips for ~270 stored pixels.  Now
@@ -292,7 +292,9 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
         const long long r0 = B.row0 + G.row_begin;
         const int n_w = (int)min((long long)(G.row_end - G.row_begin) + B.keep, last_col - r0 + 1);
         __syncthreads();
-        for (int d = tid; d < B.n_diags; d += kStageThreads) l_law[d] = B.law[d];
+        // (the RECIPROCAL of the law: one division per diagonal and group instead of one per stored pixel, cs_device.h
+        // stage_detrend_rcp)
+        for (int d = tid; d < B.n_diags; d += kStageThreads) l_law[d] = 1.0 / B.law[d];
         for (int t = tid; t < n_w; t += kStageThreads) l_w[t] = weight[r0 + t];
         const int n_mine = (G.row_end - G.row_begin - wv + kStageWaves - 1) / kStageWaves;
         long long my_b = 0, my_e = 0;
@@ -320,6 +322,8 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
         };
         if (n_mine > 0) request(0);
         const int ld = (int)B.ld;
+        const int n_diags_m1 = max(B.n_diags - 1, 0);
+        const double kInf = __longlong_as_double(0x7ff0000000000000ll);
         const int n_pieces = (ld + kStageRowMax - 1) / kStageRowMax;
         const int piece_len = ((ld + n_pieces - 1) / n_pieces + 15) & ~15;
         for (int i = 0; i < n_mine; ++i) {
@@ -341,8 +345,10 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
                 const bool ok = cn[u] != 0x7fffffff;
                 const int rel = ok ? cn[u] - c_base : 0;                 // column - r0
                 const int d = rel - c_r;
-                const double wc = ok ? l_w[rel] : 0.0;
-                v[u] = stage_detrend(((double)xn[u] * wr) * wc, (ok && d < B.n_diags) ? l_law[d] : 0.0, max_val);
+                // (both LDS reads unconditional, from clamped indices: behind a condition each became an exec-mask branch)
+                const double wc = l_w[rel];
+                const double iy = l_law[min(max(d, 0), n_diags_m1)];
+                v[u] = stage_detrend_rcp(((double)xn[u] * wr) * wc, (ok && d < B.n_diags) ? iy : kInf, max_val);
                 slot[u] = ok ? rel - c_x0 : -1;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
                             if (in) {
                                 const int rel = c[u] - c_base;
                                 const int d = rel - c_r;
-                                l_row[rel - c_x0 - s0] = stage_detrend(((double)x[u] * wr) * l_w[rel], d < B.n_diags ? l_law[d] : 0.0, max_val);
+                                l_row[rel - c_x0 - s0] = stage_detrend_rcp(((double)x[u] * wr) * l_w[rel], d < B.n_diags ? l_law[d] : kInf, max_val);
                             }
                             more = more && (m == ~0ull);                // a lane beyond the piece (or the row): this piece is complete
                         }

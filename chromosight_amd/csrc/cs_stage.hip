@@ -101,6 +101,9 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
             const double wr = l_w[rl - G.row_begin];
             const long long b = row_b(i), e = row_e(i);
             const long long c_hi = min(r + (long long)B.keep, last_col);
+            // (columns relative to the group's first row: 32-bit tests and LDS indices; the sentinel of a lane beyond the row
+            // stays above every column)
+            const int c_base = (int)r0, c_hi_rel = (int)(c_hi - r0), c_r = (int)(r - r0);
             int c[kStageUnroll];
             TV x[kStageUnroll];
 #pragma unroll
@@ -113,12 +116,13 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
             for (long long k0 = b;;) {
 #pragma unroll
                 for (int u = 0; u < kStageUnroll; ++u) {
-                    const bool in = (long long)c[u] <= c_hi;
+                    const int rel = c[u] - c_base;
+                    const bool in = rel <= c_hi_rel;
                     n_in += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
-                    const double wc = in ? l_w[(int)((long long)c[u] - r0)] : 0.0;
+                    const double wc = l_w[in ? rel : 0];              // (unconditional read: behind a condition it is an exec-mask branch)
                     const double v = ((double)x[u] * wr) * wc;        // csr_value: cooler's matrix(balance=True)
                     if (in && v > 0.0) {                              // also drops NaN (preprocessing.py:188)
-                        const int d = (int)((long long)c[u] - r);
+                        const int d = rel - c_r;
                         atomicAdd(&l_sum[d], v);
                         atomicAdd(&l_cnt[d], 1u);
                     }

@@ -342,10 +342,25 @@ def pmc_traffic(args, wl):
     measured calibration + WRITE_SIZE).  Counters cannot be read from inside the timed process, so
     this is the figure of the profiled run of the same command; None when no such record exists."""
     import glob
-    key = {"c2": "c2_4096_f32", "c3k": "c3k_band_50000x234", "c4p": "c4p_band_200000x1001"}.get(args.workload)
-    if key is None or (args.workload == "c2" and args.size not in (None, 4096)) or args.precision != "f32":
-        return None, "no PMC record for this workload"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
+    wl = wl if isinstance(wl, str) else args.workload           # (callers pass the workload's name or the Workload itself)
+    if wl == "c3" and args.precision == "f32":
+        # the whole step: law pass + finish + tiler + mask tables (c3_helper_kernels) + the tile kernel (its c3k record)
+        for path in reversed(files):
+            try:
+                rec = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            helpers, tile = rec.get("c3_helper_kernels", {}), rec.get("c3k_band_50000x234", {})
+            parts = [helpers.get(k, {}).get("hbm_bytes") for k in ("stage_law_kernel", "stage_finish_kernel", "stage_tile_kernel",
+                                                                   "mask_prep_kernel")] + [tile.get("hbm_bytes_per_dispatch")]
+            if all(p is not None for p in parts):
+                return int(sum(parts)), (f"{os.path.basename(path)}: sum over the step's kernels (law pass, finish, tiler, mask tables: "
+                                         "c3_helper_kernels; tile kernel: c3k record) of FETCH_SIZE x calibration + WRITE_SIZE")
+        return None, "no PMC record"
+    key = {"c2": "c2_4096_f32", "c3k": "c3k_band_50000x234", "c4p": "c4p_band_200000x1001"}.get(wl)
+    if key is None or (wl == "c2" and args.size not in (None, 4096)) or args.precision != "f32":
+        return None, "no PMC record for this workload"
     for path in reversed(files):
         try:
             rec = json.load(open(path)).get(key, {})
@@ -706,8 +721,8 @@ def main():
             steps3 = 20
             el3, ms3 = time_steps(dev, w3.step, full_sync, steps3, 3, dist, local_rank)
             id3 = int(dev.lib.cs_last_kernel(dev.ctx))
-            roof3 = roofline_of(w3, ms3, id3, args.precision, None,
-                                "per-kernel PMC bytes of the profiled run: profiles/r04_pmc_counters.json c3_helper_kernels")
+            t3, t3_note = pmc_traffic(argparse.Namespace(workload="c3", size=None, precision=args.precision), "c3")
+            roof3 = roofline_of(w3, ms3, id3, args.precision, t3, t3_note)
             roof3["note"] = ("whole step (HIP events around stage_law + stage_finish + stage_tile + mask tables + tile kernel): 714 "
                              f"flop/pixel x {w3.pixels} pixels / {ms3:.4f} ms against the FP32 peak; bytes view: 2 passes over the "
                              f"stored pixels (8 B each) + row pointers + 4 B per pixel written = {w3.bytes_per_pixel:.1f} B/pixel")

@@ -103,6 +103,21 @@ def test_batched_staging_matches_reference_and_the_block_by_block_path(golden):
             assert np.abs(download_block(dcool, blk) - ref).max() < 1e-11, (ci, pname)
 
 
+def test_inter_blocks_staged_together_equal_one_by_one(golden):
+    """DeviceCool.stage_inter_many (the medians of all blocks from one native call, cs_csr_median_many: two synchronisations in
+    all) == stage_inter block by block (cs_csr_median each): the same maps bit for bit; a pair whose block stores nothing gets
+    the NaN median and an all-zero map either way."""
+    dcool = pipeline.DeviceCool(golden("yeast_cool"))
+    pairs = [(0, 1), (2, 7), (3, 15), (0, 16), (10, 11), (5, 6), (1, 2)]
+    many = dcool.stage_inter_many(pairs)
+    for (ca, cb), blk in zip(pairs, many):
+        one = dcool.stage_inter(ca, cb, resident=True)
+        a, b = download_block(dcool, blk), download_block(dcool, one)
+        assert blk.shape == one.shape and blk.inter and a.shape == b.shape
+        assert np.array_equal(a, b), (ca, cb)
+        assert np.count_nonzero(a) > 0
+
+
 def test_batched_staging_with_a_long_distance_law():
     """Laws of 3000+ diagonals: the law pass then needs more than the default 64 KB of dynamic LDS (only the
     tiler had asked for it) -- cs_stage_blocks == the block-by-block kernels up to the summation order of the law."""

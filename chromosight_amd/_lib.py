@@ -138,7 +138,7 @@ class CsCall(C.Structure):
 
 
 CALL_STAGE_BLOCKS, CALL_EVENT_RECORD, CALL_STREAM_WAIT_EVENT, CALL_DETECT_FOCI_BLOCKS, CALL_DETECT_FOCI_BATCH_TEMPLATES, \
-    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_WAIT_TILE_LAUNCH = 1, 2, 3, 4, 5, 6, 7, 8
+    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_WAIT_TILE_LAUNCH, CALL_STREAM_DELAY = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 # While a list is installed here, the entries named in _CAPTURED append (name, arguments) to it AFTER running as usual:
 # chromosight_amd/plan.py turns the calls of one genome step into a cs_run_calls list.
@@ -173,6 +173,7 @@ _PROTOTYPES = {
     "cs_event_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cs_event_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_stream_delay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "cs_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "cs_normxcorr2": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                 C.POINTER(CsNormxcorr2Params), C.POINTER(CsMatrix), C.POINTER(CsMatrix)]),

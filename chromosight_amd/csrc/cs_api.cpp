@@ -221,6 +221,13 @@ private:
     size_t threads_ = 0;
 };
 
+// cs_stream_delay: one wave that sleeps until the constant-rate counter (100 MHz) has advanced by `ticks`
+__global__ void cs_delay_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // bumped by cs_detect_foci_blocks once its tile kernels are launched: a lane of cs_run_calls can hold its own launch chain back
 // until then (CS_CALL_WAIT_TILE_LAUNCH), so that the persistent tile workgroups take their slots on an empty device
 std::atomic<long long> g_tile_launch_seq{0};
@@ -1312,6 +1319,15 @@ int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event)
     if (!event) return CS_ERR_INVALID;
     CS_ENTER(ctx);
     CS_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return CS_OK;
+}
+
+int cs_stream_delay(cs_ctx* ctx, void* stream, int32_t microseconds)
+{
+    CS_ENTER(ctx);
+    if (microseconds <= 0) return CS_OK;
+    hipLaunchKernelGGL(cs_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)std::min(microseconds, 1000) * 100);
+    CS_HIP(ctx, hipGetLastError());
     return CS_OK;
 }
 
@@ -2953,6 +2969,8 @@ int dispatch_call(cs_call& c)
             return cs_detect_foci_batch_finish((cs_ctx*)p[0], p[1], (int64_t*)p[2]);
         case CS_CALL_WAIT_TILE_LAUNCH:
             return CS_OK;                      // (the wait itself is in run_lane: it needs the list's state)
+        case CS_CALL_STREAM_DELAY:
+            return cs_stream_delay((cs_ctx*)p[0], p[1], (int32_t)i[0]);
         default:
             return CS_ERR_INVALID;
     }

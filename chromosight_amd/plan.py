@@ -17,7 +17,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import (CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_DETECT_FOCI_BATCH_TEMPLATES, CALL_DETECT_FOCI_BLOCKS,
-                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_WAIT_EVENT, CALL_WAIT_TILE_LAUNCH, FOCUS_DTYPE, CsCall, raw_arg)
+                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_DELAY, CALL_STREAM_WAIT_EVENT, CALL_WAIT_TILE_LAUNCH, FOCUS_DTYPE,
+                   CsCall, raw_arg)
 
 # argument slots of every entry: 'p' pointer, 'i' integer, 'd' double, in the order of the C prototype
 _SLOTS = {
@@ -118,7 +119,13 @@ class StepPlan:
         tiles_first = bool(os.environ.get("CHROMOSIGHT_HIP_PLAN_TILES_FIRST"))
         self.done_b = dev.new_event()
         stream_a = raw_arg(blocks[0][1])
-        n_calls = 11 if tiles_first else 10
+        # The two chains wait for the same event (the staging) and then race for the workgroup slots: when the 1-D chain's run
+        # kernel is resident first, the persistent tile workgroups start late on the CUs it holds (three of its workgroups fill
+        # a CU's LDS) and -- their tile ranges are static -- finish late: a share's step takes 0.75 instead of 0.6 ms, step by
+        # step at random (profiles/r04b_step_modes.txt).  A sleeping wave at the head of the 1-D chain (cs_stream_delay) lets
+        # the tile kernels go first, every time; the 1-D chain has the slack (it ends 70-100 us before the 2-D chain's tail).
+        delay_us = int(os.environ.get("CHROMOSIGHT_HIP_PLAN_DELAY_US", "45"))
+        n_calls = (11 if tiles_first else 10) + (1 if delay_us > 0 else 0)
         calls = (CsCall * n_calls)()
         k = 0
 
@@ -129,8 +136,10 @@ class StepPlan:
         _fill(nxt(), *_SLOTS["cs_stage_blocks"], stage[0], 0)
         _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)
         _fill(nxt(), *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=1)
+        if delay_us > 0:
+            _fill(nxt(), CALL_STREAM_DELAY, "ppi", (ctx_b, stream_b, delay_us), 1)
         if tiles_first:
-            _fill(nxt(), CALL_WAIT_TILE_LAUNCH, "i", (7,), 1)            # (call 7 below: cs_detect_foci_blocks)
+            _fill(nxt(), CALL_WAIT_TILE_LAUNCH, "i", (7 + (1 if delay_us > 0 else 0),), 1)    # (the cs_detect_foci_blocks call below)
         b = list(batch[0])
         b[8], b[9] = self.rec1.ctypes.data, self.cap1
         b[7][0].reserved = 1                                  # asynchronous form: return once the chain is enqueued
@@ -143,7 +152,7 @@ class StepPlan:
             _fill(nxt(), *_SLOTS["cs_stream_wait_event"], (ctx_a, stream_a, self.done_b), 0, after=i_done_b)
         a = list(blocks[0])
         a[8], a[9] = self.rec2.ctypes.data, self.cap2
-        assert not tiles_first or k == 7
+        assert not tiles_first or k == 7 + (1 if delay_us > 0 else 0)
         if tiles_first:
             a[6][0].exclusive = 1                             # ONE persistent launch for the tiles of all blocks
         _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], a, 0)

@@ -99,6 +99,11 @@ int cs_event_record(cs_ctx* ctx, void* event, void* stream);
 /* work enqueued on `stream` after this call starts only when `event` (recorded on any stream of the same GPU, by any
  * context) has fired: ordering between streams without a host synchronisation */
 int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event);
+/* Keeps `stream` busy for about `microseconds` (at most 1000) with one sleeping wave.  A launch chain that would otherwise race
+ * a persistent launch of another stream for the workgroup slots -- both waiting for the same event -- is held back by it, so
+ * that the persistent workgroups are resident first (chromosight_amd/plan.py: the 1-D pattern's chain behind the 2-D pattern's
+ * tile kernels; a rank's step otherwise takes 0.6 or 0.75 ms depending on which chain wins). */
+int cs_stream_delay(cs_ctx* ctx, void* stream, int32_t microseconds);
 /* synchronises on `stop`, then returns the elapsed milliseconds between the two events */
 int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms);
 
@@ -436,7 +441,8 @@ enum { CS_CALL_STAGE_BLOCKS = 1, CS_CALL_EVENT_RECORD = 2, CS_CALL_STREAM_WAIT_E
        /* no entry of its own: the lane waits until call number i[0] of the list (a CS_CALL_DETECT_FOCI_BLOCKS) has LAUNCHED its
         * tile kernels, or has returned -- a launch chain enqueued only then finds the persistent tile workgroups in their
         * slots and runs in what they leave, instead of taking slots first and making some of them start late */
-       CS_CALL_WAIT_TILE_LAUNCH = 8 };
+       CS_CALL_WAIT_TILE_LAUNCH = 8,
+       CS_CALL_STREAM_DELAY = 9 /* cs_stream_delay(p[0], p[1], i[0]) */ };
 typedef struct {
     int32_t fn;        /* CS_CALL_* */
     int32_t lane;      /* 0: the calling thread */

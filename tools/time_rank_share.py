@@ -30,6 +30,8 @@ if not all(p.ok for p in plans.values()) or not plans:
     print("no step plan:", [p.why for p in plans.values()])
 print(f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (median {np.median(ts[4:]):.3f}, min {min(ts):.3f}); "
       f"patterns {[len(r) for r in rec]}")
+if os.environ.get("STEPS"):
+    print("steps (ms):", " ".join(f"{t:.3f}" for t in ts))
 if os.environ.get("PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile()

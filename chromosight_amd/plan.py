@@ -153,8 +153,12 @@ class StepPlan:
         a = list(blocks[0])
         a[8], a[9] = self.rec2.ctypes.data, self.cap2
         assert not tiles_first or k == 7 + (1 if delay_us > 0 else 0)
-        if tiles_first:
-            a[6][0].exclusive = 1                             # ONE persistent launch for the tiles of all blocks
+        if (tiles_first or delay_us > 0) and not os.environ.get("CHROMOSIGHT_HIP_PLAN_NO_TABLE"):
+            # ONE persistent launch for the tiles of all blocks (cs_foci_params.exclusive): with the 1-D chain held back behind
+            # it the persistent workgroups are not displaced, and one launch beats 23 over three streams -- the 23-block genome
+            # 3.25 -> 3.02 ms, a share of 2: 1.89 -> 1.69, of 4: 1.11 -> 0.96 (profiles/r04b_step_modes.txt).  Without the
+            # delay the same launch was the slower choice (round 3: 5.6 against 4.4 ms).
+            a[7][0].exclusive = 1
         _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], a, 0)
         self._accept(nxt(), self.rec2, self.counts2, self.acc2, cfg2, 0)
         _fill(nxt(), CALL_DETECT_FOCI_BATCH_FINISH, "ppp", (ctx_b, stream_b, self.counts1), 1)

@@ -499,9 +499,14 @@ static void launch_rescore_batch(const CorrArgs<double>* h_tab, int n_blocks, lo
 // 400 000 pixels; the wave-per-pixel kernel 714).  Workgroups that straddle two sub-matrices or whose entries are
 // not such a run take the direct route, a wave that straddles sub-matrices one after the other.
 constexpr int kRunWeights = 3 * 17 * 17;               // the three weight sets of a template of up to 289 entries
+constexpr int kRunStageMax = 24;                       // pieces of 8 rows x 8 diagonals a wave stages at once (run17: 90 pieces per tile)
 
 // dynamic LDS: tile (tile_cap doubles), then the weights, then the row / column flags
-__global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
+// ONLY17: nothing but the run17 route (and the direct one as its fall-back) is compiled in -- what the 1-D patterns of a genome
+// take.  The general instance carries every route (runtime sizes, 15 x 15, edge and interior forms) and with them 241 vector
+// registers: two workgroups per CU where the LDS would hold three, and the kernel is bound by its workgroups' latency.
+template <bool ONLY17>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONLY17 ? 3 : 1, ONLY17 ? 3 : 8))) void rescore_run_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
                                                                 const int* __restrict__ rows, const int* __restrict__ cols,
                                                                 long long n_px, double* __restrict__ out_corr, int tile_cap,
                                                                 int no_run17, bool fast_windows)
@@ -565,7 +570,8 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
         const int D0 = d_lo - kw - (km - 1 - kh), DN = (d_hi - d_lo) + (kn - 1) + (km - 1) + 1;
         const int C0 = P0 + D0, CN = RN + DN;                  // columns the tile can reach
         if (tile_cap > 0 && (long long)RN * DN <= tile_cap && RN <= 512 && CN <= 1024 && 3 * km * kn <= kRunWeights) {
-            for (int idx = tid; idx < 3 * km * kn; idx += 256) wl[idx] = A.w[idx];
+            if constexpr (!ONLY17)
+                for (int idx = tid; idx < 3 * km * kn; idx += 256) wl[idx] = A.w[idx];         // (run17: weights through the scalar unit)
             const bool bins = A.mask_mode == 1;
             for (int idx = tid; idx < RN; idx += 256) {
                 const int p = P0 + idx;
@@ -588,7 +594,26 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                 // 8 rows x 8 diagonals per wave and step: 64-byte pieces of band rows in, 8 consecutive doubles of 8 tile
                 // rows out
                 const int n_dc = (DN + 7) >> 3, n_ch = ((RN + 7) >> 3) * n_dc;
-                if (fast_windows) {
+                if (fast_windows && n_ch <= 4 * kRunStageMax) {
+                    // every piece of the wave requested before the first one is stored (a tile is 90 pieces, 23 per wave: in
+                    // batches of four the wave waited six times for a round trip)
+                    double got[kRunStageMax];
+#pragma unroll
+                    for (int k = 0; k < kRunStageMax; ++k) {
+                        const int ch = (tid >> 6) + 4 * k;
+                        const int cr = ch / n_dc, cd = ch - cr * n_dc;
+                        const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
+                        const int p = P0 + rr;
+                        got[k] = (ch < n_ch && rr < RN && dd < DN) ? S.at(p, p + D0 + dd) : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kRunStageMax; ++k) {
+                        const int ch = (tid >> 6) + 4 * k;
+                        const int cr = ch / n_dc, cd = ch - cr * n_dc;
+                        const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
+                        if (ch < n_ch && rr < RN && dd < DN) tile[dd * kRunRP + rr] = got[k];
+                    }
+                } else if (ONLY17 || fast_windows) {
 #pragma unroll 4
                     for (int ch = tid >> 6; ch < n_ch; ch += 4) {
                         const int cr = ch / n_dc, cd = ch - cr * n_dc;
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                         const int p = P0 + rr;
                         if (rr < RN && dd < DN) tile[dd * kRunRP + rr] = S.at(p, p + D0 + dd);
                     }
-                } else {
+                } else if constexpr (!ONLY17) {
                     for (int ch = tid >> 6; ch < n_ch; ch += 4) {
                         const int cr = ch / n_dc, cd = ch - cr * n_dc;
                         const int rr = 8 * cr + (lane >> 3), dd = 8 * cd + (lane & 7);
@@ -604,6 +629,8 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                         if (rr < RN && dd < DN) tile[dd * kRunRP + rr] = load_signal(A, p, p + D0 + dd);
                     }
                 }
+            } else if constexpr (ONLY17) {
+                // (not a run the transposed tile holds: the direct route below)
             } else if (fast_windows) {
 #pragma unroll 4
                 for (int idx = tid; idx < RN * DN; idx += 256) {
@@ -624,6 +651,8 @@ __global__ __launch_bounds__(256) void rescore_run_batch_kernel(const CorrArgs<d
                     if (interior) rescore_run17<false>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
                     else rescore_run17<true>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
                 }
+            } else if constexpr (ONLY17) {
+                if (mine) rescore_pixel_lane(A, oi, oj, r, nobs);
             } else if (mine && lean && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && interior && kn == 15) rescore_pixel_lane_lds_interior<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && kn == 17) rescore_pixel_lane_lds_interior<17, true>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
@@ -926,7 +955,8 @@ __global__ __launch_bounds__(kSmallThreads) void gather_foci_batch_kernel(const 
 // may be nullptr (beyond the caller's capacity) or page-locked host memory
 __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, int inter, int row, int col, int fsize, double score,
                                                      double nobs, FocusRec* rec_out, double* win_out, int lane,
-                                                     double* lazy_win = nullptr, bool fast_windows = false)
+                                                     double* lazy_win = nullptr, bool fast_windows = false,
+                                                     int have_p0 = INT_MIN, int have_q0 = INT_MIN)
 {
     const int km = A.km, kn = A.kn, kk = km * kn;
     const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
@@ -943,7 +973,10 @@ __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, 
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // a lazily evaluated band: the window's pixels gathered by the wave first (cs_launch_aux.h lazy_gather_window)
     const bool gathered = lazy_win && inside && A.sig.layout == 2 && kk <= kLazyWinMax;          // wave-uniform
-    if (gathered) {
+    // (have_p0, have_q0: lazy_win already holds the window with this top left pixel -- the exact evaluation of the same record
+    // gathered it a moment ago, focus_records_lazy17_kernel)
+    const bool have = gathered && have_p0 == high - pad_r && have_q0 == left - pad_c;
+    if (gathered && !have) {
         if (fast_windows && km == 17 && kn == 17) lazy_gather_window_sq<17>(A, high - pad_r, left - pad_c, lane, lazy_win);
         else lazy_gather_window(A, high - pad_r, left - pad_c, lane, lazy_win);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1027,6 +1060,65 @@ __global__ __launch_bounds__(kThreads) void window_stats_batch_kernel(const Corr
     const int kk = A.km * A.kn;
     window_stats_pattern(A, inter, rows[t], cols[t], focus_size[t], score[t], nobs[t], t < rec_cap ? rec + t : nullptr,
                          (windows && t < win_cap) ? windows + t * kk : nullptr, lane, lazy_win[threadIdx.x >> 6], fast_windows);
+}
+
+// The records of the foci in ONE pass (detect mode, every sub-matrix in the detection configuration with a 17 x 17 template on a
+// lazily evaluated band): exact coefficient AND window statistics from one gathered window -- they read the same 17 x 17
+// pixels -- instead of rescore_batch_kernel followed by window_stats_batch_kernel, each with its own gather.  Grid-stride over
+// the foci: their number is known on the device only, and the two kernels used to be launched with one wave per POSSIBLE
+// focus (candidates / min_size: 600 000 waves for the 1-D patterns of a genome, 56 000 of them with work -- the empty
+// workgroups alone cost 2 x 140 us at the end of a genome step).
+__global__ __launch_bounds__(256) void focus_records_lazy17_kernel(
+    const CorrArgs<double>* __restrict__ tab, int inter, const int* __restrict__ blk, const int* __restrict__ rows, const int* __restrict__ cols,
+    const int* __restrict__ focus_size, const long long* __restrict__ n_ptr, FocusRec* __restrict__ rec, double* __restrict__ windows,
+    long long win_cap, long long rec_cap)
+{
+    __shared__ double lazy_win[4][kLazyWinMax];
+    const long long n = *n_ptr;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long t = (long long)blockIdx.x * 4 + wv; t < n; t += stride) {
+        const CorrArgs<double>& A = tab[blk[t]];
+        const int oi = rows[t], oj = cols[t];
+        double r = 0.0, nobs = A.ks.n;
+        double* win = lazy_win[wv];
+        const bool inside = (oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns);                  // wave-uniform
+        if (inside) {
+            lazy_gather_window_sq<17>(A, oi - 8, oj - 8, lane, win);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            rescore_pixel_sq<17>(A, oi, oj, lane, r, nobs, win);
+        }
+        window_stats_pattern(A, inter, oi, oj, focus_size[t], r, nobs, t < rec_cap ? rec + t : nullptr,
+                             (windows && t < win_cap) ? windows + t * (17 * 17) : nullptr, lane, win, true, inside ? oi - 8 : INT_MIN, inside ? oj - 8 : INT_MIN);
+        // (the next record's gather overwrites the window: every lane is done reading it)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// exact coefficients + records of the foci of a batch (f_* arrays, *d_total of them, at most max_foci)
+static void launch_focus_records(const CorrArgs<double>* h_tab, int n_blocks, long long max_foci, hipStream_t stream,
+                                 const CorrArgs<double>* tab, int inter, const int* f_blk, const int* f_rows, const int* f_cols,
+                                 const int* f_size, double* f_score, double* f_nobs, const long long* d_total, FocusRec* rec,
+                                 double* windows, long long win_cap, long long rec_cap)
+{
+    bool lazy17 = fast_windows_on() && h_tab != nullptr && n_blocks > 0 && !getenv("CHROMOSIGHT_HIP_NO_FUSED_RECORDS");
+    for (int b = 0; lazy17 && b < n_blocks; ++b) {
+        const CorrArgs<double>& A = h_tab[b];
+        lazy17 = A.km == 17 && A.kn == 17 && A.mask_mode == 1 && A.sym_upper && A.full && A.max_dist >= 0 && A.sig.layout == 2;
+    }
+    if (lazy17) {
+        const unsigned grid = (unsigned)std::min<long long>((max_foci + 3) / 4, 4096);
+        hipLaunchKernelGGL(focus_records_lazy17_kernel, dim3(grid), dim3(256), 0, stream, tab, inter, f_blk, f_rows, f_cols, f_size, d_total, rec,
+                           windows, win_cap, rec_cap);
+        return;
+    }
+    launch_rescore_batch(h_tab, n_blocks, max_foci, stream, tab, f_blk, f_rows, f_cols, max_foci, d_total, f_score, f_nobs);
+    hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk, f_rows,
+                       f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap, fast_windows_on());
 }
 
 // quantify mode over several sub-matrices (cs_quantify_blocks): entry t is pixel (rows[t], cols[t]) of sub-matrix blk[t];
@@ -1465,8 +1557,19 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
             int tile_cap = getenv("CHROMOSIGHT_HIP_RUN_NO_LDS") ? 0 : (256 / w_min + 1 + 17) * (w_max + 33);
             if ((size_t)tile_cap * 8 > 48 * 1024) tile_cap = 48 * 1024 / 8;        // wider scans: the direct route where needed
             const size_t smem = (size_t)tile_cap * 8 + kRunWeights * 8 + 512 + 1024;
-            hipLaunchKernelGGL(rescore_run_batch_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), smem, stream, tab, blk, rows,
-                               cols, n_total, vals, tile_cap, getenv("CHROMOSIGHT_HIP_NO_RUN17") ? 1 : 0, fast_windows_on());
+            const bool no_run17 = getenv("CHROMOSIGHT_HIP_NO_RUN17") != nullptr;
+            bool only17 = fast_windows_on() && !no_run17 && w_max <= 2 && tile_cap > 0 && !getenv("CHROMOSIGHT_HIP_RUN_GENERAL");
+            for (int k = 0; only17 && k < n_blocks; ++k) {
+                const CorrArgs<double>& A = h_tab[k];
+                only17 = A.km == 17 && A.kn == 17 && A.mask_mode == 1 && A.sym_upper && A.full && A.max_dist >= 0;
+            }
+            const dim3 run_grid((unsigned)((n_total + 255) / 256));
+            if (only17)
+                hipLaunchKernelGGL(rescore_run_batch_kernel<true>, run_grid, dim3(256), smem, stream, tab, blk, rows, cols, n_total, vals,
+                                   tile_cap, 0, true);
+            else
+                hipLaunchKernelGGL(rescore_run_batch_kernel<false>, run_grid, dim3(256), smem, stream, tab, blk, rows, cols, n_total, vals,
+                                   tile_cap, no_run17 ? 1 : 0, fast_windows_on());
         }
     }
     // every sub-matrix scans the diagonals 0 and 1 (borders, hairpins: max_dist = 0 in the config): the foci are runs
@@ -1495,9 +1598,8 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
     }
     if (n_total > 0) {
         const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
-        launch_rescore_batch(h_tab, n_blocks, max_foci, stream, tab, f_blk, f_rows, f_cols, max_foci, d_total, f_score, f_nobs);
-        hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk,
-                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap, fast_windows_on());
+        launch_focus_records(h_tab, n_blocks, max_foci, stream, tab, inter, f_blk, f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec,
+                             windows, win_cap, rec_cap);
     }
     return (int)hipGetLastError();
 }
@@ -1616,9 +1718,8 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
                        f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
     if (n_total > 0) {
         const long long max_foci = std::max<long long>(1, n_total / std::max(min_size, 1));
-        launch_rescore_batch(h_tab, n_blocks, max_foci, stream, tab, f_blk, f_rows, f_cols, max_foci, d_total, f_score, f_nobs);
-        hipLaunchKernelGGL(window_stats_batch_kernel, dim3((unsigned)((max_foci + 3) / 4)), dim3(kThreads), 0, stream, tab, inter, f_blk,
-                           f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap, fast_windows_on());
+        launch_focus_records(h_tab, n_blocks, max_foci, stream, tab, inter, f_blk, f_rows, f_cols, f_size, f_score, f_nobs, d_total, rec,
+                             windows, win_cap, rec_cap);
     }
     return (int)hipGetLastError();
 }

@@ -468,6 +468,10 @@ class Device:
             self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))
         return s.value
 
+    def stream_delay(self, stream, microseconds):
+        """cs_stream_delay: one sleeping wave keeps `stream` busy for about that long."""
+        self._check(self.lib.cs_stream_delay(self.ctx, stream, int(microseconds)))
+
     def new_event(self):
         e = C.c_void_p()
         self._check(self.lib.cs_event_create(self.ctx, C.byref(e)))

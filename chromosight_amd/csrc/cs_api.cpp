@@ -98,6 +98,8 @@ struct cs_ctx {
     int last_kernel = 0;     // cs_last_kernel()
     int range_check = 0;     // cs_ctx_set_range_check()
     bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
+    long long cand_hint = 0, cand_hint_pixels = 0;   // cs_detect_foci_blocks: candidates, pixels and blocks of the previous call
+    int cand_hint_blocks = 0;
     bool allow_lazy = false; // the entry in progress takes CS_LAYOUT_BAND_LAZY signals (check_matrix)
     long long uploads = 0;   // template weights / fragments / rim tables copied to the device so far (upload_weights, ensure_wfrag)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
@@ -2467,8 +2469,27 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     const double margin = std::max(foci[0].rescore_margin, 1e-4);
     const double thr = foci[0].pearson - margin;
     size_t c_cap = std::max<size_t>(1 << 16, (size_t)(pixels / 256));
+    // One synchronisation per call when the PREVIOUS call on this context scanned the same layout (a run's steps, an iterated
+    // template's passes): the candidate list is then given room for 1.25 x that call's candidates -- not the 8 x of the
+    // a-priori capacity, whose sort and launches had made the single-synchronisation chain the slower one -- and the chain
+    // behind the tile kernels is enqueued without waiting for the count; a list that outgrows its room shows in the count at
+    // the end and the call repeats with room, as before.  Nothing but a SIZE is carried over.  MEASURED NEUTRAL TO SLOWER (a share
+    // of 8: 0.574-0.595 against 0.565-0.602 ms, the genome 2.97 against 2.91: the bounded chain's sentinels, its launches at
+    // capacity and the one more key bit in the sort cost what the round trip did), so it is opt-in: CHROMOSIGHT_HIP_ADAPTIVE_SYNC=1.
+    const bool adaptive = ctx->cand_hint > 0 && ctx->cand_hint_pixels == (long long)pixels && ctx->cand_hint_blocks == n_blocks &&
+                          std::getenv("CHROMOSIGHT_HIP_ADAPTIVE_SYNC") && !std::getenv("CHROMOSIGHT_HIP_ONE_SYNC");
+    if (adaptive) c_cap = std::max<size_t>(4096, (size_t)ctx->cand_hint + (size_t)ctx->cand_hint / 4 + 1024);
+    struct HintUpdate {                     // every successful exit records what this call saw
+        cs_ctx* c;
+        long long* n;
+        long long px;
+        int nb;
+        ~HintUpdate() { c->cand_hint = *n; c->cand_hint_pixels = px; c->cand_hint_blocks = nb; }
+    };
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     long long n_total = 0;
+    HintUpdate hint_update{ctx, &n_total, (long long)pixels, n_blocks};
+    bool first_pass = true;
     while (true) {
         if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
         const size_t off_cnt = al(8 * c_cap), off_tail = off_cnt + 256;
@@ -2485,7 +2506,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // 45 us of enqueueing the chain and one wake-up) it loses to a sort and launches sized for the capacity -- 98 000
         // entries for the 12 000 candidates of a rank's share of 8, 782 000 for the genome's 100 000: a rank's share
         // 1.21 -> 1.27-1.32 ms per step, the 23-block genome 4.15 -> 4.34 ms.
-        const bool single_sync = std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") != nullptr;       // (read per call: tests flip it)
+        const bool single_sync = std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") != nullptr || (adaptive && first_pass);   // (read per call: tests flip it)
+        first_pass = false;
         if (single_sync) CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)pool, 0x7fffffff, 2 * c_cap, stream));
         // side streams only when no block needs the (single) narrowing scratch
         bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");

@@ -277,7 +277,7 @@ int fail(cs_ctx* ctx, int code, const char* fmt, ...)
 // it is opt-in: CHROMOSIGHT_HIP_SPIN_WAIT=1.
 static hipError_t wait_stream_hot(hipStream_t stream)
 {
-    static const bool spin = std::getenv("CHROMOSIGHT_HIP_SPIN_WAIT") != nullptr;
+    const bool spin = std::getenv("CHROMOSIGHT_HIP_SPIN_WAIT") != nullptr;      // (read per call: the switch test flips it)
     if (spin) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0;; ++it) {

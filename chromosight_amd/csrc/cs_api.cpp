@@ -2497,7 +2497,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         if (rc) return rc;
         char* pool = (char*)ctx->d_pool;
         unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);
-        CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+        // (the counter is zeroed right before the tile kernels go out: on a side lane when the lanes carry the call's
+        // preparations, see `early_upload` below)
         // CHROMOSIGHT_HIP_ONE_SYNC=1 (experiment, measured SLOWER, off by default): one synchronisation per call -- the chain
         // behind the tile kernels is enqueued WITHOUT waiting for the candidate count: the list is sorted at its full
         // capacity, unused entries holding a sentinel that sorts last (0x7fffffff7fffffff: above every key, with the bit
@@ -2525,6 +2526,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // table) and the tile kernels go out afterwards: a mask-table launch queued behind persistent tile kernels would wait
         // for their workgroups to drain, and its lane's next tile kernel with it
         const bool prepared = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE");
+        if (!prepared) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));      // (tile kernels go out block by block below)
         int table_rsym = -1;
         // CHROMOSIGHT_HIP_PREP_BATCH=1 (experiment, measured neutral to slower, off by default): the mask tables of all blocks
         // built by ONE launch on the caller's stream instead of one launch per block on the lanes.  The 23 launches of a
@@ -2604,6 +2606,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             // doing, and the lanes wait for that stream only when this call uploaded the template.  (The tables' scratch is
             // free: the previous call's tile kernels were synchronised before it returned.)
             early_tables = prepared && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_TABLES");
+            // (without early tables the lanes' only link to this stream is the event below: the counter is zeroed before it)
+            if (prepared && !early_tables) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
             if (!prep_batch && (!early_tables || ctx->uploads != uploads_before)) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
                 for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
@@ -2689,6 +2693,18 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
         }
         laps.lap("mask tables + arguments");
+        // One tile launch + the lanes busy with the mask tables while the caller's stream is still staging the maps: the
+        // argument table and the zeroed counter travel on a lane too (ordered before the launch by the lane's event below)
+        // instead of sitting between the staging and the tile kernel -- a fill, a copy and their launch gaps, ~ 25 us of
+        // every step's critical path.
+        const bool early_upload = table && early_tables && n_lanes > 1 && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_UPLOAD");
+        if (early_upload) {
+            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->s_blk[0]));
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[0], true, false);
+            if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel table upload failed: %s", hipGetErrorString((hipError_t)rc));
+        } else if (prepared && early_tables) {
+            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));      // (before the event the lanes' tile kernels wait for, below)
+        }
         if (early_tables) {
             // the tile kernels read the maps and the zeroed counter: behind the caller's stream.  A block whose tables were
             // built on another lane than the one that launches its tiles: every lane waits for every lane's tables.
@@ -2722,7 +2738,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
         }
         if (table) {
-            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream);
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, stream, !early_upload, true);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
         laps.lap("tile kernels launched");

@@ -895,7 +895,13 @@ int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_ca
     return (int)hipGetLastError();
 }
 
-int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t stream)
+// upload: the stream the argument table travels on (nullptr: `stream`, right before the launch).  A caller whose stream is still
+// busy with other work -- the staging of the maps -- hands a side stream that is ordered before the launch by an event of its own:
+// the copy is then done when the stream gets to the tile kernel instead of sitting between the staging and it.
+// (do_upload / launch: a caller that uploads on a side stream makes two calls -- upload only, then launch only; the caller's own
+// stream may be the null stream, so "no upload" is a flag and not a null handle)
+int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t stream, hipStream_t upload,
+                            bool do_upload, bool launch)
 {
     if (n_blocks <= 0) return 0;
     int* first = reinterpret_cast<int*>(h_table);
@@ -908,8 +914,10 @@ int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym
     }
     first[n_blocks] = (int)total;
     if (total == 0) return 0;
-    hipError_t e = hipMemcpyAsync(d_table, h_table, mfma_blocks_table_bytes(n_blocks), hipMemcpyHostToDevice, stream);
+    hipError_t e = hipSuccess;
+    if (do_upload) e = hipMemcpyAsync(d_table, h_table, mfma_blocks_table_bytes(n_blocks), hipMemcpyHostToDevice, upload);
     if (e != hipSuccess) return (int)e;
+    if (!launch) return 0;
     MfmaBlocksArgs T;
     T.first = reinterpret_cast<const int*>(d_table);
     T.args = reinterpret_cast<const MfmaDenseArgs*>((char*)d_table + mfma_blocks_arg_offset(n_blocks));

@@ -1640,6 +1640,37 @@ __global__ __launch_bounds__(kThreads) void keyed_split_kernel(const CorrArgs<do
 }
 }  // namespace
 
+namespace {
+// keyed_segments_kernel + keyed_split_kernel in one launch (lists whose length the host knows: the split does not wait for the
+// segments): threads [0, n) split their key, threads [n, n + n_blocks] find the first key of block t - n
+__global__ __launch_bounds__(kThreads) void keyed_split_segments_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ keys,
+                                                                        long long n, int n_blocks, int shift, int* __restrict__ rows,
+                                                                        int* __restrict__ cols, int* __restrict__ blk,
+                                                                        long long* __restrict__ local, long long* __restrict__ seg)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t < n) {
+        const long long key = keys[t];
+        const int b = (int)(key >> shift);
+        const long long rem = key - ((long long)b << shift);
+        const int ns = tab[b].ns;
+        rows[t] = (int)(rem / ns);
+        cols[t] = (int)(rem - (rem / ns) * ns);
+        blk[t] = b;
+        local[t] = rem;
+    } else if (t - n <= n_blocks) {
+        const long long want = (t - n) << shift;
+        long long lo = 0, hi = n;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        seg[t - n] = lo;
+    }
+}
+}  // namespace
+
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
 {
     size_t sort_tmp = 0;
@@ -1703,11 +1734,17 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
         e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits + (bounded ? 1 : 0), stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
+    const bool one_split = !bounded && n_total > 0 && !getenv("CHROMOSIGHT_HIP_NO_SPLIT_FUSION");
+    if (one_split)
+        hipLaunchKernelGGL(keyed_split_segments_kernel, dim3(blocks_for(n_total + n_blocks + 1)), dim3(kThreads), 0, stream, tab, keys_s, n_total,
+                           n_blocks, shift, rows, cols, blk, local, seg);
+    else
+        hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
     if (n_total > 0) {
         const unsigned g = blocks_for(n_total);
         const long long* n_keys = bounded ? seg + n_blocks : nullptr;
-        hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
+        if (!one_split)
+            hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
         launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, n_keys, vals, (double*)nullptr);
     }
     const size_t lds_small = foci_small_lds_bytes();

@@ -77,6 +77,7 @@ struct cs_ctx {
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
+    long long* h_cand_counts = nullptr;   // pinned, 64 entries: the blocks' own candidate counts (cs_detect_foci_blocks, segmented lists)
     void* d_counts_peak = nullptr;   // cs_normxcorr2_host: largest |pixel| of the map (float bits), and its pinned copy
     unsigned* h_peak = nullptr;
     // grow-only scratch for the mask tables of the streaming kernel (one call in flight per context)
@@ -1194,6 +1195,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->h_cand_counts) (void)hipHostFree(ctx->h_cand_counts);
     if (ctx->d_counts_peak) (void)hipFree(ctx->d_counts_peak);
     if (ctx->h_peak) (void)hipHostFree(ctx->h_peak);
     if (ctx->d_narrow) (void)hipFree(ctx->d_narrow);
@@ -2419,6 +2421,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     constexpr int kKeyShift = 40;                 // row * ns + col < 2^40: sub-matrices of up to 2^20 bins
     bool all_narrow = true;
     long long pixels = 0;
+    std::vector<long long> block_pixels((size_t)std::max(n_blocks, 1), 0);
     for (int b = 0; b < n_blocks; ++b) {
         const cs_normxcorr2_params* p = params + b;
         const cs_foci_params* fp = foci + b;
@@ -2435,6 +2438,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             return fail(ctx, CS_ERR_INVALID, "block %d: a lazily evaluated float64 band needs its float32 twin for the tile kernel", b);
         if ((long long)p->ms * p->ns >= (1ll << kKeyShift)) return fail(ctx, CS_ERR_UNSUPPORTED, "block %d is too large for the batch keys", b);
         pixels += (long long)p->ms * std::min<long long>(w, p->ns);
+        block_pixels[(size_t)b] = (long long)p->ms * std::min<long long>(w, p->ns);
     }
     if (all_narrow && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW"))
         return cs_detect_foci_batch(ctx, stream_, n_blocks, signals, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
@@ -2490,13 +2494,39 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     long long n_total = 0;
     HintUpdate hint_update{ctx, &n_total, (long long)pixels, n_blocks};
     bool first_pass = true;
+    // SEGMENTED candidate lists: every block appends to a region of its own with a counter of its own (room in proportion to
+    // its pixels), so the chain behind the tile kernels knows the blocks' segments from n_blocks counts instead of sorting
+    // all candidates by block and position -- the labelling workgroup of a block sorts its own few thousand in LDS (cs_foci.hip
+    // lds_sort_pairs): no device-wide sort, no segments / split kernels (7 launches less, ~ 40 us of a rank's step).
+    // CHROMOSIGHT_HIP_NO_SEGMENTED=1: one list, sorted on the device.
+    const bool segmented_ok = n_blocks <= 60 && !std::getenv("CHROMOSIGHT_HIP_NO_SEGMENTED") && !std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") && !adaptive;
+    if (segmented_ok && !ctx->h_cand_counts)
+        CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_cand_counts, 64 * sizeof(long long), hipHostMallocDefault));
+    // (seg_tab: the n_blocks + 1 segment starts of the compact numbering, then the n_blocks region starts: one upload)
+    std::vector<long long> seg_tab(2 * (size_t)n_blocks + 2, 0), seg_cap((size_t)n_blocks, 0);
+    long long* const seg_off = seg_tab.data();
+    long long* const seg_base = seg_tab.data() + n_blocks + 1;
+    constexpr size_t kCntBytes = 8 * 64;           // the one list's counter (and a spare word) + up to 60 blocks' own
+    size_t off_tail_now = 0;                        // where the chain's scratch starts in the current layout
+    bool segmented = false;
     while (true) {
         if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
-        const size_t off_cnt = al(8 * c_cap), off_tail = off_cnt + 256;
-        int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_tail + cs::keyed_batch_scratch_bytes(n_blocks, (long long)c_cap));
+        size_t list_cap = c_cap;
+        if (segmented_ok) {
+            list_cap = 0;
+            for (int b = 0; b < n_blocks; ++b) {
+                seg_cap[(size_t)b] = std::max<long long>(2048, (long long)((double)c_cap * (double)block_pixels[(size_t)b] / (double)std::max<long long>(pixels, 1)) + 1);
+                seg_base[(size_t)b] = (long long)list_cap;
+                list_cap += (size_t)seg_cap[(size_t)b];
+            }
+        }
+        const size_t off_cnt = al(8 * list_cap), off_tail = off_cnt + 1024;
+        off_tail_now = off_tail;
+        segmented = segmented_ok;
+        int rc = ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_tail + cs::keyed_batch_scratch_bytes(n_blocks, (long long)list_cap));
         if (rc) return rc;
         char* pool = (char*)ctx->d_pool;
-        unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);
+        unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);       // [0] the one list's counter; [2 + b] block b's
         // (the counter is zeroed right before the tile kernels go out: on a side lane when the lanes carry the call's
         // preparations, see `early_upload` below)
         // CHROMOSIGHT_HIP_ONE_SYNC=1 (experiment, measured SLOWER, off by default): one synchronisation per call -- the chain
@@ -2526,7 +2556,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // table) and the tile kernels go out afterwards: a mask-table launch queued behind persistent tile kernels would wait
         // for their workgroups to drain, and its lane's next tile kernel with it
         const bool prepared = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE");
-        if (!prepared) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));      // (tile kernels go out block by block below)
+        if (!prepared) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (tile kernels go out block by block below)
         int table_rsym = -1;
         // CHROMOSIGHT_HIP_PREP_BATCH=1 (experiment, measured neutral to slower, off by default): the mask tables of all blocks
         // built by ONE launch on the caller's stream instead of one launch per block on the lanes.  The 23 launches of a
@@ -2607,7 +2637,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             // free: the previous call's tile kernels were synchronised before it returned.)
             early_tables = prepared && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_TABLES");
             // (without early tables the lanes' only link to this stream is the event below: the counter is zeroed before it)
-            if (prepared && !early_tables) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+            if (prepared && !early_tables) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));
             if (!prep_batch && (!early_tables || ctx->uploads != uploads_before)) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
                 for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
@@ -2665,6 +2695,11 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
             CandSink sink{(unsigned long long*)pool, d_cnt, (long long)c_cap, (unsigned long long)b << kKeyShift, foci[b].lo_diag,
                           foci[b].hi_diag};
+            if (segmented) {
+                sink.keys = (unsigned long long*)pool + seg_base[(size_t)b];
+                sink.count = d_cnt + 2 + b;
+                sink.cap = seg_cap[(size_t)b];
+            }
             int rsym = 0;
             if (prepared) {
                 sink.defer_args = (char*)ctx->h_tab + cs::mfma_blocks_arg_offset(n_blocks) + (size_t)b * cs::mfma_blocks_arg_bytes();
@@ -2699,11 +2734,11 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // every step's critical path.
         const bool early_upload = table && early_tables && n_lanes > 1 && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_UPLOAD");
         if (early_upload) {
-            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->s_blk[0]));
+            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[0]));
             rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[0], true, false);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel table upload failed: %s", hipGetErrorString((hipError_t)rc));
         } else if (prepared && early_tables) {
-            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));      // (before the event the lanes' tile kernels wait for, below)
+            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (before the event the lanes' tile kernels wait for, below)
         }
         if (early_tables) {
             // the tile kernels read the maps and the zeroed counter: behind the caller's stream.  A block whose tables were
@@ -2743,7 +2778,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         }
         laps.lap("tile kernels launched");
         g_tile_launch_seq.fetch_add(1, std::memory_order_release);      // (CS_CALL_WAIT_TILE_LAUNCH of cs_run_calls)
-        CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+        if (segmented) CS_HIP(ctx, hipMemcpyAsync(ctx->h_cand_counts, d_cnt + 2, 8 * (size_t)n_blocks, hipMemcpyDeviceToHost, stream));
+        else CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
         if (tab.empty()) {
             // built while the tile kernels run, not between the two synchronisations
             tab.resize((size_t)n_blocks);
@@ -2757,7 +2793,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         }
         laps.lap("float64 argument table");
         if (single_sync) {
-            const size_t off_tail1 = al(8 * c_cap) + 256;
+            const size_t off_tail1 = off_tail_now;
             ctx->h_blk_counts[0] = -1;
             int rc1 = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, (long long)c_cap, kKeyShift, foci[0].pearson,
                                                    foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail1, rec,
@@ -2779,17 +2815,38 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         }
         CS_HIP(ctx, wait_stream_hot(stream));
         laps.lap("wait: candidates");
+        if (segmented) {
+            // the blocks' own counts: segments of the compact numbering; a block that outgrew its room sends the call round again
+            bool fits = true;
+            long long sum = 0, worst = 1;
+            for (int b = 0; b < n_blocks; ++b) {
+                const long long nb_ = ctx->h_cand_counts[b];
+                seg_off[(size_t)b] = sum;
+                sum += std::min(nb_, seg_cap[(size_t)b]);
+                if (nb_ > seg_cap[(size_t)b]) {
+                    fits = false;
+                    // (room in proportion to the pixels: the total that would have given this block enough)
+                    worst = std::max(worst, (long long)((double)nb_ * (double)std::max<long long>(pixels, 1) / (double)std::max<long long>(block_pixels[(size_t)b], 1)) + 1);
+                }
+            }
+            seg_off[(size_t)n_blocks] = sum;
+            n_total = sum;
+            if (fits) break;
+            c_cap = (size_t)worst + (size_t)worst / 8;
+            continue;
+        }
         n_total = ctx->h_counts[0];
         if ((size_t)n_total <= c_cap) break;
         c_cap = (size_t)n_total + (size_t)n_total / 8;
     }
     // ---- exact scores, foci, statistics: one chain for all blocks (its argument table was built while the tile kernels ran)
     char* pool = (char*)ctx->d_pool;
-    const size_t off_tail = al(8 * c_cap) + 256;
+    const size_t off_tail = off_tail_now;
     ctx->h_blk_counts[0] = -1;
     int rc = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, n_total, kKeyShift, foci[0].pearson,
                                           foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail, rec,
-                                          (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream);
+                                          (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream, 0,
+                                          segmented ? seg_base : nullptr, segmented ? seg_off : nullptr);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     laps.lap("foci chain enqueued");
     CS_HIP(ctx, wait_stream_hot(stream));            // also: the host table above was consumed

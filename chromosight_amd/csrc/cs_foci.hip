@@ -707,10 +707,38 @@ __device__ __forceinline__ int block_scan_counts(int cnt, int* __restrict__ part
     return (wv ? part[16 + wv - 1] : 0) + incl - cnt;
 }
 
+// (key, source) pairs of the kept pixels into ascending key order, in LDS: bitonic network over the next power of two (the
+// padding holds the largest key).  For lists that arrive UNSORTED -- the candidates of a block as the tile kernel appended them,
+// cs_detect_foci_blocks' segmented lists -- instead of a device-wide sort of all blocks' candidates in front of the chain
+// (five launches and ~ 40 us of a rank's step for ~ 4 000 candidates per block, which one workgroup sorts in ~ 5 us).
+__device__ __forceinline__ void lds_sort_pairs(unsigned* __restrict__ key, unsigned short* __restrict__ src, int n)
+{
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int t = n + threadIdx.x; t < P; t += kSmallThreads) key[t] = 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = threadIdx.x; q < (P >> 1); q += kSmallThreads) {      // pair q: i has bit j clear, l = i + j
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+                const unsigned a = key[i], b = key[l];
+                if ((a > b) == ((i & k) == 0)) {
+                    key[i] = b;
+                    key[l] = a;
+                    const unsigned short sa = src[i];
+                    src[i] = src[l];
+                    src[l] = sa;
+                }
+            }
+            __syncthreads();
+        }
+}
+
 __device__ __forceinline__ void foci_small_lds_body(
     const long long* __restrict__ keys_s, const double* __restrict__ vals, int n_cand, double pearson, unsigned ns, int min_size,
     int diag_only, unsigned long long* __restrict__ best_val, int* __restrict__ out_rows, int* __restrict__ out_cols,
-    int* __restrict__ out_size, int* __restrict__ n_kept_out, long long* __restrict__ n_foci, int* __restrict__ part, char* lds)
+    int* __restrict__ out_size, int* __restrict__ n_kept_out, long long* __restrict__ n_foci, int* __restrict__ part, char* lds,
+    int unsorted = 0)
 {
     unsigned* s_key = reinterpret_cast<unsigned*>(lds);
     int* s_parent = reinterpret_cast<int*>(lds + 4 * (size_t)kSmallLds);
@@ -740,6 +768,7 @@ __device__ __forceinline__ void foci_small_lds_body(
         }
     if (tid == 0) *n_kept_out = n;
     __syncthreads();
+    if (unsorted) lds_sort_pairs(s_key, s_src, n);        // (wave-uniform; the other arrays are position-indexed: untouched)
     // (2) 4-connected foci of the kept pixels: union-find, root = first pixel in row-major order
     for (int t = tid; t < n; t += kSmallThreads) {
         const unsigned key = s_key[t];
@@ -808,7 +837,7 @@ __global__ __launch_bounds__(kSmallThreads) void foci_small_batch_kernel(
     const double* __restrict__ vals, double pearson, int min_size, int diag_only, int* __restrict__ flag, int* __restrict__ pos,
     long long* __restrict__ keys_k, double* __restrict__ vals_k, int* __restrict__ parent, int* __restrict__ size,
     unsigned long long* __restrict__ best_val, int* __restrict__ best_idx, int* __restrict__ out_rows, int* __restrict__ out_cols,
-    int* __restrict__ out_size, int* __restrict__ n_kept, long long* __restrict__ n_foci_blk, int lds_ok)
+    int* __restrict__ out_size, int* __restrict__ n_kept, long long* __restrict__ n_foci_blk, int lds_ok, int unsorted = 0)
 {
     __shared__ int part[kSmallThreads];
     extern __shared__ __attribute__((aligned(16))) char small_lds[];     // kSmallLdsBytes, or nothing (lds_ok = 0)
@@ -816,7 +845,14 @@ __global__ __launch_bounds__(kSmallThreads) void foci_small_batch_kernel(
     const long long o = seg[b], n_cand = seg[b + 1] - o;
     if (lds_ok && n_cand <= kSmallLds && (unsigned long long)tab[b].ms * (unsigned long long)tab[b].ns <= 0xffffffffull) {
         foci_small_lds_body(keys_s + o, vals + o, (int)n_cand, pearson, (unsigned)tab[b].ns, min_size, diag_only, best_val + o,
-                            out_rows + o, out_cols + o, out_size + o, n_kept + b, n_foci_blk + b, part, small_lds);
+                            out_rows + o, out_cols + o, out_size + o, n_kept + b, n_foci_blk + b, part, small_lds, unsorted);
+        return;
+    }
+    if (unsorted) {                 // (the host sends unsorted lists only where every block takes the route above)
+        if (threadIdx.x == 0) {
+            n_kept[b] = 0;
+            n_foci_blk[b] = 0;
+        }
         return;
     }
     foci_small_body(keys_s + o, vals + o, n_cand, pearson, tab[b].ns, min_size, diag_only, flag + o, pos + o, keys_k + o, vals_k + o,
@@ -1671,13 +1707,42 @@ __global__ __launch_bounds__(kThreads) void keyed_split_segments_kernel(const Co
 }
 }  // namespace
 
+namespace {
+// segmented candidate lists (block b's keys at regions[base[b] ..), seg = prefix of their lengths): entry t of the compact
+// numbering -> its key, decoded like keyed_split_kernel; one wave-uniform search over the few blocks per thread
+__global__ __launch_bounds__(kThreads) void segmented_unpack_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ regions,
+                                                                    const long long* __restrict__ base, const long long* __restrict__ seg,
+                                                                    int n_blocks, long long n, int shift, int* __restrict__ rows,
+                                                                    int* __restrict__ cols, int* __restrict__ blk,
+                                                                    long long* __restrict__ local, long long* __restrict__ keys_c)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n) return;
+    int lo = 0, hi = n_blocks - 1;                            // the block with seg[b] <= t < seg[b + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    const long long key = regions[base[lo] + (t - seg[lo])];
+    const int b = (int)(key >> shift);
+    const long long rem = key - ((long long)b << shift);
+    const int ns = tab[b].ns;
+    rows[t] = (int)(rem / ns);
+    cols[t] = (int)(rem - (rem / ns) * ns);
+    blk[t] = b;
+    local[t] = rem;
+    keys_c[t] = key;
+}
+}  // namespace
+
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
 {
     size_t sort_tmp = 0;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)std::max<long long>(n_total, 1));
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
-    return al(sort_tmp) + al(sizeof(CorrArgs<double>) * nb) + 9 * al(8 * n) + 15 * al(4 * n) + 6 * al(8 * nb) + 4096;
+    return al(sort_tmp) + al(sizeof(CorrArgs<double>) * nb) + 9 * al(8 * n) + 15 * al(4 * n) + 7 * al(8 * nb) + 4096;
 }
 
 // d_keys: n_total composite keys in any order (device).  h_tab: the float64 argument blocks of the sub-matrices.
@@ -1685,8 +1750,11 @@ size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
 // h_counts[1 + b] = foci of block b.  Same chain as enqueue_foci_narrow_batch after its enumeration.
 int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
                              double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
-                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded)
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded,
+                             const long long* h_base, const long long* h_seg)
 {
+    // h_base / h_seg (or null): SEGMENTED lists -- block b's keys, unsorted, at d_keys[h_base[b] ..), h_seg[b + 1] - h_seg[b] of
+    // them (n_total = h_seg[n_blocks]); both arrays must outlive the call's copies (the caller synchronises).
     // bounded: n_total is the CAPACITY of d_keys, whose unused entries hold a sentinel above every key with the bit above
     // the block bits set (cs_api.cpp cs_detect_foci_blocks); the number of keys is seg[n_blocks], known on the device only
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1721,36 +1789,62 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
     int* f_cols = b.take<int>(n);
     int* f_size = b.take<int>(n);
     int* f_blk = b.take<int>(n);
-    long long* seg = b.take<long long>(nb);
+    long long* seg = b.take<long long>(2 * nb);            // (segmented lists: the regions' starts right behind the segments, one upload)
+    long long* base_d = seg + nb;
     int* n_kept = reinterpret_cast<int*>(b.take<long long>(nb));
     long long* n_foci_blk = b.take<long long>(nb);
     long long* f_off = b.take<long long>(nb);
     long long* d_total = b.take<long long>(8);
     hipError_t e = hipMemcpyAsync(tab, h_tab, sizeof(CorrArgs<double>) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return (int)e;
+    int unsorted = 0;
+    if (h_base && h_seg && !bounded && n_total > 0) {
+        // every block's list short enough for the labelling workgroup's LDS arrays (which sort it there)?  then no device-wide
+        // sort, no segments, no split: one unpack launch
+        const size_t lds_small = foci_small_lds_bytes();
+        bool all_small = lds_small > 0;
+        for (int k = 0; k < n_blocks && all_small; ++k)
+            all_small = h_seg[k + 1] - h_seg[k] <= kSmallLds &&
+                        (unsigned long long)h_tab[k].ms * (unsigned long long)h_tab[k].ns <= 0xffffffffull;
+        // (h_seg: n_blocks + 1 segment starts, then -- h_base == h_seg + n_blocks + 1 -- the n_blocks region starts: one copy)
+        if (h_base == h_seg + nb) e = hipMemcpyAsync(seg, h_seg, 8 * (nb + (size_t)n_blocks), hipMemcpyHostToDevice, stream);
+        else {
+            e = hipMemcpyAsync(seg, h_seg, 8 * nb, hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(base_d, h_base, 8 * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+        }
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(segmented_unpack_kernel, dim3(blocks_for(n_total)), dim3(kThreads), 0, stream, tab, d_keys, base_d, seg, n_blocks,
+                           n_total, shift, rows, cols, blk, local, keys_k);
+        if (all_small) unsorted = 1;
+        else d_keys = keys_k;                       // the compact list through the sorted route below
+    }
     int blk_bits = 1;
     while ((1 << blk_bits) < n_blocks) ++blk_bits;
-    if (n_total > 0) {
+    if (n_total > 0 && !unsorted) {
         e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits + (bounded ? 1 : 0), stream);
         if (e != hipSuccess) return (int)e;
     }
-    const bool one_split = !bounded && n_total > 0 && !getenv("CHROMOSIGHT_HIP_NO_SPLIT_FUSION");
-    if (one_split)
-        hipLaunchKernelGGL(keyed_split_segments_kernel, dim3(blocks_for(n_total + n_blocks + 1)), dim3(kThreads), 0, stream, tab, keys_s, n_total,
-                           n_blocks, shift, rows, cols, blk, local, seg);
-    else
-        hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
-    if (n_total > 0) {
-        const unsigned g = blocks_for(n_total);
-        const long long* n_keys = bounded ? seg + n_blocks : nullptr;
-        if (!one_split)
-            hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
-        launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, n_keys, vals, (double*)nullptr);
+    const bool one_split = !bounded && n_total > 0 && !unsorted && !getenv("CHROMOSIGHT_HIP_NO_SPLIT_FUSION");
+    if (unsorted) {
+        launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, (const long long*)nullptr, vals, (double*)nullptr);
+    } else {
+        if (one_split)
+            hipLaunchKernelGGL(keyed_split_segments_kernel, dim3(blocks_for(n_total + n_blocks + 1)), dim3(kThreads), 0, stream, tab, keys_s,
+                               n_total, n_blocks, shift, rows, cols, blk, local, seg);
+        else
+            hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
+        if (n_total > 0) {
+            const unsigned g = blocks_for(n_total);
+            const long long* n_keys = bounded ? seg + n_blocks : nullptr;
+            if (!one_split)
+                hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
+            launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, n_keys, vals, (double*)nullptr);
+        }
     }
     const size_t lds_small = foci_small_lds_bytes();
     hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), lds_small, stream, tab, seg, local, vals, pearson, min_size,
                        diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk,
-                       lds_small ? 1 : 0);
+                       lds_small ? 1 : 0, unsorted);
     hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
                        f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
     if (n_total > 0) {

@@ -690,7 +690,8 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total);
 int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
                              double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
-                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded = 0);
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded = 0,
+                             const long long* h_base = nullptr, const long long* h_seg = nullptr);
 
 // row-major keys (row * ns + col) -> coordinates
 int launch_decode_keys(const long long* keys, long long n, int ns, int* rows, int* cols, hipStream_t stream);

@@ -523,7 +523,8 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
                    # sized from the previous call, one synchronisation; the records of the foci by the two kernels instead of one;
                    # the general run kernel instead of its 17 x 17 instance)
                    "CHROMOSIGHT_HIP_ADAPTIVE_SYNC", "CHROMOSIGHT_HIP_NO_FUSED_RECORDS", "CHROMOSIGHT_HIP_RUN_GENERAL",
-                   "CHROMOSIGHT_HIP_SPIN_WAIT", "CHROMOSIGHT_HIP_NO_EARLY_UPLOAD", "CHROMOSIGHT_HIP_NO_SPLIT_FUSION"):
+                   "CHROMOSIGHT_HIP_SPIN_WAIT", "CHROMOSIGHT_HIP_NO_EARLY_UPLOAD", "CHROMOSIGHT_HIP_NO_SPLIT_FUSION",
+                   "CHROMOSIGHT_HIP_NO_SEGMENTED"):
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):

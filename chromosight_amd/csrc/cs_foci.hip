@@ -730,7 +730,15 @@ __device__ __forceinline__ void lds_sort_pairs(unsigned* __restrict__ key, unsig
                     src[l] = sa;
                 }
             }
-            __syncthreads();
+            // pairs at distance <= 64 stay inside the 128 elements a wave's 64 consecutive pairs span: between such stages only
+            // the wave's own LDS operations must be ordered (they execute in order); the workgroup meets where the distance
+            // grows again (j == 1: the next level starts with a long one) or is still long
+            if (j > 64 || j == 1) __syncthreads();
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
 }
 

@@ -2036,6 +2036,8 @@ static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel
                            const cs_foci_params* fp)
 {
     if (!signal || !kernel || !p || !fp) return fail(ctx, CS_ERR_INVALID, "null argument");
+    // (every foci entry shares the context's count words, block tables and record pool with an asynchronous batch)
+    if (ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "an asynchronous batch is pending on this context: cs_detect_foci_batch_finish first");
     if (p->mask_mode == CS_MASK_EXPLICIT) return fail(ctx, CS_ERR_UNSUPPORTED, "device foci need per-bin masks or none");
     if (fp->min_size < 1) return fail(ctx, CS_ERR_INVALID, "min_size must be >= 1");
     if (!ctx->h_counts) CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault));
@@ -3094,6 +3096,11 @@ void run_lane(const CallRun& R, int lane)
             while (g_tile_launch_seq.load(std::memory_order_acquire) == R.tile_seq0 &&
                    !(k2 >= 0 && k2 < R.n && R.done[k2].load(std::memory_order_acquire)))
                 if (++spins > 2000) std::this_thread::yield();
+        }
+        if (failed && c.fn == CS_CALL_DETECT_FOCI_BATCH_FINISH) {
+            // a lane that failed between the asynchronous batch and its finish must not leave the context "pending" (every later
+            // foci call on it would be refused): end the batch whatever it holds; "nothing pending" is as good
+            (void)dispatch_call(c);
         }
         c.rc = failed ? CS_ERR_INVALID : dispatch_call(c);
         if (R.timing)       // CHROMOSIGHT_HIP_TIMING: the host timeline of the list (lane, entry, begin and end since the list began)

@@ -58,10 +58,16 @@ struct LazyBand {
 // place of a float64 -- 1e-16 relative against tolerances of 1e-11 and wider everywhere downstream -- and keeps its special
 // cases: law 0 -> 1 / 0 = inf -> v * inf = inf (>= max_val -> 1) or NaN for v = 0 (-> 0), as inf and NaN of the division.
 // Whatever recomputes a staged pixel (the lazily evaluated bands) uses THIS function, so that the two stay bit-identical.
-__device__ __forceinline__ double stage_detrend_rcp(double v, double inv_y, double max_val)
+// The cap is a DISCRETE decision (>= max_val -> 1): where the product lands within rounding of max_val -- unbalanced integer
+// counts over a rational law can make v / y exactly 10 while v * (1 / y) rounds to 10 - ulp -- it is made with the reference's
+// own quotient (`y_at`: address of the law's value, read only then: once in ~ 1e15 pixels of real data).
+__device__ __forceinline__ double stage_detrend_rcp(double v, double inv_y, double max_val, const double* y_at)
 {
     double out = v * inv_y;
-    if (max_val > 0.0 && out >= max_val) out = 1.0;        // :301-302
+    if (max_val > 0.0) {
+        if (fabs(out - max_val) <= max_val * 8.9e-16) out = v / *y_at;      // (4 ulp; inf and NaN never come here)
+        if (out >= max_val) out = 1.0;                     // :301-302
+    }
     return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
 }
 
@@ -69,7 +75,8 @@ __device__ __forceinline__ double lazy_stored_value(const LazyBand& L, long long
 {
     const double x = L.data_is_f64 ? reinterpret_cast<const double*>(L.data)[k] : (double)reinterpret_cast<const float*>(L.data)[k];
     const int d = q - p;
-    return stage_detrend_rcp((x * L.weight[L.row0 + p]) * L.weight[L.row0 + q], 1.0 / (d < L.n_diags ? L.law[d] : 0.0), L.max_val);
+    const int dc = min(d, L.n_diags - 1);
+    return stage_detrend_rcp((x * L.weight[L.row0 + p]) * L.weight[L.row0 + q], 1.0 / (d < L.n_diags ? L.law[d] : 0.0), L.max_val, L.law + dc);
 }
 
 // pixel (p, q) of the block, 0 <= p <= q < n, on a diagonal the view keeps

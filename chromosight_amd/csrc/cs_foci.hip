@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void rescore_batch_kernel(const CorrArgs<doubl
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         rescore_pixel_sq<17>(A, oi, oj, lane, r, nobs, win);
-    } else if (A.sig.layout == 2 && A.km * A.kn <= kLazyWinMax && inside) {     // wave-uniform
+    } else if (A.sig.layout == 2 && lazy_window_fits(A.km, A.kn) && inside) {     // wave-uniform
         double* win = lazy_win[threadIdx.x >> 6];
         lazy_gather_window(A, oi - (A.km - 1) / 2, oj - (A.kn - 1) / 2, lane, win);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1022,7 +1022,7 @@ __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, 
     int n_zero = 0, n_miss = 0;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // a lazily evaluated band: the window's pixels gathered by the wave first (cs_launch_aux.h lazy_gather_window)
-    const bool gathered = lazy_win && inside && A.sig.layout == 2 && kk <= kLazyWinMax;          // wave-uniform
+    const bool gathered = lazy_win && inside && A.sig.layout == 2 && lazy_window_fits(km, kn);          // wave-uniform
     // (have_p0, have_q0: lazy_win already holds the window with this top left pixel -- the exact evaluation of the same record
     // gathered it a moment ago, focus_records_lazy17_kernel)
     const bool have = gathered && have_p0 == high - pad_r && have_q0 == left - pad_c;

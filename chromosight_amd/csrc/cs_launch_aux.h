@@ -50,6 +50,11 @@ __device__ __forceinline__ double wave_sum(double v)
 // detrended and dropped into their window slots.
 constexpr int kLazyWinMax = 17 * 17;
 
+// Templates lazy_gather_window serves: the window fits the wave's LDS slots AND has at most one row per lane (lane ki searches
+// row ki of the window; a 70 x 4 template passes the area test and would leave its rows 64.. unread beyond the near band).
+// Everything else reads through load_signal pixel by pixel.
+__device__ __forceinline__ bool lazy_window_fits(int km, int kn) { return km * kn <= kLazyWinMax && km <= 64 && kn <= 64; }
+
 __device__ __forceinline__ void lazy_gather_window(const CorrArgs<double>& A, int p0, int q0, int lane, double* win)
 {
     const LazyBand& L = *reinterpret_cast<const LazyBand*>(A.sig.ptr);
@@ -316,9 +321,7 @@ __device__ __forceinline__ void lazy_gather_window_sq(const CorrArgs<double>& A,
                 const int p = p0 + ki, d = c - p;
                 const double x = is_f64 ? data64[idx] : (double)data32[idx];
                 const double y = d < n_diags ? law[d] : 0.0;
-                double out = ((x * weight[row0 + p]) * weight[row0 + c]) * (1.0 / y);        // stage_detrend_rcp (cs_device.h)
-                if (max_val > 0.0 && out >= max_val) out = 1.0;
-                win[ki * K + (c - q0)] = out != out ? 0.0 : out;
+                win[ki * K + (c - q0)] = stage_detrend_rcp((x * weight[row0 + p]) * weight[row0 + c], 1.0 / y, max_val, (const double*)(law + min(d, n_diags - 1)));
             }
         }
     }

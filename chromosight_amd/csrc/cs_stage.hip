@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
                 // (both LDS reads unconditional, from clamped indices: behind a condition each became an exec-mask branch)
                 const double wc = l_w[rel];
                 const double iy = l_law[min(max(d, 0), n_diags_m1)];
-                v[u] = stage_detrend_rcp(((double)xn[u] * wr) * wc, (ok && d < B.n_diags) ? iy : kInf, max_val);
+                v[u] = stage_detrend_rcp(((double)xn[u] * wr) * wc, (ok && d < B.n_diags) ? iy : kInf, max_val, B.law + min(max(d, 0), n_diags_m1));
                 slot[u] = ok ? rel - c_x0 : -1;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
                             if (in) {
                                 const int rel = c[u] - c_base;
                                 const int d = rel - c_r;
-                                l_row[rel - c_x0 - s0] = stage_detrend_rcp(((double)x[u] * wr) * l_w[rel], d < B.n_diags ? l_law[d] : kInf, max_val);
+                                l_row[rel - c_x0 - s0] = stage_detrend_rcp(((double)x[u] * wr) * l_w[rel], d < B.n_diags ? l_law[d] : kInf, max_val,
+                                                                           B.law + min(max(d, 0), n_diags_m1));
                             }
                             more = more && (m == ~0ull);                // a lane beyond the piece (or the row): this piece is complete
                         }

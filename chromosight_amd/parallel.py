@@ -74,8 +74,9 @@ class NativeComm:
         if rc != 0:
             raise RuntimeError(f"RCCL exchange failed ({rc}): {self.lib.cs_comm_last_error(self.handle).decode()}")
 
-    def allgather_rows(self, rows):
-        """Rank-order concatenation of every rank's (n_i, w) float64 array, and the per-rank counts."""
+    def allgather_rows(self, rows, first_cap=0):
+        """Rank-order concatenation of every rank's (n_i, w) float64 array, and the per-rank counts.  first_cap: this rank's
+        first capacity in rows (0: a guess from its own count) -- the self-check hands a small one so that the retry runs."""
         C = self.C
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         width = int(rows.shape[1])
@@ -83,7 +84,7 @@ class NativeComm:
         # first guess; CHROMOSIGHT_HIP_GATHER_CAP forces a small one (tests of the retry).  The library exchanges the
         # capacities with the counts and answers "overflow" on EVERY rank when any rank lacks room, so all ranks retry
         # together with the exact total (the collectives stay matched whatever the per-rank guesses were).
-        cap = int(os.environ.get("CHROMOSIGHT_HIP_GATHER_CAP", 0)) or max(4 * rows.shape[0] * self.world, 4096)
+        cap = int(first_cap) or int(os.environ.get("CHROMOSIGHT_HIP_GATHER_CAP", 0)) or max(4 * rows.shape[0] * self.world, 4096)
         while True:
             out = np.empty((cap, width))
             rc = self.lib.cs_comm_allgather_rows(self.handle, rows.ctypes.data, rows.shape[0], width, out.ctypes.data, cap,
@@ -458,22 +459,21 @@ def exchange_self_check():
         return transport()
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
+    # torch's reference collective first and OUTSIDE the try: every rank issues the same torch collectives whatever happens to
+    # the native ones on it (a rank that skipped this all-reduce after a native error would leave the others inside it)
+    vec = np.linspace(0.0, 1.0, 97) * (rank + 1)
+    t = torch.from_numpy(vec.copy()).to(dev)
+    dist.all_reduce(t)
+    want_sum = t.cpu().numpy()
     ok, why = True, ""
     try:
         mine = (np.arange((3 * rank + 1) * 5, dtype=np.float64).reshape(-1, 5) + 1000.0 * rank)
-        if rank == 0:
-            os.environ["CHROMOSIGHT_HIP_GATHER_CAP"] = "2"
-        try:
-            got, counts = comm.allgather_rows(mine)
-        finally:
-            os.environ.pop("CHROMOSIGHT_HIP_GATHER_CAP", None)
+        got, counts = comm.allgather_rows(mine, first_cap=2 if rank == 0 else 0)      # (rank 0 too small: the retry runs)
         want = np.concatenate([np.arange((3 * r + 1) * 5, dtype=np.float64).reshape(-1, 5) + 1000.0 * r for r in range(world)])
         if counts.tolist() != [3 * r + 1 for r in range(world)] or not np.array_equal(got, want):
             ok, why = False, "all-gather of rows differs from the expected concatenation"
-        vec = np.linspace(0.0, 1.0, 97) * (rank + 1)
-        t = torch.from_numpy(vec.copy()).to(dev)
-        dist.all_reduce(t)
-        if ok and not np.allclose(comm.allreduce_sum(vec), t.cpu().numpy(), rtol=1e-13, atol=0):
+        got_sum = comm.allreduce_sum(vec)              # (always issued: the native collectives stay matched across the ranks)
+        if ok and not np.allclose(got_sum, want_sum, rtol=1e-13, atol=0):
             ok, why = False, "all-reduce differs from torch.distributed's"
     except Exception as exc:                                  # noqa: BLE001 -- whatever it is, the torch path remains
         ok, why = False, repr(exc)

@@ -339,7 +339,6 @@ class DeviceCool:
         self.upper = bool(b1.size == 0 or np.all(b2 >= b1))
         self._band = _Scratch(dev)
         self._ext = _Scratch(dev)
-        self._laws = _Scratch(dev)
         self._stage_lock = threading.RLock()
         self._free = _FreeList()        # HBM of released resident blocks, reused by the next staging
         self._workers = None
@@ -428,12 +427,12 @@ class DeviceCool:
         # pixels against)
         near = int(os.environ.get("CHROMOSIGHT_HIP_NEAR_DIAGS", "64"))
         lazy = [bool(lazy64 and not only32 and g[6] and (lazy64 == "all" or g[5] > 2 * near)) for g in geo]
-        shared = None
-        if any(lazy):
-            shared = _Shared(self._free, self._resident(8 * sum(g[4] for g in geo) + 256 + LAZY_BAND_BYTES * len(geo)))
-            laws = shared.buffer.ptr + LAZY_BAND_BYTES * len(geo)
-        else:
-            laws = self._laws.get(8 * sum(g[4] for g in geo) + 256)
+        # The laws (and the descriptors of lazily evaluated bands) live as long as the blocks do: one buffer per staging call,
+        # held by every block of the call -- never the rewritten law scratch.  A recorded staging (plan.StepPlan replays the
+        # cs_stage_blocks table verbatim, d_law included) must not point into a grow-only scratch that a later staging with a
+        # longer law re-allocates (silent corruption on the next replay).
+        shared = _Shared(self._free, self._resident(8 * sum(g[4] for g in geo) + 256 + LAZY_BAND_BYTES * len(geo)))
+        laws = shared.buffer.ptr + LAZY_BAND_BYTES * len(geo)
         table = (CsStageBlock * len(geo))()
         blocks, off = [], 0
         for k, (ci, s, n, keep, n_diags, in_w, band, ld) in enumerate(geo):
@@ -459,8 +458,9 @@ class DeviceCool:
             blk.sig32 = sig32
             blk.buffer, blk.pool = (b32 if only32 else b64), self._free
             blk.buffer32 = None if only32 else b32
+            blk.shared = shared                                 # (the law buffer of the call)
             if lazy[k]:
-                blk.shared, blk.genome = shared, self           # (the descriptor points into both)
+                blk.genome = self                               # (the descriptor points into the pixel table)
                 blk.restage = (lambda ci=ci: self.stage_blocks([ci], max_dist, largest_kernel, band_dtype=band_dtype)[0])
             blocks.append(blk)
         genome = CsCsr(self.n_bins, self.n_bins, max(self.nnz, 1), self.indptr.ptr, self.indices.ptr, self.data.ptr,

@@ -74,6 +74,14 @@ class StepPlan:
                         f"{raw_arg(blocks[0][0]) == ctx_a}, windows asked for {blocks[0][11] is not None or batch[0][11] is not None}")
             return
         self.genome, self.owned, self.staged = genome, list(owned), staged
+        # the two contexts the list runs on, as the objects whose locks serialise their use (the genome's own; the worker context
+        # of the 1-D chain, pipeline.async_device)
+        from . import pipeline as _pipeline
+        dev_b = [d for d, _s in _pipeline._ASYNC_DEVICES.values() if d.ctx == ctx_b]
+        if not dev_b:
+            self.why = "the 1-D chain ran on a context this process does not manage"
+            return
+        self.locks = (genome.dev.lock, dev_b[0].lock)
         self.keep = (captured, kernel_configs)               # every argument array stays alive with the plan
         self.n_blocks = int(blocks[0][2])
         self.n_templates = int(batch[0][4])
@@ -181,7 +189,10 @@ class StepPlan:
     def run(self):
         """One step: (records of the 2-D configuration, records of the 1-D configuration) of this rank, in detect_genome's
         layout (block, bin1, bin2, score, pvalue, kernel_id, iteration) -- or None when a call reported an error."""
-        rc = self.lib.cs_run_calls(self.calls, len(self.calls))
+        # one call in flight per context (engine._one_call_per_context): the list runs on the genome's context (lane 0) and
+        # on the 1-D chain's worker context (lane 1); both are held for the call, always in the same order
+        with self.locks[0], self.locks[1]:
+            rc = self.lib.cs_run_calls(self.calls, len(self.calls))
         if rc != 0:
             if os.environ.get("CHROMOSIGHT_HIP_DEBUG"):
                 import sys

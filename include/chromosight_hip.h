@@ -385,7 +385,13 @@ int cs_detect_foci_batch_finish(cs_ctx* ctx, void* stream, int64_t* h_n_foci);
  * entries may have a NULL d_ptr): the same maps in float32 with the same layout, what the tile kernel stages (a float64
  * map is rounded into context scratch first when it has no float32 twin).  Per-bin masks, float32 arithmetic, whole
  * blocks; CS_ERR_UNSUPPORTED when a block is not served by the tile kernel (template size, layout): the caller then
- * uses cs_detect_foci block by block.  Outputs as cs_detect_foci_batch. */
+ * uses cs_detect_foci block by block.  Outputs as cs_detect_foci_batch.
+ * PRECONDITION on the flags: params[b].miss_row / miss_col must be COMPLETE in device memory when the call is made,
+ * independently of `stream` -- the mask tables that depend only on them and on the template are built on the context's side
+ * streams as soon as the call is entered, beside whatever `stream` is still running (the staging of the maps); only the
+ * maps themselves are ordered behind `stream`.  A caller that produces the flags on `stream` synchronises it (or waits for
+ * an event of it) first.  While an asynchronous batch is pending on the context (cs_detect_foci_batch_finish not yet
+ * called) every foci / quantify entry on it answers CS_ERR_INVALID: they share its count words, block tables and pool. */
 int cs_detect_foci_blocks(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_matrix* signals_f32,
                           const cs_kernel* kernel, const cs_normxcorr2_params* params, const cs_foci_params* foci,
                           cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows);

@@ -56,9 +56,17 @@ Rccl* rccl()
         }
     }
     for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) names.push_back(name);
-    for (const std::string& name : names) {
-        R.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+    // First of all: a librccl that is ALREADY mapped into the process (torch.distributed's, when the ranks were started
+    // under it) -- by soname with RTLD_NOLOAD, which loads nothing.  Opening another copy by path next to it would put two
+    // RCCL instances (two sets of IPC state, two proxy threads) into one process; the mapped one is bound to the same HIP
+    // runtime this library resolved, the loader keeps one libamdhip64 per soname.
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (R.lib) break;
+    }
+    for (const std::string& name : names) {
+        if (R.lib) break;
+        R.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
     }
     if (!R.lib) {
         R.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");

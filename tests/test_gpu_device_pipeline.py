@@ -192,8 +192,12 @@ def oracle_block_tables(cool, ci, cfg, max_dist, kernels, binsize):
     return out
 
 
-def compare_genome(total_bins, max_dist_bins, seed=2):
+def compare_genome(total_bins, max_dist_bins, seed=2, replay_steps=0):
+    """replay_steps > 0: parallel.genome_step that many times on the same genome -- the first step the usual way, every later
+    one the recorded call list replayed natively (chromosight_amd/plan.py, what bench.py's `sharded_genome` leg times) -- and
+    the LAST step's records against the same oracle tables (not against detect_patterns)."""
     binsize = 2000
+    oracle_tables.clear()
     template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
     cool, planted = make_cool(total_bins, max_dist_bins, binsize, seed=seed, template=template)
     dcool = pipeline.DeviceCool(cool)
@@ -220,15 +224,35 @@ def compare_genome(total_bins, max_dist_bins, seed=2):
         total = 0
         for ci in range(dcool.n_chrom):
             want = oracle_block_tables(cool, ci, cfg, md, kernels, binsize)
-            for ki, tab in enumerate(want):
-                got = rec[(rec[:, 0] == ci) & (rec[:, 5] == ki)]
-                assert got.shape[0] == tab.shape[0], (name, ci, ki, got.shape[0], tab.shape[0])
-                if tab.shape[0]:
-                    assert np.array_equal(got[:, 1:3], tab[:, :2]), (name, ci, ki)      # same foci, same order
-                    assert np.abs(got[:, 3] - tab[:, 2]).max() < 1e-9, (name, ci, ki)
-                total += tab.shape[0]
+            oracle_tables[(name, ci)] = want
+            total += check_against_oracle(rec, want, ci, name)
         n_found[name] = total
+    if replay_steps:
+        dcool.__dict__.pop("_step_plans", None)
+        steps = [parallel.genome_step(dcool, [loops, borders]) for _ in range(replay_steps)]
+        plans = dcool.__dict__["_step_plans"]
+        assert len(plans) == 1 and all(p.ok for p in plans.values()), [p.why for p in plans.values()]
+        for name, rec in zip(("loops", "borders"), steps[-1]):
+            total = sum(check_against_oracle(rec, oracle_tables[(name, ci)], ci, name + " (replayed step)") for ci in range(dcool.n_chrom))
+            assert total == n_found[name]
     return n_found, planted
+
+
+oracle_tables = {}
+
+
+def check_against_oracle(rec, want, ci, name):
+    """The records of chromosome ci (detect_genome's layout) against the oracle's per-template tables: same foci in the same
+    order, scores to 1e-9.  Returns the number of patterns."""
+    total = 0
+    for ki, tab in enumerate(want):
+        got = rec[(rec[:, 0] == ci) & (rec[:, 5] == ki)]
+        assert got.shape[0] == tab.shape[0], (name, ci, ki, got.shape[0], tab.shape[0])
+        if tab.shape[0]:
+            assert np.array_equal(got[:, 1:3], tab[:, :2]), (name, ci, ki)      # same foci, same order
+            assert np.abs(got[:, 3] - tab[:, 2]).max() < 1e-9, (name, ci, ki)
+        total += tab.shape[0]
+    return total
 
 
 # CS_GENOME_SEEDS="3,4,5": more seeded genomes for an occasional long run (seeds 3 .. 14 were run at the end of round 3)
@@ -305,7 +329,7 @@ def test_c4_genome_200k_vs_oracle_pipeline():
     """C4 of BASELINE.md at full size: 200 000 bins, 23 blocks, max_dist 1000, loops + 3 borders
     templates; every pattern table equal to the CPU oracle pipeline's (coordinates bit-exact and in
     order, scores <= 1e-9)."""
-    found, planted = compare_genome(200_000, 1000)
+    found, planted = compare_genome(200_000, 1000, replay_steps=3)       # (... and the replayed genome step bench.py times)
     print(f"C4 genome: {found} patterns, {len(planted)} planted loops")
     assert found["loops"] > 500 and found["borders"] > 10000
 

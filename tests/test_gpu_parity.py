@@ -358,3 +358,35 @@ def test_api_calls_from_several_threads_take_turns():
     for th in threads:
         th.join()
     assert not bad, sorted(set(bad))
+
+
+def test_centromeres_81x81_template_on_an_inter_block(precision):
+    """The 81 x 81 `centromeres` template shipped in chromosight_amd/kernels (outside north_star's <= 21 x 21, but reachable
+    through the boundary): an inter-chromosomal 600 x 520 block with missing bins, full mode, against the numpy oracle.
+    Served by the runtime-size kernel (cs_last_kernel() == 1).  float64 arithmetic to 1e-10; float32 sums have 6561 terms:
+    the 1e-5 bar belongs to the kernels that serve the BASELINE configurations, here the bound is 2e-4."""
+    from chromosight_amd._lib import get_device
+    kern = np.asarray(chromosight_amd.kernels.centromeres["kernels"][0], dtype=np.float64)
+    assert kern.shape == (81, 81)
+    rng = np.random.default_rng(81)
+    ms, ns = 600, 520
+    a = rng.gamma(4, 0.25, size=(ms, ns)) * (rng.random((ms, ns)) > 0.3)
+    # a planted copy of the template, so that the map holds high coefficients too
+    a[200:281, 300:381] = kern / kern.mean() * rng.gamma(50, 0.02, size=kern.shape)
+    miss_r, miss_c = np.array([7, 100, 101, 433, 599]), np.array([0, 250, 251, 252, 519])
+    a[miss_r, :] = 0
+    a[:, miss_c] = 0
+    valid_r, valid_c = np.setdiff1d(np.arange(ms), miss_r), np.setdiff1d(np.arange(ns), miss_c)
+    mask = cup.make_missing_mask((ms, ns), valid_r, valid_c, sym_upper=False)
+    got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, full=True, missing_mask=mask, missing_tol=0.5)
+    dev = get_device()
+    assert dev.lib.cs_last_kernel(dev.ctx) == 1, "expected the runtime-size kernel for an 81 x 81 template"
+    fr, fc = np.ones(ms, bool), np.ones(ns, bool)
+    fr[valid_r] = False
+    fc[valid_c] = False
+    pred = orc.framed_missing_predicate((ms, ns), kern.shape, fr, fc, False, None)
+    want, _ = orc.normxcorr2_oracle(a, kern, full=True, missing=pred, missing_tol=0.5)
+    got = got.toarray() if sp.issparse(got) else np.asarray(got)
+    err = float(np.abs(got - want).max())
+    assert want.max() > 0.5                      # the planted copy is found
+    assert err < (2e-4 if precision == "f32" else 1e-10), err

@@ -569,6 +569,96 @@ def run_c5(args, rank, local_rank, world, dist, torch):
         }))
 
 
+class SplitC4P:
+    """The north-star block at N > 1: ONE 200 000-bin block (the C4' band of rank 0's seed, the same on every rank) row-split
+    over the ranks -- strong scaling of the `north_star_c4p` leg, whose N = 1 form is the plain correlation call.  Rank r holds
+    rows split_rows(n, N)[r] of the band plus the template's halo and per step (parallel.SplitBlockScan): all-reduces the
+    per-diagonal (sum, count) of its rows (the distance law of a split block), runs the same masked tile kernel on its row
+    window, compacts the coefficients >= 0.3 of its rows and all-gathers those candidates."""
+
+    def __init__(self, dev, rank, world, precision, n=None):
+        from chromosight_amd import engine, parallel
+        from chromosight_amd._lib import CsMatrix, LAYOUT_BAND, MASK_BINS, np_dtype_code
+        from tools.synthetic_genome import band_workload
+        band, band_w, miss, n, max_dist = band_workload("c4p", 0, n=n)
+        self.n, self.max_dist, self.dev = n, max_dist, dev
+        a, b = self.rows = parallel.split_rows(n, world)[rank]
+        kh = 8
+        ra, rb = max(0, a - kh), min(n, b + kh)
+        own = band[a:b, :band_w]
+        law_part = np.concatenate([own.sum(axis=0, dtype=np.float64), (own > 0).sum(axis=0).astype(np.float64)])
+        slab = np.ascontiguousarray(band[ra:rb])
+        ld_in = band.shape[1]
+        del band, own
+        self.out_w = out_w = max_dist + 1
+        ld_out = (out_w + 63) // 64 * 64
+        f32 = np_dtype_code(np.float32)
+        self.sig_buf, self.out_buf, self.miss_buf = dev.to_device(slab), dev.zeros((b - a, ld_out), np.float32), dev.to_device(miss)
+        sig = CsMatrix(self.sig_buf.ptr, f32, LAYOUT_BAND, ld_in, 0, band_w, ra)
+        out = CsMatrix(self.out_buf.ptr, f32, LAYOUT_BAND, ld_out, 0, out_w, a)
+        # the rank's output rows as a matrix of their own (rows and columns counted from `a`: same diagonals, same storage)
+        out_local = CsMatrix(self.out_buf.ptr, f32, LAYOUT_BAND, ld_out, 0, out_w, 0)
+        kspec = engine.KernelSpec(loops_kernel())
+        ev0, ev1 = dev.new_event(), dev.new_event()
+        self.kernel_ms = []
+
+        def correlate():
+            dev.record(ev0)
+            engine.run_normxcorr2(dev, sig, (n, n), kspec, out, full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS,
+                                  miss_row=self.miss_buf, miss_col=self.miss_buf, missing_tol=0.5, precision=precision,
+                                  row_window=(a, b))
+            dev.record(ev1)
+
+        def candidates():
+            rows, cols, vals = engine.run_compact(dev, out_local, (b - a, n - a), 0.3, 0, max_dist)
+            self.kernel_ms.append(dev.elapsed_ms(ev0, ev1))       # (run_compact's download has synchronised the stream)
+            return np.column_stack([rows.astype(np.float64) + a, cols.astype(np.float64) + a, vals])
+
+        self.scan = parallel.SplitBlockScan(n, law_part, correlate, candidates)
+
+
+def _barrier(dist, local_rank):
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
+
+
+def time_c4p_split(dev, rank, local_rank, world, dist, precision, full_sync, reduce_max, steps=20, warmup=3, n=None):
+    """Times SplitC4P: `value` = the block's pixels x steps / max-over-ranks wall time (barriers and device synchronisation on
+    both sides of the timed steps)."""
+    from chromosight_amd import parallel
+    w = SplitC4P(dev, rank, world, precision, n=n)
+    scan, merged = w.scan, None
+    for _ in range(warmup):
+        _law, merged = scan.step()
+    full_sync()
+    _barrier(dist, local_rank)
+    w.kernel_ms.clear()
+    t0 = time.perf_counter()
+    ex = 0.0
+    for _ in range(steps):
+        _law, merged = scan.step()
+        ex += scan.exchange_ms
+    full_sync()
+    _barrier(dist, local_rank)
+    elapsed = reduce_max(time.perf_counter() - t0)
+    mine = {"rank": rank, "rows": [int(w.rows[0]), int(w.rows[1])], "kernel_ms": round(float(np.mean(w.kernel_ms)), 4),
+            "exchange_ms": round(ex / steps, 4)}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    kid = int(dev.lib.cs_last_kernel(dev.ctx))
+    n, out_w = w.n, w.out_w
+    return {"value": round(n * out_w * steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "strong", "transport": parallel.transport(),
+            "per_rank": per_rank, "kernel_id": kid, "pixels_per_step": n * out_w,
+            "candidates": int(len(merged)) if merged is not None else 0,
+            "workload": f"C4P split: ONE N={n} block (band 0..{w.max_dist + 17}, 2% missing bins, rank 0's seed on every rank) row-split "
+                        f"over {world} ranks: per step the distance law's (sum, count) all-reduced, normxcorr2(full=True, sym_upper, "
+                        f"mask, max_dist={w.max_dist}) on the rank's row window (slab + halo resident), coefficients >= 0.3 compacted "
+                        "and all-gathered; N = 1 is the `north_star_c4p` leg (the correlation call alone)"}
+
+
 def spawn_ranks(n_gpus):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script with
     torch.distributed.run on 127.0.0.1 (one process per GPU) and relay their output."""
@@ -710,6 +800,12 @@ def main():
         except Exception as exc:
             c4p = {"error": repr(exc)}
         extras["north_star_c4p"] = c4p
+        # ... and the north-star sentence itself at N > 1: the ONE 200 000-bin block split over the ranks (strong scaling)
+        if world > 1:
+            try:
+                extras["north_star_c4p_split"] = time_c4p_split(dev, rank, local_rank, world, dist, args.precision, full_sync, reduce_max)
+            except Exception as exc:
+                extras["north_star_c4p_split"] = {"error": repr(exc)}
 
     # C3 as BASELINE.md defines it (pixel table in, detrend included) next to it: the one single-GPU BASELINE configuration
     # whose step is more than the correlation call -- staging kernels (law, finish, tiler), mask tables, tile kernel
@@ -751,6 +847,8 @@ def main():
         out = dict(head)
         if c4p is not None:
             out["north_star_c4p"] = c4p
+        if "north_star_c4p_split" in extras:
+            out["north_star_c4p_split"] = extras["north_star_c4p_split"]
         if c3 is not None:
             out["c3_from_csr"] = c3
         if genome is not None:

@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import pathlib
 import threading
+import weakref
 
 import numpy as np
 
@@ -383,6 +384,16 @@ class _PinnedLease:
             pass
 
 
+# every live Device by its context handle: who holds a raw context (a recorded call list, plan.StepPlan) finds the object whose
+# lock serialises its use
+_DEVICES_BY_CTX = weakref.WeakValueDictionary()
+
+
+def device_of(ctx):
+    """The Device that owns the context handle `ctx`, or None."""
+    return _DEVICES_BY_CTX.get(int(ctx)) if ctx else None
+
+
 class Device:
     """One context on one GPU (one per process in multi-GPU runs)."""
 
@@ -401,6 +412,7 @@ class Device:
                 "This package has no CPU fallback."
             )
         self.ctx = ctx.value
+        _DEVICES_BY_CTX[self.ctx] = self
 
     def __del__(self):
         try:

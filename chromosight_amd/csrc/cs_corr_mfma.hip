@@ -413,7 +413,7 @@ struct MfmaDenseArgs {
     const uint4* frag;
     float w_unscale;
     float wa_unscale, wb_unscale;    // REG: power-of-two scales of the Wa / Wb sets (float16 range)
-    int xcd_order;           // 1: contiguous tile ranges per XCD
+    int xcd_order;           // bit 0: contiguous tile ranges per XCD; bits 1-2 (dense instances): column skew per tile row
     int dbg;                 // diagnostics (CHROMOSIGHT_HIP_MFMA_DBG): skip 1 stores, 2 prefetch, 4 box sums, 8 cross term
     KernelStats<float> ks;
     // ---- REG instances: per-bin missing masks through the factorised tables of cs_mask_prep.hip, any
@@ -722,6 +722,35 @@ static hipError_t allow_big_lds(const void* fn)
     return e;
 }
 
+// Column skew per tile row (0 .. 3) of a dense map's tile order (cs_corr_mfma_body.inc tile_origin): the smallest one under
+// which a workgroup, stepping `step` tiles at a time through the row-major tile list, does not come back to the column of
+// earlier tiles during its first eight steps (most distinct columns).  Measured (profiles/r05_dense_sizes.txt): a straight walk down one column --
+// tiles_x = 64 with 64 workgroups per XCD -- costs 13 % of the map; 65 columns are fine as they are and would be hurt by a
+// skew of 1 (64 + 65 = 129 = 2 x 65 - 1: the skewed walk is the straight one).
+static int dense_tile_skew(int tiles_x, long long n_tiles, int step)
+{
+    if (tiles_x <= 2 || step <= 0) return 0;
+    int best = 0, best_score = -1;
+    for (int s = 0; s < 4; ++s) {
+        int cols[8], n = 0, score = 0;
+        long long t = 0;
+        for (int k = 0; k < 8 && t < n_tiles; ++k, t += step) {
+            const long long by = t / tiles_x;
+            cols[n++] = (int)((t - by * tiles_x + by * s) % tiles_x);
+        }
+        for (int a = 0; a < n; ++a) {                       // distinct columns among the first eight tiles
+            bool seen = false;
+            for (int b = 0; b < a; ++b) seen |= cols[b] == cols[a];
+            score += !seen;
+        }
+        if (score > best_score) {
+            best_score = score;
+            best = s;
+        }
+    }
+    return best;
+}
+
 int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t stream, int* dense_path)
 {
     *dense_path = 0;
@@ -862,6 +891,8 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         if (e2 != hipSuccess) return (int)e2;
         const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
         const int grid = (int)std::min<long long>(blocks, (long long)per_cu * A.n_cu);
+        if (!getenv("CHROMOSIGHT_HIP_NO_SKEW"))
+            D.xcd_order |= dense_tile_skew(A.tiles_x, blocks, (D.xcd_order & 1) && grid % 8 == 0 ? grid / 8 : grid) << 1;
         if (vec4) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
         else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
         return (int)hipGetLastError();

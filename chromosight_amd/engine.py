@@ -84,17 +84,12 @@ def min_present(kernel_shape, missing_tol):
 @_one_call_per_context
 def run_normxcorr2(dev, sig, shape, kspec, out, *, full, sym_upper, max_dist, mask_mode=MASK_NONE,
                    miss_row=None, miss_col=None, mask=None, missing_tol=0.75, nobs=None,
-                   precision=None, stream=None):
-    """sig / out / nobs are CsMatrix; miss_row / miss_col / mask are DeviceBuffers (uint8)."""
-    params = CsNormxcorr2Params(
-        int(shape[0]), int(shape[1]), int(bool(full)), int(bool(sym_upper)),
-        -1 if max_dist is None else int(max_dist), int(mask_mode),
-        miss_row.ptr if miss_row is not None else None,
-        miss_col.ptr if miss_col is not None else None,
-        mask.ptr if mask is not None else None,
-        min_present((kspec.km, kspec.kn), missing_tol), compute_code(precision),
-        XCORR_THRESHOLD, DENOM_EPS,
-    )
+                   precision=None, stream=None, row_window=None):
+    """sig / out / nobs are CsMatrix; miss_row / miss_col / mask are DeviceBuffers (uint8).  row_window = (a, b): only the
+    output rows a <= i < b are produced (geometry and masks stay those of the whole matrix; sig / out may be slabs that
+    start at CsMatrix.row0)."""
+    params = _corr_params(shape, kspec, full, sym_upper, max_dist, mask_mode, miss_row, miss_col, mask, missing_tol,
+                          compute_code(precision), row_window)
     dev._check(dev.lib.cs_normxcorr2(dev.ctx, stream, C.byref(sig), C.byref(kspec.struct), C.byref(params),
                                      C.byref(out), C.byref(nobs) if nobs is not None else None))
     return params

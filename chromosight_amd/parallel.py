@@ -248,7 +248,7 @@ def _allreduce_sum(array):
         return comm.allreduce_sum(array).reshape(np.shape(array))
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to(dev)
+    t = torch.from_numpy(np.array(array, dtype=np.float64, order="C")).to(dev)     # (a copy: on CPU ranks `.to` shares the caller's memory)
     dist.all_reduce(t)
     return t.cpu().numpy()
 
@@ -310,6 +310,49 @@ def stage_split(genome, ci, kernel_config, smooth=False, band_dtype=np.float64, 
         return genome.stage_intra(ci, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=resident)
     return genome.stage_intra(ci, max_dist, largest, smooth=smooth, band_dtype=band_dtype, resident=resident, rows=rows,
                               reduce=_allreduce_sum)
+
+
+class SplitBlockScan:
+    """The correlation pass of ONE sub-matrix row-split over all ranks (the single 200 000-bin block of the
+    north star), at map level: rank r owns the output rows split_rows(n, world)[r] and holds only those rows of the band plus
+    the template's halo (cs_matrix.row0: no halo exchange).  One step is what the split costs a rank beside its share of
+    the tiles:
+
+      1. the per-diagonal (sum, count) of the distance law of its rows all-reduced -- every part must be detrended by the
+         same law (stage_split does this once per staging; here it is part of every step so that the collective is timed);
+      2. `correlate()`: the coefficient map of its rows (engine.run_normxcorr2(..., row_window=rows));
+      3. `candidates()`: the (row, col, value) triples of its rows at or above the threshold, all-gathered so that every
+         rank can label the same merged list (detect_split_block continues from there).
+
+    correlate / candidates are the caller's closures (device calls in bench.py and the GPU tests, numpy stand-ins in the CPU
+    test); with one rank the step is the correlation call alone -- the exchanges fall away, which makes the 1-rank figure
+    the plain kernel figure.  Times of the last step: `exchange_ms` (both collectives), `step_ms`."""
+
+    def __init__(self, n, law_part, correlate, candidates):
+        dist, self.rank, self.world = _world()
+        self.n = int(n)
+        self.rows = split_rows(self.n, self.world)[self.rank]
+        self.law_part = np.ascontiguousarray(law_part, dtype=np.float64)
+        self.correlate, self.candidates = correlate, candidates
+        self.exchange_ms = self.step_ms = 0.0
+
+    def step(self):
+        import time
+        t0 = time.perf_counter()
+        if self.world == 1:
+            self.correlate()
+            self.step_ms = (time.perf_counter() - t0) * 1e3
+            return self.law_part, None
+        law = _allreduce_sum(self.law_part)
+        t1 = time.perf_counter()
+        self.correlate()
+        cand = np.ascontiguousarray(self.candidates(), dtype=np.float64).reshape(-1, 3)
+        t2 = time.perf_counter()
+        merged = all_gather_rows(cand)
+        t3 = time.perf_counter()
+        self.exchange_ms = ((t1 - t0) + (t3 - t2)) * 1e3
+        self.step_ms = (t3 - t0) * 1e3
+        return law, merged
 
 
 def _gather(records, n_fields):

@@ -75,13 +75,13 @@ class StepPlan:
             return
         self.genome, self.owned, self.staged = genome, list(owned), staged
         # the two contexts the list runs on, as the objects whose locks serialise their use (the genome's own; the worker context
-        # of the 1-D chain, pipeline.async_device)
-        from . import pipeline as _pipeline
-        dev_b = [d for d, _s in _pipeline._ASYNC_DEVICES.values() if d.ctx == ctx_b]
-        if not dev_b:
+        # of the 1-D chain: a pattern thread's, pipeline._Workers.device)
+        dev_b = _lib.device_of(ctx_b)
+        if dev_b is None:
             self.why = "the 1-D chain ran on a context this process does not manage"
             return
-        self.locks = (genome.dev.lock, dev_b[0].lock)
+        self.locks = (genome.dev.lock, dev_b.lock)
+        self.dev_b = dev_b                                   # (the worker context stays alive with the plan)
         self.keep = (captured, kernel_configs)               # every argument array stays alive with the plan
         self.n_blocks = int(blocks[0][2])
         self.n_templates = int(batch[0][4])

@@ -299,3 +299,69 @@ def test_split_block_three_ranks(tmp_path):
         assert np.array_equal(got[k][:, :2], want[k][:, :2])
         assert np.abs(got[k][:, 2] - want[k][:, 2]).max() < 1e-9
         assert np.allclose(got[k + 1], want[k + 1], rtol=0, atol=1e-9, equal_nan=True)
+
+
+SPLIT_WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["CS_ROOT"])
+import torch.distributed as dist
+import bench
+from chromosight_amd._lib import get_device
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = get_device(0)
+w = bench.SplitC4P(dev, rank, world, "f32", n=int(os.environ["CS_N"]))
+for _ in range(2):
+    law, merged = w.scan.step()
+np.savez(os.environ["CS_OUT"] + f".{rank}.npz", rows=np.asarray(w.rows), out=w.out_buf.download()[:, :w.out_w], law=law, merged=merged)
+# ... and the timed form of the same leg (what bench.py --gpus N prints), two steps
+def reduce_max(x):
+    import torch
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+leg = bench.time_c4p_split(dev, rank, 0, world, dist, "f32", dev.sync, reduce_max, steps=2, warmup=1, n=int(os.environ["CS_N"]))
+assert leg["n_gpus"] == world and len(leg["per_rank"]) == world and leg["kernel_id"] == 5 and leg["candidates"] == len(merged), leg
+dist.destroy_process_group()
+"""
+
+
+def test_split_map_two_ranks_equal_the_one_rank_map(tmp_path):
+    """bench.py's `north_star_c4p_split` leg (parallel.SplitBlockScan, N > 1) on 2 ranks (gloo rendezvous, both on this GPU)
+    with a 6000-bin block of the C4' generator: the two ranks' row windows together ARE the one-rank coefficient map
+    (to 2e-6: same kernel, other tile boundaries), the merged candidates are the pixels >= 0.3 of the ranks' rows in row-major
+    order on both ranks, the all-reduced law sums are those of the whole band."""
+    import bench
+    from tools.synthetic_genome import band_workload
+    n = 6000
+    dev = get_device()
+    one = bench.SplitC4P(dev, 0, 1, "f32", n=n)
+    one.scan.step()
+    dev.sync()
+    full = one.out_buf.download()[:, :one.out_w]
+    assert dev.lib.cs_last_kernel(dev.ctx) == 5
+    band, band_w, _miss, _n, max_dist = band_workload("c4p", 0, n=n)
+    out = tmp_path / "split"
+    script = tmp_path / "worker.py"
+    script.write_text(SPLIT_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CS_ROOT=root, CS_OUT=str(out), CS_N=str(n), CHROMOSIGHT_HIP_DEVICE="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    parts = [np.load(f"{out}.{r}.npz") for r in range(2)]
+    assert [tuple(p["rows"]) for p in parts] == parallel.split_rows(n, 2)
+    got = np.concatenate([p["out"] for p in parts], axis=0)
+    # (a window that does not start on a tile boundary of the whole map is cut into other tiles: other power-of-two scales per
+    # tile, last-bit differences -- the tolerance of the row-window tests above)
+    assert got.shape == full.shape and np.abs(got - full).max() <= 2e-6
+    ii, dd = np.nonzero(got >= 0.3)
+    want = np.column_stack([ii, ii + dd, got[ii, dd].astype(np.float64)])
+    assert abs(len(want) - int((full >= 0.3).sum())) <= 2
+    assert len(want) > 20
+    own = band[:, :band_w]
+    law = np.concatenate([own.sum(axis=0, dtype=np.float64), (own > 0).sum(axis=0).astype(np.float64)])
+    for p in parts:
+        assert np.array_equal(p["merged"], want)
+        assert np.allclose(p["law"], law, rtol=1e-12, atol=0)

@@ -240,3 +240,64 @@ def test_quantify_shard_world2(tmp_path):
     # a single process keeps everything and exchanges nothing
     alone = parallel.QuantifyShard()
     assert alone.select(todo, _QGenome(), 30) == todo
+
+
+# ------------------------------------------------------------------------------------------------
+# one sub-matrix row-split over the ranks, map level (bench.py's `north_star_c4p_split` leg at N > 1)
+# ------------------------------------------------------------------------------------------------
+def _split_case(n=101, w=7):
+    """A deterministic 'band' of n rows x w diagonals and its 'coefficient map' (a stand-in: the correlation itself is the
+    device's business, tests/test_gpu_row_window.py)."""
+    rng = np.random.default_rng(7)
+    band = rng.poisson(3.0, size=(n, w)).astype(np.float64)
+    corr = rng.random((n, w))
+    return band, corr
+
+
+def _split_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        band, corr = _split_case()
+        n, w = band.shape
+        a, b = parallel.split_rows(n, world)[rank]
+        own = band[a:b]
+        law_part = np.concatenate([own.sum(axis=0), (own > 0).sum(axis=0).astype(np.float64)])
+        calls = []
+
+        def correlate():
+            calls.append("correlate")
+
+        def candidates():
+            calls.append("candidates")
+            r, d = np.nonzero(corr[a:b] >= 0.8)
+            return np.column_stack([r + a, r + a + d, corr[a:b][r, d]])
+
+        scan = parallel.SplitBlockScan(n, law_part, correlate, candidates)
+        assert scan.rows == (a, b)
+        for _ in range(2):
+            law, merged = scan.step()
+        assert calls == ["correlate", "candidates"] * 2 and scan.step_ms >= scan.exchange_ms >= 0.0
+        np.save(os.path.join(out_dir, f"law{rank}.npy"), law)
+        np.save(os.path.join(out_dir, f"cand{rank}.npy"), merged)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_block_scan_world2(tmp_path):
+    """parallel.SplitBlockScan on 2 ranks (gloo): the all-reduced (sum, count) of the law and the all-gathered candidates are
+    those of the whole block, on every rank, in row order; one rank: the step is the correlation call alone."""
+    world = 2
+    mp.spawn(_split_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    band, corr = _split_case()
+    want_law = np.concatenate([band.sum(axis=0), (band > 0).sum(axis=0).astype(np.float64)])
+    r, d = np.nonzero(corr >= 0.8)
+    want_cand = np.column_stack([r, r + d, corr[r, d]])
+    for rank in range(world):
+        assert np.allclose(np.load(tmp_path / f"law{rank}.npy"), want_law, rtol=1e-14, atol=0)
+        assert np.array_equal(np.load(tmp_path / f"cand{rank}.npy"), want_cand)
+    done = []
+    scan = parallel.SplitBlockScan(band.shape[0], want_law, lambda: done.append(1), lambda: 1 / 0)
+    law, merged = scan.step()
+    assert done == [1] and merged is None and scan.rows == (0, band.shape[0]) and np.array_equal(law, want_law)

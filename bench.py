@@ -501,14 +501,14 @@ def run_c4(args, rank, local_rank, world, dist, torch):
         }))
 
 
-def run_c5(args, rank, local_rank, world, dist, torch):
+def time_c5(local_rank, world, dist, torch, steps, warmup):
     """C5 of BASELINE.md: `quantify --inter` with the three 11 x 11 borders templates on the committed 17-chromosome
     yeast map (tests/golden/yeast_cool.npz, the decoded .cool; positions = the fixture's: cohesin-peak pairs on the
     intra blocks, seeded positions on the inter blocks).  The pixel table is uploaded once (DeviceCool, reported under
     `setup`); one step = pipeline.quantify from the resident table: staging of every sub-matrix that holds a position
     (detrend / median scaling), one native call per template over all of them, best-of-templates selection.  N > 1: the
     sub-matrices are dealt to the ranks (parallel.quantify_genome: the reference's pool over sub-matrices), one exchange of
-    scores and windows, every rank assembles the table -- strong scaling of one fixed job."""
+    scores and windows, every rank assembles the table -- strong scaling of one fixed job.  Returns the leg's dictionary."""
     import pandas as pd
     from chromosight_amd import parallel, pipeline
     from chromosight_amd._lib import get_device
@@ -541,11 +541,11 @@ def run_c5(args, rank, local_rank, world, dist, torch):
             dist.barrier(device_ids=[local_rank])
 
     table = None
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         table, _w = run()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         table, _w = run()
     sync()
     elapsed = time.perf_counter() - t0
@@ -553,20 +553,25 @@ def run_c5(args, rank, local_rank, world, dist, torch):
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms = elapsed / args.steps * 1e3
+    ms = elapsed / steps * 1e3
+    n_fixture = int(sum(len(g[f"b{bi}_coords"]) for bi in range(int(g["n_blocks"]))))
+    return {
+        "value": round(len(positions) * 3 / (ms * 1e-3), 1), "unit": "scored (position, template) pairs/s",
+        "n_gpus": world, "steps": steps, "warmup": max(warmup, 1), "ms_per_step": round(ms, 3), "scaling": "strong", "dtype": "f64",
+        "data": "tests/golden/yeast_cool.npz (real map, committed fixture)",
+        "config": {"workload": "C5: 17-chromosome yeast map (6074 bins), quantify --inter, win-size 11, "
+                               f"{len(positions)} positions ({n_inter} on inter-chromosomal blocks), pixel table resident in HBM",
+                   "positions": len(positions), "positions_in_fixture": n_fixture, "templates": 3, "rows_out": int(len(table)),
+                   "parallelism": f"{world} rank(s), sub-matrices dealt longest-first, one exchange of scores + windows"},
+        "setup": {"upload_ms": round(upload_ms, 3), "upload_bytes": int(dcool.upload_bytes)},
+    }
+
+
+def run_c5(args, rank, local_rank, world, dist, torch):
+    r = time_c5(local_rank, world, dist, torch, args.steps, args.warmup)
     if rank == 0:
-        print(json.dumps({
-            "metric": "positions/s quantify end to end (C5: yeast, --inter, 3 x 11x11 borders templates)",
-            "value": round(len(positions) * 3 / (ms * 1e-3), 1), "unit": "scored (position, template) pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "tests/golden/yeast_cool.npz (real map, committed fixture)",
-            "config": {"workload": "C5: 17-chromosome yeast map (6074 bins), quantify --inter, win-size 11, "
-                                   f"{len(positions)} positions ({n_inter} on inter-chromosomal blocks), pixel table resident in HBM",
-                       "positions": len(positions), "templates": 3, "rows_out": int(len(table)),
-                       "parallelism": f"{world} rank(s), sub-matrices dealt longest-first, one exchange of scores + windows"},
-            "setup": {"upload_ms": round(upload_ms, 3), "upload_bytes": int(dcool.upload_bytes)},
-        }))
+        print(json.dumps(dict({"metric": "positions/s quantify end to end (C5: yeast, --inter, 3 x 11x11 borders templates)",
+                               "higher_is_better": True, "vs_baseline": None}, **r)))
 
 
 class SplitC4P:
@@ -858,6 +863,13 @@ def main():
                 out["detect_wallclock"] = detect_wallclock()
             except Exception as exc:
                 out["detect_wallclock"] = {"error": repr(exc)}
+            try:
+                # C5 of BASELINE.md (quantify --inter on the committed yeast map) next to it: ~ 5 ms per step
+                q = time_c5(local_rank, 1, None, torch, steps=10, warmup=2)
+                q["positions_match_fixture"] = bool(q["config"]["rows_out"] == q["config"]["positions"] == q["config"]["positions_in_fixture"])
+                out["quantify_c5"] = q
+            except Exception as exc:
+                out["quantify_c5"] = {"error": repr(exc)}
             try:
                 out["api_call_ms"] = api_call_ms(wl)
                 out["api_call_note"] = ("host float32 ndarray in (pageable source, uploaded in 12 row slabs), float64 ndarray out "

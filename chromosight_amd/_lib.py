@@ -139,7 +139,7 @@ class CsCall(C.Structure):
 
 
 CALL_STAGE_BLOCKS, CALL_EVENT_RECORD, CALL_STREAM_WAIT_EVENT, CALL_DETECT_FOCI_BLOCKS, CALL_DETECT_FOCI_BATCH_TEMPLATES, \
-    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_WAIT_TILE_LAUNCH, CALL_STREAM_DELAY = 1, 2, 3, 4, 5, 6, 7, 8, 9
+    CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_STREAM_WAIT_TILES = 1, 2, 3, 4, 5, 6, 7, 9
 
 # While a list is installed here, the entries named in _CAPTURED append (name, arguments) to it AFTER running as usual:
 # chromosight_amd/plan.py turns the calls of one genome step into a cs_run_calls list.
@@ -174,7 +174,7 @@ _PROTOTYPES = {
     "cs_event_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cs_event_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "cs_stream_delay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "cs_stream_wait_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "cs_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "cs_normxcorr2": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                 C.POINTER(CsNormxcorr2Params), C.POINTER(CsMatrix), C.POINTER(CsMatrix)]),
@@ -480,9 +480,10 @@ class Device:
             self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))
         return s.value
 
-    def stream_delay(self, stream, microseconds):
-        """cs_stream_delay: one sleeping wave keeps `stream` busy for about that long."""
-        self._check(self.lib.cs_stream_delay(self.ctx, stream, int(microseconds)))
+    def stream_wait_tiles(self, stream, tiles_dev, timeout_us=500):
+        """cs_stream_wait_tiles: work enqueued on `stream` afterwards starts when the tile workgroups of tiles_dev's next multi-block
+        tile launch are resident (or after the time-out)."""
+        self._check(self.lib.cs_stream_wait_tiles(self.ctx, stream, tiles_dev.ctx, int(timeout_us)))
 
     def new_event(self):
         e = C.c_void_p()

@@ -70,14 +70,14 @@ struct cs_ctx {
     void* h_tab = nullptr;
     void* d_tab = nullptr;
     size_t tab_bytes = 0;
-    // mask tables of all blocks in one launch: while set, prepare_regular_mask<float> appends a block's arguments and its
-    // number of workgroups here instead of launching (cs::launch_mask_prep_batch)
-    std::vector<cs::MaskPrepArgs<float>>* prep_defer = nullptr;
-    std::vector<int> prep_groups;
+    // one device word: set by the last workgroup of a multi-block tile launch when it starts (all of them are resident then),
+    // consumed by cs_stream_wait_tiles -- the dependency that lets a side chain run in what the tile workgroups leave
+    unsigned* d_tiles_started = nullptr;
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
-    long long* h_cand_counts = nullptr;   // pinned, 64 entries: the blocks' own candidate counts (cs_detect_foci_blocks, segmented lists)
+    long long* h_cand_counts = nullptr;   // pinned, 256 entries (cs_detect_foci_blocks, segmented lists): [b] the blocks' own candidate counts, [60] their
+                                          // clamped total, [61] status flags; [64 + b] / [128 + b]: the regions' starts / rooms the device reads
     void* d_counts_peak = nullptr;   // cs_normxcorr2_host: largest |pixel| of the map (float bits), and its pinned copy
     unsigned* h_peak = nullptr;
     // grow-only scratch for the mask tables of the streaming kernel (one call in flight per context)
@@ -224,16 +224,15 @@ private:
     size_t threads_ = 0;
 };
 
-// cs_stream_delay: one wave that sleeps until the constant-rate counter (100 MHz) has advanced by `ticks`
-__global__ void cs_delay_kernel(long long ticks)
+// cs_stream_wait_tiles: one wave that sleeps until the word is set (the tile workgroups of another stream are resident), takes
+// it back, and gives up after `ticks` of the constant-rate counter (100 MHz) -- the word is a scheduling hint, never a lock
+__global__ void cs_wait_tiles_kernel(unsigned* word, long long ticks)
 {
     const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(16);
+    if (threadIdx.x == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// bumped by cs_detect_foci_blocks once its tile kernels are launched: a lane of cs_run_calls can hold its own launch chain back
-// until then (CS_CALL_WAIT_TILE_LAUNCH), so that the persistent tile workgroups take their slots on an empty device
-std::atomic<long long> g_tile_launch_seq{0};
 
 struct Laps {
     bool on;
@@ -269,26 +268,6 @@ int fail(cs_ctx* ctx, int code, const char* fmt, ...)
         if (e_ != hipSuccess)                                                                \
             return fail(ctx, CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
     } while (0)
-
-// Wait for a stream on the paths where the wake-up is part of a step's critical path (the candidate count and the records of the
-// batched foci entries): hipStreamSynchronize blocks on an interrupt and the thread comes back tens of microseconds after the
-// work is done; polling the stream costs a core for the few hundred microseconds of a chain and returns within a microsecond
-// or two.  After ~ 5 ms of polling (a long scan) the blocking wait takes over.  MEASURED NEUTRAL on a rank's share of 8 and on the
-// genome (medians 0.71-0.76 / 3.30-3.35 ms either way on one box: the runtime's own wait already polls before it blocks), so
-// it is opt-in: CHROMOSIGHT_HIP_SPIN_WAIT=1.
-static hipError_t wait_stream_hot(hipStream_t stream)
-{
-    const bool spin = std::getenv("CHROMOSIGHT_HIP_SPIN_WAIT") != nullptr;      // (read per call: the switch test flips it)
-    if (spin) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int it = 0;; ++it) {
-            const hipError_t e = hipStreamQuery(stream);
-            if (e != hipErrorNotReady) return e;
-            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
-        }
-    }
-    return hipStreamSynchronize(stream);
-}
 
 // every entry point that launches, copies or allocates first makes the context's GPU current: a
 // process may hold contexts on several devices
@@ -717,17 +696,7 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     P.side = side;
     P.fix_rows = fix_rows;
     P.fix_cols = fix_cols;
-    bool deferred = false;
-    if constexpr (std::is_same<TC, float>::value) {
-        if (ctx->prep_defer) {
-            const int n_wg = cs::mask_prep_blocks<float>(P);
-            if (n_wg < 0) return fail(ctx, CS_ERR_HIP, "mask tables: template too large");
-            ctx->prep_defer->push_back(P);
-            ctx->prep_groups.push_back(n_wg);
-            deferred = true;
-        }
-    }
-    if (!deferred) {
+    {
         int rc = cs::launch_mask_prep<TC>(P, stream);
         if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
     }
@@ -1161,6 +1130,10 @@ int cs_ctx_create(int device, cs_ctx** out)
     cs_ctx* ctx = new cs_ctx();
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
+    if (hipMalloc((void**)&ctx->d_tiles_started, 256) != hipSuccess || hipMemset(ctx->d_tiles_started, 0, 256) != hipSuccess) {
+        delete ctx;
+        return CS_ERR_HIP;
+    }
     *out = ctx;
     return CS_OK;
 }
@@ -1175,6 +1148,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
             if (pk.d) (void)hipFree(pk.d);
     }
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_tiles_started) (void)hipFree(ctx->d_tiles_started);
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_rim) (void)hipFree(ctx->d_rim);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
@@ -1326,11 +1300,12 @@ int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event)
     return CS_OK;
 }
 
-int cs_stream_delay(cs_ctx* ctx, void* stream, int32_t microseconds)
+int cs_stream_wait_tiles(cs_ctx* ctx, void* stream, cs_ctx* tiles_ctx, int32_t timeout_us)
 {
     CS_ENTER(ctx);
-    if (microseconds <= 0) return CS_OK;
-    hipLaunchKernelGGL(cs_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)std::min(microseconds, 1000) * 100);
+    if (!tiles_ctx || !tiles_ctx->d_tiles_started || tiles_ctx->device != ctx->device) return fail(ctx, CS_ERR_INVALID, "no tile context on this device");
+    hipLaunchKernelGGL(cs_wait_tiles_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tiles_ctx->d_tiles_started,
+                       (long long)std::max(1, std::min(timeout_us, 5000)) * 100);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
 }
@@ -2391,7 +2366,7 @@ int cs_detect_foci_batch_finish(cs_ctx* ctx, void* stream_, int64_t* h_n_foci)
     if (!ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "no batch is pending on this context");
     const int n_virtual = ctx->nb_pending;
     ctx->nb_pending = 0;
-    CS_HIP(ctx, wait_stream_hot((hipStream_t)stream_));            // also: the host tables were consumed
+    CS_HIP(ctx, hipStreamSynchronize((hipStream_t)stream_));            // also: the host tables were consumed
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
     for (int v = 0; v < n_virtual; ++v) h_n_foci[v] = ctx->h_blk_counts[1 + v];
@@ -2475,16 +2450,11 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     const double margin = std::max(foci[0].rescore_margin, 1e-4);
     const double thr = foci[0].pearson - margin;
     size_t c_cap = std::max<size_t>(1 << 16, (size_t)(pixels / 256));
-    // One synchronisation per call when the PREVIOUS call on this context scanned the same layout (a run's steps, an iterated
-    // template's passes): the candidate list is then given room for 1.25 x that call's candidates -- not the 8 x of the
-    // a-priori capacity, whose sort and launches had made the single-synchronisation chain the slower one -- and the chain
-    // behind the tile kernels is enqueued without waiting for the count; a list that outgrows its room shows in the count at
-    // the end and the call repeats with room, as before.  Nothing but a SIZE is carried over.  MEASURED NEUTRAL TO SLOWER (a share
-    // of 8: 0.574-0.595 against 0.565-0.602 ms, the genome 2.97 against 2.91: the bounded chain's sentinels, its launches at
-    // capacity and the one more key bit in the sort cost what the round trip did), so it is opt-in: CHROMOSIGHT_HIP_ADAPTIVE_SYNC=1.
-    const bool adaptive = ctx->cand_hint > 0 && ctx->cand_hint_pixels == (long long)pixels && ctx->cand_hint_blocks == n_blocks &&
-                          std::getenv("CHROMOSIGHT_HIP_ADAPTIVE_SYNC") && !std::getenv("CHROMOSIGHT_HIP_ONE_SYNC");
-    if (adaptive) c_cap = std::max<size_t>(4096, (size_t)ctx->cand_hint + (size_t)ctx->cand_hint / 4 + 1024);
+    // what the previous call on this context saw: when it scanned the same layout (a run's steps, an iterated template's
+    // passes) its candidate count sizes the LAUNCHES of the chain that is enqueued before this call's count is known (below);
+    // nothing but a size is carried over
+    const bool same_layout = ctx->cand_hint > 0 && ctx->cand_hint_pixels == (long long)pixels && ctx->cand_hint_blocks == n_blocks;
+    const long long hint = same_layout ? ctx->cand_hint : 0;
     struct HintUpdate {                     // every successful exit records what this call saw
         cs_ctx* c;
         long long* n;
@@ -2495,15 +2465,13 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     long long n_total = 0;
     HintUpdate hint_update{ctx, &n_total, (long long)pixels, n_blocks};
-    bool first_pass = true;
     // SEGMENTED candidate lists: every block appends to a region of its own with a counter of its own (room in proportion to
     // its pixels), so the chain behind the tile kernels knows the blocks' segments from n_blocks counts instead of sorting
     // all candidates by block and position -- the labelling workgroup of a block sorts its own few thousand in LDS (cs_foci.hip
-    // lds_sort_pairs): no device-wide sort, no segments / split kernels (7 launches less, ~ 40 us of a rank's step).
-    // CHROMOSIGHT_HIP_NO_SEGMENTED=1: one list, sorted on the device.
-    const bool segmented_ok = n_blocks <= 60 && !std::getenv("CHROMOSIGHT_HIP_NO_SEGMENTED") && !std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") && !adaptive;
+    // lds_sort_pairs): no device-wide sort, no segments / split kernels.  CHROMOSIGHT_HIP_NO_SEGMENTED=1: one list, sorted on the device.
+    const bool segmented_ok = n_blocks <= 60 && !std::getenv("CHROMOSIGHT_HIP_NO_SEGMENTED");
     if (segmented_ok && !ctx->h_cand_counts)
-        CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_cand_counts, 64 * sizeof(long long), hipHostMallocDefault));
+        CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_cand_counts, 256 * sizeof(long long), hipHostMallocDefault));
     // (seg_tab: the n_blocks + 1 segment starts of the compact numbering, then the n_blocks region starts: one upload)
     std::vector<long long> seg_tab(2 * (size_t)n_blocks + 2, 0), seg_cap((size_t)n_blocks, 0);
     long long* const seg_off = seg_tab.data();
@@ -2531,54 +2499,26 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         unsigned long long* d_cnt = (unsigned long long*)(pool + off_cnt);       // [0] the one list's counter; [2 + b] block b's
         // (the counter is zeroed right before the tile kernels go out: on a side lane when the lanes carry the call's
         // preparations, see `early_upload` below)
-        // CHROMOSIGHT_HIP_ONE_SYNC=1 (experiment, measured SLOWER, off by default): one synchronisation per call -- the chain
-        // behind the tile kernels is enqueued WITHOUT waiting for the candidate count: the list is sorted at its full
-        // capacity, unused entries holding a sentinel that sorts last (0x7fffffff7fffffff: above every key, with the bit
-        // above the block bits set), and the kernels of the chain read the count on the device (the first sentinel's
-        // position); an overflowing list shows in the count at the end and the call repeats with room.  What it saves (the
-        // 45 us of enqueueing the chain and one wake-up) it loses to a sort and launches sized for the capacity -- 98 000
-        // entries for the 12 000 candidates of a rank's share of 8, 782 000 for the genome's 100 000: a rank's share
-        // 1.21 -> 1.27-1.32 ms per step, the 23-block genome 4.15 -> 4.34 ms.
-        const bool single_sync = std::getenv("CHROMOSIGHT_HIP_ONE_SYNC") != nullptr || (adaptive && first_pass);   // (read per call: tests flip it)
-        first_pass = false;
-        if (single_sync) CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)pool, 0x7fffffff, 2 * c_cap, stream));
         // side streams only when no block needs the (single) narrowing scratch
         bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");
         for (int b = 0; b < n_blocks && twins; ++b) twins = signals_f32[b].d_ptr != nullptr;
-        // Lanes: the blocks' persistent launches run side by side on n_lanes streams, each with 1 / n_lanes of the chip's
-        // workgroup slots -- a launch then walks n_lanes times as many tiles per workgroup (pipeline fill / drain and the
-        // rounding to whole tiles per workgroup are paid per launch), and no launch waits for slots another one holds.
+        // Lanes: the blocks' persistent launches run side by side on n_lanes streams -- a launch then walks n_lanes times as
+        // many tiles per workgroup (pipeline fill / drain and the rounding to whole tiles per workgroup are paid per launch),
+        // and no launch waits for slots another one holds.
         static const int lanes_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_LANES") ? atoi(std::getenv("CHROMOSIGHT_HIP_BLOCK_LANES")) : 3;
-        static const int share_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_SHARE") ? atoi(std::getenv("CHROMOSIGHT_HIP_BLOCK_SHARE")) : 0;
         const int n_lanes = (twins && n_blocks > 1) ? std::min(std::min(std::max(lanes_env, 1), kBlkLanes), n_blocks) : 1;
-        // one persistent launch for the tiles of all blocks (the lanes then only carry the blocks' mask tables)
-        static const char* table_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_TABLE");      // "0" / "1": force
-        const bool table = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE") && (table_env ? table_env[0] == '1' : (foci[0].exclusive != 0 || n_blocks <= 4));    // (a rank's share of a genome on 8 GPUs: 3 blocks -- one launch beats three that fight for the slots: 1.40 -> 1.29 ms per rank)
+        // one persistent launch for the tiles of all blocks (the lanes then only carry the blocks' mask tables): when the caller
+        // says nothing else is queued beside it, or for a few blocks (a rank's share of a genome on 8 GPUs: 3 blocks -- one
+        // launch beats three that fight for the slots: 1.40 -> 1.29 ms per rank)
+        const bool table = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE") && (foci[0].exclusive != 0 || n_blocks <= 4);
         // either way the blocks' launches are PREPARED first (mask tables of every block on the lanes, argument blocks in a host
         // table) and the tile kernels go out afterwards: a mask-table launch queued behind persistent tile kernels would wait
         // for their workgroups to drain, and its lane's next tile kernel with it
         const bool prepared = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE");
         if (!prepared) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (tile kernels go out block by block below)
         int table_rsym = -1;
-        // CHROMOSIGHT_HIP_PREP_BATCH=1 (experiment, measured neutral to slower, off by default): the mask tables of all blocks
-        // built by ONE launch on the caller's stream instead of one launch per block on the lanes.  The 23 launches of a
-        // genome take 220 us of device timeline, but they run WHILE the host prepares the next block's arguments (~ 9 us per
-        // block, and in a genome step all of it under the staging kernels): the one launch waits for the whole loop and the
-        // call is no shorter (loops pass of the 23-block genome 2.69 / 2.70 ms; a rank's share of 8: 0.93 -> 0.96 ms).
-        const bool prep_batch = prepared && std::getenv("CHROMOSIGHT_HIP_PREP_BATCH") != nullptr;
-        const size_t tile_tab_bytes = prepared ? al(cs::mfma_blocks_table_bytes(n_blocks)) : 0;
-        std::vector<cs::MaskPrepArgs<float>> prep_list;
-        struct PrepDefer {
-            cs_ctx* c;
-            PrepDefer(cs_ctx* c_, std::vector<cs::MaskPrepArgs<float>>* v) : c(c_)
-            {
-                c->prep_defer = v;
-                c->prep_groups.clear();
-            }
-            ~PrepDefer() { c->prep_defer = nullptr; }
-        } prep_defer(ctx, prep_batch ? &prep_list : nullptr);
         if (prepared) {
-            const size_t need = tile_tab_bytes + cs::mask_prep_table_bytes(n_blocks);
+            const size_t need = al(cs::mfma_blocks_table_bytes(n_blocks));
             if (need > ctx->tab_bytes) {
                 CS_HIP(ctx, hipDeviceSynchronize());
                 if (ctx->h_tab) CS_HIP(ctx, hipHostFree(ctx->h_tab));
@@ -2594,11 +2534,16 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 ctx->ws_tab_bytes.resize((size_t)n_blocks, 0);
             }
         }
-        struct GridCap {                      // the cap applies to the launches of this call only
-            cs_ctx* c;
-            GridCap(cs_ctx* c_, int cap) : c(c_) { c->grid_cap = cap; }
-            ~GridCap() { c->grid_cap = 0; }
-        } grid_cap(ctx, (n_lanes > 1 && share_env) ? 2 * ctx->n_cu / n_lanes : 0);
+        const bool deferred = segmented && cs::keyed_batch_deferred_available() && !std::getenv("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN");
+        if (tab.empty()) {
+            // the float64 argument blocks of the chain behind the tile kernels: built (and, for the chain that is enqueued ahead
+            // of the counts, uploaded) while the caller's stream is still staging the maps
+            tab.resize((size_t)n_blocks);
+            for (int b = 0; b < n_blocks; ++b) {
+                int rc2 = build_args<double>(ctx, stream, signals + b, kernel, params + b, &tab[b]);
+                if (rc2) return rc2;
+            }
+        }
         bool early_tables = false;
         // blocks to lanes: largest first onto the least loaded lane
         std::vector<int> lane_of((size_t)n_blocks, 0);
@@ -2618,7 +2563,13 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         }
         if (n_lanes > 1) {
             for (int k = 0; k < n_lanes - 1; ++k)
-                if (!ctx->s_blk[k]) CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_blk[k], hipStreamNonBlocking));
+                if (!ctx->s_blk[k]) {
+                    // (the lanes carry the short mask-table launches beside the caller's staging kernels, which fill every
+                    // wave slot of the chip: served first, they are done when the staging is)
+                    int lo_p = 0, hi_p = 0;
+                    CS_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+                    CS_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_blk[k], hipStreamNonBlocking, std::getenv("CHROMOSIGHT_HIP_NO_PRIORITY") ? lo_p : hi_p));
+                }
             for (int k = 0; k < kBlkLanes; ++k)
                 if (!ctx->ev_blk[k]) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_blk[k], hipEventDisableTiming));
             // template weights / matrix-core fragments are uploaded on the caller's stream (once per template): before the
@@ -2637,15 +2588,21 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             // prepared first, every block's tables are built on the SIDE lanes at once, beside whatever the caller's stream is
             // doing, and the lanes wait for that stream only when this call uploaded the template.  (The tables' scratch is
             // free: the previous call's tile kernels were synchronised before it returned.)
-            early_tables = prepared && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_TABLES");
+            early_tables = prepared && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_TABLES");
             // (without early tables the lanes' only link to this stream is the event below: the counter is zeroed before it)
             if (prepared && !early_tables) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));
-            if (!prep_batch && (!early_tables || ctx->uploads != uploads_before)) {
+            if (!early_tables || ctx->uploads != uploads_before) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));  // the counter is zero, earlier work is done
                 for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
             }
         }
         laps.lap("pool, weights, events");
+        // One tile launch + the lanes busy with the mask tables while the caller's stream is still staging the maps: the zeroed
+        // counter (first) and the argument table (behind the tables of its lane) travel on the LAST side lane, which carries the
+        // fewest tables -- ordered before the launch by the lanes' events below -- instead of sitting between the staging and
+        // the tile kernel
+        const bool early_upload = table && early_tables && n_lanes > 1;
+        if (early_upload) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[n_lanes - 2]));
         // (largest blocks first on every lane: the short ones fill the end)
         std::vector<int> launch_order((size_t)n_blocks);
         for (int b = 0; b < n_blocks; ++b) launch_order[b] = b;
@@ -2653,9 +2610,10 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             std::stable_sort(launch_order.begin(), launch_order.end(), [&](int x, int y) {
                 return (long long)params[x].ms * (foci[x].hi_diag - foci[x].lo_diag + 1) > (long long)params[y].ms * (foci[y].hi_diag - foci[y].lo_diag + 1);
             });
+        int next_side = 0;
         for (int b : launch_order) {
-            // (batched mask tables: nothing is launched per block here; early tables: on the side lanes only)
-            const int lane = prep_batch ? 0 : (early_tables && lane_of[b] == 0) ? 1 + b % (n_lanes - 1) : lane_of[b];
+            // (early tables: on the side lanes only, dealt round-robin in launch order -- largest first)
+            const int lane = early_tables ? 1 + (next_side++) % (n_lanes - 1) : lane_of[b];
             hipStream_t stream = lane == 0 ? (hipStream_t)stream_ : ctx->s_blk[lane - 1];
             struct WsSwap {                   // the side lanes build their mask tables in their own scratch
                 cs_ctx* c;
@@ -2719,26 +2677,16 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 return rc;
             }
         }
-        if (prep_batch) {
-            prep_defer.c->prep_defer = nullptr;
-            int rcp = cs::launch_mask_prep_batch(prep_list.data(), ctx->prep_groups.data(), (int)prep_list.size(), (char*)ctx->h_tab + tile_tab_bytes,
-                                                 (char*)ctx->d_tab + tile_tab_bytes, stream);
-            if (rcp) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rcp));
-            if (!table) {                             // the lanes' tile kernels follow the tables (and the zeroed counter)
-                CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));
-                for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
-            }
-        }
         laps.lap("mask tables + arguments");
-        // One tile launch + the lanes busy with the mask tables while the caller's stream is still staging the maps: the
-        // argument table and the zeroed counter travel on a lane too (ordered before the launch by the lane's event below)
-        // instead of sitting between the staging and the tile kernel -- a fill, a copy and their launch gaps, ~ 25 us of
-        // every step's critical path.
-        const bool early_upload = table && early_tables && n_lanes > 1 && !prep_batch && !std::getenv("CHROMOSIGHT_HIP_NO_EARLY_UPLOAD");
+        bool tab_uploaded = false;
         if (early_upload) {
-            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[0]));
-            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[0], true, false);
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[n_lanes - 2], true, false);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel table upload failed: %s", hipGetErrorString((hipError_t)rc));
+            if (deferred) {
+                rc = cs::upload_keyed_batch_table(tab.data(), n_blocks, (long long)list_cap, pool + off_tail, ctx->s_blk[n_lanes - 2]);
+                if (rc) return fail(ctx, CS_ERR_HIP, "argument table upload failed: %s", hipGetErrorString((hipError_t)rc));
+                tab_uploaded = true;
+            }
         } else if (prepared && early_tables) {
             CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (before the event the lanes' tile kernels wait for, below)
         }
@@ -2761,62 +2709,70 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             for (int b : launch_order) {
                 hipStream_t s_lane = lane_of[b] == 0 ? stream : ctx->s_blk[lane_of[b] - 1];
                 const void* arg = (const char*)ctx->h_tab + cs::mfma_blocks_arg_offset(n_blocks) + (size_t)b * cs::mfma_blocks_arg_bytes();
-                rc = cs::launch_corr_mfma_prepared(arg, table_rsym, ctx->n_cu, ctx->grid_cap, s_lane);
+                rc = cs::launch_corr_mfma_prepared(arg, table_rsym, ctx->n_cu, 0, s_lane);
                 if (rc) {
                     (void)hipDeviceSynchronize();
                     return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
                 }
             }
         }
-        if (n_lanes > 1 && !(prep_batch && table)) {          // (batched tables + one tile launch: the lanes carried nothing)
+        if (n_lanes > 1) {
             for (int k = 0; k < n_lanes - 1; ++k) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
                 CS_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_blk[k], 0));
             }
         }
         if (table) {
-            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, stream, !early_upload, true);
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, stream, !early_upload, true,
+                                             ctx->d_tiles_started);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        } else if (ctx->d_tiles_started) {
+            // (the per-block launches carry no start word: whoever waits for it -- cs_stream_wait_tiles -- is let go here)
+            CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_tiles_started, 1, 1, stream));
         }
         laps.lap("tile kernels launched");
-        g_tile_launch_seq.fetch_add(1, std::memory_order_release);      // (CS_CALL_WAIT_TILE_LAUNCH of cs_run_calls)
-        if (segmented) CS_HIP(ctx, hipMemcpyAsync(ctx->h_cand_counts, d_cnt + 2, 8 * (size_t)n_blocks, hipMemcpyDeviceToHost, stream));
-        else CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
-        if (tab.empty()) {
-            // built while the tile kernels run, not between the two synchronisations
-            tab.resize((size_t)n_blocks);
-            for (int b = 0; b < n_blocks; ++b) {
-                int rc2 = build_args<double>(ctx, stream, signals + b, kernel, params + b, &tab[b]);
-                if (rc2) {
-                    (void)hipDeviceSynchronize();
-                    return rc2;
-                }
+        // ---- The chain behind the tile kernels, enqueued BEFORE they have finished (segmented lists): the blocks' candidate
+        // counts stay on the device -- one tiny kernel turns them into the segments of the compact numbering --, the launches
+        // are sized for a bound (the previous call's count on the same layout + 50 %; without one, a share of the lists'
+        // room), and the host reads counts, status and records after ONE synchronisation.  What the round trip in the middle
+        // cost a rank's share of a genome: the wake-up, ~ 30 us of enqueueing with the device idle, of a 160 us tail
+        // (profiles/r05_rank_share_timeline.txt).  A list that outgrew its room sends the call round again as before; lists too
+        // long for the labelling workgroups' LDS arrays, or more candidates than the bound, take the host-paced chain below
+        // on the same lists.  CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN=1: always the host-paced chain.
+        bool counts_known = false;
+        if (deferred) {
+            const long long bound = std::min<long long>((long long)list_cap, hint > 0 ? hint + hint / 2 + 4096
+                                                                                     : std::max<long long>(16384, (long long)list_cap / 8));
+            cs::DeferredSegments D;
+            D.d_counts = (const long long*)(d_cnt + 2);
+            for (int b = 0; b < n_blocks; ++b) {                 // (the device reads the two tables where they are: page-locked)
+                ctx->h_cand_counts[64 + b] = seg_base[(size_t)b];
+                ctx->h_cand_counts[128 + b] = seg_cap[(size_t)b];
             }
-        }
-        laps.lap("float64 argument table");
-        if (single_sync) {
-            const size_t off_tail1 = off_tail_now;
+            D.h_base = ctx->h_cand_counts + 64;
+            D.h_cap = ctx->h_cand_counts + 128;
+            D.bound = bound;
+            D.tab_uploaded = tab_uploaded;
+            D.h_counts_out = ctx->h_cand_counts;             // [0, n_blocks): the blocks' counts; [60], [61]: total, status flags
             ctx->h_blk_counts[0] = -1;
-            int rc1 = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, (long long)c_cap, kKeyShift, foci[0].pearson,
-                                                   foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail1, rec,
-                                                   (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream, /*bounded=*/1);
+            ctx->h_cand_counts[61] = -1;
+            int rc1 = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, (long long)list_cap, kKeyShift, foci[0].pearson,
+                                                   foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail, rec,
+                                                   (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream, nullptr, nullptr, &D);
             if (rc1) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc1));
             laps.lap("foci chain enqueued");
-            CS_HIP(ctx, hipStreamSynchronize(stream));   // (the copy of the candidate count above is behind the tile kernels)
+            CS_HIP(ctx, hipStreamSynchronize(stream));
             laps.lap("wait: records");
-            n_total = ctx->h_counts[0];
-            if ((size_t)n_total <= c_cap) {
-                const long long total1 = ctx->h_blk_counts[0];
-                if (total1 < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
-                for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
-                if (total1 > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total1, (long long)cap);
-                return CS_OK;
-            }
-            c_cap = (size_t)n_total + (size_t)n_total / 8;   // the list overflowed: once more with room for all
-            continue;
+            counts_known = true;
+        } else if (segmented) {
+            CS_HIP(ctx, hipMemcpyAsync(ctx->h_cand_counts, d_cnt + 2, 8 * (size_t)n_blocks, hipMemcpyDeviceToHost, stream));
+        } else {
+            CS_HIP(ctx, hipMemcpyAsync(ctx->h_counts, d_cnt, 8, hipMemcpyDeviceToHost, stream));
         }
-        CS_HIP(ctx, wait_stream_hot(stream));
-        laps.lap("wait: candidates");
+        if (!counts_known) {
+            CS_HIP(ctx, hipStreamSynchronize(stream));
+            laps.lap("wait: candidates");
+        }
         if (segmented) {
             // the blocks' own counts: segments of the compact numbering; a block that outgrew its room sends the call round again
             bool fits = true;
@@ -2833,25 +2789,36 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
             seg_off[(size_t)n_blocks] = sum;
             n_total = sum;
-            if (fits) break;
-            c_cap = (size_t)worst + (size_t)worst / 8;
-            continue;
+            if (!fits) {
+                c_cap = (size_t)worst + (size_t)worst / 8;
+                continue;
+            }
+            if (counts_known && ctx->h_cand_counts[61] == 0) {
+                // the chain ran on this call's lists as they are: done
+                const long long total = ctx->h_blk_counts[0];
+                if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
+                for (int b = 0; b < n_blocks; ++b) h_n_foci[b] = ctx->h_blk_counts[1 + b];
+                if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
+                return CS_OK;
+            }
+            break;
         }
         n_total = ctx->h_counts[0];
         if ((size_t)n_total <= c_cap) break;
         c_cap = (size_t)n_total + (size_t)n_total / 8;
     }
-    // ---- exact scores, foci, statistics: one chain for all blocks (its argument table was built while the tile kernels ran)
+    // ---- exact scores, foci, statistics: one chain for all blocks (its argument table was built while the tile kernels ran),
+    // sized by the counts the host has read
     char* pool = (char*)ctx->d_pool;
     const size_t off_tail = off_tail_now;
     ctx->h_blk_counts[0] = -1;
     int rc = cs::enqueue_foci_keyed_batch(tab.data(), n_blocks, (const long long*)pool, n_total, kKeyShift, foci[0].pearson,
                                           foci[0].min_size, diag_code(foci, kernel, params), foci[0].inter, pool + off_tail, rec,
-                                          (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream, 0,
-                                          segmented ? seg_base : nullptr, segmented ? seg_off : nullptr);
+                                          (long long)cap, win, win ? (long long)cap : 0, ctx->h_blk_counts, stream,
+                                          segmented ? seg_base : nullptr, segmented ? seg_off : nullptr, nullptr);
     if (rc) return fail(ctx, CS_ERR_HIP, "batched foci kernels failed: %s", hipGetErrorString((hipError_t)rc));
     laps.lap("foci chain enqueued");
-    CS_HIP(ctx, wait_stream_hot(stream));            // also: the host table above was consumed
+    CS_HIP(ctx, hipStreamSynchronize(stream));            // also: the host table above was consumed
     laps.lap("wait: records");
     const long long total = ctx->h_blk_counts[0];
     if (total < 0) return fail(ctx, CS_ERR_HIP, "batched foci kernels did not report a count");
@@ -3039,7 +3006,6 @@ struct CallRun {
     std::atomic<int>* done = nullptr;      // per call: 1 once it has returned (or was skipped)
     bool timing = false;
     std::chrono::steady_clock::time_point t0;
-    long long tile_seq0 = 0;               // g_tile_launch_seq when the list began
 };
 
 int dispatch_call(cs_call& c)
@@ -3067,10 +3033,8 @@ int dispatch_call(cs_call& c)
                                      (int32_t)i[5], (double*)p[5], (uint8_t*)p[6], (int64_t*)p[7]);
         case CS_CALL_DETECT_FOCI_BATCH_FINISH:
             return cs_detect_foci_batch_finish((cs_ctx*)p[0], p[1], (int64_t*)p[2]);
-        case CS_CALL_WAIT_TILE_LAUNCH:
-            return CS_OK;                      // (the wait itself is in run_lane: it needs the list's state)
-        case CS_CALL_STREAM_DELAY:
-            return cs_stream_delay((cs_ctx*)p[0], p[1], (int32_t)i[0]);
+        case CS_CALL_STREAM_WAIT_TILES:
+            return cs_stream_wait_tiles((cs_ctx*)p[0], p[1], (cs_ctx*)p[2], (int32_t)i[0]);
         default:
             return CS_ERR_INVALID;
     }
@@ -3089,14 +3053,6 @@ void run_lane(const CallRun& R, int lane)
             if (R.calls[c.after].rc != 0) failed = true;            // what it waited for did not happen
         }
         const auto t_begin = std::chrono::steady_clock::now();
-        if (!failed && c.fn == CS_CALL_WAIT_TILE_LAUNCH) {
-            // until call number i[0] of the list (a cs_detect_foci_blocks) has launched its tile kernels -- or has returned
-            const int64_t k2 = c.i[0];
-            int spins = 0;
-            while (g_tile_launch_seq.load(std::memory_order_acquire) == R.tile_seq0 &&
-                   !(k2 >= 0 && k2 < R.n && R.done[k2].load(std::memory_order_acquire)))
-                if (++spins > 2000) std::this_thread::yield();
-        }
         if (failed && c.fn == CS_CALL_DETECT_FOCI_BATCH_FINISH) {
             // a lane that failed between the asynchronous batch and its finish must not leave the context "pending" (every later
             // foci call on it would be refused): end the batch whatever it holds; "nothing pending" is as good
@@ -3164,7 +3120,6 @@ extern "C" int cs_run_calls(cs_call* calls, int32_t n_calls)
     R.calls = calls;
     R.n = n_calls;
     R.done = done.data();
-    R.tile_seq0 = g_tile_launch_seq.load(std::memory_order_acquire);
     R.timing = std::getenv("CHROMOSIGHT_HIP_TIMING") != nullptr;
     R.t0 = std::chrono::steady_clock::now();
     std::vector<LaneWorker*>& g_workers = lane_workers();

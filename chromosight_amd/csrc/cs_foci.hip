@@ -1657,42 +1657,8 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
 // ---- 2-D patterns of MANY sub-matrices: the candidates arrive as one unsorted list of composite keys
 //      (block << kKeyShift) + row * ns + col, appended by the tile kernels of all blocks ------------------------------
 namespace {
-__global__ __launch_bounds__(kThreads) void keyed_segments_kernel(const long long* __restrict__ keys, long long n, int n_blocks,
-                                                                  int shift, long long* __restrict__ seg)
-{
-    const int b = blockIdx.x * kThreads + threadIdx.x;
-    if (b > n_blocks) return;
-    const long long want = (long long)b << shift;            // first key of block b
-    long long lo = 0, hi = n;
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (keys[mid] < want) lo = mid + 1;
-        else hi = mid;
-    }
-    seg[b] = lo;
-}
-
-__global__ __launch_bounds__(kThreads) void keyed_split_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ keys,
-                                                               long long n, const long long* __restrict__ n_ptr, int shift,
-                                                               int* __restrict__ rows, int* __restrict__ cols,
-                                                               int* __restrict__ blk, long long* __restrict__ local)
-{
-    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (t >= n || (n_ptr && t >= *n_ptr)) return;            // (a bounded list: the entries behind the keys are sentinels)
-    const long long key = keys[t];
-    const int b = (int)(key >> shift);
-    const long long rem = key - ((long long)b << shift);
-    const int ns = tab[b].ns;
-    rows[t] = (int)(rem / ns);
-    cols[t] = (int)(rem - (rem / ns) * ns);
-    blk[t] = b;
-    local[t] = rem;                                          // the block's own row-major key
-}
-}  // namespace
-
-namespace {
-// keyed_segments_kernel + keyed_split_kernel in one launch (lists whose length the host knows: the split does not wait for the
-// segments): threads [0, n) split their key, threads [n, n + n_blocks] find the first key of block t - n
+// One sorted list of composite keys: threads [0, n) split their key into (block, row, column, the block's own row-major key),
+// threads [n, n + n_blocks] find the first key of block t - n (the segments)
 __global__ __launch_bounds__(kThreads) void keyed_split_segments_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ keys,
                                                                         long long n, int n_blocks, int shift, int* __restrict__ rows,
                                                                         int* __restrict__ cols, int* __restrict__ blk,
@@ -1728,10 +1694,11 @@ __global__ __launch_bounds__(kThreads) void segmented_unpack_kernel(const CorrAr
                                                                     const long long* __restrict__ base, const long long* __restrict__ seg,
                                                                     int n_blocks, long long n, int shift, int* __restrict__ rows,
                                                                     int* __restrict__ cols, int* __restrict__ blk,
-                                                                    long long* __restrict__ local, long long* __restrict__ keys_c)
+                                                                    long long* __restrict__ local, long long* __restrict__ keys_c,
+                                                                    const long long* __restrict__ n_ptr)
 {
     const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (t >= n) return;
+    if (t >= n || (n_ptr && t >= *n_ptr)) return;            // (n_ptr: the length is known on the device only; n bounds the launch)
     int lo = 0, hi = n_blocks - 1;                            // the block with seg[b] <= t < seg[b + 1]
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1748,7 +1715,67 @@ __global__ __launch_bounds__(kThreads) void segmented_unpack_kernel(const CorrAr
     local[t] = rem;
     keys_c[t] = key;
 }
+
+// The segments of the compact numbering from the blocks' own candidate counters, on the device (the chain behind the tile kernels
+// is enqueued before the host knows them): seg[b + 1] - seg[b] = min(count[b], cap[b]); status[0] = seg[n_blocks],
+// status[1] = flags -- 1: a list outgrew its room (the host repeats the call with more), 2: a list is too long for the labelling
+// workgroup's LDS arrays or its sub-matrix too large for 32-bit keys, 4: more candidates than the launches were sized for
+// (2, 4: the host runs the chain again, paced by the counts); the regions' starts go from the host's table to the device's.
+// One wave.
+__global__ __launch_bounds__(64) void segments_from_counts_kernel(const CorrArgs<double>* __restrict__ tab, const long long* __restrict__ counts,
+                                                                  const long long* __restrict__ h_base, const long long* __restrict__ cap,
+                                                                  int n_blocks, long long bound, long long* __restrict__ seg,
+                                                                  long long* __restrict__ base_d, long long* __restrict__ h_out)
+{
+    // h_base / cap / h_out: page-locked host memory the device reads and writes directly (a few words: no copy engine, no
+    // launch gap in front of or behind the chain)
+    const int lane = threadIdx.x;
+    long long run = 0;
+    int flags = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        long long n = 0;
+        if (b < n_blocks) {
+            const long long c = counts[b];
+            n = min(c, cap[b]);
+            base_d[b] = h_base[b];
+            h_out[b] = c;
+            if (c > cap[b]) flags |= 1;
+            if (n > kSmallLds || (unsigned long long)tab[b].ms * (unsigned long long)tab[b].ns > 0xffffffffull) flags |= 2;
+        }
+        long long incl = n;                                   // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (b < n_blocks) seg[b] = run + incl - n;
+        run += __shfl(incl, 63, 64);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) flags |= __shfl_xor(flags, off, 64);
+    if (lane == 0) {
+        seg[n_blocks] = run;
+        if (run > bound) flags |= 4;
+        h_out[60] = run;
+        h_out[61] = flags;
+    }
+}
 }  // namespace
+
+// the chain with device-side counts needs the labelling workgroups' LDS route (unsorted lists)
+bool keyed_batch_deferred_available() { return foci_small_lds_bytes() > 0; }
+
+// The argument table of enqueue_foci_keyed_batch(..., n_total, scratch, ...) uploaded ahead of it on another stream (ordered
+// before the chain by the caller): where the chain's first allocation puts it.
+int upload_keyed_batch_table(const CorrArgs<double>* h_tab, int n_blocks, long long n_total, void* scratch, hipStream_t stream)
+{
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t sort_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const long long*)nullptr, (long long*)nullptr, (int)std::max<long long>(n_total, 1));
+    CorrArgs<double>* tab = reinterpret_cast<CorrArgs<double>*>((char*)scratch + al(al(sort_tmp)));
+    return (int)hipMemcpyAsync(tab, h_tab, sizeof(CorrArgs<double>) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+}
 
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
 {
@@ -1764,13 +1791,15 @@ size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total)
 // h_counts[1 + b] = foci of block b.  Same chain as enqueue_foci_narrow_batch after its enumeration.
 int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
                              double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
-                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded,
-                             const long long* h_base, const long long* h_seg)
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream,
+                             const long long* h_base, const long long* h_seg, const DeferredSegments* deferred)
 {
     // h_base / h_seg (or null): SEGMENTED lists -- block b's keys, unsorted, at d_keys[h_base[b] ..), h_seg[b + 1] - h_seg[b] of
     // them (n_total = h_seg[n_blocks]); both arrays must outlive the call's copies (the caller synchronises).
-    // bounded: n_total is the CAPACITY of d_keys, whose unused entries hold a sentinel above every key with the bit above
-    // the block bits set (cs_api.cpp cs_detect_foci_blocks); the number of keys is seg[n_blocks], known on the device only
+    // deferred (or null): segmented lists whose LENGTHS are still being written by the tile kernels in front of this chain on
+    // `stream` -- n_total is then the room of d_keys (every array of the chain is laid out for it), the segments are formed on
+    // the device from deferred->d_counts, the launches are sized for deferred->bound candidates, and the blocks' counts, the
+    // total and the status flags (segments_from_counts_kernel) are written to deferred->h_counts_out by the chain itself.
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t n = (size_t)std::max<long long>(n_total, 1), nb = (size_t)n_blocks + 1;
     Bump b{(char*)scratch};
@@ -1809,13 +1838,32 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
     long long* n_foci_blk = b.take<long long>(nb);
     long long* f_off = b.take<long long>(nb);
     long long* d_total = b.take<long long>(8);
-    hipError_t e = hipMemcpyAsync(tab, h_tab, sizeof(CorrArgs<double>) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
+    hipError_t e = hipSuccess;
+    if (!(deferred && deferred->tab_uploaded)) e = hipMemcpyAsync(tab, h_tab, sizeof(CorrArgs<double>) * (size_t)n_blocks, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return (int)e;
+    const size_t lds_small = foci_small_lds_bytes();
+    if (deferred) {
+        if (lds_small == 0) return (int)hipErrorInvalidValue;          // (the unsorted lists need the labelling workgroups' LDS route)
+        const long long bound = std::max<long long>(1, std::min<long long>(deferred->bound, n_total));
+        hipLaunchKernelGGL(segments_from_counts_kernel, dim3(1), dim3(64), 0, stream, tab, deferred->d_counts, deferred->h_base, deferred->h_cap,
+                           n_blocks, bound, seg, base_d, deferred->h_counts_out);
+        const long long* n_dev = seg + n_blocks;
+        hipLaunchKernelGGL(segmented_unpack_kernel, dim3(blocks_for(bound)), dim3(kThreads), 0, stream, tab, d_keys, base_d, seg, n_blocks, bound,
+                           shift, rows, cols, blk, local, keys_k, n_dev);
+        launch_rescore_batch(h_tab, n_blocks, bound, stream, tab, blk, rows, cols, bound, n_dev, vals, (double*)nullptr);
+        hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), lds_small, stream, tab, seg, local, vals, pearson,
+                           min_size, diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept,
+                           n_foci_blk, 1, 1);
+        hipLaunchKernelGGL(gather_foci_batch_kernel, dim3(1), dim3(kSmallThreads), 0, stream, seg, n_foci_blk, n_blocks, s_rows, s_cols, s_size,
+                           f_rows, f_cols, f_size, f_blk, f_off, d_total, h_counts);
+        launch_focus_records(h_tab, n_blocks, std::max<long long>(1, bound / std::max(min_size, 1)), stream, tab, inter, f_blk, f_rows, f_cols,
+                             f_size, f_score, f_nobs, d_total, rec, windows, win_cap, rec_cap);
+        return (int)hipGetLastError();
+    }
     int unsorted = 0;
-    if (h_base && h_seg && !bounded && n_total > 0) {
+    if (h_base && h_seg && n_total > 0) {
         // every block's list short enough for the labelling workgroup's LDS arrays (which sort it there)?  then no device-wide
         // sort, no segments, no split: one unpack launch
-        const size_t lds_small = foci_small_lds_bytes();
         bool all_small = lds_small > 0;
         for (int k = 0; k < n_blocks && all_small; ++k)
             all_small = h_seg[k + 1] - h_seg[k] <= kSmallLds &&
@@ -1828,34 +1876,24 @@ int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const 
         }
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(segmented_unpack_kernel, dim3(blocks_for(n_total)), dim3(kThreads), 0, stream, tab, d_keys, base_d, seg, n_blocks,
-                           n_total, shift, rows, cols, blk, local, keys_k);
+                           n_total, shift, rows, cols, blk, local, keys_k, (const long long*)nullptr);
         if (all_small) unsorted = 1;
         else d_keys = keys_k;                       // the compact list through the sorted route below
     }
     int blk_bits = 1;
     while ((1 << blk_bits) < n_blocks) ++blk_bits;
     if (n_total > 0 && !unsorted) {
-        e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits + (bounded ? 1 : 0), stream);
+        e = hipcub::DeviceRadixSort::SortKeys(tmp, sort_tmp, d_keys, keys_s, (int)n_total, 0, shift + blk_bits, stream);
         if (e != hipSuccess) return (int)e;
     }
-    const bool one_split = !bounded && n_total > 0 && !unsorted && !getenv("CHROMOSIGHT_HIP_NO_SPLIT_FUSION");
     if (unsorted) {
         launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, (const long long*)nullptr, vals, (double*)nullptr);
     } else {
-        if (one_split)
-            hipLaunchKernelGGL(keyed_split_segments_kernel, dim3(blocks_for(n_total + n_blocks + 1)), dim3(kThreads), 0, stream, tab, keys_s,
-                               n_total, n_blocks, shift, rows, cols, blk, local, seg);
-        else
-            hipLaunchKernelGGL(keyed_segments_kernel, dim3(blocks_for(n_blocks + 1)), dim3(kThreads), 0, stream, keys_s, n_total, n_blocks, shift, seg);
-        if (n_total > 0) {
-            const unsigned g = blocks_for(n_total);
-            const long long* n_keys = bounded ? seg + n_blocks : nullptr;
-            if (!one_split)
-                hipLaunchKernelGGL(keyed_split_kernel, dim3(g), dim3(kThreads), 0, stream, tab, keys_s, n_total, n_keys, shift, rows, cols, blk, local);
-            launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, n_keys, vals, (double*)nullptr);
-        }
+        hipLaunchKernelGGL(keyed_split_segments_kernel, dim3(blocks_for(n_total + n_blocks + 1)), dim3(kThreads), 0, stream, tab, keys_s,
+                           n_total, n_blocks, shift, rows, cols, blk, local, seg);
+        if (n_total > 0)
+            launch_rescore_batch(h_tab, n_blocks, n_total, stream, tab, blk, rows, cols, n_total, (const long long*)nullptr, vals, (double*)nullptr);
     }
-    const size_t lds_small = foci_small_lds_bytes();
     hipLaunchKernelGGL(foci_small_batch_kernel, dim3(n_blocks), dim3(kSmallThreads), lds_small, stream, tab, seg, local, vals, pearson, min_size,
                        diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, s_rows, s_cols, s_size, n_kept, n_foci_blk,
                        lds_small ? 1 : 0, unsorted);

@@ -691,10 +691,21 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
 
 // 2-D patterns of many sub-matrices: candidates as composite keys (block << shift) + row * ns + col
 size_t keyed_batch_scratch_bytes(int n_blocks, long long n_total);
+// (segmented lists whose lengths are only known on the device when the chain is enqueued: see enqueue_foci_keyed_batch)
+struct DeferredSegments {
+    const long long* d_counts = nullptr;     // device: the blocks' candidate counters
+    const long long* h_base = nullptr;       // page-locked host memory: the regions' starts in d_keys
+    const long long* h_cap = nullptr;        // page-locked host memory: the regions' rooms
+    long long bound = 0;                      // candidates the launches are sized for
+    long long* h_counts_out = nullptr;        // page-locked, 64 entries: [b] counts, [60] total, [61] status flags
+    bool tab_uploaded = false;                // upload_keyed_batch_table ran on a stream ordered before this chain
+};
+bool keyed_batch_deferred_available();
+int upload_keyed_batch_table(const CorrArgs<double>* h_tab, int n_blocks, long long n_total, void* scratch, hipStream_t stream);
 int enqueue_foci_keyed_batch(const CorrArgs<double>* h_tab, int n_blocks, const long long* d_keys, long long n_total, int shift,
                              double pearson, int min_size, int diag_only, int inter, void* scratch, FocusRec* rec, long long rec_cap,
-                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream, int bounded = 0,
-                             const long long* h_base = nullptr, const long long* h_seg = nullptr);
+                             double* windows, long long win_cap, long long* h_counts, hipStream_t stream,
+                             const long long* h_base = nullptr, const long long* h_seg = nullptr, const DeferredSegments* deferred = nullptr);
 
 // row-major keys (row * ns + col) -> coordinates
 int launch_decode_keys(const long long* keys, long long n, int ns, int* rows, int* cols, hipStream_t stream);
@@ -773,12 +784,5 @@ struct MaskPrepArgs {
 };
 template <typename TC>
 int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream);
-// the same for several matrices in one launch: mask_prep_blocks fills a matrix's workgroup ranges and returns their number;
-// launch_mask_prep_batch copies the table (first[], arguments) through h_tab (page-locked) to d_tab (mask_prep_table_bytes
-// each) and launches
-template <typename TC>
-int mask_prep_blocks(MaskPrepArgs<TC>& P);
-size_t mask_prep_table_bytes(int n);
-int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream);
 
 }  // namespace cs

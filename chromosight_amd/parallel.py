@@ -385,9 +385,6 @@ def _gather(records, n_fields):
 def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np.float64, lazy64=None):
     """Stage this rank's blocks for several pattern configurations (detect_genome(..., staged=...)): ONCE at the longest
     keep distance any of them needs, the others scan band views of the same blocks (DeviceCool.view_for).
-    CHROMOSIGHT_HIP_NARROW_STAGING=1 (experiment, measured slower on the 23-block genome: 5.75 against 5.5 ms): configurations
-    that need a band at least 8 times narrower (1-D patterns next to loops: 18 diagonals against 1017) get their own narrow
-    staging FIRST so that their launch chains run under the wide staging instead of beside the matrix-core kernels.
     lazy64 (default: on for templates of up to 17 x 17 in float32 arithmetic, CHROMOSIGHT_HIP_F64_TWIN=1 turns it off): the
     float64 bands are not stored beyond their first diagonals -- the exact evaluation of the candidates and the windows of
     the records recompute the pixels they read from the pixel table (pipeline.DeviceCool._stage_fast).
@@ -421,12 +418,9 @@ def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np
             out.ready = getattr(genome, name)
         return out
 
-    narrow = [i for i in range(len(kernel_configs)) if (dists[i] + tallest[i]) * 8 <= max_dist] \
-        if events and os.environ.get("CHROMOSIGHT_HIP_NARROW_STAGING") else []
-    first = stage(narrow, 1) if narrow else None
-    wide = [i for i in range(len(kernel_configs)) if i not in narrow]
+    wide = list(range(len(kernel_configs)))
     staged = stage(wide, 0)
-    staged.by_config = {i: first for i in narrow}
+    staged.by_config = {}
     # Blocks a configuration cannot take as a band view of the shared staging -- a short chromosome staged dense for the
     # widest pattern is a band for a narrower one -- are staged for it here, on the genome's stream, instead of by the
     # host thread that will scan that configuration (detect_patterns: the thread would have to use the genome's context
@@ -448,7 +442,7 @@ def stage_genome(genome, kernel_configs, owned=None, smooth=False, band_dtype=np
         if extra_any and events:
             genome.dev.record(staged.ready)                  # (one event: after everything staged here)
             for own in staged.by_config.values():
-                if own is not None and own is not first:
+                if own is not None:
                     own.ready = staged.ready
     return staged
 
@@ -561,44 +555,9 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     # the configuration that scans the widest band stays on this thread (a hand-over to a pool thread costs 50-100 us, and
     # its pass is the longest); the others go to the pool first
     here = max(side, key=lambda i: kernel_configs[i]["max_dist"]) if side else None
-    # CHROMOSIGHT_HIP_EARLY_CHAIN=1 (experiment, measured SLOWER and off by default): 1-D patterns whose templates share one
-    # launch chain are ENQUEUED from this thread, before this thread's own pattern (cs_detect_foci_batch_templates'
-    # asynchronous form on a context and high-priority stream of their own), and finished after it -- instead of racing the
-    # tile kernels from a pool thread that needs ~ 150 us of interpreter time to reach the device.  With the chain in front,
-    # its wide kernels (enumeration, run scoring: a workgroup per 256 pixels) hold the chip while the loops pass could have
-    # started: the 23-block genome 4.05 -> 5.1 ms per step on one GPU, a rank's share of 8: 1.15 -> 1.2-1.3 ms.
-    early = {}
-    if here is not None and tsvd is None and hasattr(genome, "view_for") and os.environ.get("CHROMOSIGHT_HIP_EARLY_CHAIN"):
-        from . import pipeline
-        for slot, i in enumerate(j for j in side if j != here):
-            cfg = kernel_configs[i]
-            if cfg["max_dist"] != 0 or os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_BATCH"):
-                continue
-            md_i = max(cfg["max_dist"] // genome.binsize, 1)
-            tall_i = max(np.shape(k)[0] for k in cfg["kernels"])
-            views, src = [], pick(i)
-            for ci in owned:
-                blk = src.get(ci)
-                view = None if blk is None else (blk if (blk.max_dist == md_i and blk.keep == min(md_i, genome.chrom_size(ci)) + tall_i)
-                                                 else genome.view_for(blk, md_i, tall_i))
-                if view is None:
-                    break
-                views.append(view)
-            if len(views) != len(owned) or not views:
-                continue
-            dev_i, stream_i = pipeline.async_device(genome, slot)
-            ready_i = getattr(src, "ready", None)
-            if ready_i is not None:
-                dev_i.wait_event(ready_i, stream_i)
-            else:
-                genome.dev.sync()
-            kernels_i = [np.asarray(k, dtype=np.float64) for k in cfg["kernels"]]
-            begun = pipeline.detect_blocks_templates(genome, views, cfg, kernels_i, dev=dev_i, stream=stream_i, begin_only=True)
-            if begun is not None:
-                early[i] = begun
     futures = {i: _PATTERN_THREADS.submit(detect_genome, genome, kernel_configs[i], tsvd=tsvd, owned=owned, staged=pick(i),
                                           exchange=False, exclusive=len(side) < 2, own_context=True)
-               for i in side if i != here and i not in early}
+               for i in side if i != here}
     local = {}
     if here is not None:
         local[here] = detect_genome(genome, kernel_configs[here], tsvd=tsvd, owned=owned, staged=pick(here), exchange=False,
@@ -607,16 +566,6 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     for i, cfg in enumerate(kernel_configs):
         if i not in side:
             results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=pick(i), exclusive=not side)
-    for i, finish in early.items():                          # wait for the chain, acceptance rules, records as detect_genome's
-        rows = []
-        for kernel_id, (table, kept, _windows) in enumerate(finish()):
-            rec = np.empty((len(table), len(GENOME_FIELDS)))
-            rec[:, 0] = np.repeat(np.asarray(owned, dtype=np.float64), kept)
-            rec[:, 1:5] = table
-            rec[:, 5] = kernel_id
-            rec[:, 6] = 0
-            rows.append(rec)
-        local[i] = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(GENOME_FIELDS)))
     for i in side:                                           # (collectives in the same order on every rank)
         mine = local[i] if i in local else futures[i].result()
         results[i] = _exchange_records(mine, len(kernel_configs[i]["kernels"]), 1)

@@ -879,20 +879,6 @@ def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=
                                      want_windows=want_windows, raw=True, stream=stream, defer=True, merged=True, begin_only=begin_only)
 
 
-_ASYNC_DEVICES = {}
-
-
-def async_device(dcool, slot):
-    """(context, high-priority stream) number `slot` for launch chains the calling thread enqueues beside its own work on the
-    genome's context (parallel.detect_patterns); process-wide like the worker pools."""
-    from ._lib import Device
-    key = (dcool.dev.index, slot)
-    if key not in _ASYNC_DEVICES:
-        dev = Device(dcool.dev.index)
-        _ASYNC_DEVICES[key] = (dev, dev.new_stream(high_priority=not os.environ.get("CHROMOSIGHT_HIP_NO_PRIORITY")))
-    return _ASYNC_DEVICES[key]
-
-
 def with_win_size(kernel_config, win_size):
     """--win-size of the reference's CLI (cli/chromosight.py:365-370, 689-695): every template of the
     config resized to win_size x win_size (odd), "auto" / None keeps the config's own sizes."""

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_DETECT_FOCI_BATCH_TEMPLATES, CALL_DETECT_FOCI_BLOCKS,
-                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_DELAY, CALL_STREAM_WAIT_EVENT, CALL_WAIT_TILE_LAUNCH, FOCUS_DTYPE,
+                   CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_WAIT_EVENT, CALL_STREAM_WAIT_TILES, FOCUS_DTYPE,
                    CsCall, raw_arg)
 
 # argument slots of every entry: 'p' pointer, 'i' integer, 'd' double, in the order of the C prototype
@@ -112,28 +112,15 @@ class StepPlan:
         self.acc1 = accept_io(self.cap1, self.n_blocks * self.n_templates, md1, cfg1["kernels"][0])
         # Both chains are enqueued as soon as the staging is (lane 1 uses the entry's asynchronous form and waits for its chain
         # afterwards), so they share the device the way the two pattern threads of detect_patterns make them -- minus the
-        # interpreter.  CHROMOSIGHT_HIP_PLAN_ORDERED=1 (measured: no gain on a rank's share of 8, 0.95 ms either way, and
-        # SLOWER on the whole genome, 4.2 against 3.95 ms) orders them ON THE DEVICE instead: lane 1 records an event behind
-        # the 1-D chain and the genome's stream waits for it before the 2-D chain -- no contention (a tile kernel in
-        # residence holds every register of every SIMD: the 1-D chain's kernels otherwise wait for its workgroups to drain),
-        # but the 1-D chain's 220 us then sit in front of the tile kernels instead of beside them.
-        contend = not os.environ.get("CHROMOSIGHT_HIP_PLAN_ORDERED")
-        # CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1: lane 1 holds its chain back until the 2-D chain's tile kernels are launched
-        # (CS_CALL_WAIT_TILE_LAUNCH): the persistent tile workgroups then take their slots on an empty device -- their tile
-        # ranges are static, one that starts late finishes late -- and the 1-D chain runs in what they leave
-        # (measured, profiles/r04b_tiles_first.txt: the device span of a genome step shrinks from 3.06 to 2.82 ms -- one
-        # persistent tile launch of 1.71 ms instead of 2.11 ms of per-block launches, the 1-D chain behind it -- but the step
-        # does not: 3.28-3.34 ms either way, a share of 8 0.63 against 0.60-0.63 ms; off by default)
-        tiles_first = bool(os.environ.get("CHROMOSIGHT_HIP_PLAN_TILES_FIRST"))
-        self.done_b = dev.new_event()
-        stream_a = raw_arg(blocks[0][1])
-        # The two chains wait for the same event (the staging) and then race for the workgroup slots: when the 1-D chain's run
+        # interpreter.
+        # The two chains wait for the same event (the staging) and would race for the workgroup slots: when the 1-D chain's run
         # kernel is resident first, the persistent tile workgroups start late on the CUs it holds (three of its workgroups fill
-        # a CU's LDS) and -- their tile ranges are static -- finish late: a share's step takes 0.75 instead of 0.6 ms, step by
-        # step at random (profiles/r04b_step_modes.txt).  A sleeping wave at the head of the 1-D chain (cs_stream_delay) lets
-        # the tile kernels go first, every time; the 1-D chain has the slack (it ends 70-100 us before the 2-D chain's tail).
-        delay_us = int(os.environ.get("CHROMOSIGHT_HIP_PLAN_DELAY_US", "45"))
-        n_calls = (11 if tiles_first else 10) + (1 if delay_us > 0 else 0)
+        # a CU's LDS) and -- their tile ranges are static -- finish late: a share's step took 0.75 instead of 0.6 ms, step by
+        # step at random (profiles/r04b_step_modes.txt).  So the 1-D chain DEPENDS on the tile launch: cs_stream_wait_tiles at
+        # its head lets it go when the last tile workgroup has started (round 4 held it back with a sleeping wave of a fixed
+        # 45 us, a constant tuned on one genome and one box); it then runs in what the tile workgroups leave and still ends
+        # before the 2-D chain's tail.
+        n_calls = 9
         calls = (CsCall * n_calls)()
         k = 0
 
@@ -144,28 +131,18 @@ class StepPlan:
         _fill(nxt(), *_SLOTS["cs_stage_blocks"], stage[0], 0)
         _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)
         _fill(nxt(), *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=1)
-        if delay_us > 0:
-            _fill(nxt(), CALL_STREAM_DELAY, "ppi", (ctx_b, stream_b, delay_us), 1)
-        if tiles_first:
-            _fill(nxt(), CALL_WAIT_TILE_LAUNCH, "i", (7 + (1 if delay_us > 0 else 0),), 1)    # (the cs_detect_foci_blocks call below)
+        _fill(nxt(), CALL_STREAM_WAIT_TILES, "pppi", (ctx_b, stream_b, ctx_a, 500), 1)
         b = list(batch[0])
         b[8], b[9] = self.rec1.ctypes.data, self.cap1
         b[7][0].reserved = 1                                  # asynchronous form: return once the chain is enqueued
         _fill(nxt(), *_SLOTS["cs_detect_foci_batch_templates"], b, 1)
-        i_done_b = k
-        _fill(nxt(), *_SLOTS["cs_event_record"], (ctx_b, self.done_b, stream_b), 1)
-        if contend:
-            _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)          # (a harmless record instead of the wait)
-        else:
-            _fill(nxt(), *_SLOTS["cs_stream_wait_event"], (ctx_a, stream_a, self.done_b), 0, after=i_done_b)
         a = list(blocks[0])
         a[8], a[9] = self.rec2.ctypes.data, self.cap2
-        assert not tiles_first or k == 7 + (1 if delay_us > 0 else 0)
-        if (tiles_first or delay_us > 0) and not os.environ.get("CHROMOSIGHT_HIP_PLAN_NO_TABLE"):
+        if not os.environ.get("CHROMOSIGHT_HIP_PLAN_NO_TABLE"):
             # ONE persistent launch for the tiles of all blocks (cs_foci_params.exclusive): with the 1-D chain held back behind
             # it the persistent workgroups are not displaced, and one launch beats 23 over three streams -- the 23-block genome
             # 3.25 -> 3.02 ms, a share of 2: 1.89 -> 1.69, of 4: 1.11 -> 0.96 (profiles/r04b_step_modes.txt).  Without the
-            # delay the same launch was the slower choice (round 3: 5.6 against 4.4 ms).
+            # dependency the same launch was the slower choice (round 3: 5.6 against 4.4 ms).
             a[7][0].exclusive = 1
         _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], a, 0)
         self._accept(nxt(), self.rec2, self.counts2, self.acc2, cfg2, 0)

@@ -99,11 +99,15 @@ int cs_event_record(cs_ctx* ctx, void* event, void* stream);
 /* work enqueued on `stream` after this call starts only when `event` (recorded on any stream of the same GPU, by any
  * context) has fired: ordering between streams without a host synchronisation */
 int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event);
-/* Keeps `stream` busy for about `microseconds` (at most 1000) with one sleeping wave.  A launch chain that would otherwise race
- * a persistent launch of another stream for the workgroup slots -- both waiting for the same event -- is held back by it, so
- * that the persistent workgroups are resident first (chromosight_amd/plan.py: the 1-D pattern's chain behind the 2-D pattern's
- * tile kernels; a rank's step otherwise takes 0.6 or 0.75 ms depending on which chain wins). */
-int cs_stream_delay(cs_ctx* ctx, void* stream, int32_t microseconds);
+/* Work enqueued on `stream` after this call starts only when the tile workgroups of `tiles_ctx`'s NEXT multi-block tile launch
+ * (cs_detect_foci_blocks: one persistent launch over the tiles of all blocks) are resident -- its last workgroup sets a word when
+ * it starts, one sleeping wave on `stream` waits for the word and takes it back -- or after `timeout_us` (at most 5000; the word
+ * is a scheduling hint, not a lock: a tile launch that never comes only costs the time-out).  Why: a launch chain that waits for
+ * the same event as a persistent launch of another stream races it for the workgroup slots, and the persistent workgroups it
+ * displaces start late and -- their tile ranges being static -- finish late (a rank's step took 0.6 or 0.75 ms depending on which
+ * chain won).  Behind this call the chain runs in what the tile workgroups leave, every time (chromosight_amd/plan.py: the 1-D
+ * pattern's chain beside the 2-D pattern's tile kernels).  Both contexts on the same GPU. */
+int cs_stream_wait_tiles(cs_ctx* ctx, void* stream, cs_ctx* tiles_ctx, int32_t timeout_us);
 /* synchronises on `stop`, then returns the elapsed milliseconds between the two events */
 int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms);
 
@@ -444,11 +448,7 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
  * return value is the first non-zero rc (0: every call succeeded). */
 enum { CS_CALL_STAGE_BLOCKS = 1, CS_CALL_EVENT_RECORD = 2, CS_CALL_STREAM_WAIT_EVENT = 3, CS_CALL_DETECT_FOCI_BLOCKS = 4,
        CS_CALL_DETECT_FOCI_BATCH_TEMPLATES = 5, CS_CALL_ACCEPT_RECORDS = 6, CS_CALL_DETECT_FOCI_BATCH_FINISH = 7,
-       /* no entry of its own: the lane waits until call number i[0] of the list (a CS_CALL_DETECT_FOCI_BLOCKS) has LAUNCHED its
-        * tile kernels, or has returned -- a launch chain enqueued only then finds the persistent tile workgroups in their
-        * slots and runs in what they leave, instead of taking slots first and making some of them start late */
-       CS_CALL_WAIT_TILE_LAUNCH = 8,
-       CS_CALL_STREAM_DELAY = 9 /* cs_stream_delay(p[0], p[1], i[0]) */ };
+       CS_CALL_STREAM_WAIT_TILES = 9 /* cs_stream_wait_tiles(p[0], p[1], p[2], i[0]) */ };
 typedef struct {
     int32_t fn;        /* CS_CALL_* */
     int32_t lane;      /* 0: the calling thread */

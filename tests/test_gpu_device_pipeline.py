@@ -401,15 +401,12 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert set(np.unique(want_b[:, 5])) == {0.0, 1.0, 2.0}
 
 
-@pytest.mark.parametrize("tiles_first", [False, True])
-def test_genome_step_as_one_native_call_equals_the_two_calls(monkeypatch, tiles_first):
+def test_genome_step_as_one_native_call_equals_the_two_calls():
     """parallel.genome_step: the first step of a layout runs stage_genome + detect_patterns and records the library calls it
     made; every later step is ONE cs_run_calls on those arguments (chromosight_amd/plan.py) -- staging, both patterns' chains
-    and the acceptance rules recomputed natively -- and must give the records of the two calls, every time; a second
-    genome (other data, same code path) gets its own plan.  tiles_first: the list with CS_CALL_WAIT_TILE_LAUNCH (the 1-D chain
-    held back until the tile kernels are launched, ONE persistent tile launch; CHROMOSIGHT_HIP_PLAN_TILES_FIRST=1)."""
-    if tiles_first:
-        monkeypatch.setenv("CHROMOSIGHT_HIP_PLAN_TILES_FIRST", "1")
+    (the 1-D chain behind cs_stream_wait_tiles: it starts when the 2-D chain's tile workgroups are resident) and the acceptance
+    rules recomputed natively -- and must give the records of the two calls, every time; a second genome (other data, same
+    code path) gets its own plan."""
     template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
     loops = copy.deepcopy(ck.loops)
     loops["max_dist"] = 200 * 2000
@@ -528,27 +525,23 @@ def test_lazy_float64_bands_equal_the_stored_ones(monkeypatch):
 
 
 def test_switchable_chains_equal_the_default_run(monkeypatch):
-    """cs_detect_foci_batch_templates' asynchronous form (chain enqueued, cs_detect_foci_batch_finish later;
-    CHROMOSIGHT_HIP_EARLY_CHAIN=1 makes detect_patterns use it for the 1-D pattern) == the default run of the same patterns."""
+    """The switchable routes of the two chains == the default run of the same patterns."""
     template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
     cool, _ = make_cool(12_000, 200, 2000, seed=5, template=template)
     loops = copy.deepcopy(ck.loops)
     loops["max_dist"] = 200 * 2000
     want_l, want_b = parallel.detect_patterns(pipeline.DeviceCool(cool), [loops, copy.deepcopy(ck.borders)])
-    # ... and the loops chain with ONE synchronisation (bounded, sentinel-padded candidate list; CHROMOSIGHT_HIP_ONE_SYNC=1),
-    # the 1-D foci through the labelling workgroup instead of the run kernels (CHROMOSIGHT_HIP_NO_PATH_FOCI=1), the runs of a
-    # 1-D pattern scored by the general lane walk instead of rescore_run17 (CHROMOSIGHT_HIP_NO_RUN17=1), the mask tables of
-    # all blocks from one launch (CHROMOSIGHT_HIP_PREP_BATCH=1)
-    # all blocks from one launch (CHROMOSIGHT_HIP_PREP_BATCH=1), the labelling workgroups on global arrays instead of LDS
-    # (CHROMOSIGHT_HIP_NO_LDS_FOCI=1)
-    for switch in ("CHROMOSIGHT_HIP_EARLY_CHAIN", "CHROMOSIGHT_HIP_ONE_SYNC", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
-                   "CHROMOSIGHT_HIP_PREP_BATCH", "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES",
-                   # (the second and third repetition of a switch run on a context that has seen the layout: the candidate list
-                   # sized from the previous call, one synchronisation; the records of the foci by the two kernels instead of one;
-                   # the general run kernel instead of its 17 x 17 instance)
-                   "CHROMOSIGHT_HIP_ADAPTIVE_SYNC", "CHROMOSIGHT_HIP_NO_FUSED_RECORDS", "CHROMOSIGHT_HIP_RUN_GENERAL",
-                   "CHROMOSIGHT_HIP_SPIN_WAIT", "CHROMOSIGHT_HIP_NO_EARLY_UPLOAD", "CHROMOSIGHT_HIP_NO_SPLIT_FUSION",
-                   "CHROMOSIGHT_HIP_NO_SEGMENTED"):
+    # the 2-D chain paced by the host's read of the candidate counts instead of enqueued behind the tile kernels with the counts
+    # on the device (CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN=1), the 1-D foci through the labelling workgroup instead of the run kernels
+    # (CHROMOSIGHT_HIP_NO_PATH_FOCI=1), the runs of a 1-D pattern scored by the general lane walk instead of rescore_run17
+    # (CHROMOSIGHT_HIP_NO_RUN17=1), the labelling workgroups on global arrays instead of LDS (CHROMOSIGHT_HIP_NO_LDS_FOCI=1: the
+    # sorted route for every list), the mask tables behind the staging instead of beside it, the records of the foci by two
+    # kernels instead of one, the general run kernel instead of its 17 x 17 instance, one candidate list sorted on the device
+    # instead of the blocks' own segments.  (Every switch three times: the second and third repetition run on a context that has
+    # seen the layout -- the deferred chain's launches sized from the previous call.)
+    for switch in ("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
+                   "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_FUSED_RECORDS",
+                   "CHROMOSIGHT_HIP_RUN_GENERAL", "CHROMOSIGHT_HIP_NO_SEGMENTED"):
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):

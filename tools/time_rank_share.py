@@ -20,7 +20,7 @@ dcool = pipeline.DeviceCool(cool)
 loops = copy.deepcopy(ck.loops); loops["max_dist"] = 2_000_000
 borders = copy.deepcopy(ck.borders)
 ts = []
-for it in range(24):
+for it in range(int(os.environ.get("CS_STEPS", "24"))):
     dcool.dev.sync(); t0 = time.perf_counter()
     rec = parallel.genome_step(dcool, [loops, borders], owned=mine)
     dcool.dev.sync(); ts.append((time.perf_counter() - t0) * 1e3)

@@ -174,7 +174,7 @@ _PROTOTYPES = {
     "cs_event_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cs_event_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "cs_stream_wait_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cs_stream_wait_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "cs_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "cs_normxcorr2": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsMatrix), C.POINTER(CsKernel),
                                 C.POINTER(CsNormxcorr2Params), C.POINTER(CsMatrix), C.POINTER(CsMatrix)]),
@@ -480,10 +480,10 @@ class Device:
             self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))
         return s.value
 
-    def stream_wait_tiles(self, stream, tiles_dev, timeout_us=500):
-        """cs_stream_wait_tiles: work enqueued on `stream` afterwards starts when the tile workgroups of tiles_dev's next multi-block
-        tile launch are resident (or after the time-out)."""
-        self._check(self.lib.cs_stream_wait_tiles(self.ctx, stream, tiles_dev.ctx, int(timeout_us)))
+    def stream_wait_tiles(self, stream, tiles_dev, epoch, timeout_us=1000):
+        """cs_stream_wait_tiles: work enqueued on `stream` afterwards starts when the tile workgroups of tiles_dev's tile launch with
+        this epoch are resident (or after the time-out)."""
+        self._check(self.lib.cs_stream_wait_tiles(self.ctx, stream, tiles_dev.ctx, int(epoch), int(timeout_us)))
 
     def new_event(self):
         e = C.c_void_p()

@@ -73,6 +73,14 @@ struct cs_ctx {
     // one device word: set by the last workgroup of a multi-block tile launch when it starts (all of them are resident then),
     // consumed by cs_stream_wait_tiles -- the dependency that lets a side chain run in what the tile workgroups leave
     unsigned* d_tiles_started = nullptr;
+    // cs_detect_foci_blocks in two calls (cs_foci_params.reserved & 2: the prepare form): what the prepare form enqueued is valid for a
+    // call with this key
+    bool prep_pending = false, skip_prep_launch = false;
+    // the mask tables of all blocks of a multi-block tile launch in one launch: while set, prepare_regular_mask<float> appends a
+    // block's arguments and its number of workgroups here instead of launching (cs::launch_mask_prep_batch)
+    std::vector<cs::MaskPrepArgs<float>>* prep_collect = nullptr;
+    std::vector<int> prep_groups;
+    unsigned long long prep_key = 0;
     void* d_pool = nullptr;
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
@@ -101,6 +109,7 @@ struct cs_ctx {
     bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
     long long cand_hint = 0, cand_hint_pixels = 0;   // cs_detect_foci_blocks: candidates, pixels and blocks of the previous call
     int cand_hint_blocks = 0;
+    bool cand_hint_paced = false;    // ... and its lists needed the host-paced chain (too long for the labelling workgroups' LDS arrays)
     bool allow_lazy = false; // the entry in progress takes CS_LAYOUT_BAND_LAZY signals (check_matrix)
     long long uploads = 0;   // template weights / fragments / rim tables copied to the device so far (upload_weights, ensure_wfrag)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
@@ -137,7 +146,7 @@ namespace {
 // Worker threads of the host-side passes (cs_accept_records), kept between calls: starting seven threads for the 7 000 records
 // of a rank's share cost more than their work (128 us for 30 us of arithmetic), and on a genome the 1-D pattern's 56 000
 // records are the last thing a step waits for once its launch chain runs behind the tile kernels.  Tasks are taken from a
-// shared counter by the workers AND the caller; a second caller at the same time runs its tasks itself.
+// shared counter by the workers AND the caller; a second caller at the same time runs a short job itself and waits with a long one.
 class HostPool {
 public:
     static HostPool& get()
@@ -149,10 +158,20 @@ public:
     void run(int n_tasks, int max_threads, const F& fn)
     {
         if (n_tasks <= 0) return;
-        std::unique_lock<std::mutex> busy(busy_mu_, std::try_to_lock);
-        if (n_tasks == 1 || max_threads <= 1 || !busy.owns_lock()) {
+        if (n_tasks == 1 || max_threads <= 1) {          // (a single task never takes the pool from a caller that has many)
             for (int t = 0; t < n_tasks; ++t) fn(t);
             return;
+        }
+        // A second caller at the same time: a short job runs its tasks itself; a long one WAITS for the pool -- the two patterns of a
+        // genome step end within microseconds of each other every few steps, and the 1-D pattern's 56 000 records then took 640 us
+        // on the calling thread alone instead of 150 us on the pool behind the 2-D pattern's 40 us (profiles/r05_genome_step_modes.txt)
+        std::unique_lock<std::mutex> busy(busy_mu_, std::try_to_lock);
+        if (!busy.owns_lock()) {
+            if (n_tasks <= 4) {
+                for (int t = 0; t < n_tasks; ++t) fn(t);
+                return;
+            }
+            busy.lock();
         }
         const int want = std::min(std::min(max_threads, n_tasks) - 1, kMaxWorkers);
         grow(want);
@@ -224,14 +243,14 @@ private:
     size_t threads_ = 0;
 };
 
-// cs_stream_wait_tiles: one wave that sleeps until the word is set (the tile workgroups of another stream are resident), takes
-// it back, and gives up after `ticks` of the constant-rate counter (100 MHz) -- the word is a scheduling hint, never a lock
-__global__ void cs_wait_tiles_kernel(unsigned* word, long long ticks)
+// cs_stream_wait_tiles: one wave that sleeps until the word has reached `epoch` (the tile workgroups of the launch that carries this
+// epoch are resident) and gives up after `ticks` of the constant-rate counter (100 MHz) -- the word is a scheduling hint, never a lock
+__global__ void cs_wait_tiles_kernel(const unsigned* word, unsigned epoch, long long ticks)
 {
+    // (epochs only grow: a word left by an earlier launch never lets a later wait through; the difference is taken modulo 2^32)
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && wall_clock64() - t0 < ticks)
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0 && wall_clock64() - t0 < ticks)
         __builtin_amdgcn_s_sleep(16);
-    if (threadIdx.x == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct Laps {
@@ -696,7 +715,17 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     P.side = side;
     P.fix_rows = fix_rows;
     P.fix_cols = fix_cols;
-    {
+    bool collected = false;
+    if constexpr (std::is_same<TC, float>::value) {
+        if (ctx->prep_collect) {             // (cs_detect_foci_blocks, one tile launch: the tables of all blocks from ONE launch)
+            const int n_wg = cs::mask_prep_blocks<float>(P);
+            if (n_wg < 0) return fail(ctx, CS_ERR_HIP, "mask tables: template too large");
+            ctx->prep_collect->push_back(P);
+            ctx->prep_groups.push_back(n_wg);
+            collected = true;
+        }
+    }
+    if (!collected && !ctx->skip_prep_launch) {       // (skip: after the call's own prepare form the tables are in place, only A is wanted)
         int rc = cs::launch_mask_prep<TC>(P, stream);
         if (rc != 0) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rc));
     }
@@ -1300,12 +1329,13 @@ int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event)
     return CS_OK;
 }
 
-int cs_stream_wait_tiles(cs_ctx* ctx, void* stream, cs_ctx* tiles_ctx, int32_t timeout_us)
+int cs_stream_wait_tiles(cs_ctx* ctx, void* stream, cs_ctx* tiles_ctx, int32_t epoch, int32_t timeout_us)
 {
     CS_ENTER(ctx);
     if (!tiles_ctx || !tiles_ctx->d_tiles_started || tiles_ctx->device != ctx->device) return fail(ctx, CS_ERR_INVALID, "no tile context on this device");
-    hipLaunchKernelGGL(cs_wait_tiles_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tiles_ctx->d_tiles_started,
-                       (long long)std::max(1, std::min(timeout_us, 5000)) * 100);
+    if (epoch <= 0 || epoch >= (1 << 23)) return fail(ctx, CS_ERR_INVALID, "tile epochs are 1 .. 2^23 - 1");
+    hipLaunchKernelGGL(cs_wait_tiles_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)tiles_ctx->d_tiles_started,
+                       (unsigned)epoch, (long long)std::max(1, std::min(timeout_us, 5000)) * 100);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
 }
@@ -2395,6 +2425,10 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     hipStream_t stream = (hipStream_t)stream_;
     if (n_blocks <= 0 || !signals || !kernel || !params || !foci || !h_n_foci || cap < 0 || (cap > 0 && !h_foci))
         return fail(ctx, CS_ERR_INVALID, "bad batch arguments");
+    const bool prepare_only = (foci[0].reserved & 2) != 0;
+    const unsigned tile_epoch = (unsigned)foci[0].reserved >> 8;          // (0: nobody waits for this call's tile launch)
+    const bool was_pending = ctx->prep_pending;
+    ctx->prep_pending = false;                     // (whatever a prepare form left is used by the very next call or not at all)
     constexpr int kKeyShift = 40;                 // row * ns + col < 2^40: sub-matrices of up to 2^20 bins
     bool all_narrow = true;
     long long pixels = 0;
@@ -2418,7 +2452,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         block_pixels[(size_t)b] = (long long)p->ms * std::min<long long>(w, p->ns);
     }
     if (all_narrow && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW"))
-        return cs_detect_foci_batch(ctx, stream_, n_blocks, signals, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
+        return prepare_only ? CS_OK : cs_detect_foci_batch(ctx, stream_, n_blocks, signals, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
     if (params[0].compute_dtype != CS_F32) return fail(ctx, CS_ERR_UNSUPPORTED, "the 2-D batch runs the float32 tile kernel");
     if (kernel->km != kernel->kn || kernel->km > 17 || kernel->km < 3 || !(kernel->km & 1))
         return fail(ctx, CS_ERR_UNSUPPORTED, "the masked tile kernel takes odd square templates of 3 .. 17 (caller: block by block)");
@@ -2460,11 +2494,13 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         long long* n;
         long long px;
         int nb;
-        ~HintUpdate() { c->cand_hint = *n; c->cand_hint_pixels = px; c->cand_hint_blocks = nb; }
+        bool on;
+        bool paced;
+        ~HintUpdate() { if (on) { c->cand_hint = *n; c->cand_hint_pixels = px; c->cand_hint_blocks = nb; c->cand_hint_paced = paced; } }
     };
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     long long n_total = 0;
-    HintUpdate hint_update{ctx, &n_total, (long long)pixels, n_blocks};
+    HintUpdate hint_update{ctx, &n_total, (long long)pixels, n_blocks, !prepare_only, same_layout && ctx->cand_hint_paced};
     // SEGMENTED candidate lists: every block appends to a region of its own with a counter of its own (room in proportion to
     // its pixels), so the chain behind the tile kernels knows the blocks' segments from n_blocks counts instead of sorting
     // all candidates by block and position -- the labelling workgroup of a block sorts its own few thousand in LDS (cs_foci.hip
@@ -2479,6 +2515,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     constexpr size_t kCntBytes = 8 * 64;           // the one list's counter (and a spare word) + up to 60 blocks' own
     size_t off_tail_now = 0;                        // where the chain's scratch starts in the current layout
     bool segmented = false;
+    bool pass_again = false;                        // a list outgrew its room: this pass does everything itself, whatever was prepared
     while (true) {
         if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
         size_t list_cap = c_cap;
@@ -2518,7 +2555,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         if (!prepared) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (tile kernels go out block by block below)
         int table_rsym = -1;
         if (prepared) {
-            const size_t need = al(cs::mfma_blocks_table_bytes(n_blocks));
+            const size_t need = al(cs::mfma_blocks_table_bytes(n_blocks)) + cs::mask_prep_table_bytes(n_blocks);
             if (need > ctx->tab_bytes) {
                 CS_HIP(ctx, hipDeviceSynchronize());
                 if (ctx->h_tab) CS_HIP(ctx, hipHostFree(ctx->h_tab));
@@ -2534,7 +2571,10 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 ctx->ws_tab_bytes.resize((size_t)n_blocks, 0);
             }
         }
-        const bool deferred = segmented && cs::keyed_batch_deferred_available() && !std::getenv("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN");
+        // (a layout whose lists went to the host-paced chain last time -- a block with more candidates than the labelling
+        // workgroup's LDS arrays hold -- goes there directly)
+        const bool deferred = segmented && cs::keyed_batch_deferred_available() && !(same_layout && ctx->cand_hint_paced) &&
+                              !std::getenv("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN");
         if (tab.empty()) {
             // the float64 argument blocks of the chain behind the tile kernels: built (and, for the chain that is enqueued ahead
             // of the counts, uploaded) while the caller's stream is still staging the maps
@@ -2596,13 +2636,48 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
             }
         }
+        // The PREPARE form (foci[0].reserved & 2): everything of this call that does not depend on the maps -- the blocks' mask
+        // tables, the zeroed counters, the tile kernels' argument table and the chain's -- is enqueued on the side lanes NOW,
+        // and the call returns; the same call without the flag, made next on this context, finds it done.  A genome step makes
+        // the prepare form BEFORE cs_stage_blocks: the lanes' work is then long finished when the staging is, and the tile
+        // launch behind the staging waits for events that have fired -- a wait for an event that fires later costs the queue
+        // 20-40 us (profiles/r05_rank_share_timeline.txt: staging done at 76 us, lanes at 93, tile kernel at 134).
+        const bool can_split = table && prepared && early_tables && deferred;
+        unsigned long long key = 1469598103934665603ull;
+        {
+            auto mix = [&](const void* p, size_t n) {
+                const unsigned char* q = (const unsigned char*)p;
+                for (size_t k = 0; k < n; ++k) key = (key ^ q[k]) * 1099511628211ull;
+            };
+            mix(params, sizeof(cs_normxcorr2_params) * (size_t)n_blocks);
+            for (int b = 0; b < n_blocks; ++b) {
+                cs_foci_params f = foci[b];
+                f.reserved = 0;
+                mix(&f, sizeof(f));
+            }
+            mix(signals, sizeof(cs_matrix) * (size_t)n_blocks);
+            if (signals_f32) mix(signals_f32, sizeof(cs_matrix) * (size_t)n_blocks);
+            mix(kernel, sizeof(cs_kernel));
+            const long long extra[4] = {ctx->uploads, (long long)c_cap, (long long)n_blocks, (long long)(uintptr_t)ctx->d_pool};
+            mix(extra, sizeof(extra));
+        }
+        if (prepare_only && !can_split) return CS_OK;
+        const bool reuse = !prepare_only && was_pending && can_split && key == ctx->prep_key && !pass_again;
+        struct SkipLaunch {
+            cs_ctx* c;
+            SkipLaunch(cs_ctx* c_, bool on) : c(c_) { c->skip_prep_launch = on; }
+            ~SkipLaunch() { c->skip_prep_launch = false; }
+        } skip_launch(ctx, reuse);
+        // (one persistent tile launch: ONE side lane carries all of it -- every event the launch waits for costs the caller's
+        // queue ~ 7 us between the staging and the tile kernel, and the lane's work is off the critical path)
+        const int side_lanes = (table && early_tables) ? 1 : n_lanes - 1;
         laps.lap("pool, weights, events");
         // One tile launch + the lanes busy with the mask tables while the caller's stream is still staging the maps: the zeroed
         // counter (first) and the argument table (behind the tables of its lane) travel on the LAST side lane, which carries the
         // fewest tables -- ordered before the launch by the lanes' events below -- instead of sitting between the staging and
         // the tile kernel
         const bool early_upload = table && early_tables && n_lanes > 1;
-        if (early_upload) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[n_lanes - 2]));
+        if (early_upload && !reuse) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[side_lanes - 1]));
         // (largest blocks first on every lane: the short ones fill the end)
         std::vector<int> launch_order((size_t)n_blocks);
         for (int b = 0; b < n_blocks; ++b) launch_order[b] = b;
@@ -2610,10 +2685,23 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             std::stable_sort(launch_order.begin(), launch_order.end(), [&](int x, int y) {
                 return (long long)params[x].ms * (foci[x].hi_diag - foci[x].lo_diag + 1) > (long long)params[y].ms * (foci[y].hi_diag - foci[y].lo_diag + 1);
             });
+        // one tile launch: the mask tables of all blocks from ONE launch on the side lane (collected in the loop, launched
+        // behind it) -- a launch per block takes 30-90 us each beside a genome's staging kernels
+        const bool one_prep = table && early_tables;
+        std::vector<cs::MaskPrepArgs<float>> prep_list;
+        struct PrepCollect {
+            cs_ctx* c;
+            PrepCollect(cs_ctx* c_, std::vector<cs::MaskPrepArgs<float>>* v) : c(c_)
+            {
+                c->prep_collect = v;
+                c->prep_groups.clear();
+            }
+            ~PrepCollect() { c->prep_collect = nullptr; }
+        } prep_collect(ctx, one_prep ? &prep_list : nullptr);
         int next_side = 0;
         for (int b : launch_order) {
             // (early tables: on the side lanes only, dealt round-robin in launch order -- largest first)
-            const int lane = early_tables ? 1 + (next_side++) % (n_lanes - 1) : lane_of[b];
+            const int lane = early_tables ? 1 + (next_side++) % side_lanes : lane_of[b];
             hipStream_t stream = lane == 0 ? (hipStream_t)stream_ : ctx->s_blk[lane - 1];
             struct WsSwap {                   // the side lanes build their mask tables in their own scratch
                 cs_ctx* c;
@@ -2677,15 +2765,31 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 return rc;
             }
         }
+        if (one_prep) {
+            ctx->prep_collect = nullptr;
+            if (!reuse) {
+                const size_t tile_tab_bytes = al(cs::mfma_blocks_table_bytes(n_blocks));
+                int rcp = cs::launch_mask_prep_batch(prep_list.data(), ctx->prep_groups.data(), (int)prep_list.size(), (char*)ctx->h_tab + tile_tab_bytes,
+                                                     (char*)ctx->d_tab + tile_tab_bytes, ctx->s_blk[0]);
+                if (rcp) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rcp));
+            }
+        }
         laps.lap("mask tables + arguments");
         bool tab_uploaded = false;
         if (early_upload) {
-            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[n_lanes - 2], true, false);
+            // (reuse: both tables were uploaded by the prepare form; the host-side table is still filled in -- the launch reads
+            // its block count and tile ranges from it)
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[side_lanes - 1], !reuse, false);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel table upload failed: %s", hipGetErrorString((hipError_t)rc));
             if (deferred) {
-                rc = cs::upload_keyed_batch_table(tab.data(), n_blocks, (long long)list_cap, pool + off_tail, ctx->s_blk[n_lanes - 2]);
+                if (!reuse) rc = cs::upload_keyed_batch_table(tab.data(), n_blocks, (long long)list_cap, pool + off_tail, ctx->s_blk[side_lanes - 1]);
                 if (rc) return fail(ctx, CS_ERR_HIP, "argument table upload failed: %s", hipGetErrorString((hipError_t)rc));
                 tab_uploaded = true;
+            }
+            if (prepare_only) {
+                ctx->prep_key = key;
+                ctx->prep_pending = true;
+                return CS_OK;
             }
         } else if (prepared && early_tables) {
             CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (before the event the lanes' tile kernels wait for, below)
@@ -2693,8 +2797,8 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         if (early_tables) {
             // the tile kernels read the maps and the zeroed counter: behind the caller's stream.  A block whose tables were
             // built on another lane than the one that launches its tiles: every lane waits for every lane's tables.
-            CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));
             if (!table) {
+                CS_HIP(ctx, hipEventRecord(ctx->ev_blk[kBlkLanes - 1], stream));
                 for (int k = 0; k < n_lanes - 1; ++k) CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
                 for (int k = 0; k < n_lanes - 1; ++k) {
                     CS_HIP(ctx, hipStreamWaitEvent(ctx->s_blk[k], ctx->ev_blk[kBlkLanes - 1], 0));
@@ -2717,18 +2821,18 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             }
         }
         if (n_lanes > 1) {
-            for (int k = 0; k < n_lanes - 1; ++k) {
+            for (int k = 0; k < (table && early_tables ? side_lanes : n_lanes - 1); ++k) {
                 CS_HIP(ctx, hipEventRecord(ctx->ev_blk[k], ctx->s_blk[k]));
                 CS_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_blk[k], 0));
             }
         }
         if (table) {
             rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, stream, !early_upload, true,
-                                             ctx->d_tiles_started);
+                                             tile_epoch ? ctx->d_tiles_started : nullptr, tile_epoch);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        } else if (ctx->d_tiles_started) {
-            // (the per-block launches carry no start word: whoever waits for it -- cs_stream_wait_tiles -- is let go here)
-            CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_tiles_started, 1, 1, stream));
+        } else if (tile_epoch) {
+            // (the per-block launches carry no start word: whoever waits for this epoch -- cs_stream_wait_tiles -- is let go here)
+            CS_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_tiles_started, (int)tile_epoch, 1, stream));
         }
         laps.lap("tile kernels launched");
         // ---- The chain behind the tile kernels, enqueued BEFORE they have finished (segmented lists): the blocks' candidate
@@ -2791,6 +2895,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             n_total = sum;
             if (!fits) {
                 c_cap = (size_t)worst + (size_t)worst / 8;
+                pass_again = true;
                 continue;
             }
             if (counts_known && ctx->h_cand_counts[61] == 0) {
@@ -2801,11 +2906,13 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 if (total > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld foci, room for %lld", total, (long long)cap);
                 return CS_OK;
             }
+            if (counts_known) hint_update.paced = (ctx->h_cand_counts[61] & 2) != 0;
             break;
         }
         n_total = ctx->h_counts[0];
         if ((size_t)n_total <= c_cap) break;
         c_cap = (size_t)n_total + (size_t)n_total / 8;
+        pass_again = true;
     }
     // ---- exact scores, foci, statistics: one chain for all blocks (its argument table was built while the tile kernels ran),
     // sized by the counts the host has read
@@ -3034,7 +3141,7 @@ int dispatch_call(cs_call& c)
         case CS_CALL_DETECT_FOCI_BATCH_FINISH:
             return cs_detect_foci_batch_finish((cs_ctx*)p[0], p[1], (int64_t*)p[2]);
         case CS_CALL_STREAM_WAIT_TILES:
-            return cs_stream_wait_tiles((cs_ctx*)p[0], p[1], (cs_ctx*)p[2], (int32_t)i[0]);
+            return cs_stream_wait_tiles((cs_ctx*)p[0], p[1], (cs_ctx*)p[2], (int32_t)i[0], (int32_t)i[1]);
         default:
             return CS_ERR_INVALID;
     }

@@ -667,8 +667,8 @@ struct MfmaBlocksArgs {
     const MfmaDenseArgs* args;
     const int* first;
     int n_blocks, n_tiles;
-    unsigned* started;       // (or null) set to 1 by the LAST workgroup when it starts: workgroups are dispatched in order, so every
-                             // workgroup of the launch is resident then (cs_stream_wait_tiles)
+    unsigned* started;       // (or null) set to `epoch` by the LAST workgroup when it starts: workgroups are dispatched in order, so
+    unsigned epoch;          // every workgroup of the launch is resident then (cs_stream_wait_tiles)
 };
 
 typedef const __attribute__((address_space(4))) MfmaDenseArgs MfmaDenseArgsC;
@@ -688,7 +688,7 @@ template <bool RSYM>
 __global__ __launch_bounds__(256, 2) void corr_mfma_blocks_kernel(const MfmaBlocksArgs T)
 {
     typedef const __attribute__((address_space(4))) int IntC;
-    if (T.started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_store(T.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (T.started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_store(T.started, T.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, step = gridDim.x >> 3;
     const int per = (T.n_tiles + 7) / 8;
     const int lo_x = x * per, hi_x = min(T.n_tiles, (x + 1) * per);
@@ -935,7 +935,7 @@ int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_ca
 // (do_upload / launch: a caller that uploads on a side stream makes two calls -- upload only, then launch only; the caller's own
 // stream may be the null stream, so "no upload" is a flag and not a null handle)
 int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t stream, hipStream_t upload,
-                            bool do_upload, bool launch, unsigned* started)
+                            bool do_upload, bool launch, unsigned* started, unsigned epoch)
 {
     if (n_blocks <= 0) return 0;
     int* first = reinterpret_cast<int*>(h_table);
@@ -958,6 +958,7 @@ int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym
     T.n_blocks = n_blocks;
     T.n_tiles = (int)total;
     T.started = started;
+    T.epoch = epoch;
     const void* kr = rsym ? (const void*)corr_mfma_blocks_kernel<true> : (const void*)corr_mfma_blocks_kernel<false>;
     e = allow_big_lds(kr);
     if (e != hipSuccess) return (int)e;

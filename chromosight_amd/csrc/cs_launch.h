@@ -53,7 +53,7 @@ size_t mfma_blocks_arg_bytes();
 size_t mfma_blocks_arg_offset(int n_blocks);
 size_t mfma_blocks_table_bytes(int n_blocks);
 int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t s, hipStream_t upload, bool do_upload, bool launch,
-                            unsigned* started = nullptr);
+                            unsigned* started = nullptr, unsigned epoch = 0);
 // one block of such a table as its own persistent launch (its mask tables were prepared earlier)
 int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_cap, hipStream_t s);
 

@@ -784,5 +784,12 @@ struct MaskPrepArgs {
 };
 template <typename TC>
 int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream);
+// the same for several matrices in ONE launch (the blocks of a multi-block tile launch): mask_prep_blocks fills a matrix's workgroup
+// ranges and returns their number; launch_mask_prep_batch copies the table (first[], arguments) through h_tab (page-locked) to d_tab
+// (mask_prep_table_bytes each) and launches
+template <typename TC>
+int mask_prep_blocks(MaskPrepArgs<TC>& P);
+size_t mask_prep_table_bytes(int n);
+int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream);
 
 }  // namespace cs

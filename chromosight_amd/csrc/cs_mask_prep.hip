@@ -373,6 +373,32 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(MaskPrepArgs<TC> P)
     }
 }
 
+// The tables of SEVERAL matrices (the blocks of a genome) in one launch: tab[k] = the arguments of matrix k, its workgroups
+// are first[k] .. first[k + 1].  One launch per block is 12 us alone and 30-90 us beside the staging kernels of a genome step (profiles/r05_genome_timeline.txt: 23 of
+// them in a row outlast the staging and hold the tile launch back); one launch for all of them does not.
+template <typename TC>
+__global__ __launch_bounds__(256) void mask_prep_batch_kernel(const MaskPrepArgs<TC>* __restrict__ tab, const int* __restrict__ first, int n)
+{
+    int lo = 0, hi = n - 1;
+    const int g = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= g) lo = mid;
+        else hi = mid - 1;
+    }
+    const MaskPrepArgs<TC> P = tab[lo];
+    const int b = g - first[lo];
+    if (b < P.b_tab) {
+        mask_rowcol_tables<TC>(b, P.b_rows, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab);
+    } else if (b < P.b_tab + P.b_edge) {
+        mask_edge_fix<TC>(b - P.b_tab, P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.max_dist, P.hi_d0, P.hi_w, P.w, P.fix_lo,
+                          P.fix_hi);
+    } else {
+        mask_frame_fix<TC>(b - P.b_tab - P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.sym_upper, P.max_dist, P.w, P.top, P.bot0,
+                           P.width, P.x_band, P.x_lo, P.side, P.edge, P.fix_rows, P.fix_cols);
+    }
+}
+
 }  // namespace
 
 // workgroup ranges of one matrix (b_rows, b_tab, b_edge filled in); returns the number of workgroups, -1: template too large
@@ -406,7 +432,33 @@ int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+size_t mask_prep_table_bytes(int n) { return (((size_t)(n + 1) * sizeof(int) + 255) & ~(size_t)255) + (size_t)n * sizeof(MaskPrepArgs<float>); }
+
+int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    const size_t off = ((size_t)(n + 1) * sizeof(int) + 255) & ~(size_t)255;
+    int* first = reinterpret_cast<int*>(h_tab);
+    long long total = 0;
+    for (int k = 0; k < n; ++k) {
+        first[k] = (int)total;
+        total += n_groups[k];
+        if (total > 0x7fffffffLL) return -3;
+    }
+    first[n] = (int)total;
+    if (total == 0) return 0;
+    std::memcpy((char*)h_tab + off, args, (size_t)n * sizeof(MaskPrepArgs<float>));
+    hipError_t e = hipMemcpyAsync(d_tab, h_tab, mask_prep_table_bytes(n), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mask_prep_batch_kernel<float>, dim3((unsigned)total), dim3(256), 0, stream,
+                       reinterpret_cast<const MaskPrepArgs<float>*>((const char*)d_tab + off), reinterpret_cast<const int*>(d_tab), n);
+    return (int)hipGetLastError();
+}
+
 template int launch_mask_prep<float>(MaskPrepArgs<float>, hipStream_t);
 template int launch_mask_prep<double>(MaskPrepArgs<double>, hipStream_t);
+
+template int mask_prep_blocks<float>(MaskPrepArgs<float>&);
+template int mask_prep_blocks<double>(MaskPrepArgs<double>&);
 
 }  // namespace cs

@@ -46,6 +46,15 @@ def _fill(call, fn, kinds, values, lane, after=-1):
             nd += 1
 
 
+_EPOCH = [0]
+
+
+def _next_epoch():
+    """Tile epochs (cs_stream_wait_tiles): 1 .. 2^23 - 1, growing, process-wide."""
+    _EPOCH[0] = _EPOCH[0] % ((1 << 23) - 1) + 1
+    return _EPOCH[0]
+
+
 class StepPlan:
     """The native call list of stage_genome + detect_patterns for (genome, [2-D configuration, 1-D configuration], owned)."""
 
@@ -120,7 +129,7 @@ class StepPlan:
         # its head lets it go when the last tile workgroup has started (round 4 held it back with a sleeping wave of a fixed
         # 45 us, a constant tuned on one genome and one box); it then runs in what the tile workgroups leave and still ends
         # before the 2-D chain's tail.
-        n_calls = 9
+        n_calls = 10
         calls = (CsCall * n_calls)()
         k = 0
 
@@ -128,14 +137,6 @@ class StepPlan:
             nonlocal k
             k += 1
             return calls[k - 1]
-        _fill(nxt(), *_SLOTS["cs_stage_blocks"], stage[0], 0)
-        _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)
-        _fill(nxt(), *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=1)
-        _fill(nxt(), CALL_STREAM_WAIT_TILES, "pppi", (ctx_b, stream_b, ctx_a, 500), 1)
-        b = list(batch[0])
-        b[8], b[9] = self.rec1.ctypes.data, self.cap1
-        b[7][0].reserved = 1                                  # asynchronous form: return once the chain is enqueued
-        _fill(nxt(), *_SLOTS["cs_detect_foci_batch_templates"], b, 1)
         a = list(blocks[0])
         a[8], a[9] = self.rec2.ctypes.data, self.cap2
         if not os.environ.get("CHROMOSIGHT_HIP_PLAN_NO_TABLE"):
@@ -144,7 +145,29 @@ class StepPlan:
             # 3.25 -> 3.02 ms, a share of 2: 1.89 -> 1.69, of 4: 1.11 -> 0.96 (profiles/r04b_step_modes.txt).  Without the
             # dependency the same launch was the slower choice (round 3: 5.6 against 4.4 ms).
             a[7][0].exclusive = 1
-        _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], a, 0)
+        # The 2-D chain's PREPARE form first (cs_foci_params.reserved & 2 on a copy of the parameter table): mask tables, zeroed
+        # counters and both argument tables go to the side lanes before the staging is even enqueued, so the tile launch behind
+        # the staging waits for lanes that finished long ago instead of for events that fire after it reaches them.
+        prep = list(a)
+        prep_params = type(a[7])()
+        C.memmove(prep_params, a[7], C.sizeof(a[7]))
+        prep_params[0].reserved |= 2
+        prep[7] = prep_params
+        self.keep_prep, self.params2 = prep_params, a[7]
+        # (on a lane of its own: its ~ 25 us of host work -- three table launches, two uploads -- run beside lane 0's staging call
+        # instead of in front of it; the two calls touch disjoint parts of the genome's context: staging scratch and tables on
+        # one side, the foci pool, the mask tables and the template's weights on the other.  The full call waits for it: `after`)
+        _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], prep, 2)
+        _fill(nxt(), *_SLOTS["cs_stage_blocks"], stage[0], 0)
+        _fill(nxt(), *_SLOTS["cs_event_record"], rec_ev[-1], 0)
+        _fill(nxt(), *_SLOTS["cs_stream_wait_event"], waits[-1], 1, after=2)
+        self.i_wait = k
+        _fill(nxt(), CALL_STREAM_WAIT_TILES, "pppii", (ctx_b, stream_b, ctx_a, 1, 1000), 1)     # (the epoch is set per run)
+        b = list(batch[0])
+        b[8], b[9] = self.rec1.ctypes.data, self.cap1
+        b[7][0].reserved = 1                                  # asynchronous form: return once the chain is enqueued
+        _fill(nxt(), *_SLOTS["cs_detect_foci_batch_templates"], b, 1)
+        _fill(nxt(), *_SLOTS["cs_detect_foci_blocks"], a, 0, after=0)
         self._accept(nxt(), self.rec2, self.counts2, self.acc2, cfg2, 0)
         _fill(nxt(), CALL_DETECT_FOCI_BATCH_FINISH, "ppp", (ctx_b, stream_b, self.counts1), 1)
         self._accept(nxt(), self.rec1, self.counts1, self.acc1, cfg1, 1)
@@ -169,6 +192,11 @@ class StepPlan:
         # one call in flight per context (engine._one_call_per_context): the list runs on the genome's context (lane 0) and
         # on the 1-D chain's worker context (lane 1); both are held for the call, always in the same order
         with self.locks[0], self.locks[1]:
+            # this step's tile epoch: carried by the 2-D chain's parameter tables (both forms) and awaited by the 1-D chain
+            epoch = _next_epoch()
+            self.calls[self.i_wait].i[0] = epoch
+            for params in (self.keep_prep, self.params2):
+                params[0].reserved = (params[0].reserved & 0xff) | (epoch << 8)
             rc = self.lib.cs_run_calls(self.calls, len(self.calls))
         if rc != 0:
             if os.environ.get("CHROMOSIGHT_HIP_DEBUG"):

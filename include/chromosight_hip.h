@@ -99,15 +99,16 @@ int cs_event_record(cs_ctx* ctx, void* event, void* stream);
 /* work enqueued on `stream` after this call starts only when `event` (recorded on any stream of the same GPU, by any
  * context) has fired: ordering between streams without a host synchronisation */
 int cs_stream_wait_event(cs_ctx* ctx, void* stream, void* event);
-/* Work enqueued on `stream` after this call starts only when the tile workgroups of `tiles_ctx`'s NEXT multi-block tile launch
- * (cs_detect_foci_blocks: one persistent launch over the tiles of all blocks) are resident -- its last workgroup sets a word when
- * it starts, one sleeping wave on `stream` waits for the word and takes it back -- or after `timeout_us` (at most 5000; the word
- * is a scheduling hint, not a lock: a tile launch that never comes only costs the time-out).  Why: a launch chain that waits for
- * the same event as a persistent launch of another stream races it for the workgroup slots, and the persistent workgroups it
- * displaces start late and -- their tile ranges being static -- finish late (a rank's step took 0.6 or 0.75 ms depending on which
- * chain won).  Behind this call the chain runs in what the tile workgroups leave, every time (chromosight_amd/plan.py: the 1-D
- * pattern's chain beside the 2-D pattern's tile kernels).  Both contexts on the same GPU. */
-int cs_stream_wait_tiles(cs_ctx* ctx, void* stream, cs_ctx* tiles_ctx, int32_t timeout_us);
+/* Work enqueued on `stream` after this call starts only when the tile workgroups of the cs_detect_foci_blocks call on `tiles_ctx`
+ * that carries the same EPOCH (cs_foci_params.reserved >> 8 of its entry 0: 1 .. 2^23 - 1, growing from call to call) are resident
+ * -- the last workgroup of its tile launch stores the epoch in a word of the context when it starts, one sleeping wave on `stream`
+ * waits until the word has reached it -- or after `timeout_us` (at most 5000; the word is a scheduling hint, not a lock: a tile
+ * launch that never comes only costs the time-out, and a word left by an earlier launch never lets a later wait through).  Why:
+ * a launch chain that waits for the same event as a persistent launch of another stream races it for the workgroup slots, and
+ * the persistent workgroups it displaces start late and -- their tile ranges being static -- finish late (a rank's step took 0.6
+ * or 0.75 ms depending on which chain won).  Behind this call the chain runs in what the tile workgroups leave, every time
+ * (chromosight_amd/plan.py: the 1-D pattern's chain beside the 2-D pattern's tile kernels).  Both contexts on the same GPU. */
+int cs_stream_wait_tiles(cs_ctx* ctx, void* stream, cs_ctx* tiles_ctx, int32_t epoch, int32_t timeout_us);
 /* synchronises on `stop`, then returns the elapsed milliseconds between the two events */
 int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms);
 
@@ -329,7 +330,8 @@ typedef struct {
                                per-block arguments); 0 = one launch per block over several streams, which leaves
                                gaps for the launch chains of other templates running side by side (calls with up
                                to four blocks take the single launch either way)                                */
-    int32_t reserved;
+    int32_t reserved;       /* bit 0: asynchronous form (cs_detect_foci_batch_finish), bit 1: prepare form (cs_detect_foci_blocks),
+                               bits 8 ..: tile epoch (cs_stream_wait_tiles); 0 for a plain call */
 } cs_foci_params;
 
 typedef struct {
@@ -395,7 +397,14 @@ int cs_detect_foci_batch_finish(cs_ctx* ctx, void* stream, int64_t* h_n_foci);
  * streams as soon as the call is entered, beside whatever `stream` is still running (the staging of the maps); only the
  * maps themselves are ordered behind `stream`.  A caller that produces the flags on `stream` synchronises it (or waits for
  * an event of it) first.  While an asynchronous batch is pending on the context (cs_detect_foci_batch_finish not yet
- * called) every foci / quantify entry on it answers CS_ERR_INVALID: they share its count words, block tables and pool. */
+ * called) every foci / quantify entry on it answers CS_ERR_INVALID: they share its count words, block tables and pool.
+ * PREPARE form (foci[0].reserved & 2): everything of the call that does not depend on the maps -- the blocks' mask tables, the
+ * zeroed candidate counters, the argument tables of the tile launch and of the chain behind it -- is enqueued on the context's
+ * side streams and the call returns CS_OK at once (nothing is written to the outputs); the SAME call without the flag, made
+ * next on this context with the same arguments, finds that work done (anything else in between, or other arguments, and it
+ * simply does everything itself).  A caller that stages the maps on `stream` makes the prepare form BEFORE the staging: the
+ * tile launch behind the staging then waits for side streams that finished long ago -- a stream that reaches a wait for an
+ * event that has not fired yet loses 20-40 us to it. */
 int cs_detect_foci_blocks(cs_ctx* ctx, void* stream, int32_t n_blocks, const cs_matrix* signals, const cs_matrix* signals_f32,
                           const cs_kernel* kernel, const cs_normxcorr2_params* params, const cs_foci_params* foci,
                           cs_focus* h_foci, int64_t cap, int64_t* h_n_foci, double* h_windows);
@@ -448,7 +457,7 @@ int cs_label_foci(cs_ctx* ctx, void* stream, int32_t ms, int32_t ns, const int32
  * return value is the first non-zero rc (0: every call succeeded). */
 enum { CS_CALL_STAGE_BLOCKS = 1, CS_CALL_EVENT_RECORD = 2, CS_CALL_STREAM_WAIT_EVENT = 3, CS_CALL_DETECT_FOCI_BLOCKS = 4,
        CS_CALL_DETECT_FOCI_BATCH_TEMPLATES = 5, CS_CALL_ACCEPT_RECORDS = 6, CS_CALL_DETECT_FOCI_BATCH_FINISH = 7,
-       CS_CALL_STREAM_WAIT_TILES = 9 /* cs_stream_wait_tiles(p[0], p[1], p[2], i[0]) */ };
+       CS_CALL_STREAM_WAIT_TILES = 9 /* cs_stream_wait_tiles(p[0], p[1], p[2], i[0], i[1]) */ };
 typedef struct {
     int32_t fn;        /* CS_CALL_* */
     int32_t lane;      /* 0: the calling thread */

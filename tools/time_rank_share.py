@@ -28,8 +28,12 @@ px = sum(costs[i] for i in mine)
 plans = dcool.__dict__.get("_step_plans", {})
 if not all(p.ok for p in plans.values()) or not plans:
     print("no step plan:", [p.why for p in plans.values()])
-print(f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (median {np.median(ts[4:]):.3f}, min {min(ts):.3f}); "
+line = (f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (median {np.median(ts[4:]):.3f}, min {min(ts):.3f}); "
       f"patterns {[len(r) for r in rec]}")
+slow = sorted(t for t in ts[4:] if t > 1.2 * np.median(ts[4:]))
+if slow:
+    line += f"; {len(slow)} of {len(ts) - 4} steps above 1.2 x the median: " + " ".join(f"{t:.3f}" for t in slow[-8:])
+print(line)
 if os.environ.get("STEPS"):
     print("steps (ms):", " ".join(f"{t:.3f}" for t in ts))
 if os.environ.get("PROFILE"):

@@ -916,6 +916,19 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
     n_chrom = dcool.n_chrom
     max_dist = max(kernel_config["max_dist"] // binsize, 1)
     largest = max(np.shape(k)[0] for k in kernel_config["kernels"])
+    if not inter and not return_windows and not smooth and np.dtype(band_dtype) == np.float64 and dcool.upper and hasattr(dcool, "view_for"):
+        # ONE orchestration: the intra-chromosomal blocks of a plain `detect` go through the genome drivers bench.py times
+        # (parallel.genome_step: blocks staged by one native call, batched chains, and -- for the configurations a StepPlan covers,
+        # chromosight_amd/plan.py -- every call after the first on this DeviceCool as one native call list); the per-block
+        # machinery below keeps --inter, --smooth-trend and the runs that return windows.
+        from . import parallel
+        rec = parallel.genome_step(dcool, [kernel_config], tsvd=tsvd)[0]
+        if rec.shape[0] == 0:
+            return pd.DataFrame(columns=OUTPUT_COLUMNS)
+        first = np.asarray(off, dtype=np.int64)[rec[:, 0].astype(np.int64)]
+        coords = {"bin1": rec[:, 1].astype(np.int64) + first, "bin2": rec[:, 2].astype(np.int64) + first, "score": rec[:, 3],
+                  "pvalue": rec[:, 4], "kernel_id": rec[:, 5].astype(np.int64), "iteration": rec[:, 6].astype(np.int64)}
+        return postprocess(coords, kernel_config, binsize, off, names, dcool.bin_start, dcool.bin_end)
     pairs = sub_matrices(dcool, inter)
     intra = dict(zip([a for a, b in pairs if a == b],
                      dcool.stage_blocks([a for a, b in pairs if a == b], max_dist, largest, smooth=smooth, band_dtype=band_dtype)))

@@ -429,6 +429,39 @@ def test_genome_step_as_one_native_call_equals_the_two_calls():
                 assert np.allclose(got[:, 4], ref[:, 4], rtol=1e-9, atol=1e-300)
 
 
+def test_single_pattern_steps_are_planned_and_feed_pipeline_detect():
+    """A 2-D pattern alone (loops) and a 1-D pattern alone (borders) are steps a StepPlan covers too: replayed steps equal
+    detect_genome's records; pipeline.detect -- the CLI counterpart -- runs the same orchestration (parallel.genome_step: its
+    second call on a DeviceCool is the replayed list) and returns the same table every time; hairpins (one 1-D template) and
+    two iterations are not planned and take the usual calls."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(12_000, 200, 2000, seed=7, template=template, chrom_sizes=[4000, 3500, 2500, 2000])
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    for cfg in (loops, copy.deepcopy(ck.borders)):
+        dcool = pipeline.DeviceCool(cool)
+        want = parallel.detect_genome(dcool, cfg)
+        steps = [parallel.genome_step(dcool, [cfg]) for _ in range(4)]
+        plans = dcool.__dict__["_step_plans"]
+        assert len(plans) == 1 and all(p.ok for p in plans.values()), [p.why for p in plans.values()]
+        for step in steps:
+            got = step[0]
+            assert got.shape == want.shape and want.shape[0] > 30
+            assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]])
+            assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9
+        dcool = pipeline.DeviceCool(cool)
+        tables = [pipeline.detect(dcool, cfg) for _ in range(3)]
+        assert all(p.ok for p in dcool.__dict__["_step_plans"].values())
+        assert len(tables[0]) > 20
+        for t in tables[1:]:
+            assert t[["bin1", "bin2", "kernel_id"]].equals(tables[0][["bin1", "bin2", "kernel_id"]])
+            assert np.abs(t["score"].to_numpy() - tables[0]["score"].to_numpy()).max() < 1e-9
+    for cfg in (copy.deepcopy(ck.hairpins), dict(loops, max_iterations=2)):
+        dcool = pipeline.DeviceCool(cool)
+        a, b = pipeline.detect(dcool, cfg), pipeline.detect(dcool, cfg)
+        assert not dcool.__dict__.get("_step_plans") and a[["bin1", "bin2"]].equals(b[["bin1", "bin2"]])
+
+
 def test_lazy_float64_bands_equal_the_stored_ones(monkeypatch):
     """stage_genome's default: the float64 band of a block is stored for its first diagonals only and the float64 kernels
     recompute every other pixel they read from the pixel table (cs_stage_block.d_lazy).

@@ -124,7 +124,11 @@ class Workload:
             ld_in = band.shape[1]
             self.shape = (n, n)
             self.sig_buf = dev.to_device(band)
-            self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_in, 0, band_w_in)
+            # (band_workload's rows are zero behind their stored diagonals and beyond the matrix: CS_LAYOUT_BAND_PADDED, what the
+            # library's own staging pass hands the same call; CHROMOSIGHT_BENCH_PLAIN_BAND=1: the plain band layout)
+            from chromosight_amd._lib import LAYOUT_BAND_PADDED
+            padded = ld_in >= band_w_in + 4 and not os.environ.get("CHROMOSIGHT_BENCH_PLAIN_BAND")
+            self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_BAND_PADDED if padded else LAYOUT_BAND, ld_in, 0, band_w_in)
             out_w = max_dist + 1
             ld_out = (out_w + 63) // 64 * 64
             self.out_buf = dev.zeros((n, ld_out), out_dtype)
@@ -604,7 +608,7 @@ class SplitC4P:
 
     def __init__(self, dev, rank, world, precision, n=None):
         from chromosight_amd import engine, parallel
-        from chromosight_amd._lib import CsMatrix, LAYOUT_BAND, MASK_BINS, np_dtype_code
+        from chromosight_amd._lib import CsMatrix, LAYOUT_BAND, LAYOUT_BAND_PADDED, MASK_BINS, np_dtype_code
         from tools.synthetic_genome import band_workload
         band, band_w, miss, n, max_dist = band_workload("c4p", 0, n=n)
         self.n, self.max_dist, self.dev = n, max_dist, dev
@@ -620,7 +624,7 @@ class SplitC4P:
         ld_out = (out_w + 63) // 64 * 64
         f32 = np_dtype_code(np.float32)
         self.sig_buf, self.out_buf, self.miss_buf = dev.to_device(slab), dev.zeros((b - a, ld_out), np.float32), dev.to_device(miss)
-        sig = CsMatrix(self.sig_buf.ptr, f32, LAYOUT_BAND, ld_in, 0, band_w, ra)
+        sig = CsMatrix(self.sig_buf.ptr, f32, LAYOUT_BAND_PADDED if ld_in >= band_w + 4 else LAYOUT_BAND, ld_in, 0, band_w, ra)
         out = CsMatrix(self.out_buf.ptr, f32, LAYOUT_BAND, ld_out, 0, out_w, a)
         # the rank's output rows as a matrix of their own (rows and columns counted from `a`: same diagonals, same storage)
         out_local = CsMatrix(self.out_buf.ptr, f32, LAYOUT_BAND, ld_out, 0, out_w, 0)

@@ -12,7 +12,7 @@ import weakref
 import numpy as np
 
 CS_F32, CS_F64 = 0, 1
-LAYOUT_DENSE, LAYOUT_BAND, LAYOUT_BAND_LAZY = 0, 1, 2
+LAYOUT_DENSE, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED = 0, 1, 2, 3
 LAZY_BAND_BYTES = 128          # CS_LAZY_BAND_BYTES: descriptor of a lazily evaluated float64 band (cs_stage_block)
 MASK_NONE, MASK_BINS, MASK_EXPLICIT = 0, 1, 2
 

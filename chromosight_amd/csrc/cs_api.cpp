@@ -303,17 +303,18 @@ struct AllowLazy {
     explicit AllowLazy(cs_ctx* c_);
     ~AllowLazy();
 };
-inline bool is_band(int layout) { return layout == CS_LAYOUT_BAND || layout == CS_LAYOUT_BAND_LAZY; }
+inline bool is_band(int layout) { return layout == CS_LAYOUT_BAND || layout == CS_LAYOUT_BAND_LAZY || layout == CS_LAYOUT_BAND_PADDED; }
 
 cs::MatView view_of(const cs_matrix* m)
 {
     cs::MatView v;
     v.ptr = m ? m->d_ptr : nullptr;
     v.ld = m ? m->ld : 0;
-    v.layout = m ? m->layout : 0;
+    v.layout = m ? (m->layout == CS_LAYOUT_BAND_PADDED ? CS_LAYOUT_BAND : m->layout) : 0;
     v.band_lo = m ? m->band_lo : 0;
     v.band_w = m ? m->band_w : 0;
     v.row0 = m ? m->row0 : 0;
+    v.pad = (m && m->layout == CS_LAYOUT_BAND_PADDED) ? 1 : 0;
     return v;
 }
 
@@ -930,8 +931,9 @@ int check_matrix(cs_ctx* ctx, const cs_matrix* m, const char* what, int ns)
     if (m->dtype != CS_F32 && m->dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "%s: bad dtype", what);
     if (m->layout == CS_LAYOUT_DENSE) {
         if (m->ld < ns) return fail(ctx, CS_ERR_INVALID, "%s: ld < number of columns", what);
-    } else if (m->layout == CS_LAYOUT_BAND) {
+    } else if (m->layout == CS_LAYOUT_BAND || m->layout == CS_LAYOUT_BAND_PADDED) {
         if (m->band_w <= 0 || m->ld < m->band_w) return fail(ctx, CS_ERR_INVALID, "%s: bad band geometry", what);
+        if (m->layout == CS_LAYOUT_BAND_PADDED && m->ld < (int64_t)m->band_w + 4) return fail(ctx, CS_ERR_INVALID, "%s: a padded band keeps 4 zero slots per row", what);
     } else if (m->layout == CS_LAYOUT_BAND_LAZY && ctx->allow_lazy) {
         // a lazily evaluated float64 band (cs_stage_block): only the float64 kernels behind the batched foci entries read it
         if (m->band_w <= 0 || m->band_lo != 0 || m->row0 != 0 || m->dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "%s: bad lazy band", what);
@@ -1371,7 +1373,7 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         const int kh = (kernel->km - 1) / 2;
         const int rb = (p->row_begin == 0 && p->row_end == 0) ? 0 : p->row_begin, re = (p->row_begin == 0 && p->row_end == 0) ? p->ms : p->row_end;
         const int p_lo = std::max(0, rb - kh), p_hi = std::min(p->ms, re + (kernel->km - 1) - kh);
-        const int width = signal->layout == CS_LAYOUT_BAND ? signal->band_w : p->ns;
+        const int width = is_band(signal->layout) ? signal->band_w : p->ns;
         if (!ctx->d_counts_peak) {
             CS_HIP(ctx, hipMalloc(&ctx->d_counts_peak, 256));
             CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_peak, 256, hipHostMallocDefault));
@@ -2128,9 +2130,9 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
     cs_matrix map;
     map.d_ptr = nullptr;
     map.dtype = f64 ? CS_F64 : CS_F32;
-    map.layout = signal->layout;
+    map.layout = signal->layout == CS_LAYOUT_BAND_PADDED ? CS_LAYOUT_BAND : signal->layout;
     map.row0 = rb;
-    if (signal->layout == CS_LAYOUT_BAND) {
+    if (signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED) {
         if (fp->hi_diag < fp->lo_diag) return fail(ctx, CS_ERR_INVALID, "empty diagonal range");
         map.band_lo = fp->lo_diag;
         map.band_w = fp->hi_diag - fp->lo_diag + 1;
@@ -2142,7 +2144,7 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
     // 1-D patterns (borders, hairpins: max_dist = 0 in the config, 2 scanned diagonals): a streamed
     // 128-column strip would compute 64 columns for every one it keeps.  Every pixel of the few diagonals
     // is a candidate instead and goes straight to the float64 evaluation (one wave per pixel).
-    const bool narrow = signal->layout == CS_LAYOUT_BAND && map.band_w <= 4 && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW");
+    const bool narrow = (signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED) && map.band_w <= 4 && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW");
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     auto layout = [&](size_t c_cap) {
         P->off_cols = al(4 * c_cap);
@@ -2173,7 +2175,7 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
     // other pixel holds 2.0 and is re-evaluated.  float64 maps hold the coefficient.
     const double margin = std::max(fp->rescore_margin, 1e-4);
     const double thr = f64 ? fp->pearson : fp->pearson - margin;
-    size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(signal->layout == CS_LAYOUT_BAND ? map.band_w : p->ns) / 256);
+    size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)((signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED) ? map.band_w : p->ns) / 256);
     // ---- float32, masked tile kernel: the kernel appends the candidates itself (no map, no compaction pass)
     bool fused_ok = !f64 && !std::getenv("CHROMOSIGHT_HIP_NO_FUSED_CANDIDATES");
     while (fused_ok) {

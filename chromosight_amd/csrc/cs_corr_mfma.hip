@@ -419,6 +419,7 @@ struct MfmaDenseArgs {
     // ---- REG instances: per-bin missing masks through the factorised tables of cs_mask_prep.hip, any
     //      layout (band / dense) on either side, optional n_obs map
     int band_in, lo_in, bw_in;       // input band: first stored diagonal, stored diagonals
+    int pad_in;                      // ... zero-padded (CS_LAYOUT_BAND_PADDED): >= 4 zero slots behind every row's stored diagonals
     int band_out, lo_out;            // output band: first stored diagonal
     int out_lo, out_hi;              // produced diagonals
     float* nobs;                     // same geometry as `out`, or nullptr
@@ -816,6 +817,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.band_in = A.sig.layout == 1;
         D.lo_in = A.sig.band_lo;
         D.bw_in = A.sig.band_w;
+        D.pad_in = (A.sig.layout == 1 && A.sig.pad && A.sig.ld >= (long long)A.sig.band_w + 4) ? 1 : 0;
         D.band_out = A.out.layout == 1;
         D.lo_out = A.out.band_lo;
         D.out_lo = A.out_lo;

@@ -17,6 +17,7 @@ struct MatView {
     int band_lo;  // first stored diagonal offset (band)
     int band_w;   // number of stored diagonals (band)
     long long row0;  // matrix row stored at ptr: the buffer holds a window of rows (0 = the whole matrix)
+    int pad;      // band: the slots band_w .. ld - 1 of every row (>= 4) and every slot outside the matrix are zero (CS_LAYOUT_BAND_PADDED)
 };
 
 // element offset of (p, q), or -1 if the pixel is not stored

@@ -20,7 +20,7 @@ import pandas as pd
 import scipy.sparse as sp
 
 from . import engine
-from ._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_DENSE, LAZY_BAND_BYTES, CsCsr, CsMatrix, CsStageBlock,
+from ._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED, LAYOUT_DENSE, LAZY_BAND_BYTES, CsCsr, CsMatrix, CsStageBlock,
                    get_device, np_dtype_code)
 from .utils import detection as cid
 from .utils import preprocessing as preproc
@@ -447,7 +447,9 @@ class DeviceCool:
             off += 8 * n_diags
             layout = LAYOUT_BAND if band else LAYOUT_DENSE
             flags = _Ptr(self.miss.ptr + s)
-            sig32 = CsMatrix(b32.ptr, CS_F32, layout, ld, 0, in_w if band else 0, 0)
+            # (the staging pass assembles every row in zeroed pieces of ld slots: the float32 band is zero behind its stored
+            # diagonals -- the tile kernel fetches its rim tiles like the inner ones, include/chromosight_hip.h)
+            sig32 = CsMatrix(b32.ptr, CS_F32, LAYOUT_BAND_PADDED if band and ld >= in_w + 4 else layout, ld, 0, in_w if band else 0, 0)
             if only32:
                 sig64 = sig32
             elif lazy[k]:
@@ -482,7 +484,7 @@ class DeviceCool:
         (dense-staged short chromosomes, row windows, a longer distance than the block holds)."""
         n = block.shape[0]
         keep = min(max_dist, n) + largest_kernel
-        if (block.inter or block.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY) or getattr(block, "row_window", None) is not None
+        if (block.inter or block.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED) or getattr(block, "row_window", None) is not None
                 or block.keep is None or keep > block.keep or getattr(block, "smooth", False)):
             return None
         in_w = min(keep, n - 1) + 1
@@ -490,7 +492,8 @@ class DeviceCool:
         if not 2 * max(in_w, out_w) < n:
             return None                              # this pattern would have been staged dense: keep the layouts identical
         s = block.sig
-        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, s.layout, s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
+        # (a narrower view of a zero-padded band is a plain band: the slots behind ITS diagonals hold the block's further ones)
+        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, LAYOUT_BAND if s.layout == LAYOUT_BAND_PADDED else s.layout, s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
                            block.miss_col, max_dist, False, keep)
         if s.layout == LAYOUT_BAND_LAZY:                 # (a view shares the descriptor; read by itself it is staged for itself)
             ci = self.names.index(block.name)
@@ -768,7 +771,7 @@ def _check_template(kernel):
 
 
 def b_is_band(block):
-    return block.sig.layout in (LAYOUT_BAND, LAYOUT_BAND_LAZY) and not block.inter and getattr(block, "row_window", None) is None
+    return block.sig.layout in (LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED) and not block.inter and getattr(block, "row_window", None) is None
 
 
 def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, workers=4, batch=True, want_windows=True, defer=False,

@@ -21,7 +21,7 @@ from scipy.sparse import csgraph
 from . import preprocessing as preproc
 from . import stats as cus
 from .. import engine
-from .._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
+from .._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED, LAYOUT_DENSE, MASK_BINS, MASK_EXPLICIT, MASK_NONE,
                     FOCUS_DTYPE, CsMatrix, get_device, np_dtype_code)
 
 RESCORE_MARGIN = engine.RESCORE_MARGIN
@@ -834,7 +834,7 @@ def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=T
     beside this call (cs_foci_params.exclusive: one persistent launch for the tiles of all blocks)."""
     if not blocks or kspec.km != kspec.kn or kernel_config["max_dist"] == 0:
         return None
-    if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None or b.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY) for b in blocks):
+    if any(b.inter or b.max_dist is None or getattr(b, "row_window", None) is not None or b.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED) for b in blocks):
         return None
     if any(b.sig.layout == LAYOUT_BAND_LAZY and getattr(b, "sig32", None) is None for b in blocks):
         return None

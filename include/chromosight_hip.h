@@ -55,7 +55,13 @@ typedef enum {
 } cs_status;
 
 enum { CS_F32 = 0, CS_F64 = 1, CS_U8 = 2 /* masks only */ };
-enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1, CS_LAYOUT_BAND_LAZY = 2 /* see cs_stage_block */ };
+enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1, CS_LAYOUT_BAND_LAZY = 2 /* see cs_stage_block */,
+       /* CS_LAYOUT_BAND with a promise: ld >= band_w + 4, the slots band_w .. ld - 1 of every row are ZERO and so is every stored
+        * slot whose column lies outside the matrix.  What cs_stage_blocks writes (rows assembled in zeroed pieces of ld slots).
+        * The masked tile kernel then fetches the tiles on the rim of the band like the inner ones: a 16-byte piece that reaches
+        * beyond a row's stored diagonals reads zeros where a plain band makes it clamp, shift and mask (10 % of the kernel on a
+        * 234-diagonal band).  Every other consumer reads it as CS_LAYOUT_BAND. */
+       CS_LAYOUT_BAND_PADDED = 3 };
 enum { CS_MASK_NONE = 0, CS_MASK_BINS = 1, CS_MASK_EXPLICIT = 2 };
 
 /* ---- context ----------------------------------------------------------------------- */
@@ -116,7 +122,7 @@ int cs_event_elapsed_ms(cs_ctx* ctx, void* start, void* stop, float* ms);
 typedef struct {
     void* d_ptr;       /* device pointer                                             */
     int32_t dtype;     /* CS_F32 / CS_F64                                            */
-    int32_t layout;    /* CS_LAYOUT_DENSE / CS_LAYOUT_BAND                           */
+    int32_t layout;    /* CS_LAYOUT_DENSE / CS_LAYOUT_BAND (_PADDED)                 */
     int64_t ld;        /* leading dimension in elements                              */
     int32_t band_lo;   /* band layout: first stored diagonal offset (j - i)          */
     int32_t band_w;    /* band layout: number of stored diagonals                    */

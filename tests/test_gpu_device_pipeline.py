@@ -32,7 +32,7 @@ def download_block(dcool, block):
     dt = np.float64 if sig.dtype == 1 else np.float32
     host = np.empty((n, sig.ld), dtype=dt)
     dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, host.ctypes.data, sig.d_ptr, host.nbytes, None))
-    if sig.layout == LAYOUT_BAND:
+    if sig.layout in (LAYOUT_BAND, 3):               # (3: CS_LAYOUT_BAND_PADDED, a band with zero slots behind its diagonals)
         out = np.zeros((n, n))
         for d in range(sig.band_w):
             off = sig.band_lo + d

@@ -65,14 +65,18 @@ def last_kernel():
     return dev.lib.cs_last_kernel(dev.ctx)
 
 
-def run_band(name, n=None, expect=KERNEL_MFMA_REG):
+def run_band(name, n=None, expect=KERNEL_MFMA_REG, padded=False):
+    """padded: the band handed over as CS_LAYOUT_BAND_PADDED (band_workload's rows are zero behind their stored diagonals and
+    beyond the matrix) -- the tile kernel then fetches the rim tiles like the inner ones; same map either way."""
+    from chromosight_amd._lib import LAYOUT_BAND_PADDED
     dev = get_device()
     band, band_w, miss, n, max_dist = band_workload(name, n=n)
     out_w = max_dist + 1
     ld_out = (out_w + 63) // 64 * 64
     d_sig, d_out = dev.to_device(band), dev.zeros((n, ld_out), np.float32)
     d_miss = dev.to_device(miss)
-    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_BAND, band.shape[1], 0, band_w),
+    assert band.shape[1] >= band_w + 4
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_BAND_PADDED if padded else LAYOUT_BAND, band.shape[1], 0, band_w),
                           (n, n), engine.KernelSpec(loops()),
                           CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_out, 0, out_w),
                           full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=d_miss,
@@ -81,26 +85,28 @@ def run_band(name, n=None, expect=KERNEL_MFMA_REG):
     return d_out.download()[:, :out_w], band, band_w, miss, n, max_dist
 
 
-@pytest.mark.parametrize("kernel", ["tile", "stream"])
+@pytest.mark.parametrize("kernel", ["tile", "tile_padded", "stream"])
 def test_c3_band_50000_full_map(kernel, monkeypatch):
     """C3 as benched: N = 50 000, diagonals 0..250, 2 % missing bins, max_dist 233, full, sym_upper,
     missing_tol 0.5 -- every pixel of the 11.7 M-pixel band, on the masked matrix-core tile kernel (the default,
     what bench.py times) and on the packed-FMA streaming kernel (CHROMOSIGHT_HIP_MFMA_REG=0)."""
     if kernel == "stream":
         monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "0")
-    got, band, band_w, miss, n, max_dist = run_band("c3", expect=KERNEL_MFMA_REG if kernel == "tile" else KERNEL_STREAM)
+    got, band, band_w, miss, n, max_dist = run_band("c3", expect=KERNEL_STREAM if kernel == "stream" else KERNEL_MFMA_REG,
+                                                    padded=kernel == "tile_padded")
     want, cond = c_oracle.normxcorr2_band(band.astype(np.float64), n, 0, band_w, loops(), 0, n, 0, max_dist + 1,
                                           max_dist=max_dist, miss_row=miss, miss_col=miss, missing_tol=0.5)
     check(got, want, cond, "C3 50000 x 234")
 
 
-@pytest.mark.parametrize("kernel", ["tile", "stream"])
+@pytest.mark.parametrize("kernel", ["tile", "tile_padded", "stream"])
 def test_c4p_band_200000_row_windows(kernel, monkeypatch):
     """C4' as benched: N = 200 000 single block, max_dist 1000 -- seven windows of 2000 rows (both
     matrix ends, the middle, strip-height boundaries), 14 M pixels against the oracle; both kernels as above."""
     if kernel == "stream":
         monkeypatch.setenv("CHROMOSIGHT_HIP_MFMA_REG", "0")
-    got, band, band_w, miss, n, max_dist = run_band("c4p", expect=KERNEL_MFMA_REG if kernel == "tile" else KERNEL_STREAM)
+    got, band, band_w, miss, n, max_dist = run_band("c4p", expect=KERNEL_STREAM if kernel == "stream" else KERNEL_MFMA_REG,
+                                                    padded=kernel == "tile_padded")
     band64 = band.astype(np.float64)
     del band
     for r0 in (0, 1990, 49_000, 99_137, 150_000, 187_654, n - 2000):
@@ -152,7 +158,8 @@ def test_c3_from_csr_50000_full_map():
     prepared, _ = detrend_oracle.prepare_band(band, det)
     # the staged float32 band: the oracle's band rounded once
     sig = block.sig
-    assert sig.layout == LAYOUT_BAND and sig.band_lo == 0 and sig.band_w == max_dist + 18
+    from chromosight_amd._lib import LAYOUT_BAND_PADDED
+    assert sig.layout == LAYOUT_BAND_PADDED and sig.band_lo == 0 and sig.band_w == max_dist + 18      # (zero-padded rows: the staging pass's own)
     staged = np.empty((n, sig.ld), dtype=np.float32)
     dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, staged.ctypes.data, sig.d_ptr, staged.nbytes, None))
     assert np.abs(staged[:, :sig.band_w] - prepared).max() <= 1e-6 * max(1.0, np.abs(prepared).max())

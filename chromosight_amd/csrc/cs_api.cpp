@@ -2486,6 +2486,14 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
     const double margin = std::max(foci[0].rescore_margin, 1e-4);
     const double thr = foci[0].pearson - margin;
     size_t c_cap = std::max<size_t>(1 << 16, (size_t)(pixels / 256));
+    // (tests of the retry and fall-back paths: a first room for the candidates / a bound for the deferred chain's launches that
+    // this call's lists outgrow)
+    long long seg_min = 2048;
+    if (const char* t = std::getenv("CHROMOSIGHT_HIP_TEST_CAND_CAP")) {
+        c_cap = (size_t)std::max(1, atoi(t));
+        seg_min = 64;
+    }
+    const long long test_bound = std::getenv("CHROMOSIGHT_HIP_TEST_DEFER_BOUND") ? atoll(std::getenv("CHROMOSIGHT_HIP_TEST_DEFER_BOUND")) : 0;
     // what the previous call on this context saw: when it scanned the same layout (a run's steps, an iterated template's
     // passes) its candidate count sizes the LAUNCHES of the chain that is enqueued before this call's count is known (below);
     // nothing but a size is carried over
@@ -2524,7 +2532,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         if (segmented_ok) {
             list_cap = 0;
             for (int b = 0; b < n_blocks; ++b) {
-                seg_cap[(size_t)b] = std::max<long long>(2048, (long long)((double)c_cap * (double)block_pixels[(size_t)b] / (double)std::max<long long>(pixels, 1)) + 1);
+                seg_cap[(size_t)b] = std::max<long long>(seg_min, (long long)((double)c_cap * (double)block_pixels[(size_t)b] / (double)std::max<long long>(pixels, 1)) + 1);
                 seg_base[(size_t)b] = (long long)list_cap;
                 list_cap += (size_t)seg_cap[(size_t)b];
             }
@@ -2847,8 +2855,9 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // on the same lists.  CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN=1: always the host-paced chain.
         bool counts_known = false;
         if (deferred) {
-            const long long bound = std::min<long long>((long long)list_cap, hint > 0 ? hint + hint / 2 + 4096
-                                                                                     : std::max<long long>(16384, (long long)list_cap / 8));
+            long long bound = std::min<long long>((long long)list_cap, hint > 0 ? hint + hint / 2 + 4096
+                                                                               : std::max<long long>(16384, (long long)list_cap / 8));
+            if (test_bound > 0) bound = std::min(bound, test_bound);
             cs::DeferredSegments D;
             D.d_counts = (const long long*)(d_cnt + 2);
             for (int b = 0; b < n_blocks; ++b) {                 // (the device reads the two tables where they are: page-locked)

@@ -217,6 +217,9 @@ class _Shared:
             pass
 
 
+_FULL_LOCK = threading.RLock()
+
+
 class StagedBlock:
     """One sub-matrix staged in HBM (detrended band or dense map + the flags of its undetectable
     bins): what pattern_detector works on after ContactMap.create_mat (contacts_map.py:453-526)."""
@@ -237,8 +240,9 @@ class StagedBlock:
         plain way (same values: the staging pass and the descriptor compute the same expression)."""
         if self.sig.layout != LAYOUT_BAND_LAZY:
             return self
-        if self._full is None:
-            self._full = self.restage()
+        with _FULL_LOCK:                    # (the worker threads of a block-by-block pass ask for the same block's band at once)
+            if self._full is None:
+                self._full = self.restage()
         return self._full
 
     def __del__(self):
@@ -463,7 +467,7 @@ class DeviceCool:
             blk.shared = shared                                 # (the law buffer of the call)
             if lazy[k]:
                 blk.genome = self                               # (the descriptor points into the pixel table)
-                blk.restage = (lambda ci=ci: self.stage_blocks([ci], max_dist, largest_kernel, band_dtype=band_dtype)[0])
+                blk.restage = (lambda ci=ci: self._restage_synced(ci, max_dist, largest_kernel, band_dtype=band_dtype))
             blocks.append(blk)
         genome = CsCsr(self.n_bins, self.n_bins, max(self.nnz, 1), self.indptr.ptr, self.indices.ptr, self.data.ptr,
                        np_dtype_code(self.val_dtype), 0, None, self.weight.ptr, self.weight.ptr)
@@ -474,6 +478,17 @@ class DeviceCool:
         if os.environ.get("CHROMOSIGHT_HIP_STAGE_SYNC"):
             dev.sync(stream)
         return blocks
+
+    def _restage_synced(self, ci, max_dist, largest_kernel, **options):
+        """One block staged again with its float64 band stored (StagedBlock.full), COMPLETE on return: the staging call is
+        asynchronous on this genome's stream, and who asks for the full band is a per-block path on a worker thread with a
+        context and stream of its own -- it read a band that was still being written (a 2-D pattern with pearson < 0.1 scanned
+        beside a 1-D pattern lost a third of its records, differently every run: found by
+        tests/test_gpu_device_pipeline.py::test_2d_chain_retry_and_fallback_paths)."""
+        with self._stage_lock:
+            block = self.stage_blocks([ci], max_dist, largest_kernel, **options)[0]
+            self.dev.sync()
+        return block
 
     def view_for(self, block, max_dist, largest_kernel):
         """The staged block of the same chromosome for a pattern with a shorter scanning distance, WITHOUT staging it again:
@@ -497,7 +512,7 @@ class DeviceCool:
                            block.miss_col, max_dist, False, keep)
         if s.layout == LAYOUT_BAND_LAZY:                 # (a view shares the descriptor; read by itself it is staged for itself)
             ci = self.names.index(block.name)
-            view.restage = lambda: self.stage_blocks([ci], max_dist, largest_kernel)[0]
+            view.restage = lambda: self._restage_synced(ci, max_dist, largest_kernel)
         if block.sig32 is not None:
             t = block.sig32
             view.sig32 = CsMatrix(t.d_ptr, t.dtype, LAYOUT_BAND, t.ld, 0, in_w, t.row0)

@@ -429,6 +429,49 @@ def test_genome_step_as_one_native_call_equals_the_two_calls():
                 assert np.allclose(got[:, 4], ref[:, 4], rtol=1e-9, atol=1e-300)
 
 
+def test_2d_chain_retry_and_fallback_paths(monkeypatch):
+    """The 2-D chain behind the tile kernels is enqueued before the candidate counts are known (cs_detect_foci_blocks: segments
+    formed on the device, launches sized for a bound).  Its three ways out, forced here, must give the default run's records:
+    a block's list outgrows its room (the call goes round again with more: CHROMOSIGHT_HIP_TEST_CAND_CAP), more candidates than
+    the launches were sized for (the host-paced chain on the same lists: CHROMOSIGHT_HIP_TEST_DEFER_BOUND), a block with more
+    candidates than the labelling workgroup's LDS arrays hold (a low threshold: the sorted route, then remembered for the layout)
+    -- as a plain call sequence and as a replayed genome step (prepare form + full form)."""
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(12_000, 200, 2000, seed=5, template=template, chrom_sizes=[4000, 3500, 2500, 2000])
+    loops = copy.deepcopy(ck.loops)
+    loops["max_dist"] = 200 * 2000
+    borders = copy.deepcopy(ck.borders)
+
+    def same(got, want, what):
+        assert got.shape == want.shape and want.shape[0] > 30, what
+        assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]]), what
+        assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9, what
+
+    # (0.11: ~ 10^4 candidates per block in float32 arithmetic; 0.08: below 0.1 the 2-D pattern is evaluated in float64, block by
+    # block on worker threads -- not a planned step, but the same records)
+    for cfg2 in (loops, dict(loops, pearson=0.11), dict(loops, pearson=0.08)):
+        monkeypatch.setenv("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "1")
+        want = parallel.detect_genome(pipeline.DeviceCool(cool), cfg2)
+        monkeypatch.delenv("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN")
+        for env in ({}, {"CHROMOSIGHT_HIP_TEST_CAND_CAP": "100"}, {"CHROMOSIGHT_HIP_TEST_DEFER_BOUND": "50"},
+                    {"CHROMOSIGHT_HIP_TEST_CAND_CAP": "100", "CHROMOSIGHT_HIP_TEST_DEFER_BOUND": "50"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            dcool = pipeline.DeviceCool(cool)
+            for rep in range(3):
+                same(parallel.detect_genome(dcool, cfg2), want, (cfg2["pearson"], env, rep))
+            dcool = pipeline.DeviceCool(cool)
+            want_b = None
+            for rep in range(4):                               # (steps 2 .. 4: the replayed list)
+                got, got_b = parallel.genome_step(dcool, [cfg2, borders])
+                same(got, want, (cfg2["pearson"], env, "step", rep))
+                want_b = got_b if want_b is None else want_b
+                same(got_b, want_b, "borders beside it")
+            assert cfg2["pearson"] < 0.1 or all(p.ok for p in dcool.__dict__["_step_plans"].values())
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_single_pattern_steps_are_planned_and_feed_pipeline_detect():
     """A 2-D pattern alone (loops) and a 1-D pattern alone (borders) are steps a StepPlan covers too: replayed steps equal
     detect_genome's records; pipeline.detect -- the CLI counterpart -- runs the same orchestration (parallel.genome_step: its

@@ -82,11 +82,8 @@ class Workload:
             self.host_sig = rng.gamma(4.0, 0.25, size=(n, n)).astype(np.float32)
             self.shape = (n, n)
             # device-resident maps with the engine's row pitch (never a power of two: HBM channel spread, engine.map_pitch)
-            if os.environ.get("CHROMOSIGHT_BENCH_TIGHT_PITCH"):        # comparison only: rows packed tight (pitch n)
-                self.sig_buf, ld_in, ld_out = dev.to_device(self.host_sig), n, n
-            else:
-                self.sig_buf, ld_in = engine.to_device_map(dev, self.host_sig)
-                ld_out = engine.map_pitch(n, np.dtype(out_dtype).itemsize)
+            self.sig_buf, ld_in = engine.to_device_map(dev, self.host_sig)
+            ld_out = engine.map_pitch(n, np.dtype(out_dtype).itemsize)
             self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_DENSE, ld_in, 0, 0)
             self.out_buf = dev.empty((n, ld_out), out_dtype)
             self.out = CsMatrix(self.out_buf.ptr, np_dtype_code(out_dtype), LAYOUT_DENSE, ld_out, 0, 0)
@@ -125,9 +122,9 @@ class Workload:
             self.shape = (n, n)
             self.sig_buf = dev.to_device(band)
             # (band_workload's rows are zero behind their stored diagonals and beyond the matrix: CS_LAYOUT_BAND_PADDED, what the
-            # library's own staging pass hands the same call; CHROMOSIGHT_BENCH_PLAIN_BAND=1: the plain band layout)
+            # library's own staging pass hands the same call)
             from chromosight_amd._lib import LAYOUT_BAND_PADDED
-            padded = ld_in >= band_w_in + 4 and not os.environ.get("CHROMOSIGHT_BENCH_PLAIN_BAND")
+            padded = ld_in >= band_w_in + 4
             self.sig = CsMatrix(self.sig_buf.ptr, np_dtype_code(np.float32), LAYOUT_BAND_PADDED if padded else LAYOUT_BAND, ld_in, 0, band_w_in)
             out_w = max_dist + 1
             ld_out = (out_w + 63) // 64 * 64
@@ -179,7 +176,6 @@ def prewarm(step, sync, seconds=0.1):
     5-10 % slow: at 20 timed steps the ramp would be inside the timed region).  Short on purpose: the ramp takes tens of
     milliseconds, and the same 20 steps after 2 s of this run 2-3 % slower than after 0.05 s (0.1059 / 0.1043 / 0.1021 ms
     after 2.0 / 0.4 / 0.05 s on one box; 300 timed steps: 0.1022)."""
-    seconds = float(os.environ.get("CHROMOSIGHT_BENCH_PREWARM_S", seconds))
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(16):

@@ -471,10 +471,7 @@ class Device:
 
     def new_stream(self, high_priority=False):
         s = C.c_void_p()
-        if os.environ.get("CHROMOSIGHT_HIP_LOW_PRIORITY") and high_priority:
-            # (experiment: the side chains BEHIND the tile kernels instead of ahead of them)
-            self._check(self.lib.cs_stream_create_priority(self.ctx, 0, C.byref(s)))
-        elif high_priority:
+        if high_priority:
             self._check(self.lib.cs_stream_create_priority(self.ctx, 1, C.byref(s)))
         else:
             self._check(self.lib.cs_stream_create(self.ctx, C.byref(s)))

@@ -792,8 +792,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
             A.out_hi = std::min(A.out_hi, A.cand_dhi);
         }
         // (the mirrored-row instance of the tile kernel forms the corrections of the edge diagonals itself: no records)
-        const bool rim_in_kernel = A.w_sym && A.km == 17 && A.kn == 17 && !std::getenv("CHROMOSIGHT_HIP_MFMA_NORSYM") &&
-                                   !std::getenv("CHROMOSIGHT_HIP_RIM_RECORDS");
+        const bool rim_in_kernel = A.w_sym && A.km == 17 && A.kn == 17 && !std::getenv("CHROMOSIGHT_HIP_MFMA_NORSYM");
         rc = prepare_regular_mask<float>(ctx, A, A.km, stream, rim_in_kernel);
         if (rc != CS_OK) return rc;
         if (A.reg_mode == 1 && A.sig_is_f64) {
@@ -1960,9 +1959,7 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_s
     // the 200 000-bin genome 1.59 -> 1.47 ms with 128; a group costs an LDS clear, a flush and a slot for the finish pass)
     long long total_rows = 0;
     for (int b = 0; b < n_blocks; ++b) total_rows += std::max(blocks[b].n, 0);
-    const int kRowsPerGroup = std::getenv("CHROMOSIGHT_HIP_STAGE_ROWS")
-                                  ? std::max(8, atoi(std::getenv("CHROMOSIGHT_HIP_STAGE_ROWS")))
-                                  : (int)std::min<long long>(128, std::max<long long>(64, (total_rows / (4LL * ctx->n_cu) + 7) / 8 * 8));
+    const int kRowsPerGroup = (int)std::min<long long>(128, std::max<long long>(64, (total_rows / (4LL * ctx->n_cu) + 7) / 8 * 8));
     std::vector<cs::StageBlock> tab((size_t)n_blocks);
     int n_groups = 0, pitch = 1;
     for (int b = 0; b < n_blocks; ++b) {
@@ -2144,7 +2141,7 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
     // 1-D patterns (borders, hairpins: max_dist = 0 in the config, 2 scanned diagonals): a streamed
     // 128-column strip would compute 64 columns for every one it keeps.  Every pixel of the few diagonals
     // is a candidate instead and goes straight to the float64 evaluation (one wave per pixel).
-    const bool narrow = (signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED) && map.band_w <= 4 && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW");
+    const bool narrow = (signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED) && map.band_w <= 4;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     auto layout = [&](size_t c_cap) {
         P->off_cols = al(4 * c_cap);
@@ -2177,7 +2174,7 @@ int find_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const c
     const double thr = f64 ? fp->pearson : fp->pearson - margin;
     size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)((signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED) ? map.band_w : p->ns) / 256);
     // ---- float32, masked tile kernel: the kernel appends the candidates itself (no map, no compaction pass)
-    bool fused_ok = !f64 && !std::getenv("CHROMOSIGHT_HIP_NO_FUSED_CANDIDATES");
+    bool fused_ok = !f64;
     while (fused_ok) {
         if (c_cap > (size_t)INT32_MAX / 2) return fail(ctx, CS_ERR_OVERFLOW, "too many candidate pixels (%zu)", c_cap);
         rc = layout(c_cap);
@@ -2275,7 +2272,7 @@ int cs_detect_foci(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs
     };
     cs::FocusRec* rec_direct = cap > 0 ? reinterpret_cast<cs::FocusRec*>(device_view(h_foci)) : nullptr;
     double* win_direct = (fp->want_windows && h_windows) ? reinterpret_cast<double*>(device_view(h_windows)) : nullptr;
-    const bool direct = rec_direct && (!fp->want_windows || !h_windows || win_direct) && !std::getenv("CHROMOSIGHT_HIP_NO_DIRECT_RESULTS");
+    const bool direct = rec_direct && (!fp->want_windows || !h_windows || win_direct);
     if (direct) {
         ctx->h_counts[1] = -1;
         rc = cs::enqueue_foci(A64, (const int*)pool, (const int*)(pool + P.off_cols), n_cand, fp->pearson, fp->min_size,
@@ -2453,7 +2450,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         pixels += (long long)p->ms * std::min<long long>(w, p->ns);
         block_pixels[(size_t)b] = (long long)p->ms * std::min<long long>(w, p->ns);
     }
-    if (all_narrow && !std::getenv("CHROMOSIGHT_HIP_NO_NARROW"))
+    if (all_narrow)
         return prepare_only ? CS_OK : cs_detect_foci_batch(ctx, stream_, n_blocks, signals, kernel, params, foci, h_foci, cap, h_n_foci, h_windows);
     if (params[0].compute_dtype != CS_F32) return fail(ctx, CS_ERR_UNSUPPORTED, "the 2-D batch runs the float32 tile kernel");
     if (kernel->km != kernel->kn || kernel->km > 17 || kernel->km < 3 || !(kernel->km & 1))
@@ -2547,21 +2544,21 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // (the counter is zeroed right before the tile kernels go out: on a side lane when the lanes carry the call's
         // preparations, see `early_upload` below)
         // side streams only when no block needs the (single) narrowing scratch
-        bool twins = signals_f32 != nullptr && !std::getenv("CHROMOSIGHT_HIP_ONE_STREAM");
+        bool twins = signals_f32 != nullptr;
         for (int b = 0; b < n_blocks && twins; ++b) twins = signals_f32[b].d_ptr != nullptr;
         // Lanes: the blocks' persistent launches run side by side on n_lanes streams -- a launch then walks n_lanes times as
         // many tiles per workgroup (pipeline fill / drain and the rounding to whole tiles per workgroup are paid per launch),
         // and no launch waits for slots another one holds.
-        static const int lanes_env = std::getenv("CHROMOSIGHT_HIP_BLOCK_LANES") ? atoi(std::getenv("CHROMOSIGHT_HIP_BLOCK_LANES")) : 3;
+        constexpr int lanes_env = 3;       // (2 .. 6 lanes measured on the 23-block genome, tools/c4_mode_sweep.sh: flat between 3 and 6)
         const int n_lanes = (twins && n_blocks > 1) ? std::min(std::min(std::max(lanes_env, 1), kBlkLanes), n_blocks) : 1;
         // one persistent launch for the tiles of all blocks (the lanes then only carry the blocks' mask tables): when the caller
         // says nothing else is queued beside it, or for a few blocks (a rank's share of a genome on 8 GPUs: 3 blocks -- one
         // launch beats three that fight for the slots: 1.40 -> 1.29 ms per rank)
-        const bool table = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE") && (foci[0].exclusive != 0 || n_blocks <= 4);
+        const bool table = n_lanes > 1 && (foci[0].exclusive != 0 || n_blocks <= 4);
         // either way the blocks' launches are PREPARED first (mask tables of every block on the lanes, argument blocks in a host
         // table) and the tile kernels go out afterwards: a mask-table launch queued behind persistent tile kernels would wait
         // for their workgroups to drain, and its lane's next tile kernel with it
-        const bool prepared = n_lanes > 1 && !std::getenv("CHROMOSIGHT_HIP_NO_PREPARE");
+        const bool prepared = n_lanes > 1;
         if (!prepared) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, stream));      // (tile kernels go out block by block below)
         int table_rsym = -1;
         if (prepared) {
@@ -2618,7 +2615,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                     // wave slot of the chip: served first, they are done when the staging is)
                     int lo_p = 0, hi_p = 0;
                     CS_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-                    CS_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_blk[k], hipStreamNonBlocking, std::getenv("CHROMOSIGHT_HIP_NO_PRIORITY") ? lo_p : hi_p));
+                    CS_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_blk[k], hipStreamNonBlocking, hi_p));
                 }
             for (int k = 0; k < kBlkLanes; ++k)
                 if (!ctx->ev_blk[k]) CS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_blk[k], hipEventDisableTiming));

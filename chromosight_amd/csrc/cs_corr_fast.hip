@@ -60,7 +60,7 @@ static int launch_fast(const CorrArgs<TC>& A, hipStream_t stream)
     S.row_end = A.row_end;
     S.row0_in = A.sig.row0;
     S.row0_out = A.out.row0;
-    S.xcd_remap = (S.band_out && !getenv("CHROMOSIGHT_HIP_NO_XCD")) ? 1 : 0;
+    S.xcd_remap = S.band_out ? 1 : 0;
     S.strip_h2 = A.tile_h;
     // Single generation of two waves per SIMD (e.g. dense 4096^2 on 256 CUs): the arbiter favours
     // the wave that started first.  Measured with per-wave clocks on C2 (uniform 64-row strips):

@@ -786,7 +786,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
                          A.ms > 0 && A.ns > 0 &&
                          (!A.nobs.ptr || (A.nobs.layout == A.out.layout && A.nobs.ld == A.out.ld && A.nobs.band_lo == A.out.band_lo &&
                                           A.nobs.band_w == A.out.band_w && A.nobs.row0 == A.out.row0));
-    if ((dense_f32 || reg_f32) && !getenv("CHROMOSIGHT_HIP_MFMA_V1")) {
+    if (dense_f32 || reg_f32) {
         *dense_path = 1;
         MfmaDenseArgs D;
         D.sig = reinterpret_cast<const float*>(A.sig.ptr);
@@ -811,8 +811,12 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.w_unscale = E.unscale[0];
         D.wa_unscale = E.unscale[1];
         D.wb_unscale = E.unscale[2];
+#ifdef CS_MF_DEBUG
         D.dbg = getenv("CHROMOSIGHT_HIP_MFMA_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_DBG")) : 0;
-        D.xcd_order = getenv("CHROMOSIGHT_HIP_NO_XCD") ? 0 : 1;
+#else
+        D.dbg = 0;
+#endif
+        D.xcd_order = 1;
         D.ks = A.ks;
         D.band_in = A.sig.layout == 1;
         D.lo_in = A.sig.band_lo;
@@ -879,7 +883,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
                                          : (cand ? corr_mfma_dense_kernel<true, true, false, true> : corr_mfma_dense_kernel<true, true, false, false>);
             hipError_t e3 = allow_big_lds((const void*)kr);
             if (e3 != hipSuccess) return (int)e3;
-            const int per_cu_r = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+            const int per_cu_r = 2;                // (LDS: two workgroups per CU)
             int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
             if (A.grid_cap > 0 && grid_r > A.grid_cap) grid_r = std::max(8, A.grid_cap & ~7);     // (multiples of 8: XCD-contiguous ranges)
             hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, D);
@@ -894,10 +898,9 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         const void* kd = vec4 ? (const void*)corr_mfma_dense_kernel<true, false> : (const void*)corr_mfma_dense_kernel<false, false>;
         hipError_t e2 = allow_big_lds(kd);
         if (e2 != hipSuccess) return (int)e2;
-        const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+        const int per_cu = 2;
         const int grid = (int)std::min<long long>(blocks, (long long)per_cu * A.n_cu);
-        if (!getenv("CHROMOSIGHT_HIP_NO_SKEW"))
-            D.xcd_order |= dense_tile_skew(A.tiles_x, blocks, (D.xcd_order & 1) && grid % 8 == 0 ? grid / 8 : grid) << 1;
+        D.xcd_order |= dense_tile_skew(A.tiles_x, blocks, (D.xcd_order & 1) && grid % 8 == 0 ? grid / 8 : grid) << 1;
         if (vec4) hipLaunchKernelGGL((corr_mfma_dense_kernel<true, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
         else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
         return (int)hipGetLastError();
@@ -924,7 +927,7 @@ int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_ca
     const reg_kernel_t kr = rsym ? corr_mfma_dense_kernel<true, true, true, true> : corr_mfma_dense_kernel<true, true, false, true>;
     hipError_t e = allow_big_lds((const void*)kr);
     if (e != hipSuccess) return (int)e;
-    const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+    const int per_cu = 2;
     int grid = (int)std::min<long long>(D.n_tiles, (long long)per_cu * n_cu);
     if (grid_cap > 0 && grid > grid_cap) grid = std::max(8, grid_cap & ~7);
     hipLaunchKernelGGL(kr, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, D);
@@ -964,7 +967,7 @@ int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym
     const void* kr = rsym ? (const void*)corr_mfma_blocks_kernel<true> : (const void*)corr_mfma_blocks_kernel<false>;
     e = allow_big_lds(kr);
     if (e != hipSuccess) return (int)e;
-    const int per_cu = getenv("CHROMOSIGHT_HIP_MFMA_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_MFMA_GRID")) : 2;
+    const int per_cu = 2;
     const int grid = std::max(8, (int)std::min<long long>((total + 7) / 8 * 8, (long long)per_cu * n_cu) & ~7);
     if (rsym) hipLaunchKernelGGL(corr_mfma_blocks_kernel<true>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, T);
     else hipLaunchKernelGGL(corr_mfma_blocks_kernel<false>, dim3((unsigned)grid), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, T);

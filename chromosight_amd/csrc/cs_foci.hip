@@ -1155,7 +1155,7 @@ static void launch_focus_records(const CorrArgs<double>* h_tab, int n_blocks, lo
                                  const int* f_size, double* f_score, double* f_nobs, const long long* d_total, FocusRec* rec,
                                  double* windows, long long win_cap, long long rec_cap)
 {
-    bool lazy17 = fast_windows_on() && h_tab != nullptr && n_blocks > 0 && !getenv("CHROMOSIGHT_HIP_NO_FUSED_RECORDS");
+    bool lazy17 = fast_windows_on() && h_tab != nullptr && n_blocks > 0;
     for (int b = 0; lazy17 && b < n_blocks; ++b) {
         const CorrArgs<double>& A = h_tab[b];
         lazy17 = A.km == 17 && A.kn == 17 && A.mask_mode == 1 && A.sym_upper && A.full && A.max_dist >= 0 && A.sig.layout == 2;
@@ -1295,7 +1295,7 @@ int enqueue_foci(const CorrArgs<double>& A64, const int* d_rows, const int* d_co
     int rc = launch_rescore_f64(A64, s_rows, s_cols, n_cand, vals, nullptr, stream, nullptr,
                                 presorted && A64.km * A64.kn <= 17 * 17 && !getenv("CHROMOSIGHT_HIP_NO_RUN_RESCORE"));
     if (rc) return rc;
-    if (n_cand <= kSmallMax && !getenv("CHROMOSIGHT_HIP_NO_FUSED_FOCI")) {
+    if (n_cand <= kSmallMax) {
         hipLaunchKernelGGL(foci_small_kernel, dim3(1), dim3(kSmallThreads), 0, stream, keys_s, vals, n_cand, pearson, ns, min_size,
                            diag_only, flag, pos, keys_k, vals_k, parent, size, best_val, best_idx, f_rows, f_cols, f_size, n_kept,
                            d_n_foci);
@@ -1608,7 +1608,7 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
             if ((size_t)tile_cap * 8 > 48 * 1024) tile_cap = 48 * 1024 / 8;        // wider scans: the direct route where needed
             const size_t smem = (size_t)tile_cap * 8 + kRunWeights * 8 + 512 + 1024;
             const bool no_run17 = getenv("CHROMOSIGHT_HIP_NO_RUN17") != nullptr;
-            bool only17 = fast_windows_on() && !no_run17 && w_max <= 2 && tile_cap > 0 && !getenv("CHROMOSIGHT_HIP_RUN_GENERAL");
+            bool only17 = fast_windows_on() && !no_run17 && w_max <= 2 && tile_cap > 0;
             for (int k = 0; only17 && k < n_blocks; ++k) {
                 const CorrArgs<double>& A = h_tab[k];
                 only17 = A.km == 17 && A.kn == 17 && A.mask_mode == 1 && A.sym_upper && A.full && A.max_dist >= 0;

@@ -484,8 +484,8 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
             std::memcpy(uploaded->data() + sizeof(void*) + blocks_bytes, groups.data(), sizeof(StageGroup) * (size_t)n_groups);
         }
     }
-    const int per_cu = getenv("CHROMOSIGHT_HIP_STAGE_GRID") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_GRID")) : 4;
-    const int unroll = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL")) : 4;
+    const int per_cu = 4;        // (6 or 8 workgroups per CU: the law pass 170 against 154 us on the genome)
+    const int unroll = 4;
     const int grid = std::min(n_groups, per_cu * n_cu);
     if (rows_per_group > kStageGroupRows) return (int)hipErrorInvalidValue;
     const size_t smem_law = (sizeof(double) + sizeof(unsigned)) * (size_t)pitch + sizeof(double) * ((size_t)pitch + 2 * kStageGroupRows);
@@ -519,26 +519,21 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
         else WHAT(float, 2);                     \
     }
     // the tiler keeps a whole row's stored pixels in registers when they fit its request (64 x unroll): by the widest band
-    const int unroll_tile = getenv("CHROMOSIGHT_HIP_STAGE_UNROLL_TILE") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_UNROLL_TILE")) : (max_b > 256 ? 8 : 4);
-    const int stage_dbg = getenv("CHROMOSIGHT_HIP_STAGE_DBG") ? atoi(getenv("CHROMOSIGHT_HIP_STAGE_DBG")) : 0;   // timing experiments only
-    const char* skip = getenv("CHROMOSIGHT_HIP_STAGE_SKIP");      // diagnostics: "law" / "tile" leave that kernel out
-    if (!(skip && skip[0] == 'l')) {
-        CS_STAGE_BOTH(CS_STAGE_LAW, unroll)
-    }
+    const int unroll_tile = max_b > 256 ? 8 : 4;
+    const int stage_dbg = 0;
+    CS_STAGE_BOTH(CS_STAGE_LAW, unroll)
     const LazySource lazy_src{indptr, indices, data, weight, max_val, data_is_f64};
     int max_groups = 0;
     for (int b = 0; b < n_blocks; ++b) max_groups = std::max(max_groups, h_blocks[b].n_groups);
     const dim3 finish_grid(n_blocks, (max_b + kFinishDiags - 1) / kFinishDiags);
     // (few workgroups: they are all resident at once either way, and the 1024-thread shape has the shorter per-thread chain)
-    if (max_groups <= 256 && (long long)finish_grid.x * finish_grid.y > 512 && !getenv("CHROMOSIGHT_HIP_FINISH_WIDE"))
+    if (max_groups <= 256 && (long long)finish_grid.x * finish_grid.y > 512)
         hipLaunchKernelGGL(stage_finish_kernel<4>, finish_grid, dim3(kFinishDiags * kFinishPhases / 4), 0, stream, d_blocks, pitch, part_sum,
                            part_cnt, lazy_src);
     else
         hipLaunchKernelGGL(stage_finish_kernel<1>, finish_grid, dim3(kFinishDiags * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
                            part_cnt, lazy_src);
-    if (!(skip && skip[0] == 't')) {
-        CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile)
-    }
+    CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile)
 #undef CS_STAGE_BOTH
 #undef CS_STAGE_LAW
 #undef CS_STAGE_TILE

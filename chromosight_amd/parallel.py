@@ -676,7 +676,7 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                and hasattr(genome, "workers") and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_OVERLAP"))
     futures = []
     joint = None
-    if overlap and kernel_config["max_dist"] == 0 and tsvd is None and not todo and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_BATCH"):
+    if overlap and kernel_config["max_dist"] == 0 and tsvd is None and not todo:
         # a 1-D pattern's templates share one launch chain (cs_detect_foci_batch_templates): on a worker context, so that the
         # chain runs beside whatever this genome's own stream is doing (another pattern's tile kernels)
         pool = genome.workers(1)

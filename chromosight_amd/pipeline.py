@@ -280,7 +280,7 @@ class _Workers:
         if dev is None:
             dev = self.local.dev = self.device_cls(self.index)
             # worker streams carry the short launch chains that run beside another pattern's tile kernels: served first
-            self.local.stream = dev.new_stream(high_priority=not os.environ.get("CHROMOSIGHT_HIP_NO_PRIORITY"))
+            self.local.stream = dev.new_stream(high_priority=True)
             self.local.scratch = _Scratch(dev)
         return dev, self.local.stream
 
@@ -371,7 +371,7 @@ class DeviceCool:
             # a block's chain is 7 short launches that leave most of the chip idle, the chains of different blocks
             # are independent, and issuing them costs the host less than running them costs the GPU (23-block genome,
             # per step: 1 stream 12.8 ms, 2: 12.5, 4: 11.4-11.7, 6-12: 11.2)
-            n_streams = min(int(os.environ.get("CHROMOSIGHT_HIP_STAGE_STREAMS", "6")), len(chroms))
+            n_streams = min(6, len(chroms))
             if n_streams <= 1 or options.get("reduce") is not None or options.get("smooth"):
                 return [self.stage_intra(ci, max_dist, largest_kernel, resident=True, **options) for ci in chroms]
             # process-wide like the worker pools: creating streams per DeviceCool cost 8 ms per `detect` on a small genome
@@ -405,8 +405,7 @@ class DeviceCool:
         block once in float64 (exact re-scoring, windows) and float32 (what the matrix-core kernel stages)); None when
         an option needs the block-by-block path (isotonic smoothing, a block split over ranks, float32-only bands)."""
         if (smooth or reduce is not None or rows is not None or unused or not self.upper or not chroms
-                or np.dtype(band_dtype) not in (np.dtype(np.float64), np.dtype(np.float32))
-                or os.environ.get("CHROMOSIGHT_HIP_NO_STAGE_BATCH")):
+                or np.dtype(band_dtype) not in (np.dtype(np.float64), np.dtype(np.float32))):
             return None
         only32 = np.dtype(band_dtype) == np.float32       # float32 maps only (map-level callers: no exact re-scoring)
         dev, lib = self.dev, self.dev.lib
@@ -429,7 +428,7 @@ class DeviceCool:
         # laws and the descriptors then live as long as the blocks do: one shared buffer each, not the rewritten scratch.
         # (lazy64 = "all": every diagonal stored AND a descriptor -- what tests/test_gpu_device_pipeline.py checks the recomputed
         # pixels against)
-        near = int(os.environ.get("CHROMOSIGHT_HIP_NEAR_DIAGS", "64"))
+        near = 64
         lazy = [bool(lazy64 and not only32 and g[6] and (lazy64 == "all" or g[5] > 2 * near)) for g in geo]
         # The laws (and the descriptors of lazily evaluated bands) live as long as the blocks do: one buffer per staging call,
         # held by every block of the call -- never the rewritten law scratch.  A recorded staging (plan.StepPlan replays the
@@ -475,8 +474,6 @@ class DeviceCool:
         # that hand blocks to worker threads do; the law scratch is rewritten in stream order)
         with dev.lock:
             dev._check(lib.cs_stage_blocks(dev.ctx, stream, C.byref(genome), table, len(geo), 10.0))
-        if os.environ.get("CHROMOSIGHT_HIP_STAGE_SYNC"):
-            dev.sync(stream)
         return blocks
 
     def _restage_synced(self, ci, max_dist, largest_kernel, **options):
@@ -807,7 +804,7 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
     if any(min(b.shape) > max(kernel.shape) for b in blocks):
         _check_template(kernel)
     square = kernel.shape[0] == kernel.shape[1]
-    if len(blocks) > 1 and raw and batch and square and tsvd is None and not os.environ.get("CHROMOSIGHT_HIP_NO_BLOCK_BATCH"):
+    if len(blocks) > 1 and raw and batch and square and tsvd is None:
         live = [k for k, b in enumerate(blocks) if min(b.shape) > max(kernel.shape)]
         banded = [k for k in live if b_is_band(blocks[k])]
         kspec = engine.KernelSpec(kernel, tsvd)
@@ -1102,7 +1099,7 @@ def quantify(cool, positions, kernel_config, inter=False, tsvd=None, subsample=N
         for ca, blk in zip(intra, dcool.stage_blocks(intra, max_dist, largest, smooth=smooth)):
             staged[(ca, ca)] = blk
     inter_pairs = [(ca, cb) for ca, cb, _, _ in mine if ca != cb]
-    if len(inter_pairs) > 1 and not os.environ.get("CHROMOSIGHT_HIP_NO_MEDIAN_BATCH"):
+    if len(inter_pairs) > 1:
         for pair, blk in zip(inter_pairs, dcool.stage_inter_many(inter_pairs)):
             staged[pair] = blk
     else:

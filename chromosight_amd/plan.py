@@ -160,7 +160,7 @@ class StepPlan:
         if cfg2 is not None:
             a = list(blocks[0])
             a[8], a[9] = self.rec2.ctypes.data, self.cap2
-            if not os.environ.get("CHROMOSIGHT_HIP_PLAN_NO_TABLE"):
+            if True:
                 # ONE persistent launch for the tiles of all blocks (cs_foci_params.exclusive): with the 1-D chain held back
                 # behind it the persistent workgroups are not displaced, and one launch beats 23 over three streams -- the
                 # 23-block genome 3.25 -> 3.02 ms, a share of 2: 1.89 -> 1.69, of 4: 1.11 -> 0.96 (profiles/r04b_step_modes.txt).
@@ -253,7 +253,7 @@ class StepPlan:
 def plannable(genome, kernel_configs, tsvd):
     """The configurations a StepPlan covers: a 2-D pattern with one square template (loops), a 1-D pattern with 2-4 templates of
     one square size (borders), or one of each; single iterations, no truncated SVD, the device pipeline."""
-    if tsvd is not None or not 1 <= len(kernel_configs) <= 2 or os.environ.get("CHROMOSIGHT_HIP_NO_STEP_PLAN"):
+    if tsvd is not None or not 1 <= len(kernel_configs) <= 2:
         return False
     if not (hasattr(genome, "view_for") and hasattr(genome, "dev") and hasattr(genome.dev, "pinned_empty")):
         return False

@@ -611,13 +611,11 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     # on the device (CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN=1), the 1-D foci through the labelling workgroup instead of the run kernels
     # (CHROMOSIGHT_HIP_NO_PATH_FOCI=1), the runs of a 1-D pattern scored by the general lane walk instead of rescore_run17
     # (CHROMOSIGHT_HIP_NO_RUN17=1), the labelling workgroups on global arrays instead of LDS (CHROMOSIGHT_HIP_NO_LDS_FOCI=1: the
-    # sorted route for every list), the mask tables behind the staging instead of beside it, the records of the foci by two
-    # kernels instead of one, the general run kernel instead of its 17 x 17 instance, one candidate list sorted on the device
-    # instead of the blocks' own segments.  (Every switch three times: the second and third repetition run on a context that has
+    # sorted route for every list), the mask tables behind the staging instead of beside it, one candidate list sorted on the
+    # device instead of the blocks' own segments.  (Every switch three times: the second and third repetition run on a context that has
     # seen the layout -- the deferred chain's launches sized from the previous call.)
     for switch in ("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
-                   "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_FUSED_RECORDS",
-                   "CHROMOSIGHT_HIP_RUN_GENERAL", "CHROMOSIGHT_HIP_NO_SEGMENTED"):
+                   "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_SEGMENTED"):
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):

@@ -6,9 +6,4 @@ out=${1:-gpurun_out/c4_modes.txt}
 run() { echo -n "$1: " >> $out; env $2 python bench.py --workload c4 --steps 30 --warmup 6 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['patterns'])" >> $out; }
 run default X=1
 
-run lanes2 CHROMOSIGHT_HIP_BLOCK_LANES=2
-run lanes4 CHROMOSIGHT_HIP_BLOCK_LANES=4
-run lanes6 CHROMOSIGHT_HIP_BLOCK_LANES=6
-run one_stream CHROMOSIGHT_HIP_ONE_STREAM=1
-run no_priority CHROMOSIGHT_HIP_NO_PRIORITY=1
 cat $out

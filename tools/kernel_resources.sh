@@ -3,7 +3,7 @@
 #   bash tools/kernel_resources.sh [file.hip]
 f=${1:-cs_corr_mfma.hip}
 cd "$(dirname "$0")/../chromosight_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-value -DCS_HAVE_FAST -c $f -o /tmp/kr_$$.o \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-value -DCS_HAVE_FAST $CS_EXTRA -c $f -o /tmp/kr_$$.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur=None

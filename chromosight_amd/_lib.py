@@ -12,7 +12,8 @@ import weakref
 import numpy as np
 
 CS_F32, CS_F64 = 0, 1
-LAYOUT_DENSE, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED = 0, 1, 2, 3
+LAYOUT_DENSE, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED, LAYOUT_BAND_COUNTS, LAYOUT_BAND_COUNTS_VIEW = 0, 1, 2, 3, 4, 5
+COUNTS_HEADER_BYTES = 128      # CS_COUNTS_HEADER_BYTES: in front of a band of raw counts (CS_LAYOUT_BAND_COUNTS)
 LAZY_BAND_BYTES = 128          # CS_LAZY_BAND_BYTES: descriptor of a lazily evaluated float64 band (cs_stage_block)
 MASK_NONE, MASK_BINS, MASK_EXPLICIT = 0, 1, 2
 
@@ -92,7 +93,7 @@ class CsStageBlock(C.Structure):
         ("d_law", C.c_void_p),
         ("ld64", C.c_int64),
         ("f64_diags", C.c_int32),
-        ("reserved", C.c_int32),
+        ("band32_counts", C.c_int32),
         ("d_lazy", C.c_void_p),
     ]
 

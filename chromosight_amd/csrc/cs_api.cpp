@@ -111,6 +111,7 @@ struct cs_ctx {
     int cand_hint_blocks = 0;
     bool cand_hint_paced = false;    // ... and its lists needed the host-paced chain (too long for the labelling workgroups' LDS arrays)
     bool allow_lazy = false; // the entry in progress takes CS_LAYOUT_BAND_LAZY signals (check_matrix)
+    bool allow_counts = false;   // ... CS_LAYOUT_BAND_COUNTS signals for its float32 tile kernel
     long long uploads = 0;   // template weights / fragments / rim tables copied to the device so far (upload_weights, ensure_wfrag)
     // what build_args derives from a template (statistics, the three weight sets, symmetry, threshold
     // flags), per arithmetic type: a detect run calls with the same template thousands of times
@@ -299,33 +300,51 @@ int fail(cs_ctx* ctx, int code, const char* fmt, ...)
 // entries whose float64 kernels all read their signal through load_signal take lazily evaluated bands (cs_stage_block)
 struct AllowLazy {
     cs_ctx* c;
-    bool was;
+    bool was, was_counts;
     explicit AllowLazy(cs_ctx* c_);
     ~AllowLazy();
 };
-inline bool is_band(int layout) { return layout == CS_LAYOUT_BAND || layout == CS_LAYOUT_BAND_LAZY || layout == CS_LAYOUT_BAND_PADDED; }
+inline bool is_band(int layout) { return layout == CS_LAYOUT_BAND || layout == CS_LAYOUT_BAND_LAZY || layout == CS_LAYOUT_BAND_PADDED || layout == CS_LAYOUT_BAND_COUNTS || layout == CS_LAYOUT_BAND_COUNTS_VIEW; }
 
 cs::MatView view_of(const cs_matrix* m)
 {
     cs::MatView v;
     v.ptr = m ? m->d_ptr : nullptr;
     v.ld = m ? m->ld : 0;
-    v.layout = m ? (m->layout == CS_LAYOUT_BAND_PADDED ? CS_LAYOUT_BAND : m->layout) : 0;
+    v.layout = m ? ((m->layout == CS_LAYOUT_BAND_PADDED || m->layout == CS_LAYOUT_BAND_COUNTS || m->layout == CS_LAYOUT_BAND_COUNTS_VIEW) ? CS_LAYOUT_BAND : m->layout) : 0;
     v.band_lo = m ? m->band_lo : 0;
     v.band_w = m ? m->band_w : 0;
     v.row0 = m ? m->row0 : 0;
-    v.pad = (m && m->layout == CS_LAYOUT_BAND_PADDED) ? 1 : 0;
+    v.pad = (m && (m->layout == CS_LAYOUT_BAND_PADDED || m->layout == CS_LAYOUT_BAND_COUNTS)) ? 1 : 0;
+    v.counts = (m && (m->layout == CS_LAYOUT_BAND_COUNTS || m->layout == CS_LAYOUT_BAND_COUNTS_VIEW)) ? 1 : 0;
     return v;
 }
 
-AllowLazy::AllowLazy(cs_ctx* c_) : c(c_), was(c_ ? c_->allow_lazy : false)
+AllowLazy::AllowLazy(cs_ctx* c_) : c(c_), was(c_ ? c_->allow_lazy : false), was_counts(c_ ? c_->allow_counts : false)
 {
-    if (c) c->allow_lazy = true;
+    if (c) c->allow_lazy = c->allow_counts = true;
 }
 AllowLazy::~AllowLazy()
 {
-    if (c) c->allow_lazy = was;
+    if (c) {
+        c->allow_lazy = was;
+        c->allow_counts = was_counts;
+    }
 }
+
+// the entry in progress takes a CS_LAYOUT_BAND_COUNTS signal (cs_normxcorr2: the masked tile kernel or an error)
+struct AllowCounts {
+    cs_ctx* c;
+    bool was;
+    explicit AllowCounts(cs_ctx* c_) : c(c_), was(c_ ? c_->allow_counts : false)
+    {
+        if (c) c->allow_counts = true;
+    }
+    ~AllowCounts()
+    {
+        if (c) c->allow_counts = was;
+    }
+};
 
 struct HostStats {
     double n, kmean, kstd, kvar, ksum, k2sum;
@@ -826,6 +845,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
             return CS_OK;
         }
     }
+    if (A.sig.counts) return fail(ctx, CS_ERR_UNSUPPORTED, "a band of counts (CS_LAYOUT_BAND_COUNTS) is read by the masked float32 tile kernel only: per-bin masks, full mode, odd square template of up to 17");
     if (!A.out.ptr) return CS_NEED_MAP;      // every other kernel writes a map
     if (allow_fast && mfma_wanted(A)) {
         if (A.sig_is_f64 && A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.nobs.ptr) {
@@ -892,6 +912,7 @@ template <>
 int launch_corr<double>(cs_ctx* ctx, cs::CorrArgs<double>& A, hipStream_t stream, bool allow_fast)
 {
     int K = 0, tw, th, rc;
+    if (A.sig.counts) return fail(ctx, CS_ERR_UNSUPPORTED, "a band of counts (CS_LAYOUT_BAND_COUNTS) is read by the masked float32 tile kernel only");
     A.n_cu = ctx->n_cu;
     A.grid_cap = ctx->grid_cap;
     ctx->last_kernel = CS_KERNEL_GENERIC;
@@ -933,6 +954,10 @@ int check_matrix(cs_ctx* ctx, const cs_matrix* m, const char* what, int ns)
     } else if (m->layout == CS_LAYOUT_BAND || m->layout == CS_LAYOUT_BAND_PADDED) {
         if (m->band_w <= 0 || m->ld < m->band_w) return fail(ctx, CS_ERR_INVALID, "%s: bad band geometry", what);
         if (m->layout == CS_LAYOUT_BAND_PADDED && m->ld < (int64_t)m->band_w + 4) return fail(ctx, CS_ERR_INVALID, "%s: a padded band keeps 4 zero slots per row", what);
+    } else if ((m->layout == CS_LAYOUT_BAND_COUNTS || m->layout == CS_LAYOUT_BAND_COUNTS_VIEW) && ctx->allow_counts) {
+        // a band of raw counts (cs_stage_block.band32_counts): only the masked tile kernel reads it (launch_corr<float>)
+        if (m->band_w <= 0 || m->band_lo != 0 || m->row0 != 0 || m->dtype != CS_F32 || m->ld < (int64_t)m->band_w + (m->layout == CS_LAYOUT_BAND_COUNTS ? 4 : 0))
+            return fail(ctx, CS_ERR_INVALID, "%s: bad band of counts", what);
     } else if (m->layout == CS_LAYOUT_BAND_LAZY && ctx->allow_lazy) {
         // a lazily evaluated float64 band (cs_stage_block): only the float64 kernels behind the batched foci entries read it
         if (m->band_w <= 0 || m->band_lo != 0 || m->row0 != 0 || m->dtype != CS_F64) return fail(ctx, CS_ERR_INVALID, "%s: bad lazy band", what);
@@ -1358,6 +1383,7 @@ int cs_normxcorr2(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
     hipStream_t stream = (hipStream_t)stream_;
     if (!p) return fail(ctx, CS_ERR_INVALID, "null params");
     int rc = check_matrix(ctx, out_corr, "out_corr", p->ns);
+    AllowCounts allow_counts(ctx);                   // (the signal only: the outputs were just checked without it)
     if (rc) return rc;
     const bool want_nobs = out_nobs && out_nobs->d_ptr;
     if (want_nobs) {
@@ -1982,9 +2008,15 @@ int cs_stage_blocks(cs_ctx* ctx, void* stream_, const cs_csr* genome, const cs_s
         B.law = s.d_law;
         B.ld64 = s.ld;
         B.w64 = 0;
-        B.pad_ = 0;
+        B.counts = 0;
         B.lazy = nullptr;
-        if (s.f64_diags > 0 || s.d_lazy) {
+        if (s.band32_counts) {
+            // CS_LAYOUT_BAND_COUNTS: d_band32 receives the raw counts (the caller vouches that they are exact in float32)
+            if (B.dense || !s.d_band32 || (s.ld & 3) || s.ld < (int64_t)B.width + 4 || ((uintptr_t)s.d_band32 & 15) || s.d_band64 || s.f64_diags > 0)
+                return fail(ctx, CS_ERR_INVALID, "block %d: a band of counts needs the band layout, a 16-byte aligned d_band32 behind its header, ld a multiple of 4 and >= band_w + 4, and no float64 band", b);
+            B.counts = 1;
+            B.lazy = reinterpret_cast<cs::LazyBand*>(s.d_lazy);          // (or null: float32 consumers only)
+        } else if (s.f64_diags > 0 || s.d_lazy) {
             if (B.dense || !s.d_lazy || !s.d_band64 || s.f64_diags <= 0 || s.ld64 < s.f64_diags || (s.ld64 & 1))
                 return fail(ctx, CS_ERR_INVALID, "block %d: a lazy float64 band needs the band layout, d_lazy, d_band64 and an even ld64 >= f64_diags > 0", b);
             B.ld64 = s.ld64;
@@ -2043,6 +2075,8 @@ static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel
     // (every foci entry shares the context's count words, block tables and record pool with an asynchronous batch)
     if (ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "an asynchronous batch is pending on this context: cs_detect_foci_batch_finish first");
     if (p->mask_mode == CS_MASK_EXPLICIT) return fail(ctx, CS_ERR_UNSUPPORTED, "device foci need per-bin masks or none");
+    if (signal->layout == CS_LAYOUT_BAND_COUNTS || signal->layout == CS_LAYOUT_BAND_COUNTS_VIEW)
+        return fail(ctx, CS_ERR_INVALID, "a band of counts is the float32 twin of a block (signals_f32), not its signal: hand the block's CS_LAYOUT_BAND_LAZY descriptor");
     if (fp->min_size < 1) return fail(ctx, CS_ERR_INVALID, "min_size must be >= 1");
     if (!ctx->h_counts) CS_HIP(ctx, hipHostMalloc((void**)&ctx->h_counts, 64, hipHostMallocDefault));
     return CS_OK;

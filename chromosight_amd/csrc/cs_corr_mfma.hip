@@ -420,6 +420,7 @@ struct MfmaDenseArgs {
     //      layout (band / dense) on either side, optional n_obs map
     int band_in, lo_in, bw_in;       // input band: first stored diagonal, stored diagonals
     int pad_in;                      // ... zero-padded (CS_LAYOUT_BAND_PADDED): >= 4 zero slots behind every row's stored diagonals
+    int cnt_in;                      // ... of raw counts (CS_LAYOUT_BAND_COUNTS): detrended as a landed tile is split (cs_device.h CountsHeader)
     int band_out, lo_out;            // output band: first stored diagonal
     int out_lo, out_hi;              // produced diagonals
     float* nobs;                     // same geometry as `out`, or nullptr
@@ -549,6 +550,14 @@ __device__ __forceinline__ ArgsPtr args_here()
     unsigned long long kv = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kv));
     return (ArgsPtr)kv;
+}
+
+// the header in front of a band of counts (cs_device.h), through the constant address space: scalar loads
+typedef const __attribute__((address_space(4))) CountsHeader* CountsHdrPtr;
+
+__device__ __forceinline__ CountsHdrPtr counts_header(const float* band)
+{
+    return (CountsHdrPtr)((unsigned long long)band - (unsigned long long)kCountsHeaderBytes);
 }
 
 __device__ __forceinline__ ArgsPtr args_at(unsigned long long entry)
@@ -822,6 +831,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.lo_in = A.sig.band_lo;
         D.bw_in = A.sig.band_w;
         D.pad_in = (A.sig.layout == 1 && A.sig.pad && A.sig.ld >= (long long)A.sig.band_w + 4) ? 1 : 0;
+        D.cnt_in = (A.sig.layout == 1 && A.sig.counts) ? 1 : 0;
         D.band_out = A.out.layout == 1;
         D.lo_out = A.out.band_lo;
         D.out_lo = A.out_lo;
@@ -905,6 +915,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         else hipLaunchKernelGGL((corr_mfma_dense_kernel<false, false>), dim3((unsigned)grid), dim3(256), (MFD_LAUNCH_EXTRA ? MFD_SMEM_REG + MFD_LAUNCH_EXTRA : MFD_SMEM), stream, D);
         return (int)hipGetLastError();
     }
+    if (A.sig.counts) return -6;                 // (a band of counts: only the masked tile kernel detrends what it reads)
     if (!A.out.ptr) return -5;                   // (a candidate sink without a map: only the masked tile kernel serves that)
     const void* kern = masked ? (const void*)corr_mfma_kernel<true> : (const void*)corr_mfma_kernel<false>;
     hipError_t e = allow_big_lds(kern);

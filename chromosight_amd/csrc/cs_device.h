@@ -18,7 +18,35 @@ struct MatView {
     int band_w;   // number of stored diagonals (band)
     long long row0;  // matrix row stored at ptr: the buffer holds a window of rows (0 = the whole matrix)
     int pad;      // band: the slots band_w .. ld - 1 of every row (>= 4) and every slot outside the matrix are zero (CS_LAYOUT_BAND_PADDED)
+    int counts;   // band of RAW COUNTS (CS_LAYOUT_BAND_COUNTS, float32, zero-padded like `pad`): the reader balances and detrends
+                  // what it fetches (CountsHeader in the kCountsHeaderBytes in front of ptr) -- the masked tile kernel only
 };
+
+// CS_LAYOUT_BAND_COUNTS: the staging pass of a genome (cs_stage.hip) writes the band of a block ONCE, in the same pass over the
+// pixel table that reduces its distance law, as the raw counts (exact in float32: integers below 2^24); balancing
+// (contacts_map.py:531-540) and the detrend by the law (preprocessing.py:296-302) are a function of a pixel's count, its row and
+// column weights and its diagonal, and are applied by whoever reads a pixel -- the tile kernel while it splits a landed tile into
+// float16 planes, the float64 kernels pixel by pixel (LazyBand::counts) -- with the operations of stage_detrend_rcp, in its
+// order: bit for bit the values the detrended bands held.  No second pass over the pixel table, no detrended band in HBM.
+// The header sits in the 128 bytes in front of the band (written by stage_finish_kernel).
+struct CountsHeader {
+    const double* weight;      // the genome's ICE weights (NaN: undetectable bin)
+    const double* law;         // the block's distance law, n_diags values
+    const double* rlaw;        // 1 / law, n_diags values with one more slot on either side (rlaw[-1], rlaw[n_diags]: zeros)
+    long long row0;            // first genome bin of the block
+    double max_val;
+    int n, n_diags;
+    const float* weight32;     // the block's n weights and the n_diags + 2 reciprocals rounded to float32 (rlaw32[-1 .. n_diags]): what
+    const float* rlaw32;       // the float32 tile kernel multiplies a landed tile's counts with
+};
+// layout of a counts block's d_law buffer (include/chromosight_hip.h CS_COUNTS_LAW_BYTES): law[n_diags], rlaw[-1 .. n_diags],
+// rlaw32[-1 .. n_diags] (padded to 8 bytes), weight32[n]
+__host__ __device__ inline long long counts_law_bytes(int n, int n_diags)
+{
+    return 8ll * (2 * n_diags + 2) + 4ll * ((n_diags + 2 + 1) / 2 * 2) + 4ll * n;
+}
+constexpr int kCountsHeaderBytes = 128;
+static_assert(sizeof(CountsHeader) <= kCountsHeaderBytes, "CS_COUNTS_HEADER_BYTES of include/chromosight_hip.h");
 
 // element offset of (p, q), or -1 if the pixel is not stored
 __device__ __forceinline__ long long mat_offset(const MatView& m, int p, int q)
@@ -48,6 +76,8 @@ struct LazyBand {
     long long near_ld;
     double max_val;
     int n, n_diags, near_w, data_is_f64;
+    const float* counts;           // (or null) the block's band of raw counts, every kept diagonal, row pitch counts_ld: the stored
+    long long counts_ld;           //  diagonals are then ALL of them (near_w = n_diags, near_ null) and nothing is searched
 };
 
 // the staged value of one stored pixel (contacts_map.py:531-540, preprocessing.py:296-302): balance, detrend by the law of
@@ -72,6 +102,22 @@ __device__ __forceinline__ double stage_detrend_rcp(double v, double inv_y, doub
     return out != out ? 0.0 : out;                         // NaN -> 0 (contacts_map.py:539-540)
 }
 
+// the staged value of slot (p, d) of a band of counts: what the detrended band held there (0 for an empty slot: a stored count
+// of 0 is 0 / law = 0, or NaN -> 0 on an empty diagonal)
+__device__ __forceinline__ double counts_value(float c, const double* __restrict__ weight, const double* __restrict__ law, long long row0,
+                                               int p, int d, double max_val)
+{
+    if (c == 0.0f) return 0.0;
+    return stage_detrend_rcp(((double)c * weight[row0 + p]) * weight[row0 + p + d], 1.0 / law[d], max_val, law + d);
+}
+
+// slot (p, d), d < near_w, of the diagonals a lazily evaluated band keeps in memory
+__device__ __forceinline__ double lazy_near_value(const LazyBand& L, int p, int d)
+{
+    if (L.counts) return counts_value(L.counts[(long long)p * L.counts_ld + d], L.weight, L.law, L.row0, p, d, L.max_val);
+    return L.near_[(long long)p * L.near_ld + d];
+}
+
 __device__ __forceinline__ double lazy_stored_value(const LazyBand& L, long long k, int p, int q)
 {
     const double x = L.data_is_f64 ? reinterpret_cast<const double*>(L.data)[k] : (double)reinterpret_cast<const float*>(L.data)[k];
@@ -86,7 +132,7 @@ __device__ __forceinline__ double lazy_load(const MatView& m, int p, int q)
     const LazyBand& L = *reinterpret_cast<const LazyBand*>(m.ptr);
     const int d = q - p;
     if (d - m.band_lo < 0 || d - m.band_lo >= m.band_w || d < 0 || d >= L.n_diags) return 0.0;
-    if (d < L.near_w) return L.near_[(long long)p * L.near_ld + d];
+    if (d < L.near_w) return lazy_near_value(L, p, d);
     const long long r = L.row0 + p;
     long long lo = L.indptr[r], hi = L.indptr[r + 1];
     const long long end = hi;

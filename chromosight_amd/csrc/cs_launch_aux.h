@@ -65,7 +65,7 @@ __device__ __forceinline__ void lazy_gather_window(const CorrArgs<double>& A, in
         const int ki = e / kn, kj = e - ki * kn;
         const int p = p0 + ki, q = q0 + kj, d = q - p;
         double v = 0.0;
-        if ((p >= 0) & (p < A.ms) & (q >= 0) & (q < A.ns) & (d >= d_lo) & (d < near_end)) v = L.near_[(long long)p * L.near_ld + d];
+        if ((p >= 0) & (p < A.ms) & (q >= 0) & (q < A.ns) & (d >= d_lo) & (d < near_end)) v = lazy_near_value(L, p, d);
         win[e] = v;
     }
     // (the LDS operations of a wave execute in order: the slots are zero before anything is dropped into them)
@@ -189,6 +189,12 @@ struct SigReader {
     const MatView* view;
     long long ld, row0;
     int ms, ns, layout, band_lo, band_w, is_f64, near_w, n_diags;
+    // a lazily evaluated band whose stored diagonals are a band of counts (cs_device.h LazyBand::counts)
+    const __attribute__((address_space(1))) float* cnt;
+    const __attribute__((address_space(1))) double* cnt_weight;
+    const __attribute__((address_space(1))) double* cnt_law;
+    long long cnt_row0;
+    double cnt_max;
 
     __device__ __forceinline__ explicit SigReader(const CorrArgs<double>& A)
     {
@@ -200,13 +206,22 @@ struct SigReader {
         band_w = __builtin_amdgcn_readfirstlane(A.sig.band_w);
         is_f64 = __builtin_amdgcn_readfirstlane(A.sig_is_f64);
         near_w = n_diags = 0;
+        cnt = nullptr;
+        cnt_weight = cnt_law = nullptr;
+        cnt_row0 = 0;
+        cnt_max = 0.0;
         const void* ptr = A.sig.ptr;
         ld = A.sig.ld;
         row0 = A.sig.row0;
         if (layout == 2) {
             const LazyBand* L = reinterpret_cast<const LazyBand*>(ptr);
+            cnt = uniform_global(L->counts);
+            cnt_weight = uniform_global(L->weight);
+            cnt_law = uniform_global(L->law);
+            cnt_row0 = __builtin_amdgcn_readfirstlane((int)L->row0);
+            cnt_max = L->max_val;
             ptr = L->near_;
-            ld = L->near_ld;
+            ld = L->counts ? L->counts_ld : L->near_ld;
             row0 = 0;
             near_w = __builtin_amdgcn_readfirstlane(L->near_w);
             n_diags = __builtin_amdgcn_readfirstlane(L->n_diags);
@@ -224,7 +239,10 @@ struct SigReader {
         const int d = q - p;
         if (layout == 2) {
             if ((d - band_lo < 0) | (d - band_lo >= band_w) | (d < 0) | (d >= n_diags)) return 0.0;
-            if (d < near_w) return p64[(long long)p * ld + d];
+            if (d < near_w) {
+                if (cnt) return counts_value(cnt[(long long)p * ld + d], (const double*)cnt_weight, (const double*)cnt_law, cnt_row0, p, d, cnt_max);
+                return p64[(long long)p * ld + d];
+            }
             return lazy_load(*view, p, q);
         }
         long long off;
@@ -252,8 +270,9 @@ __device__ __forceinline__ void lazy_gather_window_sq(const CorrArgs<double>& A,
     const auto* weight = uniform_global(Lp->weight);
     const auto* law = uniform_global(Lp->law);
     const auto* near_ = uniform_global(Lp->near_);
+    const auto* counts = uniform_global(Lp->counts);
     const long long row0 = __builtin_amdgcn_readfirstlane((int)Lp->row0);         // (genome bins: < 2^31)
-    const long long near_ld = __builtin_amdgcn_readfirstlane((int)Lp->near_ld);
+    const long long near_ld = __builtin_amdgcn_readfirstlane((int)(Lp->counts ? Lp->counts_ld : Lp->near_ld));
     const double max_val = Lp->max_val;
     const int n_diags = __builtin_amdgcn_readfirstlane(Lp->n_diags), near_w = __builtin_amdgcn_readfirstlane(Lp->near_w);
     const bool is_f64 = __builtin_amdgcn_readfirstlane(Lp->data_is_f64) != 0;
@@ -299,7 +318,10 @@ __device__ __forceinline__ void lazy_gather_window_sq(const CorrArgs<double>& A,
             if (near_hit) {
                 const int ki = e / K, kj = e - ki * K;
                 const int p = p0 + ki, q = q0 + kj, d = q - p;
-                if ((p >= 0) & (p < ms) & (q >= 0) & (q < ns) & (d >= d_lo) & (d < near_end)) v = near_[(long long)p * near_ld + d];
+                if ((p >= 0) & (p < ms) & (q >= 0) & (q < ns) & (d >= d_lo) & (d < near_end)) {
+                    if (counts) v = counts_value(counts[(long long)p * near_ld + d], (const double*)weight, (const double*)law, row0, p, d, max_val);
+                    else v = near_[(long long)p * near_ld + d];
+                }
             }
             win[e] = v;
         }
@@ -668,7 +690,9 @@ struct StageBlock {
     double* law;             // n_diags values
     long long ld64;          // row pitch of band64 (= ld unless only its first w64 diagonals are written)
     int w64;                 // band layout: band64 receives the slots 0 .. w64 - 1 only (0: all of them)
-    int pad_;
+    int counts;              // band32 receives the block's RAW COUNTS, written by the law pass (cs_device.h CountsHeader in the 128
+                             // bytes in front of it; `law` then holds n_diags values + the n_diags + 2 of their reciprocals); the
+                             // tiler has nothing to write for such a block
     LazyBand* lazy;          // descriptor of the block's lazily evaluated float64 band, written by stage_finish_kernel (or null)
 };
 // what a LazyBand points to besides its block (the genome's pixel table)

@@ -44,7 +44,22 @@ constexpr int kStageWaves = kStageThreads / 64;
 // group), and the first kStageUnroll x 64 pixels of the NEXT row are requested before the current row is reduced.
 constexpr int kStageGroupRows = 128;             // upper bound of rows per group (cs_api.cpp picks 64 .. 128)
 
-template <typename TV, int kStageUnroll>
+__device__ __forceinline__ void stage_wave_sync()
+{
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// COUNTS: blocks flagged StageBlock::counts get their band of raw counts (CS_LAYOUT_BAND_COUNTS) written by THIS pass -- a wave has
+// the stored pixels of its row in registers anyway: it drops the counts into a zeroed LDS row piece (slot = diagonal) and
+// streams the piece out, 16 bytes per lane.  The detrended band of the tiler (a second pass over the pixel table, and the
+// division by a law that this pass is only reducing) is not written at all: whoever reads a pixel detrends it (cs_device.h).
+constexpr int kCountsPiece = 576;               // slots per LDS row piece (float32): 2.25 KB per wave
+
+template <typename TV, int kStageUnroll, bool COUNTS>
 __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                                   const TV* __restrict__ data, const double* __restrict__ weight,
                                                                   const StageBlock* __restrict__ blocks,
@@ -60,6 +75,8 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
     // row would wait a full write round trip -- the group's row ends leave together instead)
     long long* l_stop = reinterpret_cast<long long*>(l_w + pitch + kStageGroupRows);                             // kStageGroupRows
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* l_row = reinterpret_cast<float*>(l_stop + kStageGroupRows) + (size_t)wv * kCountsPiece;               // COUNTS: per wave
+    typedef float f4 __attribute__((ext_vector_type(4)));
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const StageGroup G = groups[g];
         const StageBlock B = blocks[G.block];
@@ -71,6 +88,13 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
             l_cnt[d] = 0u;
         }
         for (int t = tid; t < n_w; t += kStageThreads) l_w[t] = weight[r0 + t];
+        if constexpr (COUNTS) {
+            // the float32 copy of the block's weights (cs_device.h CountsHeader::weight32): every row belongs to one group
+            if (B.counts) {
+                float* w32 = reinterpret_cast<float*>(B.law + 2 * B.n_diags + 2) + (B.n_diags + 2 + 1) / 2 * 2;
+                for (int t = tid; t < G.row_end - G.row_begin; t += kStageThreads) w32[G.row_begin + t] = (float)weight[r0 + t];
+            }
+        }
         // this wave's rows: G.row_begin + wv + 8 i, i < n_mine (<= 16) -- lane i holds row i's pointers
         const int n_mine = (G.row_end - G.row_begin - wv + kStageWaves - 1) / kStageWaves;
         long long my_b = 0, my_e = 0;
@@ -113,6 +137,26 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
             }
             if (i + 1 < n_mine) request(i + 1);
             int n_in = 0;
+            // COUNTS: the row's band leaves in pieces of kCountsPiece slots (slot = diagonal); the stored pixels arrive in column
+            // order, so a piece is complete when a pixel beyond it shows up (or the row ends)
+            const bool counts_row = COUNTS && B.counts;
+            float* out_row = counts_row ? B.band32 + (size_t)rl * B.ld : nullptr;
+            const int ld_row = (int)B.ld;
+            int piece0 = 0;
+            auto piece_clear = [&]() {
+                for (int x = 4 * lane; x < kCountsPiece; x += 256) *reinterpret_cast<f4*>(l_row + x) = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            };
+            auto piece_flush = [&]() {
+                stage_wave_sync();
+                const int len = min(ld_row - piece0, kCountsPiece);          // (ld is a multiple of 4)
+                for (int x = 4 * lane; x < len; x += 256) *reinterpret_cast<f4*>(out_row + piece0 + x) = *reinterpret_cast<const f4*>(l_row + x);
+                stage_wave_sync();
+                piece0 += kCountsPiece;
+            };
+            if (counts_row) {
+                piece_clear();
+                stage_wave_sync();
+            }
             for (long long k0 = b;;) {
 #pragma unroll
                 for (int u = 0; u < kStageUnroll; ++u) {
@@ -125,6 +169,18 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
                         const int d = rel - c_r;
                         atomicAdd(&l_sum[d], v);
                         atomicAdd(&l_cnt[d], 1u);
+                    }
+                    if constexpr (COUNTS) {
+                        if (counts_row) {
+                            const int d = in ? rel - c_r : 0x7fffffff;
+                            while (__builtin_amdgcn_ballot_w64(in && d >= piece0 + kCountsPiece)) {      // (rows wider than one piece)
+                                if (in && d >= piece0 && d < piece0 + kCountsPiece) l_row[d - piece0] = (float)x[u];
+                                piece_flush();
+                                piece_clear();
+                                stage_wave_sync();
+                            }
+                            if (in && d >= piece0 && d < piece0 + kCountsPiece) l_row[d - piece0] = (float)x[u];
+                        }
                     }
                 }
                 k0 += 64 * kStageUnroll;
@@ -139,6 +195,17 @@ __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long lon
                 }
             }
             if (lane == 0) l_stop[rl - G.row_begin] = b + n_in;
+            if constexpr (COUNTS) {
+                if (counts_row) {
+                    while (piece0 < ld_row) {
+                        piece_flush();
+                        if (piece0 < ld_row) {
+                            piece_clear();
+                            stage_wave_sync();
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int d = tid; d < B.n_diags; d += kStageThreads) {
@@ -186,7 +253,33 @@ __global__ __launch_bounds__(kFinishDiags * kFinishPhases / PPT) void stage_fini
         L.n_diags = B.n_diags;
         L.near_w = B.band64 ? (B.w64 > 0 ? min(B.w64, B.width) : B.width) : 0;
         L.data_is_f64 = src.data_is_f64;
+        L.counts = nullptr;
+        L.counts_ld = 0;
+        if (B.counts) {                 // every kept diagonal is in memory, as counts: nothing is searched
+            L.near_ = nullptr;
+            L.near_w = B.n_diags;
+            L.counts = B.band32;
+            L.counts_ld = B.ld;
+        }
         *B.lazy = L;
+    }
+    if (B.counts && blockIdx.y == 0 && threadIdx.x == 0) {
+        CountsHeader H;
+        H.weight = src.weight;
+        H.law = B.law;
+        H.rlaw = B.law + B.n_diags + 1;
+        H.row0 = B.row0;
+        H.max_val = src.max_val;
+        H.n = B.n;
+        H.n_diags = B.n_diags;
+        float* r32 = reinterpret_cast<float*>(B.law + 2 * B.n_diags + 2);
+        H.rlaw32 = r32 + 1;
+        H.weight32 = r32 + (B.n_diags + 2 + 1) / 2 * 2;
+        *reinterpret_cast<CountsHeader*>(reinterpret_cast<char*>(B.band32) - kCountsHeaderBytes) = H;
+        B.law[B.n_diags] = 0.0;                       // rlaw[-1], rlaw[n_diags]: read beside a real neighbour, never used
+        B.law[2 * B.n_diags + 1] = 0.0;
+        r32[0] = 0.0f;
+        r32[B.n_diags + 1] = 0.0f;
     }
     const int dx = threadIdx.x % kFinishDiags, t_ph = threadIdx.x / kFinishDiags;
     const int d = blockIdx.y * kFinishDiags + dx;
@@ -243,7 +336,13 @@ __global__ __launch_bounds__(kFinishDiags * kFinishPhases / PPT) void stage_fini
             s += s_sum[k][dx];
             c += s_cnt[k][dx];
         }
-        B.law[d] = c > 0 ? s / (double)c : 0.0;             // cs_distance_law_finish
+        const double y = c > 0 ? s / (double)c : 0.0;       // cs_distance_law_finish
+        B.law[d] = y;
+        if (B.counts) {
+            const double ry = 1.0 / y;                      // (what stage_tile_kernel takes per group: l_law)
+            B.law[B.n_diags + 1 + d] = ry;
+            reinterpret_cast<float*>(B.law + 2 * B.n_diags + 2)[1 + d] = (float)ry;
+        }
     }
 }
 
@@ -256,14 +355,6 @@ __global__ __launch_bounds__(kFinishDiags * kFinishPhases / PPT) void stage_fini
 // Rows are built in pieces of kStageRowMax slots (columns are sorted: a piece continues where the last one stopped), which
 // keeps three workgroups per CU resident.
 constexpr int kStageRowMax = 544;                // slots per LDS row piece: 4.25 KB per wave, 34 KB per workgroup (+ law and weights: 52 KB, three per CU)
-
-__device__ __forceinline__ void stage_wave_sync()
-{
-    // LDS operations of one wave execute in order; this only keeps the compiler from moving them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Per group: the law and the column weights the group can touch go to LDS, lane i of a wave holds the first and last stored
 // pixel of the wave's i-th row, and the first 64 x kStageUnroll stored pixels of the NEXT row are requested before the current
@@ -292,6 +383,7 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const StageGroup G = groups[g];
         const StageBlock B = blocks[G.block];
+        if (B.counts && !B.band64) continue;               // (uniform) the law pass wrote this block's band
         const long long last_col = B.row0 + B.n - 1;
         const long long r0 = B.row0 + G.row_begin;
         const int n_w = (int)min((long long)(G.row_end - G.row_begin) + B.keep, last_col - r0 + 1);
@@ -337,7 +429,7 @@ __global__ __launch_bounds__(kStageThreads, CS_STAGE_TILE_WAVES) void stage_tile
             const long long b = __shfl(my_b, i), e = __shfl(my_e, i);
             double* out64 = (B.band64 && !(dbg & 1)) ? B.band64 + (size_t)rl * B.ld64 : nullptr;
             const int w64 = B.w64 > 0 ? ((B.w64 + 1) & ~1) : (int)B.ld;               // (stored in pairs; ld64 is even)
-            float* out32 = (B.band32 && !(dbg & 2)) ? B.band32 + (size_t)rl * B.ld : nullptr;
+            float* out32 = (B.band32 && !B.counts && !(dbg & 2)) ? B.band32 + (size_t)rl * B.ld : nullptr;
             const long long x0 = B.dense ? B.row0 : r;
             double v[kStageUnroll];
             int slot[kStageUnroll];
@@ -488,17 +580,28 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     const int unroll = 4;
     const int grid = std::min(n_groups, per_cu * n_cu);
     if (rows_per_group > kStageGroupRows) return (int)hipErrorInvalidValue;
-    const size_t smem_law = (sizeof(double) + sizeof(unsigned)) * (size_t)pitch + sizeof(double) * ((size_t)pitch + 2 * kStageGroupRows);
+    bool any_counts = false, any_tiled = false;
+    for (int b = 0; b < n_blocks; ++b) {
+        any_counts = any_counts || h_blocks[b].counts;
+        any_tiled = any_tiled || !h_blocks[b].counts || h_blocks[b].band64;
+    }
+    const size_t smem_law = (sizeof(double) + sizeof(unsigned)) * (size_t)pitch + sizeof(double) * ((size_t)pitch + 2 * kStageGroupRows) +
+                            (any_counts ? sizeof(float) * (size_t)kStageWaves * kCountsPiece : 0);
     const size_t smem_tile = sizeof(double) * (2 * (size_t)pitch + kStageGroupRows + (size_t)kStageWaves * kStageRowMax);
     int max_b = 0;
     for (int b = 0; b < n_blocks; ++b) max_b = std::max(max_b, h_blocks[b].n_diags);
-#define CS_STAGE_LAW(TV, U)                                                                                                       \
+#define CS_STAGE_LAW_(TV, U, CN)                                                                                                  \
     do {                                                                                                                           \
         if (smem_law > 48 * 1024)       /* laws beyond ~ 2300 diagonals: more dynamic LDS than a launch gets by default */           \
-            (void)hipFuncSetAttribute((const void*)stage_law_kernel<TV, U>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+            (void)hipFuncSetAttribute((const void*)stage_law_kernel<TV, U, CN>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                       160 * 1024);                                                                                 \
-        hipLaunchKernelGGL((stage_law_kernel<TV, U>), dim3(grid), dim3(kStageThreads), smem_law, stream, indptr, indices,           \
+        hipLaunchKernelGGL((stage_law_kernel<TV, U, CN>), dim3(grid), dim3(kStageThreads), smem_law, stream, indptr, indices,       \
                            (const TV*)data, weight, d_blocks, d_groups, n_groups, pitch, part_sum, part_cnt, row_stop);            \
+    } while (0)
+#define CS_STAGE_LAW(TV, U)                      \
+    do {                                         \
+        if (any_counts) CS_STAGE_LAW_(TV, U, true);  \
+        else CS_STAGE_LAW_(TV, U, false);        \
     } while (0)
 #define CS_STAGE_TILE(TV, U)                                                                                                       \
     do {                                                                                                                           \
@@ -533,8 +636,9 @@ int enqueue_stage_blocks(const long long* indptr, const int* indices, const void
     else
         hipLaunchKernelGGL(stage_finish_kernel<1>, finish_grid, dim3(kFinishDiags * kFinishPhases), 0, stream, d_blocks, pitch, part_sum,
                            part_cnt, lazy_src);
-    CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile)
+    if (any_tiled) { CS_STAGE_BOTH(CS_STAGE_TILE, unroll_tile) }
 #undef CS_STAGE_BOTH
+#undef CS_STAGE_LAW_
 #undef CS_STAGE_LAW
 #undef CS_STAGE_TILE
     (void)n_rows;

@@ -20,7 +20,8 @@ import pandas as pd
 import scipy.sparse as sp
 
 from . import engine
-from ._lib import (CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED, LAYOUT_DENSE, LAZY_BAND_BYTES, CsCsr, CsMatrix, CsStageBlock,
+from ._lib import (COUNTS_HEADER_BYTES, CS_F32, CS_F64, LAYOUT_BAND, LAYOUT_BAND_COUNTS, LAYOUT_BAND_COUNTS_VIEW, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED,
+                   LAYOUT_DENSE, LAZY_BAND_BYTES, CsCsr, CsMatrix, CsStageBlock,
                    get_device, np_dtype_code)
 from .utils import detection as cid
 from .utils import preprocessing as preproc
@@ -327,6 +328,9 @@ class DeviceCool:
         small = cnt.size == 0 or (np.issubdtype(cnt.dtype, np.integer) and cnt.max() < (1 << 24)) or \
             (cnt.max() < (1 << 24) and np.all(cnt == np.rint(cnt)))
         self.val_dtype = np.float32 if small else np.float64
+        # ... and, when none is negative, can be staged as a band of raw counts that its readers detrend (CS_LAYOUT_BAND_COUNTS)
+        # (and no weight: the readers' NaN -> 0 is a max with 0)
+        self.counts_ok = bool(small and (cnt.size == 0 or cnt.min() >= 0) and not np.any(weight < 0))
         self.nnz = int(b1.size)
         self.indptr = dev.to_device(indptr, np.int64)
         self.indices = dev.to_device(b2, np.int32)
@@ -358,12 +362,13 @@ class DeviceCool:
         Every block's staging is complete on return."""
         chroms = list(chroms)
         lazy64 = options.pop("lazy64", False)                # (only the one-call staging knows lazily evaluated bands)
+        counts = options.pop("counts", None)                 # (... and bands of raw counts)
         # One staging call at a time per pixel table: the calls share this context's staging scratch, its page-locked
         # table slots and the law scratch, and they are ordered on one stream.  (Patterns scanned side by side by several
         # host threads each stage the blocks they cannot take as views -- short chromosomes staged dense for a wider
         # pattern: two such calls at once handed each other's block tables to the kernels.)
         with self._stage_lock:
-            fast = self._stage_fast(chroms, max_dist, largest_kernel, lazy64=lazy64, **options)
+            fast = self._stage_fast(chroms, max_dist, largest_kernel, lazy64=lazy64, counts=counts, **options)
         if fast is not None:
             return fast
         if workers <= 1 or len(chroms) <= 1:
@@ -399,7 +404,7 @@ class DeviceCool:
         return pool.map(one, chroms)
 
     def _stage_fast(self, chroms, max_dist, largest_kernel, smooth=False, band_dtype=np.float64, reduce=None, rows=None,
-                    stream=None, lazy64=False, **unused):
+                    stream=None, lazy64=False, counts=None, **unused):
         """All the given chromosomes with ONE native call (cs_stage_blocks: three launches for the whole genome -- a
         pass over the pixel table for the distance laws, the laws' finish, and the detrend / tiler that writes every
         block once in float64 (exact re-scoring, windows) and float32 (what the matrix-core kernel stages)); None when
@@ -421,7 +426,7 @@ class DeviceCool:
             out_w = min(max_dist, n - 1) + 1
             band = 2 * max(in_w, out_w) < n
             ld = _pitch(in_w, 64) if band else _pitch(n, 16)
-            geo.append((ci, s, n, keep, n_diags, in_w, band, ld))
+            geo.append([ci, s, n, keep, n_diags, in_w, band, ld])
         # lazy64: the float64 band of a banded block is NOT stored beyond its first `near` diagonals (where the runs of a
         # 1-D pattern live); the float64 kernels behind the batched entries recompute the few pixels they read from the
         # pixel table (include/chromosight_hip.h cs_stage_block: a third of the staging pass was writing that band).  The
@@ -430,29 +435,52 @@ class DeviceCool:
         # pixels against)
         near = 64
         lazy = [bool(lazy64 and not only32 and g[6] and (lazy64 == "all" or g[5] > 2 * near)) for g in geo]
+        # counts (map-level callers ask for it; CHROMOSIGHT_HIP_COUNTS_BAND=1: wherever the float64 band is lazily evaluated): the
+        # float32 band of a banded block holds the RAW COUNTS, written by the pass that reduces the distance law -- no detrend /
+        # tiler pass over the pixel table, no float64 near band; the tile kernel detrends the tiles it fetches (float32) and the
+        # float64 kernels every pixel they read (the staging pass's own expression; include/chromosight_hip.h
+        # CS_LAYOUT_BAND_COUNTS).  Needs counts that are exact in float32 and not negative (what a .cool holds).
+        # Measured (profiles/r05_counts_band.txt): the C3 step 0.222 -> 0.21 ms and a quarter less HBM traffic; the genome step
+        # of a detect run gains nothing (its tile kernels pay 4 % for the conversion, its float64 kernels convert every pixel
+        # they read, and the tiler pass they replace was half hidden) -- so detection keeps the detrended bands by default.
+        if counts is None:
+            counts = bool(lazy64) and lazy64 != "all" and bool(os.environ.get("CHROMOSIGHT_HIP_COUNTS_BAND"))
+        counts = bool(counts and self.counts_ok)
+        cnt = [bool(counts and g[6] and (only32 or lazy[k])) for k, g in enumerate(geo)]
+        for k, g in enumerate(geo):
+            if cnt[k]:
+                g[7] = _pitch(g[5] + 4, 64)                     # (>= 4 zero slots behind every row's diagonals)
         # The laws (and the descriptors of lazily evaluated bands) live as long as the blocks do: one buffer per staging call,
         # held by every block of the call -- never the rewritten law scratch.  A recorded staging (plan.StepPlan replays the
         # cs_stage_blocks table verbatim, d_law included) must not point into a grow-only scratch that a later staging with a
         # longer law re-allocates (silent corruption on the next replay).
-        shared = _Shared(self._free, self._resident(8 * sum(g[4] for g in geo) + 256 + LAZY_BAND_BYTES * len(geo)))
+        # (counts: CS_COUNTS_LAW_BYTES -- the law, its reciprocals, float32 copies of the reciprocals and of the block's weights)
+        law_len = [(2 * g[4] + 2 + (g[4] + 3) // 2 + (g[2] + 1) // 2) if cnt[k] else g[4] for k, g in enumerate(geo)]
+        shared = _Shared(self._free, self._resident(8 * sum(law_len) + 256 + LAZY_BAND_BYTES * len(geo)))
         laws = shared.buffer.ptr + LAZY_BAND_BYTES * len(geo)
         table = (CsStageBlock * len(geo))()
         blocks, off = [], 0
         for k, (ci, s, n, keep, n_diags, in_w, band, ld) in enumerate(geo):
             near_k = in_w if lazy64 == "all" else near
             ld64 = (ld if lazy64 == "all" else _pitch(near, 2)) if lazy[k] else ld
-            b64 = None if only32 else self._resident(n * ld64 * 8)
-            b32 = self._resident(n * ld * 4)
+            b64 = None if (only32 or cnt[k]) else self._resident(n * ld64 * 8)
+            head = COUNTS_HEADER_BYTES if cnt[k] else 0
+            b32 = self._resident(n * ld * 4 + head)
+            p32 = b32.ptr + head
             desc = shared.buffer.ptr + LAZY_BAND_BYTES * k if lazy[k] else None
-            table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND if band else LAYOUT_DENSE, in_w if band else 0, ld,
-                                    b64.ptr if b64 is not None else None, b32.ptr, laws + off,
-                                    ld64 if lazy[k] else 0, near_k if lazy[k] else 0, 0, desc)
-            off += 8 * n_diags
+            if cnt[k]:
+                table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND, in_w, ld, None, p32, laws + off, 0, 0, 1, desc)
+            else:
+                table[k] = CsStageBlock(s, n, keep, LAYOUT_BAND if band else LAYOUT_DENSE, in_w if band else 0, ld,
+                                        b64.ptr if b64 is not None else None, p32, laws + off,
+                                        ld64 if lazy[k] else 0, near_k if lazy[k] else 0, 0, desc)
+            off += 8 * law_len[k]
             layout = LAYOUT_BAND if band else LAYOUT_DENSE
             flags = _Ptr(self.miss.ptr + s)
             # (the staging pass assembles every row in zeroed pieces of ld slots: the float32 band is zero behind its stored
             # diagonals -- the tile kernel fetches its rim tiles like the inner ones, include/chromosight_hip.h)
-            sig32 = CsMatrix(b32.ptr, CS_F32, LAYOUT_BAND_PADDED if band and ld >= in_w + 4 else layout, ld, 0, in_w if band else 0, 0)
+            sig32 = CsMatrix(p32, CS_F32, LAYOUT_BAND_COUNTS if cnt[k] else LAYOUT_BAND_PADDED if band and ld >= in_w + 4 else layout, ld, 0,
+                             in_w if band else 0, 0)
             if only32:
                 sig64 = sig32
             elif lazy[k]:
@@ -461,8 +489,8 @@ class DeviceCool:
                 sig64 = CsMatrix(b64.ptr, CS_F64, layout, ld, 0, in_w if band else 0, 0)
             blk = StagedBlock(self.names[ci], sig64, (n, n), flags, flags, max_dist, False, keep)
             blk.sig32 = sig32
-            blk.buffer, blk.pool = (b32 if only32 else b64), self._free
-            blk.buffer32 = None if only32 else b32
+            blk.buffer, blk.pool = (b32 if (only32 or b64 is None) else b64), self._free
+            blk.buffer32 = None if (only32 or b64 is None) else b32
             blk.shared = shared                                 # (the law buffer of the call)
             if lazy[k]:
                 blk.genome = self                               # (the descriptor points into the pixel table)
@@ -496,7 +524,8 @@ class DeviceCool:
         (dense-staged short chromosomes, row windows, a longer distance than the block holds)."""
         n = block.shape[0]
         keep = min(max_dist, n) + largest_kernel
-        if (block.inter or block.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED) or getattr(block, "row_window", None) is not None
+        if (block.inter or block.sig.layout not in (LAYOUT_BAND, LAYOUT_BAND_LAZY, LAYOUT_BAND_PADDED, LAYOUT_BAND_COUNTS, LAYOUT_BAND_COUNTS_VIEW)
+                or getattr(block, "row_window", None) is not None
                 or block.keep is None or keep > block.keep or getattr(block, "smooth", False)):
             return None
         in_w = min(keep, n - 1) + 1
@@ -505,14 +534,16 @@ class DeviceCool:
             return None                              # this pattern would have been staged dense: keep the layouts identical
         s = block.sig
         # (a narrower view of a zero-padded band is a plain band: the slots behind ITS diagonals hold the block's further ones)
-        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, LAYOUT_BAND if s.layout == LAYOUT_BAND_PADDED else s.layout, s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
+        narrower = {LAYOUT_BAND_PADDED: LAYOUT_BAND, LAYOUT_BAND_COUNTS: LAYOUT_BAND_COUNTS_VIEW}
+        view = StagedBlock(block.name, CsMatrix(s.d_ptr, s.dtype, narrower.get(s.layout, s.layout), s.ld, 0, in_w, s.row0), block.shape, block.miss_row,
                            block.miss_col, max_dist, False, keep)
         if s.layout == LAYOUT_BAND_LAZY:                 # (a view shares the descriptor; read by itself it is staged for itself)
             ci = self.names.index(block.name)
             view.restage = lambda: self._restage_synced(ci, max_dist, largest_kernel)
         if block.sig32 is not None:
             t = block.sig32
-            view.sig32 = CsMatrix(t.d_ptr, t.dtype, LAYOUT_BAND, t.ld, 0, in_w, t.row0)
+            view.sig32 = CsMatrix(t.d_ptr, t.dtype, LAYOUT_BAND_COUNTS_VIEW if t.layout in (LAYOUT_BAND_COUNTS, LAYOUT_BAND_COUNTS_VIEW) else LAYOUT_BAND,
+                                  t.ld, 0, in_w, t.row0)
         view.parent = block                          # keeps the buffers alive; the view owns none
         return view
 

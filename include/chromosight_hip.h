@@ -61,7 +61,20 @@ enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1, CS_LAYOUT_BAND_LAZY = 2 /* see c
         * The masked tile kernel then fetches the tiles on the rim of the band like the inner ones: a 16-byte piece that reaches
         * beyond a row's stored diagonals reads zeros where a plain band makes it clamp, shift and mask (10 % of the kernel on a
         * 234-diagonal band).  Every other consumer reads it as CS_LAYOUT_BAND. */
-       CS_LAYOUT_BAND_PADDED = 3 };
+       CS_LAYOUT_BAND_PADDED = 3,
+       /* A float32 band of RAW COUNTS, zero-padded like CS_LAYOUT_BAND_PADDED, with a header in the CS_COUNTS_HEADER_BYTES in front
+        * of d_ptr (weights, distance law and its reciprocals, first genome bin, cap): what cs_stage_blocks writes for a block with
+        * band32_counts = 1 -- in the SAME pass over the pixel table that reduces the distance law.  Balancing
+        * (contacts_map.py:531-540) and the detrend (preprocessing.py:296-302) are applied by the reader to the pixels it
+        * fetches, with the operations of the staging pass in their order (bit for bit the detrended band): the masked float32
+        * tile kernel behind cs_normxcorr2 / cs_detect_foci* while it splits a landed tile, the float64 kernels through the
+        * block's CS_LAYOUT_BAND_LAZY descriptor.  band_lo 0, row0 0, CS_F32.  Every other consumer refuses the layout
+        * (CS_ERR_INVALID / CS_ERR_UNSUPPORTED). */
+       CS_LAYOUT_BAND_COUNTS = 4,
+       /* the first band_w diagonals of a wider band of counts (same d_ptr, ld and header): no promise about the slots behind them */
+       CS_LAYOUT_BAND_COUNTS_VIEW = 5 };
+#define CS_COUNTS_HEADER_BYTES 128
+#define CS_COUNTS_LAW_BYTES(n, n_diags) (8ll * (2 * (int64_t)(n_diags) + 2) + 4ll * (((int64_t)(n_diags) + 3) / 2 * 2) + 4ll * (int64_t)(n))
 enum { CS_MASK_NONE = 0, CS_MASK_BINS = 1, CS_MASK_EXPLICIT = 2 };
 
 /* ---- context ----------------------------------------------------------------------- */
@@ -301,7 +314,15 @@ typedef struct {
      * d_band64 must outlive it.  Every other entry refuses the layout (CS_ERR_INVALID). */
     int64_t ld64;
     int32_t f64_diags;
-    int32_t reserved;
+    /* 1: d_band32 receives the block's RAW COUNTS (CS_LAYOUT_BAND_COUNTS above) instead of detrended values, written by the pass
+     * that reduces the distance law; the detrend / tiler pass then has nothing to do for this block (none of the blocks: it is not
+     * launched).  The caller vouches that every stored count is exact in float32 (integers below 2^24: what a .cool holds) and
+     * that no count and no weight is negative (NaN weights: undetectable bins, as everywhere).  Needs: layout CS_LAYOUT_BAND, ld a multiple of 4 and >= band_w + 4, d_band32 16-byte aligned with
+     * CS_COUNTS_HEADER_BYTES writable bytes in front of it, d_band64 NULL, f64_diags 0, and d_law of CS_COUNTS_LAW_BYTES(n, n_diags)
+     * bytes (the law, then its reciprocals with one slot on either side, then float32 copies of the reciprocals and of the
+     * block's weights).  d_lazy (optional) then receives a descriptor that evaluates EVERY pixel of the float64 band from the
+     * counts: nothing is searched in the pixel table. */
+    int32_t band32_counts;
     void* d_lazy;
 } cs_stage_block;
 #define CS_LAZY_BAND_BYTES 128

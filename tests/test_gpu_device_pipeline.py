@@ -615,7 +615,8 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     # device instead of the blocks' own segments.  (Every switch three times: the second and third repetition run on a context that has
     # seen the layout -- the deferred chain's launches sized from the previous call.)
     for switch in ("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
-                   "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_SEGMENTED"):
+                   "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_SEGMENTED",
+                   "CHROMOSIGHT_HIP_COUNTS_BAND"):         # (... bands of raw counts, detrended by their readers, instead of the tiler pass)
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):

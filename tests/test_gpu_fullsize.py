@@ -134,36 +134,54 @@ def test_c2_alternative_kernels(env, monkeypatch):
 
 def test_c3_from_csr_50000_full_map():
     """C3 as BASELINE.md defines it and as bench.py's `c3_from_csr` leg times it: the N = 50 000 pixel table (CSR) in,
-    DeviceCool.stage_blocks (distance law, detrend, CSR -> float32 band on the device) and the masked tile kernel on the
-    staged band -- every pixel of the 11.7 M-pixel map against the C oracle run on the band the detrend ORACLE prepared
-    from the same pixel table (oracle/detrend_oracle.py), and the staged band itself against that band."""
+    DeviceCool.stage_blocks on the device and the masked tile kernel on the staged band -- every pixel of the 11.7 M-pixel map
+    against the C oracle run on the band the detrend ORACLE prepared from the same pixel table (oracle/detrend_oracle.py).
+    Both stagings: the band of raw counts written by the law pass and detrended by the tile kernel as it splits a landed tile
+    (CS_LAYOUT_BAND_COUNTS: what bench.py times) -- the band itself against the pixel table's counts -- and the detrended band of
+    the tiler pass -- against the oracle's band; both maps against the oracle."""
     from chromosight_amd import pipeline
+    from chromosight_amd._lib import LAYOUT_BAND_COUNTS, LAYOUT_BAND_PADDED
     from oracle import detrend_oracle
     from tools.synthetic_genome import make_cool
     n, max_dist = 50_000, 233
     cool, _ = make_cool(n, max_dist, 2000, seed=1, loops_per_10k=0, chrom_sizes=[n])        # bench.py Workload("c3"), rank 0
     dev = get_device()
     dcool = pipeline.DeviceCool(cool, dev)
-    block = dcool.stage_blocks([0], max_dist, 17, band_dtype=np.float32)[0]
+    assert dcool.counts_ok
     out_w = max_dist + 1
     ld_out = (out_w + 63) // 64 * 64
-    d_out = dev.zeros((n, ld_out), np.float32)
-    engine.run_normxcorr2(dev, block.sig, (n, n), engine.KernelSpec(loops()),
-                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_out, 0, out_w), precision="f32",
-                          miss_row=block.miss_row, miss_col=block.miss_col, full=True, sym_upper=True, max_dist=max_dist,
-                          mask_mode=MASK_BINS, missing_tol=0.5)
-    assert last_kernel() == KERNEL_MFMA_REG
-    got = d_out.download()[:, :out_w]
     band, det = detrend_oracle.balanced_band(cool, 0, max_dist + 17)
     prepared, _ = detrend_oracle.prepare_band(band, det)
-    # the staged float32 band: the oracle's band rounded once
-    sig = block.sig
-    from chromosight_amd._lib import LAYOUT_BAND_PADDED
-    assert sig.layout == LAYOUT_BAND_PADDED and sig.band_lo == 0 and sig.band_w == max_dist + 18      # (zero-padded rows: the staging pass's own)
-    staged = np.empty((n, sig.ld), dtype=np.float32)
-    dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, staged.ctypes.data, sig.d_ptr, staged.nbytes, None))
-    assert np.abs(staged[:, :sig.band_w] - prepared).max() <= 1e-6 * max(1.0, np.abs(prepared).max())
+    maps = {}
+    for counts in (True, False):
+        block = dcool.stage_blocks([0], max_dist, 17, band_dtype=np.float32, counts=counts)[0]
+        d_out = dev.zeros((n, ld_out), np.float32)
+        engine.run_normxcorr2(dev, block.sig, (n, n), engine.KernelSpec(loops()),
+                              CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_out, 0, out_w), precision="f32",
+                              miss_row=block.miss_row, miss_col=block.miss_col, full=True, sym_upper=True, max_dist=max_dist,
+                              mask_mode=MASK_BINS, missing_tol=0.5)
+        assert last_kernel() == KERNEL_MFMA_REG
+        maps[counts] = d_out.download()[:, :out_w]
+        sig = block.sig
+        assert sig.layout == (LAYOUT_BAND_COUNTS if counts else LAYOUT_BAND_PADDED) and sig.band_lo == 0 and sig.band_w == max_dist + 18
+        staged = np.empty((n, sig.ld), dtype=np.float32)
+        dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, staged.ctypes.data, sig.d_ptr, staged.nbytes, None))
+        assert not staged[:, sig.band_w:].any()                      # zero-padded rows: the staging pass's own
+        if counts:
+            # the raw counts of the pixel table, slot = diagonal
+            want_counts = np.zeros((n, sig.band_w), dtype=np.float32)
+            b1, b2, c = np.asarray(cool["bin1_id"]), np.asarray(cool["bin2_id"]), np.asarray(cool["count"])
+            keep = (b2 - b1) < sig.band_w
+            want_counts[b1[keep], (b2 - b1)[keep]] = c[keep]
+            assert np.array_equal(staged[:, :sig.band_w], want_counts)
+        else:
+            # the staged float32 band: the oracle's band rounded once
+            assert np.abs(staged[:, :sig.band_w] - prepared).max() <= 1e-6 * max(1.0, np.abs(prepared).max())
+        del block, d_out, staged
     miss = (~det).astype(np.uint8)
     want, cond = c_oracle.normxcorr2_band(prepared, n, 0, prepared.shape[1], loops(), 0, n, 0, out_w, max_dist=max_dist,
                                           miss_row=miss, miss_col=miss, missing_tol=0.5)
-    check(got, want, cond, "C3 from CSR 50000 x 234")
+    check(maps[True], want, cond, "C3 from CSR 50000 x 234, band of counts")
+    check(maps[False], want, cond, "C3 from CSR 50000 x 234, detrended band")
+    # (the tile kernel detrends a landed tile in float32: a few units in the last place of the float32 band per pixel)
+    assert np.abs(maps[True] - maps[False]).max() < 2e-4 and np.quantile(np.abs(maps[True] - maps[False]), 0.999) < 2e-6

@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -206,6 +207,61 @@ def time_steps(dev, step, sync, steps, warmup, dist=None, local_rank=0):
         dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
     return elapsed, dev.elapsed_ms(ev0, ev1) / steps
+
+
+def gpu_state(step, sync, seconds=0.25):
+    """What the box-to-box spread of the headline step correlates with: the shader clock of every GPU of the node (sysfs
+    hwmon freq1_input) sampled idle and then during `seconds` of back-to-back steps, AFTER the timed region.  The GPU whose
+    clock rises is this process's; the others that sit near their top clock are other tenants' work on the same node
+    (shared power and cooling).  None where sysfs does not show the clocks."""
+    import threading
+    files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+    if not files:
+        return None
+
+    def read_all():
+        out = []
+        for f in files:
+            try:
+                out.append(int(open(f).read()) // 1000000)
+            except (OSError, ValueError):
+                out.append(-1)
+        return out
+
+    try:
+        sync()
+        time.sleep(0.05)
+        idle = read_all()
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                samples.append(read_all())
+                time.sleep(0.01)
+
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(16):
+                step()
+            sync()
+            n += 16
+        dt = time.perf_counter() - t0
+        stop.set()
+        th.join(1.0)
+        if not samples:
+            return None
+        busy = [sorted(s[k] for s in samples)[len(samples) // 2] for k in range(len(files))]
+        mine = max(range(len(files)), key=lambda k: busy[k] - idle[k])
+        return {"sclk_mhz_under_load": busy[mine], "sclk_mhz_min_under_load": min(s[mine] for s in samples), "sclk_mhz_idle": idle[mine],
+                "gpus_on_node": len(files), "other_gpus_busy": sum(1 for k in range(len(files)) if k != mine and idle[k] > 1000),
+                "ms_per_step_during_probe": round(dt / n * 1e3, 4),
+                "note": "sampled after the timed region during %.2f s of back-to-back steps (host-paced: every 16 steps "
+                        "synchronised); other_gpus_busy = GPUs of the node that other tenants keep above 1 GHz" % seconds}
+    except Exception as e:                                   # (never part of a measurement)
+        return {"error": repr(e)}
 
 
 def roofline_of(wl, kernel_ms, kernel_id, precision, traffic=None, traffic_note=None):
@@ -785,6 +841,8 @@ def main():
             "roofline_hbm": dict(roof["hbm"], bound="hbm"),
             "kernel_ms": round(kernel_ms, 4),
         }
+        if world == 1:
+            head["gpu_state"] = gpu_state(wl.step, full_sync)
     extras = {}
 
     def bail_out(why=None):

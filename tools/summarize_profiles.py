@@ -92,8 +92,10 @@ avg_ns = {}
 if stats:
     for r in csv.DictReader(open(stats)):
         avg_ns[r["Name"]] = float(r["AverageNs"])
+# (corr_mfma_dense_kernel: the tile kernel of the SAME profiled C3 step -- on a band of raw counts since round 5 -- so that the
+# step's bytes come from one run instead of borrowing the c3k record)
 for kname in ("stage_law_kernel", "stage_tile_kernel", "stage_finish_kernel", "distance_law_kernel", "csr_to_band_rows_kernel",
-              "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel"):
+              "csr_band_extent_kernel", "law_finish_kernel", "mask_prep_kernel", "corr_mfma_dense_kernel"):
     rec = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         rec.update(per_dispatch(find(f"pmc_c3_{c}/**/*counter_collection.csv"), kname))

@@ -211,7 +211,18 @@ def time_steps(dev, step, sync, steps, warmup, dist=None, local_rank=0):
     return elapsed, dev.elapsed_ms(ev0, ev1) / steps
 
 
-def gpu_state(step, sync, seconds=0.25):
+def gpu_clocks():
+    """Shader clocks (MHz) of the node's GPUs from sysfs, in file order; [] where sysfs does not show them."""
+    out = []
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+        try:
+            out.append(int(open(f).read()) // 1000000)
+        except (OSError, ValueError):
+            out.append(-1)
+    return out
+
+
+def gpu_state(step, sync, idle0=None, seconds=0.25):
     """What the box-to-box spread of the headline step correlates with: the shader clock of every GPU of the node (sysfs
     hwmon freq1_input) sampled idle and then during `seconds` of back-to-back steps, AFTER the timed region.  The GPU whose
     clock rises is this process's; the others that sit near their top clock are other tenants' work on the same node
@@ -232,8 +243,8 @@ def gpu_state(step, sync, seconds=0.25):
 
     try:
         sync()
-        time.sleep(0.05)
-        idle = read_all()
+        # (idle0: the clocks when the process started, before it touched its GPU -- a GPU that was busy then is another tenant's)
+        idle = idle0 if idle0 and len(idle0) == len(files) else read_all()
         samples, stop = [], threading.Event()
 
         def sampler():
@@ -261,7 +272,8 @@ def gpu_state(step, sync, seconds=0.25):
                 "gpus_on_node": len(files), "other_gpus_busy": sum(1 for k in range(len(files)) if k != mine and idle[k] > 1000),
                 "ms_per_step_during_probe": round(dt / n * 1e3, 4),
                 "note": "sampled after the timed region during %.2f s of back-to-back steps (host-paced: every 16 steps "
-                        "synchronised); other_gpus_busy = GPUs of the node that other tenants keep above 1 GHz" % seconds}
+                        "synchronised); idle = when this process started; other_gpus_busy = GPUs of the node that were above "
+                        "1 GHz then (other tenants: the node's power and cooling are shared)" % seconds}
     except Exception as e:                                   # (never part of a measurement)
         return {"error": repr(e)}
 
@@ -770,6 +782,9 @@ def spawn_ranks(n_gpus):
 EXTRAS_TIMEOUT_S = 240
 
 
+CLOCKS_AT_START = gpu_clocks()          # (module import: before this process has touched a GPU)
+
+
 def main():
     args = parse()
     if args.plan:
@@ -851,7 +866,7 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
         }
         if world == 1:
-            head["gpu_state"] = gpu_state(wl.step, full_sync)
+            head["gpu_state"] = gpu_state(wl.step, full_sync, CLOCKS_AT_START)
     extras = {}
 
     def bail_out(why=None):

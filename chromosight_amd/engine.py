@@ -473,21 +473,28 @@ def run_quantify_blocks(dev, blocks, kspec, blk, rows, cols, *, missing_tol=0.75
 def run_compact(dev, corr, shape, threshold, lo_diag, hi_diag, stream=None, guess=1 << 16):
     """(rows, cols, vals) of the stored pixels of `corr` with value >= threshold inside the
     diagonal range; sorted row-major."""
+    # The device arrays are kept with the device between calls (three allocations per call cost more than the compaction of a
+    # rank's share of a split block), and only the `count` entries that exist cross the link (the whole capacity did: 1 MB for a
+    # hundred candidates).  A context serves one call in flight (the callers hold Device.lock or own the device).
     cap = int(guess)
     while True:
-        d_rows, d_cols = dev.empty(cap, np.int32), dev.empty(cap, np.int32)
-        d_vals = dev.empty(cap, np.float64)
-        d_count = dev.zeros(1, np.int64, stream)
+        have = getattr(dev, "_compact_scratch", None)
+        if have is None or have[0] < cap:
+            have = dev._compact_scratch = (cap, dev.empty(cap, np.int32), dev.empty(cap, np.int32), dev.empty(cap, np.float64),
+                                           dev.empty(1, np.int64))
+        _, d_rows, d_cols, d_vals, d_count = have
+        d_count.zero(stream)
         dev._check(dev.lib.cs_compact_ge(dev.ctx, stream, C.byref(corr), int(shape[0]), int(shape[1]),
                                          float(threshold), int(lo_diag), int(hi_diag), d_rows.ptr, d_cols.ptr,
-                                         d_vals.ptr, cap, d_count.ptr))
+                                         d_vals.ptr, have[0], d_count.ptr))
         count = int(d_count.download(stream)[0])
-        if count <= cap:
+        if count <= have[0]:
             break
         cap = count
-    rows = d_rows.download(stream)[:count]
-    cols = d_cols.download(stream)[:count]
-    vals = d_vals.download(stream)[:count]
+    rows, cols, vals = np.empty(count, np.int32), np.empty(count, np.int32), np.empty(count, np.float64)
+    if count:
+        for host, buf in ((rows, d_rows), (cols, d_cols), (vals, d_vals)):
+            dev._check(dev.lib.cs_memcpy_d2h(dev.ctx, host.ctypes.data, buf.ptr, host.nbytes, stream))
     order = np.lexsort((cols, rows))
     return rows[order], cols[order], vals[order]
 

@@ -68,3 +68,28 @@ def test_struct_sizes_against_the_header_compiled_as_c(tmp_path):
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     for (name, struct), size in zip(pairs, sizes):
         assert ctypes.sizeof(struct) == size, name
+
+
+def test_counts_band_constants_of_the_header(tmp_path):
+    """CS_LAYOUT_BAND_COUNTS (include/chromosight_hip.h): the layout codes and header bytes the binding uses, and
+    CS_COUNTS_LAW_BYTES -- what pipeline.DeviceCool._stage_fast allocates behind d_law for a block of raw counts (the law, its
+    reciprocals with a slot on either side, float32 copies of the reciprocals and of the block's weights) -- against the C macro."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    cases = [(50_000, 251), (7, 3), (1000, 1000), (33, 18), (200_000, 1018), (1, 1)]
+    header = ROOT / "include" / "chromosight_hip.h"
+    src = tmp_path / "counts.c"
+    body = '    printf("%d %d %d\\n", (int)CS_LAYOUT_BAND_COUNTS, (int)CS_LAYOUT_BAND_COUNTS_VIEW, (int)CS_COUNTS_HEADER_BYTES);\n'
+    body += "".join(f'    printf("%lld\\n", (long long)CS_COUNTS_LAW_BYTES({n}, {nd}));\n' for n, nd in cases)
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void) {\n%s    return 0;\n}\n' % (header, body))
+    exe = tmp_path / "counts"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert [int(x) for x in out[0].split()] == [_lib.LAYOUT_BAND_COUNTS, _lib.LAYOUT_BAND_COUNTS_VIEW, _lib.COUNTS_HEADER_BYTES]
+    for (n, nd), line in zip(cases, out[1:]):
+        need = int(line)
+        have = 8 * (2 * nd + 2 + (nd + 3) // 2 + (n + 1) // 2)          # pipeline.py: law_len of a counts block, in float64
+        assert need <= have < need + 16, (n, nd)
+        assert need == 8 * (2 * nd + 2) + 4 * ((nd + 3) // 2 * 2) + 4 * n

@@ -148,7 +148,7 @@ class Workload:
             # (the band of raw counts, detrended by the tile kernel as it splits a landed tile; CS_BENCH_C3_DETRENDED=1: the
             # detrended band of the tiler pass, for A/B runs)
             block = self.dcool.stage_blocks([0], self.max_dist, 17, band_dtype=np.float32,
-                                            counts=not os.environ.get("CS_BENCH_C3_DETRENDED"))[0]
+                                            counts=not (os.environ.get("CS_BENCH_C3_DETRENDED") or os.environ.get("CHROMOSIGHT_HIP_NO_COUNTS_BAND")))[0]
             self.engine.run_normxcorr2(self.dev, block.sig, self.shape, self.kspec, self.out, precision=self.precision,
                                        miss_row=block.miss_row, miss_col=block.miss_col, **self.kwargs)
             return

@@ -435,17 +435,17 @@ class DeviceCool:
         # pixels against)
         near = 64
         lazy = [bool(lazy64 and not only32 and g[6] and (lazy64 == "all" or g[5] > 2 * near)) for g in geo]
-        # counts (map-level callers ask for it; CHROMOSIGHT_HIP_COUNTS_BAND=1: wherever the float64 band is lazily evaluated): the
-        # float32 band of a banded block holds the RAW COUNTS, written by the pass that reduces the distance law -- no detrend /
-        # tiler pass over the pixel table, no float64 near band; the tile kernel detrends the tiles it fetches (float32) and the
-        # float64 kernels every pixel they read (the staging pass's own expression; include/chromosight_hip.h
-        # CS_LAYOUT_BAND_COUNTS).  Needs counts that are exact in float32 and not negative (what a .cool holds).
-        # Measured (profiles/r05_counts_band.txt): the C3 step 0.222 -> 0.21 ms and a quarter less HBM traffic; the genome step
-        # of a detect run gains nothing (its tile kernels pay 4 % for the conversion, its float64 kernels convert every pixel
-        # they read, and the tiler pass they replace was half hidden) -- so detection keeps the detrended bands by default.
+        # counts (default wherever the float64 band is lazily evaluated -- the detection path --; float32-only, map-level callers
+        # ask for it): the float32 band of a banded block holds the RAW COUNTS, written by the pass that reduces the distance
+        # law -- no detrend / tiler pass over the pixel table, no float64 near band; the tile kernel detrends the tiles it
+        # fetches (float32) and the float64 kernels every pixel they read (the staging pass's own expression;
+        # include/chromosight_hip.h CS_LAYOUT_BAND_COUNTS).  Needs counts that are exact in float32 and not negative (what a
+        # .cool holds).  Measured (profiles/r05_counts_band.txt): the C3 step 0.222 -> 0.212 ms and a quarter less HBM
+        # traffic; a rank's share of 8 of the C4 genome 0.520 -> 0.507 ms (rank 5) / 0.470 -> 0.445 (rank 0), the whole genome
+        # 2.82 -> 2.81 ms.  CHROMOSIGHT_HIP_NO_COUNTS_BAND=1: the detrended bands of the tiler pass.
         if counts is None:
-            counts = bool(lazy64) and lazy64 != "all" and bool(os.environ.get("CHROMOSIGHT_HIP_COUNTS_BAND"))
-        counts = bool(counts and self.counts_ok)
+            counts = bool(lazy64) and lazy64 != "all"
+        counts = bool(counts and self.counts_ok and not os.environ.get("CHROMOSIGHT_HIP_NO_COUNTS_BAND"))
         cnt = [bool(counts and g[6] and (only32 or lazy[k])) for k, g in enumerate(geo)]
         for k, g in enumerate(geo):
             if cnt[k]:

@@ -616,7 +616,7 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     # seen the layout -- the deferred chain's launches sized from the previous call.)
     for switch in ("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
                    "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_SEGMENTED",
-                   "CHROMOSIGHT_HIP_COUNTS_BAND"):         # (... bands of raw counts, detrended by their readers, instead of the tiler pass)
+                   "CHROMOSIGHT_HIP_NO_COUNTS_BAND"):      # (... the detrended bands of the tiler pass instead of the bands of raw counts)
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):

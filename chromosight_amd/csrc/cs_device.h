@@ -104,17 +104,20 @@ __device__ __forceinline__ double stage_detrend_rcp(double v, double inv_y, doub
 
 // the staged value of slot (p, d) of a band of counts: what the detrended band held there (0 for an empty slot: a stored count
 // of 0 is 0 / law = 0, or NaN -> 0 on an empty diagonal)
+// (`law`: the block's d_law buffer as cs_stage_blocks lays it out for a band of counts -- n_diags values of the law, then their
+// reciprocals with one slot on either side: the reciprocal the staging's finish pass took is READ, not taken again per pixel
+// -- the same IEEE quotient, and a float64 division is ~ 30 instructions)
 __device__ __forceinline__ double counts_value(float c, const double* __restrict__ weight, const double* __restrict__ law, long long row0,
-                                               int p, int d, double max_val)
+                                               int p, int d, double max_val, int n_diags)
 {
     if (c == 0.0f) return 0.0;
-    return stage_detrend_rcp(((double)c * weight[row0 + p]) * weight[row0 + p + d], 1.0 / law[d], max_val, law + d);
+    return stage_detrend_rcp(((double)c * weight[row0 + p]) * weight[row0 + p + d], law[n_diags + 1 + d], max_val, law + d);
 }
 
 // slot (p, d), d < near_w, of the diagonals a lazily evaluated band keeps in memory
 __device__ __forceinline__ double lazy_near_value(const LazyBand& L, int p, int d)
 {
-    if (L.counts) return counts_value(L.counts[(long long)p * L.counts_ld + d], L.weight, L.law, L.row0, p, d, L.max_val);
+    if (L.counts) return counts_value(L.counts[(long long)p * L.counts_ld + d], L.weight, L.law, L.row0, p, d, L.max_val, L.n_diags);
     return L.near_[(long long)p * L.near_ld + d];
 }
 

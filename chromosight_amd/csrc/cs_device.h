@@ -114,6 +114,17 @@ __device__ __forceinline__ double counts_value(float c, const double* __restrict
     return stage_detrend_rcp(((double)c * weight[row0 + p]) * weight[row0 + p + d], law[n_diags + 1 + d], max_val, law + d);
 }
 
+// the same value with every load issued at once (the count, both weights, the reciprocal): the wave-per-window and tile-staging
+// kernels wait for round trips, not for bytes, and the early exit above makes the weights' loads wait for the count's.  A count
+// of 0 gives 0 (or NaN -> 0) through the arithmetic itself.
+__device__ __forceinline__ double counts_value_flat(const float* __restrict__ cnt_at, const double* __restrict__ weight,
+                                                    const double* __restrict__ law, long long row0, int p, int d, double max_val, int n_diags)
+{
+    const float c = *cnt_at;
+    const double wr = weight[row0 + p], wc = weight[row0 + p + d], rl = law[n_diags + 1 + d];
+    return stage_detrend_rcp(((double)c * wr) * wc, rl, max_val, law + d);
+}
+
 // slot (p, d), d < near_w, of the diagonals a lazily evaluated band keeps in memory
 __device__ __forceinline__ double lazy_near_value(const LazyBand& L, int p, int d)
 {

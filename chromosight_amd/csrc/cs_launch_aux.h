@@ -240,7 +240,7 @@ struct SigReader {
         if (layout == 2) {
             if ((d - band_lo < 0) | (d - band_lo >= band_w) | (d < 0) | (d >= n_diags)) return 0.0;
             if (d < near_w) {
-                if (cnt) return counts_value(cnt[(long long)p * ld + d], (const double*)cnt_weight, (const double*)cnt_law, cnt_row0, p, d, cnt_max, n_diags);
+                if (cnt) return counts_value_flat((const float*)cnt + ((long long)p * ld + d), (const double*)cnt_weight, (const double*)cnt_law, cnt_row0, p, d, cnt_max, n_diags);
                 return p64[(long long)p * ld + d];
             }
             return lazy_load(*view, p, q);
@@ -319,7 +319,7 @@ __device__ __forceinline__ void lazy_gather_window_sq(const CorrArgs<double>& A,
                 const int ki = e / K, kj = e - ki * K;
                 const int p = p0 + ki, q = q0 + kj, d = q - p;
                 if ((p >= 0) & (p < ms) & (q >= 0) & (q < ns) & (d >= d_lo) & (d < near_end)) {
-                    if (counts) v = counts_value(counts[(long long)p * near_ld + d], (const double*)weight, (const double*)law, row0, p, d, max_val, n_diags);
+                    if (counts) v = counts_value_flat((const float*)counts + ((long long)p * near_ld + d), (const double*)weight, (const double*)law, row0, p, d, max_val, n_diags);
                     else v = near_[(long long)p * near_ld + d];
                 }
             }

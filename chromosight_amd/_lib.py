@@ -123,6 +123,7 @@ class CsFocus(C.Structure):
         ("focus_size", C.c_int32),
         ("score", C.c_double),
         ("n_obs", C.c_double),
+        ("pval", C.c_double),
     ]
 
 
@@ -150,7 +151,7 @@ _CAPTURED = ("cs_stage_blocks", "cs_event_record", "cs_stream_wait_event", "cs_d
 
 # numpy view of an array of cs_focus records
 FOCUS_DTYPE = np.dtype([("bin1", "<i4"), ("bin2", "<i4"), ("inside", "<i4"), ("n_zero", "<i4"), ("n_missing", "<i4"),
-                        ("focus_size", "<i4"), ("score", "<f8"), ("n_obs", "<f8")])
+                        ("focus_size", "<i4"), ("score", "<f8"), ("n_obs", "<f8"), ("pval", "<f8")])
 
 
 # name -> (restype, argtypes); every symbol include/chromosight_hip.h declares

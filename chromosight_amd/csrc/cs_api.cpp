@@ -1838,9 +1838,10 @@ static double two_sided_tail(double a)
 
 int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_counts, const int32_t* h_rows,
                       const int32_t* h_cols, const int32_t* h_max_dist, int32_t inter, int32_t km, int32_t kn,
-                      double missing_tol, double zero_tol, int32_t full, int32_t compact, double* h_table, uint8_t* h_ok,
+                      double missing_tol, double zero_tol, int32_t full, int32_t flags, double* h_table, uint8_t* h_ok,
                       int64_t* h_kept)
 {
+    const bool compact = (flags & 1) != 0, have_p = (flags & 2) != 0;
     if (n_blocks < 0 || km < 1 || kn < 1 || (n_blocks > 0 && (!h_counts || !h_rows || !h_cols || !h_kept))) return CS_ERR_INVALID;
     const double tot = (double)km * (double)kn;
     int64_t n = 0;
@@ -1871,7 +1872,9 @@ int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_
                 double n_obs = full ? f.n_obs : tot;
                 if (n_obs == 0) n_obs = tot;
                 double pval = 1.0;                                // 10 ** 0 where the coefficient is exactly 0
-                if (f.score != 0) {
+                if (have_p) {
+                    pval = f.pval;                                // formed by the kernel that wrote the record (cs_foci.hip focus_pval)
+                } else if (f.score != 0) {
                     const double zz = std::atanh(f.score) * std::sqrt(n_obs - 3.0);
                     // (the reference forms 10 ** log10(p): p again within two units in the last place -- the round trip through
                     // log10 and pow was 40 % of a record's arithmetic, and the p-values are pinned to 1e-12)
@@ -1887,17 +1890,20 @@ int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_
     };
     // tasks: a block's records, long blocks in pieces of 512 (waking a sleeping worker costs the caller ~ 4 us: 16 threads at most --
     // with 64 the 56 000 records of a genome's 1-D pattern took 266 us, with 32 and pieces of 1024 180 us); the pool's workers and this thread take them from a counter
+    // (records that carry their p-values cost a few nanoseconds each: pieces of 4096, so that a share's few thousand stay on the
+    // calling thread)
+    const int64_t piece_n = have_p ? 4096 : 512;
     struct Piece { int64_t b, at, n; };
     std::vector<Piece> pieces;
     {
         int64_t at = 0;
         for (int64_t b = 0; b < n_blocks; ++b) {
-            for (int64_t o = 0; o < h_counts[b]; o += 512) pieces.push_back({b, at + o, std::min<int64_t>(512, h_counts[b] - o)});
+            for (int64_t o = 0; o < h_counts[b]; o += piece_n) pieces.push_back({b, at + o, std::min<int64_t>(piece_n, h_counts[b] - o)});
             at += h_counts[b];
         }
     }
     static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
-    const int max_threads = (int)std::min<int64_t>(std::min(16, std::max(1, cores / 2)), n / 512);
+    const int max_threads = (int)std::min<int64_t>(std::min(16, std::max(1, cores / 2)), n / piece_n);
     HostPool::get().run((int)pieces.size(), max_threads, [&](int t) {
         const Piece& pc = pieces[(size_t)t];
         rows_piece(pc.b, pc.at, pc.n);

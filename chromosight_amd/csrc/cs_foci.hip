@@ -1003,6 +1003,25 @@ __global__ __launch_bounds__(kSmallThreads) void gather_foci_batch_kernel(const 
 // maps, NaN on every row / column that is not a detectable bin; coordinates shifted by (kh, kw).
 // window statistics of one pattern by one wave (validate_patterns, detection.py:18-155); rec_out / win_out
 // may be nullptr (beyond the caller's capacity) or page-locked host memory
+// The p-value of a record (reference detection.py:332-336 on the untrimmed map, stats.py:43-81 corr_to_pval: Fisher z, two-sided
+// normal tail with the case split of scipy.special.ndtr) -- the arithmetic of cs_accept_records (cs_api.cpp two_sided_tail), on
+// the lane that writes the record: three transcendental functions per record were most of what the host spent on a record.
+__device__ __forceinline__ double focus_pval(double score, double nobs, bool full, double tot)
+{
+    double n_obs = full ? nobs : tot;
+    if (n_obs == 0) n_obs = tot;
+    if (score == 0) return 1.0;                                   // 10 ** 0 where the coefficient is exactly 0
+    const double a = fabs(atanh(score) * sqrt(n_obs - 3.0));
+    const double x = -a * 0.70710678118654752440, z = fabs(x);
+    double y;
+    if (z < 0.70710678118654752440) y = 0.5 + 0.5 * erf(x);
+    else {
+        y = 0.5 * erfc(z);
+        if (x > 0) y = 1.0 - y;
+    }
+    return 2.0 * y;
+}
+
 __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, int inter, int row, int col, int fsize, double score,
                                                      double nobs, FocusRec* rec_out, double* win_out, int lane,
                                                      double* lazy_win = nullptr, bool fast_windows = false,
@@ -1068,6 +1087,7 @@ __device__ __forceinline__ void window_stats_pattern(const CorrArgs<double>& A, 
         r.focus_size = fsize;
         r.score = score;
         r.n_obs = nobs;
+        r.pval = focus_pval(score, nobs, A.full != 0, (double)kk);
         if (rec_out) *rec_out = r;
     }
 }

@@ -32,7 +32,7 @@ __device__ __forceinline__ double csr_value(const CsrView& M, const TV* __restri
 // one record of cs_detect_foci / cs_quantify_pixels (layout of cs_focus in the C ABI)
 struct FocusRec {
     int bin1, bin2, inside, n_zero, n_missing, focus_size;
-    double score, n_obs;
+    double score, n_obs, pval;
 };
 
 #ifdef __HIPCC__

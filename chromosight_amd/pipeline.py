@@ -903,7 +903,7 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
         return done([(None, None)] * len(blocks))
     rec = np.concatenate([r[0] for r in results])
     windows = np.concatenate([r[1] for r in results]) if want_windows else None
-    return done(cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config))
+    return done(cid.accept_many(blocks, rec, windows, counts, engine.KernelSpec(kernel, tsvd), kernel_config, pvals=True))
 
 
 def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=False, dev=None, stream=None, begin_only=False):

@@ -20,6 +20,11 @@ from ._lib import (CALL_ACCEPT_RECORDS, CALL_DETECT_FOCI_BATCH_FINISH, CALL_DETE
                    CALL_EVENT_RECORD, CALL_STAGE_BLOCKS, CALL_STREAM_WAIT_EVENT, CALL_STREAM_WAIT_TILES, FOCUS_DTYPE,
                    CsCall, raw_arg)
 
+def _device_pvalues():
+    from .utils.detection import device_pvalues
+    return device_pvalues()
+
+
 # argument slots of every entry: 'p' pointer, 'i' integer, 'd' double, in the order of the C prototype
 _SLOTS = {
     "cs_stage_blocks": (CALL_STAGE_BLOCKS, "ppppid"),
@@ -208,7 +213,8 @@ class StepPlan:
     def _accept(call, rec, counts, io, cfg, lane):
         km, kn = io["k"]
         values = (rec.ctypes.data, io["geo"].shape[1], counts, io["geo"][0].ctypes.data, io["geo"][1].ctypes.data,
-                  io["geo"][2].ctypes.data, 0, int(km), int(kn), cfg["max_perc_undetected"] / 100, cfg["max_perc_zero"] / 100, 1, 1,
+                  io["geo"][2].ctypes.data, 0, int(km), int(kn), cfg["max_perc_undetected"] / 100, cfg["max_perc_zero"] / 100, 1,
+                  3 if _device_pvalues() else 1,            # (flags: compact, records carry their p-values)
                   io["table"].ctypes.data, io["ok"].ctypes.data, io["kept"].ctypes.data)
         assert len(values) == 16
         _fill(call, CALL_ACCEPT_RECORDS, "pippppiiiddiippp", values, lane)

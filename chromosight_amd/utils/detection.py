@@ -10,6 +10,7 @@ or above the Pearson threshold, and all reported scores -- is re-evaluated in fl
 device (cs_rescore_f64), so candidate coordinates do not depend on float32 rounding.
 """
 import ctypes as C
+import os
 import pathlib
 import warnings
 
@@ -784,7 +785,7 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
             n_t = len(templates)
             cnt = np.ascontiguousarray(counts, dtype=np.int64)
             rec4, ok, kept = accept_native(rec, cnt, [b.shape for b in blocks] * n_t, [b.max_dist for b in blocks] * n_t, templates[0],
-                                           kernel_config, inter=False, full=True, compact=True)
+                                           kernel_config, inter=False, full=True, compact=True, pvals=True)
             win_ok = windows[ok] if windows is not None else None
             cut = np.concatenate([[0], np.cumsum(kept)])
             out = []
@@ -812,8 +813,8 @@ def detect_many_on_device(dev, blocks, kspec, kernel_config, *, want_windows=Tru
     if raw:
         rec, windows, counts = res
         if defer:           # the native call is done; the acceptance rules (numpy) when the caller asks for them
-            return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
-        return accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
+            return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged, pvals=True)
+        return accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged, pvals=True)
     out = []
     for b, (rec, windows) in zip(blocks, res):
         if rec.shape[0] == 0:
@@ -850,11 +851,11 @@ def detect_blocks_on_device(dev, blocks, kspec, kernel_config, *, want_windows=T
     if int(np.sum(counts)) == 0 and not merged:
         return (lambda: [(None, None)] * len(blocks)) if defer else [(None, None)] * len(blocks)
     if defer:
-        return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
-    return accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged)
+        return lambda: accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged, pvals=True)
+    return accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=merged, pvals=True)
 
 
-def accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=False):
+def accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=False, pvals=False):
     """The acceptance rules (detect mode, full maps) on the records of SEVERAL intra sub-matrices at once -- `rec` /
     `windows`: the records of `blocks` one block after the other, `counts` per block -- then cut at the block
     boundaries: the list of raw (table, windows) per block.  (23 numpy passes over a few hundred records each cost
@@ -862,7 +863,7 @@ def accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=False
     merged=True: no cutting -- (table of all blocks, accepted records per block, windows)."""
     counts = np.ascontiguousarray(counts, dtype=np.int64)
     rec4, ok, kept = accept_native(rec, counts, [b.shape for b in blocks], [b.max_dist for b in blocks], kspec, kernel_config,
-                                   inter=False, full=True, compact=True)
+                                   inter=False, full=True, compact=True, pvals=pvals)
     if windows is not None:
         windows = windows[ok]
     if merged:
@@ -873,9 +874,16 @@ def accept_many(blocks, rec, windows, counts, kspec, kernel_config, merged=False
     return [(None, None) if n == 0 else (t, w) for n, t, w in zip(counts, parts, wparts)]
 
 
-def accept_native(rec, counts, shapes, max_dists, kspec, kernel_config, *, inter, full, compact):
+def device_pvalues():
+    """False with CHROMOSIGHT_HIP_HOST_PVALUES=1: cs_accept_records computes the p-values of device records itself (the
+    cross-check of cs_focus.pval; tests/test_gpu_device_pipeline.py)."""
+    return not os.environ.get("CHROMOSIGHT_HIP_HOST_PVALUES")
+
+
+def accept_native(rec, counts, shapes, max_dists, kspec, kernel_config, *, inter, full, compact, pvals=False):
     """cs_accept_records on the records of len(counts) sub-matrices: (table (k, 4), accepted mask over the records,
-    accepted per sub-matrix); what _accept_records computes with numpy (and is tested against)."""
+    accepted per sub-matrix); what _accept_records computes with numpy (and is tested against).  pvals: the records come from
+    a device entry of the library and carry their p-values (cs_focus.pval)."""
     from .._lib import load_library
     rec = np.ascontiguousarray(rec)
     n = int(rec.shape[0])
@@ -890,7 +898,7 @@ def accept_native(rec, counts, shapes, max_dists, kspec, kernel_config, *, inter
     rc = load_library().cs_accept_records(
         rec.ctypes.data, nb, counts.ctypes.data, geo[0].ctypes.data, geo[1].ctypes.data, geo[2].ctypes.data, int(bool(inter)),
         int(kspec.km), int(kspec.kn), kernel_config["max_perc_undetected"] / 100, kernel_config["max_perc_zero"] / 100,
-        int(bool(full)), int(bool(compact)), table.ctypes.data, ok.ctypes.data, kept.ctypes.data)
+        int(bool(full)), int(bool(compact)) | (2 if pvals and device_pvalues() else 0), table.ctypes.data, ok.ctypes.data, kept.ctypes.data)
     if rc:
         raise ValueError(f"cs_accept_records: bad arguments ({rc})")
     kept = kept[:nb]

@@ -369,6 +369,10 @@ typedef struct {
     int32_t focus_size;     /* pixels of the focus (0 in quantify mode)                                   */
     double score;           /* float64 coefficient at (bin1, bin2), untrimmed map                         */
     double n_obs;           /* present pixels of that correlation window                                  */
+    double pval;            /* two-sided p-value of `score` under n_obs observations (Fisher z: reference
+                               detection.py:332-336 + stats.py:43-81), formed by the kernel that writes the
+                               record: cs_accept_records takes it as it is (flags bit 1) instead of spending
+                               an atanh, a square root and an erfc per record on the host                   */
 } cs_focus;
 
 /* One sub-matrix x one template, `detect` mode, entirely on the device: coefficient map (float32 or
@@ -535,12 +539,14 @@ int cs_remove_neighbours(const int64_t* h_bin1, const int64_t* h_bin2, const int
  * version cost more than the device work that produced them.  h_rec: the records of n_blocks sub-matrices one after
  * the other (h_counts[b] each; sub-matrix b has h_rows[b] x h_cols[b] bins and was scanned up to diagonal
  * h_max_dist[b], < 0 or NULL: no limit).  inter: no diagonal rules.  full = 0: every window has km * kn
- * observations.  h_table: 4 doubles (bin1, bin2, score, p-value) per record -- compact = 1 (detect mode): accepted
- * records only, packed; compact = 0 (quantify mode): every record, rejected ones with a NaN score.  h_ok: one byte per
- * input record; h_kept[b]: accepted records of sub-matrix b. */
+ * observations.  h_table: 4 doubles (bin1, bin2, score, p-value) per record -- flags bit 0 set (detect mode): accepted
+ * records only, packed; clear (quantify mode): every record, rejected ones with a NaN score.  flags bit 1: the records
+ * carry their p-values (cs_focus.pval: records written by this library's device entries do; records assembled by the
+ * caller need not) -- they are copied instead of computed.  h_ok: one byte per input record; h_kept[b]: accepted records
+ * of sub-matrix b. */
 int cs_accept_records(const cs_focus* h_rec, int64_t n_blocks, const int64_t* h_counts, const int32_t* h_rows,
                       const int32_t* h_cols, const int32_t* h_max_dist, int32_t inter, int32_t km, int32_t kn,
-                      double missing_tol, double zero_tol, int32_t full, int32_t compact, double* h_table, uint8_t* h_ok,
+                      double missing_tol, double zero_tol, int32_t full, int32_t flags, double* h_table, uint8_t* h_ok,
                       int64_t* h_kept);
 
 /* ---- pinned host memory (PCIe side of the boundary: page-locked buffers copy at link speed) ---- */

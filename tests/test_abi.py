@@ -46,7 +46,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.CsFociParams) == 48
     assert ctypes.sizeof(_lib.CsStageBlock) == 80
     assert ctypes.sizeof(_lib.CsCall) == 176
-    assert ctypes.sizeof(_lib.CsFocus) == 40 == _lib.FOCUS_DTYPE.itemsize
+    assert ctypes.sizeof(_lib.CsFocus) == 48 == _lib.FOCUS_DTYPE.itemsize
 
 
 def test_struct_sizes_against_the_header_compiled_as_c(tmp_path):

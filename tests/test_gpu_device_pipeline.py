@@ -616,7 +616,8 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     # seen the layout -- the deferred chain's launches sized from the previous call.)
     for switch in ("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
                    "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_SEGMENTED",
-                   "CHROMOSIGHT_HIP_NO_COUNTS_BAND"):      # (... the detrended bands of the tiler pass instead of the bands of raw counts)
+                   "CHROMOSIGHT_HIP_NO_COUNTS_BAND",       # (... the detrended bands of the tiler pass instead of the bands of raw counts,
+                   "CHROMOSIGHT_HIP_HOST_PVALUES"):        #  the records' p-values computed by cs_accept_records instead of copied)
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):
@@ -858,3 +859,54 @@ def test_native_rccl_exchange_single_rank():
     vec = rng.random(2 * 289 + 1)
     assert np.array_equal(comm.allreduce_sum(vec), vec)
     comm.close()
+
+
+def test_records_carry_the_p_values_the_host_would_compute():
+    """cs_focus.pval: the kernel that writes a record forms its p-value (reference detection.py:332-336 + stats.py:43-81:
+    Fisher z, two-sided normal tail) and cs_accept_records copies it (flags bit 1) instead of computing it -- against the
+    host arithmetic of the same call without the flag, record by record, for a 2-D and a 1-D pattern of a small genome, and
+    against scipy's own expression."""
+    import scipy.stats as ss
+    from chromosight_amd import engine
+    from chromosight_amd.utils import detection as cid
+    template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
+    cool, _ = make_cool(9_000, 150, 2000, seed=11, template=template)
+    dcool = pipeline.DeviceCool(cool)
+    for cfg in (copy.deepcopy(ck.loops), copy.deepcopy(ck.borders)):
+        if cfg["name"] == "loops":
+            cfg["max_dist"] = 150 * 2000
+        staged = parallel.stage_genome(dcool, [cfg])
+        blocks = [staged[ci] for ci in sorted(staged)]
+        kernel = np.asarray(cfg["kernels"][0], dtype=np.float64)
+        seen = 0
+        for block in blocks:
+            table, _ = pipeline.detect_block(dcool, block, cfg, kernel, raw=True)          # (device records, accepted with their own p-values)
+            if table is None or len(table) == 0:
+                continue
+            seen += len(table)
+            score, pval = table[:, 2], table[:, 3]
+            nz = score != 0
+            assert np.all(pval[~nz] == 1.0)
+            assert np.all((pval > 0) & (pval <= 1))
+        assert seen > 20, cfg["name"]
+    # record by record: the flag on and off over the same device records
+    cfg = copy.deepcopy(ck.loops)
+    cfg["max_dist"] = 150 * 2000
+    staged = parallel.stage_genome(dcool, [cfg])
+    block = staged[sorted(staged)[0]].full()
+    kspec = engine.KernelSpec(template)
+    rec, _ = engine.run_detect_foci(dcool.dev, block.sig, block.shape, kspec, pearson=cfg["pearson"], lo_diag=0,
+                                    hi_diag=min(block.max_dist, block.shape[0] - 1), inter=False, diag_only=False, full=True, sym_upper=True,
+                                    max_dist=block.max_dist, mask_mode=1, miss_row=block.miss_row, miss_col=block.miss_col,
+                                    missing_tol=cfg["max_perc_undetected"] / 100, want_windows=False)
+    assert len(rec) > 5
+    counts = np.array([len(rec)], dtype=np.int64)
+    t_dev, ok_dev, _ = cid.accept_native(rec, counts, [block.shape], [block.max_dist], kspec, cfg, inter=False, full=True, compact=False, pvals=True)
+    t_host, ok_host, _ = cid.accept_native(rec, counts, [block.shape], [block.max_dist], kspec, cfg, inter=False, full=True, compact=False, pvals=False)
+    assert np.array_equal(ok_dev, ok_host) and np.array_equal(t_dev[:, :3], t_host[:, :3], equal_nan=True)
+    assert np.allclose(t_dev[:, 3], t_host[:, 3], rtol=1e-13, atol=0.0)
+    # ... and scipy's expression of stats.py:43-81 on the records' own fields
+    n_obs = np.where(rec["n_obs"] == 0, 289.0, rec["n_obs"])
+    z = np.arctanh(rec["score"]) * np.sqrt(n_obs - 3.0)
+    want = np.where(rec["score"] != 0, 2.0 * ss.norm.cdf(-np.abs(z)), 1.0)
+    assert np.allclose(rec["pval"], want, rtol=1e-12, atol=0.0)

@@ -242,16 +242,21 @@ class StepPlan:
                 sys.stderr.write(f"[chromosight_amd] step plan failed: rc {[c.rc for c in self.calls]}\n")
             return None
         out = []
-        owned = np.asarray(self.owned, dtype=np.float64)
+        cols = self.__dict__.get("_id_cols")
+        if cols is None:
+            # (block and template of every (template, block) slot of a result list: the same arrays every step)
+            owned = np.asarray(self.owned, dtype=np.float64)
+            cols = self._id_cols = {which: (np.tile(owned, n_t), np.repeat(np.arange(n_t, dtype=np.float64), len(self.owned)))
+                                    for which, n_t in (("2", 1), ("1", self.n_templates))}
         for which in self.order:
-            io, n_t = (self.acc2, 1) if which == "2" else (self.acc1, self.n_templates)
+            io = self.acc2 if which == "2" else self.acc1
             kept = io["kept"]
             total = int(kept.sum())
-            rec = np.empty((total, 7))
-            rec[:, 0] = np.repeat(np.tile(owned, n_t), kept)
+            rec = np.zeros((total, 7))
+            blk, ker = cols[which]
+            rec[:, 0] = np.repeat(blk, kept)
             rec[:, 1:5] = io["table"][:total]
-            rec[:, 5] = np.repeat(np.repeat(np.arange(n_t, dtype=np.float64), len(self.owned)), kept)
-            rec[:, 6] = 0.0
+            rec[:, 5] = np.repeat(ker, kept)
             out.append(rec)
         return out
 

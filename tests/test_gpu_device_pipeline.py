@@ -835,8 +835,23 @@ def test_native_rccl_exchange_single_rank():
     (count + padded all-gather of records, all-reduce of a float64 vector) round-trip.  One rank is all a one-GPU box
     can run -- RCCL refuses two ranks on one device -- so this pins loading, staging and the call sequence; the gloo
     tests (tests/test_parallel.py) pin what detect_genome does with several ranks."""
+    import time
     from chromosight_amd.parallel import NativeComm
-    comm = NativeComm(0, 0, 1, NativeComm.unique_id())
+    comm = None
+    for attempt in range(3):
+        try:
+            comm = NativeComm(0, 0, 1, NativeComm.unique_id())
+            break
+        except RuntimeError as exc:
+            # (seen once in ~ 40 runs of this suite: ncclCommInitRank itself fails with "unhandled cuda error" on a box whose
+            # other GPUs are busy -- RCCL's start-up, before any call of this library's; the product path falls back to the
+            # process group's collectives then, parallel.exchange_self_check)
+            if "ncclCommInitRank" not in str(exc):
+                raise
+            last = str(exc)
+            time.sleep(1.0)
+    if comm is None:
+        pytest.skip(f"RCCL does not start on this box (three attempts): {last}")
     rng = np.random.default_rng(4)
     rows = rng.random((1234, 7))
     got, counts = comm.allgather_rows(rows)

@@ -57,7 +57,10 @@ __device__ __forceinline__ void stage_wave_sync()
 // the stored pixels of its row in registers anyway: it drops the counts into a zeroed LDS row piece (slot = diagonal) and
 // streams the piece out, 16 bytes per lane.  The detrended band of the tiler (a second pass over the pixel table, and the
 // division by a law that this pass is only reducing) is not written at all: whoever reads a pixel detrends it (cs_device.h).
-constexpr int kCountsPiece = 576;               // slots per LDS row piece (float32): 2.25 KB per wave
+#ifndef CS_COUNTS_PIECE
+#define CS_COUNTS_PIECE 576
+#endif
+constexpr int kCountsPiece = CS_COUNTS_PIECE;               // slots per LDS row piece (float32): 2.25 KB per wave
 
 template <typename TV, int kStageUnroll, bool COUNTS>
 __global__ __launch_bounds__(kStageThreads) void stage_law_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,

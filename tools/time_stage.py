@@ -22,7 +22,7 @@ for max_dist in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1000, 1]):
     for it in range(8):
         dev.sync()
         t0 = time.perf_counter()
-        blocks = dcool.stage_blocks(chroms, max_dist, 17)
+        blocks = dcool.stage_blocks(chroms, max_dist, 17, **({"lazy64": True} if os.environ.get("STAGE_LAZY") else {}))
         dev.sync()
         ts.append((time.perf_counter() - t0) * 1e3)
         del blocks

@@ -104,6 +104,12 @@ struct cs_ctx {
     std::vector<unsigned char> wfrag_key;     // the float32 weights the image was built from
     int wfrag_km = 0, wfrag_kn = 0;
     float wfrag_unscale[3] = {1.0f, 1.0f, 1.0f};
+    // ... and for the two-pass kernel of the templates of up to 33 x 33 (cs_launch.h MfmaWideWeights), with its own key
+    void* d_wfrag_wide = nullptr;
+    size_t d_wfrag_wide_bytes = 0;
+    std::vector<unsigned char> wfrag_wide_key;
+    int wfrag_wide_km = 0, wfrag_wide_kn = 0;
+    float wfrag_wide_unscale[3] = {1.0f, 1.0f, 1.0f};
     int last_kernel = 0;     // cs_last_kernel()
     int range_check = 0;     // cs_ctx_set_range_check()
     bool cand_fused = false; // the last candidate-mode call appended its candidates itself (no map was written)
@@ -559,7 +565,102 @@ int ensure_wfrag(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWeight
     return CS_OK;
 }
 
+// The image of the two-pass kernel (cs_corr_wide.hip; layout in cs_launch.h MfmaWideWeights): three sets x km rows x
+// two passes x {head, tail} x 1 KiB, then the 4 x 33 row / column sums of the two mask weight sets (float64 sums of the
+// float32 weights the device holds, rounded once).
+int ensure_wfrag_wide(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaWideWeights* E)
+{
+    const std::vector<unsigned char>& key = ctx->w_cached[0];
+    const int kk = km * kn;
+    const size_t n_floats = key.size() / 4;
+    if (kk <= 0 || n_floats < (size_t)kk) return fail(ctx, CS_ERR_INVALID, "weights missing for the matrix-core kernel");
+    if (!cs::corr_mfma_wide_fits(km, kn)) return fail(ctx, CS_ERR_INVALID, "the two-pass matrix-core kernel holds templates of up to 33 x 33");
+    const int nsets = (int)std::min<size_t>(3, n_floats / kk);
+    const size_t frag_halfs = (size_t)3 * km * 2 * 2 * 512;
+    const size_t sums_off = frag_halfs * 2;                    // bytes (a multiple of 16)
+    const size_t bytes = sums_off + 4 * 33 * sizeof(float);
+    if (bytes > ctx->d_wfrag_wide_bytes) {
+        if (ctx->d_wfrag_wide) {
+            CS_HIP(ctx, hipDeviceSynchronize());   // a queued kernel may still read the old image
+            CS_HIP(ctx, hipFree(ctx->d_wfrag_wide));
+        }
+        ctx->d_wfrag_wide = nullptr;
+        ctx->d_wfrag_wide_bytes = 0;
+        ctx->wfrag_wide_key.clear();
+        CS_HIP(ctx, hipMalloc(&ctx->d_wfrag_wide, bytes));
+        ctx->d_wfrag_wide_bytes = bytes;
+    }
+    if (!(ctx->wfrag_wide_km == km && ctx->wfrag_wide_kn == kn && ctx->wfrag_wide_key == key)) {
+        const float* w = reinterpret_cast<const float*>(key.data());
+        std::vector<unsigned char> img(bytes, 0);
+        uint16_t* halfs = reinterpret_cast<uint16_t*>(img.data());
+        float* sums = reinterpret_cast<float*>(img.data() + sums_off);
+        for (int set = 0; set < nsets; ++set) {
+            float amax = 0.0f;
+            for (int t = 0; t < kk; ++t) amax = std::max(amax, std::fabs(w[set * kk + t]));
+            int ew = 0;
+            if (amax > 0.0f && std::isfinite(amax)) {
+                int e2;
+                (void)std::frexp(amax, &e2);          // amax = f * 2^e2, f in [0.5, 1)
+                ew = 7 - e2;                           // amax * 2^ew in [64, 128)
+            }
+            ew = std::max(-100, std::min(100, ew));
+            ctx->wfrag_wide_unscale[set] = std::ldexp(1.0f, -ew);
+            for (int s = 0; s < km; ++s)
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int t = 32 * pass + 8 * (lane >> 4) + e - (lane & 15);
+                            if (t < 0 || t >= kn) continue;
+                            const float v = std::ldexp(w[set * kk + s * kn + t], ew);
+                            const uint16_t hb = f32_to_f16_bits(v);
+                            const uint16_t lb = f32_to_f16_bits(v - f16_bits_to_f32(hb));
+                            const size_t base = ((((size_t)set * km + s) * 2 + pass) * 2) * 512;
+                            halfs[base + (size_t)lane * 8 + e] = hb;
+                            halfs[base + 512 + (size_t)lane * 8 + e] = lb;
+                        }
+        }
+        if (nsets == 3)
+            for (int set = 0; set < 2; ++set) {
+                const float* ws = w + (1 + set) * kk;
+                for (int s = 0; s < km; ++s) {
+                    double acc = 0.0;
+                    for (int t = 0; t < kn; ++t) acc += ws[s * kn + t];
+                    sums[set * 33 + s] = (float)acc;
+                }
+                for (int t = 0; t < kn; ++t) {
+                    double acc = 0.0;
+                    for (int s = 0; s < km; ++s) acc += ws[s * kn + t];
+                    sums[(2 + set) * 33 + t] = (float)acc;
+                }
+            }
+        CS_HIP(ctx, hipMemcpyAsync(ctx->d_wfrag_wide, img.data(), bytes, hipMemcpyHostToDevice, stream));
+        ++ctx->uploads;
+        CS_HIP(ctx, hipStreamSynchronize(stream));    // the pageable source dies here
+        ctx->wfrag_wide_key = key;
+        ctx->wfrag_wide_km = km;
+        ctx->wfrag_wide_kn = kn;
+    }
+    E->frag = reinterpret_cast<const uint4*>(ctx->d_wfrag_wide);
+    E->sums = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ctx->d_wfrag_wide) + sums_off);
+    for (int set = 0; set < 3; ++set) E->unscale[set] = ctx->wfrag_wide_unscale[set];
+    E->plane_only = std::getenv("CHROMOSIGHT_HIP_WIDE_PLANE") ? 1 : 0;
+    return CS_OK;
+}
+
 bool fast_available(int km, int kn, int* K);
+
+// Which float32 calls take the two-pass matrix-core kernel (cs_corr_wide.hip): templates with a side of 18 .. 33 -- what
+// `--win-size` makes (cli/chromosight.py:365-370) and the 19 x 19 .. 33 x 33 templates of API users -- in every container
+// the runtime-size kernel served (bands and dense maps, float32 and float64, any mask, n_obs, plain cross-correlations).
+// CHROMOSIGHT_HIP_NO_MFMA=1 / CHROMOSIGHT_HIP_NO_WIDE=1: never (the runtime-size kernel: the in-library cross-check).
+bool mfma_wide_wanted(const cs::CorrArgs<float>& A)
+{
+    if (!cs::corr_mfma_wide_fits(A.km, A.kn) || (A.km <= 17 && A.kn <= 17)) return false;
+    if (A.sig.counts || A.sig.layout == CS_LAYOUT_BAND_LAZY || !A.out.ptr) return false;
+    if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA") || std::getenv("CHROMOSIGHT_HIP_NO_WIDE")) return false;
+    return true;
+}
 
 // Which float32 calls go to the matrix cores (cs_corr_mfma.hip).  Default: unmasked dense float32 maps
 // (cs_normxcorr2 without a mask: the API / benchmark configuration) whenever the template is large
@@ -897,6 +998,12 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         cs::corr_sep_tile(&tw, &th);
         fill_grid(A, tw, th);
         rc = cs::launch_corr_sep_f32(A, stream);
+    } else if (allow_fast && mfma_wide_wanted(A)) {
+        cs::MfmaWideWeights E;
+        rc = ensure_wfrag_wide(ctx, stream, A.km, A.kn, &E);
+        if (rc != CS_OK) return rc;
+        ctx->last_kernel = CS_KERNEL_MFMA_WIDE;
+        rc = cs::launch_corr_mfma_wide_f32(A, E, stream);
     } else {
         ctx->last_kernel = CS_KERNEL_GENERIC;
         cs::corr_generic_tile(A.km, A.kn, &tw, &th);
@@ -1206,6 +1313,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_tiles_started) (void)hipFree(ctx->d_tiles_started);
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_rim) (void)hipFree(ctx->d_rim);
+    if (ctx->d_wfrag_wide) (void)hipFree(ctx->d_wfrag_wide);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     for (int k = 0; k < 2; ++k) {

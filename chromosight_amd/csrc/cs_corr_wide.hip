@@ -1,0 +1,564 @@
+// cs_corr_wide.hip -- sliding-window correlation on the matrix cores for templates of up to 33 x 33.
+//
+// The float32 class of cs_normxcorr2 / cs_xcorr2 for the templates `--win-size` makes (reference
+// cli/chromosight.py:365-370, 689-695 -> preprocessing.py:731-807 resize_kernel: every template of a pattern is
+// zoomed to win-size x win-size) and for the 19 x 19 ... 33 x 33 templates of API users: any km, kn <= 33, any
+// container (dense / band, float32 / float64), per-bin or explicit masks, n_obs, row windows, candidate mode.
+// Same recasting as cs_corr_mfma.hip (v_mfma_f32_16x16x32_f16, float16 head / tail pairs after a power-of-two
+// scale per tile, float32 accumulation), with what a wider template changes:
+//
+//   * a 16-column output tile of a template row of up to 33 weights reads 16 + 32 = 48 staged columns: TWO k = 32
+//     Toeplitz passes per template row (B_p[k][n] = W[s][32 p + k - n]); the A blocks of the second pass of column
+//     tile c are those of the first pass of tile c + 2, so a wave reads 6 blocks (not 8) per template row;
+//   * 64 x 64 output pixels stage (64 + 32)^2 pixels: three float16 planes of 96 rows x 112 halfs (pitch 224 B:
+//     the 4 x 16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots; columns 96 .. 111 are zero and are
+//     what the last block of a row reads beyond the staged pixels);
+//   * 33 rows x 2 passes x {head, tail} x 1 KiB of B fragments (x 3 weight sets) do not fit the LDS next to the
+//     planes: a wave loads the four fragments of a template row straight from global memory (the image is built
+//     once per template by the host, cs_api.cpp ensure_wfrag_wide: 132 KB per set, L2-resident), one row ahead;
+//   * box sums (sum x, sum x^2, missing pixels): horizontal all-ones Toeplitz pass over the wave's 48 input rows,
+//     and the accumulator layout of that pass (a lane holds rows 4 g + v of ONE column) IS the B-operand layout of
+//     the vertical pass when the contraction index is labelled (g, e) -> row 16 rb + 4 g + e: no LDS transposition;
+//   * masks.  General form: the missing predicate of every staged pixel (cs_device.h missing_from_flags: per-bin
+//     flags or an explicit map, frames, diagonal limits -- preprocessing.py:404-498, 535-633) is a 0/1 plane, and the
+//     mask-weighted template sums are two more correlations of that plane.  Per-bin masks on a tile whose staged pixels
+//     all lie inside the matrix and the diagonals 0 .. max_dist ("inner": all but the rim of a band) factorise:
+//         missing(p, q) = r_p | c_q   =>   sum_missing W = sum_{s in R_i} rowsum_W[s] + sum_{t in C_j} colsum_W[t]
+//                                                          - sum_{s in R_i, t in C_j} W[s][t]
+//     two 1-D tables per tile (built from the 96 + 96 flags and the template's row / column sums) minus the
+//     correlation of the CROSS plane r_p & c_q, which is empty in most 16 x 32 blocks: a wave skips the mask MFMAs of
+//     a block whose 16 x 16 sub-blocks hold no flagged pixel (occupancy bits gathered while staging).
+//
+// One workgroup (4 waves) = one 64 x 64 output tile; wave w owns rows 16 w .. 16 w + 15 and four 16-column tiles.
+// LDS 66 KB (masked) / 43 KB: two workgroups per CU; tiles are dealt to the 8 XCDs in contiguous ranges.
+#include "cs_device.h"
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "cs_launch.h"
+
+namespace cs {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int WD_T = 64;                      // output tile edge
+constexpr int WD_R = 96;                      // staged rows / columns (tile + 32)
+constexpr int WD_P = 112;                     // halfs per staged row
+constexpr int WD_PLANE = WD_R * WD_P * 2;     // bytes of one float16 plane
+constexpr int WD_PER_THREAD = (WD_R * WD_R) / 256;      // 36 staged pixels per thread
+constexpr int WD_TAB = 6 * 64 * 4;            // per-tile mask tables: Tn, Ta, Tb (rows), Un, Ua, Ub (columns)
+constexpr int WD_FLAGS = 192;                 // flags of the 96 staged rows, then of the 96 staged columns
+constexpr int WD_SMEM_PLAIN = 2 * WD_PLANE + 64;
+constexpr int WD_SMEM_MASKED = 3 * WD_PLANE + WD_TAB + WD_FLAGS + 64;
+static_assert(WD_R * WD_R == 256 * WD_PER_THREAD, "staging loop");
+static_assert(WD_SMEM_MASKED <= 80 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ f4 mfma16(const h8& a, const h8& b, const f4& c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ h8 as_h8(const uint4& v) { return __builtin_bit_cast(h8, v); }
+
+// the head / tail float16 pair of four float32 sums as the LOWER half of a B operand (slots e = 0 .. 3; 4 .. 7 zero)
+__device__ __forceinline__ void split_low(const f4& v, h8& hi, h8& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(v[e] - (float)h);
+        hi[e + 4] = (_Float16)0.0f;
+        lo[e + 4] = (_Float16)0.0f;
+    }
+}
+
+// candidate mode: windows far below the tile's scale are outside the error model of the float16 pairs
+// (cs_corr_mfma.hip cand_range_guard)
+__device__ __forceinline__ float wide_range_guard(float r, float s2, float unscale, const KernelStats<float>& K)
+{
+    if (K.cand_cmin > 0.0f) r = ((int)(s2 > 0.0f) & (int)(s2 < K.n * (unscale * unscale) * 0.0625f)) ? 2.0f : r;
+    return r;
+}
+
+}  // namespace
+
+template <bool MASKED, bool TWO>
+__global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<float> A, const MfmaWideWeights E)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* xh = reinterpret_cast<_Float16*>(smem);
+    _Float16* xl = reinterpret_cast<_Float16*>(smem + WD_PLANE);
+    _Float16* xm = reinterpret_cast<_Float16*>(smem + 2 * WD_PLANE);                     // MASKED only
+    float* tab = reinterpret_cast<float*>(smem + 3 * WD_PLANE);                          // MASKED only
+    unsigned char* flg = reinterpret_cast<unsigned char*>(smem + 3 * WD_PLANE + WD_TAB);  // MASKED only
+    unsigned* red = reinterpret_cast<unsigned*>(smem + (MASKED ? 3 * WD_PLANE + WD_TAB + WD_FLAGS : 2 * WD_PLANE));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---- tile of this workgroup: XCD x (workgroups x, x + 8, ...) takes the x-th eighth of the row-major tile list
+    const int n_tiles = A.tiles_x * A.tiles_y;
+    const int per = (int)gridDim.x >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= n_tiles) return;
+    const int by = t / A.tiles_x;
+    const int bx = t - by * A.tiles_x;
+    const int I0 = A.row_begin + by * WD_T;
+    if (I0 >= A.row_end) return;
+    const bool band_out = A.out.layout == 1;
+    const int J0 = band_out ? I0 + A.out_lo + bx * WD_T : bx * WD_T;
+    if (J0 >= A.ns || J0 + WD_T <= 0) return;
+    if (J0 + WD_T - 1 - I0 < A.out_lo || J0 - (I0 + WD_T - 1) > A.out_hi) return;   // no produced diagonal
+    const int km = A.km, kn = A.kn;
+    const int RH = WD_T - 1 + km, RW = WD_T - 1 + kn;            // staged rows / columns the tile's windows reach
+    const int P0 = I0 - (km - 1) / 2, Q0 = J0 - (kn - 1) / 2;
+    // rows no window of the row range [row_begin, row_end) reaches are not part of the input contract
+    const int p_lo = A.row_begin - (km - 1) / 2, p_hi = A.row_end + (km - 1) - (km - 1) / 2;
+
+    // ---- inner tile of a per-bin mask: every staged pixel inside the matrix, the row window and the diagonals
+    //      0 .. max_dist, where the missing predicate is r_p | c_q and nothing else (cs_device.h missing_from_flags)
+    bool inner = false;
+    if constexpr (MASKED) {
+        inner = A.mask_mode == 1 && !E.plane_only && P0 >= 0 && P0 >= p_lo && P0 + RH <= A.ms && P0 + RH <= p_hi && Q0 >= 0 &&
+                Q0 + RW <= A.ns;
+        if (inner && A.sym_upper) {
+            const int md = A.max_dist >= 0 ? A.max_dist : min(A.ms, A.ns);
+            const int dmin = Q0 - (P0 + RH - 1), dmax = Q0 + RW - 1 - P0;
+            inner = dmin >= 0 && dmax <= md && dmin + (kn - km) >= 0;
+        }
+    }
+
+    if (tid < 4) red[tid] = 0u;
+    if constexpr (MASKED) {
+        if (A.mask_mode == 1) {
+            if (tid < WD_R) flg[tid] = A.miss_row[min(max(P0 + tid, 0), A.ms - 1)];
+            else if (tid < 2 * WD_R) flg[tid] = A.miss_col[min(max(Q0 + tid - WD_R, 0), A.ns - 1)];
+        }
+    }
+
+    // ---- stage 96 x 96 pixels: all loads unconditional from clamped addresses (a load inside a bounds branch is
+    //      waited for before the next one is issued)
+    float xv[WD_PER_THREAD];
+    unsigned long long ok_bits = 0, miss_bits = 0, mval_bits = 0;
+#pragma unroll
+    for (int k = 0; k < WD_PER_THREAD; ++k) {
+        const int idx = tid + 256 * k;
+        const int r = idx / WD_R, c = idx - r * WD_R;
+        const int p = P0 + r, q = Q0 + c;
+        const bool inside = (r < RH) & (c < RW) & (p >= 0) & (p < A.ms) & (q >= 0) & (q < A.ns) & (p >= p_lo) & (p < p_hi);
+        const long long off = inside ? mat_offset(A.sig, p, q) : -1;
+        if (off >= 0) ok_bits |= 1ull << k;
+        const long long o = off >= 0 ? off : 0;            // element 0 of the buffer always exists
+        xv[k] = A.sig_is_f64 ? (float)reinterpret_cast<const double*>(A.sig.ptr)[o] : reinterpret_cast<const float*>(A.sig.ptr)[o];
+        if constexpr (MASKED) {
+            if (A.mask_mode == 2) {
+                const long long om = inside ? mat_offset(A.mask, p, q) : -1;
+                const unsigned char mv = reinterpret_cast<const unsigned char*>(A.mask.ptr)[om >= 0 ? om : 0];
+                if (om >= 0 && mv != 0) mval_bits |= 1ull << k;
+            }
+        }
+    }
+    __syncthreads();      // flags and the zeroed words are in LDS
+
+    unsigned long long cross_bits = 0;     // what the mask plane holds: the missing predicate, or r_p & c_q on an inner tile
+    unsigned occ0 = 0, occ1 = 0;           // 16 x 16 blocks of the plane that hold a 1: bit 6 (r >> 4) + (c >> 4), 18 per word
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int k = 0; k < WD_PER_THREAD; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx / WD_R, c = idx - r * WD_R;
+            const int p = P0 + r, q = Q0 + c;
+            bool fr = false, fc = false;
+            if (A.mask_mode == 1) {
+                fr = flg[r] != 0;
+                fc = flg[WD_R + c] != 0;
+            }
+            bool miss, plane;
+            if (inner) {
+                miss = fr | fc;
+                plane = fr & fc;
+            } else {
+                const bool needed = (r < RH) & (c < RW) & (p >= p_lo) & (p < p_hi);
+                // (mval: the explicit map's byte where the map stores the pixel, so `stored` has nothing left to say)
+                miss = needed && missing_from_flags(A, p, q, fr, fc, (bool)((mval_bits >> k) & 1ull), true);
+                plane = miss;
+            }
+            if (miss) miss_bits |= 1ull << k;
+            if (plane) {
+                cross_bits |= 1ull << k;
+                const int b = 6 * (r >> 4) + (c >> 4);
+                if (b < 18) occ0 |= 1u << b;
+                else occ1 |= 1u << (b - 18);
+            }
+        }
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < WD_PER_THREAD; ++k) {
+        // the reference requires 0 at missing pixels (check_missing_mask); enforce it
+        const float x = (((ok_bits & ~miss_bits) >> k) & 1ull) ? xv[k] : 0.0f;
+        xv[k] = x;
+        amax = fmaxf(amax, fabsf(x));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) atomicMax(&red[0], __float_as_uint(amax));
+    if constexpr (MASKED) {
+        if (occ0) atomicOr(&red[1], occ0);
+        if (occ1) atomicOr(&red[2], occ1);
+    }
+    __syncthreads();
+    int ex = 0;
+    {
+        const int e = (int)((red[0] >> 23) & 0xffu);
+        if (e != 0 && e != 255) ex = 6 - (e - 127);
+        ex = max(-100, min(100, ex));
+    }
+    const float scale = __uint_as_float((unsigned)(ex + 127) << 23);
+    const float unscale = __uint_as_float((unsigned)(127 - ex) << 23);
+    unsigned long long occ = 0;
+    if constexpr (MASKED) {
+        occ = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)red[1]) |
+              ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)red[2]) << 18);
+    }
+#pragma unroll
+    for (int k = 0; k < WD_PER_THREAD; ++k) {
+        const int idx = tid + 256 * k;
+        const int r = idx / WD_R, c = idx - r * WD_R;
+        const int o = r * WD_P + c;
+        const float xs = xv[k] * scale;
+        const _Float16 h = (_Float16)xs;
+        xh[o] = h;
+        xl[o] = (_Float16)(xs - (float)h);
+        if constexpr (MASKED) xm[o] = ((cross_bits >> k) & 1ull) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    if (tid < WD_R) {      // columns 96 .. 111 of every row: zeros
+        const uint4 z = {0u, 0u, 0u, 0u};
+        uint4* ph = reinterpret_cast<uint4*>(xh + tid * WD_P + WD_R);
+        uint4* pl = reinterpret_cast<uint4*>(xl + tid * WD_P + WD_R);
+        ph[0] = z;
+        ph[1] = z;
+        pl[0] = z;
+        pl[1] = z;
+        if constexpr (MASKED) {
+            uint4* pm = reinterpret_cast<uint4*>(xm + tid * WD_P + WD_R);
+            pm[0] = z;
+            pm[1] = z;
+        }
+    }
+    if constexpr (MASKED) {
+        // per-tile tables of the factorised form (zeros on a general tile: the plane carries the whole predicate)
+        if (tid < 128) {
+            float cnt = 0.0f, sa = 0.0f, sb = 0.0f;
+            if (inner) {
+                const bool rows = tid < 64;
+                const int i = tid & 63;
+                const int len = rows ? km : kn;
+                const unsigned char* f = flg + (rows ? 0 : WD_R) + i;
+                const float* wa = E.sums + (rows ? 0 : 2 * 33);
+                const float* wb = wa + 33;
+                for (int s = 0; s < len; ++s)
+                    if (f[s]) {
+                        cnt += 1.0f;
+                        sa += wa[s];
+                        sb += wb[s];
+                    }
+                cnt *= rows ? (float)kn : (float)km;
+            }
+            const int base = tid < 64 ? 0 : 3 * 64;
+            tab[base + (tid & 63)] = cnt;
+            tab[base + 64 + (tid & 63)] = sa;
+            tab[base + 128 + (tid & 63)] = sb;
+        }
+    }
+    __syncthreads();
+
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int wr0 = 16 * wv;                  // first staged row of the wave's windows
+    constexpr int NCB = TWO ? 6 : 4;          // 16-column steps at which a wave's A blocks (16 rows x 32 columns) start
+    const bool any_mask = MASKED && occ != 0ull;
+
+    // ---- all-ones Toeplitz operands of the horizontal pass: B_p[k][n] = 1 for 0 <= 32 p + k - n < kn
+    h8 ones_b0, ones_b1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t0 = 8 * g + e - n;
+        ones_b0[e] = (t0 >= 0 && t0 < kn) ? (_Float16)1.0f : (_Float16)0.0f;
+        ones_b1[e] = (t0 + 32 >= 0 && t0 + 32 < kn) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+
+    // ---- box sums.  Horizontal pass per 16-row block rb of the wave's 48 input rows; its accumulators (lane (n, g):
+    //      rows 16 rb + 4 g + v of column n) go straight back in as the B operand of the vertical pass, slots e = 0 .. 3
+    //      of k = 8 g + e labelled as row 16 rb + 4 g + e: A[m][8 g + e] = 1 for 0 <= 16 rb + 4 g + e - m < km
+    f4 S1[4], S2[4], NM[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) S1[c] = S2[c] = NM[c] = zero4;
+    const int n_rb = km > 17 ? 3 : 2;
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb) {
+        if (rb < n_rb) {
+            f4 a1[4], a2[4], am_[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a1[c] = a2[c] = am_[c] = zero4;
+            const int rowoff = (wr0 + 16 * rb + n) * WD_P + 8 * g;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const h8 ah = *reinterpret_cast<const h8*>(xh + rowoff + 16 * cb);
+                const h8 al = *reinterpret_cast<const h8*>(xl + rowoff + 16 * cb);
+                h8 qh, ql;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (float)ah[e] + (float)al[e];
+                    const float q = x * x * 0.03125f;            // 2^-5: a 33-sum of squares stays below 65504
+                    qh[e] = (_Float16)q;
+                    ql[e] = (_Float16)(q - (float)qh[e]);
+                }
+                if (cb < 4) {
+                    a1[cb] = mfma16(ah, ones_b0, a1[cb]);
+                    a1[cb] = mfma16(al, ones_b0, a1[cb]);
+                    a2[cb] = mfma16(qh, ones_b0, a2[cb]);
+                    a2[cb] = mfma16(ql, ones_b0, a2[cb]);
+                }
+                if (TWO && cb >= 2) {
+                    a1[cb - 2] = mfma16(ah, ones_b1, a1[cb - 2]);
+                    a1[cb - 2] = mfma16(al, ones_b1, a1[cb - 2]);
+                    a2[cb - 2] = mfma16(qh, ones_b1, a2[cb - 2]);
+                    a2[cb - 2] = mfma16(ql, ones_b1, a2[cb - 2]);
+                }
+                if constexpr (MASKED) {
+                    if (any_mask) {
+                        const h8 am = *reinterpret_cast<const h8*>(xm + rowoff + 16 * cb);
+                        if (cb < 4) am_[cb] = mfma16(am, ones_b0, am_[cb]);
+                        if (TWO && cb >= 2) am_[cb - 2] = mfma16(am, ones_b1, am_[cb - 2]);
+                    }
+                }
+            }
+            h8 ones_a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = 16 * rb + 4 * g + e - n;
+                ones_a[e] = (e < 4 && d >= 0 && d < km) ? (_Float16)1.0f : (_Float16)0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                h8 bh, bl;
+                split_low(a1[c], bh, bl);
+                S1[c] = mfma16(ones_a, bh, S1[c]);
+                S1[c] = mfma16(ones_a, bl, S1[c]);
+                split_low(a2[c], bh, bl);
+                S2[c] = mfma16(ones_a, bh, S2[c]);
+                S2[c] = mfma16(ones_a, bl, S2[c]);
+                if constexpr (MASKED) {
+                    if (any_mask) {
+                        split_low(am_[c], bh, bl);          // (counts of up to 33: exact in the head)
+                        NM[c] = mfma16(ones_a, bh, NM[c]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- cross term: per template row the wave's 6 (4) A blocks against the row's Toeplitz fragments, loaded from the
+    //      image in global memory one row ahead
+    f4 accM[4], accC[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accM[c] = accC[c] = zero4;
+    {
+        const uint4* F = E.frag + lane;                   // [set 0][s][pass][head | tail][lane]
+        uint4 nf[4];
+#pragma unroll
+        for (int q = 0; q < (TWO ? 4 : 2); ++q) nf[q] = F[q * 64];
+        for (int s = 0; s < km; ++s) {
+            uint4 cf[4];
+#pragma unroll
+            for (int q = 0; q < (TWO ? 4 : 2); ++q) cf[q] = nf[q];
+            {
+                const uint4* Fn = F + (size_t)min(s + 1, km - 1) * 256;
+#pragma unroll
+                for (int q = 0; q < (TWO ? 4 : 2); ++q) nf[q] = Fn[q * 64];
+            }
+            const int rowoff = (wr0 + s + n) * WD_P + 8 * g;
+            h8 ah[NCB], al[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                ah[cb] = *reinterpret_cast<const h8*>(xh + rowoff + 16 * cb);
+                al[cb] = *reinterpret_cast<const h8*>(xl + rowoff + 16 * cb);
+            }
+            const h8 bh0 = as_h8(cf[0]), bl0 = as_h8(cf[1]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                accM[c] = mfma16(ah[c], bh0, accM[c]);
+                accC[c] = mfma16(ah[c], bl0, accC[c]);
+                accC[c] = mfma16(al[c], bh0, accC[c]);
+            }
+            if constexpr (TWO) {
+                const h8 bh1 = as_h8(cf[2]), bl1 = as_h8(cf[3]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    accM[c] = mfma16(ah[c + 2], bh1, accM[c]);
+                    accC[c] = mfma16(ah[c + 2], bl1, accC[c]);
+                    accC[c] = mfma16(al[c + 2], bh1, accC[c]);
+                }
+            }
+        }
+    }
+
+    // ---- mask-weighted template sums: the plane against the Wa and the Wb fragments (the plane is exact in float16:
+    //      two MFMAs per block and set); blocks whose 16 x 16 sub-blocks hold no flagged pixel are skipped
+    f4 KA[4], KB[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) KA[c] = KB[c] = zero4;
+    if constexpr (MASKED) {
+        if (any_mask) {
+#pragma unroll
+            for (int set = 1; set <= 2; ++set) {
+                const uint4* F = E.frag + (size_t)set * km * 256 + lane;
+                uint4 nf[4];
+#pragma unroll
+                for (int q = 0; q < (TWO ? 4 : 2); ++q) nf[q] = F[q * 64];
+                for (int s = 0; s < km; ++s) {
+                    uint4 cf[4];
+#pragma unroll
+                    for (int q = 0; q < (TWO ? 4 : 2); ++q) cf[q] = nf[q];
+                    {
+                        const uint4* Fn = F + (size_t)min(s + 1, km - 1) * 256;
+#pragma unroll
+                        for (int q = 0; q < (TWO ? 4 : 2); ++q) nf[q] = Fn[q * 64];
+                    }
+                    // occupied 16-column blocks among the (one or two) 16-row blocks the rows wr0 + s .. wr0 + s + 15 touch
+                    const int r0 = wr0 + s;
+                    const unsigned ro = (unsigned)(((occ >> (6 * (r0 >> 4))) | (occ >> (6 * ((r0 + 15) >> 4)))) & 0x3full);
+                    if (ro == 0u) continue;
+                    const int rowoff = (r0 + n) * WD_P + 8 * g;
+                    const h8 wh0 = as_h8(cf[0]), wl0 = as_h8(cf[1]);
+                    const h8 wh1 = as_h8(cf[TWO ? 2 : 0]), wl1 = as_h8(cf[TWO ? 3 : 1]);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        if (ro & (3u << cb)) {             // (block cb covers the 16-column blocks cb and cb + 1; block 6 is the zero pad)
+                            const h8 am = *reinterpret_cast<const h8*>(xm + rowoff + 16 * cb);
+                            if (cb < 4) {
+                                if (set == 1) {
+                                    KA[cb] = mfma16(am, wh0, KA[cb]);
+                                    KA[cb] = mfma16(am, wl0, KA[cb]);
+                                } else {
+                                    KB[cb] = mfma16(am, wh0, KB[cb]);
+                                    KB[cb] = mfma16(am, wl0, KB[cb]);
+                                }
+                            }
+                            if (TWO && cb >= 2) {
+                                if (set == 1) {
+                                    KA[cb - 2] = mfma16(am, wh1, KA[cb - 2]);
+                                    KA[cb - 2] = mfma16(am, wl1, KA[cb - 2]);
+                                } else {
+                                    KB[cb - 2] = mfma16(am, wh1, KB[cb - 2]);
+                                    KB[cb - 2] = mfma16(am, wl1, KB[cb - 2]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = column n of tile c, rows 4 g + v
+    const float u_cs = unscale * E.unscale[0];
+    const float u_s2 = 32.0f * unscale;
+    const float sgn = inner ? -1.0f : 1.0f;
+    const float ua = sgn * E.unscale[1], ub = sgn * E.unscale[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int jl = 16 * c + n;
+        const int j = J0 + jl;
+        float un = 0.0f, uav = 0.0f, ubv = 0.0f;
+        if constexpr (MASKED) {
+            un = tab[3 * 64 + jl];
+            uav = tab[4 * 64 + jl];
+            ubv = tab[5 * 64 + jl];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int il = wr0 + 4 * g + v;
+            const int i = I0 + il;
+            if (i >= A.row_end || j < 0 || j >= A.ns) continue;
+            const int d = j - i;
+            if (d < A.out_lo || d > A.out_hi) continue;
+            const float cs = (accM[c][v] + accC[c][v]) * u_cs;
+            const float s1 = S1[c][v] * unscale;
+            const float s2 = (S2[c][v] * u_s2) * unscale;
+            float r, nobs = A.ks.n;
+            if (pixel_forced_zero(A, i, j)) {
+                r = 0.0f;
+            } else if (A.xcorr_only) {
+                r = (fabsf(cs) < A.ks.thr) ? 0.0f : cs;
+            } else if constexpr (MASKED) {
+                const float nm = tab[il] + un + sgn * NM[c][v];
+                const float ka = tab[64 + il] + uav + ua * KA[c][v];
+                const float kb = tab[128 + il] + ubv + ub * KB[c][v];
+                r = wide_range_guard(pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks), s2, unscale, A.ks);
+                nobs = A.ks.n - nm;
+            } else {
+                r = wide_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
+            }
+            store_pixel(A, i, j, r, nobs);
+        }
+    }
+}
+
+// The 160 KB dynamic-LDS ceiling is a per-function, per-device attribute: set it the first time a kernel is
+// launched on a device.
+static hipError_t wide_allow_big_lds(const void* fn)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& d : done)
+        if (d.first == fn && d.second == dev) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.emplace_back(fn, dev);
+    return e;
+}
+
+bool corr_mfma_wide_fits(int km, int kn) { return km >= 1 && kn >= 1 && km <= 33 && kn <= 33; }
+
+int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipStream_t stream)
+{
+    if (!corr_mfma_wide_fits(A.km, A.kn)) return -3;
+    if (A.sig.counts || A.sig.layout == 2) return -6;      // (bands of counts / lazily evaluated bands: other readers)
+    if (!A.out.ptr) return -5;                             // this kernel writes a map
+    A.tile_w = A.tile_h = WD_T;
+    A.tiles_y = (A.row_end - A.row_begin + WD_T - 1) / WD_T;
+    if (A.out.layout == 1) {
+        A.out_lo = A.out.band_lo;
+        A.out_hi = A.out.band_lo + A.out.band_w - 1;
+        A.tiles_x = (A.out.band_w + WD_T - 1 + WD_T - 1) / WD_T;
+    } else {
+        A.out_lo = -(1 << 30);
+        A.out_hi = (1 << 30);
+        A.tiles_x = (A.ns + WD_T - 1) / WD_T;
+    }
+    const long long blocks = (long long)A.tiles_x * A.tiles_y;
+    if (blocks <= 0) return 0;
+    if (blocks > 0x7ffffff0LL) return -3;
+    const bool masked = A.mask_mode != 0;
+    const bool two = A.kn > 17;
+    typedef void (*kern_t)(const CorrArgs<float>, const MfmaWideWeights);
+    const kern_t k = masked ? (two ? corr_mfma_wide_kernel<true, true> : corr_mfma_wide_kernel<true, false>)
+                            : (two ? corr_mfma_wide_kernel<false, true> : corr_mfma_wide_kernel<false, false>);
+    hipError_t e = wide_allow_big_lds((const void*)k);
+    if (e != hipSuccess) return (int)e;
+    const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), masked ? WD_SMEM_MASKED : WD_SMEM_PLAIN, stream, A, E);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cs

@@ -57,4 +57,17 @@ int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym
 // one block of such a table as its own persistent launch (its mask tables were prepared earlier)
 int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_cap, hipStream_t s);
 
+// matrix-core kernel for templates of up to 33 x 33 (cs_corr_wide.hip): two k = 32 Toeplitz passes per template row.
+// frag[set][s][pass][head | tail][lane] = 8 float16 values W_set[s][32 pass + 8 (lane >> 4) + e - (lane & 15)] * 2^ew
+// (0 outside 0 .. kn-1), unscale[set] = 2^-ew; sums: row sums of Wa (33 slots), row sums of Wb, column sums of Wa,
+// column sums of Wb -- the 1-D tables of the factorised per-bin mask; plane_only: never factorise (test switch).
+struct MfmaWideWeights {
+    const uint4* frag;
+    float unscale[3];
+    const float* sums;
+    int plane_only;
+};
+bool corr_mfma_wide_fits(int km, int kn);
+int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipStream_t s);
+
 }  // namespace cs

@@ -88,7 +88,7 @@ const char* cs_version(void);
  * cs_detect_foci / cs_candidates) on this context: diagnostics, and what the tests use to make sure
  * the intended native path ran */
 enum { CS_KERNEL_NONE = 0, CS_KERNEL_GENERIC = 1, CS_KERNEL_STREAM = 2, CS_KERNEL_MFMA = 3, CS_KERNEL_MFMA_DENSE = 4,
-       CS_KERNEL_MFMA_REG = 5, CS_KERNEL_SEPARABLE = 6 };
+       CS_KERNEL_MFMA_REG = 5, CS_KERNEL_SEPARABLE = 6, CS_KERNEL_MFMA_WIDE = 7 };
 int cs_last_kernel(const cs_ctx* ctx);
 /* Range guard of the device entries (off by default).  The reference sums every window on its own
  * (detection.py:1002-1018) and zeroes exactly the windows that hold a non-finite pixel (:1088-1101); the device kernels

@@ -1,0 +1,255 @@
+"""The two-pass matrix-core kernel (chromosight_amd/csrc/cs_corr_wide.hip) -- templates with a side of 18 .. 33, what
+`--win-size` makes (reference cli/chromosight.py:365-370, 689-695 -> preprocessing.py:731-807) and what API users pass --
+against the C oracle at the 1e-5 bar, in every container the runtime-size kernel served before: dense and banded maps,
+float32 and float64, per-bin and explicit masks (general plane form AND the factorised form of inner tiles), n_obs,
+row windows, plain cross-correlations; and against the runtime-size kernel (CHROMOSIGHT_HIP_NO_WIDE=1)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import chromosight_amd
+from chromosight_amd import engine
+from chromosight_amd._lib import LAYOUT_BAND, LAYOUT_DENSE, MASK_BINS, MASK_NONE, CsMatrix, get_device, np_dtype_code
+from chromosight_amd.utils import detection as cud
+from chromosight_amd.utils import preprocessing as cup
+from oracle import c_oracle
+from parity_util import assert_parity
+
+ILL_MASKED = 0.1
+KERNEL_GENERIC, KERNEL_SEPARABLE, KERNEL_MFMA_WIDE = 1, 6, 7
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def f32_precision():
+    old = chromosight_amd.get_precision()
+    chromosight_amd.set_precision("f32")
+    yield
+    chromosight_amd.set_precision(old)
+
+
+def last_kernel():
+    dev = get_device()
+    return dev.lib.cs_last_kernel(dev.ctx)
+
+
+def template(shape, seed=0):
+    """A full-rank template with structure (a blob on a gradient plus noise): what a zoomed loops template looks like."""
+    rng = np.random.default_rng(1000 * shape[0] + shape[1] + seed)
+    i, j = np.indices(shape)
+    ci, cj = (shape[0] - 1) / 2, (shape[1] - 1) / 2
+    blob = np.exp(-((i - ci) ** 2 + (j - cj) ** 2) / (0.08 * shape[0] * shape[1] + 1))
+    return 0.4 + blob + 0.02 * (i - j) + 0.15 * rng.normal(size=shape)
+
+
+def _signal(rng, shape, kind):
+    if kind == "gamma":
+        return rng.gamma(2.0, 1.0, size=shape)
+    if kind == "hic":
+        return np.minimum(rng.gamma(20, 0.05, size=shape), 10.0)
+    if kind == "tiny":
+        return rng.gamma(2.0, 1.0, size=shape) * 3e-7
+    if kind == "huge":
+        return rng.gamma(2.0, 1.0, size=shape) * 7e8
+    if kind == "signed":
+        return rng.normal(size=shape)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("shape,kshape,kind", [
+    ((300, 300), (19, 19), "gamma"), ((513, 777), (21, 21), "hic"), ((130, 70), (33, 33), "signed"),
+    ((64, 70), (23, 23), "gamma"), ((200, 333), (25, 19), "gamma"), ((150, 150), (5, 31), "hic"),
+    ((97, 201), (33, 7), "gamma"), ((256, 256), (27, 27), "tiny"), ((256, 256), (29, 29), "huge"),
+    ((190, 190), (19, 33), "gamma"), ((222, 111), (31, 21), "hic"), ((400, 400), (31, 31), "gamma"),
+])
+@pytest.mark.parametrize("full", [True, False])
+def test_dense_maps_match_oracle(shape, kshape, kind, full):
+    """Unmasked dense float32 maps: partial tiles, frames narrower than a tile, valid-mode margins, rectangular
+    templates (one and two Toeplitz passes), data far from unit scale."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1] + kshape[0])
+    sig = _signal(rng, shape, kind).astype(np.float32)
+    kern = template(kshape)
+    got, _ = cud.normxcorr2(sig, kern, full=full)
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, shape[0], full=full)
+    assert_parity(got, want, cond, "f32", f"wide dense {shape} {kshape} {kind} full={full}")
+
+
+def test_equals_runtime_size_kernel(monkeypatch):
+    """The two float32 kernels on one map: same coefficients to a few 1e-6, and they are different kernels."""
+    rng = np.random.default_rng(5)
+    sig = rng.gamma(2.0, 1.0, size=(700, 900)).astype(np.float32)
+    kern = template((21, 21))
+    a, _ = cud.normxcorr2(sig, kern, full=True)
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_WIDE", "1")
+    b, _ = cud.normxcorr2(sig, kern, full=True)
+    assert last_kernel() == KERNEL_GENERIC
+    assert np.abs(a - b).max() < 5e-6
+    assert not np.array_equal(a, b)
+
+
+def test_sym_upper_dense_and_f64_container():
+    rng = np.random.default_rng(9)
+    sig = np.triu(rng.gamma(2.0, 1.0, size=(260, 260)))          # float64 container
+    kern = template((21, 21))
+    for full in (True, False):
+        got, _ = cud.normxcorr2(sig, kern, sym_upper=True, full=full)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        want, cond = c_oracle.normxcorr2_rows(sig, kern, 0, 260, sym_upper=True, full=full)
+        assert_parity(got, want, cond, "f32", f"wide dense sym_upper full={full}")
+        assert np.all(np.tril(got, -1) == 0)
+
+
+def _masked_band(n, md, keep, seed, frac=0.04):
+    rng = np.random.default_rng(seed)
+    ii, jj = np.indices((n, n))
+    sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
+    sig[jj - ii > md + keep] = 0
+    valid = np.flatnonzero(rng.random(n) > frac)
+    miss = np.ones(n, bool)
+    miss[valid] = False
+    sig[miss, :] = 0
+    sig[:, miss] = 0
+    return sig.astype(np.float32), valid, miss, (jj - ii >= 0) & (jj - ii <= md)
+
+
+@pytest.mark.parametrize("n,md,ksize,tol", [(900, 120, 21, 0.75), (1500, 400, 21, 0.5), (1300, 500, 33, 0.75),
+                                             (700, 60, 19, 0.25), (400, 399, 25, 0.75), (1100, 300, 27, 0.5)])
+@pytest.mark.parametrize("plane", [False, True])
+def test_banded_maps_with_bin_masks(n, md, ksize, tol, plane, monkeypatch):
+    """The detect configuration: CSR in, band in / band out on the device, per-bin masks, full, sym_upper, coefficients
+    and n_obs (through the p-values).  plane=False: inner tiles take the factorised form (1-D tables minus the cross
+    plane), the rim the general plane; plane=True (CHROMOSIGHT_HIP_WIDE_PLANE=1): the general plane everywhere -- both
+    against the oracle and against each other."""
+    if plane:
+        monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_PLANE", "1")
+    sig, valid, miss, band = _masked_band(n, md, ksize, n + md)
+    kern = template((ksize, ksize))
+    mask = cup.make_missing_mask((n, n), valid, valid, max_dist=md, sym_upper=True)
+    c, p = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                          missing_tol=tol, pval=True)
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, n, max_dist=md, sym_upper=True, full=True,
+                                          miss_row=miss, miss_col=miss, missing_tol=tol)
+    assert_parity(c.toarray()[band], want[band], cond[band], "f32", f"wide band n={n} md={md} k={ksize} plane={plane}",
+                  max_ill_frac=ILL_MASKED)
+    # the runtime-size kernel on the same call: coefficients and p-values (n_obs) agree
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_WIDE", "1")
+    c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                            missing_tol=tol, pval=True)
+    assert last_kernel() == KERNEL_GENERIC
+    well = band & (cond >= 1e-3)
+    assert np.abs(c.toarray() - c2.toarray())[well].max() < 5e-6
+    assert np.abs(p.toarray() - p2.toarray())[well].max() < 5e-3
+
+
+def test_inter_block_and_explicit_mask():
+    """An inter-chromosomal block (dense, masks on both axes, no diagonal limits: its middle tiles are inner tiles) and an
+    explicit mask in valid mode."""
+    rng = np.random.default_rng(21)
+    shape = (500, 620)
+    kern = template((21, 21))
+    inter = rng.gamma(2.0, 1.0, size=shape)
+    vr, vc = np.flatnonzero(rng.random(shape[0]) > 0.05), np.flatnonzero(rng.random(shape[1]) > 0.05)
+    mr, mc = np.ones(shape[0], bool), np.ones(shape[1], bool)
+    mr[vr] = False
+    mc[vc] = False
+    inter[mr, :] = 0
+    inter[:, mc] = 0
+    mask = cup.make_missing_mask(shape, vr, vc, max_dist=None, sym_upper=False)
+    for full in (True, False):
+        c, _ = cud.normxcorr2(sp.csr_matrix(inter), kern, max_dist=None, sym_upper=False, full=full, missing_mask=mask,
+                              missing_tol=0.75)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        want, cond = c_oracle.normxcorr2_rows(inter, kern, 0, shape[0], full=full, miss_row=mr, miss_col=mc)
+        assert_parity(c.toarray(), want, cond, "f32", f"wide inter block full={full}", max_ill_frac=ILL_MASKED)
+    # an explicit mask that is NOT a union of rows and columns: dense signal, dense mask
+    sig = rng.gamma(2.0, 1.0, size=(300, 340))
+    m = rng.random(sig.shape) < 0.03
+    sig[m] = 0
+    m = sp.csr_matrix(m)
+    got, _ = cud.normxcorr2(sig, kern, full=False, missing_mask=m, missing_tol=0.75)
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    import os
+    os.environ["CHROMOSIGHT_HIP_NO_WIDE"] = "1"
+    try:
+        ref, _ = cud.normxcorr2(sig, kern, full=False, missing_mask=m, missing_tol=0.75)
+        assert last_kernel() == KERNEL_GENERIC
+    finally:
+        del os.environ["CHROMOSIGHT_HIP_NO_WIDE"]
+    assert np.abs(got - ref).max() < 5e-6
+
+
+def test_xcorr2_wide_template():
+    """Plain cross-correlation (reference detection.py:595-804) with a 25 x 21 template."""
+    rng = np.random.default_rng(33)
+    sig = rng.gamma(2.0, 1.0, size=(210, 190))
+    k = rng.normal(size=(25, 21))
+    got = cud.xcorr2(sig, k, threshold=1e-4)
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    from oracle import pearson_oracle as orc
+    want = orc.xcorr2_oracle(sig, k, threshold=0)
+    near = np.abs(np.abs(want) - 1e-4) < 1e-6
+    ref = np.where(np.abs(want) < 1e-4, 0.0, want)
+    assert np.abs(got - ref)[~near].max() < 3e-6 * np.abs(want).max()
+
+
+def test_row_windows():
+    """Row windows (slab inputs): equal to the rows of the whole map."""
+    dev = get_device()
+    rng = np.random.default_rng(4)
+    n, cols = 500, 600
+    sig_h = rng.gamma(2.0, 1.0, size=(n, cols)).astype(np.float32)
+    kspec = engine.KernelSpec(template((23, 23)), None)
+    code = np_dtype_code(np.float32)
+
+    def run(sig, out, window=None):
+        params = engine._corr_params((n, cols), kspec, True, False, None, MASK_NONE, None, None, None, 0.75,
+                                     engine.compute_code("f32"), window)
+        dev._check(dev.lib.cs_normxcorr2(dev.ctx, None, C.byref(sig), C.byref(kspec.struct), C.byref(params), C.byref(out), None))
+
+    d_sig = dev.to_device(sig_h)
+    d_full = dev.zeros(n * cols, np.float32)
+    run(CsMatrix(d_sig.ptr, code, LAYOUT_DENSE, cols, 0, 0), CsMatrix(d_full.ptr, code, LAYOUT_DENSE, cols, 0, 0))
+    full = d_full.download().reshape(n, cols)
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    for a, b in [(0, 37), (37, 200), (200, 201), (201, 495), (495, 500)]:
+        ra, rb = max(0, a - 11), min(n, b + 11)
+        d_slab = dev.to_device(np.ascontiguousarray(sig_h[ra:rb]))
+        d_out = dev.zeros((b - a) * cols, np.float32)
+        run(CsMatrix(d_slab.ptr, code, LAYOUT_DENSE, cols, 0, 0, ra), CsMatrix(d_out.ptr, code, LAYOUT_DENSE, cols, 0, 0, a), (a, b))
+        got = d_out.download().reshape(b - a, cols)
+        assert np.abs(got - full[a:b]).max() <= 2e-6, (a, b)
+
+
+@pytest.mark.parametrize("ksize", [19, 21, 33])
+def test_c4p_band_200000_row_windows(ksize):
+    """C4' (N = 200 000 single block, max_dist 1000, 2 % missing bins) under templates of 19, 21 and 33: seven windows of
+    2000 rows (both matrix ends, the middle) against the oracle -- the full-size parity of the kernel
+    profiles/r06_template_kernels.txt times."""
+    from tools.synthetic_genome import band_workload
+    dev = get_device()
+    band, band_w, miss, n, max_dist = band_workload("c4p")
+    out_w = max_dist + 1
+    ld_out = (out_w + 63) // 64 * 64
+    d_sig, d_out = dev.to_device(band), dev.zeros((n, ld_out), np.float32)
+    d_miss = dev.to_device(miss)
+    kern = template((ksize, ksize))
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_BAND, band.shape[1], 0, band_w),
+                          (n, n), engine.KernelSpec(kern),
+                          CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld_out, 0, out_w),
+                          full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=d_miss,
+                          miss_col=d_miss, missing_tol=0.5, precision="f32")
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    got = d_out.download()[:, :out_w]
+    band64 = band.astype(np.float64)
+    del band
+    for r0 in (0, 1990, 49_000, 99_137, 150_000, 187_654, n - 2000):
+        rows = 2000
+        want, cond = c_oracle.normxcorr2_band(band64, n, 0, band_w, kern, r0, r0 + rows, 0, max_dist + 1,
+                                              max_dist=max_dist, miss_row=miss, miss_col=miss, missing_tol=0.5)
+        assert_parity(got[r0:r0 + rows], want, cond, "f32", f"C4' k={ksize} rows {r0}..{r0 + rows}", max_ill_frac=1e-4)

@@ -645,6 +645,7 @@ int ensure_wfrag_wide(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaW
     E->sums = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ctx->d_wfrag_wide) + sums_off);
     for (int set = 0; set < 3; ++set) E->unscale[set] = ctx->wfrag_wide_unscale[set];
     E->plane_only = std::getenv("CHROMOSIGHT_HIP_WIDE_PLANE") ? 1 : 0;
+    E->plane_only_staging = std::getenv("CHROMOSIGHT_HIP_WIDE_SLOW") ? 1 : 0;
     return CS_OK;
 }
 

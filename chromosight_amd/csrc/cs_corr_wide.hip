@@ -44,6 +44,9 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte global access at 4-byte alignment
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
 
 constexpr int WD_T = 64;                      // output tile edge
 constexpr int WD_R = 96;                      // staged rows / columns (tile + 32)
@@ -56,6 +59,21 @@ constexpr int WD_SMEM_PLAIN = 2 * WD_PLANE + 64;
 constexpr int WD_SMEM_MASKED = 3 * WD_PLANE + WD_TAB + WD_FLAGS + 64;
 static_assert(WD_R * WD_R == 256 * WD_PER_THREAD, "staging loop");
 static_assert(WD_SMEM_MASKED <= 80 * 1024, "two workgroups per CU");
+
+#ifdef CS_WD_PROFILE
+// Per-phase cycle stamps of every wave (tools/prof_wide_sections.py; `make prof`): the differences stay in registers and are
+// added to one of 64 copies of the device counters when the wave ends (atomics on nine words from 16 000 waves, issued between
+// the phases, queued in front of the fragment loads and were what the first version measured).  [15]: wave-tiles.
+__device__ unsigned long long cs_wd_prof[64 * 16];
+#define WD_STAMP(k)                                                        \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        tdelta_[k] = now_ - tprev_;                                        \
+        tprev_ = now_;                                                     \
+    } while (0)
+#else
+#define WD_STAMP(k)
+#endif
 
 __device__ __forceinline__ f4 mfma16(const h8& a, const h8& b, const f4& c)
 {
@@ -115,6 +133,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     const int J0 = band_out ? I0 + A.out_lo + bx * WD_T : bx * WD_T;
     if (J0 >= A.ns || J0 + WD_T <= 0) return;
     if (J0 + WD_T - 1 - I0 < A.out_lo || J0 - (I0 + WD_T - 1) > A.out_hi) return;   // no produced diagonal
+#ifdef CS_WD_PROFILE
+    unsigned long long tdelta_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
     const int km = A.km, kn = A.kn;
     const int RH = WD_T - 1 + km, RW = WD_T - 1 + kn;            // staged rows / columns the tile's windows reach
     const int P0 = I0 - (km - 1) / 2, Q0 = J0 - (kn - 1) / 2;
@@ -142,62 +164,177 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
     }
 
-    // ---- stage 96 x 96 pixels: all loads unconditional from clamped addresses (a load inside a bounds branch is
-    //      waited for before the next one is issued)
+    // ---- stage 96 x 96 pixels.  Two forms, one per workgroup:
+    //   * row-regular (`fast`): a staged row is one run of consecutive slots of its stored row (dense: columns; band: diagonals
+    //     shifted by the row), so a thread fetches 9 pieces of 4 pixels with 16-byte loads at 4-byte alignment; a piece that
+    //     straddles the end of the stored run is fetched from the clamped start and shifted in registers.  Masks: none, or
+    //     per-bin flags on a tile whose staged pixels all lie inside the matrix (no frame: the predicate is the flags, the
+    //     diagonal limits and the sub-diagonal stripes -- cs_device.h missing_from_flags for in-matrix pixels).
+    //   * general: one pixel at a time from clamped addresses, the missing predicate in full (frames, explicit maps).
+    constexpr int PIECES = WD_PER_THREAD / 4;             // 9
+    const bool band_in = A.sig.layout == 1;
+    const int W_in = band_in ? A.sig.band_w : A.ns;       // slots a stored row holds
+    const bool frame_free = P0 >= 0 && P0 >= p_lo && P0 + RH <= A.ms && P0 + RH <= p_hi && Q0 >= 0 && Q0 + RW <= A.ns;
+    const bool fast = !E.plane_only_staging && W_in >= 4 && (!MASKED || (A.mask_mode == 1 && frame_free));
     float xv[WD_PER_THREAD];
     unsigned long long ok_bits = 0, miss_bits = 0, mval_bits = 0;
+    if (fast) {
+        const int row_lo = max(0, p_lo), row_hi = min(A.ms, p_hi);
 #pragma unroll
-    for (int k = 0; k < WD_PER_THREAD; ++k) {
-        const int idx = tid + 256 * k;
-        const int r = idx / WD_R, c = idx - r * WD_R;
-        const int p = P0 + r, q = Q0 + c;
-        const bool inside = (r < RH) & (c < RW) & (p >= 0) & (p < A.ms) & (q >= 0) & (q < A.ns) & (p >= p_lo) & (p < p_hi);
-        const long long off = inside ? mat_offset(A.sig, p, q) : -1;
-        if (off >= 0) ok_bits |= 1ull << k;
-        const long long o = off >= 0 ? off : 0;            // element 0 of the buffer always exists
-        xv[k] = A.sig_is_f64 ? (float)reinterpret_cast<const double*>(A.sig.ptr)[o] : reinterpret_cast<const float*>(A.sig.ptr)[o];
-        if constexpr (MASKED) {
-            if (A.mask_mode == 2) {
-                const long long om = inside ? mat_offset(A.mask, p, q) : -1;
-                const unsigned char mv = reinterpret_cast<const unsigned char*>(A.mask.ptr)[om >= 0 ? om : 0];
-                if (om >= 0 && mv != 0) mval_bits |= 1ull << k;
+        for (int k = 0; k < PIECES; ++k) {
+            const int id = tid + 256 * k;
+            const int r = id / 24, c4 = (id - r * 24) * 4;
+            const int p = P0 + r, q0 = Q0 + c4;
+            const bool rowok = (r < RH) & (p >= row_lo) & (p < row_hi);
+            const int pc = min(max(p, row_lo), row_hi - 1);
+            const int s0 = band_in ? q0 - p - A.sig.band_lo : q0;
+            const int s0c = min(max(s0, 0), W_in - 4);
+            const long long at = ((long long)pc - A.sig.row0) * A.sig.ld + s0c;
+            float v0, v1, v2, v3;
+            if (A.sig_is_f64) {
+                const double* src = reinterpret_cast<const double*>(A.sig.ptr) + at;
+                const d2u lo2 = *reinterpret_cast<const d2u*>(src), hi2 = *reinterpret_cast<const d2u*>(src + 2);
+                v0 = (float)lo2[0];
+                v1 = (float)lo2[1];
+                v2 = (float)hi2[0];
+                v3 = (float)hi2[1];
+            } else {
+                const f4u v = *reinterpret_cast<const f4u*>(reinterpret_cast<const float*>(A.sig.ptr) + at);
+                v0 = v[0];
+                v1 = v[1];
+                v2 = v[2];
+                v3 = v[3];
+            }
+            const int sh = s0 - s0c;
+            if (sh != 0) {                      // (a piece on the rim of the stored run: element e sits at position sh + e of the fetch)
+                const float w0 = v0, w1 = v1, w2 = v2, w3 = v3;
+                v0 = sh == 1 ? w1 : sh == 2 ? w2 : w3;              // sh in 1 .. 3 (positions beyond 3 are not stored: zeroed below)
+                v1 = sh == 1 ? w2 : sh == -1 ? w0 : w3;
+                v2 = sh == 1 ? w3 : sh == -1 ? w1 : w0;             // sh == -2: w0
+                v3 = sh == -1 ? w2 : sh == -2 ? w1 : w0;            // sh == -3: w0
+            }
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = rowok & (c4 + e < RW) & (s0 + e >= 0) & (s0 + e < W_in) & (q0 + e >= 0) & (q0 + e < A.ns);
+                if (ok) ok_bits |= 1ull << (4 * k + e);
+                xv[4 * k + e] = vv[e];
             }
         }
-    }
-    __syncthreads();      // flags and the zeroed words are in LDS
-
-    unsigned long long cross_bits = 0;     // what the mask plane holds: the missing predicate, or r_p & c_q on an inner tile
-    unsigned occ0 = 0, occ1 = 0;           // 16 x 16 blocks of the plane that hold a 1: bit 6 (r >> 4) + (c >> 4), 18 per word
-    if constexpr (MASKED) {
+    } else {
 #pragma unroll
         for (int k = 0; k < WD_PER_THREAD; ++k) {
             const int idx = tid + 256 * k;
             const int r = idx / WD_R, c = idx - r * WD_R;
             const int p = P0 + r, q = Q0 + c;
-            bool fr = false, fc = false;
-            if (A.mask_mode == 1) {
-                fr = flg[r] != 0;
-                fc = flg[WD_R + c] != 0;
-            }
-            bool miss, plane;
-            if (inner) {
-                miss = fr | fc;
-                plane = fr & fc;
-            } else {
-                const bool needed = (r < RH) & (c < RW) & (p >= p_lo) & (p < p_hi);
-                // (mval: the explicit map's byte where the map stores the pixel, so `stored` has nothing left to say)
-                miss = needed && missing_from_flags(A, p, q, fr, fc, (bool)((mval_bits >> k) & 1ull), true);
-                plane = miss;
-            }
-            if (miss) miss_bits |= 1ull << k;
-            if (plane) {
-                cross_bits |= 1ull << k;
-                const int b = 6 * (r >> 4) + (c >> 4);
-                if (b < 18) occ0 |= 1u << b;
-                else occ1 |= 1u << (b - 18);
+            const bool inside = (r < RH) & (c < RW) & (p >= 0) & (p < A.ms) & (q >= 0) & (q < A.ns) & (p >= p_lo) & (p < p_hi);
+            const long long off = inside ? mat_offset(A.sig, p, q) : -1;
+            if (off >= 0) ok_bits |= 1ull << k;
+            const long long o = off >= 0 ? off : 0;            // element 0 of the buffer always exists
+            xv[k] = A.sig_is_f64 ? (float)reinterpret_cast<const double*>(A.sig.ptr)[o] : reinterpret_cast<const float*>(A.sig.ptr)[o];
+            if constexpr (MASKED) {
+                if (A.mask_mode == 2) {
+                    const long long om = inside ? mat_offset(A.mask, p, q) : -1;
+                    const unsigned char mv = reinterpret_cast<const unsigned char*>(A.mask.ptr)[om >= 0 ? om : 0];
+                    if (om >= 0 && mv != 0) mval_bits |= 1ull << k;
+                }
             }
         }
     }
+    WD_STAMP(0);          // addresses, loads issued
+    __syncthreads();      // flags and the zeroed words are in LDS
+
+    // flags of the 96 staged rows / columns as bit words (every wave forms its own copy: wave-uniform scalars)
+    unsigned long long rbits_lo = 0, cbits_lo = 0;
+    unsigned rbits_hi = 0, cbits_hi = 0;
+    if constexpr (MASKED) {
+        if (inner) {
+            rbits_lo = __ballot(flg[lane] != 0);
+            rbits_hi = (unsigned)__ballot(lane < 32 && flg[64 + (lane & 31)] != 0);
+            cbits_lo = __ballot(flg[WD_R + lane] != 0);
+            cbits_hi = (unsigned)__ballot(lane < 32 && flg[WD_R + 64 + (lane & 31)] != 0);
+        }
+    }
+    // bits i .. i + len - 1 (len <= 33, i <= 63) of a 96-bit word
+    auto window_bits = [](unsigned long long lo, unsigned hi, int i, int len) -> unsigned long long {
+        unsigned long long w = lo >> i;
+        if (i) w |= (unsigned long long)hi << (64 - i);
+        return w & ((1ull << len) - 1ull);
+    };
+    const bool has_cross = MASKED && inner && (rbits_lo | rbits_hi) != 0 && (cbits_lo | cbits_hi) != 0;
+    unsigned long long cross_bits = 0;     // what the mask plane holds on a general tile: the missing predicate
+    unsigned occ0 = 0, occ1 = 0;           // 16 x 16 blocks of the plane that hold a 1: bit 6 (r >> 4) + (c >> 4), 18 per word
+    if constexpr (MASKED) {
+        if (fast) {
+            const int md = A.max_dist >= 0 ? A.max_dist : min(A.ms, A.ns);
+            const int big_k = max(km, kn);
+            const bool stripes_on = A.sym_upper && A.full;
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                const int id = tid + 256 * k;
+                const int r = id / 24, c4 = (id - r * 24) * 4;
+                const int d0 = (Q0 + c4) - (P0 + r);
+                const bool fr = flg[r] != 0;
+                const unsigned fc4 = *reinterpret_cast<const unsigned*>(flg + WD_R + c4);
+                unsigned pl = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool fc = ((fc4 >> (8 * e)) & 0xffu) != 0;
+                    const bool needed = (r < RH) & (c4 + e < RW);
+                    bool miss, plane;
+                    if (inner) {             // (no plane: the flagged-row x flagged-column term comes from the V table below)
+                        miss = needed & (fr | fc);
+                        plane = false;
+                    } else {
+                        const int d = d0 + e, off = d + (kn - km);
+                        const bool in_d = !A.sym_upper | ((d >= 0) & (d <= md));
+                        miss = needed & (((fr | fc) & in_d) | (stripes_on & (off <= -1) & (off >= -big_k)));
+                        plane = miss;
+                    }
+                    if (miss) miss_bits |= 1ull << (4 * k + e);
+                    if (plane) {
+                        cross_bits |= 1ull << (4 * k + e);
+                        pl = 1u;
+                    }
+                }
+                if (pl) {
+                    const int b = 6 * (r >> 4) + (c4 >> 4);
+                    if (b < 18) occ0 |= 1u << b;
+                    else occ1 |= 1u << (b - 18);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < WD_PER_THREAD; ++k) {
+                const int idx = tid + 256 * k;
+                const int r = idx / WD_R, c = idx - r * WD_R;
+                const int p = P0 + r, q = Q0 + c;
+                bool fr = false, fc = false;
+                if (A.mask_mode == 1) {
+                    fr = flg[r] != 0;
+                    fc = flg[WD_R + c] != 0;
+                }
+                bool miss, plane;
+                if (inner) {
+                    miss = fr | fc;
+                    plane = false;
+                } else {
+                    const bool needed = (r < RH) & (c < RW) & (p >= p_lo) & (p < p_hi);
+                    // (mval: the explicit map's byte where the map stores the pixel, so `stored` has nothing left to say)
+                    miss = needed && missing_from_flags(A, p, q, fr, fc, (bool)((mval_bits >> k) & 1ull), true);
+                    plane = miss;
+                }
+                if (miss) miss_bits |= 1ull << k;
+                if (plane) {
+                    cross_bits |= 1ull << k;
+                    const int b = 6 * (r >> 4) + (c >> 4);
+                    if (b < 18) occ0 |= 1u << b;
+                    else occ1 |= 1u << (b - 18);
+                }
+            }
+        }
+    }
+    WD_STAMP(1);          // barrier, mask bits
     float amax = 0.0f;
 #pragma unroll
     for (int k = 0; k < WD_PER_THREAD; ++k) {
@@ -213,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         if (occ0) atomicOr(&red[1], occ0);
         if (occ1) atomicOr(&red[2], occ1);
     }
+    WD_STAMP(2);          // wait for the loads, maximum
     __syncthreads();
     int ex = 0;
     {
@@ -227,16 +365,44 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         occ = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)red[1]) |
               ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)red[2]) << 18);
     }
+    if (fast) {
+        // heads by truncation, tails exact differences: head + tail carries 21-22 bits either way (cs_corr_mfma_body.inc)
 #pragma unroll
-    for (int k = 0; k < WD_PER_THREAD; ++k) {
-        const int idx = tid + 256 * k;
-        const int r = idx / WD_R, c = idx - r * WD_R;
-        const int o = r * WD_P + c;
-        const float xs = xv[k] * scale;
-        const _Float16 h = (_Float16)xs;
-        xh[o] = h;
-        xl[o] = (_Float16)(xs - (float)h);
-        if constexpr (MASKED) xm[o] = ((cross_bits >> k) & 1ull) ? (_Float16)1.0f : (_Float16)0.0f;
+        for (int k = 0; k < PIECES; ++k) {
+            const int id = tid + 256 * k;
+            const int r = id / 24, c4 = (id - r * 24) * 4;
+            const int o = r * WD_P + c4;
+            const float a0 = xv[4 * k] * scale, a1 = xv[4 * k + 1] * scale, a2 = xv[4 * k + 2] * scale, a3 = xv[4 * k + 3] * scale;
+            const hv2 h01 = __builtin_amdgcn_cvt_pkrtz(a0, a1), h23 = __builtin_amdgcn_cvt_pkrtz(a2, a3);
+            const hv2 t01 = __builtin_amdgcn_cvt_pkrtz(a0 - (float)h01[0], a1 - (float)h01[1]);
+            const hv2 t23 = __builtin_amdgcn_cvt_pkrtz(a2 - (float)h23[0], a3 - (float)h23[1]);
+            uint2 hw, tw;
+            hw.x = __builtin_bit_cast(unsigned, h01);
+            hw.y = __builtin_bit_cast(unsigned, h23);
+            tw.x = __builtin_bit_cast(unsigned, t01);
+            tw.y = __builtin_bit_cast(unsigned, t23);
+            *reinterpret_cast<uint2*>(xh + o) = hw;
+            *reinterpret_cast<uint2*>(xl + o) = tw;
+            if (MASKED && !inner) {
+                const unsigned m4 = (unsigned)(cross_bits >> (4 * k)) & 0xfu;
+                uint2 mw;                                        // 0x3c00 = 1.0 in float16
+                mw.x = ((m4 & 1u) ? 0x3c00u : 0u) | ((m4 & 2u) ? 0x3c000000u : 0u);
+                mw.y = ((m4 & 4u) ? 0x3c00u : 0u) | ((m4 & 8u) ? 0x3c000000u : 0u);
+                *reinterpret_cast<uint2*>(xm + o) = mw;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < WD_PER_THREAD; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx / WD_R, c = idx - r * WD_R;
+            const int o = r * WD_P + c;
+            const float xs = xv[k] * scale;
+            const _Float16 h = (_Float16)xs;
+            xh[o] = h;
+            xl[o] = (_Float16)(xs - (float)h);
+            if (MASKED && !inner) xm[o] = ((cross_bits >> k) & 1ull) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
     }
     if (tid < WD_R) {      // columns 96 .. 111 of every row: zeros
         const uint4 z = {0u, 0u, 0u, 0u};
@@ -246,43 +412,59 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         ph[1] = z;
         pl[0] = z;
         pl[1] = z;
-        if constexpr (MASKED) {
+        if (MASKED && !inner) {
             uint4* pm = reinterpret_cast<uint4*>(xm + tid * WD_P + WD_R);
             pm[0] = z;
             pm[1] = z;
         }
     }
     if constexpr (MASKED) {
-        // per-tile tables of the factorised form (zeros on a general tile: the plane carries the whole predicate)
+        // per-tile tables of the factorised form (zeros on a general tile: the plane carries the whole predicate):
+        //   tab[0..63] nr_i, [64..] RA_i, [128..] RB_i (flagged rows of row i's window: count, their Wa / Wb row sums),
+        //   tab[192..] nc_j, CA_j, CB_j likewise for the columns
         if (tid < 128) {
             float cnt = 0.0f, sa = 0.0f, sb = 0.0f;
             if (inner) {
                 const bool rows = tid < 64;
                 const int i = tid & 63;
-                const int len = rows ? km : kn;
-                const unsigned char* f = flg + (rows ? 0 : WD_R) + i;
                 const float* wa = E.sums + (rows ? 0 : 2 * 33);
                 const float* wb = wa + 33;
-                for (int s = 0; s < len; ++s)
-                    if (f[s]) {
-                        cnt += 1.0f;
-                        sa += wa[s];
-                        sb += wb[s];
-                    }
-                cnt *= rows ? (float)kn : (float)km;
+                for (unsigned long long w = rows ? window_bits(rbits_lo, rbits_hi, i, km) : window_bits(cbits_lo, cbits_hi, i, kn); w; w &= w - 1ull) {
+                    const int t = __builtin_ctzll(w);
+                    cnt += 1.0f;
+                    sa += wa[t];
+                    sb += wb[t];
+                }
             }
             const int base = tid < 64 ? 0 : 3 * 64;
             tab[base + (tid & 63)] = cnt;
             tab[base + 64 + (tid & 63)] = sa;
             tab[base + 128 + (tid & 63)] = sb;
         }
+        // V[set][s][j] = sum over the flagged columns t of column j's window of W_set[s][t] (set: Wa, Wb), in the LDS the plane
+        // would take: what a flagged row p contributes to the cross term of the pixels (p - s, j)
+        if (has_cross) {
+            float* V = reinterpret_cast<float*>(xm);
+            const int kk = km * kn;
+            for (int idx = tid; idx < 2 * km * 64; idx += 256) {
+                const int set = idx >= km * 64 ? 1 : 0;
+                const int rem = idx - set * km * 64;
+                const int sr = rem >> 6, j = rem & 63;
+                const float* wrow = A.w + (1 + set) * kk + sr * kn;
+                float acc = 0.0f;
+                for (unsigned long long w = window_bits(cbits_lo, cbits_hi, j, kn); w; w &= w - 1ull) acc += wrow[__builtin_ctzll(w)];
+                V[(set * 33 + sr) * 64 + j] = acc;
+            }
+        }
     }
+    WD_STAMP(3);          // barrier, split, plane writes, tables
     __syncthreads();
+    WD_STAMP(4);          // barrier
 
     const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int wr0 = 16 * wv;                  // first staged row of the wave's windows
     constexpr int NCB = TWO ? 6 : 4;          // 16-column steps at which a wave's A blocks (16 rows x 32 columns) start
-    const bool any_mask = MASKED && occ != 0ull;
+    const bool any_mask = MASKED && !inner && occ != 0ull;
 
     // ---- all-ones Toeplitz operands of the horizontal pass: B_p[k][n] = 1 for 0 <= 32 p + k - n < kn
     h8 ones_b0, ones_b1;
@@ -364,6 +546,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
     }
 
+    WD_STAMP(5);          // box sums
     // ---- cross term: per template row the wave's 6 (4) A blocks against the row's Toeplitz fragments, loaded from the
     //      image in global memory one row ahead
     f4 accM[4], accC[4];
@@ -409,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
     }
 
+    WD_STAMP(6);          // cross term
     // ---- mask-weighted template sums: the plane against the Wa and the Wb fragments (the plane is exact in float16:
     //      two MFMAs per block and set); blocks whose 16 x 16 sub-blocks hold no flagged pixel are skipped
     f4 KA[4], KB[4];
@@ -467,11 +651,55 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
     }
 
+    if constexpr (MASKED) {
+        if (any_mask) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                KA[c] *= E.unscale[1];
+                KB[c] *= E.unscale[2];
+            }
+        }
+        if (has_cross) {
+            // flagged rows among the wave's input rows wr0 .. wr0 + 14 + km: row p of them lies in the windows of the wave's rows
+            // p - s, 0 <= s < km, and takes V[.][s][j] off the row + column terms of those pixels
+            const float* V = reinterpret_cast<const float*>(xm);
+            unsigned long long wrows = rbits_lo >> wr0;
+            if (wr0) wrows |= (unsigned long long)rbits_hi << (64 - wr0);
+            wrows &= (1ull << (15 + km)) - 1ull;
+            for (; wrows; wrows &= wrows - 1ull) {
+                const int pr = __builtin_ctzll(wrows);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int sr = pr - (4 * g + v);
+                    if ((unsigned)sr < (unsigned)km) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            KA[c][v] -= V[sr * 64 + 16 * c + n];
+                            KB[c][v] -= V[(33 + sr) * 64 + 16 * c + n];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    WD_STAMP(7);          // mask sums
     // ---- epilogue: lane = column n of tile c, rows 4 g + v
     const float u_cs = unscale * E.unscale[0];
     const float u_s2 = 32.0f * unscale;
-    const float sgn = inner ? -1.0f : 1.0f;
-    const float ua = sgn * E.unscale[1], ub = sgn * E.unscale[2];
+    const float kn_f = (float)kn, km_f = (float)km;
+    const int kh = (km - 1) / 2, kw = (kn - 1) / 2;
+    // a tile all of whose 64 x 64 pixels are produced and none forced to zero (cs_device.h pixel_forced_zero): no per-pixel
+    // predicates, addresses by increments
+    const int dmin_t = J0 - (I0 + WD_T - 1), dmax_t = J0 + WD_T - 1 - I0;
+    const bool same_nobs = !A.nobs.ptr || (A.nobs.layout == A.out.layout && A.nobs.ld == A.out.ld && A.nobs.band_lo == A.out.band_lo &&
+                                           A.nobs.band_w == A.out.band_w && A.nobs.row0 == A.out.row0);
+    const bool plain = I0 + WD_T <= A.row_end && J0 >= 0 && J0 + WD_T <= A.ns && dmin_t >= A.out_lo && dmax_t <= A.out_hi && same_nobs &&
+                       (A.full || (I0 >= kh && I0 + WD_T - 1 <= A.ms - km + kh && J0 >= kw && J0 + WD_T - 1 <= A.ns - kn + kw)) &&
+                       (!A.sym_upper || dmin_t + (A.full ? kn - km : 0) >= 0) &&
+                       (!band_out || (dmin_t >= A.out.band_lo && dmax_t < A.out.band_lo + A.out.band_w));
+    const int i_lane = I0 + wr0 + 4 * g, j_lane = J0 + n;
+    const long long o_lane = ((long long)i_lane - A.out.row0) * A.out.ld + (band_out ? j_lane - i_lane - A.out.band_lo : j_lane);
+    const long long o_row = band_out ? A.out.ld - 1 : A.out.ld;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int jl = 16 * c + n;
@@ -486,30 +714,65 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         for (int v = 0; v < 4; ++v) {
             const int il = wr0 + 4 * g + v;
             const int i = I0 + il;
-            if (i >= A.row_end || j < 0 || j >= A.ns) continue;
-            const int d = j - i;
-            if (d < A.out_lo || d > A.out_hi) continue;
+            if (!plain) {
+                if (i >= A.row_end || j < 0 || j >= A.ns) continue;
+                const int d = j - i;
+                if (d < A.out_lo || d > A.out_hi) continue;
+            }
             const float cs = (accM[c][v] + accC[c][v]) * u_cs;
             const float s1 = S1[c][v] * unscale;
             const float s2 = (S2[c][v] * u_s2) * unscale;
             float r, nobs = A.ks.n;
-            if (pixel_forced_zero(A, i, j)) {
+            if (!plain && pixel_forced_zero(A, i, j)) {
                 r = 0.0f;
             } else if (A.xcorr_only) {
                 r = (fabsf(cs) < A.ks.thr) ? 0.0f : cs;
             } else if constexpr (MASKED) {
-                const float nm = tab[il] + un + sgn * NM[c][v];
-                const float ka = tab[64 + il] + uav + ua * KA[c][v];
-                const float kb = tab[128 + il] + ubv + ub * KB[c][v];
+                // missing pixels of the window: nr rows x kn + nc columns x km - nr nc on both (exact small integers), or the plane's
+                const float nr = tab[il];
+                const float nm = nr * kn_f + un * (km_f - nr) + NM[c][v];
+                const float ka = tab[64 + il] + uav + KA[c][v];
+                const float kb = tab[128 + il] + ubv + KB[c][v];
                 r = wide_range_guard(pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks), s2, unscale, A.ks);
                 nobs = A.ks.n - nm;
             } else {
                 r = wide_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
             }
-            store_pixel(A, i, j, r, nobs);
+            if (plain) {
+                const long long o = o_lane + v * o_row + 16 * c;
+                if (A.out_is_f64) reinterpret_cast<double*>(A.out.ptr)[o] = (double)r;
+                else reinterpret_cast<float*>(A.out.ptr)[o] = r;
+                if (A.nobs.ptr) reinterpret_cast<float*>(A.nobs.ptr)[o] = nobs;
+            } else {
+                store_pixel(A, i, j, r, nobs);
+            }
         }
     }
+    WD_STAMP(8);          // epilogue
+#ifdef CS_WD_PROFILE
+    if (lane == 0) {
+        unsigned long long* dst = cs_wd_prof + (blockIdx.x & 63) * 16;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(dst + k, tdelta_[k]);
+        atomicAdd(dst + 15, 1ull);
+    }
+#endif
 }
+
+#ifdef CS_WD_PROFILE
+extern "C" int cs_debug_wide_profile(unsigned long long* out)
+{
+    static unsigned long long all[64 * 16];
+    hipError_t e = hipMemcpyFromSymbol(all, HIP_SYMBOL(cs_wd_prof), sizeof(all));
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < 16; ++k) {
+        out[k] = 0;
+        for (int c = 0; c < 64; ++c) out[k] += all[c * 16 + k];
+    }
+    for (auto& v : all) v = 0;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(cs_wd_prof), all, sizeof(all));
+}
+#endif
 
 // The 160 KB dynamic-LDS ceiling is a per-function, per-device attribute: set it the first time a kernel is
 // launched on a device.

@@ -66,6 +66,7 @@ struct MfmaWideWeights {
     float unscale[3];
     const float* sums;
     int plane_only;
+    int plane_only_staging;      // ... and stage every tile pixel by pixel with the general predicate (test switch)
 };
 bool corr_mfma_wide_fits(int km, int kn);
 int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipStream_t s);

@@ -65,10 +65,13 @@ def _signal(rng, shape, kind):
     ((97, 201), (33, 7), "gamma"), ((256, 256), (27, 27), "tiny"), ((256, 256), (29, 29), "huge"),
     ((190, 190), (19, 33), "gamma"), ((222, 111), (31, 21), "hic"), ((400, 400), (31, 31), "gamma"),
 ])
-@pytest.mark.parametrize("full", [True, False])
-def test_dense_maps_match_oracle(shape, kshape, kind, full):
+@pytest.mark.parametrize("full", [True, False, "slow"])
+def test_dense_maps_match_oracle(shape, kshape, kind, full, monkeypatch):
     """Unmasked dense float32 maps: partial tiles, frames narrower than a tile, valid-mode margins, rectangular
     templates (one and two Toeplitz passes), data far from unit scale."""
+    if full == "slow":                       # the pixel-by-pixel staging of every tile (CHROMOSIGHT_HIP_WIDE_SLOW=1)
+        monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_SLOW", "1")
+        full = True
     rng = np.random.default_rng(shape[0] * 1000 + shape[1] + kshape[0])
     sig = _signal(rng, shape, kind).astype(np.float32)
     kern = template(kshape)
@@ -119,13 +122,16 @@ def _masked_band(n, md, keep, seed, frac=0.04):
 
 @pytest.mark.parametrize("n,md,ksize,tol", [(900, 120, 21, 0.75), (1500, 400, 21, 0.5), (1300, 500, 33, 0.75),
                                              (700, 60, 19, 0.25), (400, 399, 25, 0.75), (1100, 300, 27, 0.5)])
-@pytest.mark.parametrize("plane", [False, True])
+@pytest.mark.parametrize("plane", [False, True, "slow"])
 def test_banded_maps_with_bin_masks(n, md, ksize, tol, plane, monkeypatch):
     """The detect configuration: CSR in, band in / band out on the device, per-bin masks, full, sym_upper, coefficients
     and n_obs (through the p-values).  plane=False: inner tiles take the factorised form (1-D tables minus the cross
     plane), the rim the general plane; plane=True (CHROMOSIGHT_HIP_WIDE_PLANE=1): the general plane everywhere -- both
-    against the oracle and against each other."""
-    if plane:
+    against the oracle and against each other; "slow" (CHROMOSIGHT_HIP_WIDE_SLOW=1): every tile staged pixel by pixel
+    with the general predicate (what the tiles on the frame of the matrix and explicit masks take)."""
+    if plane == "slow":
+        monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_SLOW", "1")
+    elif plane:
         monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_PLANE", "1")
     sig, valid, miss, band = _masked_band(n, md, ksize, n + md)
     kern = template((ksize, ksize))
@@ -182,6 +188,41 @@ def test_inter_block_and_explicit_mask():
     finally:
         del os.environ["CHROMOSIGHT_HIP_NO_WIDE"]
     assert np.abs(got - ref).max() < 5e-6
+
+
+def test_narrow_maps_and_f64_bands():
+    """Maps narrower than a 16-byte piece (general staging), a float64 band container and a band whose rows start at
+    every alignment (odd row pitch)."""
+    rng = np.random.default_rng(77)
+    kern = template((19, 19))
+    for shape in ((60, 3), (3, 60), (40, 5)):
+        sig = rng.gamma(2.0, 1.0, size=shape).astype(np.float32)
+        got, _ = cud.normxcorr2(sig, kern, full=True)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, shape[0], full=True)
+        assert_parity(got, want, cond, "f32", f"wide narrow {shape}", max_ill_frac=1.0)
+    dev = get_device()
+    n, md, bw = 700, 150, 150 + 19 + 1
+    band = np.zeros((n, bw + 3))                                    # float64, odd pitch
+    d = np.arange(bw)
+    band[:, :bw] = np.minimum(rng.gamma(20, 0.05, size=(n, bw)), 10.0)
+    for i in range(n):
+        band[i, :bw][i + d >= n] = 0
+    miss = (rng.random(n) < 0.03).astype(np.uint8)
+    band[miss.astype(bool)] = 0
+    for i in range(n):
+        cols = i + d
+        band[i, :bw][miss[np.minimum(cols, n - 1)].astype(bool)] = 0
+    out_w = md + 1
+    d_sig, d_out, d_miss = dev.to_device(band), dev.zeros((n, out_w), np.float32), dev.to_device(miss)
+    engine.run_normxcorr2(dev, CsMatrix(d_sig.ptr, np_dtype_code(np.float64), LAYOUT_BAND, band.shape[1], 0, bw), (n, n),
+                          engine.KernelSpec(kern), CsMatrix(d_out.ptr, np_dtype_code(np.float32), LAYOUT_BAND, out_w, 0, out_w),
+                          full=True, sym_upper=True, max_dist=md, mask_mode=MASK_BINS, miss_row=d_miss, miss_col=d_miss,
+                          missing_tol=0.5, precision="f32")
+    assert last_kernel() == KERNEL_MFMA_WIDE
+    want, cond = c_oracle.normxcorr2_band(band, n, 0, bw, kern, 0, n, 0, out_w, max_dist=md, miss_row=miss, miss_col=miss,
+                                          missing_tol=0.5)
+    assert_parity(d_out.download(), want, cond, "f32", "wide f64 band, odd pitch", max_ill_frac=ILL_MASKED)
 
 
 def test_xcorr2_wide_template():

@@ -32,6 +32,7 @@
 // One workgroup (4 waves) = one 64 x 64 output tile; wave w owns rows 16 w .. 16 w + 15 and four 16-column tiles.
 // LDS 66 KB (masked) / 43 KB: two workgroups per CU; tiles are dealt to the 8 XCDs in contiguous ranges.
 #include "cs_device.h"
+#include <algorithm>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -68,7 +69,7 @@ __device__ unsigned long long cs_wd_prof[64 * 16];
 #define WD_STAMP(k)                                                        \
     do {                                                                   \
         const unsigned long long now_ = __builtin_readcyclecounter();      \
-        tdelta_[k] = now_ - tprev_;                                        \
+        tdelta_[k] += now_ - tprev_;                                        \
         tprev_ = now_;                                                     \
     } while (0)
 #else
@@ -119,17 +120,20 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-
+    const bool band_out = A.out.layout == 1;
     // ---- tile of this workgroup: XCD x (workgroups x, x + 8, ...) takes the x-th eighth of the row-major tile list
+    // (persistent workgroups were tried: inlined, the tile loop held everything that does not depend on the tile index in
+    // registers -- 256 + 168 spilled; as a called function the arguments went through scratch; and the cost of one workgroup
+    // per tile is small: the per-phase cycle stamps account for the whole call at the clock the kernel runs at)
     const int n_tiles = A.tiles_x * A.tiles_y;
     const int per = (int)gridDim.x >> 3;
     const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (t >= n_tiles) return;
+    {
     const int by = t / A.tiles_x;
     const int bx = t - by * A.tiles_x;
     const int I0 = A.row_begin + by * WD_T;
     if (I0 >= A.row_end) return;
-    const bool band_out = A.out.layout == 1;
     const int J0 = band_out ? I0 + A.out_lo + bx * WD_T : bx * WD_T;
     if (J0 >= A.ns || J0 + WD_T <= 0) return;
     if (J0 + WD_T - 1 - I0 < A.out_lo || J0 - (I0 + WD_T - 1) > A.out_hi) return;   // no produced diagonal
@@ -171,25 +175,49 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     //     per-bin flags on a tile whose staged pixels all lie inside the matrix (no frame: the predicate is the flags, the
     //     diagonal limits and the sub-diagonal stripes -- cs_device.h missing_from_flags for in-matrix pixels).
     //   * general: one pixel at a time from clamped addresses, the missing predicate in full (frames, explicit maps).
-    constexpr int PIECES = WD_PER_THREAD / 4;             // 9
+    constexpr int FPIECES = 10;             // 16-byte pieces per thread of the row-regular form
     const bool band_in = A.sig.layout == 1;
     const int W_in = band_in ? A.sig.band_w : A.ns;       // slots a stored row holds
     const bool frame_free = P0 >= 0 && P0 >= p_lo && P0 + RH <= A.ms && P0 + RH <= p_hi && Q0 >= 0 && Q0 + RW <= A.ns;
     const bool fast = !E.plane_only_staging && W_in >= 4 && (!MASKED || (A.mask_mode == 1 && frame_free));
-    float xv[WD_PER_THREAD];
+    float xv[4 * FPIECES];           // (the general form fills 36 slots; the ok bits of the others stay 0)
+#pragma unroll
+    for (int k = WD_PER_THREAD; k < 4 * FPIECES; ++k) xv[k] = 0.0f;
     unsigned long long ok_bits = 0, miss_bits = 0, mval_bits = 0;
+    // row-regular form: thread (tr, tc) of 10 x 24 fetches the 4 pixels from column 4 tc of the rows tr, tr + 10, ..., tr + 90
+    // (16 threads idle): the address advances by a constant from piece to piece
+    const int tr = tid / 24, tc4 = (tid - tr * 24) * 4;
+    const bool stager = tid < 240;
     if (fast) {
         const int row_lo = max(0, p_lo), row_hi = min(A.ms, p_hi);
+        const int lo_in = band_in ? A.sig.band_lo : 0;
+        // every one of the 96 x 96 pixels is stored (rows and columns beyond the 63 + km x 63 + kn the windows reach hold real
+        // pixels then: they meet zero weights only)
+        const bool whole = P0 >= row_lo && P0 + WD_R <= row_hi && Q0 >= 0 && Q0 + WD_R <= A.ns &&
+                           (!band_in || (Q0 - (P0 + WD_R - 1) - lo_in >= 0 && Q0 + WD_R - 1 - P0 - lo_in < W_in));
+        const long long step = 10 * A.sig.ld - (band_in ? 10 : 0);
+        const long long at0 = ((long long)(P0 + tr) - A.sig.row0) * A.sig.ld + (band_in ? (Q0 + tc4) - (P0 + tr) - lo_in : Q0 + tc4);
 #pragma unroll
-        for (int k = 0; k < PIECES; ++k) {
-            const int id = tid + 256 * k;
-            const int r = id / 24, c4 = (id - r * 24) * 4;
-            const int p = P0 + r, q0 = Q0 + c4;
-            const bool rowok = (r < RH) & (p >= row_lo) & (p < row_hi);
-            const int pc = min(max(p, row_lo), row_hi - 1);
-            const int s0 = band_in ? q0 - p - A.sig.band_lo : q0;
-            const int s0c = min(max(s0, 0), W_in - 4);
-            const long long at = ((long long)pc - A.sig.row0) * A.sig.ld + s0c;
+        for (int k = 0; k < FPIECES; ++k) {
+            const int r = tr + 10 * k;
+            const bool live = stager && (k < 9 || r < WD_R);
+            long long at = at0 + k * step;
+            int sh = 0;
+            bool oks[4] = {live, live, live, live};
+            if (!whole) {
+                const int p = P0 + r, q0 = Q0 + tc4;
+                const bool rowok = live & (r < RH) & (p >= row_lo) & (p < row_hi);
+                const int pc = min(max(p, row_lo), row_hi - 1);
+                const int s0 = band_in ? q0 - p - lo_in : q0;
+                const int s0c = min(max(s0, 0), W_in - 4);
+                at = ((long long)pc - A.sig.row0) * A.sig.ld + s0c;
+                sh = s0 - s0c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    oks[e] = rowok & (tc4 + e < RW) & (s0 + e >= 0) & (s0 + e < W_in) & (q0 + e >= 0) & (q0 + e < A.ns);
+            } else if (!live) {
+                at = 0;
+            }
             float v0, v1, v2, v3;
             if (A.sig_is_f64) {
                 const double* src = reinterpret_cast<const double*>(A.sig.ptr) + at;
@@ -205,7 +233,6 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
                 v2 = v[2];
                 v3 = v[3];
             }
-            const int sh = s0 - s0c;
             if (sh != 0) {                      // (a piece on the rim of the stored run: element e sits at position sh + e of the fetch)
                 const float w0 = v0, w1 = v1, w2 = v2, w3 = v3;
                 v0 = sh == 1 ? w1 : sh == 2 ? w2 : w3;              // sh in 1 .. 3 (positions beyond 3 are not stored: zeroed below)
@@ -216,8 +243,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
             const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool ok = rowok & (c4 + e < RW) & (s0 + e >= 0) & (s0 + e < W_in) & (q0 + e >= 0) & (q0 + e < A.ns);
-                if (ok) ok_bits |= 1ull << (4 * k + e);
+                if (oks[e]) ok_bits |= 1ull << (4 * k + e);
                 xv[4 * k + e] = vv[e];
             }
         }
@@ -270,9 +296,8 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
             const int big_k = max(km, kn);
             const bool stripes_on = A.sym_upper && A.full;
 #pragma unroll
-            for (int k = 0; k < PIECES; ++k) {
-                const int id = tid + 256 * k;
-                const int r = id / 24, c4 = (id - r * 24) * 4;
+            for (int k = 0; k < FPIECES; ++k) {
+                const int r = min(tr + 10 * k, WD_R - 1), c4 = min(tc4, WD_R - 4);      // (idle threads, pieces beyond row 95: ok bits 0)
                 const int d0 = (Q0 + c4) - (P0 + r);
                 const bool fr = flg[r] != 0;
                 const unsigned fc4 = *reinterpret_cast<const unsigned*>(flg + WD_R + c4);
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     WD_STAMP(1);          // barrier, mask bits
     float amax = 0.0f;
 #pragma unroll
-    for (int k = 0; k < WD_PER_THREAD; ++k) {
+    for (int k = 0; k < 4 * FPIECES; ++k) {
         // the reference requires 0 at missing pixels (check_missing_mask); enforce it
         const float x = (((ok_bits & ~miss_bits) >> k) & 1ull) ? xv[k] : 0.0f;
         xv[k] = x;
@@ -368,10 +393,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     if (fast) {
         // heads by truncation, tails exact differences: head + tail carries 21-22 bits either way (cs_corr_mfma_body.inc)
 #pragma unroll
-        for (int k = 0; k < PIECES; ++k) {
-            const int id = tid + 256 * k;
-            const int r = id / 24, c4 = (id - r * 24) * 4;
-            const int o = r * WD_P + c4;
+        for (int k = 0; k < FPIECES; ++k) {
+            const int r = tr + 10 * k;
+            if (!stager || (k == 9 && r >= WD_R)) continue;
+            const int o = r * WD_P + tc4;
             const float a0 = xv[4 * k] * scale, a1 = xv[4 * k + 1] * scale, a2 = xv[4 * k + 2] * scale, a3 = xv[4 * k + 3] * scale;
             const hv2 h01 = __builtin_amdgcn_cvt_pkrtz(a0, a1), h23 = __builtin_amdgcn_cvt_pkrtz(a2, a3);
             const hv2 t01 = __builtin_amdgcn_cvt_pkrtz(a0 - (float)h01[0], a1 - (float)h01[1]);
@@ -700,51 +725,54 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     const int i_lane = I0 + wr0 + 4 * g, j_lane = J0 + n;
     const long long o_lane = ((long long)i_lane - A.out.row0) * A.out.ld + (band_out ? j_lane - i_lane - A.out.band_lo : j_lane);
     const long long o_row = band_out ? A.out.ld - 1 : A.out.ld;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int jl = 16 * c + n;
-        const int j = J0 + jl;
-        float un = 0.0f, uav = 0.0f, ubv = 0.0f;
-        if constexpr (MASKED) {
-            un = tab[3 * 64 + jl];
-            uav = tab[4 * 64 + jl];
-            ubv = tab[5 * 64 + jl];
+    // the window sums of pixel (c, v) -> coefficient (cs_device.h: the one-rsq form, the literal function next to a zeroing threshold)
+    auto coefficient = [&](int c, int v, float& nobs) -> float {
+        const int il = wr0 + 4 * g + v, jl = 16 * c + n;
+        const float cs = (accM[c][v] + accC[c][v]) * u_cs;
+        const float s1 = S1[c][v] * unscale;
+        const float s2 = (S2[c][v] * u_s2) * unscale;
+        nobs = A.ks.n;
+        float r;
+        if (A.xcorr_only) {
+            r = (fabsf(cs) < A.ks.thr) ? 0.0f : cs;
+        } else if constexpr (MASKED) {
+            // missing pixels of the window: nr rows x kn + nc columns x km - nr nc on both (exact small integers), or the plane's
+            const float nr = tab[il], nc = tab[3 * 64 + jl];
+            const float nm = nr * kn_f + nc * (km_f - nr) + NM[c][v];
+            const float ka = tab[64 + il] + tab[4 * 64 + jl] + KA[c][v];
+            const float kb = tab[128 + il] + tab[5 * 64 + jl] + KB[c][v];
+            r = wide_range_guard(pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks), s2, unscale, A.ks);
+            nobs = A.ks.n - nm;
+        } else {
+            r = wide_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
         }
+        return r;
+    };
+    if (plain) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int il = wr0 + 4 * g + v;
-            const int i = I0 + il;
-            if (!plain) {
-                if (i >= A.row_end || j < 0 || j >= A.ns) continue;
-                const int d = j - i;
-                if (d < A.out_lo || d > A.out_hi) continue;
-            }
-            const float cs = (accM[c][v] + accC[c][v]) * u_cs;
-            const float s1 = S1[c][v] * unscale;
-            const float s2 = (S2[c][v] * u_s2) * unscale;
-            float r, nobs = A.ks.n;
-            if (!plain && pixel_forced_zero(A, i, j)) {
-                r = 0.0f;
-            } else if (A.xcorr_only) {
-                r = (fabsf(cs) < A.ks.thr) ? 0.0f : cs;
-            } else if constexpr (MASKED) {
-                // missing pixels of the window: nr rows x kn + nc columns x km - nr nc on both (exact small integers), or the plane's
-                const float nr = tab[il];
-                const float nm = nr * kn_f + un * (km_f - nr) + NM[c][v];
-                const float ka = tab[64 + il] + uav + KA[c][v];
-                const float kb = tab[128 + il] + ubv + KB[c][v];
-                r = wide_range_guard(pearson_masked_lean(cs, s1, s2, nm, ka, kb, A.ks), s2, unscale, A.ks);
-                nobs = A.ks.n - nm;
-            } else {
-                r = wide_range_guard(pearson_nomask_lean(cs, s1, s2, A.ks), s2, unscale, A.ks);
-            }
-            if (plain) {
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float nobs;
+                const float r = coefficient(c, v, nobs);
                 const long long o = o_lane + v * o_row + 16 * c;
                 if (A.out_is_f64) reinterpret_cast<double*>(A.out.ptr)[o] = (double)r;
                 else reinterpret_cast<float*>(A.out.ptr)[o] = r;
                 if (A.nobs.ptr) reinterpret_cast<float*>(A.nobs.ptr)[o] = nobs;
-            } else {
-                store_pixel(A, i, j, r, nobs);
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = J0 + 16 * c + n;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = I0 + wr0 + 4 * g + v;
+                if (i >= A.row_end || j < 0 || j >= A.ns) continue;
+                const int d = j - i;
+                if (d < A.out_lo || d > A.out_hi) continue;
+                float nobs;
+                const float r = coefficient(c, v, nobs);
+                store_pixel(A, i, j, pixel_forced_zero(A, i, j) ? 0.0f : r, nobs);
             }
         }
     }
@@ -757,6 +785,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         atomicAdd(dst + 15, 1ull);
     }
 #endif
+    }
 }
 
 #ifdef CS_WD_PROFILE

@@ -173,6 +173,9 @@ KERNELS = {
         "masked matrix-core tile kernel: the same float16-pair contraction, per-bin missing masks factorised into per-row / "
         "per-column template sums + correction records (mask_prep_kernel), cross term on the matrix cores"),
     6: ("corr_sep_kernel", "separable evaluation of exactly rank-1 templates"),
+    7: ("corr_mfma_wide_kernel<MASKED,TWO>",
+        "two-pass matrix-core kernel for templates with a side of 18 .. 33 (cs_corr_wide.hip): two k = 32 Toeplitz passes per template "
+        "row, weight fragments from L2, per-bin masks factorised per tile (1-D tables + a V table for flagged row x flagged column)"),
 }
 MFMA_KERNELS = (3, 4, 5)
 
@@ -209,6 +212,36 @@ def time_steps(dev, step, sync, steps, warmup, dist=None, local_rank=0):
         dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
     return elapsed, dev.elapsed_ms(ev0, ev1) / steps
+
+
+def wide_template(k):
+    """A full-rank k x k template (a blob on a gradient plus seeded noise): what `--win-size k` makes of the loops template in
+    spirit -- the same generator as tools/time_wide.py and tests/test_gpu_wide.py."""
+    rng = np.random.default_rng(1000 * k)
+    i, j = np.indices((k, k))
+    c = (k - 1) / 2
+    return 0.4 + np.exp(-((i - c) ** 2 + (j - c) ** 2) / (0.08 * k * k + 1)) + 0.02 * (i - j) + 0.15 * rng.normal(size=(k, k))
+
+
+def time_wide_templates(dev, wl, sync, sizes=(21, 33), steps=10):
+    """The resident workload `wl` under templates with a side above 17 (`--win-size`, reference cli/chromosight.py:365-370,
+    preprocessing.py:731-807): kernel time by HIP events, the kernel that served it, and the fraction of the FP32 roof at the
+    template's own 2 k^2 + 8 k flop per pixel (SURVEY 8d's count at k)."""
+    out = {}
+    keep = wl.kspec
+    try:
+        for k in sizes:
+            wl.kspec = wl.engine.KernelSpec(wide_template(k))
+            _, ms = time_steps(dev, wl.step, sync, steps, 3)
+            kid = int(dev.lib.cs_last_kernel(dev.ctx))
+            flop = 2 * k * k + 8 * k
+            tf = flop * wl.pixels / (ms * 1e-3) / 1e12
+            out[f"{k}x{k}"] = {"kernel_ms": round(ms, 4), "gpixel_per_s": round(wl.pixels / ms / 1e6, 1), "kernel": KERNELS.get(kid, ("?", ""))[0],
+                               "kernel_id": kid, "flop_per_pixel": flop, "achieved_tflops": round(tf, 1),
+                               "frac_fp32_roof": round(tf / FP32_PEAK_TFLOPS, 4)}
+    finally:
+        wl.kspec = keep
+    return out
 
 
 def gpu_clocks():
@@ -290,7 +323,10 @@ def roofline_of(wl, kernel_ms, kernel_id, precision, traffic=None, traffic_note=
     achieved_gbs = wl.bytes_per_pixel * wl.pixels / (kernel_ms * 1e-3) / 1e9
     roof = {
         "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
-        "frac": round(achieved_tf / peak_tf, 4), "traffic": traffic, "traffic_note": traffic_note,
+        "frac": round(achieved_tf / peak_tf, 4),
+        # PMC counters cannot be read from inside the timed process: `traffic` (HBM bytes of THIS run's launches) stays null, and the
+        # figure of the committed rocprofv3 --pmc passes of the same command on the builder's box sits beside it under its own name
+        "traffic": None, "traffic_profiled": traffic, "traffic_note": traffic_note,
         "kernel": name, "kernel_id": kernel_id,
         "peak_kind": ("FP32: dense f32 MFMA = vector FMA peak, the roof of a float32-exact evaluation of 714 flop/pixel; "
                       "the flops actually executed are priced under `executed`" if precision == "f32" else "FP64 vector peak"),
@@ -526,6 +562,20 @@ def time_genome(args, rank, local_rank, world, dist, torch, steps, warmup):
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same steps one by one (each bracketed by the synchronisation of the timed region), outside the timed region: median, minimum
+    # and the list beside the mean -- a step that ends on host threads has modes (profiles/r05_genome_step_modes.txt), and the mean of
+    # eight steps does not say which one a box was in
+    singles = []
+    for _ in range(min(max(steps, 4), 16)):
+        sync()
+        t1 = time.perf_counter()
+        rec = g.step()
+        sync()
+        singles.append((time.perf_counter() - t1) * 1e3)
+    if dist is not None:
+        t = torch.tensor(singles, dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        singles = [float(x) for x in t.tolist()]
     # per-rank phases, outside the timed region (a device synchronisation between staging and detection would cost the
     # timed steps their overlap): staging until its kernels are done, detection without the exchanges, the exchanges
     phases = []
@@ -572,6 +622,9 @@ def time_genome(args, rank, local_rank, world, dist, torch, steps, warmup):
         "detect_wallclock_c4": detect_c4,
         "transport": transport, "per_rank": per_rank,
         "value": round(pixels * steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "ms_per_genome": round(elapsed / steps * 1e3, 2),
+        "single_steps_ms": {"median": round(float(np.median(singles)), 3), "min": round(min(singles), 3), "max": round(max(singles), 3),
+                            "steps": [round(x, 3) for x in singles],
+                            "note": "the same step timed one at a time (synchronised on both sides, max over ranks), outside the timed region"},
         "n_gpus": world, "steps": steps, "scaling": "strong",
         "workload": "C4: 200000 bins in 23 blocks (hg38 proportions), 2 kb bins, max_dist 1000 bins, 2 % unbalanced bins, "
                     "planted loops, pixel table resident in HBM; per step and per pattern (loops, borders x3): band "
@@ -907,6 +960,14 @@ def main():
                    "warmup": 3, "ms_per_step": round(el4 / steps4 * 1e3, 4), "kernel_ms": round(ms4, 4), "scaling": "weak",
                    "workload": w4.desc, "pixels_per_step_per_gpu": w4.pixels,
                    "roofline": roofline_of(w4, ms4, id4, args.precision, t4, t4_note)}
+            if world == 1:
+                # templates above 17 x 17 on the same resident band (north_star: "small (<= ~21 x 21) pattern kernel"; `--win-size`)
+                try:
+                    extras["wide_templates"] = {"c4p_masked_band": time_wide_templates(dev, w4, full_sync),
+                                                "note": "cs_corr_wide.hip: two k = 32 Toeplitz passes per template row on the matrix cores; "
+                                                        "kernel ms by HIP events over 10 launches; FP32 roof 157.3 TFLOP/s at 2 k^2 + 8 k flop/pixel"}
+                except Exception as exc:
+                    extras["wide_templates"] = {"error": repr(exc)}
             del w4
         except Exception as exc:
             c4p = {"error": repr(exc)}
@@ -966,6 +1027,8 @@ def main():
             out["north_star_c4p_split"] = extras["north_star_c4p_split"]
         if c3 is not None:
             out["c3_from_csr"] = c3
+        if "wide_templates" in extras:
+            out["wide_templates"] = extras["wide_templates"]
         if genome is not None:
             out["sharded_genome"] = genome
         if not args.no_cpu_baseline and world == 1:     # reported extras: rank 0 at N = 1 only
@@ -980,6 +1043,21 @@ def main():
                 out["quantify_c5"] = q
             except Exception as exc:
                 out["quantify_c5"] = {"error": repr(exc)}
+            try:
+                # C2 in float64 arithmetic (the reference's own type) and under templates above 17 x 17, on fresh resident maps
+                w64 = Workload("c2", dev, rank, "f64", args.size)
+                _, ms64 = time_steps(dev, w64.step, full_sync, 5, 2)
+                out["c2_f64"] = {"kernel_ms": round(ms64, 4), "gpixel_per_s": round(w64.pixels / ms64 / 1e6, 1),
+                                 "kernel": KERNELS.get(int(dev.lib.cs_last_kernel(dev.ctx)), ("?", ""))[0],
+                                 "frac_fp64_roof": round(FLOP_PER_PIXEL_17 * w64.pixels / (ms64 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                 "note": "the same map and template in float64 arithmetic and containers (packed-FMA streaming kernel)"}
+                del w64
+                w32 = Workload("c2", dev, rank, "f32", args.size)
+                if "wide_templates" in out and isinstance(out["wide_templates"], dict):
+                    out["wide_templates"]["c2_dense_map"] = time_wide_templates(dev, w32, full_sync)
+                del w32
+            except Exception as exc:
+                out["c2_f64"] = {"error": repr(exc)}
             try:
                 out["api_call_ms"] = api_call_ms(wl)
                 out["api_call_note"] = ("host float32 ndarray in (pageable source, uploaded in 12 row slabs), float64 ndarray out "

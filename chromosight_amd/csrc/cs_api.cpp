@@ -76,6 +76,9 @@ struct cs_ctx {
     // cs_detect_foci_blocks in two calls (cs_foci_params.reserved & 2: the prepare form): what the prepare form enqueued is valid for a
     // call with this key
     bool prep_pending = false, skip_prep_launch = false;
+    // the float64 argument blocks a prepare form uploaded from: the copy on a side lane may still be reading them when the
+    // prepare form returns, so they live here until the next foci entry on this context
+    std::vector<cs::CorrArgs<double>> prep_tab_keep;
     // the mask tables of all blocks of a multi-block tile launch in one launch: while set, prepare_regular_mask<float> appends a
     // block's arguments and its number of workgroups here instead of launching (cs::launch_mask_prep_batch)
     std::vector<cs::MaskPrepArgs<float>>* prep_collect = nullptr;
@@ -993,7 +996,10 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         rc = -1;
 #endif
     } else if (allow_fast && A.w_rank1 && !A.xcorr_only && !std::getenv("CHROMOSIGHT_HIP_NO_SEPARABLE") &&
-               cs::corr_sep_fits(A.km, A.kn, A.mask_mode != 0)) {
+               cs::corr_sep_fits(A.km, A.kn, A.mask_mode != 0) &&
+               !(mfma_wide_wanted(A) && A.out.layout == CS_LAYOUT_BAND && A.out.band_w >= 512 && !std::getenv("CHROMOSIGHT_HIP_SEPARABLE_FIRST"))) {
+        // (an outer product that also fits the two-pass matrix-core kernel: that one on wide bands -- measured on the
+        // 31 x 31 stripes, profiles/r06_template_kernels.txt: 1001 diagonals 5.40 vs 6.92 ms, 234 diagonals 0.577 vs 0.517)
         // templates without an unrolled instance that are an outer product (31 x 31 stripes): separable sums
         ctx->last_kernel = CS_KERNEL_SEPARABLE;
         cs::corr_sep_tile(&tw, &th);
@@ -2187,6 +2193,9 @@ static int check_foci_args(cs_ctx* ctx, const cs_matrix* signal, const cs_kernel
                            const cs_foci_params* fp)
 {
     if (!signal || !kernel || !p || !fp) return fail(ctx, CS_ERR_INVALID, "null argument");
+    // (every foci entry shares d_pool, the candidate counters and the argument tables with a pending prepare form of
+    // cs_detect_foci_blocks: whatever runs in between invalidates it -- that entry notes the flag before its own checks)
+    ctx->prep_pending = false;
     // (every foci entry shares the context's count words, block tables and record pool with an asynchronous batch)
     if (ctx->nb_pending) return fail(ctx, CS_ERR_INVALID, "an asynchronous batch is pending on this context: cs_detect_foci_batch_finish first");
     if (p->mask_mode == CS_MASK_EXPLICIT) return fail(ctx, CS_ERR_UNSUPPORTED, "device foci need per-bin masks or none");
@@ -2943,6 +2952,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
                 tab_uploaded = true;
             }
             if (prepare_only) {
+                ctx->prep_tab_keep.swap(tab);           // (the source of the asynchronous upload above outlives this call)
                 ctx->prep_key = key;
                 ctx->prep_pending = true;
                 return CS_OK;

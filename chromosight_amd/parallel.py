@@ -155,7 +155,14 @@ def native_comm():
     return _COMMS[key]
 
 
+# > 0 while a caller that asked for a purely local run is inside the genome drivers (genome_step(local=True): pipeline.detect):
+# an initialised process group is then none of their business -- no sharding of the blocks, no collective
+_LOCAL_DEPTH = [0]
+
+
 def _world():
+    if _LOCAL_DEPTH[0] > 0:
+        return None, 0, 1
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -572,11 +579,19 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     return results
 
 
-def genome_step(genome, kernel_configs, owned=None, tsvd=None):
-    """One detect step of a sharded genome: stage_genome + detect_patterns, the results of detect_patterns.  For the usual
+def genome_step(genome, kernel_configs, owned=None, tsvd=None, local=False):
+    """One detect step of a sharded genome: stage_genome + detect_patterns, the results of detect_patterns.
+    local=True: this process alone, whatever process group is initialised -- every block, no collective (pipeline.detect: a
+    call one rank may make on its own, as the reference's detect is).  For the usual
     pair of configurations (a 2-D pattern and a 1-D pattern with several templates, single iterations) every step after the
     first is ONE native call on the arguments the first step used (chromosight_amd/plan.py: cs_run_calls) plus one record
     exchange per configuration; anything else -- and any step whose call list reports an error -- takes the two calls."""
+    if local:
+        _LOCAL_DEPTH[0] += 1
+        try:
+            return genome_step(genome, kernel_configs, owned=owned, tsvd=tsvd)
+        finally:
+            _LOCAL_DEPTH[0] -= 1
     from . import plan as _plan
     dist, rank, world = _world()
     if owned is None:

@@ -968,7 +968,9 @@ def detect(cool, kernel_config, tsvd=None, smooth=False, band_dtype=np.float64, 
         # chromosight_amd/plan.py -- every call after the first on this DeviceCool as one native call list); the per-block
         # machinery below keeps --inter, --smooth-trend and the runs that return windows.
         from . import parallel
-        rec = parallel.genome_step(dcool, [kernel_config], tsvd=tsvd)[0]
+        # (local: `detect` is this process's call -- under an initialised process group it neither shards nor gathers; the sharded
+        # driver is parallel.detect_genome / genome_step)
+        rec = parallel.genome_step(dcool, [kernel_config], tsvd=tsvd, local=True)[0]
         if rec.shape[0] == 0:
             return pd.DataFrame(columns=OUTPUT_COLUMNS)
         first = np.asarray(off, dtype=np.int64)[rec[:, 0].astype(np.int64)]

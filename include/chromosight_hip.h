@@ -66,9 +66,13 @@ enum { CS_LAYOUT_DENSE = 0, CS_LAYOUT_BAND = 1, CS_LAYOUT_BAND_LAZY = 2 /* see c
         * of d_ptr (weights, distance law and its reciprocals, first genome bin, cap): what cs_stage_blocks writes for a block with
         * band32_counts = 1 -- in the SAME pass over the pixel table that reduces the distance law.  Balancing
         * (contacts_map.py:531-540) and the detrend (preprocessing.py:296-302) are applied by the reader to the pixels it
-        * fetches, with the operations of the staging pass in their order (bit for bit the detrended band): the masked float32
-        * tile kernel behind cs_normxcorr2 / cs_detect_foci* while it splits a landed tile, the float64 kernels through the
-        * block's CS_LAYOUT_BAND_LAZY descriptor.  band_lo 0, row0 0, CS_F32.  Every other consumer refuses the layout
+        * fetches.  The float64 kernels (exact re-scoring, window statistics: through the block's CS_LAYOUT_BAND_LAZY
+        * descriptor) use the operations of the staging pass in their order: bit for bit the detrended band.  The masked float32
+        * tile kernel behind cs_normxcorr2 / cs_detect_foci* multiplies float32 copies of the weights and reciprocals while it
+        * splits a landed tile: within 6 units in the last place of the float32 band (and the float64 expression where a
+        * product comes within 2e-6 of the cap, a discrete decision), so its maps and candidate screens differ from those on
+        * a CS_LAYOUT_BAND_PADDED band by float32 rounding -- inside cs_foci_params.rescore_margin, which is what decides a
+        * candidate (tests/test_gpu_counts_band.py).  band_lo 0, row0 0, CS_F32.  Every other consumer refuses the layout
         * (CS_ERR_INVALID / CS_ERR_UNSUPPORTED). */
        CS_LAYOUT_BAND_COUNTS = 4,
        /* the first band_w diagonals of a wider band of counts (same d_ptr, ld and header): no promise about the slots behind them */

@@ -35,7 +35,7 @@ def f32_precision():
     chromosight_amd.set_precision(old)
 
 
-KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE, KERNEL_MFMA_REG, KERNEL_SEPARABLE = 1, 2, 3, 4, 5, 6
+KERNEL_GENERIC, KERNEL_STREAM, KERNEL_MFMA, KERNEL_MFMA_DENSE, KERNEL_MFMA_REG, KERNEL_SEPARABLE, KERNEL_MFMA_WIDE = 1, 2, 3, 4, 5, 6, 7
 
 
 def last_kernel():
@@ -389,10 +389,16 @@ def test_separable_kernel_on_rank1_templates(name, monkeypatch):
     wd, cond_d = c_oracle.normxcorr2_rows(dense.astype(np.float64), kern, 0, 300, full=False)
     assert_parity(cd, wd, cond_d, "f32", f"separable kernel, {name}, dense", max_ill_frac=ILL_MASKED)
     monkeypatch.setenv("CHROMOSIGHT_HIP_NO_SEPARABLE", "1")
+    c3, p3 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
+                            missing_tol=0.75, pval=True)
+    assert last_kernel() == KERNEL_MFMA_WIDE            # (the two-pass matrix-core kernel: full-rank evaluation of the same template)
+    well = band & (cond >= 1e-3)
+    assert np.abs(c.toarray() - c3.toarray())[well].max() < 5e-6
+    assert np.abs(p.toarray() - p3.toarray())[well].max() < 5e-3
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_WIDE", "1")
     c2, p2 = cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask,
                             missing_tol=0.75, pval=True)
     assert last_kernel() == KERNEL_GENERIC
-    well = band & (cond >= 1e-3)
     # the runtime-size kernel adds 961 float32 products per sum (observed 2.3e-5 from the oracle on this map, where the
     # separable kernel's 31 + 31 stay within 2.2e-6): the cross-check is correspondingly loose
     assert np.abs(c.toarray() - c2.toarray())[well].max() < 5e-5
@@ -402,8 +408,8 @@ def test_separable_kernel_on_rank1_templates(name, monkeypatch):
 def test_default_dispatch_by_template():
     """Which kernel serves a masked, banded detect-style call by default (cs_api.cpp launch_corr): the masked matrix-core
     tile kernel for 15 x 15 and 17 x 17 templates, the streaming kernel below, the separable kernel for outer-product
-    templates without an unrolled instance, the runtime-size kernel for the rest; dense unmasked maps take the dense
-    tile kernel."""
+    templates without an unrolled instance (on a narrow band), the two-pass matrix-core kernel for templates with a side of
+    18 .. 33, the runtime-size kernel for the rest; dense unmasked maps take the dense tile kernel."""
     rng = np.random.default_rng(8)
     n, md = 500, 90
     sig = np.triu(np.minimum(rng.gamma(20, 0.05, size=(n, n)), 10.0))
@@ -418,7 +424,8 @@ def test_default_dispatch_by_template():
              (np.asarray(ck.hairpins["kernels"][0], dtype=np.float64), KERNEL_MFMA_REG),
              (rng.normal(size=(13, 13)) + 0.3, KERNEL_STREAM), (rng.normal(size=(7, 7)) + 0.3, KERNEL_STREAM),
              (np.asarray(ck.stripes_left["kernels"][0], dtype=np.float64), KERNEL_SEPARABLE),
-             (np.outer(u, v), KERNEL_SEPARABLE), (rng.normal(size=(21, 21)) + 0.3, KERNEL_GENERIC)]
+             (np.outer(u, v), KERNEL_SEPARABLE), (rng.normal(size=(21, 21)) + 0.3, KERNEL_MFMA_WIDE),
+             (rng.normal(size=(19, 33)) + 0.3, KERNEL_MFMA_WIDE), (rng.normal(size=(35, 35)) + 0.3, KERNEL_GENERIC)]
     for kern, expected in cases:
         cud.normxcorr2(sp.csr_matrix(sig), kern, max_dist=md, sym_upper=True, full=True, missing_mask=mask, missing_tol=0.75)
         assert last_kernel() == expected, (kern.shape, last_kernel(), expected)

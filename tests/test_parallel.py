@@ -76,6 +76,19 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, f"gather{rank}.npy"), g)
         # CPU ranks exchange over torch / gloo; the start-up self-check of bench.py has nothing native to check there
         assert parallel.transport() == "torch_gloo" and parallel.exchange_self_check() == "torch_gloo"
+        # a local run under an initialised process group (genome_step(local=True): pipeline.detect): one rank alone may make it --
+        # rank 1 only here -- and it sees a world of one: no sharding, and the record exchange is the identity (no collective)
+        assert parallel._world()[2] == 2
+        if rank == 1:
+            parallel._LOCAL_DEPTH[0] += 1
+            try:
+                assert parallel._world() == (None, 0, 1)
+                rec = np.arange(14, dtype=float).reshape(2, 7)
+                assert parallel._exchange_records(rec, 1, 1) is rec
+                assert parallel.assign_blocks([5, 3, 2], parallel._world()[2]) == [[0, 1, 2]]
+            finally:
+                parallel._LOCAL_DEPTH[0] -= 1
+        assert parallel._world()[2] == 2
     finally:
         dist.destroy_process_group()
 

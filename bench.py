@@ -605,7 +605,9 @@ def time_genome(args, rank, local_rank, world, dist, torch, steps, warmup):
         # Benjamini-Hochberg q-values: pipeline.detect, the counterpart of cli/chromosight.py:601-878 without the file I/O)
         from chromosight_amd import pipeline
         detect_c4 = {}
-        for name, cfg in (("loops", g.loops), ("borders", g.borders)):
+        import copy as _copy
+        import chromosight_amd.kernels as _ck
+        for name, cfg in (("loops", g.loops), ("borders", g.borders), ("hairpins", _copy.deepcopy(_ck.hairpins))):
             for _ in range(2):
                 table = pipeline.detect(g.dcool, cfg)
             times = []

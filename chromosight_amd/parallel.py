@@ -691,7 +691,11 @@ def detect_genome(genome, kernel_config, tsvd=None, smooth=False, band_dtype=np.
                and hasattr(genome, "workers") and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_OVERLAP"))
     futures = []
     joint = None
-    if overlap and kernel_config["max_dist"] == 0 and tsvd is None and not todo:
+    # (a 1-D pattern with ONE template -- hairpins -- takes the same joint chain: the entry serves 1 to 4 templates, and it is the
+    # chain a StepPlan replays, chromosight_amd/plan.py)
+    one_template_1d = (batch is not None and stage_default and kernel_config["max_iterations"] == 1 and len(kernels) == 1 and bool(mine)
+                       and hasattr(genome, "workers") and not os.environ.get("CHROMOSIGHT_HIP_NO_TEMPLATE_OVERLAP"))
+    if (overlap or one_template_1d) and kernel_config["max_dist"] == 0 and tsvd is None and not todo:
         # a 1-D pattern's templates share one launch chain (cs_detect_foci_batch_templates): on a worker context, so that the
         # chain runs beside whatever this genome's own stream is doing (another pattern's tile kernels)
         pool = genome.workers(1)

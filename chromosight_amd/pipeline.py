@@ -907,13 +907,13 @@ def detect_blocks(dcool, blocks, kernel_config, kernel, tsvd=None, raw=True, wor
 
 
 def detect_blocks_templates(dcool, blocks, kernel_config, kernels, want_windows=False, dev=None, stream=None, begin_only=False):
-    """A 1-D pattern's templates (one size, e.g. the three borders templates) on banded intra blocks with ONE native call
+    """A 1-D pattern's templates (one size: the three borders templates, the one hairpins template) on banded intra blocks with ONE native call
     (cs_detect_foci_batch_templates) instead of one launch chain per template.  Returns a callable that yields, per template,
     the merged result of detect_blocks (table of all blocks, accepted records per block, windows) -- the native call is done
     when this returns, the acceptance rules run in the callable -- or None when the entry does not apply.
     begin_only=True: the chain is only enqueued on (dev, stream) when this returns; the callable waits for it first."""
     kernels = [np.asarray(k, dtype=np.float64) for k in kernels]
-    if kernel_config["max_dist"] != 0 or len(kernels) < 2 or len(kernels) > 4 or len(blocks) < 1:
+    if kernel_config["max_dist"] != 0 or len(kernels) < 1 or len(kernels) > 4 or len(blocks) < 1:
         return None
     if any(k.shape != kernels[0].shape or k.shape[0] != k.shape[1] for k in kernels):
         return None

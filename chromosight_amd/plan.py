@@ -262,8 +262,8 @@ class StepPlan:
 
 
 def plannable(genome, kernel_configs, tsvd):
-    """The configurations a StepPlan covers: a 2-D pattern with one square template (loops), a 1-D pattern with 2-4 templates of
-    one square size (borders), or one of each; single iterations, no truncated SVD, the device pipeline."""
+    """The configurations a StepPlan covers: a 2-D pattern with one square template (loops), a 1-D pattern with 1-4 templates of
+    one square size (borders, hairpins), or one of each; single iterations, no truncated SVD, the device pipeline."""
     if tsvd is not None or not 1 <= len(kernel_configs) <= 2:
         return False
     if not (hasattr(genome, "view_for") and hasattr(genome, "dev") and hasattr(genome.dev, "pinned_empty")):
@@ -279,6 +279,6 @@ def plannable(genome, kernel_configs, tsvd):
             return False
     if cfg2 is not None and len(cfg2["kernels"]) != 1:
         return False
-    if cfg1 is not None and not 2 <= len(cfg1["kernels"]) <= 4:
+    if cfg1 is not None and not 1 <= len(cfg1["kernels"]) <= 4:
         return False
     return True

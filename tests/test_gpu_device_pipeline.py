@@ -475,13 +475,13 @@ def test_2d_chain_retry_and_fallback_paths(monkeypatch):
 def test_single_pattern_steps_are_planned_and_feed_pipeline_detect():
     """A 2-D pattern alone (loops) and a 1-D pattern alone (borders) are steps a StepPlan covers too: replayed steps equal
     detect_genome's records; pipeline.detect -- the CLI counterpart -- runs the same orchestration (parallel.genome_step: its
-    second call on a DeviceCool is the replayed list) and returns the same table every time; hairpins (one 1-D template) and
-    two iterations are not planned and take the usual calls."""
+    second call on a DeviceCool is the replayed list) and returns the same table every time; so is hairpins (ONE 1-D template:
+    the joint chain serves 1 to 4 templates); two iterations are not planned and take the usual calls."""
     template = np.asarray(ck.loops["kernels"][0], dtype=np.float64)
     cool, _ = make_cool(12_000, 200, 2000, seed=7, template=template, chrom_sizes=[4000, 3500, 2500, 2000])
     loops = copy.deepcopy(ck.loops)
     loops["max_dist"] = 200 * 2000
-    for cfg in (loops, copy.deepcopy(ck.borders)):
+    for cfg in (loops, copy.deepcopy(ck.borders), copy.deepcopy(ck.hairpins)):
         dcool = pipeline.DeviceCool(cool)
         want = parallel.detect_genome(dcool, cfg)
         steps = [parallel.genome_step(dcool, [cfg]) for _ in range(4)]
@@ -489,17 +489,17 @@ def test_single_pattern_steps_are_planned_and_feed_pipeline_detect():
         assert len(plans) == 1 and all(p.ok for p in plans.values()), [p.why for p in plans.values()]
         for step in steps:
             got = step[0]
-            assert got.shape == want.shape and want.shape[0] > 30
+            assert got.shape == want.shape and want.shape[0] > (30 if cfg["max_dist"] or len(cfg["kernels"]) > 1 else 3)
             assert np.array_equal(got[:, [0, 1, 2, 5, 6]], want[:, [0, 1, 2, 5, 6]])
             assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-9
         dcool = pipeline.DeviceCool(cool)
         tables = [pipeline.detect(dcool, cfg) for _ in range(3)]
         assert all(p.ok for p in dcool.__dict__["_step_plans"].values())
-        assert len(tables[0]) > 20
+        assert len(tables[0]) > (20 if cfg["max_dist"] or len(cfg["kernels"]) > 1 else 2)
         for t in tables[1:]:
             assert t[["bin1", "bin2", "kernel_id"]].equals(tables[0][["bin1", "bin2", "kernel_id"]])
             assert np.abs(t["score"].to_numpy() - tables[0]["score"].to_numpy()).max() < 1e-9
-    for cfg in (copy.deepcopy(ck.hairpins), dict(loops, max_iterations=2)):
+    for cfg in (dict(loops, max_iterations=2),):
         dcool = pipeline.DeviceCool(cool)
         a, b = pipeline.detect(dcool, cfg), pipeline.detect(dcool, cfg)
         assert not dcool.__dict__.get("_step_plans") and a[["bin1", "bin2"]].equals(b[["bin1", "bin2"]])
@@ -851,7 +851,10 @@ def test_native_rccl_exchange_single_rank():
             last = str(exc)
             time.sleep(1.0)
     if comm is None:
-        pytest.skip(f"RCCL does not start on this box (three attempts): {last}")
+        # not a skip: a transport that does not come up is a finding -- reported as an expected failure with RCCL's
+        # own error text, so that it shows in the summary without turning a box's start-up trouble into a red suite
+        print(f"[rccl] ncclCommInitRank failed three times: {last}")
+        pytest.xfail(f"RCCL does not start on this box (three attempts): {last}")
     rng = np.random.default_rng(4)
     rows = rng.random((1234, 7))
     got, counts = comm.allgather_rows(rows)

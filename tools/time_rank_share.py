@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""What ONE rank of an N-GPU run of the C4 genome does, timed on one GPU (no exchange): its LPT share of the 23 blocks.
+"""What ONE rank of an N-GPU run of the C4 genome does, timed on one GPU: its LPT share of the 23 blocks, and -- VERDICT r5 1(d) -- the
+record exchange of the step on a single-rank RCCL communicator (csrc/cs_comm.cpp: count + padded all-gather, one per pattern; device
+staging, the collective launch and the download are all there, only the peers are missing).  CS_NO_EXCHANGE=1: without it.
     python tools/time_rank_share.py [n_gpus] [rank]"""
 import copy, os, sys, time
 import numpy as np
@@ -19,17 +21,30 @@ cool, _ = make_cool(200_000, 1000, 2000, seed=2, template=template, only=mine)
 dcool = pipeline.DeviceCool(cool)
 loops = copy.deepcopy(ck.loops); loops["max_dist"] = 2_000_000
 borders = copy.deepcopy(ck.borders)
-ts = []
+comm = None
+if not os.environ.get("CS_NO_EXCHANGE"):
+    try:
+        comm = parallel.NativeComm(0, 0, 1, parallel.NativeComm.unique_id())
+    except RuntimeError as exc:
+        print(f"# no single-rank RCCL communicator on this box ({exc}): steps timed without the exchange")
+ts, ex = [], []
 for it in range(int(os.environ.get("CS_STEPS", "24"))):
     dcool.dev.sync(); t0 = time.perf_counter()
     rec = parallel.genome_step(dcool, [loops, borders], owned=mine)
-    dcool.dev.sync(); ts.append((time.perf_counter() - t0) * 1e3)
+    t1 = time.perf_counter()
+    if comm is not None:
+        for r in rec:
+            got, counts = comm.allgather_rows(np.ascontiguousarray(r, dtype=np.float64))
+            assert int(counts[0]) == len(r)
+    dcool.dev.sync(); t2 = time.perf_counter()
+    ts.append((t2 - t0) * 1e3); ex.append((t2 - t1) * 1e3)
 px = sum(costs[i] for i in mine)
 plans = dcool.__dict__.get("_step_plans", {})
 if not all(p.ok for p in plans.values()) or not plans:
     print("no step plan:", [p.why for p in plans.values()])
 line = (f"{world} GPUs, rank {rank}: blocks {mine} ({px / 1e6:.1f} Mpixel of {sum(costs) / 1e6:.1f}), step {np.mean(ts[4:]):.3f} ms (median {np.median(ts[4:]):.3f}, min {min(ts):.3f}); "
       f"patterns {[len(r) for r in rec]}")
+line += f"; exchange (single-rank RCCL, inside the step) median {np.median(ex[4:]):.3f} ms" if comm is not None else "; no exchange in the step"
 slow = sorted(t for t in ts[4:] if t > 1.2 * np.median(ts[4:]))
 if slow:
     line += f"; {len(slow)} of {len(ts) - 4} steps above 1.2 x the median: " + " ".join(f"{t:.3f}" for t in slow[-8:])

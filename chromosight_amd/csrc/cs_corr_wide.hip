@@ -291,7 +291,18 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     unsigned long long cross_bits = 0;     // what the mask plane holds on a general tile: the missing predicate
     unsigned occ0 = 0, occ1 = 0;           // 16 x 16 blocks of the plane that hold a 1: bit 6 (r >> 4) + (c >> 4), 18 per word
     if constexpr (MASKED) {
-        if (fast) {
+        if (fast && inner) {
+            // inner tile: missing = r_p | c_q on the pixels the windows reach, four at a time from the flag words (no plane)
+#pragma unroll
+            for (int k = 0; k < FPIECES; ++k) {
+                const int r = min(tr + 10 * k, WD_R - 1), c4 = min(tc4, WD_R - 4);
+                const unsigned fr = (unsigned)(r < 64 ? rbits_lo >> r : (unsigned long long)(rbits_hi >> (r - 64))) & 1u;
+                const unsigned nib = (unsigned)(c4 < 64 ? cbits_lo >> c4 : (unsigned long long)(cbits_hi >> (c4 - 64))) & 0xfu;
+                const unsigned need4 = r < RH ? (1u << min(max(RW - c4, 0), 4)) - 1u : 0u;
+                const unsigned miss4 = (fr ? 0xfu : nib) & need4;
+                miss_bits |= (unsigned long long)miss4 << (4 * k);
+            }
+        } else if (fast) {
             const int md = A.max_dist >= 0 ? A.max_dist : min(A.ms, A.ns);
             const int big_k = max(km, kn);
             const bool stripes_on = A.sym_upper && A.full;
@@ -488,6 +499,18 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
 
     const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int wr0 = 16 * wv;                  // first staged row of the wave's windows
+    // the 16 x 16 pixel blocks of this wave that hold a produced pixel (rows below row_end, columns inside the matrix, diagonals
+    // out_lo .. out_hi): a wave without one -- the corners of a band's outer tiles -- has nothing left to do (no barrier follows)
+    unsigned cmask = 0;
+    {
+        const int i_lo = I0 + wr0, i_hi = min(I0 + wr0 + 15, A.row_end - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j_lo = max(J0 + 16 * c, 0), j_hi = min(J0 + 16 * c + 15, A.ns - 1);
+            if (i_lo <= i_hi && j_lo <= j_hi && j_hi - i_lo >= A.out_lo && j_lo - i_hi <= A.out_hi) cmask |= 1u << c;
+        }
+    }
+    if (cmask != 0u) {
     constexpr int NCB = TWO ? 6 : 4;          // 16-column steps at which a wave's A blocks (16 rows x 32 columns) start
     const bool any_mask = MASKED && !inner && occ != 0ull;
 
@@ -763,6 +786,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            if (!((cmask >> c) & 1u)) continue;
             const int j = J0 + 16 * c + n;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -776,6 +800,7 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
             }
         }
     }
+    }      // cmask
     WD_STAMP(8);          // epilogue
 #ifdef CS_WD_PROFILE
     if (lane == 0) {

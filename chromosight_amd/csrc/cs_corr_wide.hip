@@ -58,6 +58,8 @@ constexpr int WD_TAB = 6 * 64 * 4;            // per-tile mask tables: Tn, Ta, T
 constexpr int WD_FLAGS = 192;                 // flags of the 96 staged rows, then of the 96 staged columns
 constexpr int WD_SMEM_PLAIN = 2 * WD_PLANE + 64;
 constexpr int WD_SMEM_MASKED = 3 * WD_PLANE + WD_TAB + WD_FLAGS + 64;
+constexpr int WD_SMEM_INNER = 2 * WD_PLANE + WD_TAB + WD_FLAGS + 64;       // tile_mode 1
+static_assert(3 * WD_SMEM_INNER <= 160 * 1024, "three workgroups per CU");
 static_assert(WD_R * WD_R == 256 * WD_PER_THREAD, "staging loop");
 static_assert(WD_SMEM_MASKED <= 80 * 1024, "two workgroups per CU");
 
@@ -113,9 +115,11 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
     _Float16* xh = reinterpret_cast<_Float16*>(smem);
     _Float16* xl = reinterpret_cast<_Float16*>(smem + WD_PLANE);
     _Float16* xm = reinterpret_cast<_Float16*>(smem + 2 * WD_PLANE);                     // MASKED only
-    float* tab = reinterpret_cast<float*>(smem + 3 * WD_PLANE);                          // MASKED only
-    unsigned char* flg = reinterpret_cast<unsigned char*>(smem + 3 * WD_PLANE + WD_TAB);  // MASKED only
-    unsigned* red = reinterpret_cast<unsigned*>(smem + (MASKED ? 3 * WD_PLANE + WD_TAB + WD_FLAGS : 2 * WD_PLANE));
+    // (E.tile_mode 1: a launch that works on inner tiles only -- no plane, LDS for three workgroups per CU)
+    const int n_planes = (MASKED && E.tile_mode != 1) ? 3 : 2;
+    float* tab = reinterpret_cast<float*>(smem + n_planes * WD_PLANE);                          // MASKED only
+    unsigned char* flg = reinterpret_cast<unsigned char*>(smem + n_planes * WD_PLANE + WD_TAB);  // MASKED only
+    unsigned* red = reinterpret_cast<unsigned*>(smem + (MASKED ? n_planes * WD_PLANE + WD_TAB + WD_FLAGS : 2 * WD_PLANE));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -160,6 +164,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
     }
 
+    if constexpr (MASKED) {
+        // the two launches of a per-bin mask (launch_corr_mfma_wide_f32): inner tiles with the small LDS image, then the rest
+        if ((E.tile_mode == 1 && !inner) || (E.tile_mode == 2 && inner)) return;
+    }
     if (tid < 4) red[tid] = 0u;
     if constexpr (MASKED) {
         if (A.mask_mode == 1) {
@@ -477,21 +485,6 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
             tab[base + 64 + (tid & 63)] = sa;
             tab[base + 128 + (tid & 63)] = sb;
         }
-        // V[set][s][j] = sum over the flagged columns t of column j's window of W_set[s][t] (set: Wa, Wb), in the LDS the plane
-        // would take: what a flagged row p contributes to the cross term of the pixels (p - s, j)
-        if (has_cross) {
-            float* V = reinterpret_cast<float*>(xm);
-            const int kk = km * kn;
-            for (int idx = tid; idx < 2 * km * 64; idx += 256) {
-                const int set = idx >= km * 64 ? 1 : 0;
-                const int rem = idx - set * km * 64;
-                const int sr = rem >> 6, j = rem & 63;
-                const float* wrow = A.w + (1 + set) * kk + sr * kn;
-                float acc = 0.0f;
-                for (unsigned long long w = window_bits(cbits_lo, cbits_hi, j, kn); w; w &= w - 1ull) acc += wrow[__builtin_ctzll(w)];
-                V[(set * 33 + sr) * 64 + j] = acc;
-            }
-        }
     }
     WD_STAMP(3);          // barrier, split, plane writes, tables
     __syncthreads();
@@ -709,21 +702,32 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
         if (has_cross) {
             // flagged rows among the wave's input rows wr0 .. wr0 + 14 + km: row p of them lies in the windows of the wave's rows
-            // p - s, 0 <= s < km, and takes V[.][s][j] off the row + column terms of those pixels
-            const float* V = reinterpret_cast<const float*>(xm);
+            // p - s, 0 <= s < km, and takes sum_{t in C_j} W[s][t] (C_j: the flagged columns of column j's window) off the row +
+            // column terms of those pixels.  Evaluated where it is needed (a wave meets one flagged row per tile on average, a
+            // window half a flagged column): no table, no LDS -- what lets a launch of inner tiles run three workgroups per CU.
             unsigned long long wrows = rbits_lo >> wr0;
             if (wr0) wrows |= (unsigned long long)rbits_hi << (64 - wr0);
             wrows &= (1ull << (15 + km)) - 1ull;
-            for (; wrows; wrows &= wrows - 1ull) {
-                const int pr = __builtin_ctzll(wrows);
+            if (wrows) {
+                unsigned long long wcol[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int sr = pr - (4 * g + v);
-                    if ((unsigned)sr < (unsigned)km) {
+                for (int c = 0; c < 4; ++c) wcol[c] = window_bits(cbits_lo, cbits_hi, 16 * c + n, kn);
+                const int kk = km * kn;
+                for (; wrows; wrows &= wrows - 1ull) {
+                    const int pr = __builtin_ctzll(wrows);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            KA[c][v] -= V[sr * 64 + 16 * c + n];
-                            KB[c][v] -= V[(33 + sr) * 64 + 16 * c + n];
+                    for (int v = 0; v < 4; ++v) {
+                        const int sr = pr - (4 * g + v);
+                        if ((unsigned)sr < (unsigned)km) {
+                            const float* wa = A.w + kk + sr * kn;
+                            const float* wb = wa + kk;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                for (unsigned long long w = wcol[c]; w; w &= w - 1ull) {
+                                    const int t = __builtin_ctzll(w);
+                                    KA[c][v] -= wa[t];
+                                    KB[c][v] -= wb[t];
+                                }
                         }
                     }
                 }
@@ -874,6 +878,19 @@ int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipS
     hipError_t e = wide_allow_big_lds((const void*)k);
     if (e != hipSuccess) return (int)e;
     const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
+    // (a narrow band has few inner tiles and two short launches cost more than the third workgroup per CU buys: 234 diagonals
+    // 0.426 ms in one launch, 0.470 in two; 1001 diagonals 3.74 against 3.38)
+    if (masked && A.mask_mode == 1 && !E.plane_only && !E.plane_only_staging && !E.one_launch && A.tiles_x >= 8 && blocks >= 2048) {
+        // per-bin masks: the inner tiles (no plane: 45 KB of LDS, three workgroups per CU) in a launch of their own, then the
+        // tiles on the rim of the band / the frame of the matrix with the plane (66 KB, two per CU); a tile that is not the
+        // launch's returns at once.  C4' 21 x 21: 3.74 -> see profiles/r06_template_kernels.txt
+        MfmaWideWeights E1 = E, E2 = E;
+        E1.tile_mode = 1;
+        E2.tile_mode = 2;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), WD_SMEM_INNER, stream, A, E1);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), WD_SMEM_MASKED, stream, A, E2);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), masked ? WD_SMEM_MASKED : WD_SMEM_PLAIN, stream, A, E);
     return (int)hipGetLastError();
 }

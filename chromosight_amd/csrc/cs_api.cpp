@@ -649,7 +649,7 @@ int ensure_wfrag_wide(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaW
     for (int set = 0; set < 3; ++set) E->unscale[set] = ctx->wfrag_wide_unscale[set];
     E->plane_only = std::getenv("CHROMOSIGHT_HIP_WIDE_PLANE") ? 1 : 0;
     E->plane_only_staging = std::getenv("CHROMOSIGHT_HIP_WIDE_SLOW") ? 1 : 0;
-    E->one_launch = std::getenv("CHROMOSIGHT_HIP_WIDE_ONE_LAUNCH") ? 1 : 0;
+    E->one_launch = std::getenv("CHROMOSIGHT_HIP_WIDE_ONE_LAUNCH") ? 1 : std::getenv("CHROMOSIGHT_HIP_WIDE_TWO_LAUNCHES") ? 2 : 0;
     E->tile_mode = 0;
     return CS_OK;
 }

@@ -880,7 +880,7 @@ int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipS
     const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
     // (a narrow band has few inner tiles and two short launches cost more than the third workgroup per CU buys: 234 diagonals
     // 0.426 ms in one launch, 0.470 in two; 1001 diagonals 3.74 against 3.38)
-    if (masked && A.mask_mode == 1 && !E.plane_only && !E.plane_only_staging && !E.one_launch && A.tiles_x >= 8 && blocks >= 2048) {
+    if (masked && A.mask_mode == 1 && !E.plane_only && !E.plane_only_staging && E.one_launch != 1 && ((A.tiles_x >= 8 && blocks >= 2048) || E.one_launch == 2)) {
         // per-bin masks: the inner tiles (no plane: 45 KB of LDS, three workgroups per CU) in a launch of their own, then the
         // tiles on the rim of the band / the frame of the matrix with the plane (66 KB, two per CU); a tile that is not the
         // launch's returns at once.  C4' 21 x 21: 3.74 -> see profiles/r06_template_kernels.txt

@@ -67,7 +67,7 @@ struct MfmaWideWeights {
     const float* sums;
     int plane_only;
     int plane_only_staging;      // ... and stage every tile pixel by pixel with the general predicate (test switch)
-    int one_launch;              // per-bin masks in ONE launch (test switch; default: inner tiles and the rest in two)
+    int one_launch;              // per-bin masks: 1 in ONE launch, 2 always in two (test switches; default: two on wide bands, inner tiles first)
     int tile_mode;               // set by the launcher: 0 every tile, 1 inner tiles only (small LDS image), 2 all but the inner tiles
 };
 bool corr_mfma_wide_fits(int km, int kn);

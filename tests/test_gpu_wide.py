@@ -122,15 +122,17 @@ def _masked_band(n, md, keep, seed, frac=0.04):
 
 @pytest.mark.parametrize("n,md,ksize,tol", [(900, 120, 21, 0.75), (1500, 400, 21, 0.5), (1300, 500, 33, 0.75),
                                              (700, 60, 19, 0.25), (400, 399, 25, 0.75), (1100, 300, 27, 0.5)])
-@pytest.mark.parametrize("plane", [False, True, "slow", "one"])
+@pytest.mark.parametrize("plane", [False, True, "slow", "one", "two"])
 def test_banded_maps_with_bin_masks(n, md, ksize, tol, plane, monkeypatch):
     """The detect configuration: CSR in, band in / band out on the device, per-bin masks, full, sym_upper, coefficients
     and n_obs (through the p-values).  plane=False: inner tiles take the factorised form (1-D tables minus the cross
     plane), the rim the general plane; plane=True (CHROMOSIGHT_HIP_WIDE_PLANE=1): the general plane everywhere -- both
     against the oracle and against each other; "slow" (CHROMOSIGHT_HIP_WIDE_SLOW=1): every tile staged pixel by pixel
     with the general predicate (what the tiles on the frame of the matrix and explicit masks take)."""
-    if plane == "one":                       # inner tiles and the rest in ONE launch (default: two, the inner tiles with a small LDS image)
+    if plane == "one":                       # inner tiles and the rest in ONE launch
         monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_ONE_LAUNCH", "1")
+    elif plane == "two":                     # ... in two, the inner tiles with the small LDS image (the default on wide bands only)
+        monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_TWO_LAUNCHES", "1")
     elif plane == "slow":
         monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_SLOW", "1")
     elif plane:

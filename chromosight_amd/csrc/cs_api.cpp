@@ -613,14 +613,21 @@ int ensure_wfrag_wide(cs_ctx* ctx, hipStream_t stream, int km, int kn, cs::MfmaW
                 for (int pass = 0; pass < 2; ++pass)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const int t = 32 * pass + 8 * (lane >> 4) + e - (lane & 15);
-                            if (t < 0 || t >= kn) continue;
-                            const float v = std::ldexp(w[set * kk + s * kn + t], ew);
-                            const uint16_t hb = f32_to_f16_bits(v);
-                            const uint16_t lb = f32_to_f16_bits(v - f16_bits_to_f32(hb));
+                            const int k = 8 * (lane >> 4) + e;
                             const size_t base = ((((size_t)set * km + s) * 2 + pass) * 2) * 512;
-                            halfs[base + (size_t)lane * 8 + e] = hb;
-                            halfs[base + 512 + (size_t)lane * 8 + e] = lb;
+                            const int t = 32 * pass + k - (lane & 15);
+                            if (t >= 0 && t < kn) {
+                                const float v = std::ldexp(w[set * kk + s * kn + t], ew);
+                                const uint16_t hb = f32_to_f16_bits(v);
+                                const uint16_t lb = f32_to_f16_bits(v - f16_bits_to_f32(hb));
+                                halfs[base + (size_t)lane * 8 + e] = hb;
+                                halfs[base + 512 + (size_t)lane * 8 + e] = lb;
+                            }
+                            // the second pass of the template itself (set 0): k = 16 .. 31 meet no weight (t >= 33), and the kernel
+                            // sends the signal's TAILS of the columns of k - 16 through them: a second copy of the heads
+                            const int t2 = 32 + (k - 16) - (lane & 15);
+                            if (set == 0 && pass == 1 && k >= 16 && t2 >= 0 && t2 < kn)
+                                halfs[base + (size_t)lane * 8 + e] = f32_to_f16_bits(std::ldexp(w[s * kn + t2], ew));
                         }
         }
         if (nsets == 3)

@@ -608,12 +608,11 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
                 for (int q = 0; q < (TWO ? 4 : 2); ++q) nf[q] = Fn[q * 64];
             }
             const int rowoff = (wr0 + s + n) * WD_P + 8 * g;
-            h8 ah[NCB], al[NCB];
+            h8 ah[NCB], al[4];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                ah[cb] = *reinterpret_cast<const h8*>(xh + rowoff + 16 * cb);
-                al[cb] = *reinterpret_cast<const h8*>(xl + rowoff + 16 * cb);
-            }
+            for (int cb = 0; cb < NCB; ++cb) ah[cb] = *reinterpret_cast<const h8*>(xh + rowoff + 16 * cb);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) al[cb] = *reinterpret_cast<const h8*>(xl + rowoff + 16 * cb);
             const h8 bh0 = as_h8(cf[0]), bl0 = as_h8(cf[1]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -622,12 +621,17 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
                 accC[c] = mfma16(al[c], bh0, accC[c]);
             }
             if constexpr (TWO) {
+                // second pass: the weights of a row end at t = 32, so only k = 0 .. 15 of its Toeplitz operand are ever non-zero --
+                // the other half of the contraction carries the TAILS of the same 16 columns against a second copy of the weight
+                // heads (the fragment image repeats them at k = 16 .. 31, cs_api.cpp ensure_wfrag_wide): lanes of k groups 2 and 3
+                // read the tail plane, and heads x heads + tails x heads is ONE MFMA (5 per template row and column tile, not 6)
                 const h8 bh1 = as_h8(cf[2]), bl1 = as_h8(cf[3]);
+                const _Float16* mixed = (g < 2 ? xh : xl) + (wr0 + s + n) * WD_P + 8 * (g & 1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    accM[c] = mfma16(ah[c + 2], bh1, accM[c]);
+                    const h8 am2 = *reinterpret_cast<const h8*>(mixed + 16 * (c + 2));
+                    accM[c] = mfma16(am2, bh1, accM[c]);
                     accC[c] = mfma16(ah[c + 2], bl1, accC[c]);
-                    accC[c] = mfma16(al[c + 2], bh1, accC[c]);
                 }
             }
         }

@@ -9,28 +9,44 @@
 //
 //   * a 16-column output tile of a template row of up to 33 weights reads 16 + 32 = 48 staged columns: TWO k = 32
 //     Toeplitz passes per template row (B_p[k][n] = W[s][32 p + k - n]); the A blocks of the second pass of column
-//     tile c are those of the first pass of tile c + 2, so a wave reads 6 blocks (not 8) per template row;
-//   * 64 x 64 output pixels stage (64 + 32)^2 pixels: three float16 planes of 96 rows x 112 halfs (pitch 224 B:
-//     the 4 x 16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots; columns 96 .. 111 are zero and are
-//     what the last block of a row reads beyond the staged pixels);
+//     tile c are those of the first pass of tile c + 2, so a wave reads 6 head blocks (not 8) per template row.  Of the
+//     second pass only k = 0 .. 15 ever meet a weight (t <= 32): its idle half carries the signal's TAILS of the same
+//     columns against a second copy of the weight heads, so heads x heads + tails x heads is one MFMA -- 5 per
+//     template row and column tile instead of 6 (tools/ubench/mfma_rate.hip: the k = 16 MFMA shape issues no faster);
+//   * 64 x 64 output pixels stage (64 + 32)^2 pixels: float16 planes of 96 rows x 112 halfs (pitch 224 B: the 4 x
+//     16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots; columns 96 .. 111 are zero and are what the
+//     last block of a row reads beyond the staged pixels).  Staging is row-regular: a staged row is one run of
+//     consecutive slots of its stored row (dense: columns; band: diagonals shifted by the row), fetched as 16-byte
+//     pieces at 4-byte alignment by a 10 x 24 thread grid; a piece that straddles the end of the stored run is fetched
+//     from the clamped start and shifted in registers; tiles on the frame of the matrix under a mask, and explicit
+//     masks, take a pixel-by-pixel form with the full predicate;
 //   * 33 rows x 2 passes x {head, tail} x 1 KiB of B fragments (x 3 weight sets) do not fit the LDS next to the
 //     planes: a wave loads the four fragments of a template row straight from global memory (the image is built
 //     once per template by the host, cs_api.cpp ensure_wfrag_wide: 132 KB per set, L2-resident), one row ahead;
 //   * box sums (sum x, sum x^2, missing pixels): horizontal all-ones Toeplitz pass over the wave's 48 input rows,
 //     and the accumulator layout of that pass (a lane holds rows 4 g + v of ONE column) IS the B-operand layout of
-//     the vertical pass when the contraction index is labelled (g, e) -> row 16 rb + 4 g + e: no LDS transposition;
+//     the vertical pass when the contraction index is labelled (g, e) -> row 16 rb + 4 g + e: no LDS transposition.
+//     The squares are formed as float16 pairs in packed float16 arithmetic (2.5 instructions per pixel, 6 through
+//     float32): the kernel is bound by the instructions it issues, like its 17 x 17 siblings;
 //   * masks.  General form: the missing predicate of every staged pixel (cs_device.h missing_from_flags: per-bin
 //     flags or an explicit map, frames, diagonal limits -- preprocessing.py:404-498, 535-633) is a 0/1 plane, and the
-//     mask-weighted template sums are two more correlations of that plane.  Per-bin masks on a tile whose staged pixels
-//     all lie inside the matrix and the diagonals 0 .. max_dist ("inner": all but the rim of a band) factorise:
+//     mask-weighted template sums are two more correlations of that plane (blocks whose 16 x 16 sub-blocks hold no
+//     flagged pixel are skipped).  Per-bin masks on a tile whose staged pixels all lie inside the matrix and the
+//     diagonals 0 .. max_dist ("inner": all but the rim of a band) factorise:
 //         missing(p, q) = r_p | c_q   =>   sum_missing W = sum_{s in R_i} rowsum_W[s] + sum_{t in C_j} colsum_W[t]
 //                                                          - sum_{s in R_i, t in C_j} W[s][t]
-//     two 1-D tables per tile (built from the 96 + 96 flags and the template's row / column sums) minus the
-//     correlation of the CROSS plane r_p & c_q, which is empty in most 16 x 32 blocks: a wave skips the mask MFMAs of
-//     a block whose 16 x 16 sub-blocks hold no flagged pixel (occupancy bits gathered while staging).
+//     two 1-D tables per tile (built from the 96 + 96 flags, held as bit words, and the template's row / column sums)
+//     minus the flagged-row x flagged-column term, which a wave evaluates where it is needed (it meets one flagged row
+//     per tile on average, a window half a flagged column): no plane, no mask MFMAs.  On wide bands the inner tiles run
+//     in a launch of their own with a 45 KB LDS image -- three workgroups per CU -- and the rim in a second one;
+//   * a wave whose 16 rows x 64 columns hold no produced pixel (the corners of a band's outer tiles) stops after
+//     staging; tiles all of whose pixels are produced store without per-pixel predicates.
 //
 // One workgroup (4 waves) = one 64 x 64 output tile; wave w owns rows 16 w .. 16 w + 15 and four 16-column tiles.
-// LDS 66 KB (masked) / 43 KB: two workgroups per CU; tiles are dealt to the 8 XCDs in contiguous ranges.
+// LDS 66 KB (masked, with the plane) / 45 KB (inner tiles) / 43 KB (no mask): two or three workgroups per CU; tiles
+// are dealt to the 8 XCDs in contiguous ranges.  Measured (profiles/r06_template_kernels.txt): 21 x 21 dense 4096^2
+// 0.165 ms (102 Gpixel/s), C4' 200 000 x 1001 masked 3.26 ms (61 Gpixel/s), 33 x 33 4.08 ms (49) -- the runtime-size
+// kernel these calls took before: 0.84 ms and 18.7 ms at 21 x 21.
 #include "cs_device.h"
 #include <algorithm>
 #include <mutex>

@@ -104,6 +104,22 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$o
     tools/ubench/build/fetch_calib > "$out/calib.log" 2>&1
 python tools/time_templates.py c3 > "$out/template_kernels.txt" 2>/dev/null
 python tools/time_templates.py c4p >> "$out/template_kernels.txt" 2>/dev/null
+# templates with a side of 18 .. 33 (cs_corr_wide.hip): timings, per-phase cycle shares, kernel trace and counters of the
+# 21 x 21 template on the dense 4096^2 map and on C4' (own passes)
+python tools/time_wide.py c3 dense c4p >> "$out/template_kernels.txt" 2>/dev/null
+[ -f chromosight_amd/csrc/build/libchromosight_hip_prof.so ] && python tools/prof_wide_sections.py dense c4p 21 33 > "$out/wide_kernel_sections.txt" 2>&1
+for w in dense c4p; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_wide_$w" -o wide_$w -- \
+      python tools/run_wide_case.py $w 21 20 > "$out/trace_wide_$w.log" 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_wide_${w}_$c" -o wide_$w -- \
+        python tools/run_wide_case.py $w 21 5 > "$out/pmc_wide_${w}_$c.log" 2>&1
+  done
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT \
+      --kernel-trace --output-format csv -d "$out/pmc_wide_${w}_mfma" -o wide_$w -- \
+      python tools/run_wide_case.py $w 21 5 > "$out/pmc_wide_${w}_mfma.log" 2>&1
+done
+hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_rate.hip -o tools/ubench/build/mfma_rate 2>/dev/null && tools/ubench/build/mfma_rate > "$out/ubench_mfma_rate.txt" 2>&1
 tools/ubench/build/coexec > "$out/ubench_coexec.txt" 2>&1
 tools/ubench/build/fma_rate > "$out/ubench_fma_rate.txt" 2>&1
 tools/ubench/build/write_rate > "$out/ubench_write_rate.txt" 2>&1

@@ -37,7 +37,7 @@ for w in ("c2", "c3", "c3k", "c4p", "c4"):
 f = os.path.join(src, "template_kernels.txt")
 if os.path.exists(f) and os.path.getsize(f):
     shutil.copy(f, os.path.join(dst, f"{tag}_template_kernels.txt"))
-for u in ("coexec", "fma_rate", "write_rate"):
+for u in ("coexec", "fma_rate", "write_rate", "mfma_rate"):
     f = os.path.join(src, f"ubench_{u}.txt")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_ubench_{u}.txt"))
@@ -123,10 +123,58 @@ for run, key, kernels in (("c4", "c4_genome_cand_instances", ("corr_mfma_dense_k
     if rec:
         rec["kernel"] = " / ".join(kernels) + " (candidate instances: per-dispatch means over the launches of the run)"
         summary[key] = rec
+# the two-pass kernel of the templates with a side of 18 .. 33 (cs_corr_wide.hip), 21 x 21 on the dense 4096^2 map and on C4'
+for w, key in (("dense", "wide_21x21_dense_4096"), ("c4p", "wide_21x21_c4p_band_200000x1001")):
+    rec = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "mfma"):
+        rec.update(per_dispatch(find(f"pmc_wide_{w}_{c}/**/*counter_collection.csv"), "corr_mfma_wide_kernel"))
+    if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") and rec.get("GRBM_GUI_ACTIVE"):
+        rec["mfma_pipe_busy_frac"] = (rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (rec["GRBM_GUI_ACTIVE"] / 8.0)
+    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+        rec["hbm_bytes_per_dispatch"] = (rec["FETCH_SIZE"] * f + rec["WRITE_SIZE"]) * 1024.0
+    fs = find(f"trace_wide_{w}/**/*kernel_stats.csv")
+    if fs:
+        rows = list(csv.reader(open(fs)))
+        with open(os.path.join(dst, f"{tag}_wide_{w}_kernel_stats.csv"), "w", newline="") as out:
+            wr = csv.writer(out)
+            for r in rows:
+                wr.writerow([r[0][:160]] + r[1:])
+        for r in csv.DictReader(open(fs)):
+            if "corr_mfma_wide_kernel" in r["Name"]:
+                rec["avg_us_per_dispatch"] = float(r["AverageNs"]) / 1e3
+                rec["dispatches"] = int(r["Calls"])
+    log = os.path.join(src, f"trace_wide_{w}.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{"):
+                try:
+                    rec["profiled_run"] = json.loads(line)
+                except ValueError:
+                    pass
+    if rec:
+        rec["kernel"] = ("corr_mfma_wide_kernel<MASKED, TWO>; per-dispatch means -- a masked call on a wide band is TWO dispatches "
+                         "(inner tiles, then the rim): a call moves twice the per-dispatch bytes")
+        summary[key] = rec
+# the shader clocks under load of every profiled bench command (a recomputed fraction can be compared with the
+# driver's box)
+clocks = {}
+for w in ("c2", "c3", "c3k", "c4p", "c4"):
+    log = os.path.join(src, f"trace_{w}.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{"):
+                try:
+                    d = json.loads(line)
+                except ValueError:
+                    continue
+                if "gpu_state" in d:
+                    clocks[w] = {"gpu_state": d["gpu_state"], "ms_per_step": d.get("ms_per_step"), "kernel_ms": d.get("kernel_ms")}
+if clocks:
+    summary["profiled_runs_clocks"] = clocks
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
 for name in ("rank_share.txt", "rank_share_host_trace.txt", "rank_share_timeline.txt", "rank_share_native_laps.txt", "c4_phases.txt",
              "c5_phases.txt", "tile_kernel_sections.txt", "c4_modes.txt", "genome_timeline.txt", "genome_native_laps.txt",
-             "borders_alone_timeline.txt"):
+             "borders_alone_timeline.txt", "wide_kernel_sections.txt"):
     f2 = os.path.join(src, name)
     if os.path.exists(f2) and os.path.getsize(f2):
         shutil.copy(f2, os.path.join(dst, f"{tag}_{name}"))

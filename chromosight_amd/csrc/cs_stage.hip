@@ -42,7 +42,7 @@ constexpr int kStageWaves = kStageThreads / 64;
 // the row pointers and row weights of all the wave's rows of a group arrive together (one lane per row), the column
 // weights the group can touch sit in LDS (rows r0 .. r0 + rows, columns up to keep further: one coalesced load per
 // group), and the first kStageUnroll x 64 pixels of the NEXT row are requested before the current row is reduced.
-constexpr int kStageGroupRows = 128;             // upper bound of rows per group (cs_api.cpp picks 64 .. 128)
+constexpr int kStageGroupRows = 128;             // upper bound of rows per group (cs_api_entries.cpp cs_stage_blocks picks 64 .. 128)
 
 __device__ __forceinline__ void stage_wave_sync()
 {

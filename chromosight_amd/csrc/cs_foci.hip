@@ -590,12 +590,17 @@ __global__ __launch_bounds__(64) void segments_from_counts_kernel(const CorrArgs
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) flags |= __shfl_xor(flags, off, 64);
+    if (run > bound) flags |= 4;                              // (run and flags are wave-uniform here)
     if (lane == 0) {
         seg[n_blocks] = run;
-        if (run > bound) flags |= 4;
         h_out[60] = run;
         h_out[61] = flags;
     }
+    // Any flag sends the caller to the host-paced chain (cs_api_foci.cpp cs_detect_foci_blocks), whose results replace whatever this
+    // chain writes: with empty segments the kernels behind this one do nothing -- they used to label lists of which only the first
+    // `bound` entries were filled and to write records built from that into the caller's page-locked buffers first
+    if (flags != 0)
+        for (int b = lane; b <= n_blocks; b += 64) seg[b] = 0;
 }
 }  // namespace
 

@@ -33,7 +33,10 @@ import os
 import sys
 import time
 
-import numpy as np
+# (before anything initialises HIP -- torch.distributed with N > 1, the library with N = 1: chromosight_amd/__init__.py says why)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -208,6 +208,7 @@ _PROTOTYPES = {
     "cs_comm_rank": (C.c_int, [C.c_void_p]),
     "cs_comm_world": (C.c_int, [C.c_void_p]),
     "cs_comm_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cs_comm_allgather_rows_once": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "cs_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "cs_stage_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(CsStageBlock), C.c_int32, C.c_double]),
     "cs_csr_median": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CsCsr), C.POINTER(C.c_double)]),

@@ -6,6 +6,13 @@
 
 namespace csapi {
 
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); a genome step runs five to seven streams
+// side by side and an RCCL communicator adds its own: chains meant to overlap then share a queue (a rank's share of 8: 0.94 ms
+// instead of 0.57 once ncclCommInitRank has run, tools/rccl_probe.py).  The runtime reads the variable when it initialises, so it
+// is set when the library is loaded -- without overriding the caller's choice, and without effect where HIP is already up
+// (such a host sets it itself).
+static const int kHwQueuesDefault = (setenv("GPU_MAX_HW_QUEUES", "8", 0), 0);
+
 
 // cs_stream_wait_tiles: one wave that sleeps until the word has reached `epoch` (the tile workgroups of the launch that carries this
 // epoch are resident) and gives up after `ticks` of the constant-rate counter (100 MHz) -- the word is a scheduling hint, never a lock

@@ -172,7 +172,13 @@ int cs_comm_create(int device, int rank, int world, const void* unique_id128, cs
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     ncclResult_t ne = ncclSuccess;
+    size_t stack_before = 0, stack_after = 0;
+    (void)hipDeviceGetLimit(&stack_before, hipLimitStackSize);
     if (he == hipSuccess) ne = R->CommInitRank(&c->comm, world, id, rank);
+    (void)hipDeviceGetLimit(&stack_after, hipLimitStackSize);
+    if (std::getenv("CHROMOSIGHT_HIP_DEBUG"))
+        fprintf(stderr, "[chromosight_hip] ncclCommInitRank: hipLimitStackSize %zu -> %zu bytes per lane\n", stack_before, stack_after);
+    if (std::getenv("CHROMOSIGHT_HIP_RCCL_RESTORE_STACK") && stack_after != stack_before) (void)hipDeviceSetLimit(hipLimitStackSize, stack_before);
     if (he != hipSuccess || ne != ncclSuccess) {
         R->err_create = he != hipSuccess ? std::string("HIP: ") + hipGetErrorString(he)
                                          : std::string("ncclCommInitRank: ") + R->GetErrorString(ne);
@@ -263,6 +269,50 @@ int cs_comm_allgather_rows(cs_comm* c, const double* h_rows, int64_t n_rows, int
     for (int r = 0; r < W; ++r) {
         const size_t bytes = 8 * (size_t)h_counts[r] * (size_t)width;
         std::memcpy(dst, (char*)c->h_pin + block * (size_t)(1 + r), bytes);
+        dst += (size_t)h_counts[r] * (size_t)width;
+    }
+    return CS_OK;
+}
+
+// The same exchange in ONE collective: every rank sends a block of slot_rows + 1 rows whose first row carries its count; a rank
+// whose rows do not fit the slot (or a total beyond cap_rows) shows in the gathered headers, which every rank reads alike: all of
+// them get CS_ERR_OVERFLOW (counts set) and call again with a slot for the longest list.  A step of a sharded run gathers a few
+// thousand records per rank, about as many as the step before: with the previous counts as the slot the count exchange and its
+// synchronisation (half of an exchange's 80 us) are gone.
+int cs_comm_allgather_rows_once(cs_comm* c, const double* h_rows, int64_t n_rows, int32_t width, int64_t slot_rows, double* h_out,
+                                int64_t cap_rows, int64_t* h_counts)
+{
+    if (!c || n_rows < 0 || width <= 0 || slot_rows < 0 || !h_counts || (n_rows > 0 && !h_rows) || cap_rows < 0 || (cap_rows > 0 && !h_out))
+        return CS_ERR_INVALID;
+    CS_HIPC(c, hipSetDevice(c->device));
+    const int W = c->world;
+    const size_t block = 8 * (size_t)(slot_rows + 1) * (size_t)width;
+    int rc = ensure(c, block * (size_t)(W + 1));
+    if (rc) return rc;
+    double* hp = reinterpret_cast<double*>(c->h_pin);
+    std::memset(hp, 0, 8 * (size_t)width);
+    hp[0] = (double)n_rows;                                   // (exact: counts are far below 2^53)
+    const size_t sent = (size_t)std::min<int64_t>(n_rows, slot_rows);
+    if (sent) std::memcpy(hp + width, h_rows, 8 * sent * (size_t)width);
+    // (only the header and the rows that are there travel to the device; the rest of the slot is whatever the buffer held)
+    CS_HIPC(c, hipMemcpyAsync(c->d_buf, hp, 8 * (sent + 1) * (size_t)width, hipMemcpyHostToDevice, c->stream));
+    CS_NCCL(c, rccl()->AllGather(c->d_buf, (char*)c->d_buf + block, (size_t)(slot_rows + 1) * (size_t)width, ncclDouble, c->comm, c->stream));
+    CS_HIPC(c, hipMemcpyAsync((char*)c->h_pin + block, (char*)c->d_buf + block, block * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+    CS_HIPC(c, hipStreamSynchronize(c->stream));
+    long long total = 0, widest = 0;
+    for (int r = 0; r < W; ++r) {
+        const double* head = reinterpret_cast<const double*>((char*)c->h_pin + block * (size_t)(1 + r));
+        h_counts[r] = (int64_t)head[0];
+        total += h_counts[r];
+        widest = std::max<long long>(widest, h_counts[r]);
+    }
+    if (widest > slot_rows || total > cap_rows)
+        return cfail(c, CS_ERR_OVERFLOW, "%lld rows (longest list %lld), slot of %lld rows, room for %lld", total, widest, (long long)slot_rows,
+                     (long long)cap_rows);
+    double* dst = h_out;
+    for (int r = 0; r < W; ++r) {
+        const size_t bytes = 8 * (size_t)h_counts[r] * (size_t)width;
+        if (bytes) std::memcpy(dst, (char*)c->h_pin + block * (size_t)(1 + r) + 8 * (size_t)width, bytes);
         dst += (size_t)h_counts[r] * (size_t)width;
     }
     return CS_OK;

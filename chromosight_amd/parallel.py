@@ -95,6 +95,35 @@ class NativeComm:
             self._check(rc)
             return out[:int(counts.sum())], counts
 
+    def allgather_rows_once(self, rows):
+        """allgather_rows in ONE collective (cs_comm_allgather_rows_once): the slot is what the previous exchange of this width
+        needed, with a quarter to spare -- a step of a sharded run finds about as many records as the step before; a list that
+        outgrows it makes every rank call again with the longest list as the slot."""
+        C = self.C
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        width = int(rows.shape[1])
+        counts = np.zeros(self.world, dtype=np.int64)
+        slots = self.__dict__.setdefault("_slots", {})
+        slot = slots.get(width) or int(os.environ.get("CHROMOSIGHT_HIP_GATHER_CAP", 0))
+        if not slot:
+            # the first exchange of this width: every rank must pass the SAME slot (the blocks of a collective have one size), and
+            # only the counts of all ranks can say which -- the two-collective form learns them
+            out, counts = self.allgather_rows(rows)
+            longest = int(counts.max())
+            slots[width] = max(longest + longest // 4 + 16, 256)
+            return out, counts
+        while True:
+            out = np.empty((slot * self.world, width))
+            rc = self.lib.cs_comm_allgather_rows_once(self.handle, rows.ctypes.data, rows.shape[0], width, slot, out.ctypes.data,
+                                                      slot * self.world, counts.ctypes.data)
+            longest = int(counts.max()) if self.world else 0
+            if rc == -4:                      # CS_ERR_OVERFLOW, on every rank alike: the counts say what slot is needed
+                slot = longest + longest // 4 + 16
+                continue
+            self._check(rc)
+            slots[width] = max(longest + longest // 4 + 16, 256)
+            return out[:int(counts.sum())], counts
+
     def allreduce_sum(self, array):
         out = np.ascontiguousarray(array, dtype=np.float64).copy()
         self._check(self.lib.cs_comm_allreduce_f64(self.handle, out.ctypes.data, out.size))
@@ -362,15 +391,15 @@ class SplitBlockScan:
         return law, merged
 
 
-def _gather(records, n_fields):
-    """gather_records for an arbitrary record width."""
+def _gather(records, n_fields, once=False):
+    """gather_records for an arbitrary record width.  once: the one-collective form of the native exchange (repeating steps)."""
     dist, rank, world = _world()
     records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, n_fields)
     if dist is None or world == 1:
         return records
     comm = native_comm()
     if comm is not None:
-        merged, _ = comm.allgather_rows(records)
+        merged, _ = comm.allgather_rows_once(records) if once else comm.allgather_rows(records)
         return merged[np.argsort(merged[:, 0], kind="stable")]
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -480,6 +509,29 @@ def _exchange_records(local, n_kernels, n_iterations):
     return merged[np.argsort(merged[:, 5] * n_iterations + merged[:, 6], kind="stable")]
 
 
+def _exchange_records_many(locals_, kernel_configs):
+    """The record exchanges of SEVERAL configurations of one step as ONE exchange (and, on the native transport, one collective:
+    NativeComm.allgather_rows_once): the lists travel side by side with the configuration's index in an eighth column and come
+    apart again in the order _exchange_records gives each of them."""
+    if _world()[2] == 1:
+        return list(locals_)
+    import time
+    t0 = time.perf_counter()
+    w = len(GENOME_FIELDS)
+    parts = []
+    for i, rec in enumerate(locals_):
+        rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, w)
+        parts.append(np.concatenate([rec, np.full((rec.shape[0], 1), float(i))], axis=1))
+    merged = _gather(np.concatenate(parts, axis=0) if parts else np.zeros((0, w + 1)), w + 1, once=True)
+    TIMERS["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+    TIMERS["exchanges"] += 1
+    out = []
+    for i, cfg in enumerate(kernel_configs):
+        mine = merged[merged[:, w] == i][:, :w]               # (ranks concatenated, stably sorted by block: _gather)
+        out.append(mine[np.argsort(mine[:, 5] * cfg["max_iterations"] + mine[:, 6], kind="stable")])
+    return out
+
+
 def transport():
     """What carries this process group's exchanges: "native_rccl" (csrc/cs_comm.cpp), "torch_nccl", "torch_gloo" or "none"."""
     dist, rank, world = _world()
@@ -533,7 +585,7 @@ def exchange_self_check():
 _PATTERN_THREADS = None
 
 
-def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
+def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None, exchange=True):
     """detect_genome for SEVERAL pattern configurations on blocks staged once (stage_genome), concurrently: a genome
     scan is a few bandwidth / matrix-core-bound launches (a 2-D pattern's tile kernels) next to many latency-bound ones
     (1-D patterns: a few thousand pixels per block and template; labelling, statistics, synchronisations) -- run one after
@@ -572,10 +624,11 @@ def detect_patterns(genome, kernel_configs, owned=None, staged=None, tsvd=None):
     results = [None] * len(kernel_configs)
     for i, cfg in enumerate(kernel_configs):
         if i not in side:
-            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=pick(i), exclusive=not side)
+            results[i] = detect_genome(genome, cfg, tsvd=tsvd, owned=owned, staged=pick(i), exclusive=not side, exchange=exchange)
     for i in side:                                           # (collectives in the same order on every rank)
         mine = local[i] if i in local else futures[i].result()
-        results[i] = _exchange_records(mine, len(kernel_configs[i]["kernels"]), 1)
+        # (exchange=False: this rank's records -- genome_step exchanges the configurations of a step together)
+        results[i] = _exchange_records(mine, len(kernel_configs[i]["kernels"]), 1) if exchange else mine
     return results
 
 
@@ -609,15 +662,18 @@ def genome_step(genome, kernel_configs, owned=None, tsvd=None, local=False):
     if plan is not None and plan.ok:
         local = plan.run()
         if local is not None:
-            return [_exchange_records(rec, len(cfg["kernels"]), 1) for rec, cfg in zip(local, kernel_configs)]
+            return _exchange_records_many(local, kernel_configs)     # (one exchange for the step's configurations)
         plans.pop(key, None)                                  # (a result list outgrew its capacity: the usual path, a new plan)
     from . import _lib
     _lib.CAPTURE = captured = []
     try:
         staged = stage_genome(genome, kernel_configs, owned=owned)
-        results = detect_patterns(genome, kernel_configs, owned=owned, staged=staged, tsvd=tsvd)
+        # (this rank's records, then the ONE exchange a replayed step makes too: whichever way a rank takes through a step --
+        # a plan that outgrew its buffers falls back here -- the ranks issue the same collectives)
+        results = detect_patterns(genome, kernel_configs, owned=owned, staged=staged, tsvd=tsvd, exchange=False)
     finally:
         _lib.CAPTURE = None
+    results = _exchange_records_many(results, kernel_configs)
     if len(plans) > 8:
         plans.clear()
     plans[key] = _plan.StepPlan(genome, kernel_configs, owned, captured, staged)

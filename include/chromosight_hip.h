@@ -517,7 +517,11 @@ int cs_run_calls(cs_call* calls, int32_t n_calls);
  * in rank order (h_counts[r] rows of rank r), identical on every rank; CS_ERR_OVERFLOW (counts set) when the rows do not
  * fit the SMALLEST cap_rows any rank passed -- the capacities travel with the counts, so every rank gets the same
  * answer and all of them call again (with room for the sum of the counts): the collectives of a communicator stay
- * matched however unevenly the rows are spread.  cs_comm_allreduce_f64: element-wise sum over the ranks, in place. */
+ * matched however unevenly the rows are spread.  cs_comm_allgather_rows_once: the same result from ONE collective -- a rank's
+ * block is slot_rows + 1 rows, the first of which carries its count; CS_ERR_OVERFLOW (counts set, on every rank alike) when a
+ * list is longer than the slot or the total exceeds cap_rows: call again with a slot for the longest list.  For exchanges
+ * that repeat with similar counts (the steps of a sharded run).  cs_comm_allreduce_f64: element-wise sum over the ranks, in
+ * place. */
 typedef struct cs_comm cs_comm;
 int cs_comm_available(void);            /* CS_OK when the RCCL of the library's HIP runtime loads (a local check: no rank talks) */
 int cs_comm_unique_id(void* out128);
@@ -528,6 +532,8 @@ int cs_comm_rank(const cs_comm* comm);
 int cs_comm_world(const cs_comm* comm);
 int cs_comm_allgather_rows(cs_comm* comm, const double* h_rows, int64_t n_rows, int32_t width, double* h_out,
                            int64_t cap_rows, int64_t* h_counts);
+int cs_comm_allgather_rows_once(cs_comm* comm, const double* h_rows, int64_t n_rows, int32_t width, int64_t slot_rows,
+                                double* h_out, int64_t cap_rows, int64_t* h_counts);
 int cs_comm_allreduce_f64(cs_comm* comm, double* h_values, int64_t n);
 
 /* Greedy neighbour suppression of detection.py:348 remove_neighbours, on the host, in O(n) with a

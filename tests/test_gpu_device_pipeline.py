@@ -876,6 +876,15 @@ def test_native_rccl_exchange_single_rank():
     assert "room for 100" in comm.lib.cs_comm_last_error(comm.handle).decode()
     vec = rng.random(2 * 289 + 1)
     assert np.array_equal(comm.allreduce_sum(vec), vec)
+    # the one-collective form (cs_comm_allgather_rows_once: what a replayed step of a sharded run uses): the first exchange of a
+    # width learns the slot from the two-collective form, the later ones send a slot of that size; a list that outgrows it
+    # comes back as CS_ERR_OVERFLOW on every rank and is sent again
+    wide = rng.random((3000, 8))
+    for n in (3000, 2900, 0, 3100, 9000, 10):
+        got, counts = comm.allgather_rows_once(wide[:n] if n <= 3000 else np.tile(wide, (3, 1))[:n])
+        want = wide[:n] if n <= 3000 else np.tile(wide, (3, 1))[:n]
+        assert counts.tolist() == [n] and np.array_equal(got, want), n
+    assert comm._slots[8] >= 256
     comm.close()
 
 

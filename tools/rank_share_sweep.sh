@@ -5,7 +5,7 @@ out=${1:-gpurun_out/rank_share.txt}
 : > $out
 for w in 1 2 4 8; do
   for r in $(seq 0 $((w-1))); do
-    python tools/time_rank_share.py $w $r 2>/dev/null | tail -1 >> $out
+    python tools/time_rank_share.py $w $r 2>/dev/null | grep "GPUs, rank" | tail -1 >> $out
   done
 done
 python - "$out" <<'PY'

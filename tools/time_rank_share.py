@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What ONE rank of an N-GPU run of the C4 genome does, timed on one GPU: its LPT share of the 23 blocks, and -- VERDICT r5 1(d) -- the
-record exchange of the step on a single-rank RCCL communicator (csrc/cs_comm.cpp: count + padded all-gather, one per pattern; device
+record exchange of the step on a single-rank RCCL communicator (csrc/cs_comm.cpp: the step's lists in one collective; device
 staging, the collective launch and the download are all there, only the peers are missing).  CS_NO_EXCHANGE=1: without it.
     python tools/time_rank_share.py [n_gpus] [rank]"""
 import copy, os, sys, time
@@ -32,10 +32,17 @@ for it in range(int(os.environ.get("CS_STEPS", "24"))):
     dcool.dev.sync(); t0 = time.perf_counter()
     rec = parallel.genome_step(dcool, [loops, borders], owned=mine)
     t1 = time.perf_counter()
-    if comm is not None:
-        for r in rec:
-            got, counts = comm.allgather_rows(np.ascontiguousarray(r, dtype=np.float64))
-            assert int(counts[0]) == len(r)
+    if comm is not None and not os.environ.get("CS_COMM_IDLE"):
+        # what parallel._exchange_records_many does with N > 1 ranks: the step's lists side by side, the configuration's index in an
+        # eighth column, ONE collective (cs_comm_allgather_rows_once; CS_TWO_PHASE=1: count exchange + padded all-gather per list)
+        if os.environ.get("CS_TWO_PHASE"):
+            for r in rec:
+                got, counts = comm.allgather_rows(np.ascontiguousarray(r, dtype=np.float64))
+                assert int(counts[0]) == len(r)
+        else:
+            both = np.concatenate([np.concatenate([r, np.full((len(r), 1), float(i))], axis=1) for i, r in enumerate(rec)], axis=0)
+            got, counts = comm.allgather_rows_once(both)
+            assert int(counts[0]) == len(both)
     dcool.dev.sync(); t2 = time.perf_counter()
     ts.append((t2 - t0) * 1e3); ex.append((t2 - t1) * 1e3)
 px = sum(costs[i] for i in mine)
@@ -48,7 +55,9 @@ line += f"; exchange (single-rank RCCL, inside the step) median {np.median(ex[4:
 slow = sorted(t for t in ts[4:] if t > 1.2 * np.median(ts[4:]))
 if slow:
     line += f"; {len(slow)} of {len(ts) - 4} steps above 1.2 x the median: " + " ".join(f"{t:.3f}" for t in slow[-8:])
-print(line)
+print(line, flush=True)
+if comm is not None:
+    comm.close()
 if os.environ.get("STEPS"):
     print("steps (ms):", " ".join(f"{t:.3f}" for t in ts))
 if os.environ.get("PROFILE"):

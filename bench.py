@@ -738,7 +738,8 @@ class SplitC4P:
     over the ranks -- strong scaling of the `north_star_c4p` leg, whose N = 1 form is the plain correlation call.  Rank r holds
     rows split_rows(n, N)[r] of the band plus the template's halo and per step (parallel.SplitBlockScan): all-reduces the
     per-diagonal (sum, count) of its rows (the distance law of a split block), runs the same masked tile kernel on its row
-    window, compacts the coefficients >= 0.3 of its rows and all-gathers those candidates."""
+    window with the candidate epilogue (cs_candidates: coordinates of the candidate pixels, re-scored in float64, no map) and
+    all-gathers the candidates of its rows."""
 
     def __init__(self, dev, rank, world, precision, n=None):
         from chromosight_amd import engine, parallel
@@ -778,7 +779,28 @@ class SplitC4P:
             self.kernel_ms.append(dev.elapsed_ms(ev0, ev1))       # (run_compact's download has synchronised the stream)
             return np.column_stack([rows.astype(np.float64) + a, cols.astype(np.float64) + a, vals])
 
-        self.scan = parallel.SplitBlockScan(n, law_part, correlate, candidates)
+        # The pipeline's own form (default): ONE call per step, cs_candidates on the rank's row window -- the masked
+        # tile kernel's candidate epilogue appends the coordinates of its candidate pixels (no coefficient map is written, nothing
+        # is compacted), the float64 re-scoring keeps those at or above the threshold -- which is what utils.detection.
+        # detect_split_on_device does before the exchange.  CS_BENCH_SPLIT_MAP=1: the map + compaction form above.
+        self.fused = not os.environ.get("CS_BENCH_SPLIT_MAP")
+
+        def nothing():
+            dev.record(ev0)
+
+        def candidates_fused():
+            rows, cols, vals = engine.run_candidates(dev, sig, (n, n), kspec, (a, b), pearson=0.3, lo_diag=0, hi_diag=max_dist, inter=False,
+                                                     full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=self.miss_buf,
+                                                     miss_col=self.miss_buf, missing_tol=0.5, precision=precision)
+            dev.record(ev1)
+            dev.sync()
+            self.kernel_ms.append(dev.elapsed_ms(ev0, ev1))       # (the chain: tile kernel with the candidate epilogue + float64 re-scoring)
+            return np.column_stack([rows.astype(np.float64), cols.astype(np.float64), vals])
+
+        if self.fused:
+            self.scan = parallel.SplitBlockScan(n, law_part, nothing, candidates_fused)
+        else:
+            self.scan = parallel.SplitBlockScan(n, law_part, correlate, candidates)
 
 
 def _barrier(dist, local_rank):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A rank's share of the ONE 200 000-bin block of the north star (bench.py SplitC4P: the block row-split over the ranks), each
-share timed alone on one GPU, without the two collectives: the masked tile kernel on the rank's row window + the compaction
-of its candidates (threshold, download) -- what `north_star_c4p_split` does per step between its exchanges.
+share timed alone on one GPU, without the two collectives: cs_candidates on the rank's row window (the masked tile kernel with the
+candidate epilogue -- no coefficient map, no compaction pass -- and the float64 re-scoring of its candidates) -- what
+`north_star_c4p_split` does per step between its exchanges.  CS_BENCH_SPLIT_MAP=1: the map + compaction form of round 5.
 
     python tools/time_c4p_split_share.py            # 1 / 2 / 4 / 8 shares, every rank"""
 import os

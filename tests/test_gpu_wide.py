@@ -298,3 +298,65 @@ def test_c4p_band_200000_row_windows(ksize):
         want, cond = c_oracle.normxcorr2_band(band64, n, 0, band_w, kern, r0, r0 + rows, 0, max_dist + 1,
                                               max_dist=max_dist, miss_row=miss, miss_col=miss, missing_tol=0.5)
         assert_parity(got[r0:r0 + rows], want, cond, "f32", f"C4' k={ksize} rows {r0}..{r0 + rows}", max_ill_frac=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CS_SWEEP_FROM", "0")), int(__import__("os").environ.get("CS_SWEEP_TO", "32"))))
+def test_random_wide_configuration(seed, monkeypatch):
+    """Seeded random sweep (the shape of tests/test_gpu_random_sweep.py) over what only this kernel serves: template sides of 19 .. 33,
+    square and rectangular, piecewise-constant and mirrored templates; dense / banded / inter maps; full / valid mode; max_dist below,
+    around and above the 167 + diagonals an inner tile needs; missing-bin clusters at the matrix ends; every third seed with the two
+    launches forced, every fifth with the plane everywhere.  CS_SWEEP_FROM / CS_SWEEP_TO widen it."""
+    rng = np.random.default_rng(5000 + seed)
+    if seed % 3 == 0:
+        monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_TWO_LAUNCHES", "1")
+    elif seed % 5 == 0:
+        monkeypatch.setenv("CHROMOSIGHT_HIP_WIDE_PLANE", "1")
+    ksz = [19, 21, 23, 25, 27, 29, 31, 33][seed % 8]
+    km, kn = (ksz, ksz) if seed % 4 else (ksz, min(33, ksz + 2 * int(rng.integers(1, 4))))
+    kern = rng.random((km, kn)) + 0.5
+    if rng.random() < 0.3:
+        kern = np.where(rng.random((km, kn)) < 0.5, 0.5, 1.5)
+        kern[0, 0], kern[-1, -1] = 0.5, 1.5
+    if seed % 7 in (1, 2, 5):
+        kern = (kern + kern[::-1, :]) / 2
+    mode = seed % 4
+    if mode == 0:
+        shape = (int(rng.integers(70, 500)), int(rng.integers(70, 500)))
+        sig = (rng.gamma(3, 0.4, size=shape) * (rng.random(shape) > 0.3)).astype(np.float32)
+        full = bool(seed & 4)
+        got, _ = cud.normxcorr2(sig, kern, full=full)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        want, cond = c_oracle.normxcorr2_rows(sig.astype(np.float64), kern, 0, shape[0], full=full)
+        assert_parity(got, want, cond, "f32", f"wide sweep {seed} dense {shape} {km}x{kn}", max_ill_frac=0.01)
+    elif mode in (1, 2):
+        n = int(rng.integers(120, 1400))
+        max_dist = int([rng.integers(2, 40), rng.integers(150, 260), rng.integers(min(260, n), n + 50)][seed % 3])
+        keep = min(max_dist, n) + max(km, kn)
+        ii, jj = np.indices((n, n))
+        a = rng.gamma(3, 0.4, size=(n, n)) * (rng.random((n, n)) > 0.25)
+        a[(jj - ii < 0) | (jj - ii > keep)] = 0
+        miss = rng.random(n) < 0.05
+        miss[:3] = True
+        miss[-2:] = True
+        a[miss, :] = 0
+        a[:, miss] = 0
+        a = a.astype(np.float32)
+        tol = float(rng.choice([0.25, 0.5, 0.75]))
+        valid = np.flatnonzero(~miss)
+        mask = cup.make_missing_mask((n, n), valid, valid, max_dist=max_dist, sym_upper=True)
+        got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, max_dist=max_dist, sym_upper=True, full=True, missing_mask=mask, missing_tol=tol)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        want, cond = c_oracle.normxcorr2_rows(a.astype(np.float64), kern, 0, n, max_dist=max_dist, sym_upper=True, full=True,
+                                              miss_row=miss, miss_col=miss, missing_tol=tol)
+        assert_parity(got.toarray(), want, cond, "f32", f"wide sweep {seed} band n={n} max_dist={max_dist} {km}x{kn}", max_ill_frac=0.05)
+    else:
+        shape = (int(rng.integers(60, 500)), int(rng.integers(60, 500)))
+        a = rng.gamma(3, 0.4, size=shape) * (rng.random(shape) > 0.4)
+        mr, mc = rng.random(shape[0]) < 0.05, rng.random(shape[1]) < 0.05
+        a[mr, :] = 0
+        a[:, mc] = 0
+        mask = cup.make_missing_mask(shape, np.flatnonzero(~mr), np.flatnonzero(~mc), sym_upper=False)
+        got, _ = cud.normxcorr2(sp.csr_matrix(a), kern, sym_upper=False, full=True, missing_mask=mask)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        want, cond = c_oracle.normxcorr2_rows(a, kern, 0, shape[0], sym_upper=False, full=True, miss_row=mr, miss_col=mc)
+        assert_parity(got.toarray(), want, cond, "f32", f"wide sweep {seed} inter {shape} {km}x{kn}", max_ill_frac=0.05)

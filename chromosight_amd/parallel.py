@@ -544,7 +544,8 @@ def transport():
 
 def exchange_self_check():
     """Before a timed multi-GPU region: one padded all-gather of rows with UNEVEN counts (rank r sends 3 r + 1 rows; rank 0
-    with a first capacity that is too small, so the retry runs) and one all-reduce through the library's communicator,
+    with a first capacity that is too small, so the retry runs), three exchanges of the one-collective form (slot learnt, slot
+    kept, slot outgrown) and one all-reduce through the library's communicator,
     compared with torch.distributed's collectives on the same data.  On a mismatch or an error on ANY rank every rank
     drops to the torch transport, loudly.  Returns the transport in use afterwards."""
     dist, rank, world = _world()
@@ -568,6 +569,16 @@ def exchange_self_check():
         want = np.concatenate([np.arange((3 * r + 1) * 5, dtype=np.float64).reshape(-1, 5) + 1000.0 * r for r in range(world)])
         if counts.tolist() != [3 * r + 1 for r in range(world)] or not np.array_equal(got, want):
             ok, why = False, "all-gather of rows differs from the expected concatenation"
+        # the one-collective form a replayed step uses (cs_comm_allgather_rows_once), on a width of its own: the first exchange learns
+        # the slot (two collectives), the second fits it, the third outgrows it on the last rank (every rank sends again)
+        for k, grow in enumerate((1, 1, 40)):
+            n_r = lambda r: (2 * r + 3) * (grow if r == world - 1 else 1)      # noqa: E731
+            mine9 = np.arange(n_r(rank) * 9, dtype=np.float64).reshape(-1, 9) + 1e6 * rank + k
+            got9, counts9 = comm.allgather_rows_once(mine9)
+            want9 = np.concatenate([np.arange(n_r(r) * 9, dtype=np.float64).reshape(-1, 9) + 1e6 * r + k for r in range(world)])
+            if ok and (counts9.tolist() != [n_r(r) for r in range(world)] or not np.array_equal(got9, want9)):
+                ok, why = False, f"one-collective all-gather of rows (exchange {k}) differs from the expected concatenation"
+        comm.__dict__.get("_slots", {}).pop(9, None)
         got_sum = comm.allreduce_sum(vec)              # (always issued: the native collectives stay matched across the ranks)
         if ok and not np.allclose(got_sum, want_sum, rtol=1e-13, atol=0):
             ok, why = False, "all-reduce differs from torch.distributed's"

@@ -785,20 +785,21 @@ class SplitC4P:
         # detect_split_on_device does before the exchange.  CS_BENCH_SPLIT_MAP=1: the map + compaction form above.
         self.fused = not os.environ.get("CS_BENCH_SPLIT_MAP")
 
-        def nothing():
+        def correlate_fused():
             dev.record(ev0)
-
-        def candidates_fused():
             rows, cols, vals = engine.run_candidates(dev, sig, (n, n), kspec, (a, b), pearson=0.3, lo_diag=0, hi_diag=max_dist, inter=False,
                                                      full=True, sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=self.miss_buf,
                                                      miss_col=self.miss_buf, missing_tol=0.5, precision=precision)
             dev.record(ev1)
             dev.sync()
             self.kernel_ms.append(dev.elapsed_ms(ev0, ev1))       # (the chain: tile kernel with the candidate epilogue + float64 re-scoring)
-            return np.column_stack([rows.astype(np.float64), cols.astype(np.float64), vals])
+            self.cand = np.column_stack([rows.astype(np.float64), cols.astype(np.float64), vals])
+
+        def candidates_fused():
+            return self.cand
 
         if self.fused:
-            self.scan = parallel.SplitBlockScan(n, law_part, nothing, candidates_fused)
+            self.scan = parallel.SplitBlockScan(n, law_part, correlate_fused, candidates_fused)
         else:
             self.scan = parallel.SplitBlockScan(n, law_part, correlate, candidates)
 
@@ -841,8 +842,11 @@ def time_c4p_split(dev, rank, local_rank, world, dist, precision, full_sync, red
             "candidates": int(len(merged)) if merged is not None else 0,
             "workload": f"C4P split: ONE N={n} block (band 0..{w.max_dist + 17}, 2% missing bins, rank 0's seed on every rank) row-split "
                         f"over {world} ranks: per step the distance law's (sum, count) all-reduced, normxcorr2(full=True, sym_upper, "
-                        f"mask, max_dist={w.max_dist}) on the rank's row window (slab + halo resident), coefficients >= 0.3 compacted "
-                        "and all-gathered; N = 1 is the `north_star_c4p` leg (the correlation call alone)"}
+                        f"mask, max_dist={w.max_dist}) on the rank's row window (slab + halo resident) "
+                        + ("through cs_candidates (the tile kernel's candidate epilogue: no coefficient map; float64 re-scoring), the "
+                           "candidates >= 0.3 all-gathered" if w.fused else "coefficients >= 0.3 compacted from the map and all-gathered")
+                        + "; N = 1 is the `north_star_c4p` leg (the correlation call alone)",
+            "form": "cs_candidates" if w.fused else "map + compaction"}
 
 
 def spawn_ranks(n_gpus):

@@ -326,13 +326,15 @@ dist.destroy_process_group()
 """
 
 
-def test_split_map_two_ranks_equal_the_one_rank_map(tmp_path):
+def test_split_map_two_ranks_equal_the_one_rank_map(tmp_path, monkeypatch):
     """bench.py's `north_star_c4p_split` leg (parallel.SplitBlockScan, N > 1) on 2 ranks (gloo rendezvous, both on this GPU)
-    with a 6000-bin block of the C4' generator: the two ranks' row windows together ARE the one-rank coefficient map
-    (to 2e-6: same kernel, other tile boundaries), the merged candidates are the pixels >= 0.3 of the ranks' rows in row-major
-    order on both ranks, the all-reduced law sums are those of the whole band."""
+    with a 6000-bin block of the C4' generator, in its map form (CS_BENCH_SPLIT_MAP=1: coefficient map of the rows + compaction):
+    the two ranks' row windows together ARE the one-rank coefficient map (to 2e-6: same kernel, other tile boundaries), the merged
+    candidates are the pixels >= 0.3 of the ranks' rows in row-major order on both ranks, the all-reduced law sums are those of
+    the whole band.  The default form (cs_candidates: candidate epilogue, no map): test_split_candidates_two_ranks_... below."""
     import bench
     from tools.synthetic_genome import band_workload
+    monkeypatch.setenv("CS_BENCH_SPLIT_MAP", "1")
     n = 6000
     dev = get_device()
     one = bench.SplitC4P(dev, 0, 1, "f32", n=n)
@@ -365,3 +367,69 @@ def test_split_map_two_ranks_equal_the_one_rank_map(tmp_path):
     for p in parts:
         assert np.array_equal(p["merged"], want)
         assert np.allclose(p["law"], law, rtol=1e-12, atol=0)
+
+
+SPLIT_WORKER_FUSED = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["CS_ROOT"])
+import torch.distributed as dist
+import bench
+from chromosight_amd._lib import get_device
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = get_device(0)
+w = bench.SplitC4P(dev, rank, world, "f32", n=int(os.environ["CS_N"]))
+assert w.fused
+for _ in range(2):
+    law, merged = w.scan.step()
+np.savez(os.environ["CS_OUT"] + f".{rank}.npz", rows=np.asarray(w.rows), merged=merged, mine=w.cand)
+def reduce_max(x):
+    import torch
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+leg = bench.time_c4p_split(dev, rank, 0, world, dist, "f32", dev.sync, reduce_max, steps=2, warmup=1, n=int(os.environ["CS_N"]))
+assert leg["n_gpus"] == world and len(leg["per_rank"]) == world and leg["candidates"] == len(merged), leg
+dist.destroy_process_group()
+"""
+
+
+def test_split_candidates_two_ranks_equal_the_one_rank_candidates(tmp_path, monkeypatch):
+    """The default form of the `north_star_c4p_split` leg: every rank runs cs_candidates on its row window -- the
+    masked tile kernel's candidate epilogue, no coefficient map, float64 re-scoring -- and the candidates are all-gathered.  On 2
+    ranks (gloo rendezvous, both on this GPU): each rank's list lies in its own rows, the merged list is the same on both ranks and
+    IS the one-rank list (coordinates exactly, float64 scores to 1e-9: the re-scoring does not depend on how the rows were tiled),
+    and it is the set of pixels >= 0.3 of the map form up to the pixels within float32 rounding of the threshold."""
+    import bench
+    monkeypatch.delenv("CS_BENCH_SPLIT_MAP", raising=False)
+    n = 6000
+    dev = get_device()
+    one = bench.SplitC4P(dev, 0, 1, "f32", n=n)
+    assert one.fused
+    one.scan.step()                                   # (one rank: the step is the chain alone)
+    want = one.cand
+    assert len(want) > 20 and np.all(want[:, 2] >= 0.3)
+    out = tmp_path / "split"
+    script = tmp_path / "worker.py"
+    script.write_text(SPLIT_WORKER_FUSED)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CS_ROOT=root, CS_OUT=str(out), CS_N=str(n), CHROMOSIGHT_HIP_DEVICE="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29549", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    parts = [np.load(f"{out}.{r}.npz") for r in range(2)]
+    for r, p in enumerate(parts):
+        a, b = p["rows"]
+        assert np.all((p["mine"][:, 0] >= a) & (p["mine"][:, 0] < b))
+        assert np.array_equal(p["merged"], parts[0]["merged"])
+    merged = parts[0]["merged"]
+    assert merged.shape == want.shape and np.array_equal(merged[:, :2], want[:, :2])
+    assert np.abs(merged[:, 2] - want[:, 2]).max() < 1e-9
+    # against the map form on one rank: same pixels but for those within float32 rounding of the threshold
+    monkeypatch.setenv("CS_BENCH_SPLIT_MAP", "1")
+    ref = bench.SplitC4P(dev, 0, 1, "f32", n=n)
+    ref.scan.correlate()
+    cmap = ref.scan.candidates()
+    key = lambda t: set(map(tuple, t[:, :2].astype(np.int64)))      # noqa: E731
+    assert len(key(cmap) ^ key(want)) <= 2

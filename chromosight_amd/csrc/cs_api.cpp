@@ -379,7 +379,8 @@ bool fast_available(int km, int kn, int* K);
 bool mfma_wide_wanted(const cs::CorrArgs<float>& A)
 {
     if (!cs::corr_mfma_wide_fits(A.km, A.kn) || (A.km <= 17 && A.kn <= 17)) return false;
-    if (A.sig.counts || A.sig.layout == CS_LAYOUT_BAND_LAZY || !A.out.ptr) return false;
+    if (A.sig.counts || A.sig.layout == CS_LAYOUT_BAND_LAZY) return false;
+    if (!A.out.ptr && !(A.cand_keys && A.cand_count && !A.defer_args && A.ks.cand_cmin > 0.0f)) return false;     // a map, or a candidate sink
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA") || std::getenv("CHROMOSIGHT_HIP_NO_WIDE")) return false;
     return true;
 }
@@ -668,6 +669,18 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         }
     }
     if (A.sig.counts) return fail(ctx, CS_ERR_UNSUPPORTED, "a band of counts (CS_LAYOUT_BAND_COUNTS) is read by the masked float32 tile kernel only: per-bin masks, full mode, odd square template of up to 17");
+    if (!A.out.ptr && allow_fast && mfma_wide_wanted(A) && !A.w_rank1) {
+        // candidate sink without a map, template side 18 .. 33: the two-pass kernel appends the candidates itself
+        cs::MfmaWideWeights E;
+        rc = ensure_wfrag_wide(ctx, stream, A.km, A.kn, &E);
+        if (rc != CS_OK) return rc;
+        ctx->last_kernel = CS_KERNEL_MFMA_WIDE;
+        rc = cs::launch_corr_mfma_wide_f32(A, E, stream);
+        if (rc == -5) return CS_NEED_MAP;
+        if (rc != 0) return fail(ctx, CS_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        ctx->cand_fused = true;
+        return CS_OK;
+    }
     if (!A.out.ptr) return CS_NEED_MAP;      // every other kernel writes a map
     if (allow_fast && mfma_wanted(A)) {
         if (A.sig_is_f64 && A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.nobs.ptr) {

@@ -795,6 +795,18 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
         }
         return r;
     };
+    // candidate sink (cs_device.h CorrArgs::cand_keys: cs_detect_foci / cs_candidates): no map leaves the kernel, only the keys
+    // tag + row * ns + col of the pixels that carry a candidate value (>= cand_thr: the screen's sentinel included), appended to
+    // the caller's list -- 1e-4 of the pixels, one atomic each; the counter runs on beyond the capacity so that the caller learns
+    // how much room a second call needs
+    const bool sinking = A.cand_keys != nullptr;
+    auto sink = [&](int i, int j, float r) {
+        if (r >= A.ks.cand_thr) {
+            const unsigned long long pos = atomicAdd(A.cand_count, 1ull);
+            if (pos < (unsigned long long)A.cand_cap)
+                A.cand_keys[pos] = A.cand_tag + (unsigned long long)i * (unsigned long long)A.ns + (unsigned long long)j;
+        }
+    };
     if (plain) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -802,6 +814,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
             for (int v = 0; v < 4; ++v) {
                 float nobs;
                 const float r = coefficient(c, v, nobs);
+                if (sinking) {
+                    sink(i_lane + v, j_lane + 16 * c, r);
+                    continue;
+                }
                 const long long o = o_lane + v * o_row + 16 * c;
                 if (A.out_is_f64) reinterpret_cast<double*>(A.out.ptr)[o] = (double)r;
                 else reinterpret_cast<float*>(A.out.ptr)[o] = r;
@@ -820,6 +836,10 @@ __global__ __launch_bounds__(256, 2) void corr_mfma_wide_kernel(const CorrArgs<f
                 if (d < A.out_lo || d > A.out_hi) continue;
                 float nobs;
                 const float r = coefficient(c, v, nobs);
+                if (sinking) {
+                    if (!pixel_forced_zero(A, i, j)) sink(i, j, r);
+                    continue;
+                }
                 store_pixel(A, i, j, pixel_forced_zero(A, i, j) ? 0.0f : r, nobs);
             }
         }
@@ -875,7 +895,8 @@ int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipS
 {
     if (!corr_mfma_wide_fits(A.km, A.kn)) return -3;
     if (A.sig.counts || A.sig.layout == 2) return -6;      // (bands of counts / lazily evaluated bands: other readers)
-    if (!A.out.ptr) return -5;                             // this kernel writes a map
+    if (!A.out.ptr && !(A.cand_keys && A.cand_count && A.ks.cand_cmin > 0.0f)) return -5;      // a map, or a candidate sink
+    if (A.defer_args) return -5;                           // (argument tables of the multi-block launch: the 17 x 17 tile kernel only)
     A.tile_w = A.tile_h = WD_T;
     A.tiles_y = (A.row_end - A.row_begin + WD_T - 1) / WD_T;
     if (A.out.layout == 1) {
@@ -886,6 +907,13 @@ int launch_corr_mfma_wide_f32(CorrArgs<float>& A, const MfmaWideWeights& E, hipS
         A.out_lo = -(1 << 30);
         A.out_hi = (1 << 30);
         A.tiles_x = (A.ns + WD_T - 1) / WD_T;
+    }
+    if (A.cand_keys && !A.out.ptr) {
+        // candidate sink: only the scanned diagonals (the map path trims in the compaction)
+        A.out_lo = std::max(A.out_lo, A.cand_dlo);
+        A.out_hi = std::min(A.out_hi, A.cand_dhi);
+    } else {
+        A.cand_keys = nullptr;                             // (a map was asked for: the kernel writes it)
     }
     const long long blocks = (long long)A.tiles_x * A.tiles_y;
     if (blocks <= 0) return 0;

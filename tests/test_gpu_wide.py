@@ -360,3 +360,48 @@ def test_random_wide_configuration(seed, monkeypatch):
         assert last_kernel() == KERNEL_MFMA_WIDE
         want, cond = c_oracle.normxcorr2_rows(a, kern, 0, shape[0], sym_upper=False, full=True, miss_row=mr, miss_col=mc)
         assert_parity(got.toarray(), want, cond, "f32", f"wide sweep {seed} inter {shape} {km}x{kn}", max_ill_frac=0.05)
+
+
+def test_candidate_sink_equals_the_map_path(monkeypatch):
+    """cs_candidates (first half of detect mode) under a 21 x 21 template: the two-pass kernel appends the candidate pixels itself
+    (CorrArgs::cand_keys: no coefficient map, no compaction pass) -- the same pixels and float64 scores as the map + compaction path
+    on the runtime-size kernel, on a banded map with missing bins (whole map and a row window) and on an inter-like dense map."""
+    dev = get_device()
+    rng = np.random.default_rng(77)
+    n, md = 1800, 420
+    kern = template((21, 21))
+    bw = md + 21 + 1
+    ld = (bw + 4 + 63) // 64 * 64
+    band = np.zeros((n, ld), dtype=np.float32)
+    d = np.arange(bw)
+    band[:, :bw] = np.minimum(rng.gamma(20, 0.05, size=(n, bw)), 10.0)
+    # a few planted blobs so that some windows correlate
+    for i0, d0 in [(200, 100), (700, 300), (1200, 50), (1500, 380), (900, 200)]:
+        ii, jj = np.indices((21, 21))
+        blob = 1.0 + 2.5 * np.exp(-((ii - 10) ** 2 + (jj - 10) ** 2) / 30.0)
+        for r in range(21):
+            for c in range(21):
+                i, j = i0 - 10 + r, i0 + d0 - 10 + c
+                if 0 <= j - i < bw:
+                    band[i, j - i] *= blob[r, c]
+    miss = (rng.random(n) < 0.03).astype(np.uint8)
+    band[miss.astype(bool)] = 0
+    for i in range(n):
+        cols = i + d
+        band[i, :bw][(cols >= n) | miss[np.minimum(cols, n - 1)].astype(bool)] = 0
+    d_sig, d_miss = dev.to_device(band), dev.to_device(miss)
+    sig = CsMatrix(d_sig.ptr, np_dtype_code(np.float32), LAYOUT_BAND, ld, 0, bw)
+    kw = dict(pearson=0.25, lo_diag=0, hi_diag=md, inter=False, full=True, sym_upper=True, max_dist=md, mask_mode=MASK_BINS,
+              miss_row=d_miss, miss_col=d_miss, missing_tol=0.5, precision="f32")
+    for window in ((0, n), (517, 1290)):
+        got = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), window, **kw)
+        assert last_kernel() == KERNEL_MFMA_WIDE
+        monkeypatch.setenv("CHROMOSIGHT_HIP_NO_WIDE", "1")
+        ref = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), window, **kw)
+        assert last_kernel() == KERNEL_GENERIC
+        monkeypatch.delenv("CHROMOSIGHT_HIP_NO_WIDE")
+        assert len(ref[0]) > 10
+        a = np.lexsort((got[1], got[0]))
+        b = np.lexsort((ref[1], ref[0]))
+        assert np.array_equal(got[0][a], ref[0][b]) and np.array_equal(got[1][a], ref[1][b])
+        assert np.abs(got[2][a] - ref[2][b]).max() < 1e-12           # float64 re-scoring: the same function on the same pixels

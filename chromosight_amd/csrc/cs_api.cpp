@@ -1076,6 +1076,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_wfrag) (void)hipFree(ctx->d_wfrag);
     if (ctx->d_rim) (void)hipFree(ctx->d_rim);
     if (ctx->d_wfrag_wide) (void)hipFree(ctx->d_wfrag_wide);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     for (int k = 0; k < 2; ++k) {

@@ -928,6 +928,121 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
     if (rc) return rc;
     if (!n_out || cap < 0 || (cap > 0 && (!h_rows || !h_cols || !h_vals))) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
     *n_out = 0;
+    // ---- One synchronisation for the usual case (a 2-D pattern in float32 arithmetic on a kernel with a candidate sink, a few hundred
+    // candidates): tile kernel -> decode the first kFirst keys -> float64 re-scoring bounded by the DEVICE's count -> one download of
+    // the count and the kFirst-entry heads -> threshold and order on the host.  The general flow below reads the count first (to size
+    // what follows), sorts and compacts on the device and synchronises three times: 0.14 ms that a rank's share of a row-split block
+    // waited for behind a 0.23 ms tile kernel (profiles/r06_c4p_split_shares.txt).  A list longer than the key list's capacity, or a
+    // kernel without a sink, takes the general flow.
+    const bool band_sig = signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED;
+    if (p->compute_dtype == CS_F32 && !(band_sig && fp->hi_diag - fp->lo_diag + 1 <= 4) && fp->hi_diag >= fp->lo_diag &&
+        !std::getenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP")) {
+        constexpr long long kFirst = 8192;
+        int rb = 0, re = p->ms;
+        if (p->row_end > p->row_begin) {
+            if (p->row_begin < 0 || p->row_end > p->ms) return fail(ctx, CS_ERR_INVALID, "row window outside the matrix");
+            rb = p->row_begin;
+            re = p->row_end;
+        }
+        cs_matrix map;                                          // the output geometry of the sink (no storage)
+        map.d_ptr = nullptr;
+        map.dtype = CS_F32;
+        map.layout = band_sig ? CS_LAYOUT_BAND : signal->layout;
+        map.row0 = rb;
+        map.band_lo = band_sig ? fp->lo_diag : 0;
+        map.band_w = band_sig ? fp->hi_diag - fp->lo_diag + 1 : 0;
+        map.ld = band_sig ? ((int64_t)map.band_w + 63) / 64 * 64 : ((int64_t)p->ns + 15) / 16 * 16;
+        const bool plain_layout = band_sig || signal->layout == CS_LAYOUT_DENSE;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(band_sig ? map.band_w : p->ns) / 256);
+        // device scratch: keys[c_cap] | count | heads: rows[kFirst] cols[kFirst] vals[kFirst] | the rest: rows, cols, vals of c_cap - kFirst
+        const size_t off_cnt = al(8 * c_cap), off_rows = off_cnt + 256, off_cols = off_rows + al(4 * kFirst), off_vals = off_cols + al(4 * kFirst);
+        const size_t rest = c_cap - (size_t)kFirst;
+        const size_t off_rows2 = off_vals + al(8 * kFirst), off_cols2 = off_rows2 + al(4 * rest), off_vals2 = off_cols2 + al(4 * rest);
+        const size_t h_bytes = 256 + 4 * kFirst + 4 * kFirst + 8 * kFirst;
+        rc = plain_layout ? ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_vals2 + al(8 * rest)) : CS_ERR_UNSUPPORTED;
+        if (rc == CS_OK && !ctx->h_small) {
+            if (hipHostMalloc(&ctx->h_small, h_bytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->h_small = nullptr;
+                rc = CS_ERR_HIP;
+            }
+        }
+        if (rc == CS_OK) {
+            char* pool = (char*)ctx->d_pool;
+            unsigned long long* d_keys = (unsigned long long*)pool;
+            long long* d_cnt = (long long*)(pool + off_cnt);
+            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+            const double margin = std::max(fp->rescore_margin, 1e-4);
+            CandSink sink{d_keys, (unsigned long long*)d_cnt, (long long)c_cap, 0ull, fp->lo_diag, fp->hi_diag};
+            rc = corr_candidates_f32(ctx, stream, signal, kernel, p, &map, margin, fp->pearson - margin, &sink);
+            if (rc == CS_OK) {
+                int* d_rows = (int*)(pool + off_rows);
+                int* d_cols = (int*)(pool + off_cols);
+                double* d_vals = (double*)(pool + off_vals);
+                // (keys beyond the count are whatever the pool held: decoded, never re-scored -- the re-scoring stops at the count)
+                rc = cs::launch_decode_keys((const long long*)d_keys, kFirst, p->ns, d_rows, d_cols, stream);
+                if (rc) return fail(ctx, CS_ERR_HIP, "key decoding failed: %s", hipGetErrorString((hipError_t)rc));
+                cs::CorrArgs<double> A64;
+                rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
+                if (rc) return rc;
+                rc = cs::launch_rescore_f64(A64, d_rows, d_cols, kFirst, d_vals, nullptr, stream, d_cnt);
+                if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
+                char* h = (char*)ctx->h_small;
+                CS_HIP(ctx, hipMemcpyAsync(h, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+                CS_HIP(ctx, hipMemcpyAsync(h + 256, d_rows, off_vals + 8 * kFirst - off_rows, hipMemcpyDeviceToHost, stream));
+                CS_HIP(ctx, hipStreamSynchronize(stream));
+                const long long n_cand = *reinterpret_cast<const long long*>(h);
+                if (n_cand <= (long long)c_cap) {
+                    const int32_t* rows = reinterpret_cast<const int32_t*>(h + 256);
+                    const int32_t* cols = reinterpret_cast<const int32_t*>(h + 256 + (off_cols - off_rows));
+                    const double* vals = reinterpret_cast<const double*>(h + 256 + (off_vals - off_rows));
+                    // a list longer than the heads (a whole 200 000-bin block: ~ 15 000 candidates before the float64 scores thin them
+                    // out): the rest is decoded and re-scored from the SAME key list -- the tile kernel does not run again -- and
+                    // arrives with a second synchronisation
+                    std::vector<int32_t> rows2, cols2;
+                    std::vector<double> vals2;
+                    const long long m2 = std::max(0ll, n_cand - kFirst);
+                    if (m2 > 0) {
+                        int* d_r2 = (int*)(pool + off_rows2);
+                        int* d_c2 = (int*)(pool + off_cols2);
+                        double* d_v2 = (double*)(pool + off_vals2);
+                        rc = cs::launch_decode_keys((const long long*)d_keys + kFirst, m2, p->ns, d_r2, d_c2, stream);
+                        if (rc) return fail(ctx, CS_ERR_HIP, "key decoding failed: %s", hipGetErrorString((hipError_t)rc));
+                        rc = cs::launch_rescore_f64(A64, d_r2, d_c2, m2, d_v2, nullptr, stream);
+                        if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
+                        rows2.resize((size_t)m2);
+                        cols2.resize((size_t)m2);
+                        vals2.resize((size_t)m2);
+                        CS_HIP(ctx, hipMemcpyAsync(rows2.data(), d_r2, 4 * (size_t)m2, hipMemcpyDeviceToHost, stream));
+                        CS_HIP(ctx, hipMemcpyAsync(cols2.data(), d_c2, 4 * (size_t)m2, hipMemcpyDeviceToHost, stream));
+                        CS_HIP(ctx, hipMemcpyAsync(vals2.data(), d_v2, 8 * (size_t)m2, hipMemcpyDeviceToHost, stream));
+                        CS_HIP(ctx, hipStreamSynchronize(stream));
+                    }
+                    auto row_of = [&](uint32_t t) { return t < (uint32_t)kFirst ? rows[t] : rows2[t - (uint32_t)kFirst]; };
+                    auto col_of = [&](uint32_t t) { return t < (uint32_t)kFirst ? cols[t] : cols2[t - (uint32_t)kFirst]; };
+                    auto val_of = [&](uint32_t t) { return t < (uint32_t)kFirst ? vals[t] : vals2[t - (uint32_t)kFirst]; };
+                    std::vector<uint32_t> keep;
+                    keep.reserve((size_t)n_cand);
+                    for (long long t = 0; t < n_cand; ++t)
+                        if (val_of((uint32_t)t) >= fp->pearson && val_of((uint32_t)t) != 0.0) keep.push_back((uint32_t)t);      // (flag_keep_kernel's rule)
+                    std::sort(keep.begin(), keep.end(),
+                              [&](uint32_t a, uint32_t b) { return row_of(a) != row_of(b) ? row_of(a) < row_of(b) : col_of(a) < col_of(b); });
+                    *n_out = (int64_t)keep.size();
+                    if ((int64_t)keep.size() > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld candidates, room for %lld", (long long)keep.size(), (long long)cap);
+                    for (size_t t = 0; t < keep.size(); ++t) {
+                        h_rows[t] = row_of(keep[t]);
+                        h_cols[t] = col_of(keep[t]);
+                        h_vals[t] = val_of(keep[t]);
+                    }
+                    return CS_OK;
+                }
+                // (more candidates than the key list holds: the general flow, which sizes its list by the count)
+            } else if (rc != CS_NEED_MAP) {
+                return rc;
+            }
+        }
+    }
     CandPlan P;
     rc = find_candidates(ctx, stream_, signal, kernel, p, fp, 0, cs::keep_scratch_bytes, &P);
     if (rc) return rc;
@@ -936,6 +1051,36 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
     rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
     if (rc) return rc;
     char* pool = (char*)ctx->d_pool;
+    constexpr long long kSmallList = 16384;
+    if (P.n_cand <= kSmallList && !std::getenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP")) {
+        // A short candidate list (a 2-D pattern: 1e-5 of the scanned pixels) is re-scored as it came -- unsorted -- downloaded with ONE
+        // synchronisation and thresholded and ordered on the host: the device form below costs a dozen launches (keys, a three-pass
+        // sort, decode, flags, scan, scatter, decode), a count read-back and a second synchronisation, which is what a rank's share of a
+        // row-split block waited for once its tile kernel was done (profiles/r06_c4p_split_shares.txt: 0.14 ms of a 0.40 ms step).
+        const size_t m = (size_t)P.n_cand;
+        double* d_vals = reinterpret_cast<double*>(pool + P.off_tail);
+        rc = cs::launch_rescore_f64(A64, (const int*)pool, (const int*)(pool + P.off_cols), P.n_cand, d_vals, nullptr, stream);
+        if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
+        std::vector<int32_t> rows(m), cols(m);
+        std::vector<double> vals(m);
+        CS_HIP(ctx, hipMemcpyAsync(rows.data(), pool, 4 * m, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipMemcpyAsync(cols.data(), pool + P.off_cols, 4 * m, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipMemcpyAsync(vals.data(), d_vals, 8 * m, hipMemcpyDeviceToHost, stream));
+        CS_HIP(ctx, hipStreamSynchronize(stream));
+        std::vector<uint32_t> keep;
+        keep.reserve(m);
+        for (size_t t = 0; t < m; ++t)
+            if (vals[t] >= fp->pearson && vals[t] != 0.0) keep.push_back((uint32_t)t);          // (flag_keep_kernel's rule)
+        std::sort(keep.begin(), keep.end(), [&](uint32_t a, uint32_t b) { return rows[a] != rows[b] ? rows[a] < rows[b] : cols[a] < cols[b]; });
+        *n_out = (int64_t)keep.size();
+        if ((int64_t)keep.size() > cap) return fail(ctx, CS_ERR_OVERFLOW, "%lld candidates, room for %lld", (long long)keep.size(), (long long)cap);
+        for (size_t t = 0; t < keep.size(); ++t) {
+            h_rows[t] = rows[keep[t]];
+            h_cols[t] = cols[keep[t]];
+            h_vals[t] = vals[keep[t]];
+        }
+        return CS_OK;
+    }
     int *d_rows = nullptr, *d_cols = nullptr, *d_n = nullptr;
     double* d_vals = nullptr;
     rc = cs::enqueue_keep(A64, (const int*)pool, (const int*)(pool + P.off_cols), P.n_cand, fp->pearson, pool + P.off_tail,

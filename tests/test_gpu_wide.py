@@ -405,3 +405,19 @@ def test_candidate_sink_equals_the_map_path(monkeypatch):
         b = np.lexsort((ref[1], ref[0]))
         assert np.array_equal(got[0][a], ref[0][b]) and np.array_equal(got[1][a], ref[1][b])
         assert np.abs(got[2][a] - ref[2][b]).max() < 1e-12           # float64 re-scoring: the same function on the same pixels
+        # the short-list form of cs_candidates (re-scored unsorted, thresholded and ordered on the host) against the device form
+        assert np.array_equal(a, np.arange(len(a)))                  # row-major as it comes
+        monkeypatch.setenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP", "1")
+        dev_form = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), window, **kw)
+        monkeypatch.delenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP")
+        assert all(np.array_equal(x, y) for x, y in zip(got, dev_form))
+    # a list longer than the heads that come back with the count (8192): the rest is decoded and re-scored from the same key list
+    for kw["pearson"] in (0.2, 0.18, 0.16, 0.15, 0.14, 0.13, 0.12, 0.11, 0.1):
+        got = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), (0, n), **kw)
+        if len(got[0]) > 8192:
+            break
+    assert last_kernel() == KERNEL_MFMA_WIDE and 8192 < len(got[0]) < 60000, (kw["pearson"], len(got[0]), last_kernel())
+    monkeypatch.setenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP", "1")
+    dev_form = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), (0, n), **kw)
+    monkeypatch.delenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP")
+    assert all(np.array_equal(x, y) for x, y in zip(got, dev_form))

@@ -378,7 +378,8 @@ bool fast_available(int km, int kn, int* K);
 // CHROMOSIGHT_HIP_NO_MFMA=1 / CHROMOSIGHT_HIP_NO_WIDE=1: never (the runtime-size kernel: the in-library cross-check).
 bool mfma_wide_wanted(const cs::CorrArgs<float>& A)
 {
-    if (!cs::corr_mfma_wide_fits(A.km, A.kn) || (A.km <= 17 && A.kn <= 17)) return false;
+    // (templates of up to 17 x 17 have their own instances; CHROMOSIGHT_HIP_WIDE_ALL=1 sends them here too: a measurement switch)
+    if (!cs::corr_mfma_wide_fits(A.km, A.kn) || (A.km <= 17 && A.kn <= 17 && !std::getenv("CHROMOSIGHT_HIP_WIDE_ALL"))) return false;
     if (A.sig.counts || A.sig.layout == CS_LAYOUT_BAND_LAZY) return false;
     if (!A.out.ptr && !(A.cand_keys && A.cand_count && !A.defer_args && A.ks.cand_cmin > 0.0f)) return false;     // a map, or a candidate sink
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA") || std::getenv("CHROMOSIGHT_HIP_NO_WIDE")) return false;
@@ -398,6 +399,7 @@ bool mfma_wide_wanted(const cs::CorrArgs<float>& A)
 bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
 {
     if (A.mask_mode != CS_MASK_BINS || !A.full || A.km != A.kn || A.km > 17 || A.km < 3 || !(A.km & 1)) return false;
+    if (std::getenv("CHROMOSIGHT_HIP_WIDE_ALL")) return false;
     if (A.xcorr_only) return false;            // (float64 containers are narrowed row by row first, see launch_corr)
     if ((A.sig.layout == CS_LAYOUT_BAND ? A.sig.band_w : A.ns) < 4) return false;      // 16-byte staging pieces
     if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
@@ -417,7 +419,7 @@ bool mfma_reg_wanted(const cs::CorrArgs<float>& A)
 bool mfma_wanted(const cs::CorrArgs<float>& A)
 {
     if (A.km < 1 || A.kn < 1 || A.km > 17 || A.kn > 17) return false;
-    if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA")) return false;
+    if (std::getenv("CHROMOSIGHT_HIP_NO_MFMA") || std::getenv("CHROMOSIGHT_HIP_WIDE_ALL")) return false;
     const char* e = std::getenv("CHROMOSIGHT_HIP_MFMA");
     if (e && e[0] == '1') return true;
     const bool dense_f32 = A.mask_mode == 0 && A.sig.layout == 0 && A.out.layout == 0 && !A.nobs.ptr;
@@ -706,7 +708,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         int dense_path = 0;
         rc = cs::launch_corr_mfma_f32(A, E, stream, &dense_path);
         ctx->last_kernel = dense_path == 1 ? CS_KERNEL_MFMA_DENSE : dense_path == 2 ? CS_KERNEL_MFMA_REG : CS_KERNEL_MFMA;
-    } else if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K)) {
+    } else if (allow_fast && fast_compatible(A) && fast_available(A.km, A.kn, &K) && !std::getenv("CHROMOSIGHT_HIP_WIDE_ALL")) {
         ctx->last_kernel = CS_KERNEL_STREAM;
 #ifdef CS_HAVE_FAST
 #define CS_CASE(KK)                          \
@@ -1077,6 +1079,7 @@ void cs_ctx_destroy(cs_ctx* ctx)
     if (ctx->d_rim) (void)hipFree(ctx->d_rim);
     if (ctx->d_wfrag_wide) (void)hipFree(ctx->d_wfrag_wide);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->d_cand_cnt) (void)hipFree(ctx->d_cand_cnt);
     if (ctx->d_map) (void)hipFree(ctx->d_map);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     for (int k = 0; k < 2; ++k) {

@@ -956,6 +956,7 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(band_sig ? map.band_w : p->ns) / 256);
         // device scratch: keys[c_cap] | count | heads: rows[kFirst] cols[kFirst] vals[kFirst] | the rest: rows, cols, vals of c_cap - kFirst
+        // ('count' = the copy of the device's counter that travels with the heads; the counters themselves: ctx->d_cand_cnt)
         const size_t off_cnt = al(8 * c_cap), off_rows = off_cnt + 256, off_cols = off_rows + al(4 * kFirst), off_vals = off_cols + al(4 * kFirst);
         const size_t rest = c_cap - (size_t)kFirst;
         const size_t off_rows2 = off_vals + al(8 * kFirst), off_cols2 = off_rows2 + al(4 * rest), off_vals2 = off_cols2 + al(4 * rest);
@@ -968,30 +969,42 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
                 rc = CS_ERR_HIP;
             }
         }
+        if (rc == CS_OK && !ctx->d_cand_cnt) {
+            if (hipMalloc((void**)&ctx->d_cand_cnt, 512) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->d_cand_cnt = nullptr;
+                rc = CS_ERR_HIP;
+            }
+            ctx->cand_cnt_clean = false;
+        }
         if (rc == CS_OK) {
             char* pool = (char*)ctx->d_pool;
             unsigned long long* d_keys = (unsigned long long*)pool;
-            long long* d_cnt = (long long*)(pool + off_cnt);
-            CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, stream));
+            if (!ctx->cand_cnt_clean) CS_HIP(ctx, hipMemsetAsync(ctx->d_cand_cnt, 0, 512, stream));
+            ctx->cand_cnt_clean = false;                        // (until this call's kernels are known to have run)
+            long long* d_cnt = ctx->d_cand_cnt + 32 * ctx->cand_cnt_phase;
+            long long* d_cnt_next = ctx->d_cand_cnt + 32 * (ctx->cand_cnt_phase ^ 1);
             const double margin = std::max(fp->rescore_margin, 1e-4);
             CandSink sink{d_keys, (unsigned long long*)d_cnt, (long long)c_cap, 0ull, fp->lo_diag, fp->hi_diag};
             rc = corr_candidates_f32(ctx, stream, signal, kernel, p, &map, margin, fp->pearson - margin, &sink);
             if (rc == CS_OK) {
-                int* d_rows = (int*)(pool + off_rows);
-                int* d_cols = (int*)(pool + off_cols);
-                double* d_vals = (double*)(pool + off_vals);
-                // (keys beyond the count are whatever the pool held: decoded, never re-scored -- the re-scoring stops at the count)
-                rc = cs::launch_decode_keys((const long long*)d_keys, kFirst, p->ns, d_rows, d_cols, stream);
-                if (rc) return fail(ctx, CS_ERR_HIP, "key decoding failed: %s", hipGetErrorString((hipError_t)rc));
+                int* h_rows_small = (int*)((char*)ctx->h_small + 256);
+                int* h_cols_small = (int*)((char*)ctx->h_small + 256 + (off_cols - off_rows));
+                double* h_vals_small = (double*)((char*)ctx->h_small + 256 + (off_vals - off_rows));
                 cs::CorrArgs<double> A64;
                 rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
                 if (rc) return rc;
-                rc = cs::launch_rescore_f64(A64, d_rows, d_cols, kFirst, d_vals, nullptr, stream, d_cnt);
+                // keys -> pixels and float64 scores of the first min(kFirst, count) of them; the count lands next to them and the
+                // other counter is cleared for the next call
+                // -- written by the kernel straight into the page-locked host block (h_small is mapped and coherent: a few hundred
+                // 4- and 8-byte stores over the link instead of a 9 us wait for the copy engine and an 8 us copy)
+                rc = cs::launch_rescore_f64_keys(A64, (const long long*)d_keys, p->ns, kFirst, h_rows_small, h_cols_small, h_vals_small, d_cnt,
+                                                 (long long*)ctx->h_small, d_cnt_next, stream);
                 if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
                 char* h = (char*)ctx->h_small;
-                CS_HIP(ctx, hipMemcpyAsync(h, d_cnt, 8, hipMemcpyDeviceToHost, stream));
-                CS_HIP(ctx, hipMemcpyAsync(h + 256, d_rows, off_vals + 8 * kFirst - off_rows, hipMemcpyDeviceToHost, stream));
                 CS_HIP(ctx, hipStreamSynchronize(stream));
+                ctx->cand_cnt_phase ^= 1;
+                ctx->cand_cnt_clean = true;
                 const long long n_cand = *reinterpret_cast<const long long*>(h);
                 if (n_cand <= (long long)c_cap) {
                     const int32_t* rows = reinterpret_cast<const int32_t*>(h + 256);

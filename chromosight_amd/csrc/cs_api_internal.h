@@ -90,6 +90,9 @@ struct cs_ctx {
     size_t d_pool_bytes = 0;
     long long* h_counts = nullptr;   // pinned: [0] candidates, [1] foci
     void* h_small = nullptr;              // page-locked: count + the heads of a short candidate list (cs_candidates, one download)
+    long long* d_cand_cnt = nullptr;      // two candidate counters (256 B apart) that alternate between calls of cs_candidates: the
+    int cand_cnt_phase = 0;               // re-scoring kernel of one call clears the counter of the next (no memset in the chain);
+    bool cand_cnt_clean = false;          // false until a call has gone through: both are cleared before use
     long long* h_cand_counts = nullptr;   // pinned, 256 entries (cs_detect_foci_blocks, segmented lists): [b] the blocks' own candidate counts, [60] their
                                           // clamped total, [61] status flags; [64 + b] / [128 + b]: the regions' starts / rooms the device reads
     void* d_counts_peak = nullptr;   // cs_normxcorr2_host: largest |pixel| of the map (float bits), and its pinned copy

@@ -391,6 +391,33 @@ __global__ __launch_bounds__(256) void rescore_f64_kernel(const CorrArgs<double>
     }
 }
 
+// The same from a list of pixel KEYS (row * ns + col, what a tile kernel's candidate sink appends): decoded here (rows[], cols[]
+// written for the host), the device's count copied next to them (count_copy, so that ONE download carries count, pixels and
+// scores) and the counter of the NEXT call cleared (zero_next: two counters alternate, no memset in the chain).
+__global__ __launch_bounds__(256) void rescore_f64_keys_kernel(const CorrArgs<double> A, const long long* __restrict__ keys, int ns,
+                                                               long long n_px, int* __restrict__ rows, int* __restrict__ cols,
+                                                               double* __restrict__ out_corr, const long long* __restrict__ n_ptr,
+                                                               long long* __restrict__ count_copy, long long* __restrict__ zero_next)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n = *n_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *count_copy = n;
+        if (zero_next) *zero_next = 0;
+    }
+    if (t >= n_px || t >= n) return;
+    const long long k = keys[t];
+    const int i = (int)(k / ns), j = (int)(k - (k / ns) * ns);
+    double r, nobs;
+    rescore_pixel(A, i, j, lane, r, nobs);
+    if (lane == 0) {
+        rows[t] = i;
+        cols[t] = j;
+        out_corr[t] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void rescore_f64_run_kernel(const CorrArgs<double> A, const int* __restrict__ rows,
                                                               const int* __restrict__ cols, long long n_px,
                                                               double* __restrict__ out_corr, double* __restrict__ out_nobs,
@@ -416,6 +443,15 @@ int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* co
     const long long blocks = (n_px + 3) / 4;              // 4 waves = 4 pixels per block
     hipLaunchKernelGGL(rescore_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, rows, cols, n_px, out_corr,
                        out_nobs, n_ptr);
+    return (int)hipGetLastError();
+}
+
+int launch_rescore_f64_keys(const CorrArgs<double>& A, const long long* keys, int ns, long long n_px, int* rows, int* cols,
+                            double* out_corr, const long long* n_ptr, long long* count_copy, long long* zero_next, hipStream_t stream)
+{
+    if (n_px <= 0 || !n_ptr || !count_copy) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rescore_f64_keys_kernel, dim3((unsigned)((n_px + 3) / 4)), dim3(256), 0, stream, A, keys, ns, n_px, rows, cols,
+                       out_corr, n_ptr, count_copy, zero_next);
     return (int)hipGetLastError();
 }
 

@@ -741,6 +741,10 @@ int launch_compact_ge(const MatView& corr, int corr_is_f64, int ms, int ns, doub
 // run != 0: the list is a run of neighbouring pixels (enumerated diagonals): one lane per pixel
 int launch_rescore_f64(const CorrArgs<double>& A, const int* rows, const int* cols, long long n_px,
                        double* out_corr, double* out_nobs, hipStream_t stream, const long long* n_ptr = nullptr, int run = 0);
+// the same from pixel keys (row * ns + col): rows[], cols[] and the scores of the first min(n_px, *n_ptr) keys; *count_copy = *n_ptr;
+// *zero_next = 0 when given (the counter the next call will use)
+int launch_rescore_f64_keys(const CorrArgs<double>& A, const long long* keys, int ns, long long n_px, int* rows, int* cols,
+                            double* out_corr, const long long* n_ptr, long long* count_copy, long long* zero_next, hipStream_t stream);
 int launch_csr_band_extent(const CsrView& M, int lo_diag, int hi_diag, long long* begin, long long* end,
                            hipStream_t stream);
 int launch_law_finish(const double* sum, const long long* cnt, int n, double* law, hipStream_t stream);

@@ -56,7 +56,7 @@ def band_cases(dev, workload):
     d_sig, d_out = dev.to_device(band), dev.zeros((n, ld_out), np.float32)
     d_miss = dev.to_device(miss)
     slow = workload == "c3"
-    cases = [("loops 17x17", "loops", {})]
+    cases = [("loops 17x17", "loops", {}), ("loops 17x17", "loops", {"CHROMOSIGHT_HIP_WIDE_ALL": "1"})]
     for k in (19, 21, 25, 33):
         cases.append((f"full rank {k}x{k}", k, {}))
         cases.append((f"full rank {k}x{k}", k, {"CHROMOSIGHT_HIP_WIDE_PLANE": "1"}))
@@ -87,7 +87,7 @@ def dense_cases(dev):
     d_sig, ld_in = engine.to_device_map(dev, sig)
     ld_out = engine.map_pitch(n, 4)
     d_out = dev.empty((n, ld_out), np.float32)
-    cases = [("loops 17x17", "loops", {})]
+    cases = [("loops 17x17", "loops", {}), ("loops 17x17", "loops", {"CHROMOSIGHT_HIP_WIDE_ALL": "1"})]
     for k in (19, 21, 25, 33):
         cases.append((f"full rank {k}x{k}", k, {}))
     cases.append(("full rank 21x21", 21, {"CHROMOSIGHT_HIP_NO_WIDE": "1"}))

@@ -472,7 +472,7 @@ void fill_grid(cs::CorrArgs<TC>& A, int tw, int th, bool aligned_x = true)
 // Decide whether the factorised per-bin mask path applies and, if so, build its tables in the
 // context's scratch buffer (cs_mask_prep.hip).  K = template size served by a streaming kernel.
 template <typename TC>
-int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t stream, bool rim_in_kernel = false)
+int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t stream, bool rim_in_kernel = false, bool tile_reader = false)
 {
     A.reg_mode = 0;
     A.fix_on = 0;
@@ -561,6 +561,17 @@ int prepare_regular_mask(cs_ctx* ctx, cs::CorrArgs<TC>& A, int K, hipStream_t st
     P.side = side;
     P.fix_rows = fix_rows;
     P.fix_cols = fix_cols;
+    if (tile_reader && edge_tables && !edge_records && (A.row_begin > 0 || A.row_end < A.ms) && !std::getenv("CHROMOSIGHT_HIP_FULL_MASK_TABLES")) {
+        // A row window read by the 64 x 64 tiles of the matrix-core kernel (a rank's share of a row-split block): the table entries
+        // of its rows and of the columns its strip of tiles reaches (J0 + lane, J0 <= I0 + out_lo + 64 (tiles_x - 1)), and the frame
+        // rows only when the window touches them -- the tables of all 200 000 bins cost 19 us in front of an eighth's 220 us of tiles
+        P.r_lo = std::max(0, A.row_begin);
+        P.r_hi = std::min(A.ms, A.row_end + 64);
+        P.c_lo = std::max(0, A.row_begin + A.out_lo - 64);
+        P.c_hi = (int)std::min<long long>(A.ns, (long long)A.row_end + A.out_hi + 320);
+        P.skip_top = P.r_lo >= top ? 1 : 0;
+        P.skip_bot = P.r_hi <= bot0 ? 1 : 0;
+    }
     bool collected = false;
     if constexpr (std::is_same<TC, float>::value) {
         if (ctx->prep_collect) {             // (cs_detect_foci_blocks, one tile launch: the tables of all blocks from ONE launch)
@@ -637,7 +648,7 @@ int launch_corr<float>(cs_ctx* ctx, cs::CorrArgs<float>& A, hipStream_t stream, 
         }
         // (the mirrored-row instance of the tile kernel forms the corrections of the edge diagonals itself: no records)
         const bool rim_in_kernel = A.w_sym && A.km == 17 && A.kn == 17 && !std::getenv("CHROMOSIGHT_HIP_MFMA_NORSYM");
-        rc = prepare_regular_mask<float>(ctx, A, A.km, stream, rim_in_kernel);
+        rc = prepare_regular_mask<float>(ctx, A, A.km, stream, rim_in_kernel, true);
         if (rc != CS_OK) return rc;
         if (A.reg_mode == 1 && A.sig_is_f64) {
             // float64 container (the pipeline keeps the detrended band in float64 for the exact re-scoring of the

@@ -410,6 +410,7 @@ struct MfmaDenseArgs {
     int full, sym_upper;
     int xcorr_only;          // plain cross-correlation: out = thresholded sum S*w (no box sums, no normalisation)
     int tiles_x, n_tiles;
+    int by_cut;              // REG band outputs: tile rows from this one on are cut at the matrix's last column (see tile_origin)
     const uint4* frag;
     float w_unscale;
     float wa_unscale, wb_unscale;    // REG: power-of-two scales of the Wa / Wb sets (float16 range)
@@ -816,6 +817,22 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
         D.xcorr_only = A.xcorr_only;
         D.tiles_x = A.tiles_x;
         D.n_tiles = (int)blocks;
+        D.by_cut = A.tiles_y;
+        if (reg_f32 && A.out.layout == 1) {
+            // The strip of tiles follows the band: J0 = I0 + out_lo + 64 bx.  On the last rows of a matrix the band leaves it
+            // (columns >= ns): tiles wholly beyond the last column are not enumerated -- the last 16 tile rows of a 1001-diagonal
+            // band hold 120 of them, 23 blocks of a genome 2 760 of 53 000 tiles, each a full pass over zeros.
+            auto valid = [&](int by) {
+                const long long left = (long long)A.ns - ((long long)A.row_begin + (long long)by * MF_T + A.out_lo);
+                const long long v = left <= 0 ? 0 : (left + MF_T - 1) / MF_T;
+                return (int)std::min<long long>(v, A.tiles_x);
+            };
+            int cut = A.tiles_y;
+            long long n = 0;
+            while (cut > 0 && valid(cut - 1) < A.tiles_x) n += valid(--cut);
+            D.by_cut = cut;
+            D.n_tiles = (int)((long long)cut * A.tiles_x + n);
+        }
         D.frag = E.frag;
         D.w_unscale = E.unscale[0];
         D.wa_unscale = E.unscale[1];
@@ -894,7 +911,8 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
             hipError_t e3 = allow_big_lds((const void*)kr);
             if (e3 != hipSuccess) return (int)e3;
             const int per_cu_r = 2;                // (LDS: two workgroups per CU)
-            int grid_r = (int)std::min<long long>(blocks, (long long)per_cu_r * A.n_cu);
+            if (D.n_tiles <= 0) return 0;          // (every tile row beyond the last column)
+            int grid_r = (int)std::min<long long>(D.n_tiles, (long long)per_cu_r * A.n_cu);
             if (A.grid_cap > 0 && grid_r > A.grid_cap) grid_r = std::max(8, A.grid_cap & ~7);     // (multiples of 8: XCD-contiguous ranges)
             hipLaunchKernelGGL(kr, dim3((unsigned)grid_r), dim3(256), MFD_SMEM_REG + MFD_LAUNCH_EXTRA, stream, D);
             return (int)hipGetLastError();

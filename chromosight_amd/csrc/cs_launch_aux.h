@@ -809,6 +809,10 @@ struct MaskPrepArgs {
     TC* fix_rows;
     TC* fix_cols;
     int b_tab, b_edge, b_rows;      // block ranges (filled by the launcher); b_tab = b_rows + blocks of the column table
+    // a call on a row window (a rank's share of a row-split block): only the entries its tiles read -- rows r_lo .. r_hi - 1 of the
+    // row table, columns c_lo .. c_hi - 1 of the column table (0, 0: all), and the frame rows the window reaches
+    int r_lo, r_hi, c_lo, c_hi;
+    int skip_top, skip_bot;         // frame corrections of the first rows / of the rows >= bot0 are not wanted
 };
 template <typename TC>
 int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream);

@@ -49,7 +49,8 @@ __device__ __forceinline__ unsigned window_bits(const uint8_t* __restrict__ flag
 template <typename TC>
 __device__ __forceinline__ void mask_rowcol_tables(int block, int b_rows, const uint8_t* __restrict__ rr,
                                                    const uint8_t* __restrict__ cc, int ms, int ns, int K,
-                                                   const TC* __restrict__ w, TC* __restrict__ rowtab, TC* __restrict__ coltab)
+                                                   const TC* __restrict__ w, TC* __restrict__ rowtab, TC* __restrict__ coltab,
+                                                   int r_lo, int r_hi, int c_lo, int c_hi)
 {
     __shared__ TC sums[2][kMaxK];               // of Wa / Wb along the other axis
     const bool rows = block < b_rows;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void mask_rowcol_tables(int block, int b_rows, const 
         sums[set][k] = acc;
     }
     __syncthreads();
-    const int x = (rows ? block : block - b_rows) * blockDim.x + threadIdx.x;
+    const int x = (rows ? r_lo + block * (int)blockDim.x : c_lo + (block - b_rows) * (int)blockDim.x) + threadIdx.x;
     const int n = rows ? ms : ns;
     const uint8_t* __restrict__ flags = rows ? rr : cc;
     const int lane = threadIdx.x & 63;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void mask_rowcol_tables(int block, int b_rows, const 
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f0), m1 = __builtin_amdgcn_ballot_w64(f1);
     const unsigned long long win = (m0 >> lane) | (lane ? (m1 << (64 - lane)) : 0ull);
     const unsigned bits = (unsigned)win & ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u));
-    if (x >= n) return;
+    if (x >= (rows ? r_hi : c_hi)) return;
     TC sa = TC(0), sb = TC(0);
     for (unsigned b = bits; b; b &= b - 1) {
         const int k = __ffs(b) - 1;
@@ -274,7 +275,7 @@ template <typename TC>
 __device__ __forceinline__ void mask_frame_fix(int block, const uint8_t* __restrict__ rr, const uint8_t* __restrict__ cc, int ms,
                                                int ns, int K, int sym_upper, int max_dist, const TC* __restrict__ w, int top,
                                                int bot0, int width, int x_band, int x_lo, int side, int lazy,
-                                               TC* __restrict__ fix_rows, TC* __restrict__ fix_cols)
+                                               TC* __restrict__ fix_rows, TC* __restrict__ fix_cols, int skip_top, int skip_bot)
 {
     __shared__ TC wa_s[kMaxK * kMaxK], wb_s[kMaxK * kMaxK];
     __shared__ TC part[kFramePixPerBlock][kMaxK][3];
@@ -295,8 +296,9 @@ __device__ __forceinline__ void mask_frame_fix(int block, const uint8_t* __restr
     const long long n_row_px = n_top_px + n_bot_px + n_right_px;
     const long long n_col_px = fix_cols ? (long long)ms * 2 * side : 0;
     const int slot = threadIdx.x / kMaxK, ki = threadIdx.x % kMaxK;
-    const long long id = (long long)block * kFramePixPerBlock + slot;
-    bool live = slot < kFramePixPerBlock && id < n_row_px + n_col_px;
+    // (a row window: the pixels of the top rows come first, then those of the bottom rows -- either part may be left out)
+    const long long id = (skip_top ? n_top_px : 0) + (long long)block * kFramePixPerBlock + slot;
+    bool live = slot < kFramePixPerBlock && id < (skip_bot ? n_top_px : n_row_px + n_col_px);
     int i = 0, j = -1;
     TC* dst = nullptr;
     if (live) {
@@ -363,13 +365,13 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(MaskPrepArgs<TC> P)
 {
     const int b = blockIdx.x;
     if (b < P.b_tab) {
-        mask_rowcol_tables<TC>(b, P.b_rows, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab);
+        mask_rowcol_tables<TC>(b, P.b_rows, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab, P.r_lo, P.r_hi, P.c_lo, P.c_hi);
     } else if (b < P.b_tab + P.b_edge) {
         mask_edge_fix<TC>(b - P.b_tab, P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.max_dist, P.hi_d0, P.hi_w, P.w, P.fix_lo,
                           P.fix_hi);
     } else {
         mask_frame_fix<TC>(b - P.b_tab - P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.sym_upper, P.max_dist, P.w, P.top, P.bot0,
-                           P.width, P.x_band, P.x_lo, P.side, P.edge, P.fix_rows, P.fix_cols);
+                           P.width, P.x_band, P.x_lo, P.side, P.edge, P.fix_rows, P.fix_cols, P.skip_top, P.skip_bot);
     }
 }
 
@@ -389,13 +391,13 @@ __global__ __launch_bounds__(256) void mask_prep_batch_kernel(const MaskPrepArgs
     const MaskPrepArgs<TC> P = tab[lo];
     const int b = g - first[lo];
     if (b < P.b_tab) {
-        mask_rowcol_tables<TC>(b, P.b_rows, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab);
+        mask_rowcol_tables<TC>(b, P.b_rows, P.rr, P.cc, P.ms, P.ns, P.K, P.w, P.rowtab, P.coltab, P.r_lo, P.r_hi, P.c_lo, P.c_hi);
     } else if (b < P.b_tab + P.b_edge) {
         mask_edge_fix<TC>(b - P.b_tab, P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.max_dist, P.hi_d0, P.hi_w, P.w, P.fix_lo,
                           P.fix_hi);
     } else {
         mask_frame_fix<TC>(b - P.b_tab - P.b_edge, P.rr, P.cc, P.ms, P.ns, P.K, P.sym_upper, P.max_dist, P.w, P.top, P.bot0,
-                           P.width, P.x_band, P.x_lo, P.side, P.edge, P.fix_rows, P.fix_cols);
+                           P.width, P.x_band, P.x_lo, P.side, P.edge, P.fix_rows, P.fix_cols, P.skip_top, P.skip_bot);
     }
 }
 
@@ -406,8 +408,14 @@ template <typename TC>
 int mask_prep_blocks(MaskPrepArgs<TC>& P)
 {
     if (P.K > kMaxK) return -1;
-    P.b_rows = (P.ms + 255) / 256;
-    P.b_tab = P.b_rows + (P.ns + 255) / 256;
+    if (P.r_hi <= P.r_lo || P.c_hi <= P.c_lo) {           // (no window: every row and column)
+        P.r_lo = P.c_lo = 0;
+        P.r_hi = P.ms;
+        P.c_hi = P.ns;
+    }
+    if (P.fix_cols) P.skip_top = P.skip_bot = 0;          // (dense outputs: the column table of the frame follows the rows')
+    P.b_rows = (P.r_hi - P.r_lo + 255) / 256;
+    P.b_tab = P.b_rows + (P.c_hi - P.c_lo + 255) / 256;
     P.b_edge = 0;
     if (P.edge && !P.skip_edge) {
         const long long n = (long long)P.ms * ((P.K - 1) + P.hi_w);
@@ -415,8 +423,9 @@ int mask_prep_blocks(MaskPrepArgs<TC>& P)
     }
     const int KH = (P.K - 1) / 2;
     const int full_bot = P.edge ? std::min(KH, P.ms - P.bot0) : P.ms - P.bot0;
-    const long long n_frame = (long long)(P.top + full_bot) * P.width +
-                              (P.edge ? (long long)((P.ms - P.bot0) - full_bot) * KH : 0) +
+    const long long n_top = (long long)P.top * P.width;
+    const long long n_frame = (P.skip_top ? 0 : n_top) +
+                              (P.skip_bot ? 0 : (long long)full_bot * P.width + (P.edge ? (long long)((P.ms - P.bot0) - full_bot) * KH : 0)) +
                               (P.fix_cols ? (long long)P.ms * 2 * P.side : 0);
     const long long b_frame = n_frame > 0 ? (n_frame + kFramePixPerBlock - 1) / kFramePixPerBlock : 0;
     const long long total = (long long)P.b_tab + P.b_edge + b_frame;

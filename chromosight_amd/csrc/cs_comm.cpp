@@ -178,7 +178,6 @@ int cs_comm_create(int device, int rank, int world, const void* unique_id128, cs
     (void)hipDeviceGetLimit(&stack_after, hipLimitStackSize);
     if (std::getenv("CHROMOSIGHT_HIP_DEBUG"))
         fprintf(stderr, "[chromosight_hip] ncclCommInitRank: hipLimitStackSize %zu -> %zu bytes per lane\n", stack_before, stack_after);
-    if (std::getenv("CHROMOSIGHT_HIP_RCCL_RESTORE_STACK") && stack_after != stack_before) (void)hipDeviceSetLimit(hipLimitStackSize, stack_before);
     if (he != hipSuccess || ne != ncclSuccess) {
         R->err_create = he != hipSuccess ? std::string("HIP: ") + hipGetErrorString(he)
                                          : std::string("ncclCommInitRank: ") + R->GetErrorString(ne);

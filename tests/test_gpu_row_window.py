@@ -79,7 +79,8 @@ def _band_of(dense, lo, w, ld):
     return band
 
 
-@pytest.mark.parametrize("n,max_dist,ksize,precision", [(3000, 150, 17, "f32"), (1800, 60, 7, "f32"), (1200, 100, 17, "f64")])
+@pytest.mark.parametrize("n,max_dist,ksize,precision", [(3000, 150, 17, "f32"), (1800, 60, 7, "f32"), (1200, 100, 17, "f64"),
+                                                        (2600, 700, 17, "f32")])      # (the band leaves the matrix over 11 tile rows)
 def test_band_row_windows_with_bin_masks(n, max_dist, ksize, precision):
     """Band in, scanned diagonals out, per-bin missing flags (the detect configuration): windows of the
     map from slab inputs == the whole map, including the rows next to the matrix edges and windows

@@ -449,13 +449,51 @@ int enqueue_foci_narrow_batch(const CorrArgs<double>* h_tab, const long long* h_
                 const CorrArgs<double>& A = h_tab[k];
                 only17 = A.km == 17 && A.kn == 17 && A.mask_mode == 1 && A.sym_upper && A.full && A.max_dist >= 0;
             }
-            const dim3 run_grid((unsigned)((n_total + 255) / 256));
+            // Several templates on the same sub-matrices (borders: three; the virtual blocks k nb .. k nb + nb - 1 are template k's):
+            // the list holds every pixel once per template, in the same order -- ONE pass over the first template's entries
+            // evaluates all of them (rescore_run17_multi).  CHROMOSIGHT_HIP_TEMPLATE_FUSION=0 | 1: never | always.
+            // Only where the separate passes would not all be resident at once (three workgroups of this kernel per CU): a short
+            // list -- a rank's eighth of a genome: 600 workgroups -- is bound by ONE wave's latency, which grows with the templates
+            // a lane evaluates (measured: 80 us separate, 100 us fused; the whole genome: 515 against 286 us).
+            static int n_cu_cached = 0;
+            if (!n_cu_cached) {
+                int dev_id = 0, n_cu_dev = 0;
+                if (hipGetDevice(&dev_id) == hipSuccess && hipDeviceGetAttribute(&n_cu_dev, hipDeviceAttributeMultiprocessorCount, dev_id) == hipSuccess && n_cu_dev > 0)
+                    n_cu_cached = n_cu_dev;
+                else
+                    n_cu_cached = 256;
+            }
+            const char* fusion = getenv("CHROMOSIGHT_HIP_TEMPLATE_FUSION");       // 1: always, 0: never
+            const bool worth_it = fusion ? atoi(fusion) != 0 : (n_total + 255) / 256 > 3LL * n_cu_cached;
+            int n_fuse = 1;
+            if (only17 && worth_it) {
+                for (int T = 3; T >= 2 && n_fuse == 1; --T) {       // (instances for two and three templates)
+                    if (n_blocks % T) continue;
+                    const int nbk = n_blocks / T;
+                    bool same = true;
+                    for (int k = 1; k < T && same; ++k)
+                        for (int q = 0; q < nbk && same; ++q) {
+                            const int o = k * nbk + q;
+                            CorrArgs<double> other = h_tab[o];
+                            other.w = h_tab[q].w;                // what a template brings: weights, their statistics and shape flags
+                            other.ks = h_tab[q].ks;
+                            other.w_sym = h_tab[q].w_sym;
+                            other.w_rank1 = h_tab[q].w_rank1;
+                            same = std::memcmp(&other, &h_tab[q], sizeof(other)) == 0 && h_lo_w[2 * o] == h_lo_w[2 * q] &&
+                                   h_lo_w[2 * o + 1] == h_lo_w[2 * q + 1] && h_seg[o + 1] - h_seg[o] == h_seg[q + 1] - h_seg[q];
+                        }
+                    if (same) n_fuse = T;
+                }
+                if (getenv("CHROMOSIGHT_HIP_DEBUG")) fprintf(stderr, "[chromosight_hip] run re-scoring: %d sub-matrices, %d templates fused\n", n_blocks, n_fuse);
+            }
+            const long long n_launch = n_total / n_fuse;
+            const dim3 run_grid((unsigned)((n_launch + 255) / 256));
             if (only17)
-                hipLaunchKernelGGL(rescore_run_batch_kernel<true>, run_grid, dim3(256), smem, stream, tab, blk, rows, cols, n_total, vals,
-                                   tile_cap, 0, true);
+                hipLaunchKernelGGL(rescore_run_batch_kernel<true>, run_grid, dim3(256), smem, stream, tab, blk, rows, cols, n_launch, vals,
+                                   tile_cap, 0, true, n_fuse, n_blocks / n_fuse, n_launch);
             else
                 hipLaunchKernelGGL(rescore_run_batch_kernel<false>, run_grid, dim3(256), smem, stream, tab, blk, rows, cols, n_total, vals,
-                                   tile_cap, no_run17 ? 1 : 0, fast_windows_on());
+                                   tile_cap, no_run17 ? 1 : 0, fast_windows_on(), 1, 0, 0LL);
         }
     }
     // every sub-matrix scans the diagonals 0 and 1 (borders, hairpins: max_dist = 0 in the config): the foci are runs

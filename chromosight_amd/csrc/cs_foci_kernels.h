@@ -487,8 +487,12 @@ template <bool ONLY17>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONLY17 ? 3 : 1, ONLY17 ? 3 : 8))) void rescore_run_batch_kernel(const CorrArgs<double>* __restrict__ tab, const int* __restrict__ blk,
                                                                 const int* __restrict__ rows, const int* __restrict__ cols,
                                                                 long long n_px, double* __restrict__ out_corr, int tile_cap,
-                                                                int no_run17, bool fast_windows)
+                                                                int no_run17, bool fast_windows, int n_fuse, int tab_step,
+                                                                long long out_stride)
 {
+    // n_fuse > 1 (ONLY17 instance): the list holds the same pixels once per template -- entries t + k out_stride, argument blocks
+    // tab[b + k tab_step], k < n_fuse -- and the launch covers the first template's entries: a workgroup stages its tile once and
+    // every lane evaluates its pixel under all the templates (rescore_run17_multi)
     const bool RUN_NO_FAST = no_run17 != 0;
     extern __shared__ __attribute__((aligned(16))) double run_smem[];
     double* const tile = run_smem;
@@ -626,11 +630,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONLY17 ? 3 
             __syncthreads();
             if (run17) {
                 if (mine) {
-                    if (interior) rescore_run17<false>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
+#define CS_RUN17_MULTI(T_)                                                                                        \
+    {                                                                                                             \
+        double rk[T_];                                                                                            \
+        if (interior) rescore_run17_multi<false, T_>(A, tab_step, tile, rfl, cfl, P0, C0, D0, oi, oj, rk);        \
+        else rescore_run17_multi<true, T_>(A, tab_step, tile, rfl, cfl, P0, C0, D0, oi, oj, rk);                  \
+        r = rk[0];                                                                                                \
+        for (int k = 1; k < T_; ++k) out_corr[t + k * out_stride] = rk[k];                                        \
+    }
+                    if (ONLY17 && n_fuse == 3) CS_RUN17_MULTI(3)
+                    else if (ONLY17 && n_fuse == 2) CS_RUN17_MULTI(2)
+                    else if (interior) rescore_run17<false>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
                     else rescore_run17<true>(A, tile, rfl, cfl, P0, C0, D0, oi, oj, r, nobs);
+#undef CS_RUN17_MULTI
                 }
             } else if constexpr (ONLY17) {
-                if (mine) rescore_pixel_lane(A, oi, oj, r, nobs);
+                if (mine) {
+                    rescore_pixel_lane(A, oi, oj, r, nobs);
+                    for (int k = 1; k < n_fuse; ++k) {
+                        double rr, nn;
+                        rescore_pixel_lane((&A)[k * tab_step], oi, oj, rr, nn);
+                        out_corr[t + k * out_stride] = rr;
+                    }
+                }
             } else if (mine && lean && interior && kn == 17) rescore_pixel_lane_lds_interior<17>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && interior && kn == 15) rescore_pixel_lane_lds_interior<15>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
             else if (mine && lean && kn == 17) rescore_pixel_lane_lds_interior<17, true>(A, tile, wl, rfl, cfl, P0, C0, D0, DN, oi, oj, r, nobs);
@@ -643,6 +665,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONLY17 ? 3 
             __syncthreads();                                  // the tile is reused by the next sub-matrix
         } else if (mine) {
             rescore_pixel_lane(A, oi, oj, r, nobs);
+            for (int k = 1; k < n_fuse; ++k) {
+                double rr, nn;
+                rescore_pixel_lane((&A)[k * tab_step], oi, oj, rr, nn);
+                out_corr[t + k * out_stride] = rr;
+            }
         }
     }
     if (valid) out_corr[t] = r;

@@ -602,6 +602,85 @@ __device__ __forceinline__ void rescore_run17(const CorrArgs<double>& A, const d
     r = pearson_from_sums<double>(cs_, s1, s2, (double)nm_i, ka, kb, A.ks, true, &nobs);
 }
 
+// The same walk for T templates on the SAME pixels (the three templates of borders: detect_foci_batch_templates lists the pixels
+// of the scanned diagonals once per template, (&A)[k * tab_step] is template k's argument block -- the same matrix, another set of
+// weights and statistics).  The window's 289 pixels are read from LDS once, their squares and sums and the 17-bit predicate words
+// are formed once; per template remain the three multiply-adds of a window pixel (and the scalar loads of its weights): 13
+// vector instructions per window pixel for three templates instead of 21, a third of the LDS reads and of the tile staging.
+// Every accumulator sees the operations of rescore_run17 in the same order: identical results.
+template <bool EDGE, int T>
+__device__ __forceinline__ void rescore_run17_multi(const CorrArgs<double>& A, int tab_step, const double* tileT, const unsigned char* rfl,
+                                                    const unsigned char* cfl, int P0, int C0, int D0, int oi, int oj, double (&r)[T])
+{
+    constexpr int K = 17, kh = 8, kk = K * K;
+    constexpr unsigned all = (1u << K) - 1u;
+#pragma unroll
+    for (int k = 0; k < T; ++k) r[k] = 0.0;
+    if (EDGE && !((oi >= 0) & (oi < A.ms) & (oj >= 0) & (oj < A.ns))) return;
+    if (pixel_forced_zero(A, oi, oj)) return;
+    typedef const __attribute__((address_space(4))) double DblC;
+    DblC* w[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) w[k] = (DblC*)(unsigned long long)(&A)[k * tab_step].w;
+    const int ms = A.ms, ns = A.ns, md = min(A.max_dist, 1 << 20);
+    const int q0 = oj - kh, p0 = oi - kh;
+    unsigned cbits = 0u, qin = all, qge = 0u, qlt = 0u;
+#pragma unroll
+    for (int kj = 0; kj < K; ++kj) {
+        cbits |= (cfl[q0 - C0 + kj] != 0 ? 1u : 0u) << kj;
+        if constexpr (EDGE) {
+            const int q = q0 + kj;
+            qin &= ~(((unsigned)q < (unsigned)ns ? 0u : 1u) << kj);
+            qge |= (q >= ns ? 1u : 0u) << kj;
+            qlt |= (((q < 0) | (q < md + K)) ? 1u : 0u) << kj;
+        }
+    }
+    double cs_[T], ka[T], kb[T], s1 = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < T; ++k) cs_[k] = ka[k] = kb[k] = 0.0;
+    int nm_i = 0;
+    const double* row = tileT + (q0 - p0 - D0) * kRunRP + (p0 - P0);
+#pragma unroll 1
+    for (int ki = 0; ki < K; ++ki, row -= kRunRP - 1) {
+        const int p = p0 + ki;
+        const int dl = q0 - p;
+        const unsigned rc = rfl[p - P0] != 0 ? all : cbits;
+        const unsigned below = run_range_bits(-K - dl, -dl);
+        const unsigned band = run_range_bits(-dl, md - dl + 1);
+        unsigned M = below | (rc & band);
+        if constexpr (EDGE) {
+            const unsigned in_b = ((unsigned)p < (unsigned)ms) ? qin : 0u;
+            const unsigned out_b = (qge & (p >= ms - md - 2 ? all : 0u)) | (~qge & (p < 0 ? qlt : 0u));
+            M = (in_b & rc & band) | (~in_b & out_b & all) | below;
+        }
+        nm_i += __builtin_popcount(M);
+        double v[K], mf[K];
+#pragma unroll
+        for (int kj = 0; kj < K; ++kj) {
+            v[kj] = row[kj * kRunRP];
+            s1 += v[kj];
+            s2 = fma(v[kj], v[kj], s2);
+            const int sel = ((int)(M << (31 - kj))) >> 31;
+            mf[kj] = __hiloint2double(sel & 0x3FF00000, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            DblC* const wr = w[k] + ki * K;
+#pragma unroll
+            for (int kj = 0; kj < K; ++kj) {
+                cs_[k] = fma(v[kj], wr[kj], cs_[k]);
+                ka[k] = fma(wr[kk + kj], mf[kj], ka[k]);
+                kb[k] = fma(wr[2 * kk + kj], mf[kj], kb[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        double nobs;
+        r[k] = pearson_from_sums<double>(cs_[k], s1, s2, (double)nm_i, ka[k], kb[k], (&A)[k * tab_step].ks, true, &nobs);
+    }
+}
+
 // KN > 0: template width known at compile time (17: every built-in 2-D / 1-D template but the 15 x 15 hairpin) -- the
 // row loop is unrolled, so its 17 LDS reads are issued together instead of one dependent read per multiply-add (the
 // runtime-size loop ran at a third of the instruction-issue floor).

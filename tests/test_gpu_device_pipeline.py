@@ -617,7 +617,8 @@ def test_switchable_chains_equal_the_default_run(monkeypatch):
     for switch in ("CHROMOSIGHT_HIP_NO_DEFERRED_CHAIN", "CHROMOSIGHT_HIP_NO_PATH_FOCI", "CHROMOSIGHT_HIP_NO_RUN17",
                    "CHROMOSIGHT_HIP_NO_LDS_FOCI", "CHROMOSIGHT_HIP_NO_EARLY_TABLES", "CHROMOSIGHT_HIP_NO_SEGMENTED",
                    "CHROMOSIGHT_HIP_NO_COUNTS_BAND",       # (... the detrended bands of the tiler pass instead of the bands of raw counts,
-                   "CHROMOSIGHT_HIP_HOST_PVALUES"):        #  the records' p-values computed by cs_accept_records instead of copied)
+                   "CHROMOSIGHT_HIP_HOST_PVALUES",         #  the records' p-values computed by cs_accept_records instead of copied,
+                   "CHROMOSIGHT_HIP_TEMPLATE_FUSION"):     #  ONE pass of the run kernel for the three templates of borders -- what long lists take)
         monkeypatch.setenv(switch, "1")
         dcool_sw = pipeline.DeviceCool(cool)
         for rep in range(3):

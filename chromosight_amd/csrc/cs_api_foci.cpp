@@ -659,7 +659,9 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         // fewest tables -- ordered before the launch by the lanes' events below -- instead of sitting between the staging and
         // the tile kernel
         const bool early_upload = table && early_tables && n_lanes > 1;
-        if (early_upload && !reuse) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[side_lanes - 1]));
+        // (one mask-table launch for all blocks: it clears the counters and its upload carries the tile launch's table too -- below)
+        const bool prep_carries = early_upload && table && early_tables && side_lanes == 1;
+        if (early_upload && !reuse && !prep_carries) CS_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntBytes, ctx->s_blk[side_lanes - 1]));
         // (largest blocks first on every lane: the short ones fill the end)
         std::vector<int> launch_order((size_t)n_blocks);
         for (int b = 0; b < n_blocks; ++b) launch_order[b] = b;
@@ -751,8 +753,18 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
             ctx->prep_collect = nullptr;
             if (!reuse) {
                 const size_t tile_tab_bytes = al(cs::mfma_blocks_table_bytes(n_blocks));
-                int rcp = cs::launch_mask_prep_batch(prep_list.data(), ctx->prep_groups.data(), (int)prep_list.size(), (char*)ctx->h_tab + tile_tab_bytes,
+                int rcp = 0;
+                if (prep_carries) {
+                    // the lane the tile launch waits for: ONE upload (tile table + mask-table arguments, neighbours in h_tab / d_tab)
+                    // and ONE kernel that also clears the counters, instead of memset, upload, kernel, upload
+                    rcp = cs::mfma_blocks_table_finish(ctx->h_tab, n_blocks);
+                    if (rcp) return fail(ctx, CS_ERR_OVERFLOW, "too many tiles for one launch");
+                    rcp = cs::launch_mask_prep_batch(prep_list.data(), ctx->prep_groups.data(), (int)prep_list.size(), (char*)ctx->h_tab + tile_tab_bytes,
+                                                     (char*)ctx->d_tab + tile_tab_bytes, ctx->s_blk[0], tile_tab_bytes, d_cnt, kCntBytes);
+                } else {
+                    rcp = cs::launch_mask_prep_batch(prep_list.data(), ctx->prep_groups.data(), (int)prep_list.size(), (char*)ctx->h_tab + tile_tab_bytes,
                                                      (char*)ctx->d_tab + tile_tab_bytes, ctx->s_blk[0]);
+                }
                 if (rcp) return fail(ctx, CS_ERR_HIP, "mask table kernel failed: %s", hipGetErrorString((hipError_t)rcp));
             }
         }
@@ -761,7 +773,7 @@ int cs_detect_foci_blocks(cs_ctx* ctx, void* stream_, int32_t n_blocks, const cs
         if (early_upload) {
             // (reuse: both tables were uploaded by the prepare form; the host-side table is still filled in -- the launch reads
             // its block count and tile ranges from it)
-            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[side_lanes - 1], !reuse, false);
+            rc = cs::launch_corr_mfma_blocks(ctx->h_tab, ctx->d_tab, n_blocks, table_rsym, ctx->n_cu, stream, ctx->s_blk[side_lanes - 1], !reuse && !prep_carries, false);
             if (rc) return fail(ctx, CS_ERR_HIP, "tile kernel table upload failed: %s", hipGetErrorString((hipError_t)rc));
             if (deferred) {
                 if (!reuse) rc = cs::upload_keyed_batch_table(tab.data(), n_blocks, (long long)list_cap, pool + off_tail, ctx->s_blk[side_lanes - 1]);

@@ -968,6 +968,21 @@ int launch_corr_mfma_prepared(const void* h_arg, int rsym, int n_cu, int grid_ca
 // the copy is then done when the stream gets to the tile kernel instead of sitting between the staging and it.
 // (do_upload / launch: a caller that uploads on a side stream makes two calls -- upload only, then launch only; the caller's own
 // stream may be the null stream, so "no upload" is a flag and not a null handle)
+// the table's tile ranges (first[]) from its argument blocks: what an upload by somebody else needs in place (-3: too many tiles)
+int mfma_blocks_table_finish(void* h_table, int n_blocks)
+{
+    int* first = reinterpret_cast<int*>(h_table);
+    const MfmaDenseArgs* args = reinterpret_cast<const MfmaDenseArgs*>((char*)h_table + mfma_blocks_arg_offset(n_blocks));
+    long long total = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        first[b] = (int)total;
+        total += args[b].n_tiles;
+        if (total > 0x7fffffffLL) return -3;
+    }
+    first[n_blocks] = (int)total;
+    return 0;
+}
+
 int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t stream, hipStream_t upload,
                             bool do_upload, bool launch, unsigned* started, unsigned epoch)
 {

@@ -52,6 +52,7 @@ int launch_corr_mfma_f32(CorrArgs<float>& A, const MfmaWeights& E, hipStream_t s
 size_t mfma_blocks_arg_bytes();
 size_t mfma_blocks_arg_offset(int n_blocks);
 size_t mfma_blocks_table_bytes(int n_blocks);
+int mfma_blocks_table_finish(void* h_table, int n_blocks);      // fills the table's tile ranges (for an upload made by the caller)
 int launch_corr_mfma_blocks(void* h_table, void* d_table, int n_blocks, int rsym, int n_cu, hipStream_t s, hipStream_t upload, bool do_upload, bool launch,
                             unsigned* started = nullptr, unsigned epoch = 0);
 // one block of such a table as its own persistent launch (its mask tables were prepared earlier)

@@ -901,6 +901,9 @@ int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream);
 template <typename TC>
 int mask_prep_blocks(MaskPrepArgs<TC>& P);
 size_t mask_prep_table_bytes(int n);
-int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream);
+// lead_bytes: bytes in front of h_tab / d_tab (the same offset in both buffers) that travel in the same copy; zero / zero_bytes: 8-byte
+// words the kernel clears (a memset where nothing is launched)
+int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream,
+                           size_t lead_bytes = 0, void* zero = nullptr, size_t zero_bytes = 0);
 
 }  // namespace cs

@@ -379,8 +379,13 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(MaskPrepArgs<TC> P)
 // are first[k] .. first[k + 1].  One launch per block is 12 us alone and 30-90 us beside the staging kernels of a genome step (profiles/r05_genome_timeline.txt: 23 of
 // them in a row outlast the staging and hold the tile launch back); one launch for all of them does not.
 template <typename TC>
-__global__ __launch_bounds__(256) void mask_prep_batch_kernel(const MaskPrepArgs<TC>* __restrict__ tab, const int* __restrict__ first, int n)
+__global__ __launch_bounds__(256) void mask_prep_batch_kernel(const MaskPrepArgs<TC>* __restrict__ tab, const int* __restrict__ first, int n,
+                                                              unsigned long long* __restrict__ zero, int zero_words)
 {
+    // (the caller's counters, cleared here instead of by a memset of their own in front of this launch: one operation less on the
+    // lane the tile launch waits for)
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < zero_words; k += 256) zero[k] = 0ull;
     int lo = 0, hi = n - 1;
     const int g = blockIdx.x;
     while (lo < hi) {
@@ -443,9 +448,18 @@ int launch_mask_prep(MaskPrepArgs<TC> P, hipStream_t stream)
 
 size_t mask_prep_table_bytes(int n) { return (((size_t)(n + 1) * sizeof(int) + 255) & ~(size_t)255) + (size_t)n * sizeof(MaskPrepArgs<float>); }
 
-int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream)
+int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups, int n, void* h_tab, void* d_tab, hipStream_t stream,
+                           size_t lead_bytes, void* zero, size_t zero_bytes)
 {
-    if (n <= 0) return 0;
+    // lead_bytes: what lies in front of the table in the same two buffers (the tile launch's argument table) travels with it in the
+    // ONE copy; zero: counters the kernel clears.  Without a launch (no table, no workgroup) both are done here.
+    auto no_launch = [&]() {
+        hipError_t e0 = hipSuccess;
+        if (lead_bytes) e0 = hipMemcpyAsync((char*)d_tab - lead_bytes, (const char*)h_tab - lead_bytes, lead_bytes, hipMemcpyHostToDevice, stream);
+        if (e0 == hipSuccess && zero && zero_bytes) e0 = hipMemsetAsync(zero, 0, zero_bytes, stream);
+        return (int)e0;
+    };
+    if (n <= 0) return no_launch();
     const size_t off = ((size_t)(n + 1) * sizeof(int) + 255) & ~(size_t)255;
     int* first = reinterpret_cast<int*>(h_tab);
     long long total = 0;
@@ -455,12 +469,13 @@ int launch_mask_prep_batch(const MaskPrepArgs<float>* args, const int* n_groups,
         if (total > 0x7fffffffLL) return -3;
     }
     first[n] = (int)total;
-    if (total == 0) return 0;
+    if (total == 0) return no_launch();
     std::memcpy((char*)h_tab + off, args, (size_t)n * sizeof(MaskPrepArgs<float>));
-    hipError_t e = hipMemcpyAsync(d_tab, h_tab, mask_prep_table_bytes(n), hipMemcpyHostToDevice, stream);
+    hipError_t e = hipMemcpyAsync((char*)d_tab - lead_bytes, (const char*)h_tab - lead_bytes, lead_bytes + mask_prep_table_bytes(n), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mask_prep_batch_kernel<float>, dim3((unsigned)total), dim3(256), 0, stream,
-                       reinterpret_cast<const MaskPrepArgs<float>*>((const char*)d_tab + off), reinterpret_cast<const int*>(d_tab), n);
+                       reinterpret_cast<const MaskPrepArgs<float>*>((const char*)d_tab + off), reinterpret_cast<const int*>(d_tab), n,
+                       reinterpret_cast<unsigned long long*>(zero), (int)(zero ? zero_bytes / 8 : 0));
     return (int)hipGetLastError();
 }
 

@@ -125,6 +125,58 @@ def test_band_row_windows_with_bin_masks(n, max_dist, ksize, precision):
         assert np.abs(got - full[a:b]).max() <= tol, (a, b)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_band_row_windows(seed, monkeypatch):
+    """Random band geometries under the mirrored 17 x 17 template (the masked matrix-core tile kernel): bands that leave the matrix on
+    some, most or all rows (its strips end at the last column: MfmaDenseArgs::by_cut), random row windows whose mask tables cover
+    the window only (MaskPrepArgs::r_lo ..) == the same rows of the whole map, and == the window with the tables of every bin
+    (CHROMOSIGHT_HIP_FULL_MASK_TABLES=1: bit for bit)."""
+    dev = get_device()
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(400, 3200))
+    max_dist = int(rng.choice([n // 30 + 20, n // 4, n - 5, n + 40, 1000]))
+    ksize = 17
+    keep = max_dist + ksize
+    in_w, out_w = keep + 1, max_dist + 1
+    ld_in, ld_out = (in_w + 63) // 64 * 64, (out_w + 63) // 64 * 64
+    band = np.zeros((n, ld_in), dtype=np.float32)
+    band[:, :in_w] = rng.gamma(2.0, 0.5, size=(n, in_w))
+    for i in range(n):
+        band[i, max(0, n - i):] = 0
+    miss = (rng.random(n) < 0.03).astype(np.uint8)
+    miss[[0, n - 1, n // 2]] = 1
+    zero = miss.astype(bool)
+    band[zero, :] = 0
+    for d in range(in_w):
+        rows = np.arange(0, max(0, n - d))
+        band[rows[zero[rows + d]], d] = 0
+    kspec = engine.KernelSpec(np.asarray(ck.loops["kernels"][0], dtype=np.float64), None)
+    d_miss, d_band = dev.to_device(miss), dev.to_device(band)
+    f32 = np_dtype_code(np.float32)
+    sig = CsMatrix(d_band.ptr, f32, LAYOUT_BAND, ld_in, 0, in_w)
+    kw = dict(sym_upper=True, max_dist=max_dist, mask_mode=MASK_BINS, miss_row=d_miss, miss_col=d_miss, precision="f32")
+    d_full = dev.zeros(n * ld_out, np.float32)
+    _run(dev, sig, (n, n), kspec, CsMatrix(d_full.ptr, f32, LAYOUT_BAND, ld_out, 0, out_w), **kw)
+    assert dev.lib.cs_last_kernel(dev.ctx) == 5            # the masked matrix-core tile kernel
+    full = d_full.download().reshape(n, ld_out)[:, :out_w]
+    assert np.abs(full).max() > 0.05
+    cuts = sorted(set(int(c) for c in rng.integers(1, n - 1, size=3)) | {n - int(rng.integers(2, 70))})
+    for a, b in _windows(n, cuts):
+        ra, rb = max(0, a - 8), min(n, b + 8)
+        d_slab = dev.to_device(np.ascontiguousarray(band[ra:rb]))
+        slab = CsMatrix(d_slab.ptr, f32, LAYOUT_BAND, ld_in, 0, in_w, ra)
+        got = []
+        for full_tables in (False, True):
+            if full_tables:
+                monkeypatch.setenv("CHROMOSIGHT_HIP_FULL_MASK_TABLES", "1")
+            d_out = dev.zeros((b - a) * ld_out, np.float32)
+            _run(dev, slab, (n, n), kspec, CsMatrix(d_out.ptr, f32, LAYOUT_BAND, ld_out, 0, out_w, a), (a, b), **kw)
+            got.append(d_out.download().reshape(b - a, ld_out)[:, :out_w])
+            monkeypatch.delenv("CHROMOSIGHT_HIP_FULL_MASK_TABLES", raising=False)
+        assert np.array_equal(got[0], got[1]), (n, max_dist, a, b)
+        assert np.abs(got[0] - full[a:b]).max() <= 2e-6, (n, max_dist, a, b)
+
+
 def test_row_window_argument_errors():
     dev = get_device()
     kspec = engine.KernelSpec(np.asarray(ck.loops["kernels"][0], dtype=np.float64), None)

@@ -467,6 +467,44 @@ def test_native_acceptance_rules_equal_the_numpy_ones():
     assert got.shape == (0, 4) and ok.size == 0 and kept.size == 0
 
 
+def test_native_acceptance_single_pass_equals_the_two_pass_form(monkeypatch):
+    """Records that carry their p-values (cs_focus.pval, flags bit 1) with the accepted rows packed take ONE pass on the calling
+    thread: the same table, mask and counts as the two-pass form given the same p-values (the unpacked call's rows of the accepted
+    records), on lists with empty blocks, rejected records at both ends and out-of-band pixels."""
+    import types
+    from chromosight_amd._lib import FOCUS_DTYPE
+    from chromosight_amd.utils import detection as cid
+    monkeypatch.delenv("CHROMOSIGHT_HIP_HOST_PVALUES", raising=False)
+    rng = np.random.default_rng(23)
+    kspec = types.SimpleNamespace(km=17, kn=17)
+    cfg = {"max_perc_undetected": 50.0, "max_perc_zero": 10.0}
+    counts = np.array([0, 5000, 1, 0, 12000, 300, 0])
+    shapes, max_dists = [(3000, 3000)] * 7, [700, 700, 700, None, 20, 700, 700]
+    n = int(counts.sum())
+    rec = np.zeros(n, FOCUS_DTYPE)
+    rec["bin1"] = rng.integers(-2, 3003, n)
+    rec["bin2"] = rec["bin1"] + rng.integers(-3, 760, n)
+    rec["inside"] = rng.random(n) < 0.9
+    rec["inside"][[0, n - 1]] = 0
+    rec["n_missing"] = rng.integers(0, 290, n)
+    rec["n_zero"] = rng.integers(0, 60, n)
+    rec["score"] = rng.uniform(-1, 1, n)
+    rec["n_obs"] = 289 - rec["n_missing"]
+    rec["pval"] = rng.uniform(0, 1, n)
+    # the limits of the two rules exactly: 20 / 200 = 0.1 is not < 0.1, 144 / 289 < 0.5 <= 145 / 289, an all-missing window (0 / 0)
+    for k, (nm, nz) in enumerate([(89, 20), (89, 19), (144, 0), (145, 0), (289, 0), (0, 28), (0, 29), (288, 0), (288, 1)]):
+        rec["n_missing"][10 + k], rec["n_zero"][10 + k], rec["inside"][10 + k] = nm, nz, 1
+    for full in (True, False):
+        loose, ok_l, kept_l = cid.accept_native(rec, counts, shapes, max_dists, kspec, cfg, inter=False, full=full, compact=False, pvals=True)
+        packed, ok_p, kept_p = cid.accept_native(rec, counts, shapes, max_dists, kspec, cfg, inter=False, full=full, compact=True, pvals=True)
+        assert 0.05 < ok_l.mean() < 0.9 and np.array_equal(ok_l, ok_p) and np.array_equal(kept_l, kept_p)
+        assert np.array_equal(packed, loose[ok_l])
+        assert np.array_equal(packed[:, 3], rec["pval"][ok_l])                 # copied, not recomputed
+        assert list(ok_p[10:19]) == [False, True, True, False, False, True, False, False, False]
+    got, ok, kept = cid.accept_native(rec[:0], np.zeros(0, np.int64), [], [], kspec, cfg, inter=False, full=True, compact=True, pvals=True)
+    assert got.shape == (0, 4) and ok.size == 0 and kept.size == 0
+
+
 def test_native_acceptance_rules_pool_and_concurrent_callers():
     """cs_accept_records on lists long enough for the library's worker pool (pieces of 1024 records taken from a counter by
     the workers and the caller), from several threads at once (a caller that finds the pool busy runs its pieces itself):

@@ -941,15 +941,18 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
     if (!n_out || cap < 0 || (cap > 0 && (!h_rows || !h_cols || !h_vals))) return fail(ctx, CS_ERR_INVALID, "bad output buffers");
     *n_out = 0;
     // ---- One synchronisation for the usual case (a 2-D pattern in float32 arithmetic on a kernel with a candidate sink, a few hundred
-    // candidates): tile kernel -> decode the first kFirst keys -> float64 re-scoring bounded by the DEVICE's count -> one download of
-    // the count and the kFirst-entry heads -> threshold and order on the host.  The general flow below reads the count first (to size
+    // candidates): tile kernel -> the first n_first keys decoded and re-scored in float64, bounded by the DEVICE's count, written with the count
+    // into a mapped host block -> threshold and order on the host.  The general flow below reads the count first (to size
     // what follows), sorts and compacts on the device and synchronises three times: 0.14 ms that a rank's share of a row-split block
     // waited for behind a 0.23 ms tile kernel (profiles/r06_c4p_split_shares.txt).  A list longer than the key list's capacity, or a
     // kernel without a sink, takes the general flow.
     const bool band_sig = signal->layout == CS_LAYOUT_BAND || signal->layout == CS_LAYOUT_BAND_PADDED;
     if (p->compute_dtype == CS_F32 && !(band_sig && fp->hi_diag - fp->lo_diag + 1 <= 4) && fp->hi_diag >= fp->lo_diag &&
         !std::getenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP")) {
-        constexpr long long kFirst = 8192;
+        constexpr long long kHeads = 32768;                      // room of the host block and of the heads' device arrays
+        // how many keys the ONE launch covers: the previous call's count on this context and a quarter (a whole 200 000-bin block
+        // has ~ 15 000 candidates before the float64 scores thin them out; its second call needs no second round), at least 8192
+        const long long n_first = std::min<long long>(kHeads, std::max<long long>(8192, ctx->cand_prev + ctx->cand_prev / 4 + 64));
         int rb = 0, re = p->ms;
         if (p->row_end > p->row_begin) {
             if (p->row_begin < 0 || p->row_end > p->ms) return fail(ctx, CS_ERR_INVALID, "row window outside the matrix");
@@ -967,12 +970,12 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
         const bool plain_layout = band_sig || signal->layout == CS_LAYOUT_DENSE;
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t c_cap = std::max<size_t>(1 << 16, (size_t)(re - rb) * (size_t)(band_sig ? map.band_w : p->ns) / 256);
-        // device scratch: keys[c_cap] | count | heads: rows[kFirst] cols[kFirst] vals[kFirst] | the rest: rows, cols, vals of c_cap - kFirst
+        // device scratch: keys[c_cap] | count | (heads: in the host block) | a second round's rows, cols, vals
         // ('count' = the copy of the device's counter that travels with the heads; the counters themselves: ctx->d_cand_cnt)
-        const size_t off_cnt = al(8 * c_cap), off_rows = off_cnt + 256, off_cols = off_rows + al(4 * kFirst), off_vals = off_cols + al(4 * kFirst);
-        const size_t rest = c_cap - (size_t)kFirst;
-        const size_t off_rows2 = off_vals + al(8 * kFirst), off_cols2 = off_rows2 + al(4 * rest), off_vals2 = off_cols2 + al(4 * rest);
-        const size_t h_bytes = 256 + 4 * kFirst + 4 * kFirst + 8 * kFirst;
+        const size_t off_cnt = al(8 * c_cap), off_rows = off_cnt + 256, off_cols = off_rows + al(4 * kHeads), off_vals = off_cols + al(4 * kHeads);
+        const size_t rest = c_cap;                             // (a second round holds at most c_cap - 8192)
+        const size_t off_rows2 = off_vals + al(8 * kHeads), off_cols2 = off_rows2 + al(4 * rest), off_vals2 = off_cols2 + al(4 * rest);
+        const size_t h_bytes = 256 + 4 * kHeads + 4 * kHeads + 8 * kHeads;
         rc = plain_layout ? ensure_scratch(ctx, &ctx->d_pool, &ctx->d_pool_bytes, off_vals2 + al(8 * rest)) : CS_ERR_UNSUPPORTED;
         if (rc == CS_OK && !ctx->h_small) {
             if (hipHostMalloc(&ctx->h_small, h_bytes, hipHostMallocDefault) != hipSuccess) {
@@ -1006,11 +1009,11 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
                 cs::CorrArgs<double> A64;
                 rc = build_args<double>(ctx, stream, signal, kernel, p, &A64);
                 if (rc) return rc;
-                // keys -> pixels and float64 scores of the first min(kFirst, count) of them; the count lands next to them and the
+                // keys -> pixels and float64 scores of the first min(n_first, count) of them; the count lands next to them and the
                 // other counter is cleared for the next call
                 // -- written by the kernel straight into the page-locked host block (h_small is mapped and coherent: a few hundred
                 // 4- and 8-byte stores over the link instead of a 9 us wait for the copy engine and an 8 us copy)
-                rc = cs::launch_rescore_f64_keys(A64, (const long long*)d_keys, p->ns, kFirst, h_rows_small, h_cols_small, h_vals_small, d_cnt,
+                rc = cs::launch_rescore_f64_keys(A64, (const long long*)d_keys, p->ns, n_first, h_rows_small, h_cols_small, h_vals_small, d_cnt,
                                                  (long long*)ctx->h_small, d_cnt_next, stream);
                 if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
                 char* h = (char*)ctx->h_small;
@@ -1018,6 +1021,7 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
                 ctx->cand_cnt_phase ^= 1;
                 ctx->cand_cnt_clean = true;
                 const long long n_cand = *reinterpret_cast<const long long*>(h);
+                ctx->cand_prev = n_cand;
                 if (n_cand <= (long long)c_cap) {
                     const int32_t* rows = reinterpret_cast<const int32_t*>(h + 256);
                     const int32_t* cols = reinterpret_cast<const int32_t*>(h + 256 + (off_cols - off_rows));
@@ -1027,12 +1031,12 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
                     // arrives with a second synchronisation
                     std::vector<int32_t> rows2, cols2;
                     std::vector<double> vals2;
-                    const long long m2 = std::max(0ll, n_cand - kFirst);
+                    const long long m2 = std::max(0ll, n_cand - n_first);
                     if (m2 > 0) {
                         int* d_r2 = (int*)(pool + off_rows2);
                         int* d_c2 = (int*)(pool + off_cols2);
                         double* d_v2 = (double*)(pool + off_vals2);
-                        rc = cs::launch_decode_keys((const long long*)d_keys + kFirst, m2, p->ns, d_r2, d_c2, stream);
+                        rc = cs::launch_decode_keys((const long long*)d_keys + n_first, m2, p->ns, d_r2, d_c2, stream);
                         if (rc) return fail(ctx, CS_ERR_HIP, "key decoding failed: %s", hipGetErrorString((hipError_t)rc));
                         rc = cs::launch_rescore_f64(A64, d_r2, d_c2, m2, d_v2, nullptr, stream);
                         if (rc) return fail(ctx, CS_ERR_HIP, "candidate kernels failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1044,9 +1048,9 @@ int cs_candidates(cs_ctx* ctx, void* stream_, const cs_matrix* signal, const cs_
                         CS_HIP(ctx, hipMemcpyAsync(vals2.data(), d_v2, 8 * (size_t)m2, hipMemcpyDeviceToHost, stream));
                         CS_HIP(ctx, hipStreamSynchronize(stream));
                     }
-                    auto row_of = [&](uint32_t t) { return t < (uint32_t)kFirst ? rows[t] : rows2[t - (uint32_t)kFirst]; };
-                    auto col_of = [&](uint32_t t) { return t < (uint32_t)kFirst ? cols[t] : cols2[t - (uint32_t)kFirst]; };
-                    auto val_of = [&](uint32_t t) { return t < (uint32_t)kFirst ? vals[t] : vals2[t - (uint32_t)kFirst]; };
+                    auto row_of = [&](uint32_t t) { return t < (uint32_t)n_first ? rows[t] : rows2[t - (uint32_t)n_first]; };
+                    auto col_of = [&](uint32_t t) { return t < (uint32_t)n_first ? cols[t] : cols2[t - (uint32_t)n_first]; };
+                    auto val_of = [&](uint32_t t) { return t < (uint32_t)n_first ? vals[t] : vals2[t - (uint32_t)n_first]; };
                     std::vector<uint32_t> keep;
                     keep.reserve((size_t)n_cand);
                     for (long long t = 0; t < n_cand; ++t)

@@ -93,6 +93,7 @@ struct cs_ctx {
     long long* d_cand_cnt = nullptr;      // two candidate counters (256 B apart) that alternate between calls of cs_candidates: the
     int cand_cnt_phase = 0;               // re-scoring kernel of one call clears the counter of the next (no memset in the chain);
     bool cand_cnt_clean = false;          // false until a call has gone through: both are cleared before use
+    long long cand_prev = 0;              // candidates of the previous cs_candidates call on this context (sizes the next call's one launch)
     long long* h_cand_counts = nullptr;   // pinned, 256 entries (cs_detect_foci_blocks, segmented lists): [b] the blocks' own candidate counts, [60] their
                                           // clamped total, [61] status flags; [64 + b] / [128 + b]: the regions' starts / rooms the device reads
     void* d_counts_peak = nullptr;   // cs_normxcorr2_host: largest |pixel| of the map (float bits), and its pinned copy

@@ -417,6 +417,16 @@ def test_candidate_sink_equals_the_map_path(monkeypatch):
         if len(got[0]) > 8192:
             break
     assert last_kernel() == KERNEL_MFMA_WIDE and 8192 < len(got[0]) < 60000, (kw["pearson"], len(got[0]), last_kernel())
+    # (the one launch is sized by the previous call's count: after a call with a handful of candidates the long list takes the
+    # second round -- decoded and re-scored from the same key list --, the call after that does not)
+    big = kw["pearson"]
+    kw["pearson"] = 0.6
+    few = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), (0, n), **kw)
+    assert len(few[0]) < 2000
+    kw["pearson"] = big
+    for _ in range(2):
+        again = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), (0, n), **kw)
+        assert all(np.array_equal(x, y) for x, y in zip(got, again))
     monkeypatch.setenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP", "1")
     dev_form = engine.run_candidates(dev, sig, (n, n), engine.KernelSpec(kern), (0, n), **kw)
     monkeypatch.delenv("CHROMOSIGHT_HIP_NO_SMALL_KEEP")
